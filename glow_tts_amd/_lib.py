@@ -37,6 +37,8 @@ def _declare(L):
     L.glowtts_mas_dp_f32.argtypes = [c_void_p] * 5 + [c_int] * 3 + [c_float, c_void_p]
     L.glowtts_mas_path_from_idx.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     L.glowtts_mas_f32.argtypes = [c_void_p] * 5 + [c_int] * 3 + [c_float, c_void_p]
+    L.glowtts_pack_weight.argtypes = [c_void_p] + [c_int] * 7 + [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p]
+    L.glowtts_conv_cl.argtypes = [c_void_p, c_void_p]
 
 
 def check(rc, what):

@@ -6,14 +6,19 @@
 // Mapping (CDNA4, wave64):
 //   * lane l owns R consecutive token rows x = l*R + j (R = ceil(Tx/64), compile-time 1..8); the
 //     previous column of cumulative scores lives in R VGPRs.  The only cross-lane dependency,
-//     Q[x-1][y-1] for j == 0, is one DPP wave_shr:1 move per column (no LDS, no barrier).
-//   * `value` is streamed straight from HBM into registers: each lane reads 16 B (4 columns) per
-//     row per load, a whole 32-column block (8 loads per row) is issued one block ahead of its
-//     use, which covers the ~900-cycle HBM latency.
-//   * back-pointers are 1 bit per cell, accumulated in registers for 32 columns and parked in LDS
-//     (Ty*R*8 bytes instead of the 4*Tx*Ty-byte matrix the reference re-reads).
-//   * backtrack runs on the scalar unit: for each 32-column block, lanes 0..32 fetch the bit words of
-//     the 33 rows the path can visit, and the 32 dependent steps are v_readlane + s_bitcmp.
+//     Q[x-1][y-1] for j == 0, is one DPP wave_shr:1 move per column (no LDS, no barrier); lane 0
+//     receives the "row -1" sentinel (0 at y == 0, max_neg_val after) through the DPP `old` operand.
+//   * `value` is streamed straight from HBM into registers: 16 B (4 columns) per row per load through a
+//     statically indexed ring of 16 chunk buffers, i.e. every load is issued 64 columns ahead of its
+//     use (covers the HBM / Infinity-Cache latency with a single wave per CU).
+//   * per cell: select(x == y) + compare/select max + add + 2 instructions for the back-pointer bit
+//     (v_cmp into VCC, v_addc_co shifts it into a 32-column bit word).  Cells outside the band are
+//     computed too (never read by cells inside it), so no band predicate sits on the critical path.
+//   * back-pointers: 1 bit per cell, parked in LDS per 32-column block (Ty*R*8 bytes instead of the
+//     4*Tx*Ty-byte matrix the reference re-reads).
+//   * backtrack runs on the scalar unit: per 32-column block lanes 0..32 fetch the bit words of the 33
+//     rows the path can visit; the walk jumps from move to move with s_ff1 (find-first-bit), i.e.
+//     ~(t_x + t_y/32) dependent steps instead of t_y.
 //   * the dense 0/1 path the reference API returns is written by a second, fully parallel kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,13 +26,18 @@
 
 namespace {
 
-__device__ __forceinline__ float wave_shr1(float v) {
-    // lane l receives lane l-1's value; lane 0 keeps its own (bound_ctrl = false, old = v)
-    int r = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+__device__ __forceinline__ float wave_shr1(float v, float lane0_value) {
+    // lane l receives lane l-1's v; lane 0 keeps `old` = lane0_value (bound_ctrl = false)
+    int r = __builtin_amdgcn_update_dpp(__float_as_int(lane0_value), __float_as_int(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
     return __int_as_float(r);
 }
 
-template <int R, bool VEC4>
+// bits = (bits << 1) | (a < b)      (v_cmp -> VCC, v_addc_co: bits + bits + carry-in)
+__device__ __forceinline__ void push_lt_bit(unsigned int& bits, float a, float b) {
+    asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(a), "v"(b) : "vcc");
+}
+
+template <int R, bool VEC4, bool WRITEQ>
 __global__ __launch_bounds__(64) void mas_dp_kernel(const float* __restrict__ value,
                                                     const int32_t* __restrict__ t_xs,
                                                     const int32_t* __restrict__ t_ys,
@@ -44,7 +54,7 @@ __global__ __launch_bounds__(64) void mas_dp_kernel(const float* __restrict__ va
         return;
     }
     const float* vb = value + (size_t)b * Tx * Ty;
-    float* qb = q_out ? q_out + (size_t)b * Tx * Ty : nullptr;
+    float* qb = WRITEQ ? q_out + (size_t)b * Tx * Ty : nullptr;
     const int nblk = (ty + 31) >> 5;
 
     // row pointers (rows >= Tx are clamped: they are never inside the band)
@@ -55,75 +65,78 @@ __global__ __launch_bounds__(64) void mas_dp_kernel(const float* __restrict__ va
         rowp[j] = vb + (size_t)(x < Tx ? x : Tx - 1) * Ty;
     }
 
-    float4 cur[8][R], nxt[8][R];
-    auto load_block = [&](float4 (&dst)[8][R], int blk) {
+    // one chunk = 4 columns x R rows (16 B per row per lane)
+    auto load_chunk = [&](float4 (&dst)[R], int chunk) {
+        const int y0 = chunk * 4;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int y0 = blk * 32 + c * 4;
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (VEC4) {
-                    if (y0 < Ty) v = *reinterpret_cast<const float4*>(rowp[j] + y0);
-                } else {
-                    if (y0 + 0 < Ty) v.x = rowp[j][y0 + 0];
-                    if (y0 + 1 < Ty) v.y = rowp[j][y0 + 1];
-                    if (y0 + 2 < Ty) v.z = rowp[j][y0 + 2];
-                    if (y0 + 3 < Ty) v.w = rowp[j][y0 + 3];
-                }
-                dst[c][j] = v;
+        for (int j = 0; j < R; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (VEC4) {
+                if (y0 < Ty) v = *reinterpret_cast<const float4*>(rowp[j] + y0);
+            } else {
+                if (y0 + 0 < Ty) v.x = rowp[j][y0 + 0];
+                if (y0 + 1 < Ty) v.y = rowp[j][y0 + 1];
+                if (y0 + 2 < Ty) v.z = rowp[j][y0 + 2];
+                if (y0 + 3 < Ty) v.w = rowp[j][y0 + 3];
             }
+            dst[j] = v;
         }
     };
 
     float q[R];
+    unsigned int bits[R];
 #pragma unroll
-    for (int j = 0; j < R; ++j) q[j] = 0.f;
+    for (int j = 0; j < R; ++j) { q[j] = 0.f; bits[j] = 0u; }
 
-    load_block(cur, 0);
-    for (int blk = 0; blk < nblk; ++blk) {
-        if (blk + 1 < nblk) load_block(nxt, blk + 1);
-        unsigned int bits[R];
+    auto compute_chunk = [&](const float4 (&cur)[R], int chunk) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) bits[j] = 0u;
+        for (int e = 0; e < 4; ++e) {
+            const int y = chunk * 4 + e;                                          // wave-uniform
+            const float up = wave_shr1(q[R - 1], y == 0 ? 0.f : neg);             // Q[x-1][y-1]; row -1: core.pyx:23-27
+            float qo[R];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+            for (int j = 0; j < R; ++j) qo[j] = q[j];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int y = blk * 32 + c * 4 + e;
-                if (y < ty) {                                   // wave-uniform
-                    const int lo = max(0, tx + y - ty);         // core.pyx:18
-                    const int hi = min(tx, y + 1);
-                    const float up = wave_shr1(q[R - 1]);       // Q[x-1][y-1] of the first row of this lane
-                    float qo[R];
-#pragma unroll
-                    for (int j = 0; j < R; ++j) qo[j] = q[j];
-#pragma unroll
-                    for (int j = 0; j < R; ++j) {
-                        const int x = lane * R + j;
-                        const float prevq = (j == 0) ? up : qo[j - 1];
-                        const float v_cur = (x == y) ? neg : qo[j];                       // core.pyx:19-22
-                        const float v_prev = (x == 0) ? (y == 0 ? 0.f : neg) : prevq;     // core.pyx:23-29
-                        bits[j] |= (qo[j] < prevq ? 1u : 0u) << (c * 4 + e);              // core.pyx:34 test, for the backtrack
-                        const float m = (v_prev > v_cur) ? v_prev : v_cur;                // Cython max(a,b) = b>a ? b : a
-                        const float val = (e == 0) ? cur[c][j].x : (e == 1) ? cur[c][j].y : (e == 2) ? cur[c][j].z : cur[c][j].w;
-                        const bool inb = (x >= lo) && (x < hi);
-                        q[j] = inb ? (m + val) : val;                                      // core.pyx:30; cells outside the band keep the input
-                        if (qb && inb) qb[(size_t)x * Ty + y] = q[j];
-                    }
+            for (int j = 0; j < R; ++j) {
+                const int x = lane * R + j;
+                const float v_prev = (j == 0) ? up : qo[j - 1];                   // core.pyx:23-29
+                const float v_cur = (x == y) ? neg : qo[j];                       // core.pyx:19-22
+                push_lt_bit(bits[j], qo[j], v_prev);                              // core.pyx:34 test, kept for the backtrack
+                const float m = (v_prev > v_cur) ? v_prev : v_cur;                // Cython max(a,b) = b>a ? b : a
+                const float val = (e == 0) ? cur[j].x : (e == 1) ? cur[j].y : (e == 2) ? cur[j].z : cur[j].w;
+                q[j] = m + val;                                                   // core.pyx:30
+                if (WRITEQ) {
+                    const bool inb = (y < ty) && (x >= max(0, tx + y - ty)) && (x < min(tx, y + 1));   // core.pyx:18
+                    if (inb) qb[(size_t)x * Ty + y] = q[j];
                 }
             }
         }
+    };
+
+    // ring of 16 chunk buffers = 64 columns of look-ahead; statically indexed (fully unrolled)
+    constexpr int D = 16;
+    float4 ring[D][R];
 #pragma unroll
-        for (int j = 0; j < R; ++j) dec[(blk * R + j) * 64 + lane] = bits[j];
+    for (int c = 0; c < D; ++c) load_chunk(ring[c], c);
+    const int niter = (ty + 63) >> 6;
+    for (int it = 0; it < niter; ++it) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+        for (int c = 0; c < D; ++c) {
+            float4 cur[R];
 #pragma unroll
-            for (int j = 0; j < R; ++j) cur[c][j] = nxt[c][j];
+            for (int j = 0; j < R; ++j) cur[j] = ring[c][j];
+            load_chunk(ring[c], (it + 1) * D + c);                               // refill this slot, 64 columns ahead
+            compute_chunk(cur, it * D + c);
+            if ((c & 7) == 7) {                                                  // 32 columns done: park the bit words
+                const int blk = it * 2 + (c >> 3);
+#pragma unroll
+                for (int j = 0; j < R; ++j) { dec[(blk * R + j) * 64 + lane] = bits[j]; bits[j] = 0u; }   // bit (31 - c) <-> column blk*32 + c
+            }
+        }
     }
     __syncthreads();
 
-    // ---- backtrack (core.pyx:31-35), wave-uniform state kept in SGPRs ----
+    // ---- backtrack (core.pyx:31-35): wave-uniform walk, one step per row change ----
     int index = tx - 1;
     for (int blk = nblk - 1; blk >= 0; --blk) {
         const int i0 = index;
@@ -131,36 +144,50 @@ __global__ __launch_bounds__(64) void mas_dp_kernel(const float* __restrict__ va
         unsigned int W = 0u;
         if (lane <= 32 && row >= 0) W = dec[(blk * R + (row % R)) * 64 + (row / R)];
         int myidx = -1;
-        for (int yy = 31; yy >= 0; --yy) {
-            const int y = blk * 32 + yy;
-            if (y >= ty) continue;
-            if (lane == yy) myidx = index;                       // path[index][y] = 1
+        int yy = min(31, ty - 1 - blk * 32);                    // highest column of this block inside the utterance
+        while (yy >= 0) {
+            if (lane <= yy) myidx = index;                       // path[index][y] = 1 for every column down to the move
+            if (index == 0) break;
             const unsigned int w = __builtin_amdgcn_readlane(W, i0 - index);
-            const bool mv = (index != 0) && (index == y || ((w >> yy) & 1u));
-            index = __builtin_amdgcn_readfirstlane(index - (mv ? 1 : 0));
+            const unsigned int masked = w & (0xFFFFFFFFu << (31 - yy));            // columns <= yy
+            const int c_bit = masked ? 31 - (__builtin_ffs(masked) - 1) : -1;       // highest column <= yy whose bit is set
+            const int c_diag = index - blk * 32;                                    // forced move where index == y
+            const int c_move = max(c_bit, (c_diag >= 0 && c_diag <= yy) ? c_diag : -1);
+            if (c_move < 0) break;                                                   // stays on this row for the rest of the block
+            index = __builtin_amdgcn_readfirstlane(index - 1);
+            yy = c_move - 1;
         }
-        if (idx_b && lane < 32 && blk * 32 + lane < Ty) idx_b[blk * 32 + lane] = myidx;
+        if (idx_b && lane < 32 && blk * 32 + lane < Ty) idx_b[blk * 32 + lane] = (blk * 32 + lane < ty) ? myidx : -1;
     }
     if (idx_b) for (int y = nblk * 32 + lane; y < Ty; y += 64) idx_b[y] = -1;
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void mas_path_kernel(const int32_t* __restrict__ idx, T* __restrict__ path,
-                                                       int Tx, int Ty)
+                                                       int Tx, int Ty, int vec_ok)
 {
-    // grid: (ceil(Ty/1024), Tx, B); each thread writes 4 consecutive frames of one token row
-    const int b = blockIdx.z, x = blockIdx.y;
-    const int y0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (y0 >= Ty) return;
+    // grid: (ceil(Tx/8), B); a block writes 8 token rows x all frames; each thread 4 consecutive frames
+    const int b = blockIdx.y;
+    const int x0 = blockIdx.x * 8;
     const int32_t* ib = idx + (size_t)b * Ty;
-    T* out = path + ((size_t)b * Tx + x) * Ty + y0;
-    T v[4];
+    for (int y0 = threadIdx.x * 4; y0 < Ty; y0 += 1024) {
+        int id[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (y0 + e < Ty && ib[y0 + e] == x) ? (T)1 : (T)0;
-    if (y0 + 3 < Ty && (Ty & 3) == 0) {
-        *reinterpret_cast<float4*>(out) = *reinterpret_cast<float4*>(v);      // T is 4 bytes wide
-    } else {
-        for (int e = 0; e < 4 && y0 + e < Ty; ++e) out[e] = v[e];
+        for (int e = 0; e < 4; ++e) id[e] = (y0 + e < Ty) ? ib[y0 + e] : -1;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int x = x0 + r;
+            if (x >= Tx) break;
+            T* out = path + ((size_t)b * Tx + x) * Ty + y0;
+            T v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (id[e] == x) ? (T)1 : (T)0;
+            if (vec_ok && y0 + 3 < Ty) {
+                *reinterpret_cast<float4*>(out) = *reinterpret_cast<float4*>(v);      // T is 4 bytes wide
+            } else {
+                for (int e = 0; e < 4 && y0 + e < Ty; ++e) out[e] = v[e];
+            }
+        }
     }
 }
 
@@ -168,17 +195,15 @@ template <int R>
 int launch_dp(const float* value, const int32_t* t_xs, const int32_t* t_ys, int32_t* idx_out, float* q_out,
               int B, int Tx, int Ty, float neg, hipStream_t s)
 {
-    const size_t lds = (size_t)((Ty + 31) / 32) * R * 64 * sizeof(unsigned int);
+    const size_t lds = (size_t)((Ty + 63) / 64) * 2 * R * 64 * sizeof(unsigned int);
     if (lds > 160 * 1024) return GLOWTTS_E_ARG;
     const bool vec = (Ty % 4 == 0) && ((reinterpret_cast<uintptr_t>(value) & 15) == 0);
-    auto kv = mas_dp_kernel<R, true>;
-    auto ks = mas_dp_kernel<R, false>;
-    if (lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
-    if (vec) hipLaunchKernelGGL(kv, dim3(B), dim3(64), lds, s, value, t_xs, t_ys, idx_out, q_out, Tx, Ty, neg);
-    else     hipLaunchKernelGGL(ks, dim3(B), dim3(64), lds, s, value, t_xs, t_ys, idx_out, q_out, Tx, Ty, neg);
+    void (*k)(const float*, const int32_t*, const int32_t*, int32_t*, float*, int, int, float);
+    if (q_out) k = vec ? mas_dp_kernel<R, true, true> : mas_dp_kernel<R, false, true>;
+    else       k = vec ? mas_dp_kernel<R, true, false> : mas_dp_kernel<R, false, false>;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(B), dim3(64), lds, s, value, t_xs, t_ys, idx_out, q_out, Tx, Ty, neg);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
@@ -208,9 +233,10 @@ extern "C" int glowtts_mas_path_from_idx(const int32_t* idx, void* path, int B, 
     if (!idx || !path || B < 0 || Tx < 1 || Ty < 1 || (out_dtype != 0 && out_dtype != 1)) return GLOWTTS_E_ARG;
     if (B == 0) return GLOWTTS_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    dim3 grid((Ty + 1023) / 1024, Tx, B);
-    if (out_dtype == 0) hipLaunchKernelGGL(mas_path_kernel<int32_t>, grid, dim3(256), 0, s, idx, static_cast<int32_t*>(path), Tx, Ty);
-    else                hipLaunchKernelGGL(mas_path_kernel<float>, grid, dim3(256), 0, s, idx, static_cast<float*>(path), Tx, Ty);
+    dim3 grid((Tx + 7) / 8, B);
+    const int vec_ok = (Ty % 4 == 0) && ((reinterpret_cast<uintptr_t>(path) & 15) == 0);
+    if (out_dtype == 0) hipLaunchKernelGGL(mas_path_kernel<int32_t>, grid, dim3(256), 0, s, idx, static_cast<int32_t*>(path), Tx, Ty, vec_ok);
+    else                hipLaunchKernelGGL(mas_path_kernel<float>, grid, dim3(256), 0, s, idx, static_cast<float*>(path), Tx, Ty, vec_ok);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
