@@ -1,0 +1,237 @@
+// Host-side orchestration of one decoder flow step (Modules.py:653-668 AIA) for gfx950: a fixed sequence of
+// launches of the MFMA conv kernel (gemm_cl.hip), the weight-gradient kernel (wgrad_cl.hip) and the
+// bandwidth-bound flow kernels (flow_ops.hip), all on the caller's stream.  No device synchronisation, no
+// allocation: every buffer comes from the caller (see glowtts_flow_acts / glowtts_flow_grads).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "../../include/glowtts_hip.h"
+
+namespace {
+
+#define CHECK(x) do { int rc_ = (x); if (rc_ != GLOWTTS_OK) return rc_; } while (0)
+
+struct Ctx {
+    const glowtts_flow_dims* d; const glowtts_flow_params* p; const glowtts_flow_acts* a; void* s;
+    int Tp, R, C2, H, pad;
+};
+
+Ctx make_ctx(const glowtts_flow_dims* d, const glowtts_flow_params* p, const glowtts_flow_acts* a, void* s) {
+    Ctx c{d, p, a, s, 0, 0, 0, 0, 0};
+    c.Tp = d->T + 2 * GLOWTTS_ROW_PAD; c.R = d->B * c.Tp; c.C2 = d->C / 2; c.H = d->H; c.pad = (d->ksize - 1) / 2;
+    return c;
+}
+
+int check_dims(const glowtts_flow_dims* d) {
+    if (!d || d->B < 1 || d->T < 1 || d->C < 4 || (d->C & 3) || d->H < 1 || (d->H & 3) || d->L < 1 || d->L > GLOWTTS_MAX_WN_LAYERS) return GLOWTTS_E_ARG;
+    if (d->ksize != 1 && d->ksize != 3 && d->ksize != 5) return GLOWTTS_E_ARG;
+    if ((d->ksize - 1) / 2 > GLOWTTS_ROW_PAD) return GLOWTTS_E_ARG;
+    return GLOWTTS_OK;
+}
+
+glowtts_conv_args base_args(const Ctx& c, const glowtts_packed& w, int taps) {
+    glowtts_conv_args a;
+    memset(&a, 0, sizeof(a));
+    a.rows = c.R; a.w = w.w; a.npad = w.npad; a.kchunks = w.kchunks; a.taps = taps; a.pad = (taps - 1) / 2;
+    a.precision = c.d->precision; a.rowmask = c.a->rowmask; a.rows_per_utt = c.Tp;
+    return a;
+}
+
+// Start conv + WaveNet + End conv with the coupling epilogue (Modules.py:785-806 / 858-883).
+// xsrc: rows whose first C2 channels are x_a and last C2 channels x_b; xdst: where x_b' goes.
+int coupling_net(const Ctx& c, const float* xsrc, float* xdst, bool reverse, bool keep) {
+    const glowtts_flow_params* p = c.p; const glowtts_flow_acts* A = c.a;
+    const int H = c.H, L = c.d->L;
+    // Start: h0 = (W x_a + b) * mask                                         Modules.py:791
+    {
+        glowtts_conv_args a = base_args(c, p->start, 1);
+        a.a = xsrc; a.lda = c.d->C; a.ca = c.C2; a.n = H;
+        a.epi = GLOWTTS_EPI_LINEAR; a.flags = GLOWTTS_F_BIAS | GLOWTTS_F_MASK; a.bias = p->b_start;
+        a.out0 = A->hs[0]; a.ld0 = H;
+        CHECK(glowtts_conv_cl(&a, c.s));
+    }
+    for (int l = 0; l < L; ++l) {
+        float* hin = keep ? A->hs[l] : A->hs[l & 1];
+        float* hout = keep ? (l + 1 < L ? A->hs[l + 1] : nullptr) : A->hs[(l + 1) & 1];
+        float* g = keep ? A->gates[l] : A->gates[0];
+        {   // In_l (k taps) + conditioning + tanh*sigmoid                       Modules.py:861-870
+            glowtts_conv_args a = base_args(c, p->in[l], c.d->ksize);
+            a.a = hin; a.lda = H; a.ca = H; a.n = 2 * H; a.h = H;
+            a.epi = GLOWTTS_EPI_GATE; a.bias = p->b_in[l];
+            if (p->cond) { a.cond = p->cond + (int64_t)l * 2 * H; a.ldcond = p->ldcond; }
+            a.out0 = g; a.ld0 = 2 * H;
+            CHECK(glowtts_conv_cl(&a, c.s));
+        }
+        {   // Res_Skip_l on acts = tanh*sigmoid                                 Modules.py:871-881
+            const bool last = (l == L - 1);
+            glowtts_conv_args a = base_args(c, p->rs[l], 1);
+            a.a = g; a.lda = 2 * H; a.ca = H; a.apro = GLOWTTS_APRO_PAIRMUL;
+            a.n = last ? H : 2 * H; a.h = H;
+            a.epi = GLOWTTS_EPI_RESSKIP; a.flags = (l == 0 ? GLOWTTS_F_FIRST : 0) | (last ? GLOWTTS_F_LAST : 0);
+            a.bias = p->b_rs[l];
+            a.in0 = hin; a.ldi0 = H; a.out0 = last ? A->skip : hout; a.ld0 = H; a.out1 = A->skip; a.ld1 = H;
+            CHECK(glowtts_conv_cl(&a, c.s));
+        }
+    }
+    {   // End + affine coupling                                                 Modules.py:793-806
+        glowtts_conv_args a = base_args(c, p->end, 1);
+        a.a = A->skip; a.lda = H; a.ca = H; a.n = c.d->C; a.h = c.C2;
+        a.epi = GLOWTTS_EPI_COUPLE; a.flags = reverse ? GLOWTTS_F_REVERSE : 0; a.bias = p->b_end;
+        a.in0 = xsrc + c.C2; a.ldi0 = c.d->C;
+        a.out0 = xdst + c.C2; a.ld0 = c.d->C;
+        a.out1 = keep ? A->outs : nullptr; a.ld1 = p->end.npad;
+        CHECK(glowtts_conv_cl(&a, c.s));
+    }
+    return GLOWTTS_OK;
+}
+
+__global__ void copy_half_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, int C, int n)
+{
+    // dst[r][0:n] = src[r][0:n], float4 granules
+    const int q = n / 4;
+    const long total = rows * q;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / q; const int c = (int)(i - r * q) * 4;
+        *reinterpret_cast<float4*>(dst + r * C + c) = *reinterpret_cast<const float4*>(src + r * C + c);
+    }
+}
+int copy_half(const float* src, float* dst, long rows, int C, int n, void* s) {
+    if (src == dst) return GLOWTTS_OK;
+    if (n & 3) return GLOWTTS_E_ARG;
+    long g = (rows * (n / 4) + 255) / 256; if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(copy_half_kernel, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(s), src, dst, rows, C, n);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
+__global__ __launch_bounds__(256) void utt_colsum_kernel(const float* __restrict__ x, long ldx, float* __restrict__ out, long ldout,
+                                                         int rows_per_utt, int n, int perm, int perm_h)
+{
+    const int b = blockIdx.y;
+    const int col = blockIdx.x * 256 + threadIdx.x;          // output (original-order) column
+    if (col >= n) return;
+    int pc = col;
+    if (perm == GLOWTTS_PERM_PAIR) { const int hs = col / perm_h, j = col - hs * perm_h; pc = (j >> 5) * 64 + hs * 32 + (j & 31); }
+    const float* xb = x + (long)b * rows_per_utt * ldx + pc;
+    float s = 0.f;
+    for (int r = 0; r < rows_per_utt; ++r) s += xb[(long)r * ldx];
+    out[(long)b * ldout + col] = s;
+}
+
+}  // namespace
+
+extern "C" int glowtts_utt_colsum(const float* x, int64_t ldx, float* out, int64_t ldout, int B, int rows_per_utt, int n,
+                                  int perm, int perm_h, void* stream)
+{
+    if (!x || !out || B < 1 || rows_per_utt < 1 || n < 1) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(utt_colsum_kernel, dim3((n + 255) / 256, B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, (long)ldx, out, (long)ldout, rows_per_utt, n, perm, perm_h);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
+extern "C" int glowtts_flow_forward(const glowtts_flow_dims* d, const glowtts_flow_params* p, const glowtts_flow_acts* a, void* stream)
+{
+    CHECK(check_dims(d));
+    if (!p || !a || !a->xin || !a->xmid || !a->xout || !a->rowmask || !a->skip || !a->outs) return GLOWTTS_E_ARG;
+    const Ctx c = make_ctx(d, p, a, stream);
+    // ActNorm + invertible 1x1                                                 Modules.py:693-694, 738-756
+    CHECK(glowtts_actnorm_inv1x1(a->xin, a->xmid, p->an_logs, p->an_bias, p->winfo, a->rowmask, c.R, d->C, 0, stream));
+    // x_a passes through                                                      Modules.py:808
+    CHECK(copy_half(a->xmid, a->xout, c.R, d->C, c.C2, stream));
+    return coupling_net(c, a->xmid, a->xout, false, true);
+}
+
+extern "C" int glowtts_flow_inverse(const glowtts_flow_dims* d, const glowtts_flow_params* p, const glowtts_flow_acts* a, void* stream)
+{
+    CHECK(check_dims(d));
+    if (!p || !a || !a->xin || !a->xmid || !a->xout || !a->rowmask || !a->skip || !a->hs[0] || !a->hs[1] || !a->gates[0]) return GLOWTTS_E_ARG;
+    const Ctx c = make_ctx(d, p, a, stream);
+    // reversed layer order (Modules.py:664): coupling^-1, then inv-1x1^-1, then ActNorm^-1
+    CHECK(copy_half(a->xout, a->xmid, c.R, d->C, c.C2, stream));
+    CHECK(coupling_net(c, a->xout, a->xmid, true, false));
+    return glowtts_actnorm_inv1x1(a->xmid, a->xin, p->an_logs, p->an_bias, p->winfo, a->rowmask, c.R, d->C, 1, stream);
+}
+
+extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_flow_params* p, const glowtts_flow_acts* a,
+                                     const glowtts_flow_grads* g, void* stream)
+{
+    CHECK(check_dims(d));
+    if (!p || !a || !g || !g->dx || !g->dlogdet || !g->douts || !g->dskip || !g->dh[0] || !g->dh[1] || !g->dins || !g->scratch || !g->d_an) return GLOWTTS_E_ARG;
+    const Ctx c = make_ctx(d, p, a, stream);
+    const int H = c.H, L = d->L, C = d->C, C2 = c.C2, R = c.R;
+    const int ldo = p->end.npad;          // PAIR-packed (m, logs) width
+    const int ldin = p->in[0].npad;       // PAIR-packed gate pre-activation width
+    auto wargs = [&](const float* dy, int lddy, int m, const float* x, int ldx, int ca, int taps, float* dw, float* db) {
+        glowtts_wgrad_args w; memset(&w, 0, sizeof(w));
+        w.dy = dy; w.lddy = lddy; w.m = m; w.x = x; w.ldx = ldx; w.ca = ca; w.rows = R; w.taps = taps; w.pad = (taps - 1) / 2;
+        w.precision = d->precision; w.splits = 0; w.accumulate = 1; w.dw = dw; w.dbias = db;
+        return w;
+    };
+
+    // 1. affine coupling backward                                               autograd of Modules.py:805-806
+    CHECK(glowtts_coupling_bwd(g->dx, a->xmid, a->outs, g->douts, a->rowmask, g->dlogdet, R, C, ldo, c.Tp, stream));
+    // 2. End conv: data gradient -> d(skip) (masked), weight gradient
+    {
+        glowtts_conv_args q = base_args(c, p->end_t, 1);
+        q.a = g->douts; q.lda = ldo; q.ca = ldo; q.n = H; q.epi = GLOWTTS_EPI_LINEAR; q.flags = GLOWTTS_F_MASK;
+        q.out0 = g->dskip; q.ld0 = H;
+        CHECK(glowtts_conv_cl(&q, stream));
+        glowtts_wgrad_args w = wargs(g->douts, ldo, ldo, a->skip, H, H, 1, g->dw_end, g->db_end);
+        w.perm = GLOWTTS_PERM_PAIR; w.perm_h = C2;
+        CHECK(glowtts_wgrad_cl(&w, stream));
+    }
+    // 3. WaveNet layers, last to first.  dh[cur] holds d x_{l+1} * mask.
+    int cur = 0;
+    for (int l = L - 1; l >= 0; --l) {
+        const bool last = (l == L - 1);
+        float* dnext = g->dh[cur];            // d x_{l+1} (valid when !last)
+        float* dthis = g->dh[cur ^ 1];        // d x_l (written below)
+        {   // Res_Skip data gradient + gate derivative -> dins (PAIR-packed (da, ds))
+            glowtts_conv_args q = base_args(c, p->rs_t[l], 1);
+            if (last) { q.a = g->dskip; q.lda = H; q.ca = H; }
+            else      { q.a = dnext; q.lda = H; q.ca1 = H; q.a2 = g->dskip; q.lda2 = H; q.ca = 2 * H; }
+            q.n = H; q.epi = GLOWTTS_EPI_DGATE; q.in0 = a->gates[l]; q.ldi0 = 2 * H; q.out0 = g->dins; q.ld0 = ldin;
+            CHECK(glowtts_conv_cl(&q, stream));
+        }
+        {   // Res_Skip weight gradient: rows [0,H) <- d res, rows [H,2H) <- d skip (last layer: only H rows <- d skip)
+            if (last) {
+                glowtts_wgrad_args w = wargs(g->dskip, H, H, a->gates[l], 2 * H, H, 1, g->dw_rs[l], g->db_rs[l]);
+                w.xpro = GLOWTTS_APRO_PAIRMUL;
+                CHECK(glowtts_wgrad_cl(&w, stream));
+            } else {
+                glowtts_wgrad_args w = wargs(dnext, H, H, a->gates[l], 2 * H, H, 1, g->dw_rs[l], g->db_rs[l]);
+                w.xpro = GLOWTTS_APRO_PAIRMUL;
+                CHECK(glowtts_wgrad_cl(&w, stream));
+                glowtts_wgrad_args w2 = wargs(g->dskip, H, H, a->gates[l], 2 * H, H, 1, g->dw_rs[l] + (int64_t)H * H, g->db_rs[l] + H);
+                w2.xpro = GLOWTTS_APRO_PAIRMUL;
+                CHECK(glowtts_wgrad_cl(&w2, stream));
+            }
+        }
+        {   // In_l data gradient: d x_l = (conv^T(dins) + d x_{l+1}) * mask
+            glowtts_conv_args q = base_args(c, p->in_t[l], d->ksize);
+            q.a = g->dins; q.lda = ldin; q.ca = ldin; q.n = H; q.epi = GLOWTTS_EPI_LINEAR;
+            q.flags = GLOWTTS_F_MASK | (last ? 0 : GLOWTTS_F_ADD_IN0);
+            q.in0 = last ? nullptr : dnext; q.ldi0 = H; q.out0 = dthis; q.ld0 = H;
+            CHECK(glowtts_conv_cl(&q, stream));
+        }
+        {   // In_l weight gradient
+            glowtts_wgrad_args w = wargs(g->dins, ldin, ldin, a->hs[l], H, H, d->ksize, g->dw_in[l], g->db_in[l]);
+            w.perm = GLOWTTS_PERM_PAIR; w.perm_h = H;
+            CHECK(glowtts_wgrad_cl(&w, stream));
+        }
+        if (g->dcond && p->cond)   // conditioning gradient: sum over the frames of each utterance   (autograd of Modules.py:863-866)
+            CHECK(glowtts_utt_colsum(g->dins, ldin, g->dcond + (int64_t)l * 2 * H, p->ldcond, d->B, c.Tp, 2 * H, GLOWTTS_PERM_PAIR, H, stream));
+        cur ^= 1;
+    }
+    float* dh0 = g->dh[cur];                  // d h0 * mask
+    // 4. Start conv: data gradient accumulates into d x_a, weight gradient
+    {
+        glowtts_conv_args q = base_args(c, p->start_t, 1);
+        q.a = dh0; q.lda = H; q.ca = H; q.n = C2; q.epi = GLOWTTS_EPI_LINEAR; q.flags = GLOWTTS_F_ACCUM;
+        q.out0 = g->dx; q.ld0 = C;
+        CHECK(glowtts_conv_cl(&q, stream));
+        glowtts_wgrad_args w = wargs(dh0, H, H, a->xmid, C, C2, 1, g->dw_start, g->db_start);
+        CHECK(glowtts_wgrad_cl(&w, stream));
+    }
+    // 5. inv-1x1 + ActNorm backward (dx in place), parameter-gradient data terms -> d_an
+    return glowtts_actnorm_inv1x1_bwd(g->dx, g->dx, a->xin, p->an_logs, p->an_bias, p->winfo, a->rowmask, g->d_an, g->scratch, R, C, stream);
+}

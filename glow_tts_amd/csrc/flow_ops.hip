@@ -1,0 +1,444 @@
+// Bandwidth-bound pieces of the flow decoder for gfx950 (everything that is not a dense contraction):
+// squeeze / unsqueeze (Modules.py:895-924), ActNorm (:682-711), invertible 1x1 conv (:727-758),
+// the coupling backward, log-determinant bookkeeping.  All activations are fp32 "rows" tensors
+// [B][Tp][C] (channels contiguous, Tp = T + 2*GLOWTTS_ROW_PAD, zero pad rows around every utterance).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/glowtts_hip.h"
+
+namespace {
+
+#define PADR GLOWTTS_ROW_PAD
+
+// ------------------------------------------------------------------------------------------------
+// squeeze: mel [B][Cm][Tm] -> rows [B][Tp][ns*Cm];  rows[b][PADR+t][s*Cm+c] = mel[b][c][ns*t+s] * mask'[t]
+// mask'[t] = (ns*t + ns-1 < len[b])   (Modules.py:903: mask[:, :, ns-1::ns]).  Also writes rowmask.
+// ------------------------------------------------------------------------------------------------
+template <bool TO_ROWS>
+__global__ __launch_bounds__(256) void squeeze_kernel(float* __restrict__ mel, float* __restrict__ rows,
+                                                      float* __restrict__ rowmask, const int64_t* __restrict__ lengths,
+                                                      int Cm, int Tm, int T, int ns, float fill, int use_fill)
+{
+    // block: one utterance, 32 squeezed frames (= 32*ns mel frames), all channels.  LDS tile [Cm][32*ns + 1]
+    extern __shared__ float tile[];
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * 32;
+    const int Tp = T + 2 * PADR;
+    const int W = 32 * ns;                 // mel frames per tile
+    const int ldt = W + 1;
+    const int C = Cm * ns;
+    const long len = lengths[b];
+    float* melb = mel + (long)b * Cm * Tm;
+    float* rowb = rows + ((long)b * Tp + PADR) * C;
+    if (TO_ROWS) {
+        for (int i = threadIdx.x; i < Cm * W; i += 256) {
+            const int c = i / W, y = i - c * W;
+            const int yy = t0 * ns + y;
+            tile[c * ldt + y] = (yy < T * ns) ? melb[(long)c * Tm + yy] : 0.f;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 32 * C; i += 256) {
+            const int t = i / C, ch = i - t * C;
+            if (t0 + t >= T) continue;
+            const int s = ch / Cm, c = ch - s * Cm;
+            const float m = ((long)(t0 + t) * ns + ns - 1 < len) ? 1.f : 0.f;
+            rowb[(long)(t0 + t) * C + ch] = tile[c * ldt + t * ns + s] * m;
+            if (ch == 0 && rowmask) rowmask[(long)b * Tp + PADR + t0 + t] = m;
+        }
+        if (blockIdx.x == 0) {             // zero the pad rows of this utterance (and their mask)
+            float* base = rows + (long)b * Tp * C;
+            for (int i = threadIdx.x; i < PADR * C; i += 256) { base[i] = 0.f; base[(long)(PADR + T) * C + i] = 0.f; }
+            if (rowmask && threadIdx.x < PADR) { rowmask[(long)b * Tp + threadIdx.x] = 0.f; rowmask[(long)b * Tp + PADR + T + threadIdx.x] = 0.f; }
+        }
+    } else {
+        // rows -> mel (unsqueeze, Modules.py:914-924): mel[b][c][ns*t+s] = rows[b][t][s*Cm+c] * mask'[t]; optional pad fill
+        for (int i = threadIdx.x; i < 32 * C; i += 256) {
+            const int t = i / C, ch = i - t * C;
+            const int s = ch / Cm, c = ch - s * Cm;
+            float v = 0.f;
+            if (t0 + t < T) {
+                const bool valid = ((long)(t0 + t) * ns + ns - 1 < len);
+                v = valid ? rowb[(long)(t0 + t) * C + ch] : (use_fill ? fill : 0.f);
+            }
+            tile[c * ldt + t * ns + s] = v;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < Cm * W; i += 256) {
+            const int c = i / W, y = i - c * W;
+            const int yy = t0 * ns + y;
+            if (yy < T * ns) melb[(long)c * Tm + yy] = tile[c * ldt + y];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4x4 helper: inverse + log-determinant of the inv-1x1 weights of all flows (torch.inverse / torch.logdet,
+// Modules.py:743,747).  One thread per flow, Gauss-Jordan with partial pivoting in fp32... in fp64 for safety.
+// out[f] = { W[16], Winv[16], logdet, sign }  (34 floats, stride 36)
+// ------------------------------------------------------------------------------------------------
+__global__ void inv4x4_kernel(const float* __restrict__ W, float* __restrict__ out, int F)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { a[i][j] = W[f * 16 + i * 4 + j]; a[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+    double det = 1.0;
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r) if (fabs(a[r][col]) > fabs(a[piv][col])) piv = r;
+        if (piv != col) { for (int j = 0; j < 8; ++j) { double t = a[col][j]; a[col][j] = a[piv][j]; a[piv][j] = t; } det = -det; }
+        const double d = a[col][col];
+        det *= d;
+        const double inv = 1.0 / d;
+        for (int j = 0; j < 8; ++j) a[col][j] *= inv;
+        for (int r = 0; r < 4; ++r) if (r != col) { const double m = a[r][col]; for (int j = 0; j < 8; ++j) a[r][j] -= m * a[col][j]; }
+    }
+    float* o = out + f * 36;
+    for (int i = 0; i < 16; ++i) { o[i] = W[f * 16 + i]; o[16 + i] = (float)a[i / 4][4 + (i % 4)]; }
+    o[32] = (float)log(fabs(det));          // torch.logdet is nan for det < 0; the reference keeps det > 0 (Modules.py:722-723)
+    o[33] = det > 0 ? 1.f : -1.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ActNorm + invertible 1x1, forward and inverse, one pass over the rows.
+// thread = (row, group g): channels {2g, 2g+1, C/2+2g, C/2+2g+1} <-> split index 0..3  (Modules.py:738-740)
+// ------------------------------------------------------------------------------------------------
+template <bool REVERSE>
+__global__ __launch_bounds__(256) void actnorm_inv_kernel(const float* __restrict__ xin, float* __restrict__ xout,
+                                                          const float* __restrict__ logs, const float* __restrict__ bias,
+                                                          const float* __restrict__ winfo, const float* __restrict__ rowmask,
+                                                          long rows, int C)
+{
+    const int G = C / 4, C2 = C / 2;
+    const long total = rows * G;
+    const float* Wm = winfo + (REVERSE ? 16 : 0);
+    float w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = Wm[i];
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / G;
+        const int g = (int)(i - r * G);
+        const float m = rowmask[r];
+        const float2 lo = *reinterpret_cast<const float2*>(xin + r * C + 2 * g);
+        const float2 hi = *reinterpret_cast<const float2*>(xin + r * C + C2 + 2 * g);
+        float v[4] = {lo.x, lo.y, hi.x, hi.y};
+        const int ch[4] = {2 * g, 2 * g + 1, C2 + 2 * g, C2 + 2 * g + 1};
+        float o[4];
+        if (!REVERSE) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (bias[ch[k]] + expf(logs[ch[k]]) * v[k]) * m;       // Modules.py:693
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (w[k * 4 + 0] * v[0] + w[k * 4 + 1] * v[1] + w[k * 4 + 2] * v[2] + w[k * 4 + 3] * v[3]) * m;   // :749-756
+        } else {
+            float u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = (w[k * 4 + 0] * v[0] + w[k * 4 + 1] * v[1] + w[k * 4 + 2] * v[2] + w[k * 4 + 3] * v[3]) * m;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (u[k] - bias[ch[k]]) * expf(-logs[ch[k]]) * m;      // Modules.py:690
+        }
+        *reinterpret_cast<float2*>(xout + r * C + 2 * g) = make_float2(o[0], o[1]);
+        *reinterpret_cast<float2*>(xout + r * C + C2 + 2 * g) = make_float2(o[2], o[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column statistics over rows (deterministic two-stage): sums of x*m, x*x*m per channel and of m.
+// Used by the ActNorm data-dependent init (Modules.py:698-711).  partial: [nblk][2*C + 1]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colstats_partial_kernel(const float* __restrict__ x, const float* __restrict__ rowmask,
+                                                               float* __restrict__ partial, long rows, int C, int rows_per_block)
+{
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    float* out = partial + (long)blockIdx.x * (2 * C + 1);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s1 = 0.f, s2 = 0.f;
+        for (long r = r0; r < r1; ++r) { const float m = rowmask[r]; const float v = x[r * C + c]; s1 += v * m; s2 += v * v * m; }
+        out[c] = s1; out[C + c] = s2;
+    }
+    if (threadIdx.x == 0) { float sm = 0.f; for (long r = r0; r < r1; ++r) sm += rowmask[r]; out[2 * C] = sm; }
+}
+__global__ void colstats_final_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nblk, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += partial[(long)k * n + i];
+    stats[i] = (float)s;
+}
+// logs = -0.5*log(max(var,1e-7)), bias = -mean*exp(logs)   from stats = [sum x, sum x^2, sum m]
+__global__ void actnorm_from_stats_kernel(const float* __restrict__ stats, float* __restrict__ logs, float* __restrict__ bias, int C)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float den = stats[2 * C];
+    const float mean = stats[c] / den;
+    const float sq = stats[C + c] / den;
+    const float l = 0.5f * logf(fmaxf(sq - mean * mean, 1e-7f));
+    logs[c] = -l;
+    bias[c] = -mean * expf(-l);
+}
+
+// ------------------------------------------------------------------------------------------------
+// coupling backward (autograd of Modules.py:805-806), elementwise:
+//   z_b = (m + exp(logs) x_b) mask ; logdet = sum logs*mask
+//   d m = dz_b mask ; d logs = (dz_b exp(logs) x_b + dld[b]) mask ; d x_b = dz_b exp(logs) mask
+// outs / douts are PAIR-packed [R][npair*64] (m in the first 32 of each 64, logs in the second 32)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void coupling_bwd_kernel(float* __restrict__ dz, const float* __restrict__ xmid,
+                                                           const float* __restrict__ outs, float* __restrict__ douts,
+                                                           const float* __restrict__ rowmask, const float* __restrict__ dld,
+                                                           long rows, int C, int ldo, int rows_per_utt)
+{
+    const int C2 = C / 2;
+    const long total = rows * C2;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / C2;
+        const int j = (int)(i - r * C2);
+        const float m = rowmask[r];
+        const int pc = (j >> 5) * 64 + (j & 31);
+        const float logs = outs[r * ldo + pc + 32];
+        const float e = expf(logs);
+        const float d = dz[r * C + C2 + j];
+        const float xb = xmid[r * C + C2 + j];
+        douts[r * ldo + pc] = d * m;
+        douts[r * ldo + pc + 32] = (d * e * xb + dld[r / rows_per_utt]) * m;
+        dz[r * C + C2 + j] = d * e * m;
+    }
+}
+// zero the pad columns of a PAIR-packed rows buffer once (so dgrad / wgrad read zeros there)
+__global__ void zero_kernel(float* __restrict__ p, long n)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// inv-1x1 + ActNorm backward.  dz: grad wrt the inv-1x1 output (rows, C).  x: the flow input (ActNorm input).
+//   y = (bias + exp(logs) x) mask ; z = (W y) mask
+//   dy = W^T (dz mask) ; dx = dy exp(logs) mask ; dW += (dz mask) y^T ; dlogs += dy exp(logs) x mask ; dbias += dy mask
+// parameter-grad partials per block: [nblk][2*C + 16], reduced by colstats_final_kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void actnorm_inv_bwd_kernel(const float* __restrict__ dz, float* __restrict__ dx,
+                                                              const float* __restrict__ x, const float* __restrict__ logs,
+                                                              const float* __restrict__ bias, const float* __restrict__ winfo,
+                                                              const float* __restrict__ rowmask, float* __restrict__ partial,
+                                                              long rows, int C, int rows_per_block)
+{
+    // thread owns group g = threadIdx.x % G for rows r0 + threadIdx.x / G, stepping by 256 / G ... simpler: loop
+    const int G = C / 4, C2 = C / 2;
+    extern __shared__ float red[];                 // [256][...] not used: accumulate per-thread then LDS reduce per channel
+    float w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = winfo[i];
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    // each thread handles a fixed group (g = tid % G) and rows r0 + tid / G + k * (256 / G)
+    const int tpg = 256 / G;                       // row lanes per pass (>= 1 since G <= 256 is checked on the host)
+    const int g = threadIdx.x % G;
+    const int rl = threadIdx.x / G;
+    float accW[16], accL[4], accB[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accW[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { accL[i] = 0.f; accB[i] = 0.f; }
+    const int ch[4] = {2 * g, 2 * g + 1, C2 + 2 * g, C2 + 2 * g + 1};
+    float el[4], bs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { el[k] = expf(logs[ch[k]]); bs[k] = bias[ch[k]]; }
+    if (rl < tpg) {
+        for (long r = r0 + rl; r < r1; r += tpg) {
+            const float m = rowmask[r];
+            const float2 dlo = *reinterpret_cast<const float2*>(dz + r * C + 2 * g);
+            const float2 dhi = *reinterpret_cast<const float2*>(dz + r * C + C2 + 2 * g);
+            const float2 xlo = *reinterpret_cast<const float2*>(x + r * C + 2 * g);
+            const float2 xhi = *reinterpret_cast<const float2*>(x + r * C + C2 + 2 * g);
+            const float d[4] = {dlo.x * m, dlo.y * m, dhi.x * m, dhi.y * m};
+            const float xv[4] = {xlo.x, xlo.y, xhi.x, xhi.y};
+            float y[4], dy[4], o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = (bs[k] + el[k] * xv[k]) * m;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dy[k] = (w[0 * 4 + k] * d[0] + w[1 * 4 + k] * d[1] + w[2 * 4 + k] * d[2] + w[3 * 4 + k] * d[3]) * m;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) accW[a * 4 + k] += d[a] * y[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { o[k] = dy[k] * el[k]; accL[k] += o[k] * xv[k]; accB[k] += dy[k]; }
+            *reinterpret_cast<float2*>(dx + r * C + 2 * g) = make_float2(o[0], o[1]);
+            *reinterpret_cast<float2*>(dx + r * C + C2 + 2 * g) = make_float2(o[2], o[3]);
+        }
+    }
+    // block reduction through LDS: red[24][256]
+    float* out = partial + (long)blockIdx.x * (2 * C + 16);
+    for (int q = 0; q < 24; ++q) {
+        float v = (q < 16) ? accW[q] : (q < 20 ? accL[q - 16] : accB[q - 20]);
+        red[q * 256 + threadIdx.x] = (rl < tpg) ? v : 0.f;
+    }
+    __syncthreads();
+    // dW: sum over all threads; dlogs/dbias: sum over threads with the same g
+    if (threadIdx.x < 16) {
+        float s = 0.f;
+        for (int t = 0; t < 256; ++t) s += red[threadIdx.x * 256 + t];
+        out[2 * C + threadIdx.x] = s;
+    }
+    for (int i = threadIdx.x; i < 2 * 4 * G; i += 256) {          // (which in {L,B}) x k x g
+        const int which = i / (4 * G), k = (i / G) % 4, gg = i % G;
+        float s = 0.f;
+        for (int t = gg; t < tpg * G; t += G) s += red[(16 + which * 4 + k) * 256 + t];
+        const int c = (k < 2) ? (2 * gg + k) : (C2 + 2 * gg + (k - 2));
+        out[which * C + c] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// log-determinant of the whole decoder (Modules.py:309 sum of the 3*F per-layer vectors):
+//   logdet[b] = sum_f [ (sum_c logs_f[c] + logdet(W_f) * C/4) * len'_b + sum_{valid rows of b} sum_j logs^{coupling}_f ]
+// stage 1: grid (F, B) -> part[f][b];  stage 2: fixed-order sum over f.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void logdet_partial_kernel(const float* __restrict__ outs_all, long flow_stride,
+                                                             const float* __restrict__ logs_all, const float* __restrict__ winfo_all,
+                                                             const float* __restrict__ rowmask, float* __restrict__ part,
+                                                             int B, int Tp, int C, int ldo)
+{
+    __shared__ float red[256];
+    const int f = blockIdx.x, b = blockIdx.y;
+    const int C2 = C / 2;
+    const float* outs = outs_all + (long)f * flow_stride + (long)b * Tp * ldo;
+    const float* rm = rowmask + (long)b * Tp;
+    float s = 0.f, len = 0.f;
+    for (int i = threadIdx.x; i < Tp * C2; i += 256) {
+        const int t = i / C2, j = i - t * C2;
+        s += outs[(long)t * ldo + (j >> 5) * 64 + 32 + (j & 31)] * rm[t];
+    }
+    for (int t = threadIdx.x; t < Tp; t += 256) len += rm[t];
+    float ls = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) ls += logs_all[f * C + c];
+    red[threadIdx.x] = s; __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    const float S = red[0]; __syncthreads();
+    red[threadIdx.x] = len; __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    const float L = red[0]; __syncthreads();
+    red[threadIdx.x] = ls; __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) part[f * B + b] = S + (red[0] + winfo_all[f * 36 + 32] * (float)(C / 4)) * L;
+}
+__global__ void logdet_final_kernel(const float* __restrict__ part, float* __restrict__ logdet, int F, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s += part[f * B + b];
+    logdet[b] = s;
+}
+
+inline int grid_for(long total, int per = 256, int cap = 2048) { long g = (total + per - 1) / per; return (int)(g > cap ? cap : (g < 1 ? 1 : g)); }
+#define RET_LAUNCH() return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH
+
+}  // namespace
+
+extern "C" int glowtts_squeeze_rows(const float* mel, float* rows, float* rowmask, const int64_t* lengths,
+                                    int B, int Cm, int Tm, int ns, void* stream)
+{
+    if (!mel || !rows || !lengths || B < 1 || Cm < 1 || ns < 1 || Tm < ns) return GLOWTTS_E_ARG;
+    const int T = Tm / ns;
+    const size_t lds = (size_t)Cm * (32 * ns + 1) * sizeof(float);
+    hipLaunchKernelGGL(squeeze_kernel<true>, dim3((T + 31) / 32, B), dim3(256), lds, static_cast<hipStream_t>(stream),
+                       const_cast<float*>(mel), rows, rowmask, lengths, Cm, Tm, T, ns, 0.f, 0);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_unsqueeze_rows(const float* rows, float* mel, const int64_t* lengths,
+                                      int B, int Cm, int Tm, int ns, int use_fill, float fill, void* stream)
+{
+    if (!mel || !rows || !lengths || B < 1 || Cm < 1 || ns < 1 || Tm < ns) return GLOWTTS_E_ARG;
+    const int T = Tm / ns;
+    const size_t lds = (size_t)Cm * (32 * ns + 1) * sizeof(float);
+    hipLaunchKernelGGL(squeeze_kernel<false>, dim3((T + 31) / 32, B), dim3(256), lds, static_cast<hipStream_t>(stream),
+                       mel, const_cast<float*>(rows), (float*)nullptr, lengths, Cm, Tm, T, ns, fill, use_fill);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_inv1x1_prepare(const float* W, float* winfo, int F, void* stream)
+{
+    if (!W || !winfo || F < 1) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(inv4x4_kernel, dim3((F + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), W, winfo, F);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_actnorm_inv1x1(const float* xin, float* xout, const float* logs, const float* bias,
+                                      const float* winfo, const float* rowmask, int64_t rows, int C, int reverse, void* stream)
+{
+    if (!xin || !xout || !logs || !bias || !winfo || !rowmask || rows < 1 || C < 4 || (C & 3)) return GLOWTTS_E_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(rows * (C / 4));
+    if (reverse) hipLaunchKernelGGL(actnorm_inv_kernel<true>, dim3(grid), dim3(256), 0, s, xin, xout, logs, bias, winfo, rowmask, (long)rows, C);
+    else         hipLaunchKernelGGL(actnorm_inv_kernel<false>, dim3(grid), dim3(256), 0, s, xin, xout, logs, bias, winfo, rowmask, (long)rows, C);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_actnorm_stats(const float* x, const float* rowmask, float* stats, float* scratch,
+                                     int64_t rows, int C, void* stream)
+{
+    if (!x || !rowmask || !stats || !scratch || rows < 1 || C < 1) return GLOWTTS_E_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rpb = 64;
+    const int nblk = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(colstats_partial_kernel, dim3(nblk), dim3(256), 0, s, x, rowmask, scratch, (long)rows, C, rpb);
+    const int n = 2 * C + 1;
+    hipLaunchKernelGGL(colstats_final_kernel, dim3((n + 255) / 256), dim3(256), 0, s, scratch, stats, nblk, n);
+    RET_LAUNCH();
+}
+
+extern "C" int64_t glowtts_actnorm_stats_scratch_floats(int64_t rows, int C) { return ((rows + 63) / 64) * (2 * (int64_t)C + 16); }
+
+extern "C" int glowtts_actnorm_from_stats(const float* stats, float* logs, float* bias, int C, void* stream)
+{
+    if (!stats || !logs || !bias || C < 1) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(actnorm_from_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), stats, logs, bias, C);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_coupling_bwd(float* dz, const float* xmid, const float* outs, float* douts, const float* rowmask,
+                                    const float* dlogdet, int64_t rows, int C, int ldo, int rows_per_utt, void* stream)
+{
+    if (!dz || !xmid || !outs || !douts || !rowmask || !dlogdet || rows < 1 || C < 2) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(grid_for(rows * (C / 2))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       dz, xmid, outs, douts, rowmask, dlogdet, (long)rows, C, ldo, rows_per_utt);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_fill_zero(float* p, int64_t n, void* stream)
+{
+    if (!p || n < 0) return GLOWTTS_E_ARG;
+    if (n == 0) return GLOWTTS_OK;
+    hipLaunchKernelGGL(zero_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, (long)n);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_actnorm_inv1x1_bwd(const float* dz, float* dx, const float* x, const float* logs, const float* bias,
+                                          const float* winfo, const float* rowmask, float* param_grads /* [2C+16]: dlogs, dbias, dW */,
+                                          float* scratch, int64_t rows, int C, void* stream)
+{
+    if (!dz || !dx || !x || !logs || !bias || !winfo || !rowmask || !param_grads || !scratch || rows < 1 || C < 4 || (C & 3) || C / 4 > 256) return GLOWTTS_E_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rpb = 64;
+    const int nblk = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(actnorm_inv_bwd_kernel, dim3(nblk), dim3(256), 24 * 256 * sizeof(float), s, dz, dx, x, logs, bias, winfo, rowmask,
+                       scratch, (long)rows, C, rpb);
+    const int n = 2 * C + 16;
+    hipLaunchKernelGGL(colstats_final_kernel, dim3((n + 255) / 256), dim3(256), 0, s, scratch, param_grads, nblk, n);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_decoder_logdet(const float* outs_all, int64_t flow_stride, const float* logs_all, const float* winfo_all,
+                                      const float* rowmask, float* part, float* logdet, int F, int B, int Tp, int C, int ldo, void* stream)
+{
+    if (!outs_all || !logs_all || !winfo_all || !rowmask || !part || !logdet || F < 1 || B < 1) return GLOWTTS_E_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(logdet_partial_kernel, dim3(F, B), dim3(256), 0, s, outs_all, (long)flow_stride, logs_all, winfo_all, rowmask, part, B, Tp, C, ldo);
+    hipLaunchKernelGGL(logdet_final_kernel, dim3((B + 255) / 256), dim3(256), 0, s, part, logdet, F, B);
+    RET_LAUNCH();
+}

@@ -64,6 +64,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, CT* __restrict__
 {
     constexpr int KC = 64 / sizeof(CT);
     const long total = (long)taps * kchunks * npad * KC;
+    w += (long)blockIdx.y * O * I * taps;          // batch of independent weights
+    out += (long)blockIdx.y * total;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int kk = i % KC;
         long r = i / KC;
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
                         } else {
                             // v0 = m, v1 = logs                                     Modules.py:795-806
                             float* xb = p.out0 + (long)r * p.ld0 + j;
-                            const float x = *xb;
+                            const float x = p.in0 ? p.in0[(long)r * p.ldi0 + j] : *xb;     // x_b read from the kept coupling input when given
                             if (fl & GLOWTTS_F_REVERSE) *xb = (x - v0) * exp_<EX>(-v1) * mask;
                             else                        *xb = (v0 + exp_<EX>(v1) * x) * mask;
                             if (p.out1) {
@@ -383,10 +385,10 @@ int launch_prec(const glowtts_conv_args& a, hipStream_t s)
 
 }  // namespace
 
-extern "C" int glowtts_pack_weight(const float* w, int O, int I, int taps, int transpose, int perm, int perm_h,
-                                   int precision, void* packed, int* npad_out, int* kchunks_out, void* stream)
+extern "C" int glowtts_pack_weight_batched(const float* w, int batch, int O, int I, int taps, int transpose, int perm, int perm_h,
+                                           int precision, void* packed, int* npad_out, int* kchunks_out, void* stream)
 {
-    if (O < 1 || I < 1 || taps < 1 || taps > MAX_TAPS || (precision != GLOWTTS_F32 && precision != GLOWTTS_BF16)) return GLOWTTS_E_ARG;
+    if (batch < 1 || O < 1 || I < 1 || taps < 1 || taps > MAX_TAPS || (precision != GLOWTTS_F32 && precision != GLOWTTS_BF16)) return GLOWTTS_E_ARG;
     if (perm == GLOWTTS_PERM_PAIR && (perm_h < 1 || 2 * perm_h != O)) return GLOWTTS_E_ARG;
     const int KC = precision == GLOWTTS_BF16 ? 32 : 16;
     // logical extents of the O-side index after permutation (PAIR pads each half to a multiple of 32)
@@ -401,12 +403,18 @@ extern "C" int glowtts_pack_weight(const float* w, int O, int I, int taps, int t
     if (!w) return GLOWTTS_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long total = (long)taps * kchunks * npad * KC;
-    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
     if (precision == GLOWTTS_BF16)
-        hipLaunchKernelGGL(pack_weight_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, w, static_cast<__bf16*>(packed), O, I, taps, transpose, perm, perm_h, N, kchunks * KC, npad, kchunks);
+        hipLaunchKernelGGL(pack_weight_kernel<__bf16>, dim3(blocks, batch), dim3(256), 0, s, w, static_cast<__bf16*>(packed), O, I, taps, transpose, perm, perm_h, N, kchunks * KC, npad, kchunks);
     else
-        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, s, w, static_cast<float*>(packed), O, I, taps, transpose, perm, perm_h, N, kchunks * KC, npad, kchunks);
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks, batch), dim3(256), 0, s, w, static_cast<float*>(packed), O, I, taps, transpose, perm, perm_h, N, kchunks * KC, npad, kchunks);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
+extern "C" int glowtts_pack_weight(const float* w, int O, int I, int taps, int transpose, int perm, int perm_h,
+                                   int precision, void* packed, int* npad_out, int* kchunks_out, void* stream)
+{
+    return glowtts_pack_weight_batched(w, 1, O, I, taps, transpose, perm, perm_h, precision, packed, npad_out, kchunks_out, stream);
 }
 
 extern "C" int glowtts_conv_cl(const glowtts_conv_args* args, void* stream)

@@ -67,19 +67,21 @@ __global__ __launch_bounds__(64) void mas_dp_kernel(const float* __restrict__ va
 
     // one chunk = 4 columns x R rows (16 B per row per lane)
     auto load_chunk = [&](float4 (&dst)[R], int chunk) {
-        const int y0 = chunk * 4;
+        // unconditional loads with clamped addresses: a predicated load would need a select after it,
+        // i.e. an s_waitcnt right behind the load, which destroys the look-ahead.  Columns >= Ty hold
+        // garbage that no cell inside an utterance ever reads.
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (VEC4) {
-                if (y0 < Ty) v = *reinterpret_cast<const float4*>(rowp[j] + y0);
+                const int y0 = min(chunk * 4, Ty - 4);
+                dst[j] = *reinterpret_cast<const float4*>(rowp[j] + y0);
             } else {
-                if (y0 + 0 < Ty) v.x = rowp[j][y0 + 0];
-                if (y0 + 1 < Ty) v.y = rowp[j][y0 + 1];
-                if (y0 + 2 < Ty) v.z = rowp[j][y0 + 2];
-                if (y0 + 3 < Ty) v.w = rowp[j][y0 + 3];
+                const int y0 = chunk * 4;
+                dst[j].x = rowp[j][min(y0 + 0, Ty - 1)];
+                dst[j].y = rowp[j][min(y0 + 1, Ty - 1)];
+                dst[j].z = rowp[j][min(y0 + 2, Ty - 1)];
+                dst[j].w = rowp[j][min(y0 + 3, Ty - 1)];
             }
-            dst[j] = v;
         }
     };
 

@@ -1,0 +1,295 @@
+// Weight gradient of the channels-last convolution for gfx950:
+//     dW[o][c][t] (+)= sum_r DY[r][o] * X[r + t - pad][c]          dbias[o] (+)= sum_r DY[r][o]
+// (autograd of Modules.py:791,861,871,793 and of the encoder convs).
+//
+// CDNA4 mapping
+//   * MFMA M = output channel o, N = input channel c, K = rows (utterance, frame).  The reduction runs
+//     over the SLOW (row) axis of both channels-last operands, so the fragments must be read
+//     transposed out of LDS:
+//       bf16: tiles are kept in their natural [row][channel] layout and read with ds_read_b64_tr_b16;
+//             probed on gfx950 (tools/probe_tr16.hip): in a 16-lane group, lane s supplies the address of
+//             4 contiguous bf16 and lane i receives element (i & 3) of the rows supplied by lanes
+//             (i >> 2) + 4e, e = 0..3.  With lane s pointing at [k0 + (s >> 2)][c0 + 4 (s & 3)] lane i gets
+//             channel c0 + i for the 4 rows k0..k0+3 - two reads give the 8 k-values of a 32x32x16 fragment.
+//       f32 : v_mfma_f32_32x32x2_f32 takes one k per lane: plain ds_read_b32 from the same natural layout.
+//   * all taps share one staged X tile ([32 + taps - 1 rows][64 channels]); a tap is a row offset of the
+//     fragment address, so X is read once for the 5 taps.  Accumulators: 128(o) x 64(c) x taps per block.
+//   * rows are split over gridDim.z (split-K); partial tiles are combined with fp32 atomics.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/glowtts_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WG_MAX_TAPS = 5;
+constexpr int BMO = 128;      // o per block
+constexpr int BNC = 64;       // c per block
+constexpr int BK = 32;        // rows per step
+
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return *reinterpret_cast<uint32_t*>(&v);
+}
+
+template <typename CT, int TAPS>
+__global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_args p)
+{
+    constexpr int ES = sizeof(CT);
+    constexpr int XROWS = BK + TAPS - 1;
+    // LDS row strides (bytes): natural width + 64 B so that 4 consecutive rows hit 4 different 64-B bank segments
+    constexpr int LDY = BMO * ES + 64;
+    constexpr int LDX = BNC * ES + 64;
+    constexpr int DY_BYTES = BK * LDY, X_BYTES = XROWS * LDX;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (DY_BYTES + X_BYTES)];
+    __shared__ float bias_red[8][BMO];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                 // wave tile: 64 (o) x 32 (c)
+    const int o0 = blockIdx.x * BMO, c0 = blockIdx.y * BNC;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // rows handled by this split
+    const long chunk = ((((long)p.rows + gridDim.z - 1) / gridDim.z) + BK - 1) / BK * BK;
+    const long rbeg = (long)blockIdx.z * chunk;
+    const long rend = min((long)p.rows, rbeg + chunk);
+    if (rbeg >= rend) return;
+    const int nsteps = (int)((rend - rbeg + BK - 1) / BK);
+
+    f32x16 acc[2][TAPS];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][t][r] = 0.f;
+
+    // ---- staging registers ----
+    constexpr int DY_IT = (BK * BMO / 4) / 256;               // float4 per thread for the DY tile (= 4)
+    constexpr int X_IT = (XROWS * BNC / 4 + 255) / 256;       // float4 per thread for the X tile
+    float4 rdy[DY_IT], rx[X_IT];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool want_bias = (p.dbias != nullptr) && (blockIdx.y == 0);
+
+    auto gload = [&](long r0) {
+#pragma unroll
+        for (int it = 0; it < DY_IT; ++it) {
+            const int idx = tid + it * 256;
+            const int row = idx / (BMO / 4), c4 = idx % (BMO / 4);
+            const long r = r0 + row;
+            const int col = o0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rend && col < p.m) {
+                const float* src = p.dy + r * p.lddy + col;
+                if (col + 4 <= p.m) v = *reinterpret_cast<const float4*>(src);
+                else { v.x = src[0]; if (col + 1 < p.m) v.y = src[1]; if (col + 2 < p.m) v.z = src[2]; }
+            }
+            rdy[it] = v;
+            bsum[0] += v.x; bsum[1] += v.y; bsum[2] += v.z; bsum[3] += v.w;
+        }
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) {
+            const int idx = tid + it * 256;
+            const int row = idx / (BNC / 4), c4 = idx % (BNC / 4);
+            const long r = r0 + row - p.pad;
+            const int col = c0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            // rows outside [0, rows) are zero; rows outside this split's range ARE read (halo of the split)
+            if (row < XROWS && r >= 0 && r < p.rows && col < p.ca) {
+                if (p.xpro == GLOWTTS_APRO_PAIRMUL) {
+                    const float* src = p.x + r * p.ldx + 2 * col;
+                    if (col + 4 <= p.ca) {
+                        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+                        v = make_float4(a.x * a.y, a.z * a.w, b.x * b.y, b.z * b.w);
+                    } else {
+                        v.x = src[0] * src[1];
+                        if (col + 1 < p.ca) v.y = src[2] * src[3];
+                        if (col + 2 < p.ca) v.z = src[4] * src[5];
+                    }
+                } else {
+                    const float* src = p.x + r * p.ldx + col;
+                    if (col + 4 <= p.ca) v = *reinterpret_cast<const float4*>(src);
+                    else { v.x = src[0]; if (col + 1 < p.ca) v.y = src[1]; if (col + 2 < p.ca) v.z = src[2]; }
+                }
+                if (p.xmask) { const float m = p.xmask[r]; v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
+            }
+            rx[it] = v;
+        }
+    };
+    auto sstore = [&](int buf) {
+        unsigned char* dyb = smem + buf * (DY_BYTES + X_BYTES);
+        unsigned char* xb = dyb + DY_BYTES;
+#pragma unroll
+        for (int it = 0; it < DY_IT; ++it) {
+            const int idx = tid + it * 256;
+            const int row = idx / (BMO / 4), c4 = idx % (BMO / 4);
+            if constexpr (ES == 2) {
+                uint2 w = make_uint2(pk_bf16(rdy[it].x, rdy[it].y), pk_bf16(rdy[it].z, rdy[it].w));
+                *reinterpret_cast<uint2*>(dyb + row * LDY + c4 * 8) = w;
+            } else {
+                *reinterpret_cast<float4*>(dyb + row * LDY + c4 * 16) = rdy[it];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) {
+            const int idx = tid + it * 256;
+            const int row = idx / (BNC / 4), c4 = idx % (BNC / 4);
+            if (row < XROWS) {
+                if constexpr (ES == 2) {
+                    uint2 w = make_uint2(pk_bf16(rx[it].x, rx[it].y), pk_bf16(rx[it].z, rx[it].w));
+                    *reinterpret_cast<uint2*>(xb + row * LDX + c4 * 8) = w;
+                } else {
+                    *reinterpret_cast<float4*>(xb + row * LDX + c4 * 16) = rx[it];
+                }
+            }
+        }
+    };
+
+    auto compute = [&](int buf) {
+        const unsigned char* dyb = smem + buf * (DY_BYTES + X_BYTES);
+        const unsigned char* xb = dyb + DY_BYTES;
+        if constexpr (ES == 2) {
+            // transposed fragment reads: 16-lane group gq = (lane >> 4) & 1 covers channels 16*gq..+15 of the 32-wide fragment
+            const int s = lane & 15, gq = (lane >> 4) & 1;
+#pragma unroll
+            for (int k16 = 0; k16 < BK / 16; ++k16) {
+                const int krow = k16 * 16 + 8 * lhi + (s >> 2);          // + 4 for the second read
+                bf16x8 af[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int col = (wm * 2 + mi) * 32 + gq * 16 + 4 * (s & 3);
+                    const unsigned char* a0 = dyb + krow * LDY + col * 2;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 4 * LDY));
+                    s16x4 tmp[2] = {lo, hi};
+                    af[mi] = *reinterpret_cast<bf16x8*>(tmp);
+                }
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int col = wn * 32 + gq * 16 + 4 * (s & 3);
+                    const unsigned char* b0 = xb + (krow + t) * LDX + col * 2;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0 + 4 * LDX));
+                    s16x4 tmp[2] = {lo, hi};
+                    const bf16x8 bfr = *reinterpret_cast<bf16x8*>(tmp);
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr, acc[mi][t], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int k2 = 0; k2 < BK / 2; ++k2) {
+                const int krow = k2 * 2 + lhi;
+                float af[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    af[mi] = *reinterpret_cast<const float*>(dyb + krow * LDY + ((wm * 2 + mi) * 32 + l31) * 4);
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const float bv = *reinterpret_cast<const float*>(xb + (krow + t) * LDX + (wn * 32 + l31) * 4);
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bv, acc[mi][t], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    gload(rbeg);
+    sstore(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const bool more = s + 1 < nsteps;
+        if (more) gload(rbeg + (long)(s + 1) * BK);
+        compute(s & 1);
+        if (more) sstore((s + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: dW[o][c][t] ----
+    const bool atomic = gridDim.z > 1 || p.accumulate;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int pcol = o0 + (wm * 2 + mi) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhi;    // DY column (possibly PAIR-packed)
+            if (pcol >= p.m) continue;
+            int o = pcol;
+            if (p.perm == GLOWTTS_PERM_PAIR) {
+                const int j = (pcol >> 6) * 32 + (pcol & 31);
+                if (j >= p.perm_h) continue;
+                o = ((pcol >> 5) & 1) * p.perm_h + j;
+            }
+            const int c = c0 + wn * 32 + l31;
+            if (c >= p.ca) continue;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                float* dst = p.dw + ((long)o * p.ca + c) * TAPS + t;
+                if (atomic) atomicAdd(dst, acc[mi][t][reg]);
+                else *dst = acc[mi][t][reg];
+            }
+        }
+    }
+    // ---- dbias[o] = column sums of DY (first c-tile only) ----
+    if (want_bias) {
+        const int c4 = tid % (BMO / 4), rgrp = tid / (BMO / 4);       // 8 row groups share each column quad
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias_red[rgrp][c4 * 4 + e] = bsum[e];
+        __syncthreads();
+        if (tid < BMO) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += bias_red[g][tid];
+            const int pcol = o0 + tid;
+            if (pcol < p.m) {
+                int o = pcol; bool ok = true;
+                if (p.perm == GLOWTTS_PERM_PAIR) {
+                    const int j = (pcol >> 6) * 32 + (pcol & 31);
+                    ok = j < p.perm_h;
+                    o = ((pcol >> 5) & 1) * p.perm_h + j;
+                }
+                if (ok) { if (atomic) atomicAdd(p.dbias + o, s); else p.dbias[o] = s; }
+            }
+        }
+    }
+}
+
+template <typename CT>
+int launch_w(const glowtts_wgrad_args& a, dim3 grid, hipStream_t s)
+{
+    switch (a.taps) {
+        case 1: hipLaunchKernelGGL((wgrad_kernel<CT, 1>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((wgrad_kernel<CT, 3>), grid, dim3(256), 0, s, a); break;
+        case 5: hipLaunchKernelGGL((wgrad_kernel<CT, 5>), grid, dim3(256), 0, s, a); break;
+        default: return GLOWTTS_E_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int glowtts_wgrad_cl(const glowtts_wgrad_args* args, void* stream)
+{
+    if (!args || !args->dy || !args->x || !args->dw || args->rows < 1 || args->m < 1 || args->ca < 1) return GLOWTTS_E_ARG;
+    if ((args->lddy & 3) || (args->ldx & 3) || (reinterpret_cast<uintptr_t>(args->dy) & 15) || (reinterpret_cast<uintptr_t>(args->x) & 15)) return GLOWTTS_E_ARG;
+    glowtts_wgrad_args a = *args;
+    const int mt = (a.m + BMO - 1) / BMO, nt = (a.ca + BNC - 1) / BNC;
+    int splits = a.splits;
+    if (splits < 1) {                                   // fill ~2 workgroups per CU, at least 256 rows per split
+        splits = (512 + mt * nt - 1) / (mt * nt);
+        const int maxs = (a.rows + 255) / 256;
+        if (splits > maxs) splits = maxs;
+        if (splits < 1) splits = 1;
+    }
+    dim3 grid(mt, nt, splits);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a.precision == GLOWTTS_BF16) return launch_w<__bf16>(a, grid, s);
+    if (a.precision == GLOWTTS_F32) return launch_w<float>(a, grid, s);
+    return GLOWTTS_E_ARG;
+}

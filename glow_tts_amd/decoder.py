@@ -1,0 +1,428 @@
+"""Flow decoder (Modules.py:286-309 `Decoder`, :653-924) on the HIP path.
+
+`decoder_forward` / `DecoderFunction` run Squeeze -> Stack x AIA -> Unsqueeze through the C ABI
+(glowtts_squeeze_rows, glowtts_flow_forward/inverse/backward, glowtts_unsqueeze_rows,
+glowtts_decoder_logdet).  This file only marshals pointers: weights arrive as *stacked* fp32 tensors
+(one tensor per parameter kind, leading dim = flow), are packed into MFMA tile order once per step
+(glowtts_pack_weight_batched) and every kept activation lives in buffers allocated here and handed to
+the kernels.  There is no CPU fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+from ._lib import c_int, c_void_p
+
+MAXL = 8
+ROW_PAD = 2
+c_i64 = ctypes.c_int64
+
+
+class Packed(ctypes.Structure):
+    _fields_ = [("w", c_void_p), ("npad", c_int), ("kchunks", c_int)]
+
+
+class FlowDims(ctypes.Structure):
+    _fields_ = [("B", c_int), ("T", c_int), ("C", c_int), ("H", c_int), ("L", c_int), ("ksize", c_int), ("precision", c_int)]
+
+
+class FlowParams(ctypes.Structure):
+    _fields_ = [("an_logs", c_void_p), ("an_bias", c_void_p), ("winfo", c_void_p),
+                ("start", Packed), ("in_", Packed * MAXL), ("rs", Packed * MAXL), ("end", Packed),
+                ("start_t", Packed), ("in_t", Packed * MAXL), ("rs_t", Packed * MAXL), ("end_t", Packed),
+                ("b_start", c_void_p), ("b_in", c_void_p * MAXL), ("b_rs", c_void_p * MAXL), ("b_end", c_void_p),
+                ("cond", c_void_p), ("ldcond", c_i64)]
+
+
+class FlowActs(ctypes.Structure):
+    _fields_ = [("xin", c_void_p), ("xmid", c_void_p), ("xout", c_void_p),
+                ("hs", c_void_p * MAXL), ("gates", c_void_p * MAXL), ("skip", c_void_p), ("outs", c_void_p),
+                ("rowmask", c_void_p)]
+
+
+class FlowGrads(ctypes.Structure):
+    _fields_ = [("dx", c_void_p), ("dlogdet", c_void_p), ("douts", c_void_p), ("dskip", c_void_p),
+                ("dh", c_void_p * 2), ("dins", c_void_p), ("scratch", c_void_p), ("d_an", c_void_p),
+                ("dw_start", c_void_p), ("db_start", c_void_p),
+                ("dw_in", c_void_p * MAXL), ("db_in", c_void_p * MAXL),
+                ("dw_rs", c_void_p * MAXL), ("db_rs", c_void_p * MAXL),
+                ("dw_end", c_void_p), ("db_end", c_void_p), ("dcond", c_void_p)]
+
+
+_declared = False
+
+
+def _L():
+    global _declared
+    L = _lib.lib()
+    if not _declared:
+        L.glowtts_pack_weight_batched.argtypes = [c_void_p] + [c_int] * 8 + [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p]
+        L.glowtts_squeeze_rows.argtypes = [c_void_p] * 4 + [c_int] * 4 + [c_void_p]
+        L.glowtts_unsqueeze_rows.argtypes = [c_void_p] * 3 + [c_int] * 5 + [ctypes.c_float, c_void_p]
+        L.glowtts_inv1x1_prepare.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
+        L.glowtts_actnorm_stats.argtypes = [c_void_p] * 4 + [c_i64, c_int, c_void_p]
+        L.glowtts_actnorm_stats_scratch_floats.argtypes = [c_i64, c_int]
+        L.glowtts_actnorm_stats_scratch_floats.restype = c_i64
+        L.glowtts_actnorm_from_stats.argtypes = [c_void_p] * 3 + [c_int, c_void_p]
+        L.glowtts_actnorm_inv1x1.argtypes = [c_void_p] * 6 + [c_i64, c_int, c_int, c_void_p]
+        L.glowtts_flow_forward.argtypes = [c_void_p] * 4
+        L.glowtts_flow_inverse.argtypes = [c_void_p] * 4
+        L.glowtts_flow_backward.argtypes = [c_void_p] * 5
+        L.glowtts_decoder_logdet.argtypes = [c_void_p, c_i64] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]
+        _declared = True
+    return L
+
+
+class PackedBatch:
+    """`batch` same-shape conv weights packed by one launch; element i is the i-th weight."""
+
+    def __init__(self, w, transpose, perm, perm_h, precision):
+        L = _L()
+        w = w.contiguous()
+        self.batch, O, I, taps = w.shape
+        npad, kch = c_int(0), c_int(0)
+        args = (self.batch, O, I, taps, int(transpose), perm, perm_h, precision)
+        _lib.check(L.glowtts_pack_weight_batched(None, *args, None, ctypes.byref(npad), ctypes.byref(kch), None), "pack(size)")
+        self.npad, self.kchunks = npad.value, kch.value
+        self.stride = taps * self.kchunks * self.npad * 64
+        self.data = torch.empty(self.batch * self.stride, dtype=torch.uint8, device=w.device)
+        _lib.check(L.glowtts_pack_weight_batched(_lib.ptr(w), *args, _lib.ptr(self.data), None, None, _lib.stream()), "pack")
+
+    def at(self, i):
+        return Packed(self.data.data_ptr() + i * self.stride, self.npad, self.kchunks)
+
+
+class DecoderConfig:
+    """Shapes of the decoder, from Hyper_Parameters.yaml (Decoder.*, Sound.Mel_Dim)."""
+
+    def __init__(self, mel_dim, n_flows, n_squeeze, n_split, hidden, n_layers, ksize, precision=ops.BF16):
+        assert n_split == 4, "Invertible_1x1_Conv kernels are written for Decoder.Num_Split == 4 (the reference default)"
+        self.Cm, self.F, self.ns, self.H, self.L, self.k = mel_dim, n_flows, n_squeeze, hidden, n_layers, ksize
+        self.C = mel_dim * n_squeeze
+        self.precision = precision
+        assert n_layers <= MAXL and self.C % 4 == 0 and hidden % 4 == 0
+
+
+WEIGHT_KEYS = ("an_logs", "an_bias", "inv_w", "w_start", "b_start", "w_in", "b_in", "w_rs", "b_rs",
+               "w_rs_last", "b_rs_last", "w_end", "b_end")
+
+
+class _Prepared:
+    """Packed weight images + per-flow parameter structs for one set of stacked weights."""
+
+    def __init__(self, cfg, W, need_bwd, cond=None):
+        L = _L()
+        F_, H, C, Lw = cfg.F, cfg.H, cfg.C, cfg.L
+        P = cfg.precision
+        dev = W["w_in"].device
+        self.keep = W
+        self.winfo = torch.empty(F_, 36, device=dev)
+        _lib.check(L.glowtts_inv1x1_prepare(_lib.ptr(W["inv_w"].contiguous()), _lib.ptr(self.winfo), F_, _lib.stream()), "inv1x1_prepare")
+        w_in = W["w_in"].reshape(F_ * Lw, 2 * H, H, cfg.k)
+        self.pk = {
+            "start": PackedBatch(W["w_start"], False, ops.PERM_NONE, 0, P),
+            "in": PackedBatch(w_in, False, ops.PERM_PAIR, H, P),
+            "rs_last": PackedBatch(W["w_rs_last"], False, ops.PERM_NONE, 0, P),
+            "end": PackedBatch(W["w_end"], False, ops.PERM_PAIR, C // 2, P),
+        }
+        if Lw > 1:
+            self.pk["rs"] = PackedBatch(W["w_rs"].reshape(F_ * (Lw - 1), 2 * H, H, 1), False, ops.PERM_NONE, 0, P)
+        if need_bwd:
+            self.pk.update({
+                "start_t": PackedBatch(W["w_start"], True, ops.PERM_NONE, 0, P),
+                "in_t": PackedBatch(w_in, True, ops.PERM_PAIR, H, P),
+                "rs_last_t": PackedBatch(W["w_rs_last"], True, ops.PERM_NONE, 0, P),
+                "end_t": PackedBatch(W["w_end"], True, ops.PERM_PAIR, C // 2, P),
+            })
+            if Lw > 1:
+                self.pk["rs_t"] = PackedBatch(W["w_rs"].reshape(F_ * (Lw - 1), 2 * H, H, 1), True, ops.PERM_NONE, 0, P)
+        self.ldo = self.pk["end"].npad
+        self.ldin = self.pk["in"].npad
+        self.cond = cond
+        self.params = []
+        for f in range(F_):
+            p = FlowParams()
+            p.an_logs = W["an_logs"][f].data_ptr()
+            p.an_bias = W["an_bias"][f].data_ptr()
+            p.winfo = self.winfo[f].data_ptr()
+            p.start = self.pk["start"].at(f)
+            p.end = self.pk["end"].at(f)
+            p.b_start = W["b_start"][f].data_ptr()
+            p.b_end = W["b_end"][f].data_ptr()
+            for l in range(Lw):
+                p.in_[l] = self.pk["in"].at(f * Lw + l)
+                p.b_in[l] = W["b_in"][f, l].data_ptr()
+                if l < Lw - 1:
+                    p.rs[l] = self.pk["rs"].at(f * (Lw - 1) + l)
+                    p.b_rs[l] = W["b_rs"][f, l].data_ptr()
+                else:
+                    p.rs[l] = self.pk["rs_last"].at(f)
+                    p.b_rs[l] = W["b_rs_last"][f].data_ptr()
+            if need_bwd:
+                p.start_t = self.pk["start_t"].at(f)
+                p.end_t = self.pk["end_t"].at(f)
+                for l in range(Lw):
+                    p.in_t[l] = self.pk["in_t"].at(f * Lw + l)
+                    p.rs_t[l] = self.pk["rs_t"].at(f * (Lw - 1) + l) if l < Lw - 1 else self.pk["rs_last_t"].at(f)
+            if cond is not None:            # cond [B, F, L, 2H]
+                p.cond = cond.data_ptr() + 4 * f * Lw * 2 * H
+                p.ldcond = F_ * Lw * 2 * H
+            self.params.append(p)
+
+
+def _dims(cfg, B, T):
+    return FlowDims(B, T, cfg.C, cfg.H, cfg.L, cfg.k, cfg.precision)
+
+
+def squeeze_rows(cfg, mels, lengths, want_mask=True):
+    """[B,Cm,Tm] -> rows [B*(T+4), C] (+ rowmask [B*(T+4)])."""
+    B, Cm, Tm = mels.shape
+    T = Tm // cfg.ns
+    R = B * (T + 2 * ROW_PAD)
+    rows = torch.empty(R, cfg.C, device=mels.device)
+    mask = torch.empty(R, device=mels.device) if want_mask else None
+    _lib.check(_L().glowtts_squeeze_rows(_lib.ptr(mels.contiguous()), _lib.ptr(rows), _lib.ptr(mask), _lib.ptr(lengths),
+                                         B, Cm, Tm, cfg.ns, _lib.stream()), "squeeze_rows")
+    return rows, mask, T
+
+
+def unsqueeze_rows(cfg, rows, lengths, B, Tm, fill=None):
+    mel = torch.empty(B, cfg.Cm, Tm, device=rows.device)
+    if Tm % cfg.ns:
+        mel.zero_()
+    _lib.check(_L().glowtts_unsqueeze_rows(_lib.ptr(rows), _lib.ptr(mel), _lib.ptr(lengths), B, cfg.Cm, Tm, cfg.ns,
+                                           0 if fill is None else 1, 0.0 if fill is None else float(fill), _lib.stream()), "unsqueeze_rows")
+    return mel
+
+
+class _Buffers:
+    """Kept activations of a training forward (all flows)."""
+
+    def __init__(self, cfg, prep, R, dev):
+        F_, L, H, C = cfg.F, cfg.L, cfg.H, cfg.C
+        self.x = torch.empty(F_ + 1, R, C, device=dev)
+        self.xmid = torch.empty(F_, R, C, device=dev)
+        self.hs = torch.empty(F_, L, R, H, device=dev)
+        self.gates = torch.empty(F_, L, R, 2 * H, device=dev)
+        self.skip = torch.empty(F_, R, H, device=dev)
+        self.outs = torch.empty(F_, R, prep.ldo, device=dev)
+
+    def acts(self, f, L, rowmask):
+        a = FlowActs()
+        a.xin, a.xmid, a.xout = self.x[f].data_ptr(), self.xmid[f].data_ptr(), self.x[f + 1].data_ptr()
+        for l in range(L):
+            a.hs[l] = self.hs[f, l].data_ptr()
+            a.gates[l] = self.gates[f, l].data_ptr()
+        a.skip, a.outs, a.rowmask = self.skip[f].data_ptr(), self.outs[f].data_ptr(), rowmask.data_ptr()
+        return a
+
+
+def _run_forward(cfg, prep, mels, lengths):
+    L = _L()
+    B, _, Tm = mels.shape
+    x0, rowmask, T = squeeze_rows(cfg, mels, lengths)
+    R = x0.shape[0]
+    buf = _Buffers(cfg, prep, R, mels.device)
+    buf.x[0].copy_(x0)
+    dims = _dims(cfg, B, T)
+    for f in range(cfg.F):
+        acts = buf.acts(f, cfg.L, rowmask)
+        _lib.check(L.glowtts_flow_forward(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(acts), _lib.stream()),
+                   "glowtts_flow_forward")
+    z = unsqueeze_rows(cfg, buf.x[cfg.F], lengths, B, Tm)
+    part = torch.empty(cfg.F * B, device=mels.device)
+    logdet = torch.empty(B, device=mels.device)
+    _lib.check(L.glowtts_decoder_logdet(_lib.ptr(buf.outs), R * prep.ldo, _lib.ptr(prep.keep["an_logs"].contiguous()), _lib.ptr(prep.winfo),
+                                        _lib.ptr(rowmask), _lib.ptr(part), _lib.ptr(logdet), cfg.F, B, T + 2 * ROW_PAD, cfg.C, prep.ldo,
+                                        _lib.stream()), "glowtts_decoder_logdet")
+    return z, logdet, buf, rowmask, T
+
+
+def decoder_inverse(cfg, W, z, lengths, cond=None, fill=None):
+    """Decoder.forward(reverse=True) (Modules.py:298-309): z [B,Cm,Tm] -> mels [B,Cm,ns*(Tm//ns)]."""
+    L = _L()
+    prep = _Prepared(cfg, W, need_bwd=False, cond=cond)
+    B, _, Tm = z.shape
+    x, rowmask, T = squeeze_rows(cfg, z, lengths)
+    R = x.shape[0]
+    dev = z.device
+    other = torch.empty_like(x)
+    xmid = torch.empty_like(x)
+    hs = torch.empty(2, R, cfg.H, device=dev)
+    gates = torch.empty(R, 2 * cfg.H, device=dev)
+    skip = torch.empty(R, cfg.H, device=dev)
+    dims = _dims(cfg, B, T)
+    cur, nxt = x, other
+    for f in range(cfg.F - 1, -1, -1):
+        a = FlowActs()
+        a.xout, a.xmid, a.xin = cur.data_ptr(), xmid.data_ptr(), nxt.data_ptr()
+        a.hs[0], a.hs[1] = hs[0].data_ptr(), hs[1].data_ptr()
+        a.gates[0], a.skip, a.rowmask = gates.data_ptr(), skip.data_ptr(), rowmask.data_ptr()
+        a.outs = None
+        _lib.check(L.glowtts_flow_inverse(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(a), _lib.stream()),
+                   "glowtts_flow_inverse")
+        cur, nxt = nxt, cur
+    return unsqueeze_rows(cfg, cur, lengths, B, (Tm // cfg.ns) * cfg.ns, fill=fill)
+
+
+def actnorm_data_init(cfg, W, mels, lengths, cond=None, allreduce=None):
+    """ActNorm data-dependent init (Modules.py:685-687, 698-711): runs the flows once, setting
+    W['an_logs'][f] / W['an_bias'][f] from the masked batch statistics of each flow's input.
+    `allreduce(stats)` (optional) sums the [2C+1] statistics over data-parallel ranks."""
+    L = _L()
+    with torch.no_grad():
+        B, _, Tm = mels.shape
+        x, rowmask, T = squeeze_rows(cfg, mels, lengths)
+        R = x.shape[0]
+        dev = mels.device
+        dims = _dims(cfg, B, T)
+        stats = torch.empty(2 * cfg.C + 1, device=dev)
+        scratch = torch.empty(L.glowtts_actnorm_stats_scratch_floats(R, cfg.C), device=dev)
+        bufs = [x, torch.empty_like(x)]
+        xmid = torch.empty_like(x)
+        hs = torch.empty(cfg.L, R, cfg.H, device=dev)
+        gates = torch.empty(cfg.L, R, 2 * cfg.H, device=dev)
+        skip = torch.empty(R, cfg.H, device=dev)
+        for f in range(cfg.F):
+            _lib.check(L.glowtts_actnorm_stats(_lib.ptr(bufs[0]), _lib.ptr(rowmask), _lib.ptr(stats), _lib.ptr(scratch), R, cfg.C,
+                                               _lib.stream()), "actnorm_stats")
+            if allreduce is not None:
+                allreduce(stats)
+            _lib.check(L.glowtts_actnorm_from_stats(_lib.ptr(stats), W["an_logs"][f].data_ptr(), W["an_bias"][f].data_ptr(), cfg.C,
+                                                    _lib.stream()), "actnorm_from_stats")
+            prep = _Prepared(cfg, W, need_bwd=False, cond=cond)       # re-pack is cheap relative to a one-off init
+            outs = torch.empty(R, prep.ldo, device=dev)
+            a = FlowActs()
+            a.xin, a.xmid, a.xout = bufs[0].data_ptr(), xmid.data_ptr(), bufs[1].data_ptr()
+            for l in range(cfg.L):
+                a.hs[l], a.gates[l] = hs[l].data_ptr(), gates[l].data_ptr()
+            a.skip, a.outs, a.rowmask = skip.data_ptr(), outs.data_ptr(), rowmask.data_ptr()
+            _lib.check(L.glowtts_flow_forward(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(a), _lib.stream()),
+                       "glowtts_flow_forward(init)")
+            bufs.reverse()
+
+
+class DecoderFunction(torch.autograd.Function):
+    """z, logdet = Decoder(mels)   with autograd through the hand-written backward kernels."""
+
+    @staticmethod
+    def forward(ctx, cfg, mels, lengths, cond, *weights):
+        W = dict(zip(WEIGHT_KEYS, [w.detach().contiguous() for w in weights]))
+        need_bwd = any(w.requires_grad for w in weights) or mels.requires_grad or (cond is not None and cond.requires_grad)
+        condc = cond.detach().contiguous() if cond is not None else None
+        prep = _Prepared(cfg, W, need_bwd=need_bwd, cond=condc)
+        z, logdet, buf, rowmask, T = _run_forward(cfg, prep, mels.detach(), lengths)
+        if need_bwd:
+            ctx.cfg, ctx.prep, ctx.buf, ctx.rowmask, ctx.T = cfg, prep, buf, rowmask, T
+            ctx.lengths, ctx.mel_shape = lengths, mels.shape
+            ctx.want_dmel = mels.requires_grad
+        return z, logdet
+
+    @staticmethod
+    def backward(ctx, dz, dlogdet):
+        L = _L()
+        cfg, prep, buf, rowmask, T = ctx.cfg, ctx.prep, ctx.buf, ctx.rowmask, ctx.T
+        W = prep.keep
+        B, Cm, Tm = ctx.mel_shape
+        dev = dz.device
+        F_, Lw, H, C = cfg.F, cfg.L, cfg.H, cfg.C
+        dx, _, _ = squeeze_rows(cfg, dz.contiguous(), ctx.lengths, want_mask=False)
+        R = dx.shape[0]
+        dld = dlogdet.contiguous() if dlogdet is not None else torch.zeros(B, device=dev)
+        G = {k: torch.zeros_like(W[k]) for k in WEIGHT_KEYS}
+        d_an = torch.empty(F_, 2 * C + 16, device=dev)
+        douts = torch.zeros(R, prep.ldo, device=dev)
+        dins = torch.zeros(R, prep.ldin, device=dev)
+        dskip = torch.empty(R, H, device=dev)
+        dh = torch.empty(2, R, H, device=dev)
+        scratch = torch.empty(L.glowtts_actnorm_stats_scratch_floats(R, C), device=dev)
+        dcond = torch.zeros_like(prep.cond) if prep.cond is not None else None
+        dims = _dims(cfg, B, T)
+        for f in range(F_ - 1, -1, -1):
+            g = FlowGrads()
+            g.dx, g.dlogdet, g.douts, g.dskip = dx.data_ptr(), dld.data_ptr(), douts.data_ptr(), dskip.data_ptr()
+            g.dh[0], g.dh[1], g.dins, g.scratch, g.d_an = dh[0].data_ptr(), dh[1].data_ptr(), dins.data_ptr(), scratch.data_ptr(), d_an[f].data_ptr()
+            g.dw_start, g.db_start = G["w_start"][f].data_ptr(), G["b_start"][f].data_ptr()
+            g.dw_end, g.db_end = G["w_end"][f].data_ptr(), G["b_end"][f].data_ptr()
+            for l in range(Lw):
+                g.dw_in[l], g.db_in[l] = G["w_in"][f, l].data_ptr(), G["b_in"][f, l].data_ptr()
+                if l < Lw - 1:
+                    g.dw_rs[l], g.db_rs[l] = G["w_rs"][f, l].data_ptr(), G["b_rs"][f, l].data_ptr()
+                else:
+                    g.dw_rs[l], g.db_rs[l] = G["w_rs_last"][f].data_ptr(), G["b_rs_last"][f].data_ptr()
+            if dcond is not None:
+                g.dcond = dcond.data_ptr() + 4 * f * Lw * 2 * H
+            acts = buf.acts(f, Lw, rowmask)
+            _lib.check(L.glowtts_flow_backward(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(acts), ctypes.byref(g),
+                                               _lib.stream()), "glowtts_flow_backward")
+        # log-determinant terms of the parameters (Modules.py:694, 747): logdet_b += (sum logs + logdet(W) C/4) * len_b
+        lens = rowmask.view(B, -1).sum(1)
+        s = (dld * lens).sum()
+        G["an_logs"] = d_an[:, :C] + s
+        G["an_bias"] = d_an[:, C:2 * C]
+        winv_t = prep.winfo[:, 16:32].view(F_, 4, 4).transpose(1, 2)
+        G["inv_w"] = d_an[:, 2 * C:].view(F_, 4, 4) + s * (C / 4) * winv_t
+        dmel = unsqueeze_rows(cfg, dx, ctx.lengths, B, Tm) if ctx.want_dmel else None
+        return (None, dmel, None, dcond) + tuple(G[k].view_as(W[k]) for k in WEIGHT_KEYS)
+
+
+def _wn(g, v):
+    """Old-style torch weight_norm (Modules.py:766,818,825): w = g * v / ||v||, norm over (in, k) per output channel."""
+    return g * v / v.flatten(-2).norm(dim=-1).unsqueeze(-1).unsqueeze(-1)
+
+
+def stack_decoder_weights(P, cfg, prefix="layer_Dict.Decoder.layer_Dict.Flows"):
+    """Builds the stacked effective weights from reference-named parameters (name -> tensor).
+    Differentiable torch code on small tensors (weight-norm stays in torch so its autograd is free);
+    returns the tuple in WEIGHT_KEYS order."""
+    F_, L = cfg.F, cfg.L
+    fl = lambda f: f"{prefix}.{f}.layers"
+    wn = lambda f, name: (P[f"{fl(f)}.2.layer_Dict.{name}.weight_g"], P[f"{fl(f)}.2.layer_Dict.{name}.weight_v"],
+                          P[f"{fl(f)}.2.layer_Dict.{name}.bias"])
+    an_logs = torch.stack([P[f"{fl(f)}.0.logs"].reshape(-1) for f in range(F_)])
+    an_bias = torch.stack([P[f"{fl(f)}.0.bias"].reshape(-1) for f in range(F_)])
+    inv_w = torch.stack([P[f"{fl(f)}.1.weight"] for f in range(F_)])
+    st = [wn(f, "Start") for f in range(F_)]
+    w_start = _wn(torch.stack([t[0] for t in st]), torch.stack([t[1] for t in st]))
+    b_start = torch.stack([t[2] for t in st])
+    ins = [[wn(f, f"WaveNet.layer_Dict.In_{l}") for l in range(L)] for f in range(F_)]
+    w_in = _wn(torch.stack([torch.stack([t[0] for t in row]) for row in ins]), torch.stack([torch.stack([t[1] for t in row]) for row in ins]))
+    b_in = torch.stack([torch.stack([t[2] for t in row]) for row in ins])
+    rs = [[wn(f, f"WaveNet.layer_Dict.Res_Skip_{l}") for l in range(L)] for f in range(F_)]
+    if L > 1:
+        w_rs = _wn(torch.stack([torch.stack([t[0] for t in row[:-1]]) for row in rs]), torch.stack([torch.stack([t[1] for t in row[:-1]]) for row in rs]))
+        b_rs = torch.stack([torch.stack([t[2] for t in row[:-1]]) for row in rs])
+    else:
+        dev = w_in.device
+        w_rs, b_rs = torch.zeros(F_, 0, 2 * cfg.H, cfg.H, 1, device=dev), torch.zeros(F_, 0, 2 * cfg.H, device=dev)
+    w_rs_last = _wn(torch.stack([row[-1][0] for row in rs]), torch.stack([row[-1][1] for row in rs]))
+    b_rs_last = torch.stack([row[-1][2] for row in rs])
+    w_end = torch.stack([P[f"{fl(f)}.2.layer_Dict.End.weight"] for f in range(F_)])
+    b_end = torch.stack([P[f"{fl(f)}.2.layer_Dict.End.bias"] for f in range(F_)])
+    return (an_logs, an_bias, inv_w, w_start, b_start, w_in, b_in, w_rs, b_rs, w_rs_last, b_rs_last, w_end, b_end)
+
+
+def stack_cond_weights(P, cfg, kind, prefix="layer_Dict.Decoder.layer_Dict.Flows"):
+    """Speaker_l / Prosody_l conditioning 1x1 convs (Modules.py:832-845) stacked as [F*L, 2H, D] (+ bias [F*L, 2H])."""
+    gs, vs, bs = [], [], []
+    for f in range(cfg.F):
+        for l in range(cfg.L):
+            q = f"{prefix}.{f}.layers.2.layer_Dict.WaveNet.layer_Dict.{kind}_{l}"
+            gs.append(P[q + ".weight_g"]); vs.append(P[q + ".weight_v"]); bs.append(P[q + ".bias"])
+    w = _wn(torch.stack(gs), torch.stack(vs)).squeeze(-1)
+    return w, torch.stack(bs)
+
+
+def conditioning(P, cfg, speakers=None, prosodies=None):
+    """cond[b, f, l, :] = Speaker_l(spk_b) + Prosody_l(pro_b)  (Modules.py:863-866), one batched matmul each."""
+    cond = None
+    for kind, vec in (("Speaker", speakers), ("Prosody", prosodies)):
+        if vec is None:
+            continue
+        w, b = stack_cond_weights(P, cfg, kind)
+        c = torch.einsum("nod,bd->bno", w, vec) + b
+        cond = c if cond is None else cond + c
+    if cond is None:
+        return None
+    return cond.view(cond.shape[0], cfg.F, cfg.L, 2 * cfg.H).contiguous()

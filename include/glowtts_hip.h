@@ -82,6 +82,10 @@ int glowtts_mas_f32(const float *value, int32_t *path, const int32_t *t_xs, cons
 int glowtts_pack_weight(const float *w, int O, int I, int taps, int transpose, int perm, int perm_h,
                         int precision, void *packed, int *npad_out, int *kchunks_out, void *stream);
 
+/* `batch` independent weights of identical shape, w [batch][O][I][taps] -> packed [batch][taps*kchunks*npad*64 bytes] */
+int glowtts_pack_weight_batched(const float *w, int batch, int O, int I, int taps, int transpose, int perm, int perm_h,
+                                int precision, void *packed, int *npad_out, int *kchunks_out, void *stream);
+
 #define GLOWTTS_APRO_NONE    0
 #define GLOWTTS_APRO_PAIRMUL 1  /* a[r][c] = A[r][2c] * A[r][2c+1]   (tanh*sigmoid gates, Modules.py:885-887) */
 
@@ -122,6 +126,141 @@ typedef struct glowtts_conv_args {
 } glowtts_conv_args;
 
 int glowtts_conv_cl(const glowtts_conv_args *args /* host pointer */, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Flow-decoder elementwise / reduction steps ("rows" layout).
+ * rows tensors are fp32 [B][Tp][C], Tp = T + 2*GLOWTTS_ROW_PAD, channels contiguous; the first and last
+ * GLOWTTS_ROW_PAD rows of every utterance are zero so the k=5 taps never cross utterances.
+ * rowmask [B*Tp] is 1 for valid squeezed frames (Modules.py:903), 0 for padding and pad rows.
+ */
+#define GLOWTTS_ROW_PAD 2
+
+/* Squeeze (Modules.py:895-907): mel [B][Cm][Tm] -> rows [B][Tp][ns*Cm], rows[b][PAD+t][s*Cm+c] = mel[b][c][ns*t+s]*mask;
+ * also writes rowmask (may be NULL).  T = Tm / ns (an odd tail frame is dropped like :897-898). lengths: i64 [B]. */
+int glowtts_squeeze_rows(const float *mel, float *rows, float *rowmask, const int64_t *lengths,
+                         int B, int Cm, int Tm, int ns, void *stream);
+/* Unsqueeze (Modules.py:914-924) back to [B][Cm][Tm] (* mask); with use_fill the masked frames are set to `fill`
+ * (GlowTTS.inference masked_fill_, Modules.py:202). */
+int glowtts_unsqueeze_rows(const float *rows, float *mel, const int64_t *lengths,
+                           int B, int Cm, int Tm, int ns, int use_fill, float fill, void *stream);
+/* Per-flow 4x4 inverse and log|det| (torch.inverse / torch.logdet, Modules.py:743,747).
+ * W [F][4][4] -> winfo [F][36] = { W[16], W^-1[16], logdet, sign, 0, 0 }. */
+int glowtts_inv1x1_prepare(const float *W, float *winfo, int F, void *stream);
+/* ActNorm (Modules.py:689-694) + invertible 1x1 conv (Modules.py:738-756) in one pass over the rows.
+ * reverse = 0: xout = W (bias + exp(logs) xin) ; reverse = 1: xout = (W^-1 xin - bias) exp(-logs).  In-place allowed. */
+int glowtts_actnorm_inv1x1(const float *xin, float *xout, const float *logs, const float *bias,
+                           const float *winfo, const float *rowmask, int64_t rows, int C, int reverse, void *stream);
+/* ActNorm data-dependent init statistics (Modules.py:698-703): stats [2C+1] = { sum x*m [C], sum x^2*m [C], sum m }.
+ * Deterministic two-stage reduction; scratch holds glowtts_actnorm_stats_scratch_floats(rows, C) floats.
+ * Under data parallelism the caller all-reduces `stats` before glowtts_actnorm_from_stats. */
+int glowtts_actnorm_stats(const float *x, const float *rowmask, float *stats, float *scratch,
+                          int64_t rows, int C, void *stream);
+int64_t glowtts_actnorm_stats_scratch_floats(int64_t rows, int C);
+/* logs = -0.5 log(max(var, 1e-7)), bias = -mean exp(logs)   (Modules.py:704-711) */
+int glowtts_actnorm_from_stats(const float *stats, float *logs, float *bias, int C, void *stream);
+/* Backward of the affine coupling transform (autograd of Modules.py:805-806).  dz [rows][C] in/out (x_b half becomes
+ * d x_b), xmid = coupling input, outs/douts PAIR-packed (m, logs) [rows][ldo], dlogdet [B] = dL/dlogdet. */
+int glowtts_coupling_bwd(float *dz, const float *xmid, const float *outs, float *douts, const float *rowmask,
+                         const float *dlogdet, int64_t rows, int C, int ldo, int rows_per_utt, void *stream);
+int glowtts_fill_zero(float *p, int64_t n, void *stream);
+/* Backward of inv-1x1 + ActNorm (autograd of Modules.py:693,749-756).  dz -> dx (may alias), x = flow input.
+ * param_grads [2C+16] = { dlogs[C], dbias[C], dW[16] } (data terms only; the log-det terms are added by the caller).
+ * scratch: glowtts_actnorm_stats_scratch_floats(rows, C) floats. */
+int glowtts_actnorm_inv1x1_bwd(const float *dz, float *dx, const float *x, const float *logs, const float *bias,
+                               const float *winfo, const float *rowmask, float *param_grads, float *scratch,
+                               int64_t rows, int C, void *stream);
+/* Decoder log-determinant (Modules.py:309): logdet[b] = sum_f [ (sum logs_f + logdet W_f * C/4) * len_b + sum logs^coupling ].
+ * outs_all: the F kept (m, logs) buffers, flow_stride floats apart; part [F*B] scratch. */
+int glowtts_decoder_logdet(const float *outs_all, int64_t flow_stride, const float *logs_all, const float *winfo_all,
+                           const float *rowmask, float *part, float *logdet, int F, int B, int Tp, int C, int ldo, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight / bias gradient of the channels-last convolution (autograd of the conv call sites above):
+ *     dW[o][c][t] (+)= sum_r DY[r][o] * X[r + t - pad][c]        dbias[o] (+)= sum_r DY[r][o]
+ * DY columns may be PAIR-packed (gate / coupling buffers): perm maps packed column -> o.
+ * dW is written in torch Conv1d layout [O][ca][taps] fp32.  With splits > 1 (or splits = 0: automatic) or
+ * accumulate != 0 the result is ADDED with fp32 atomics: the caller zeroes dW / dbias first.
+ */
+typedef struct glowtts_wgrad_args {
+    const float *dy; int64_t lddy;     /* [rows][lddy], columns [0, m) used */
+    const float *x;  int64_t ldx;      /* [rows][ldx] */
+    int xpro;                          /* GLOWTTS_APRO_NONE / GLOWTTS_APRO_PAIRMUL */
+    const float *xmask;                /* optional [rows] multiplier on X rows */
+    int rows, m, ca, taps, pad;
+    int perm, perm_h;                  /* DY column permutation */
+    int precision;
+    int splits, accumulate;
+    float *dw;                         /* [O][ca][taps] */
+    float *dbias;                      /* [O] or NULL */
+} glowtts_wgrad_args;
+int glowtts_wgrad_cl(const glowtts_wgrad_args *args /* host pointer */, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One flow step of the decoder = Activation_Norm -> Invertible_1x1_Conv -> Affine_Coupling_Layer
+ * (Modules.py:653-668 AIA), launched as one host call: forward (training, keeps the activations the
+ * backward needs), inverse (inference, Modules.py:664 reversed order) and backward.
+ */
+#define GLOWTTS_MAX_WN_LAYERS 8
+
+typedef struct glowtts_packed {           /* result of glowtts_pack_weight */
+    const void *w; int npad, kchunks;
+} glowtts_packed;
+
+typedef struct glowtts_flow_dims {
+    int B, T;          /* utterances, squeezed frames per utterance (rows per utterance = T + 2*GLOWTTS_ROW_PAD) */
+    int C;             /* flow channels = Mel_Dim * Num_Squeeze            (160) */
+    int H;             /* Affine_Coupling.Calc_Channels                     (192) */
+    int L;             /* WaveNet.Num_Layers                                (4)   */
+    int ksize;         /* WaveNet.Kernel_Size                               (5)   */
+    int precision;     /* GLOWTTS_F32 / GLOWTTS_BF16 for the MFMA contractions */
+} glowtts_flow_dims;
+
+typedef struct glowtts_flow_params {
+    const float *an_logs, *an_bias;       /* ActNorm [C]                                   Modules.py:675-680 */
+    const float *winfo;                   /* [36] from glowtts_inv1x1_prepare              Modules.py:725     */
+    glowtts_packed start, in[GLOWTTS_MAX_WN_LAYERS], rs[GLOWTTS_MAX_WN_LAYERS], end;          /* forward images  */
+    glowtts_packed start_t, in_t[GLOWTTS_MAX_WN_LAYERS], rs_t[GLOWTTS_MAX_WN_LAYERS], end_t;  /* transposed (backward only) */
+    const float *b_start, *b_in[GLOWTTS_MAX_WN_LAYERS], *b_rs[GLOWTTS_MAX_WN_LAYERS], *b_end; /* biases, original order */
+    const float *cond; int64_t ldcond;    /* optional conditioning [B][ldcond]; layer l reads cond + l*2H   Modules.py:863-866 */
+} glowtts_flow_params;
+
+typedef struct glowtts_flow_acts {        /* rows tensors, R = B*(T+2*PAD) rows */
+    float *xin;                           /* [R][C] flow input                                   (kept) */
+    float *xmid;                          /* [R][C] after ActNorm + inv-1x1 = coupling input     (kept) */
+    float *xout;                          /* [R][C] flow output                                         */
+    float *hs[GLOWTTS_MAX_WN_LAYERS];     /* [R][H]  WaveNet state entering layer l              (kept) */
+    float *gates[GLOWTTS_MAX_WN_LAYERS];  /* [R][2H] (tanh, sigmoid) interleaved                 (kept) */
+    float *skip;                          /* [R][H]  sum of skip outputs * mask                  (kept) */
+    float *outs;                          /* [R][ldo] PAIR-packed (m, logs), ldo = end.npad      (kept) */
+    const float *rowmask;                 /* [R] */
+} glowtts_flow_acts;
+
+typedef struct glowtts_flow_grads {       /* backward outputs; weight grads are ADDED (zero them first) */
+    float *dx;                            /* [R][C] in: dL/dxout, out: dL/dxin (in place) */
+    const float *dlogdet;                 /* [B] dL/dlogdet */
+    float *douts;                         /* [R][ldo] scratch (pad columns must be zero on entry) */
+    float *dskip;                         /* [R][H] scratch */
+    float *dh[2];                         /* [R][H] scratch x2 */
+    float *dins;                          /* [R][ldin] scratch, ldin = in[0].npad */
+    float *scratch;                       /* glowtts_actnorm_stats_scratch_floats(R, C) floats */
+    float *d_an;                          /* [2C+16] = dlogs, dbias, dW(inv-1x1) data terms (overwritten) */
+    float *dw_start, *db_start;           /* [H][C/2][1], [H] */
+    float *dw_in[GLOWTTS_MAX_WN_LAYERS], *db_in[GLOWTTS_MAX_WN_LAYERS];   /* [2H][H][k], [2H] */
+    float *dw_rs[GLOWTTS_MAX_WN_LAYERS], *db_rs[GLOWTTS_MAX_WN_LAYERS];   /* [2H|H][H][1], [2H|H] */
+    float *dw_end, *db_end;               /* [C][H][1], [C] */
+    float *dcond;                         /* [B][ldcond] or NULL: grad of the conditioning (overwritten per layer slice) */
+} glowtts_flow_grads;
+
+/* training forward: xin -> xout, fills every kept buffer of `acts` */
+int glowtts_flow_forward(const glowtts_flow_dims *d, const glowtts_flow_params *p, const glowtts_flow_acts *a, void *stream);
+/* inference inverse: xout(in) -> xin(out).  Uses hs[0], hs[1], gates[0], skip as scratch; xmid as scratch. */
+int glowtts_flow_inverse(const glowtts_flow_dims *d, const glowtts_flow_params *p, const glowtts_flow_acts *a, void *stream);
+/* backward of glowtts_flow_forward */
+int glowtts_flow_backward(const glowtts_flow_dims *d, const glowtts_flow_params *p, const glowtts_flow_acts *a,
+                          const glowtts_flow_grads *g, void *stream);
+/* per-utterance column sums: out[b][n] = sum over the rows of utterance b of x[r][col(n)]  (conditioning grads) */
+int glowtts_utt_colsum(const float *x, int64_t ldx, float *out, int64_t ldout, int B, int rows_per_utt, int n,
+                       int perm, int perm_h, void *stream);
 
 #ifdef __cplusplus
 }

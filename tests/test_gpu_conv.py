@@ -84,7 +84,7 @@ def test_gate_epilogue_and_pairmul(prec, H, C):
                 ldcond=2 * H, out0=G, ld0=2 * H)
     torch.cuda.synchronize()
     Gc = from_rows(G.cpu(), B, T)                                  # [B, 2H, T] interleaved (tanh, sigmoid)
-    tol = 3e-6 if prec == 0 else 2e-2
+    tol = 1e-5 if prec == 0 else 2e-2
     assert (Gc[:, 0::2] - ta).abs().max() <= tol and (Gc[:, 1::2] - sg).abs().max() <= tol
 
     # Res_Skip consuming the gates through the PAIRMUL prologue

@@ -1,0 +1,159 @@
+"""GPU parity: the HIP flow decoder (through glowtts_flow_forward / _inverse / _backward) vs the oracle
+(oracle/glowtts_ref.py, pinned against the reference) on the golden tiny model and on a full-width model.
+Tolerances: f32 mode (the reference's arithmetic) 1e-4 abs on z / mels (north_star: 1e-3 fp32);
+bf16 mode: 3e-2 on z, 1e-3 relative on the per-utterance log-determinant."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import glowtts_ref as O
+from helpers import load_case, tiny_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def dec_cfg(cfg, precision):
+    from glow_tts_amd.decoder import DecoderConfig
+    return DecoderConfig(cfg.mel_dim, cfg.n_flows, cfg.n_squeeze, cfg.n_split, cfg.wn_channels, cfg.wn_layers, cfg.wn_kernel, precision)
+
+
+def run_hip_decoder(sd, cfg, mels, lengths, precision, requires_grad=False, cond_vectors=None):
+    from glow_tts_amd import decoder as D
+    dc = dec_cfg(cfg, precision)
+    P = {k: v.cuda().requires_grad_(requires_grad and v.is_floating_point()) for k, v in sd.items() if "Decoder" in k}
+    W = D.stack_decoder_weights(P, dc)
+    cond = None
+    if cond_vectors is not None:
+        cond = D.conditioning(P, dc, speakers=cond_vectors.cuda())
+    z, logdet = D.DecoderFunction.apply(dc, mels.cuda(), lengths.cuda(), cond, *W)
+    return z, logdet, P, dc
+
+
+@pytest.mark.parametrize("precision,ztol,ldtol", [(0, 1e-4, 1e-4), (1, 3e-2, 2e-3)])
+def test_tiny_forward_matches_golden(precision, ztol, ldtol):
+    sd, _, r = load_case("tiny_vanilla.npz")
+    cfg = tiny_cfg("Vanilla")
+    mels, ml = torch.from_numpy(r["mels"]), torch.from_numpy(r["mel_lengths"])
+    z, logdet, _, _ = run_hip_decoder(sd, cfg, mels, ml, precision)
+    torch.cuda.synchronize()
+    assert (z.cpu() - torch.from_numpy(r["z"])).abs().max() <= ztol
+    ld = torch.from_numpy(r["log_dets"])
+    assert ((logdet.cpu() - ld).abs() <= ldtol * ld.abs().clamp_min(1.0)).all()
+    # padded frames are exactly zero (Modules.py:924)
+    mask = O.mask_from_lengths(ml, mels.shape[2])
+    assert (z.cpu() * (1 - mask)).abs().max() == 0
+
+
+@pytest.mark.parametrize("precision,tol", [(0, 2e-4), (1, 5e-2)])
+def test_tiny_inverse_matches_oracle_and_roundtrip(precision, tol):
+    from glow_tts_amd import decoder as D
+    sd, _, r = load_case("tiny_vanilla.npz")
+    cfg = tiny_cfg("Vanilla")
+    mels, ml = torch.from_numpy(r["mels"]), torch.from_numpy(r["mel_lengths"])
+    mask = O.mask_from_lengths(ml, mels.shape[2])
+    z = torch.from_numpy(r["z"])
+    want, _, _ = O.decoder(sd, z, mask, cfg, reverse=True)
+    dc = dec_cfg(cfg, precision)
+    P = {k: v.cuda() for k, v in sd.items() if "Decoder" in k}
+    W = dict(zip(D.WEIGHT_KEYS, [w.contiguous() for w in D.stack_decoder_weights(P, dc)]))
+    got = D.decoder_inverse(dc, W, z.cuda(), ml.cuda())
+    torch.cuda.synchronize()
+    assert (got.cpu() - want).abs().max() <= tol
+    assert ((got.cpu() - mels) * mask).abs().max() <= 2 * tol          # flow invertibility: decode(encode(x)) == x
+
+
+def test_tiny_backward_matches_oracle_f32():
+    """Gradients of a scalar loss of (z, logdet) w.r.t. every decoder parameter vs torch.autograd on the oracle."""
+    sd, _, r = load_case("tiny_vanilla.npz")
+    cfg = tiny_cfg("Vanilla")
+    mels, ml = torch.from_numpy(r["mels"]), torch.from_numpy(r["mel_lengths"])
+    g = torch.Generator().manual_seed(3)
+    wz = torch.randn(mels.shape, generator=g)
+    wl = torch.randn(mels.shape[0], generator=g)
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "Decoder" in k) for k, v in sd.items()}
+    mask = O.mask_from_lengths(ml, mels.shape[2])
+    zo, ldo, _ = O.decoder(sdg, mels, mask, cfg)
+    ((zo * wz).sum() + (ldo * wl).sum()).backward()
+    z, logdet, P, _ = run_hip_decoder(sd, cfg, mels, ml, 0, requires_grad=True)
+    ((z * wz.cuda()).sum() + (logdet * wl.cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k, p in P.items():
+        want = sdg[k].grad
+        got = p.grad
+        assert got is not None, k
+        err = (got.cpu() - want).abs().max().item() / (want.abs().max().item() + 1e-4)
+        worst = max(worst, err)
+        assert err < 2e-3, (k, err)
+    print("worst relative grad error", worst)
+
+
+def test_tiny_se_conditioning_forward_backward():
+    sd, _, r = load_case("tiny_se.npz")
+    cfg = tiny_cfg("SE")
+    mels, ml = torch.from_numpy(r["mels"]), torch.from_numpy(r["mel_lengths"])
+    spk = torch.nn.functional.embedding(torch.from_numpy(r["speakers"]), sd["layer_Dict.LUT.weight"])
+    z, logdet, P, _ = run_hip_decoder(sd, cfg, mels, ml, 0, requires_grad=True, cond_vectors=spk)
+    torch.cuda.synchronize()
+    assert (z.detach().cpu() - torch.from_numpy(r["z"])).abs().max() <= 1e-4
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "Decoder" in k) for k, v in sd.items()}
+    mask = O.mask_from_lengths(ml, mels.shape[2])
+    zo, ldo, _ = O.decoder(sdg, mels, mask, cfg, speakers=spk)
+    (zo.pow(2).sum() + ldo.sum()).backward()
+    (z.pow(2).sum() + logdet.sum()).backward()
+    for k, p in P.items():
+        want = sdg[k].grad
+        err = (p.grad.cpu() - want).abs().max().item() / (want.abs().max().item() + 1e-4)
+        assert err < 2e-3, (k, err)
+
+
+def test_actnorm_data_init_matches_reference():
+    """Modules.py:698-711: the fixture keeps the pre-init parameters (zeros) and the post-init ones."""
+    from glow_tts_amd import decoder as D
+    sd, _, r = load_case("tiny_vanilla.npz")
+    cfg = tiny_cfg("Vanilla")
+    dc = dec_cfg(cfg, 0)
+    P = {k: v.cuda() for k, v in sd.items() if "Decoder" in k}
+    for k in P:
+        if k.endswith("layers.0.logs") or k.endswith("layers.0.bias"):
+            P[k] = torch.zeros_like(P[k])
+    W = dict(zip(D.WEIGHT_KEYS, [w.contiguous().clone() for w in D.stack_decoder_weights(P, dc)]))
+    D.actnorm_data_init(dc, W, torch.from_numpy(r["mels"]).cuda(), torch.from_numpy(r["mel_lengths"]).cuda())
+    torch.cuda.synchronize()
+    for f in range(cfg.n_flows):
+        want_l = sd[f"layer_Dict.Decoder.layer_Dict.Flows.{f}.layers.0.logs"].reshape(-1)
+        want_b = sd[f"layer_Dict.Decoder.layer_Dict.Flows.{f}.layers.0.bias"].reshape(-1)
+        assert (W["an_logs"][f].cpu() - want_l).abs().max() < 2e-4, f
+        assert (W["an_bias"][f].cpu() - want_b).abs().max() < 2e-4, f
+
+
+@pytest.mark.parametrize("precision,ztol", [(0, 2e-4), (1, 6e-2)])
+def test_full_width_forward(precision, ztol):
+    """Default Hyper_Parameters sizes (C=160, H=192, 4 layers, k=5), 3 flows, ragged lengths, seeded weights."""
+    cfg = O.Cfg(n_flows=3)
+    g = torch.Generator().manual_seed(99)
+    sd = {}
+    for f in range(cfg.n_flows):
+        q = f"layer_Dict.Decoder.layer_Dict.Flows.{f}.layers"
+        sd[q + ".0.logs"] = torch.randn(1, 160, 1, generator=g) * 0.1
+        sd[q + ".0.bias"] = torch.randn(1, 160, 1, generator=g) * 0.1
+        sd[q + ".1.weight"] = torch.linalg.qr(torch.randn(4, 4, generator=g))[0] + 0.05 * torch.randn(4, 4, generator=g)
+        def wn(name, o, i, k):
+            sd[f"{q}.2.layer_Dict.{name}.weight_v"] = torch.randn(o, i, k, generator=g) / (i * k) ** 0.5
+            sd[f"{q}.2.layer_Dict.{name}.weight_g"] = torch.rand(o, 1, 1, generator=g) + 0.5
+            sd[f"{q}.2.layer_Dict.{name}.bias"] = torch.randn(o, generator=g) * 0.05
+        wn("Start", 192, 80, 1)
+        for l in range(4):
+            wn(f"WaveNet.layer_Dict.In_{l}", 384, 192, 5)
+            wn(f"WaveNet.layer_Dict.Res_Skip_{l}", 384 if l < 3 else 192, 192, 1)
+        sd[f"{q}.2.layer_Dict.End.weight"] = torch.randn(160, 192, 1, generator=g) * 0.02
+        sd[f"{q}.2.layer_Dict.End.bias"] = torch.randn(160, generator=g) * 0.02
+    B, Tm = 3, 300
+    ml = torch.tensor([300, 262, 120])
+    mels = (torch.randn(B, 80, Tm, generator=g) * 1.5).clamp(-4, 4)
+    mask = O.mask_from_lengths(ml, Tm)
+    want_z, want_ld, _ = O.decoder(sd, mels, mask, cfg)
+    z, logdet, _, _ = run_hip_decoder(sd, cfg, mels, ml, precision)
+    torch.cuda.synchronize()
+    assert (z.cpu() - want_z).abs().max() <= ztol
+    assert ((logdet.cpu() - want_ld).abs() <= 2e-3 * want_ld.abs().clamp_min(1.0)).all()
