@@ -1,0 +1,245 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): mel-frames/sec of a Glow-TTS training step (forward incl. log-prior + MAS +
+losses, backward, gradient all-reduce when N > 1) on LJSpeech-shaped synthetic batches, B = 32 utterances per GPU,
+T_tokens = 120, T_mel = 800 (BASELINE config 2: Vanilla, 1xMI355X, bf16), plus MAS us/utterance.
+
+    python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches it through torch.distributed.run (one rank per GPU, RCCL).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FLOP_PER_FRAME_FWD_BWD = 71.3e6      # SURVEY.md 8d / BASELINE.md: 57.05 GFLOP per 800-frame utterance (reference FlopCounterMode)
+
+
+def synthetic_batch(B, Tt, Tm, mel_dim, seed, device, ragged=False):
+    g = torch.Generator().manual_seed(seed)
+    tokens = torch.randint(0, 35, (B, Tt), generator=g)
+    mels = (torch.randn(B, mel_dim, Tm, generator=g) * 1.5).clamp(-4, 4)
+    if ragged:
+        ml = 2 * torch.randint(300, 501, (B,), generator=g).clamp(max=Tm // 2)
+        tl = torch.round(0.15 * ml).long().clamp(max=Tt)
+        ml[0], tl[0] = Tm, Tt
+    else:
+        ml = torch.full((B,), Tm, dtype=torch.long)
+        tl = torch.full((B,), Tt, dtype=torch.long)
+    for b in range(B):
+        tokens[b, tl[b]:] = 1
+        mels[b, :, ml[b]:] = -4.0
+    return tokens.to(device), tl.to(device), mels.to(device), ml.to(device)
+
+
+def build_model(precision, device):
+    import yaml
+    from glow_tts_amd.hparams import Recursive_Parse
+    from glow_tts_amd.modules import GlowTTS, MLE_Loss
+    with open(os.path.join(REPO, "glow_tts_amd", "Hyper_Parameters.default.yaml")) as f:
+        hp = yaml.safe_load(f)
+    hp["Mode"] = "Vanilla"
+    hp["HIP_Precision"] = precision
+    hp = Recursive_Parse(hp)
+    torch.manual_seed(0)
+    model = GlowTTS(hp).to(device).train()
+    # the reference zero-initialises the coupling's End conv (identity flow at step 0); give it small random values
+    # so the benchmarked step does the arithmetic of a model in training, not of the degenerate init
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(1)
+        for n, p in model.named_parameters():
+            if n.endswith("layer_Dict.End.weight"):
+                p.copy_((torch.randn(p.shape, generator=g) * 0.01).to(device))
+    return model, MLE_Loss(hp), hp
+
+
+def train_step(model, mle_loss, batch, reducer=None):
+    tokens, tl, mels, ml = batch
+    z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, _, _ = model(tokens, tl, mels, ml, None, None, None)
+    loss = mle_loss(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=ml) + \
+        torch.nn.functional.mse_loss(log_dur, log_dur_t)                                 # Train.py:203-211
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    if reducer is not None:
+        reducer.reduce(average=True)
+    return loss
+
+
+def dominant_kernel_roofline(precision, B, T, iters=30):
+    """The WaveNet In_i k=5 conv (Modules.py:861), the kernel that carries most of the FLOPs: timed alone with HIP events
+    on the launch stream.  Algorithmic FLOPs per launch = 2 * rows * 384 * 192 * 5."""
+    from glow_tts_amd import ops
+    dev = "cuda"
+    H, k = 192, 5
+    R = B * (T + 4)
+    prec = ops.BF16 if precision == "bf16" else ops.F32
+    a = torch.randn(R, H, device=dev)
+    w = torch.randn(2 * H, H, k, device=dev) / (H * k) ** 0.5
+    pw = ops.pack_weight(w, perm=ops.PERM_PAIR, perm_h=H, precision=prec)
+    bias = torch.zeros(2 * H, device=dev)
+    G = torch.empty(R, 2 * H, device=dev)
+    run = lambda: ops.conv_cl(a, pw, H, R, pad=2, epi=ops.EPI_GATE, h=H, n=2 * H, rows_per_utt=T + 4, bias=bias, out0=G, ld0=2 * H)
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) / 1e3 / iters
+    flops = 2.0 * B * T * (2 * H) * H * k              # valid rows only
+    peak = 2500.0 if precision == "bf16" else 157.3
+    ach = flops / sec / 1e12
+    return {"bound": "mfma", "kernel": "conv_cl_kernel<EPI_GATE> (WaveNet In_i k=5, 192->384)", "achieved": round(ach, 1), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "us_per_launch": round(sec * 1e6, 2), "traffic": None}
+
+
+def mas_us_per_utt(B, Tx, Ty, iters=30):
+    from glow_tts_amd import alignment
+    g = torch.Generator().manual_seed(1234)
+    v = (torch.randn(B, Ty, Tx, generator=g) * 30 - 100).cuda()
+    tx = torch.full((B,), Tx, dtype=torch.long, device="cuda")
+    ty = torch.full((B,), Ty, dtype=torch.long, device="cuda")
+    from glow_tts_amd.monotonic_align import path_from_idx
+    for _ in range(3):
+        path_from_idx(alignment.maximum_path_t(v, tx, ty), Tx)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        path_from_idx(alignment.maximum_path_t(v, tx, ty), Tx)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters / B
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference, oracle/glowtts_ref.py + oracle/mas_ref.c) timed on this host:
+    BASELINE config 1 = Vanilla, B = 8, T_tokens = 120, T_mel = 800, fp32, forward + losses + backward."""
+    from oracle import glowtts_ref as O
+    import yaml
+    from glow_tts_amd.hparams import Recursive_Parse
+    from glow_tts_amd.modules import GlowTTS
+    cores = os.cpu_count() or 1
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or cores
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    with open(os.path.join(REPO, "glow_tts_amd", "Hyper_Parameters.default.yaml")) as f:
+        hpd = yaml.safe_load(f)
+    hpd["Mode"] = "Vanilla"
+    torch.manual_seed(0)
+    model = GlowTTS(Recursive_Parse(hpd))
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    cfg = O.Cfg()
+    B, Tt, Tm = 8, 120, 800
+    tokens, tl, mels, ml = synthetic_batch(B, Tt, Tm, 80, 1234, "cpu")
+    times = []
+    t_start = time.time()
+    while len(times) < 4 and (time.time() - t_start < seconds_budget or len(times) < 2):
+        t0 = time.time()
+        out = O.forward_train(sd, cfg, tokens, tl, mels, ml)
+        mle, length = O.train_losses(out, ml, cfg)
+        for v in sd.values():
+            v.grad = None
+        (mle + length).backward()
+        times.append(time.time() - t0)
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": round(B * Tm / best, 1), "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch fp32 + C MAS), Vanilla B=8 T_mel=800 T_tok=120, fwd+losses+bwd, best of {len(times) - 1} steps after 1 warm-up, {best:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--ragged", action="store_true", help="Set V (ragged lengths) instead of Set F (fixed)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from glow_tts_amd.distributed import FlatGradReducer, actnorm_stats_allreduce
+    model, mle_loss, hp = build_model(args.precision, dev)
+    reducer = None
+    if world > 1:
+        import torch.distributed as dist
+        for p in model.parameters():                       # identical replicas
+            dist.broadcast(p.data, 0)
+        model.actnorm_allreduce = actnorm_stats_allreduce
+        reducer = FlatGradReducer(list(model.parameters()))
+    B, Tt, Tm = args.batch, 120, 800
+    batch = synthetic_batch(B, Tt, Tm, 80, 1234 + rank, dev, ragged=args.ragged)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        train_step(model, mle_loss, batch, reducer)
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        loss = train_step(model, mle_loss, batch, reducer)
+    barrier()
+    elapsed = time.time() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames = int(batch[3].sum().item())
+    if world > 1:
+        import torch.distributed as dist
+        ft = torch.tensor([frames], device=dev, dtype=torch.float64)
+        dist.all_reduce(ft)
+        frames = int(ft.item())
+    if rank == 0:
+        value = frames * args.steps / elapsed
+        out = {
+            "metric": "mel-frames/sec (train fwd+bwd)", "value": round(value, 1), "unit": "mel-frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: Vanilla single-speaker, LJSpeech-shaped synthetic (80-mel, 800 frames, 120 tokens), "
+                                   f"batch={B}/GPU, {'ragged Set V' if args.ragged else 'fixed Set F'}, forward+losses+backward"
+                                   + (", RCCL grad all-reduce" if world > 1 else ""),
+                       "global_batch": B * world, "mel_frames": Tm, "tokens": Tt, "parallelism": f"dp{world}"},
+            "loss": round(float(loss.item()), 4),
+            "model_tflops": round(value * FLOP_PER_FRAME_FWD_BWD / 1e12, 2),
+            "mas_us_per_utt": round(mas_us_per_utt(B, Tt, Tm), 3),
+            "roofline": dominant_kernel_roofline(args.precision, B, Tm // 2),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+"""Alignment block of GlowTTS.forward (Modules.py:107-122) on the HIP path:
+log-prior matrix (batched f32 MFMA GEMM, glowtts_conv_cl) -> Monotonic Alignment Search (glowtts_mas_dp_f32_t)
+-> dense 0/1 attentions (glowtts_mas_path_from_idx).  Nothing leaves the device."""
+import ctypes
+import math
+
+import torch
+
+from . import _lib, ops
+from .decoder import PackedBatch, _L
+
+LOG_2PI = math.log(2.0 * math.pi)
+_decl = False
+
+
+def _lib2():
+    global _decl
+    L = _L()
+    if not _decl:
+        L.glowtts_mas_dp_f32_t.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_void_p]
+        _decl = True
+    return L
+
+
+@torch.no_grad()
+def log_prior_t(mean, log_std, z, token_lengths, mel_lengths):
+    """Modules.py:108-114, transposed: returns value_t [B, T_mel, T_tok] = log N(z_y; mean_x, std_x) * mask.
+    mean/log_std [B, Cm, Tx], z [B, Cm, Ty] (channel-first like the reference).  Always fp32 (MAS ties)."""
+    B, Cm, Tx = mean.shape
+    Ty = z.shape[2]
+    r = torch.exp(-2.0 * log_std)                                            # [B,Cm,Tx]
+    wb = torch.cat([r, mean * r], dim=1).transpose(1, 2).contiguous()         # [B,Tx,2Cm]: (sigma^-2 | mu sigma^-2)
+    cb = (-0.5 * LOG_2PI - log_std - 0.5 * mean * mean * r).sum(1).contiguous()   # [B,Tx]
+    zt = z.transpose(1, 2).contiguous()                                       # [B,Ty,Cm] frames x channels
+    pw = PackedBatch(wb.unsqueeze(-1), False, ops.PERM_NONE, 0, ops.F32)      # per-utterance "weights" [B][Tx][2Cm]
+    out = torch.empty(B, Ty, Tx, device=z.device)
+    fmask = (torch.arange(Ty, device=z.device)[None, :] < mel_lengths[:, None]).to(torch.float32).contiguous()
+    tx = token_lengths.to(torch.int32).contiguous()
+    a = ops.ConvArgs()
+    a.a, a.lda, a.ca1, a.ca, a.apro, a.rows = zt.data_ptr(), Cm, Cm, 2 * Cm, ops.APRO_SQNEG, Ty
+    a.w, a.n, a.npad, a.kchunks, a.taps, a.pad, a.precision = pw.data.data_ptr(), Tx, pw.npad, pw.kchunks, 1, 0, ops.F32
+    a.epi, a.flags = ops.EPI_LINEAR, ops.F_BIAS | ops.F_MASK | ops.F_COLMASK
+    a.bias, a.rowmask, a.out0, a.ld0 = cb.data_ptr(), fmask.data_ptr(), out.data_ptr(), Tx
+    a.batch, a.a_bstride, a.w_bstride, a.bias_bstride, a.out_bstride, a.mask_bstride = B, Ty * Cm, pw.stride, Tx, Ty * Tx, Ty
+    a.ncols_valid = tx.data_ptr()
+    a.rows_per_utt = Ty
+    _lib.check(_lib.lib().glowtts_conv_cl(ctypes.byref(a), _lib.stream()), "glowtts_conv_cl(log_prior)")
+    return out
+
+
+@torch.no_grad()
+def maximum_path_t(value_t, token_lengths, mel_lengths, max_neg_val=-1e9):
+    """value_t [B,Ty,Tx] -> idx [B,Ty] i32 (token aligned to each frame, -1 past the utterance)."""
+    B, Ty, Tx = value_t.shape
+    idx = torch.empty(B, Ty, dtype=torch.int32, device=value_t.device)
+    tx = token_lengths.to(torch.int32).contiguous()
+    ty = mel_lengths.to(torch.int32).contiguous()
+    _lib.check(_lib2().glowtts_mas_dp_f32_t(_lib.ptr(value_t), _lib.ptr(tx), _lib.ptr(ty), _lib.ptr(idx), None, B, Tx, Ty,
+                                            max_neg_val, _lib.stream()), "glowtts_mas_dp_f32_t")
+    return idx
+
+
+@torch.no_grad()
+def align(mean, log_std, z, token_lengths, mel_lengths):
+    """-> (attentions [B,Tx,Ty] float 0/1, idx [B,Ty] i32, value_t)."""
+    from .monotonic_align import path_from_idx
+    value_t = log_prior_t(mean, log_std, z, token_lengths, mel_lengths)
+    idx = maximum_path_t(value_t, token_lengths, mel_lengths)
+    return path_from_idx(idx, mean.shape[2], torch.float32), idx, value_t

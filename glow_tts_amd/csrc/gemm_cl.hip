@@ -103,8 +103,17 @@ template <> struct Prec<__bf16> { static constexpr int KC = 32; static constexpr
 constexpr int MAX_TAPS = 5;
 
 template <typename CT, int MI, int NI, int WM, int WN, int EPI>
-__global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_conv_args p)
+__global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_conv_args pin)
 {
+    glowtts_conv_args p = pin;
+    if (p.batch > 1) {                      // batched problems: shift every base pointer
+        const long bz = blockIdx.z;
+        p.a += bz * p.a_bstride;
+        p.w = reinterpret_cast<const unsigned char*>(p.w) + bz * p.w_bstride;
+        if (p.bias) p.bias += bz * p.bias_bstride;
+        if (p.rowmask) p.rowmask += bz * p.mask_bstride;
+        p.out0 += bz * p.out_bstride;
+    }
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32, NT = WM * WN * 64;
     constexpr int AROWS = BM + MAX_TAPS - 1;
     constexpr int KC = Prec<CT>::KC, E = Prec<CT>::E;          // channels per 64-B chunk / per 16-B slot
@@ -160,6 +169,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
                         }
                     } else {
                         for (int e = 0; e < E && c + e < p.ca; ++e) f[e] = src[2 * e] * src[2 * e + 1];
+                    }
+                } else if (p.apro == GLOWTTS_APRO_SQNEG) {
+                    const bool sq = c < p.ca1;                      // ca1 is a multiple of E on this path
+                    const float* src = p.a + g * p.lda + (sq ? c : c - p.ca1);
+#pragma unroll
+                    for (int e = 0; e < E; e += 4) {
+                        const float4 v = *reinterpret_cast<const float4*>(src + e);
+                        f[e] = sq ? -0.5f * v.x * v.x : v.x; f[e + 1] = sq ? -0.5f * v.y * v.y : v.y;
+                        f[e + 2] = sq ? -0.5f * v.z * v.z : v.z; f[e + 3] = sq ? -0.5f * v.w * v.w : v.w;
                     }
                 } else {
                     const float* src;
@@ -282,6 +300,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
                     if (fl & GLOWTTS_F_RELU) v = fmaxf(v, 0.f);
                     if (fl & GLOWTTS_F_ADD_IN0) v += p.in0[(long)r * p.ldi0 + n];
                     if (fl & GLOWTTS_F_MASK) v *= mask;
+                    if ((fl & GLOWTTS_F_COLMASK) && n >= p.ncols_valid[blockIdx.z]) v = 0.f;
                     float* o = p.out0 + (long)r * p.ld0 + n;
                     if (fl & GLOWTTS_F_ACCUM) v += *o;
                     *o = v;
@@ -356,7 +375,7 @@ template <typename CT, int MI, int NI, int WM, int WN, int EPI>
 int launch_cfg(const glowtts_conv_args& a, hipStream_t s)
 {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
-    dim3 grid((a.rows + BM - 1) / BM, (a.npad + BN - 1) / BN);
+    dim3 grid((a.rows + BM - 1) / BM, (a.npad + BN - 1) / BN, a.batch > 1 ? a.batch : 1);
     hipLaunchKernelGGL((conv_cl_kernel<CT, MI, NI, WM, WN, EPI>), grid, dim3(WM * WN * 64), 0, s, a);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
@@ -365,7 +384,7 @@ template <typename CT, int EPI>
 int launch_epi(const glowtts_conv_args& a, hipStream_t s)
 {
     // tile choice: 128x128 by default; 64-row tiles when that is needed to put >= ~256 workgroups on the chip
-    const long tiles128 = (long)((a.rows + 127) / 128) * ((a.npad + 127) / 128);
+    const long tiles128 = (long)((a.rows + 127) / 128) * ((a.npad + 127) / 128) * (a.batch > 1 ? a.batch : 1);
     if (tiles128 >= 256) return launch_cfg<CT, 2, 2, 2, 2, EPI>(a, s);
     return launch_cfg<CT, 1, 2, 2, 2, EPI>(a, s);
 }
@@ -423,7 +442,9 @@ extern "C" int glowtts_conv_cl(const glowtts_conv_args* args, void* stream)
     if ((args->lda & 3) || (reinterpret_cast<uintptr_t>(args->a) & 15)) return GLOWTTS_E_ARG;
     if (args->a2 && ((args->lda2 & 3) || (reinterpret_cast<uintptr_t>(args->a2) & 15))) return GLOWTTS_E_ARG;
     glowtts_conv_args a = *args;
-    if (!a.a2) a.ca1 = a.ca;
+    if (!a.a2 && a.apro != GLOWTTS_APRO_SQNEG) a.ca1 = a.ca;
+    if (a.apro == GLOWTTS_APRO_SQNEG && ((a.ca1 % (a.precision == GLOWTTS_BF16 ? 8 : 4)) || a.ca != 2 * a.ca1)) return GLOWTTS_E_ARG;
+    if ((a.flags & GLOWTTS_F_COLMASK) && !a.ncols_valid) return GLOWTTS_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.precision == GLOWTTS_BF16) return launch_prec<__bf16>(a, s);
     if (a.precision == GLOWTTS_F32) return launch_prec<float>(a, s);

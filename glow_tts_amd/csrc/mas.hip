@@ -37,7 +37,7 @@ __device__ __forceinline__ void push_lt_bit(unsigned int& bits, float a, float b
     asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(a), "v"(b) : "vcc");
 }
 
-template <int R, bool VEC4, bool WRITEQ>
+template <int R, bool VEC4, bool WRITEQ, bool TR>
 __global__ __launch_bounds__(64) void mas_dp_kernel(const float* __restrict__ value,
                                                     const int32_t* __restrict__ t_xs,
                                                     const int32_t* __restrict__ t_ys,
@@ -66,10 +66,28 @@ __global__ __launch_bounds__(64) void mas_dp_kernel(const float* __restrict__ va
     }
 
     // one chunk = 4 columns x R rows (16 B per row per lane)
+    // TR: value is stored transposed, [Ty][Tx] (token index contiguous): one column is one coalesced row
+    const int xt = min(lane * R, Tx - R > 0 ? Tx - R : 0);      // first token row of this lane, clamped (TR + VEC4 path)
     auto load_chunk = [&](float4 (&dst)[R], int chunk) {
         // unconditional loads with clamped addresses: a predicated load would need a select after it,
         // i.e. an s_waitcnt right behind the load, which destroys the look-ahead.  Columns >= Ty hold
         // garbage that no cell inside an utterance ever reads.
+        if (TR) {
+            float v[4][R];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float* col = vb + (size_t)min(chunk * 4 + e, Ty - 1) * Tx;
+                if (VEC4 && R == 2) { const float2 t = *reinterpret_cast<const float2*>(col + xt); v[e][0] = t.x; v[e][R - 1] = t.y; }
+                else if (VEC4 && R == 4) { const float4 t = *reinterpret_cast<const float4*>(col + xt); v[e][0] = t.x; v[e][1 % R] = t.y; v[e][2 % R] = t.z; v[e][3 % R] = t.w; }
+                else {
+#pragma unroll
+                    for (int j = 0; j < R; ++j) v[e][j] = col[min(lane * R + j, Tx - 1)];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < R; ++j) dst[j] = make_float4(v[0][j], v[1][j], v[2][j], v[3][j]);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             if (VEC4) {
@@ -109,7 +127,7 @@ __global__ __launch_bounds__(64) void mas_dp_kernel(const float* __restrict__ va
                 q[j] = m + val;                                                   // core.pyx:30
                 if (WRITEQ) {
                     const bool inb = (y < ty) && (x >= max(0, tx + y - ty)) && (x < min(tx, y + 1));   // core.pyx:18
-                    if (inb) qb[(size_t)x * Ty + y] = q[j];
+                    if (inb) qb[TR ? (size_t)y * Tx + x : (size_t)x * Ty + y] = q[j];
                 }
             }
         }
@@ -195,18 +213,42 @@ __global__ __launch_bounds__(256) void mas_path_kernel(const int32_t* __restrict
 
 template <int R>
 int launch_dp(const float* value, const int32_t* t_xs, const int32_t* t_ys, int32_t* idx_out, float* q_out,
-              int B, int Tx, int Ty, float neg, hipStream_t s)
+              int B, int Tx, int Ty, float neg, bool transposed, hipStream_t s)
 {
     const size_t lds = (size_t)((Ty + 63) / 64) * 2 * R * 64 * sizeof(unsigned int);
     if (lds > 160 * 1024) return GLOWTTS_E_ARG;
-    const bool vec = (Ty % 4 == 0) && ((reinterpret_cast<uintptr_t>(value) & 15) == 0);
+    const bool al = (reinterpret_cast<uintptr_t>(value) & 15) == 0;
     void (*k)(const float*, const int32_t*, const int32_t*, int32_t*, float*, int, int, float);
-    if (q_out) k = vec ? mas_dp_kernel<R, true, true> : mas_dp_kernel<R, false, true>;
-    else       k = vec ? mas_dp_kernel<R, true, false> : mas_dp_kernel<R, false, false>;
+    if (transposed) {
+        const bool vec = al && (R == 2 || R == 4) && (Tx % R == 0) && (((size_t)Tx * sizeof(float)) % (R * sizeof(float)) == 0) && Tx >= R;
+        if (q_out) k = vec ? mas_dp_kernel<R, true, true, true> : mas_dp_kernel<R, false, true, true>;
+        else       k = vec ? mas_dp_kernel<R, true, false, true> : mas_dp_kernel<R, false, false, true>;
+    } else {
+        const bool vec = al && (Ty % 4 == 0);
+        if (q_out) k = vec ? mas_dp_kernel<R, true, true, false> : mas_dp_kernel<R, false, true, false>;
+        else       k = vec ? mas_dp_kernel<R, true, false, false> : mas_dp_kernel<R, false, false, false>;
+    }
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(B), dim3(64), lds, s, value, t_xs, t_ys, idx_out, q_out, Tx, Ty, neg);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
+int dispatch_dp(const float* value, const int32_t* t_xs, const int32_t* t_ys, int32_t* idx_out, float* q_out,
+                int B, int Tx, int Ty, float neg, bool tr, void* stream)
+{
+    if (!value || !t_xs || !t_ys || B < 0 || Tx < 1 || Ty < 1 || Tx > 512) return GLOWTTS_E_ARG;
+    if (B == 0) return GLOWTTS_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int R = (Tx + 63) / 64;
+    switch (R) {
+        case 1: return launch_dp<1>(value, t_xs, t_ys, idx_out, q_out, B, Tx, Ty, neg, tr, s);
+        case 2: return launch_dp<2>(value, t_xs, t_ys, idx_out, q_out, B, Tx, Ty, neg, tr, s);
+        case 3: return launch_dp<3>(value, t_xs, t_ys, idx_out, q_out, B, Tx, Ty, neg, tr, s);
+        case 4: return launch_dp<4>(value, t_xs, t_ys, idx_out, q_out, B, Tx, Ty, neg, tr, s);
+        case 5: case 6: return launch_dp<6>(value, t_xs, t_ys, idx_out, q_out, B, Tx, Ty, neg, tr, s);
+        default: return launch_dp<8>(value, t_xs, t_ys, idx_out, q_out, B, Tx, Ty, neg, tr, s);
+    }
 }
 
 }  // namespace
@@ -215,18 +257,14 @@ extern "C" int glowtts_mas_dp_f32(const float* value, const int32_t* t_xs, const
                                   int32_t* idx_out, float* q_out, int B, int Tx, int Ty,
                                   float max_neg_val, void* stream)
 {
-    if (!value || !t_xs || !t_ys || B < 0 || Tx < 1 || Ty < 1 || Tx > 512) return GLOWTTS_E_ARG;
-    if (B == 0) return GLOWTTS_OK;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int R = (Tx + 63) / 64;
-    switch (R) {
-        case 1: return launch_dp<1>(value, t_xs, t_ys, idx_out, q_out, B, Tx, Ty, max_neg_val, s);
-        case 2: return launch_dp<2>(value, t_xs, t_ys, idx_out, q_out, B, Tx, Ty, max_neg_val, s);
-        case 3: return launch_dp<3>(value, t_xs, t_ys, idx_out, q_out, B, Tx, Ty, max_neg_val, s);
-        case 4: return launch_dp<4>(value, t_xs, t_ys, idx_out, q_out, B, Tx, Ty, max_neg_val, s);
-        case 5: case 6: return launch_dp<6>(value, t_xs, t_ys, idx_out, q_out, B, Tx, Ty, max_neg_val, s);
-        default: return launch_dp<8>(value, t_xs, t_ys, idx_out, q_out, B, Tx, Ty, max_neg_val, s);
-    }
+    return dispatch_dp(value, t_xs, t_ys, idx_out, q_out, B, Tx, Ty, max_neg_val, false, stream);
+}
+
+extern "C" int glowtts_mas_dp_f32_t(const float* value_t, const int32_t* t_xs, const int32_t* t_ys,
+                                    int32_t* idx_out, float* q_out_t, int B, int Tx, int Ty,
+                                    float max_neg_val, void* stream)
+{
+    return dispatch_dp(value_t, t_xs, t_ys, idx_out, q_out_t, B, Tx, Ty, max_neg_val, true, stream);
 }
 
 extern "C" int glowtts_mas_path_from_idx(const int32_t* idx, void* path, int B, int Tx, int Ty,

@@ -1,0 +1,306 @@
+"""Host-side mirror of the reference's `Modules.py` for the hot path: `GlowTTS` (forward = training graph,
+inference = inverse flow) and `MLE_Loss`, with the reference's constructor convention (no arguments, hyper
+parameters from ./Hyper_Parameters.yaml), call signatures, return tuples, attribute paths and state-dict keys
+(Modules.py:16-229, 1020-1029), so checkpoints and yaml files drop in unchanged.  All arithmetic runs in the
+HIP library (glow_tts_amd/csrc) or, for the parts still marked interim in DESIGN.md, in PyTorch-ROCm device ops.
+"""
+import math
+
+import torch
+
+from . import alignment, decoder, encoder, ops
+from .hparams import get_hp
+
+
+class _Dict(torch.nn.Module):
+    """A module that only owns a `layer_Dict` (the reference's universal container)."""
+
+    def __init__(self):
+        super().__init__()
+        self.layer_Dict = torch.nn.ModuleDict()
+
+
+class _Params(torch.nn.Module):
+    """Leaf holding named parameters (weight / bias / weight_g / weight_v / ...)."""
+
+    def __init__(self, **tensors):
+        super().__init__()
+        for k, v in tensors.items():
+            self.register_parameter(k, torch.nn.Parameter(v))
+
+
+def _xavier(shape, gain=1.0):
+    w = torch.empty(shape)
+    torch.nn.init.xavier_uniform_(w, gain=gain)
+    return w
+
+
+def _conv_params(o, i, k, gains="linear", bias=True, weight_norm=False, default_init=False):
+    """Parameter leaf of a Conv1d.  `gains`: the reference's w_init_gain (Modules.py:983-1003): one gain or a list
+    applied to equal chunks of the output channels; 'zero' -> zeros; default_init -> torch.nn.Conv1d's own init."""
+    if default_init:
+        c = torch.nn.Conv1d(i, o, k)
+        w, b = c.weight.detach().clone(), c.bias.detach().clone()
+    else:
+        gl = [gains] if isinstance(gains, str) else list(gains)
+        parts = []
+        for g in gl:
+            shape = (o // len(gl), i, k)
+            if g == "zero":
+                parts.append(torch.zeros(shape))
+            elif g in ("relu", "leaky_relu"):
+                w_ = torch.empty(shape)
+                torch.nn.init.kaiming_uniform_(w_, nonlinearity=g)
+                parts.append(w_)
+            else:
+                parts.append(_xavier(shape, torch.nn.init.calculate_gain(g)))
+        w, b = torch.cat(parts, 0), torch.zeros(o)
+    t = {}
+    if bias:
+        t["bias"] = b
+    if weight_norm:                       # old-style torch weight_norm: g = ||v|| at init (Modules.py:766)
+        t["weight_g"] = w.flatten(1).norm(dim=1).view(-1, 1, 1)
+        t["weight_v"] = w
+    else:
+        t["weight"] = w
+    return _Params(**t)
+
+
+class _ActNorm(_Params):
+    """Activation_Norm parameters + the reference's plain-attribute init flag (Modules.py:673)."""
+
+    def __init__(self, C):
+        super().__init__(logs=torch.zeros(1, C, 1), bias=torch.zeros(1, C, 1))
+        self.initialized = False
+
+
+class _Flow(torch.nn.Module):
+    """AIA (Modules.py:653-660): layers = [Activation_Norm, Invertible_1x1_Conv, Affine_Coupling_Layer]."""
+
+    def __init__(self, hp):
+        super().__init__()
+        C = hp.Sound.Mel_Dim * hp.Decoder.Num_Squeeze
+        H = hp.Decoder.Affine_Coupling.Calc_Channels
+        wn = hp.Decoder.Affine_Coupling.WaveNet
+        ns = hp.Decoder.Num_Split
+        w = torch.linalg.qr(torch.randn(ns, ns))[0]                     # Modules.py:718-725
+        if torch.det(w) < 0:
+            w[:, 0] = -w[:, 0]
+        coupling = _Dict()
+        coupling.layer_Dict["Start"] = _conv_params(H, C // 2, 1, "linear", weight_norm=True)
+        wavenet = _Dict()
+        mode = hp.Mode.upper()
+        for l in range(wn.Num_Layers):
+            wavenet.layer_Dict[f"In_{l}"] = _conv_params(2 * H, H, wn.Kernel_Size, ["tanh", "sigmoid"], weight_norm=True)
+            wavenet.layer_Dict[f"Res_Skip_{l}"] = _conv_params(2 * H if l < wn.Num_Layers - 1 else H, H, 1, "linear", weight_norm=True)
+            if mode in ("SE", "GR"):
+                wavenet.layer_Dict[f"Speaker_{l}"] = _conv_params(2 * H, hp.Speaker_Embedding.Embedding_Size, 1, ["tanh", "sigmoid"], weight_norm=True)
+            if mode in ("PE", "GR"):
+                wavenet.layer_Dict[f"Prosody_{l}"] = _conv_params(2 * H, hp.Prosody_Encoder.Size, 1, ["tanh", "sigmoid"], weight_norm=True)
+            if mode == "GR":
+                wavenet.layer_Dict[f"Pitch_{l}"] = _conv_params(2 * H, hp.Decoder.Num_Squeeze, 1, ["tanh", "sigmoid"], weight_norm=True)
+        coupling.layer_Dict["WaveNet"] = wavenet
+        coupling.layer_Dict["End"] = _conv_params(C, H, 1, "zero")      # zero-init: identity coupling (Modules.py:773-778)
+        self.layers = torch.nn.ModuleList([_ActNorm(C), _Params(weight=w), coupling])
+
+
+def _build_encoder(hp):
+    e = hp.Encoder
+    C = e.Channels
+    enc = _Dict()
+    enc.layer_Dict["Embedding"] = _Params(weight=torch.randn(e.Embedding_Tokens, C) * C ** -0.5)      # Modules.py:246-250
+    pre = _Dict()
+    for i in range(e.Prenet.Stacks):
+        clrd = _Dict()
+        clrd.layer_Dict["Conv"] = _conv_params(C, C, e.Prenet.Kernel_Size, default_init=True)
+        clrd.layer_Dict["LayerNorm"] = _Params(weight=torch.ones(C), bias=torch.zeros(C))
+        pre.layer_Dict[f"CLRD_{i}"] = clrd
+    pre.layer_Dict["Conv1x1"] = _conv_params(C, C, 1, default_init=True)
+    enc.layer_Dict["Prenet"] = pre
+    tr = _Dict()
+    heads = e.Transformer.Attention.Heads
+    D = C // heads
+    win = e.Transformer.Attention.Window_Size
+    for i in range(e.Transformer.Stacks):
+        blk = _Dict()
+        att = _Params(weight_K=torch.randn(1, 2 * win + 1, D) * D ** -0.5, weight_V=torch.randn(1, 2 * win + 1, D) * D ** -0.5)
+        att.layer_Dict = torch.nn.ModuleDict()
+        for name in ("Query", "Key", "Value"):                           # xavier on Q/K/V only (RPR_MHA.py:45-47)
+            pp = _conv_params(C, C, 1, default_init=True)
+            torch.nn.init.xavier_uniform_(pp.weight)
+            att.layer_Dict[name] = pp
+        att.layer_Dict["Projection"] = _conv_params(C, C, 1, default_init=True)
+        blk.layer_Dict["Attention"] = att
+        blk.layer_Dict["LayerNorm_0"] = _Params(weight=torch.ones(C), bias=torch.zeros(C))
+        blk.layer_Dict["Conv_0"] = _conv_params(e.Transformer.Conv.Calc_Channels, C, e.Transformer.Conv.Kernel_Size, default_init=True)
+        blk.layer_Dict["Conv_1"] = _conv_params(C, e.Transformer.Conv.Calc_Channels, e.Transformer.Conv.Kernel_Size, default_init=True)
+        blk.layer_Dict["LayerNorm_1"] = _Params(weight=torch.ones(C), bias=torch.zeros(C))
+        tr.layer_Dict[f"ANCRDCN_{i}"] = blk
+    enc.layer_Dict["Transformer"] = tr
+    enc.layer_Dict["Project"] = _conv_params(hp.Sound.Mel_Dim * 2, C, 1, default_init=True)
+    dp = _Dict()
+    cin = C
+    mode = hp.Mode.upper()
+    if mode in ("SE", "GR"):
+        cin += hp.Speaker_Embedding.Embedding_Size                          # Modules.py:583-590
+    elif mode == "PE":
+        cin += hp.Prosody_Encoder.Size
+    for i in range(e.Duration_Predictor.Stacks):
+        crnd = _Dict()
+        crnd.layer_Dict["Conv"] = _conv_params(e.Duration_Predictor.Channels, cin, e.Duration_Predictor.Kernel_Size, default_init=True)
+        dp.layer_Dict[f"CRND_{i}"] = crnd
+        cin = e.Duration_Predictor.Channels
+    dp.layer_Dict["Projection"] = _conv_params(1, cin, 1, default_init=True)
+    enc.layer_Dict["Duration_Predictor"] = dp
+    return enc
+
+
+class GlowTTS(torch.nn.Module):
+    """Drop-in for Modules.GlowTTS (Modules.py:16-229)."""
+
+    def __init__(self, hp=None):
+        super().__init__()
+        self.hp = hp = hp if hp is not None else get_hp()
+        mode = hp.Mode.upper()
+        if mode not in ("VANILLA", "SE", "PE", "GR"):
+            raise ValueError("Unsupported mode: {}".format(hp.Mode))
+        self.layer_Dict = torch.nn.ModuleDict()
+        if mode in ("SE", "GR"):
+            if hp.Speaker_Embedding.Type.upper() == "LUT":
+                self.layer_Dict["LUT"] = _Params(weight=torch.empty(hp.Speaker_Embedding.Num_Speakers,
+                                                                    hp.Speaker_Embedding.Embedding_Size).uniform_(-1.0, 1.0))
+            elif hp.Speaker_Embedding.Type.upper() == "GE2E":
+                pass   # GE2E source is an un-vendored submodule of the reference: d-vectors are an input
+            else:
+                raise ValueError("Unsupported Speaker embedding type: {}".format(hp.Speaker_Embedding.Type))
+        if mode in ("PE", "GR"):
+            from .prosody import Prosody_Encoder
+            self.layer_Dict["Prosody_Encoder"] = Prosody_Encoder(hp)
+        self.layer_Dict["Encoder"] = _build_encoder(hp)
+        dec = _Dict()
+        dec.layer_Dict["Flows"] = torch.nn.ModuleList([_Flow(hp) for _ in range(hp.Decoder.Stack)])
+        self.layer_Dict["Decoder"] = dec
+        wn = hp.Decoder.Affine_Coupling.WaveNet
+        prec = {"bf16": ops.BF16, "f32": ops.F32}[str(getattr(hp, "HIP_Precision", "bf16")).lower()]
+        self.dec_cfg = decoder.DecoderConfig(hp.Sound.Mel_Dim, hp.Decoder.Stack, hp.Decoder.Num_Squeeze, hp.Decoder.Num_Split,
+                                             hp.Decoder.Affine_Coupling.Calc_Channels, wn.Num_Layers, wn.Kernel_Size, prec)
+        self.actnorm_allreduce = None     # set by the data-parallel wrapper (glow_tts_amd.distributed)
+
+    # ---------------------------------------------------------------- helpers
+    def _params(self):
+        return dict(self.named_parameters())
+
+    def _flows(self):
+        return self.layer_Dict["Decoder"].layer_Dict["Flows"]
+
+    def set_precision(self, name):
+        self.dec_cfg.precision = {"bf16": ops.BF16, "f32": ops.F32}[name]
+
+    def Mask_Generate(self, lengths, max_lengths=None, dtype=torch.float):
+        """Modules.py:206-211 (max_lengths avoids the hidden device->host sync of torch.max)."""
+        T = int(max_lengths) if max_lengths is not None else int(torch.max(lengths))
+        return (torch.arange(T, device=lengths.device)[None, :] < lengths[:, None]).unsqueeze(1).to(dtype)
+
+    def _conditioning(self, P, speakers, mels_for_ge2e, prosody_mels, prosody_lengths):
+        mode = self.hp.Mode.upper()
+        spk = pro = None
+        if "LUT" in self.layer_Dict:
+            spk = torch.nn.functional.embedding(speakers, P["layer_Dict.LUT.weight"])                   # Modules.py:73-74
+        elif mode in ("SE", "GR"):
+            # GE2E mode: the pre-computed, L2-normalised d-vectors arrive in `mels_for_ge2e` ([B, Embedding_Size])
+            spk = mels_for_ge2e.detach()                                                                  # Modules.py:75-77
+        if "Prosody_Encoder" in self.layer_Dict:
+            pro = self.layer_Dict["Prosody_Encoder"](prosody_mels, prosody_lengths)                       # Modules.py:81-82
+        return spk, pro
+
+    def _maybe_init_actnorm(self, P, mels, mel_lengths, cond):
+        """ActNorm data-dependent init on the first call (Modules.py:685-687), flag kept per flow like the reference."""
+        flows = self._flows()
+        if all(f.layers[0].initialized for f in flows):
+            return
+        W = dict(zip(decoder.WEIGHT_KEYS, [w.detach().contiguous().clone() for w in decoder.stack_decoder_weights(P, self.dec_cfg)]))
+        decoder.actnorm_data_init(self.dec_cfg, W, mels, mel_lengths, cond=None if cond is None else cond.detach(),
+                                  allreduce=self.actnorm_allreduce)
+        with torch.no_grad():
+            for i, f in enumerate(flows):
+                if not f.layers[0].initialized:
+                    f.layers[0].logs.copy_(W["an_logs"][i].view(1, -1, 1))
+                    f.layers[0].bias.copy_(W["an_bias"][i].view(1, -1, 1))
+                    f.layers[0].initialized = True
+
+    # ---------------------------------------------------------------- training graph
+    def forward(self, tokens, token_lengths, mels, mel_lengths, speakers=None, mels_for_ge2e=None, pitches=None):
+        """Modules.py:50-126.  Returns the reference's 8-tuple."""
+        hp = self.hp
+        assert bool(torch.all(mel_lengths % hp.Decoder.Num_Squeeze == 0)), "Mel lengths must be diviable by Num_Squeeze."
+        if not mels.is_cuda:
+            raise RuntimeError("glow_tts_amd runs on the GPU only (no CPU fallback)")
+        P = self._params()
+        spk, pro = self._conditioning(P, speakers, mels_for_ge2e, mels, mel_lengths)
+        token_mask = self.Mask_Generate(token_lengths, tokens.shape[1])
+        mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, self.training)
+        cond = decoder.conditioning(P, self.dec_cfg, spk, pro)
+        self._maybe_init_actnorm(P, mels, mel_lengths, cond)
+        W = decoder.stack_decoder_weights(P, self.dec_cfg)
+        z, log_dets = decoder.DecoderFunction.apply(self.dec_cfg, mels, mel_lengths, cond, *W)
+        ns = hp.Decoder.Num_Squeeze
+        z_len = (mel_lengths // ns) * ns
+        attn, idx, _ = alignment.align(mean.detach(), log_std.detach(), z.detach(), token_lengths, z_len)   # Modules.py:107-116
+        if z.shape[2] != attn.shape[2]:
+            attn = attn[:, :, :z.shape[2]]
+        mel_mean = mean @ attn                                                                       # Modules.py:120
+        mel_log_std = log_std @ attn                                                                 # Modules.py:121
+        log_dur_targets = torch.log(attn.unsqueeze(1).sum(-1) + 1e-7) * token_mask                   # Modules.py:122
+        classified = None
+        return z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_targets, attn, classified
+
+    # ---------------------------------------------------------------- inverse flow
+    @torch.no_grad()
+    def inference(self, tokens, token_lengths, mels_for_prosody=None, mel_lengths_for_prosody=None, speakers=None,
+                  mels_for_ge2e=None, pitches=None, pitch_lengths=None, noise_scale=1.0, length_scale=1.0, noises=None):
+        """Modules.py:128-204.  `noises` (optional, [B, Mel_Dim, >= max T_mel]) injects the Gaussian noise the reference
+        draws with torch.randn_like (:187) so that results are reproducible."""
+        hp = self.hp
+        P = self._params()
+        spk, pro = self._conditioning(P, speakers, mels_for_ge2e, mels_for_prosody, mel_lengths_for_prosody)
+        token_mask = self.Mask_Generate(token_lengths, tokens.shape[1])
+        mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, False)
+        if not torch.is_tensor(length_scale):
+            length_scale = torch.tensor([float(length_scale)], device=tokens.device)
+        ls = length_scale.to(tokens.device).unsqueeze(-1).unsqueeze(-1)                                   # Modules.py:169
+        dur = torch.ceil(torch.exp(log_dur) * token_mask * ls).squeeze(1)                                 # :173
+        mel_lengths = torch.clamp_min(dur.sum(1), 1.0).long()                                             # :174
+        mel_mask = self.Mask_Generate(mel_lengths)
+        amask = (token_mask.unsqueeze(-1) * mel_mask.unsqueeze(2)).squeeze(1)
+        attn = self.Path_Generate(dur, amask)                                                             # :181
+        mel_mean = mean @ attn
+        mel_log_std = log_std @ attn
+        if noises is None:
+            noises = torch.randn_like(mel_mean)
+        z = (mel_mean + torch.exp(mel_log_std) * noises[:, :, :mel_mean.shape[2]] * noise_scale) * mel_mask   # :187-191
+        cond = decoder.conditioning(P, self.dec_cfg, spk, pro)
+        W = dict(zip(decoder.WEIGHT_KEYS, [w.contiguous() for w in decoder.stack_decoder_weights(P, self.dec_cfg)]))
+        mels = decoder.decoder_inverse(self.dec_cfg, W, z.contiguous(), mel_lengths, cond=cond, fill=-float(hp.Sound.Max_Abs_Mel))   # :198-202
+        return mels, mel_lengths, attn
+
+    def Path_Generate(self, durations, masks):
+        """Modules.py:213-229."""
+        B, Tx, Ty = masks.shape
+        cum = torch.cumsum(durations, dim=1)
+        upto = (torch.arange(Ty, device=masks.device)[None, None, :] < cum[:, :, None]).to(masks.dtype)
+        prev = torch.nn.functional.pad(upto, [0, 0, 1, 0])[:, :-1]
+        return (upto - prev) * masks
+
+
+class MLE_Loss(torch.nn.modules.loss._Loss):
+    """Modules.py:1020-1029."""
+
+    def __init__(self, hp=None):
+        super().__init__()
+        self.hp = hp if hp is not None else get_hp()
+
+    def forward(self, z, mean, std, log_dets, lengths):
+        hp = self.hp
+        loss = torch.sum(std) + 0.5 * torch.sum(torch.exp(-2 * std) * (z - mean) ** 2) - torch.sum(log_dets)
+        loss = loss / (torch.sum(lengths // hp.Decoder.Num_Squeeze) * hp.Decoder.Num_Squeeze * hp.Sound.Mel_Dim)
+        return loss + 0.5 * math.log(2 * math.pi)

@@ -9,9 +9,9 @@ from ._lib import c_int, c_void_p
 
 F32, BF16 = 0, 1
 PERM_NONE, PERM_PAIR = 0, 1
-APRO_NONE, APRO_PAIRMUL = 0, 1
+APRO_NONE, APRO_PAIRMUL, APRO_SQNEG = 0, 1, 2
 EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_DGATE = 0, 1, 2, 3, 4
-F_BIAS, F_RELU, F_ADD_IN0, F_MASK, F_ACCUM, F_FIRST, F_LAST, F_REVERSE = 1, 2, 4, 8, 16, 32, 64, 128
+F_BIAS, F_RELU, F_ADD_IN0, F_MASK, F_ACCUM, F_FIRST, F_LAST, F_REVERSE, F_COLMASK = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 
 class ConvArgs(ctypes.Structure):
@@ -35,6 +35,10 @@ class ConvArgs(ctypes.Structure):
         ("out0", c_void_p), ("ld0", ctypes.c_int64),
         ("out1", c_void_p), ("ld1", ctypes.c_int64),
         ("in0", c_void_p), ("ldi0", ctypes.c_int64),
+        ("batch", c_int),
+        ("a_bstride", ctypes.c_int64), ("w_bstride", ctypes.c_int64), ("bias_bstride", ctypes.c_int64),
+        ("out_bstride", ctypes.c_int64), ("mask_bstride", ctypes.c_int64),
+        ("ncols_valid", c_void_p),
     ]
 
 

@@ -42,6 +42,11 @@ int glowtts_device_arch(char *buf, int buflen);
 int glowtts_mas_dp_f32(const float *value, const int32_t *t_xs, const int32_t *t_ys,
                        int32_t *idx_out, float *q_out, int B, int Tx, int Ty,
                        float max_neg_val, void *stream);
+/* Same search on the transposed score matrix value_t [B][Ty][Tx] (token index contiguous) - the layout the
+ * fused log-prior GEMM writes, where one frame of scores is one coalesced row.  q_out_t likewise transposed. */
+int glowtts_mas_dp_f32_t(const float *value_t, const int32_t *t_xs, const int32_t *t_ys,
+                         int32_t *idx_out, float *q_out_t, int B, int Tx, int Ty,
+                         float max_neg_val, void *stream);
 /* Dense 0/1 path from idx (core.pyx:32-35 writes these ones into a pre-zeroed array; here every
  * element is written, so `path` need not be zeroed).  out_dtype: 0 = int32, 1 = float32. */
 int glowtts_mas_path_from_idx(const int32_t *idx, void *path, int B, int Tx, int Ty,
@@ -88,6 +93,7 @@ int glowtts_pack_weight_batched(const float *w, int batch, int O, int I, int tap
 
 #define GLOWTTS_APRO_NONE    0
 #define GLOWTTS_APRO_PAIRMUL 1  /* a[r][c] = A[r][2c] * A[r][2c+1]   (tanh*sigmoid gates, Modules.py:885-887) */
+#define GLOWTTS_APRO_SQNEG   2  /* a[r][c] = c < ca1 ? -0.5 * A[r][c]^2 : A[r][c - ca1]   (log-prior operand, Modules.py:112-113) */
 
 #define GLOWTTS_EPI_LINEAR   0  /* v = acc (+bias[n]) (relu) (+in0[r][n]) (*rowmask[r]) (+= out0) -> out0[r][n]      */
 #define GLOWTTS_EPI_GATE     1  /* PAIR-packed cols: out0[r][2j],[2j+1] = tanh(a), sigmoid(s)   Modules.py:861-870   */
@@ -103,6 +109,7 @@ int glowtts_pack_weight_batched(const float *w, int batch, int O, int I, int tap
 #define GLOWTTS_F_FIRST   32   /* RESSKIP: skip accumulator is written, not accumulated */
 #define GLOWTTS_F_LAST    64   /* RESSKIP: last WaveNet layer (n = h outputs, all skip, *mask) */
 #define GLOWTTS_F_REVERSE 128  /* COUPLE: inverse coupling x_b = (x_b - m) * exp(-logs) * mask */
+#define GLOWTTS_F_COLMASK 256  /* LINEAR: zero columns n >= ncols_valid[batch]  (attention mask, Modules.py:102) */
 
 typedef struct glowtts_conv_args {
     const float *a;  int64_t lda;      /* A rows (floats per row = lda) */
@@ -123,6 +130,10 @@ typedef struct glowtts_conv_args {
     float *out0; int64_t ld0;
     float *out1; int64_t ld1;
     const float *in0; int64_t ldi0;
+    /* batched problems (gridDim.z): `rows` rows per problem; element strides between problems (0 = shared) */
+    int batch;
+    int64_t a_bstride, w_bstride /* bytes */, bias_bstride, out_bstride, mask_bstride;
+    const int32_t *ncols_valid;        /* [batch] for GLOWTTS_F_COLMASK */
 } glowtts_conv_args;
 
 int glowtts_conv_cl(const glowtts_conv_args *args /* host pointer */, void *stream);

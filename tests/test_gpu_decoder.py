@@ -137,7 +137,10 @@ def test_full_width_forward(precision, ztol):
         q = f"layer_Dict.Decoder.layer_Dict.Flows.{f}.layers"
         sd[q + ".0.logs"] = torch.randn(1, 160, 1, generator=g) * 0.1
         sd[q + ".0.bias"] = torch.randn(1, 160, 1, generator=g) * 0.1
-        sd[q + ".1.weight"] = torch.linalg.qr(torch.randn(4, 4, generator=g))[0] + 0.05 * torch.randn(4, 4, generator=g)
+        w4 = torch.linalg.qr(torch.randn(4, 4, generator=g))[0] + 0.05 * torch.randn(4, 4, generator=g)
+        if torch.det(w4) < 0:                       # the reference keeps det > 0 (Modules.py:722-723)
+            w4[:, 0] = -w4[:, 0]
+        sd[q + ".1.weight"] = w4
         def wn(name, o, i, k):
             sd[f"{q}.2.layer_Dict.{name}.weight_v"] = torch.randn(o, i, k, generator=g) / (i * k) ** 0.5
             sd[f"{q}.2.layer_Dict.{name}.weight_g"] = torch.rand(o, 1, 1, generator=g) + 0.5

@@ -1,0 +1,116 @@
+"""GPU parity of the whole training graph / inverse path (glow_tts_amd.modules.GlowTTS) vs the golden vectors of
+the reference and the oracle.  The golden state dict is loaded through load_state_dict: it also checks that the
+key layout is the reference's."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import glowtts_ref as O
+from helpers import load_case, tiny_cfg, tiny_hp_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def build(mode, precision, sd):
+    from glow_tts_amd.hparams import Recursive_Parse
+    from glow_tts_amd.modules import GlowTTS
+    hp = tiny_hp_dict(mode)
+    hp["HIP_Precision"] = precision
+    model = GlowTTS(Recursive_Parse(hp))
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    for f in model.layer_Dict["Decoder"].layer_Dict["Flows"]:      # what the reference does after loading (Train.py:527-528)
+        f.layers[0].initialized = True
+    return model.cuda().eval()
+
+
+@pytest.mark.parametrize("mode,fname", [("Vanilla", "tiny_vanilla.npz"), ("SE", "tiny_se.npz")])
+def test_state_dict_keys_match_reference(mode, fname):
+    from glow_tts_amd.hparams import Recursive_Parse
+    from glow_tts_amd.modules import GlowTTS
+    sd, _, _ = load_case(fname)
+    model = GlowTTS(Recursive_Parse(tiny_hp_dict(mode)))
+    mine = model.state_dict()
+    assert set(mine.keys()) == set(sd.keys())
+    for k in sd:
+        assert tuple(mine[k].shape) == tuple(sd[k].shape), k
+
+
+@pytest.mark.parametrize("mode,fname", [("Vanilla", "tiny_vanilla.npz"), ("SE", "tiny_se.npz")])
+def test_train_forward_losses_grads_f32(mode, fname):
+    from glow_tts_amd.modules import MLE_Loss
+    sd, grads, r = load_case(fname)
+    model = build(mode, "f32", sd)
+    t = lambda k: torch.from_numpy(r[k]).cuda()
+    spk = t("speakers") if "speakers" in r else None
+    z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, attn, _ = model(t("tokens"), t("token_lengths"), t("mels"), t("mel_lengths"), spk, None, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(attn.cpu().numpy().astype(np.int8), r["attn"]), "alignment differs from the reference"
+    for got, key, tol in [(z, "z", 1e-4), (mel_mean, "mel_mean", 1e-4), (mel_log_std, "mel_log_std", 1e-4), (log_dur, "log_dur", 1e-4),
+                          (log_dur_t, "log_dur_target", 1e-5)]:
+        assert (got.detach().cpu() - torch.from_numpy(r[key])).abs().max() <= tol, key
+    assert (log_dets.detach().cpu() - torch.from_numpy(r["log_dets"])).abs().max() <= 1e-3
+    mle = MLE_Loss(model.hp)(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=t("mel_lengths"))
+    length = torch.nn.functional.mse_loss(log_dur, log_dur_t)
+    assert abs(mle.item() - float(r["mle"])) <= 1e-4 and abs(length.item() - float(r["length"])) <= 1e-4      # NLL within 1e-3 (north_star)
+    model.zero_grad()
+    (mle + length).backward()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k, p in model.named_parameters():
+        want = grads.get(k)
+        if want is None:
+            continue
+        got = p.grad.cpu() if p.grad is not None else torch.zeros_like(want)
+        err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-5)
+        worst = max(worst, err)
+        assert err < 5e-3, (k, err)
+    print("worst relative grad error", worst)
+
+
+def test_train_forward_bf16_nll_within_1e3():
+    from glow_tts_amd.modules import MLE_Loss
+    sd, _, r = load_case("tiny_vanilla.npz")
+    model = build("Vanilla", "bf16", sd)
+    t = lambda k: torch.from_numpy(r[k]).cuda()
+    z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, attn, _ = model(t("tokens"), t("token_lengths"), t("mels"), t("mel_lengths"), None, None, None)
+    mle = MLE_Loss(model.hp)(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=t("mel_lengths"))
+    assert abs(mle.item() - float(r["mle"])) <= 1e-3 * max(1.0, abs(float(r["mle"])))
+    assert (z.detach().cpu() - torch.from_numpy(r["z"])).abs().max() <= 5e-2
+
+
+@pytest.mark.parametrize("mode,fname", [("Vanilla", "tiny_vanilla.npz"), ("SE", "tiny_se.npz")])
+def test_inference_matches_reference(mode, fname):
+    sd, _, r = load_case(fname)
+    model = build(mode, "f32", sd)
+    t = lambda k: torch.from_numpy(r[k]).cuda()
+    spk = t("speakers") if "speakers" in r else None
+    mels, lengths, attn = model.inference(t("tokens"), t("token_lengths"), None, None, spk, None, None, None,
+                                          noise_scale=float(r["noise_scale"]), length_scale=t("length_scale"), noises=t("noise"))
+    torch.cuda.synchronize()
+    assert torch.equal(lengths.cpu(), torch.from_numpy(r["inf_lengths"]))
+    assert np.array_equal(attn.cpu().numpy().astype(np.int8), r["inf_attn"])
+    want = torch.from_numpy(r["inf_mels"])
+    assert mels.shape == want.shape and (mels.cpu() - want).abs().max() <= 2e-4
+
+
+def test_actnorm_init_on_first_forward_matches_reference():
+    """Fresh ActNorm parameters (zeros, `initialized` False) -> after one forward they equal the reference's."""
+    from glow_tts_amd.hparams import Recursive_Parse
+    from glow_tts_amd.modules import GlowTTS
+    sd, _, r = load_case("tiny_vanilla.npz")
+    d = np.load(__import__("os").path.join(__import__("helpers").GOLDEN, "tiny_vanilla.npz"))
+    sd0 = dict(sd)
+    for k in d.files:
+        if k.startswith("sd_before/"):
+            sd0[k[len("sd_before/"):]] = torch.from_numpy(d[k])
+    hp = tiny_hp_dict("Vanilla"); hp["HIP_Precision"] = "f32"
+    model = GlowTTS(Recursive_Parse(hp))
+    model.load_state_dict(sd0)
+    model = model.cuda().eval()
+    t = lambda k: torch.from_numpy(r[k]).cuda()
+    model(t("tokens"), t("token_lengths"), t("mels"), t("mel_lengths"), None, None, None)
+    for i, f in enumerate(model.layer_Dict["Decoder"].layer_Dict["Flows"]):
+        assert f.layers[0].initialized
+        assert (f.layers[0].logs.cpu() - sd[f"layer_Dict.Decoder.layer_Dict.Flows.{i}.layers.0.logs"]).abs().max() < 2e-4
+        assert (f.layers[0].bias.cpu() - sd[f"layer_Dict.Decoder.layer_Dict.Flows.{i}.layers.0.bias"]).abs().max() < 2e-4
