@@ -155,7 +155,7 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
                                      const glowtts_flow_grads* g, void* stream)
 {
     CHECK(check_dims(d));
-    if (!p || !a || !g || !g->dx || !g->dlogdet || !g->douts || !g->dskip || !g->dh[0] || !g->dh[1] || !g->dins || !g->scratch || !g->d_an) return GLOWTTS_E_ARG;
+    if (!p || !a || !g || !g->dx || !g->dlogdet || !g->douts || !g->dskip || !g->dh[0] || !g->dins[0] || !g->scratch || !g->d_an) return GLOWTTS_E_ARG;
     const Ctx c = make_ctx(d, p, a, stream);
     const int H = c.H, L = d->L, C = d->C, C2 = c.C2, R = c.R;
     const int ldo = p->end.npad;          // PAIR-packed (m, logs) width
@@ -175,24 +175,27 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
         q.a = g->douts; q.lda = ldo; q.ca = ldo; q.n = H; q.epi = GLOWTTS_EPI_LINEAR; q.flags = GLOWTTS_F_MASK;
         q.out0 = g->dskip; q.ld0 = H;
         CHECK(glowtts_conv_cl(&q, stream));
-        glowtts_wgrad_args w = wargs(g->douts, ldo, ldo, a->skip, H, H, 1, g->dw_end, g->db_end);
-        w.perm = GLOWTTS_PERM_PAIR; w.perm_h = C2;
-        CHECK(glowtts_wgrad_cl(&w, stream));
+        if (!g->defer_wgrad) {
+            glowtts_wgrad_args w = wargs(g->douts, ldo, ldo, a->skip, H, H, 1, g->dw_end, g->db_end);
+            w.perm = GLOWTTS_PERM_PAIR; w.perm_h = C2;
+            CHECK(glowtts_wgrad_cl(&w, stream));
+        }
     }
-    // 3. WaveNet layers, last to first.  dh[cur] holds d x_{l+1} * mask.
-    int cur = 0;
+    // 3. WaveNet layers, last to first.  dh[l] holds d x_l * mask.
+    const bool wg = !g->defer_wgrad;
     for (int l = L - 1; l >= 0; --l) {
         const bool last = (l == L - 1);
-        float* dnext = g->dh[cur];            // d x_{l+1} (valid when !last)
-        float* dthis = g->dh[cur ^ 1];        // d x_l (written below)
+        float* dnext = last ? nullptr : g->dh[l + 1];   // d x_{l+1}
+        float* dthis = g->dh[l];                        // d x_l (written below)
+        float* dins = g->dins[l];
         {   // Res_Skip data gradient + gate derivative -> dins (PAIR-packed (da, ds))
             glowtts_conv_args q = base_args(c, p->rs_t[l], 1);
             if (last) { q.a = g->dskip; q.lda = H; q.ca = H; }
             else      { q.a = dnext; q.lda = H; q.ca1 = H; q.a2 = g->dskip; q.lda2 = H; q.ca = 2 * H; }
-            q.n = H; q.epi = GLOWTTS_EPI_DGATE; q.in0 = a->gates[l]; q.ldi0 = 2 * H; q.out0 = g->dins; q.ld0 = ldin;
+            q.n = H; q.epi = GLOWTTS_EPI_DGATE; q.in0 = a->gates[l]; q.ldi0 = 2 * H; q.out0 = dins; q.ld0 = ldin;
             CHECK(glowtts_conv_cl(&q, stream));
         }
-        {   // Res_Skip weight gradient: rows [0,H) <- d res, rows [H,2H) <- d skip (last layer: only H rows <- d skip)
+        if (wg) {   // Res_Skip weight gradient: rows [0,H) <- d res, rows [H,2H) <- d skip (last layer: only H rows <- d skip)
             if (last) {
                 glowtts_wgrad_args w = wargs(g->dskip, H, H, a->gates[l], 2 * H, H, 1, g->dw_rs[l], g->db_rs[l]);
                 w.xpro = GLOWTTS_APRO_PAIRMUL;
@@ -208,29 +211,30 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
         }
         {   // In_l data gradient: d x_l = (conv^T(dins) + d x_{l+1}) * mask
             glowtts_conv_args q = base_args(c, p->in_t[l], d->ksize);
-            q.a = g->dins; q.lda = ldin; q.ca = ldin; q.n = H; q.epi = GLOWTTS_EPI_LINEAR;
+            q.a = dins; q.lda = ldin; q.ca = ldin; q.n = H; q.epi = GLOWTTS_EPI_LINEAR;
             q.flags = GLOWTTS_F_MASK | (last ? 0 : GLOWTTS_F_ADD_IN0);
             q.in0 = last ? nullptr : dnext; q.ldi0 = H; q.out0 = dthis; q.ld0 = H;
             CHECK(glowtts_conv_cl(&q, stream));
         }
-        {   // In_l weight gradient
-            glowtts_wgrad_args w = wargs(g->dins, ldin, ldin, a->hs[l], H, H, d->ksize, g->dw_in[l], g->db_in[l]);
+        if (wg) {   // In_l weight gradient
+            glowtts_wgrad_args w = wargs(dins, ldin, ldin, a->hs[l], H, H, d->ksize, g->dw_in[l], g->db_in[l]);
             w.perm = GLOWTTS_PERM_PAIR; w.perm_h = H;
             CHECK(glowtts_wgrad_cl(&w, stream));
         }
         if (g->dcond && p->cond)   // conditioning gradient: sum over the frames of each utterance   (autograd of Modules.py:863-866)
-            CHECK(glowtts_utt_colsum(g->dins, ldin, g->dcond + (int64_t)l * 2 * H, p->ldcond, d->B, c.Tp, 2 * H, GLOWTTS_PERM_PAIR, H, stream));
-        cur ^= 1;
+            CHECK(glowtts_utt_colsum(dins, ldin, g->dcond + (int64_t)l * 2 * H, p->ldcond, d->B, c.Tp, 2 * H, GLOWTTS_PERM_PAIR, H, stream));
     }
-    float* dh0 = g->dh[cur];                  // d h0 * mask
+    float* dh0 = g->dh[0];                    // d h0 * mask
     // 4. Start conv: data gradient accumulates into d x_a, weight gradient
     {
         glowtts_conv_args q = base_args(c, p->start_t, 1);
         q.a = dh0; q.lda = H; q.ca = H; q.n = C2; q.epi = GLOWTTS_EPI_LINEAR; q.flags = GLOWTTS_F_ACCUM;
         q.out0 = g->dx; q.ld0 = C;
         CHECK(glowtts_conv_cl(&q, stream));
-        glowtts_wgrad_args w = wargs(dh0, H, H, a->xmid, C, C2, 1, g->dw_start, g->db_start);
-        CHECK(glowtts_wgrad_cl(&w, stream));
+        if (wg) {
+            glowtts_wgrad_args w = wargs(dh0, H, H, a->xmid, C, C2, 1, g->dw_start, g->db_start);
+            CHECK(glowtts_wgrad_cl(&w, stream));
+        }
     }
     // 5. inv-1x1 + ActNorm backward (dx in place), parameter-gradient data terms -> d_an
     return glowtts_actnorm_inv1x1_bwd(g->dx, g->dx, a->xin, p->an_logs, p->an_bias, p->winfo, a->rowmask, g->d_an, g->scratch, R, C, stream);

@@ -159,13 +159,17 @@ __global__ __launch_bounds__(256) void colstats_partial_kernel(const float* __re
     }
     if (threadIdx.x == 0) { float sm = 0.f; for (long r = r0; r < r1; ++r) sm += rowmask[r]; out[2 * C] = sm; }
 }
-__global__ void colstats_final_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nblk, int n)
+__global__ __launch_bounds__(256) void colstats_final_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nblk, int n)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wavefront per output: lanes stride over the partial rows, fixed-order shuffle tree (deterministic)
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (i >= n) return;
-    double s = 0.0;
-    for (int k = 0; k < nblk; ++k) s += partial[(long)k * n + i];
-    stats[i] = (float)s;
+    float s = 0.f;
+    for (int k = lane; k < nblk; k += 64) s += partial[(long)k * n + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) stats[i] = s;
 }
 // logs = -0.5*log(max(var,1e-7)), bias = -mean*exp(logs)   from stats = [sum x, sum x^2, sum m]
 __global__ void actnorm_from_stats_kernel(const float* __restrict__ stats, float* __restrict__ logs, float* __restrict__ bias, int C)
@@ -388,7 +392,7 @@ extern "C" int glowtts_actnorm_stats(const float* x, const float* rowmask, float
     const int nblk = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(colstats_partial_kernel, dim3(nblk), dim3(256), 0, s, x, rowmask, scratch, (long)rows, C, rpb);
     const int n = 2 * C + 1;
-    hipLaunchKernelGGL(colstats_final_kernel, dim3((n + 255) / 256), dim3(256), 0, s, scratch, stats, nblk, n);
+    hipLaunchKernelGGL(colstats_final_kernel, dim3((n + 3) / 4), dim3(256), 0, s, scratch, stats, nblk, n);
     RET_LAUNCH();
 }
 
@@ -429,7 +433,7 @@ extern "C" int glowtts_actnorm_inv1x1_bwd(const float* dz, float* dx, const floa
     hipLaunchKernelGGL(actnorm_inv_bwd_kernel, dim3(nblk), dim3(256), 24 * 256 * sizeof(float), s, dz, dx, x, logs, bias, winfo, rowmask,
                        scratch, (long)rows, C, rpb);
     const int n = 2 * C + 16;
-    hipLaunchKernelGGL(colstats_final_kernel, dim3((n + 255) / 256), dim3(256), 0, s, scratch, param_grads, nblk, n);
+    hipLaunchKernelGGL(colstats_final_kernel, dim3((n + 3) / 4), dim3(256), 0, s, scratch, param_grads, nblk, n);
     RET_LAUNCH();
 }
 

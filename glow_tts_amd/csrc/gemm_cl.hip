@@ -102,7 +102,7 @@ template <> struct Prec<__bf16> { static constexpr int KC = 32; static constexpr
 
 constexpr int MAX_TAPS = 5;
 
-template <typename CT, int MI, int NI, int WM, int WN, int EPI>
+template <typename CT, int MI, int NI, int WM, int WN, int EPI, bool T1>
 __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_conv_args pin)
 {
     glowtts_conv_args p = pin;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const int taps = p.taps;
+    const int taps = T1 ? 1 : p.taps;               // T1: 1x1 convs (one step per K chunk)
     const int arows = BM + taps - 1;
     const int S = p.kchunks * taps;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -144,10 +144,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    Chunk16 ra[A_IT], rw[W_IT];
+    Chunk16 raA[A_IT], raB[A_IT], rwA[W_IT], rwB[W_IT];     // two register sets each: loads are issued two steps ahead
 
     // ---- staging: global -> registers ----
-    auto gload_a = [&](int kc) {
+    auto gload_a = [&](Chunk16 (&ra)[A_IT], int kc) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int idx = tid + it * NT;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
             }
         }
     };
-    auto gload_w = [&](int s) {
+    auto gload_w = [&](Chunk16 (&rw)[W_IT], int s) {
         const int kc = s / taps, t = s - kc * taps;
         const unsigned char* base = reinterpret_cast<const unsigned char*>(p.w) + ((long)(t * p.kchunks + kc) * p.npad + n0) * 64;
 #pragma unroll
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
             else { rw[it].w[0] = rw[it].w[1] = rw[it].w[2] = rw[it].w[3] = 0u; }
         }
     };
-    auto sstore_a = [&](int buf) {
+    auto sstore_a = [&](const Chunk16 (&ra)[A_IT], int buf) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int idx = tid + it * NT;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
             if (row < AROWS) *reinterpret_cast<Chunk16*>(As + buf * (AROWS * 64) + swz(row, q)) = ra[it];
         }
     };
-    auto sstore_w = [&](int buf) {
+    auto sstore_w = [&](const Chunk16 (&rw)[W_IT], int buf) {
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int idx = tid + it * NT;
@@ -263,21 +263,48 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
     };
 
     // ---- main loop ----
-    gload_a(0);
-    gload_w(0);
-    sstore_a(0);
-    sstore_w(0);
-    __syncthreads();
-    for (int s = 0; s < S; ++s) {
-        const int kc = s / taps, tap = s - kc * taps;
-        const bool more = (s + 1 < S);
-        const bool next_a = more && (tap == taps - 1);
-        if (more) gload_w(s + 1);
-        if (next_a) gload_a(kc + 1);
-        compute(kc & 1, s & 1, tap);
-        if (more) sstore_w((s + 1) & 1);
-        if (next_a) sstore_a((kc + 1) & 1);
+    // step s = (chunk kc, tap).  Weights: W(s+2) is loaded into registers while step s computes and W(s+1) (loaded during
+    // step s-1) is written to the other LDS buffer, so every global load has two compute phases to land.
+    // Activations: taps > 1: A(kc+1) is loaded at the first tap of chunk kc and written to LDS at its last tap;
+    //              taps == 1: same two-set scheme as the weights.
+    const int KCH = p.kchunks;
+    if constexpr (T1) {
+        auto step = [&](int s, Chunk16 (&w_load)[W_IT], const Chunk16 (&w_store)[W_IT], Chunk16 (&a_load)[A_IT], const Chunk16 (&a_store)[A_IT]) {
+            if (s + 2 < S) { gload_w(w_load, s + 2); gload_a(a_load, s + 2); }
+            compute(s & 1, s & 1, 0);
+            if (s + 1 < S) { sstore_w(w_store, (s + 1) & 1); sstore_a(a_store, (s + 1) & 1); }
+            __syncthreads();
+        };
+        gload_a(raA, 0);
+        gload_w(rwA, 0);
+        if (S > 1) { gload_w(rwB, 1); gload_a(raB, 1); }
+        sstore_a(raA, 0);
+        sstore_w(rwA, 0);
         __syncthreads();
+        for (int s = 0; s < S; s += 2) {
+            step(s, rwA, rwB, raA, raB);
+            if (s + 1 < S) step(s + 1, rwB, rwA, raB, raA);
+        }
+    } else {
+        auto step = [&](int s, Chunk16 (&w_load)[W_IT], const Chunk16 (&w_store)[W_IT]) {
+            const int kc = s / taps, tap = s - kc * taps;
+            if (s + 2 < S) gload_w(w_load, s + 2);
+            if (tap == 0 && kc + 1 < KCH) gload_a(raA, kc + 1);
+            compute(kc & 1, s & 1, tap);
+            if (s + 1 < S) sstore_w(w_store, (s + 1) & 1);
+            if (tap == taps - 1 && kc + 1 < KCH) sstore_a(raA, (kc + 1) & 1);
+            __syncthreads();
+        };
+        gload_a(raA, 0);
+        gload_w(rwA, 0);
+        if (S > 1) gload_w(rwB, 1);
+        sstore_a(raA, 0);
+        sstore_w(rwA, 0);
+        __syncthreads();
+        for (int s = 0; s < S; s += 2) {
+            step(s, rwA, rwB);
+            if (s + 1 < S) step(s + 1, rwB, rwA);
+        }
     }
 
     // ---- fused epilogue ----
@@ -376,7 +403,8 @@ int launch_cfg(const glowtts_conv_args& a, hipStream_t s)
 {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     dim3 grid((a.rows + BM - 1) / BM, (a.npad + BN - 1) / BN, a.batch > 1 ? a.batch : 1);
-    hipLaunchKernelGGL((conv_cl_kernel<CT, MI, NI, WM, WN, EPI>), grid, dim3(WM * WN * 64), 0, s, a);
+    if (a.taps == 1) hipLaunchKernelGGL((conv_cl_kernel<CT, MI, NI, WM, WN, EPI, true>), grid, dim3(WM * WN * 64), 0, s, a);
+    else             hipLaunchKernelGGL((conv_cl_kernel<CT, MI, NI, WM, WN, EPI, false>), grid, dim3(WM * WN * 64), 0, s, a);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 

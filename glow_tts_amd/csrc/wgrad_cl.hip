@@ -17,6 +17,7 @@
 //   * rows are split over gridDim.z (split-K); partial tiles are combined with fp32 atomics.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "../../include/glowtts_hip.h"
 
 namespace {
@@ -26,7 +27,6 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int WG_MAX_TAPS = 5;
 constexpr int BMO = 128;      // o per block
 constexpr int BNC = 64;       // c per block
 constexpr int BK = 32;        // rows per step
@@ -37,9 +37,21 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
     return *reinterpret_cast<uint32_t*>(&v);
 }
 
+struct WCommon { int rows, pad, accumulate, njobs; };
+
+// job of this workgroup: p (by value when there is a single problem, else looked up in the device table by tile index)
 template <typename CT, int TAPS>
-__global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_args p)
+__global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job single, const glowtts_wgrad_job* __restrict__ table, const WCommon cm)
 {
+    glowtts_wgrad_job p = single;
+    int tile = blockIdx.x;
+    if (table) {                                  // binary search for the last job with tile0 <= tile (wave-uniform)
+        int lo = 0, hi = cm.njobs - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[mid].tile0 <= tile) lo = mid; else hi = mid - 1; }
+        p = table[lo];
+        tile -= p.tile0;
+    }
+    const int tile_o = tile % p.mt, tile_c = tile / p.mt;
     constexpr int ES = sizeof(CT);
     constexpr int XROWS = BK + TAPS - 1;
     // LDS row strides (bytes): natural width + 64 B so that 4 consecutive rows hit 4 different 64-B bank segments
@@ -51,13 +63,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_args p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;                 // wave tile: 64 (o) x 32 (c)
-    const int o0 = blockIdx.x * BMO, c0 = blockIdx.y * BNC;
+    const int o0 = tile_o * BMO, c0 = tile_c * BNC;
     const int l31 = lane & 31, lhi = lane >> 5;
 
     // rows handled by this split
-    const long chunk = ((((long)p.rows + gridDim.z - 1) / gridDim.z) + BK - 1) / BK * BK;
+    const long chunk = ((((long)cm.rows + gridDim.z - 1) / gridDim.z) + BK - 1) / BK * BK;
     const long rbeg = (long)blockIdx.z * chunk;
-    const long rend = min((long)p.rows, rbeg + chunk);
+    const long rend = min((long)cm.rows, rbeg + chunk);
     if (rbeg >= rend) return;
     const int nsteps = (int)((rend - rbeg + BK - 1) / BK);
 
@@ -72,11 +84,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_args p)
     // ---- staging registers ----
     constexpr int DY_IT = (BK * BMO / 4) / 256;               // float4 per thread for the DY tile (= 4)
     constexpr int X_IT = (XROWS * BNC / 4 + 255) / 256;       // float4 per thread for the X tile
-    float4 rdy[DY_IT], rx[X_IT];
+    float4 rdyA[DY_IT], rxA[X_IT], rdyB[DY_IT], rxB[X_IT];      // two register sets: loads are issued two steps ahead
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool want_bias = (p.dbias != nullptr) && (blockIdx.y == 0);
+    const bool want_bias = (p.dbias != nullptr) && (tile_c == 0);
 
-    auto gload = [&](long r0) {
+    auto gload = [&](float4 (&rdy)[DY_IT], float4 (&rx)[X_IT], long r0) {
 #pragma unroll
         for (int it = 0; it < DY_IT; ++it) {
             const int idx = tid + it * 256;
@@ -96,11 +108,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_args p)
         for (int it = 0; it < X_IT; ++it) {
             const int idx = tid + it * 256;
             const int row = idx / (BNC / 4), c4 = idx % (BNC / 4);
-            const long r = r0 + row - p.pad;
+            const long r = r0 + row - cm.pad;
             const int col = c0 + c4 * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             // rows outside [0, rows) are zero; rows outside this split's range ARE read (halo of the split)
-            if (row < XROWS && r >= 0 && r < p.rows && col < p.ca) {
+            if (row < XROWS && r >= 0 && r < cm.rows && col < p.ca) {
                 if (p.xpro == GLOWTTS_APRO_PAIRMUL) {
                     const float* src = p.x + r * p.ldx + 2 * col;
                     if (col + 4 <= p.ca) {
@@ -121,7 +133,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_args p)
             rx[it] = v;
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](const float4 (&rdy)[DY_IT], const float4 (&rx)[X_IT], int buf) {
         unsigned char* dyb = smem + buf * (DY_BYTES + X_BYTES);
         unsigned char* xb = dyb + DY_BYTES;
 #pragma unroll
@@ -201,19 +213,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_args p)
         }
     };
 
-    gload(rbeg);
-    sstore(0);
+    gload(rdyA, rxA, rbeg);
+    if (nsteps > 1) gload(rdyB, rxB, rbeg + BK);
+    sstore(rdyA, rxA, 0);
     __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        const bool more = s + 1 < nsteps;
-        if (more) gload(rbeg + (long)(s + 1) * BK);
+    for (int s = 0; s < nsteps; s += 2) {
+        if (s + 2 < nsteps) gload(rdyA, rxA, rbeg + (long)(s + 2) * BK);
         compute(s & 1);
-        if (more) sstore((s + 1) & 1);
+        if (s + 1 < nsteps) sstore(rdyB, rxB, (s + 1) & 1);
         __syncthreads();
+        if (s + 1 < nsteps) {
+            if (s + 3 < nsteps) gload(rdyB, rxB, rbeg + (long)(s + 3) * BK);
+            compute((s + 1) & 1);
+            if (s + 2 < nsteps) sstore(rdyA, rxA, (s + 2) & 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: dW[o][c][t] ----
-    const bool atomic = gridDim.z > 1 || p.accumulate;
+    const bool atomic = gridDim.z > 1 || cm.accumulate;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -261,12 +279,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_args p)
 }
 
 template <typename CT>
-int launch_w(const glowtts_wgrad_args& a, dim3 grid, hipStream_t s)
+int launch_w(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const WCommon& cm, int taps, dim3 grid, hipStream_t s)
 {
-    switch (a.taps) {
-        case 1: hipLaunchKernelGGL((wgrad_kernel<CT, 1>), grid, dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL((wgrad_kernel<CT, 3>), grid, dim3(256), 0, s, a); break;
-        case 5: hipLaunchKernelGGL((wgrad_kernel<CT, 5>), grid, dim3(256), 0, s, a); break;
+    switch (taps) {
+        case 1: hipLaunchKernelGGL((wgrad_kernel<CT, 1>), grid, dim3(256), 0, s, one, table, cm); break;
+        case 3: hipLaunchKernelGGL((wgrad_kernel<CT, 3>), grid, dim3(256), 0, s, one, table, cm); break;
+        case 5: hipLaunchKernelGGL((wgrad_kernel<CT, 5>), grid, dim3(256), 0, s, one, table, cm); break;
         default: return GLOWTTS_E_ARG;
     }
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
@@ -278,18 +296,39 @@ extern "C" int glowtts_wgrad_cl(const glowtts_wgrad_args* args, void* stream)
 {
     if (!args || !args->dy || !args->x || !args->dw || args->rows < 1 || args->m < 1 || args->ca < 1) return GLOWTTS_E_ARG;
     if ((args->lddy & 3) || (args->ldx & 3) || (reinterpret_cast<uintptr_t>(args->dy) & 15) || (reinterpret_cast<uintptr_t>(args->x) & 15)) return GLOWTTS_E_ARG;
-    glowtts_wgrad_args a = *args;
-    const int mt = (a.m + BMO - 1) / BMO, nt = (a.ca + BNC - 1) / BNC;
+    const glowtts_wgrad_args& a = *args;
+    glowtts_wgrad_job j;
+    j.dy = a.dy; j.x = a.x; j.xmask = a.xmask; j.dw = a.dw; j.dbias = a.dbias; j.lddy = a.lddy; j.ldx = a.ldx;
+    j.m = a.m; j.ca = a.ca; j.xpro = a.xpro; j.perm = a.perm; j.perm_h = a.perm_h; j.tile0 = 0;
+    j.mt = (a.m + BMO - 1) / BMO; j.nt = (a.ca + BNC - 1) / BNC; j.reserved = 0;
+    const int tiles = j.mt * j.nt;
     int splits = a.splits;
     if (splits < 1) {                                   // fill ~2 workgroups per CU, at least 256 rows per split
-        splits = (512 + mt * nt - 1) / (mt * nt);
+        splits = (512 + tiles - 1) / tiles;
         const int maxs = (a.rows + 255) / 256;
         if (splits > maxs) splits = maxs;
         if (splits < 1) splits = 1;
     }
-    dim3 grid(mt, nt, splits);
+    WCommon cm{a.rows, a.pad, a.accumulate, 1};
+    dim3 grid(tiles, 1, splits);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (a.precision == GLOWTTS_BF16) return launch_w<__bf16>(a, grid, s);
-    if (a.precision == GLOWTTS_F32) return launch_w<float>(a, grid, s);
+    if (a.precision == GLOWTTS_BF16) return launch_w<__bf16>(j, nullptr, cm, a.taps, grid, s);
+    if (a.precision == GLOWTTS_F32) return launch_w<float>(j, nullptr, cm, a.taps, grid, s);
+    return GLOWTTS_E_ARG;
+}
+
+extern "C" int glowtts_wgrad_grouped(const glowtts_wgrad_job* dev_jobs, int njobs, int total_tiles, int rows, int taps, int pad,
+                                     int precision, int splits, int accumulate, void* stream)
+{
+    if (!dev_jobs || njobs < 1 || total_tiles < 1 || rows < 1) return GLOWTTS_E_ARG;
+    if (splits < 1) splits = 1;
+    glowtts_wgrad_job dummy;
+    memset(&dummy, 0, sizeof(dummy));
+    dummy.mt = 1; dummy.nt = 1;
+    WCommon cm{rows, pad, accumulate, njobs};
+    dim3 grid(total_tiles, 1, splits);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (precision == GLOWTTS_BF16) return launch_w<__bf16>(dummy, dev_jobs, cm, taps, grid, s);
+    if (precision == GLOWTTS_F32) return launch_w<float>(dummy, dev_jobs, cm, taps, grid, s);
     return GLOWTTS_E_ARG;
 }

@@ -43,7 +43,8 @@ class FlowActs(ctypes.Structure):
 
 class FlowGrads(ctypes.Structure):
     _fields_ = [("dx", c_void_p), ("dlogdet", c_void_p), ("douts", c_void_p), ("dskip", c_void_p),
-                ("dh", c_void_p * 2), ("dins", c_void_p), ("scratch", c_void_p), ("d_an", c_void_p),
+                ("dh", c_void_p * MAXL), ("dins", c_void_p * MAXL), ("defer_wgrad", c_int),
+                ("scratch", c_void_p), ("d_an", c_void_p),
                 ("dw_start", c_void_p), ("db_start", c_void_p),
                 ("dw_in", c_void_p * MAXL), ("db_in", c_void_p * MAXL),
                 ("dw_rs", c_void_p * MAXL), ("db_rs", c_void_p * MAXL),
@@ -69,9 +70,43 @@ def _L():
         L.glowtts_flow_forward.argtypes = [c_void_p] * 4
         L.glowtts_flow_inverse.argtypes = [c_void_p] * 4
         L.glowtts_flow_backward.argtypes = [c_void_p] * 5
+        L.glowtts_wgrad_grouped.argtypes = [c_void_p] + [c_int] * 8 + [c_void_p]
         L.glowtts_decoder_logdet.argtypes = [c_void_p, c_i64] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]
         _declared = True
     return L
+
+
+class WgradJob(ctypes.Structure):
+    """Mirror of `glowtts_wgrad_job` (one weight-gradient problem of the grouped launch)."""
+    _fields_ = [("dy", c_void_p), ("x", c_void_p), ("xmask", c_void_p), ("dw", c_void_p), ("dbias", c_void_p),
+                ("lddy", c_i64), ("ldx", c_i64),
+                ("m", c_int), ("ca", c_int), ("xpro", c_int), ("perm", c_int), ("perm_h", c_int),
+                ("tile0", c_int), ("mt", c_int), ("nt", c_int), ("reserved", c_i64)]
+
+
+class WgradGroup:
+    """Collects weight-gradient problems sharing (rows, taps) and runs them as ONE glowtts_wgrad_grouped launch."""
+
+    def __init__(self, rows, taps, precision):
+        self.rows, self.taps, self.precision = rows, taps, precision
+        self.jobs, self.tiles = [], 0
+
+    def add(self, dy, lddy, m, x, ldx, ca, dw, dbias, xpro=ops.APRO_NONE, perm=ops.PERM_NONE, perm_h=0):
+        j = WgradJob()
+        j.dy, j.x, j.dw, j.dbias, j.lddy, j.ldx = dy, x, dw, dbias, lddy, ldx
+        j.m, j.ca, j.xpro, j.perm, j.perm_h = m, ca, xpro, perm, perm_h
+        j.mt, j.nt, j.tile0 = (m + 127) // 128, (ca + 63) // 64, self.tiles
+        self.tiles += j.mt * j.nt
+        self.jobs.append(j)
+
+    def launch(self, device):
+        if not self.jobs:
+            return
+        arr = (WgradJob * len(self.jobs))(*self.jobs)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.table = host.to(device, non_blocking=False)          # kept alive until the stream has consumed it
+        _lib.check(_L().glowtts_wgrad_grouped(self.table.data_ptr(), len(self.jobs), self.tiles, self.rows, self.taps, (self.taps - 1) // 2,
+                                              self.precision, 1, 0, _lib.stream()), "glowtts_wgrad_grouped")
 
 
 class PackedBatch:
@@ -332,30 +367,46 @@ class DecoderFunction(torch.autograd.Function):
         dld = dlogdet.contiguous() if dlogdet is not None else torch.zeros(B, device=dev)
         G = {k: torch.zeros_like(W[k]) for k in WEIGHT_KEYS}
         d_an = torch.empty(F_, 2 * C + 16, device=dev)
-        douts = torch.zeros(R, prep.ldo, device=dev)
-        dins = torch.zeros(R, prep.ldin, device=dev)
-        dskip = torch.empty(R, H, device=dev)
-        dh = torch.empty(2, R, H, device=dev)
+        # every flow / layer keeps its own gradient buffers: the weight gradients of ALL flows are computed afterwards by
+        # two grouped launches (k-tap problems, 1x1 problems) whose tiles fill the chip without split-K or atomics
+        douts = torch.zeros(F_, R, prep.ldo, device=dev)
+        dins = (torch.empty if prep.ldin == 2 * H else torch.zeros)(F_, Lw, R, prep.ldin, device=dev)    # only pad columns need zeros
+        dskip = torch.empty(F_, R, H, device=dev)
+        dh = torch.empty(F_, Lw, R, H, device=dev)
         scratch = torch.empty(L.glowtts_actnorm_stats_scratch_floats(R, C), device=dev)
         dcond = torch.zeros_like(prep.cond) if prep.cond is not None else None
         dims = _dims(cfg, B, T)
+        gk = WgradGroup(R, cfg.k, cfg.precision)
+        g1 = gk if cfg.k == 1 else WgradGroup(R, 1, cfg.precision)
+        C2 = C // 2
         for f in range(F_ - 1, -1, -1):
             g = FlowGrads()
-            g.dx, g.dlogdet, g.douts, g.dskip = dx.data_ptr(), dld.data_ptr(), douts.data_ptr(), dskip.data_ptr()
-            g.dh[0], g.dh[1], g.dins, g.scratch, g.d_an = dh[0].data_ptr(), dh[1].data_ptr(), dins.data_ptr(), scratch.data_ptr(), d_an[f].data_ptr()
-            g.dw_start, g.db_start = G["w_start"][f].data_ptr(), G["b_start"][f].data_ptr()
-            g.dw_end, g.db_end = G["w_end"][f].data_ptr(), G["b_end"][f].data_ptr()
+            g.dx, g.dlogdet, g.douts, g.dskip = dx.data_ptr(), dld.data_ptr(), douts[f].data_ptr(), dskip[f].data_ptr()
+            g.scratch, g.d_an, g.defer_wgrad = scratch.data_ptr(), d_an[f].data_ptr(), 1
             for l in range(Lw):
-                g.dw_in[l], g.db_in[l] = G["w_in"][f, l].data_ptr(), G["b_in"][f, l].data_ptr()
-                if l < Lw - 1:
-                    g.dw_rs[l], g.db_rs[l] = G["w_rs"][f, l].data_ptr(), G["b_rs"][f, l].data_ptr()
-                else:
-                    g.dw_rs[l], g.db_rs[l] = G["w_rs_last"][f].data_ptr(), G["b_rs_last"][f].data_ptr()
+                g.dh[l], g.dins[l] = dh[f, l].data_ptr(), dins[f, l].data_ptr()
             if dcond is not None:
                 g.dcond = dcond.data_ptr() + 4 * f * Lw * 2 * H
             acts = buf.acts(f, Lw, rowmask)
             _lib.check(L.glowtts_flow_backward(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(acts), ctypes.byref(g),
                                                _lib.stream()), "glowtts_flow_backward")
+            # weight-gradient problems of this flow (autograd of Modules.py:791,861,871,793)
+            g1.add(douts[f].data_ptr(), prep.ldo, prep.ldo, buf.skip[f].data_ptr(), H, H, G["w_end"][f].data_ptr(), G["b_end"][f].data_ptr(),
+                   perm=ops.PERM_PAIR, perm_h=C2)
+            for l in range(Lw):
+                gates = buf.gates[f, l].data_ptr()
+                if l == Lw - 1:
+                    g1.add(dskip[f].data_ptr(), H, H, gates, 2 * H, H, G["w_rs_last"][f].data_ptr(), G["b_rs_last"][f].data_ptr(), xpro=ops.APRO_PAIRMUL)
+                else:
+                    g1.add(dh[f, l + 1].data_ptr(), H, H, gates, 2 * H, H, G["w_rs"][f, l].data_ptr(), G["b_rs"][f, l].data_ptr(), xpro=ops.APRO_PAIRMUL)
+                    g1.add(dskip[f].data_ptr(), H, H, gates, 2 * H, H, G["w_rs"][f, l].data_ptr() + 4 * H * H, G["b_rs"][f, l].data_ptr() + 4 * H,
+                           xpro=ops.APRO_PAIRMUL)
+                gk.add(dins[f, l].data_ptr(), prep.ldin, prep.ldin, buf.hs[f, l].data_ptr(), H, H, G["w_in"][f, l].data_ptr(), G["b_in"][f, l].data_ptr(),
+                       perm=ops.PERM_PAIR, perm_h=H)
+            g1.add(dh[f, 0].data_ptr(), H, H, buf.xmid[f].data_ptr(), C, C2, G["w_start"][f].data_ptr(), G["b_start"][f].data_ptr())
+        gk.launch(dev)
+        if g1 is not gk:
+            g1.launch(dev)
         # log-determinant terms of the parameters (Modules.py:694, 747): logdet_b += (sum logs + logdet(W) C/4) * len_b
         lens = rowmask.view(B, -1).sum(1)
         s = (dld * lens).sum()

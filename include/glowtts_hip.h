@@ -206,6 +206,20 @@ typedef struct glowtts_wgrad_args {
 } glowtts_wgrad_args;
 int glowtts_wgrad_cl(const glowtts_wgrad_args *args /* host pointer */, void *stream);
 
+/* Grouped form: many weight-gradient problems that share (rows, taps, pad, precision) in ONE launch, so that the
+ * chip is filled by output tiles of different layers instead of by split-K over rows (no atomics, deterministic).
+ * `dev_jobs` is a DEVICE array; tile0 = running sum of mt*nt over the preceding jobs (mt = ceil(m/128), nt = ceil(ca/64)),
+ * total_tiles = sum over all jobs. */
+typedef struct glowtts_wgrad_job {
+    const float *dy; const float *x; const float *xmask; float *dw; float *dbias;
+    int64_t lddy, ldx;
+    int m, ca, xpro, perm, perm_h;
+    int tile0, mt, nt;
+    int64_t reserved;
+} glowtts_wgrad_job;
+int glowtts_wgrad_grouped(const glowtts_wgrad_job *dev_jobs, int njobs, int total_tiles, int rows, int taps, int pad,
+                          int precision, int splits, int accumulate, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * One flow step of the decoder = Activation_Norm -> Invertible_1x1_Conv -> Affine_Coupling_Layer
  * (Modules.py:653-668 AIA), launched as one host call: forward (training, keeps the activations the
@@ -251,8 +265,11 @@ typedef struct glowtts_flow_grads {       /* backward outputs; weight grads are 
     const float *dlogdet;                 /* [B] dL/dlogdet */
     float *douts;                         /* [R][ldo] scratch (pad columns must be zero on entry) */
     float *dskip;                         /* [R][H] scratch */
-    float *dh[2];                         /* [R][H] scratch x2 */
-    float *dins;                          /* [R][ldin] scratch, ldin = in[0].npad */
+    float *dh[GLOWTTS_MAX_WN_LAYERS];     /* [R][H] d(WaveNet state entering layer l) * mask; may alias as a ping-pong pair
+                                             (dh[l] != dh[l+1]) unless defer_wgrad, which needs them all distinct */
+    float *dins[GLOWTTS_MAX_WN_LAYERS];   /* [R][ldin] PAIR-packed gate pre-activation grads (pad columns zero on entry);
+                                             may all alias unless defer_wgrad */
+    int defer_wgrad;                      /* 1: skip every weight-gradient launch (the caller runs glowtts_wgrad_grouped later) */
     float *scratch;                       /* glowtts_actnorm_stats_scratch_floats(R, C) floats */
     float *d_an;                          /* [2C+16] = dlogs, dbias, dW(inv-1x1) data terms (overwritten) */
     float *dw_start, *db_start;           /* [H][C/2][1], [H] */
