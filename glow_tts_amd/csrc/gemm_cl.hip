@@ -34,7 +34,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct alignas(16) Chunk16 { uint32_t w[4]; };
+typedef uint32_t Chunk16 __attribute__((ext_vector_type(4)));      // one 16-byte LDS slot (native vector: stays in VGPRs)
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -102,7 +102,21 @@ template <> struct Prec<__bf16> { static constexpr int KC = 32; static constexpr
 
 constexpr int MAX_TAPS = 5;
 
-template <typename CT, int MI, int NI, int WM, int WN, int EPI, bool T1>
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>); the register-set selection below
+// must be resolved by `if constexpr`, not by a run-time select, or the sets are demoted to scratch memory
+template <int V> struct IC { static constexpr int value = V; };
+template <int N> struct StaticFor {
+    template <class F> __device__ __forceinline__ static void run(F&& f) { StaticFor<N - 1>::run(f); f(IC<N - 1>{}); }
+};
+template <> struct StaticFor<0> { template <class F> __device__ __forceinline__ static void run(F&&) {} };
+
+// TAPS and APRO are compile-time so that the main loop is straight-line code with a FIXED number of global loads per
+// step: the compiler's s_waitcnt bookkeeping then emits counted waits (vmcnt(N), N > 0) and the loads issued for step
+// s+2 stay in flight across the MFMAs and the barrier of step s.  (With step-dependent `if (s + 2 < S) load` the counts
+// become path dependent and every wait degenerates to vmcnt(0): measured 1700 cycles per 256-cycle MFMA step.)
+// For the same reason every load is unconditional with a clamped address and is kept RAW in registers; validity
+// masks, the fp32->bf16 conversion and the A prologue are applied when the registers are written to LDS two steps later.
+template <typename CT, int MI, int NI, int WM, int WN, int EPI, int TAPS, int APRO>
 __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_conv_args pin)
 {
     glowtts_conv_args p = pin;
@@ -115,11 +129,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
         p.out0 += bz * p.out_bstride;
     }
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32, NT = WM * WN * 64;
-    constexpr int AROWS = BM + MAX_TAPS - 1;
+    constexpr int AROWS = BM + TAPS - 1;
     constexpr int KC = Prec<CT>::KC, E = Prec<CT>::E;          // channels per 64-B chunk / per 16-B slot
     constexpr bool EX = sizeof(CT) == 4;
     constexpr int A_IT = (AROWS * 4 + NT - 1) / NT;
     constexpr int W_IT = (BN * 4) / NT;
+    constexpr int NLD = (APRO == GLOWTTS_APRO_PAIRMUL) ? E / 2 : E / 4;      // float4 loads per 16-B LDS slot
+    constexpr bool T1 = (TAPS == 1);
     static_assert((BN * 4) % NT == 0, "weight tile must divide evenly");
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AROWS * 64 + 2 * BN * 64];
@@ -131,9 +147,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const int taps = T1 ? 1 : p.taps;               // T1: 1x1 convs (one step per K chunk)
-    const int arows = BM + taps - 1;
-    const int S = p.kchunks * taps;
+    const int KCH = p.kchunks;
+    const int S = KCH * TAPS;
+    const int pad = (TAPS - 1) / 2;
     const int l31 = lane & 31, lhi = lane >> 5;
 
     f32x16 acc[MI][NI];
@@ -144,86 +160,80 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    Chunk16 raA[A_IT], raB[A_IT], rwA[W_IT], rwB[W_IT];     // two register sets each: loads are issued two steps ahead
+    typedef float4 ARegs[A_IT][NLD];
+    typedef Chunk16 WRegs[W_IT];
+    ARegs raA, raB;
+    WRegs rwA, rwB;
 
-    // ---- staging: global -> registers ----
-    auto gload_a = [&](Chunk16 (&ra)[A_IT], int kc) {
+    // ---- global -> registers (raw, unconditional, clamped) ----
+    auto gload_a = [&](ARegs& ra, int kc) __attribute__((always_inline)) {
+        kc = min(kc, KCH - 1);
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int idx = tid + it * NT;
             const int row = idx >> 2, q = idx & 3;
-            float f[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) f[e] = 0.f;
-            const long g = (long)m0 - p.pad + row;
+            long g = (long)m0 - pad + row;
+            g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
             const int c = kc * KC + q * E;
-            if (row < arows && g >= 0 && g < p.rows && c < p.ca) {
-                if (p.apro == GLOWTTS_APRO_PAIRMUL) {
-                    const float* src = p.a + g * p.lda + 2 * c;
-                    if (c + E <= p.ca) {
+            const float* src;
+            if (APRO == GLOWTTS_APRO_PAIRMUL)      src = p.a + g * p.lda + min(2 * c, (int)p.lda - 2 * E);
+            else if (APRO == GLOWTTS_APRO_SQNEG)   src = p.a + g * p.lda + min(c < p.ca1 ? c : c - p.ca1, (int)p.lda - E);
+            else {
+                const bool second = (p.a2 != nullptr) && (c >= p.ca1);
+                const float* base = second ? p.a2 : p.a;
+                const long ld = second ? p.lda2 : p.lda;
+                src = base + g * ld + min(second ? c - p.ca1 : c, (int)ld - E);
+            }
 #pragma unroll
-                        for (int e = 0; e < E; e += 2) {
-                            const float4 v = *reinterpret_cast<const float4*>(src + 2 * e);
-                            f[e] = v.x * v.y;
-                            f[e + 1] = v.z * v.w;
-                        }
-                    } else {
-                        for (int e = 0; e < E && c + e < p.ca; ++e) f[e] = src[2 * e] * src[2 * e + 1];
-                    }
-                } else if (p.apro == GLOWTTS_APRO_SQNEG) {
-                    const bool sq = c < p.ca1;                      // ca1 is a multiple of E on this path
-                    const float* src = p.a + g * p.lda + (sq ? c : c - p.ca1);
+            for (int j = 0; j < NLD; ++j) ra[it][j] = *reinterpret_cast<const float4*>(src + 4 * j);
+        }
+    };
+    auto gload_w = [&](WRegs& rw, int s) __attribute__((always_inline)) {
+        s = min(s, S - 1);
+        const int kc = s / TAPS, t = s - kc * TAPS;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(p.w) + ((long)(t * KCH + kc) * p.npad + n0) * 64;
+        const int lim = (p.npad - n0) * 64 - 16;               // last valid 16-B piece of this tile's slab
 #pragma unroll
-                    for (int e = 0; e < E; e += 4) {
-                        const float4 v = *reinterpret_cast<const float4*>(src + e);
-                        f[e] = sq ? -0.5f * v.x * v.x : v.x; f[e + 1] = sq ? -0.5f * v.y * v.y : v.y;
-                        f[e + 2] = sq ? -0.5f * v.z * v.z : v.z; f[e + 3] = sq ? -0.5f * v.w * v.w : v.w;
-                    }
-                } else {
-                    const float* src;
-                    int lim;
-                    if (p.a2 != nullptr && c >= p.ca1) { src = p.a2 + g * p.lda2 + (c - p.ca1); lim = p.ca - c; }
-                    else                                { src = p.a + g * p.lda + c;            lim = p.ca1 - c; }
-                    if (lim >= E) {
+        for (int it = 0; it < W_IT; ++it) rw[it] = *reinterpret_cast<const Chunk16*>(base + min((tid + it * NT) * 16, lim));
+    };
+    // ---- registers -> LDS (mask, prologue, convert) ----
+    auto sstore_a = [&](const ARegs& ra, int buf, int kc) __attribute__((always_inline)) {
 #pragma unroll
-                        for (int e = 0; e < E; e += 4) {
-                            const float4 v = *reinterpret_cast<const float4*>(src + e);
-                            f[e] = v.x; f[e + 1] = v.y; f[e + 2] = v.z; f[e + 3] = v.w;
-                        }
-                    } else {
-                        for (int e = 0; e < E && e < lim; ++e) f[e] = src[e];
+        for (int it = 0; it < A_IT; ++it) {
+            const int idx = tid + it * NT;
+            const int row = idx >> 2, q = idx & 3;
+            if (row >= AROWS) continue;
+            const long g = (long)m0 - pad + row;
+            const int c = kc * KC + q * E;
+            const bool rowok = (g >= 0) && (g < p.rows) && (kc < KCH);
+            float f[E];
+            if (APRO == GLOWTTS_APRO_PAIRMUL) {
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) { f[2 * j] = ra[it][j].x * ra[it][j].y; f[2 * j + 1] = ra[it][j].z * ra[it][j].w; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) { f[4 * j] = ra[it][j].x; f[4 * j + 1] = ra[it][j].y; f[4 * j + 2] = ra[it][j].z; f[4 * j + 3] = ra[it][j].w; }
+                if (APRO == GLOWTTS_APRO_SQNEG) {
+                    if (c < p.ca1) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) f[e] = -0.5f * f[e] * f[e];
                     }
                 }
             }
+#pragma unroll
+            for (int e = 0; e < E; ++e) f[e] = (rowok && (c + e < p.ca)) ? f[e] : 0.f;
+            Chunk16 o;
             if constexpr (sizeof(CT) == 2) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ra[it].w[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);
+                for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ra[it].w[e] = __float_as_uint(f[e]);
+                for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(f[e]);
             }
+            *reinterpret_cast<Chunk16*>(As + buf * (AROWS * 64) + swz(row, q)) = o;
         }
     };
-    auto gload_w = [&](Chunk16 (&rw)[W_IT], int s) {
-        const int kc = s / taps, t = s - kc * taps;
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(p.w) + ((long)(t * p.kchunks + kc) * p.npad + n0) * 64;
-#pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
-            const int idx = tid + it * NT;
-            const int n = idx >> 2;
-            if (n0 + n < p.npad) rw[it] = *reinterpret_cast<const Chunk16*>(base + (long)idx * 16);
-            else { rw[it].w[0] = rw[it].w[1] = rw[it].w[2] = rw[it].w[3] = 0u; }
-        }
-    };
-    auto sstore_a = [&](const Chunk16 (&ra)[A_IT], int buf) {
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int idx = tid + it * NT;
-            const int row = idx >> 2, q = idx & 3;
-            if (row < AROWS) *reinterpret_cast<Chunk16*>(As + buf * (AROWS * 64) + swz(row, q)) = ra[it];
-        }
-    };
-    auto sstore_w = [&](const Chunk16 (&rw)[W_IT], int buf) {
+    auto sstore_w = [&](const WRegs& rw, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int idx = tid + it * NT;
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
     };
 
     // ---- MFMA over one (chunk, tap) step ----
-    auto compute = [&](int abuf, int wbuf, int tap) {
+    auto compute = [&](int abuf, int wbuf, int tap) __attribute__((always_inline)) {
         const unsigned char* Ab = As + abuf * (AROWS * 64);
         const unsigned char* Wb = Ws + wbuf * (BN * 64);
 #pragma unroll
@@ -256,56 +266,53 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                __uint_as_float(af[mi].w[e]), __uint_as_float(bfr[ni].w[e]), acc[mi][ni], 0, 0, 0);
+                                __uint_as_float(af[mi][e]), __uint_as_float(bfr[ni][e]), acc[mi][ni], 0, 0, 0);
                     }
                 }
         }
     };
 
-    // ---- main loop ----
-    // step s = (chunk kc, tap).  Weights: W(s+2) is loaded into registers while step s computes and W(s+1) (loaded during
-    // step s-1) is written to the other LDS buffer, so every global load has two compute phases to land.
-    // Activations: taps > 1: A(kc+1) is loaded at the first tap of chunk kc and written to LDS at its last tap;
-    //              taps == 1: same two-set scheme as the weights.
-    const int KCH = p.kchunks;
-    if constexpr (T1) {
-        auto step = [&](int s, Chunk16 (&w_load)[W_IT], const Chunk16 (&w_store)[W_IT], Chunk16 (&a_load)[A_IT], const Chunk16 (&a_store)[A_IT]) {
-            if (s + 2 < S) { gload_w(w_load, s + 2); gload_a(a_load, s + 2); }
-            compute(s & 1, s & 1, 0);
-            if (s + 1 < S) { sstore_w(w_store, (s + 1) & 1); sstore_a(a_store, (s + 1) & 1); }
-            __syncthreads();
-        };
-        gload_a(raA, 0);
-        gload_w(rwA, 0);
-        if (S > 1) { gload_w(rwB, 1); gload_a(raB, 1); }
-        sstore_a(raA, 0);
-        sstore_w(rwA, 0);
-        __syncthreads();
-        for (int s = 0; s < S; s += 2) {
-            step(s, rwA, rwB, raA, raB);
-            if (s + 1 < S) step(s + 1, rwB, rwA, raB, raA);
+    // ---- main loop: two K chunks (2*TAPS steps) per iteration so that every buffer / register-set index is static ----
+    gload_a(raA, 0);
+    gload_w(rwA, 0);
+    gload_w(rwB, 1);
+    if constexpr (T1) gload_a(raB, 1);
+    sstore_a(raA, 0, 0);
+    sstore_w(rwA, 0);
+    __syncthreads();
+    auto step = [&](WRegs& wl, const WRegs& ws, ARegs& al, const ARegs& as, int half, int par, int tap, int kc) __attribute__((always_inline)) {
+        const int s = kc * TAPS + tap;
+        gload_w(wl, s + 2);                                   // W(s+2) goes into the set that held W(s)
+        if constexpr (T1) {
+            gload_a(al, kc + 2);
+            if (kc < KCH) compute(half, par, 0);
+            sstore_w(ws, par ^ 1);                            // W(s+1), loaded during step s-1
+            sstore_a(as, half ^ 1, kc + 1);
+        } else {
+            if (tap == 0) gload_a(al, kc + 1);
+            if (kc < KCH) compute(half, par, tap);
+            sstore_w(ws, par ^ 1);
+            if (tap == TAPS - 1) sstore_a(al, half ^ 1, kc + 1);
         }
-    } else {
-        auto step = [&](int s, Chunk16 (&w_load)[W_IT], const Chunk16 (&w_store)[W_IT]) {
-            const int kc = s / taps, tap = s - kc * taps;
-            if (s + 2 < S) gload_w(w_load, s + 2);
-            if (tap == 0 && kc + 1 < KCH) gload_a(raA, kc + 1);
-            compute(kc & 1, s & 1, tap);
-            if (s + 1 < S) sstore_w(w_store, (s + 1) & 1);
-            if (tap == taps - 1 && kc + 1 < KCH) sstore_a(raA, (kc + 1) & 1);
-            __syncthreads();
-        };
-        gload_a(raA, 0);
-        gload_w(rwA, 0);
-        if (S > 1) gload_w(rwB, 1);
-        sstore_a(raA, 0);
-        sstore_w(rwA, 0);
         __syncthreads();
-        for (int s = 0; s < S; s += 2) {
-            step(s, rwA, rwB);
-            if (s + 1 < S) step(s + 1, rwB, rwA);
-        }
+    };
+    // explicit compile-time unrolling (u = step inside the two-chunk group); see STEP_U below
+#define STEP_U(U)                                                                                              \
+    if constexpr ((U) < 2 * TAPS) {                                                                            \
+        constexpr int half_ = (U) / TAPS, tap_ = (U) % TAPS;                                                   \
+        if constexpr (T1) {                                                                                    \
+            if constexpr ((U) & 1) step(rwB, rwA, raB, raA, half_, 1, tap_, kc2 + half_);                      \
+            else                   step(rwA, rwB, raA, raB, half_, 0, tap_, kc2 + half_);                      \
+        } else {                                                                                               \
+            if constexpr ((U) & 1) step(rwB, rwA, raA, raA, half_, 1, tap_, kc2 + half_);                      \
+            else                   step(rwA, rwB, raA, raA, half_, 0, tap_, kc2 + half_);                      \
+        }                                                                                                      \
     }
+    for (int kc2 = 0; kc2 < KCH; kc2 += 2) {
+        STEP_U(0) STEP_U(1) STEP_U(2) STEP_U(3) STEP_U(4) STEP_U(5) STEP_U(6) STEP_U(7) STEP_U(8) STEP_U(9)
+    }
+#undef STEP_U
+    static_assert(2 * TAPS <= 10, "extend the STEP_U list");
 
     // ---- fused epilogue ----
     // accumulator element: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31
@@ -398,34 +405,52 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
     }
 }
 
-template <typename CT, int MI, int NI, int WM, int WN, int EPI>
-int launch_cfg(const glowtts_conv_args& a, hipStream_t s)
+template <typename CT, int MI, int NI, int WM, int WN, int EPI, int TAPS, int APRO>
+int launch_k(const glowtts_conv_args& a, hipStream_t s)
 {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     dim3 grid((a.rows + BM - 1) / BM, (a.npad + BN - 1) / BN, a.batch > 1 ? a.batch : 1);
-    if (a.taps == 1) hipLaunchKernelGGL((conv_cl_kernel<CT, MI, NI, WM, WN, EPI, true>), grid, dim3(WM * WN * 64), 0, s, a);
-    else             hipLaunchKernelGGL((conv_cl_kernel<CT, MI, NI, WM, WN, EPI, false>), grid, dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((conv_cl_kernel<CT, MI, NI, WM, WN, EPI, TAPS, APRO>), grid, dim3(WM * WN * 64), 0, s, a);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
-template <typename CT, int EPI>
-int launch_epi(const glowtts_conv_args& a, hipStream_t s)
+template <typename CT, int EPI, int TAPS, int APRO>
+int launch_tile(const glowtts_conv_args& a, hipStream_t s)
 {
     // tile choice: 128x128 by default; 64-row tiles when that is needed to put >= ~256 workgroups on the chip
     const long tiles128 = (long)((a.rows + 127) / 128) * ((a.npad + 127) / 128) * (a.batch > 1 ? a.batch : 1);
-    if (tiles128 >= 256) return launch_cfg<CT, 2, 2, 2, 2, EPI>(a, s);
-    return launch_cfg<CT, 1, 2, 2, 2, EPI>(a, s);
+    if (tiles128 >= 256) return launch_k<CT, 2, 2, 2, 2, EPI, TAPS, APRO>(a, s);
+    return launch_k<CT, 1, 2, 2, 2, EPI, TAPS, APRO>(a, s);
 }
 
+template <typename CT, int EPI, int APRO>
+int launch_taps(const glowtts_conv_args& a, hipStream_t s)
+{
+    switch (a.taps) {
+        case 1: return launch_tile<CT, EPI, 1, APRO>(a, s);
+        case 3: return launch_tile<CT, EPI, 3, APRO>(a, s);
+        case 5: return launch_tile<CT, EPI, 5, APRO>(a, s);
+        default: return GLOWTTS_E_ARG;
+    }
+}
+
+// the (epilogue, prologue, taps) combinations the Glow-TTS path uses; anything else is rejected
 template <typename CT>
 int launch_prec(const glowtts_conv_args& a, hipStream_t s)
 {
+    const int N = GLOWTTS_APRO_NONE, PM = GLOWTTS_APRO_PAIRMUL;
     switch (a.epi) {
-        case GLOWTTS_EPI_LINEAR:  return launch_epi<CT, GLOWTTS_EPI_LINEAR>(a, s);
-        case GLOWTTS_EPI_GATE:    return launch_epi<CT, GLOWTTS_EPI_GATE>(a, s);
-        case GLOWTTS_EPI_RESSKIP: return launch_epi<CT, GLOWTTS_EPI_RESSKIP>(a, s);
-        case GLOWTTS_EPI_COUPLE:  return launch_epi<CT, GLOWTTS_EPI_COUPLE>(a, s);
-        case GLOWTTS_EPI_DGATE:   return launch_epi<CT, GLOWTTS_EPI_DGATE>(a, s);
+        case GLOWTTS_EPI_LINEAR:
+            if (a.apro == N) return launch_taps<CT, GLOWTTS_EPI_LINEAR, GLOWTTS_APRO_NONE>(a, s);
+            if (a.apro == PM && a.taps == 1) return launch_tile<CT, GLOWTTS_EPI_LINEAR, 1, GLOWTTS_APRO_PAIRMUL>(a, s);
+            if constexpr (sizeof(CT) == 4) {
+                if (a.apro == GLOWTTS_APRO_SQNEG && a.taps == 1) return launch_tile<CT, GLOWTTS_EPI_LINEAR, 1, GLOWTTS_APRO_SQNEG>(a, s);
+            }
+            return GLOWTTS_E_ARG;
+        case GLOWTTS_EPI_GATE:    return a.apro == N ? launch_taps<CT, GLOWTTS_EPI_GATE, GLOWTTS_APRO_NONE>(a, s) : GLOWTTS_E_ARG;
+        case GLOWTTS_EPI_RESSKIP: return (a.apro == PM && a.taps == 1) ? launch_tile<CT, GLOWTTS_EPI_RESSKIP, 1, GLOWTTS_APRO_PAIRMUL>(a, s) : GLOWTTS_E_ARG;
+        case GLOWTTS_EPI_COUPLE:  return (a.apro == N && a.taps == 1) ? launch_tile<CT, GLOWTTS_EPI_COUPLE, 1, GLOWTTS_APRO_NONE>(a, s) : GLOWTTS_E_ARG;
+        case GLOWTTS_EPI_DGATE:   return (a.apro == N && a.taps == 1) ? launch_tile<CT, GLOWTTS_EPI_DGATE, 1, GLOWTTS_APRO_NONE>(a, s) : GLOWTTS_E_ARG;
         default: return GLOWTTS_E_ARG;
     }
 }
@@ -473,6 +498,13 @@ extern "C" int glowtts_conv_cl(const glowtts_conv_args* args, void* stream)
     if (!a.a2 && a.apro != GLOWTTS_APRO_SQNEG) a.ca1 = a.ca;
     if (a.apro == GLOWTTS_APRO_SQNEG && ((a.ca1 % (a.precision == GLOWTTS_BF16 ? 8 : 4)) || a.ca != 2 * a.ca1)) return GLOWTTS_E_ARG;
     if ((a.flags & GLOWTTS_F_COLMASK) && !a.ncols_valid) return GLOWTTS_E_ARG;
+    {   // loads are unconditional 16-byte vectors: rows must be wide enough for the last (possibly partial) K slot
+        const int E = a.precision == GLOWTTS_BF16 ? 8 : 4;
+        if ((a.ca & 3) || a.kchunks * (a.precision == GLOWTTS_BF16 ? 32 : 16) < a.ca) return GLOWTTS_E_ARG;
+        if (a.apro == GLOWTTS_APRO_PAIRMUL) { if (a.lda < 2 * E) return GLOWTTS_E_ARG; }
+        else if (a.lda < E || (a.a2 && a.lda2 < E)) return GLOWTTS_E_ARG;
+        if (a.a2 && (a.ca1 % E)) return GLOWTTS_E_ARG;
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.precision == GLOWTTS_BF16) return launch_prec<__bf16>(a, s);
     if (a.precision == GLOWTTS_F32) return launch_prec<float>(a, s);

@@ -39,8 +39,16 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
 
 struct WCommon { int rows, pad, accumulate, njobs; };
 
+// pointers that come out of the device job table are "generic" to the compiler, which would emit flat_load (counted on
+// BOTH vmcnt and lgkmcnt, i.e. every LDS wait would also drain the prefetch).  They are global: say so.
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg4(const float* p) {
+    const f32x4n v = *(const f32x4n __attribute__((address_space(1)))*)(p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // job of this workgroup: p (by value when there is a single problem, else looked up in the device table by tile index)
-template <typename CT, int TAPS>
+template <typename CT, int TAPS, int XPRO>
 __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job single, const glowtts_wgrad_job* __restrict__ table, const WCommon cm)
 {
     glowtts_wgrad_job p = single;
@@ -81,88 +89,79 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][t][r] = 0.f;
 
-    // ---- staging registers ----
+    // ---- staging: raw unconditional loads (clamped addresses) two steps ahead; masks / prologue / bf16 conversion at the
+    //      LDS store (same reasoning as conv_cl_kernel: a fixed number of loads per step keeps the vmcnt waits counted) ----
     constexpr int DY_IT = (BK * BMO / 4) / 256;               // float4 per thread for the DY tile (= 4)
-    constexpr int X_IT = (XROWS * BNC / 4 + 255) / 256;       // float4 per thread for the X tile
-    float4 rdyA[DY_IT], rxA[X_IT], rdyB[DY_IT], rxB[X_IT];      // two register sets: loads are issued two steps ahead
+    constexpr int X_IT = (XROWS * BNC / 4 + 255) / 256;       // 4-channel groups per thread for the X tile
+    constexpr int XL = (XPRO == GLOWTTS_APRO_PAIRMUL) ? 2 : 1;
+    typedef float4 DYRegs[DY_IT];
+    typedef float4 XRegs[X_IT][XL];
+    DYRegs rdyA, rdyB;
+    XRegs rxA, rxB;
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     const bool want_bias = (p.dbias != nullptr) && (tile_c == 0);
+    const int lim_dy = (int)p.lddy - 4;
+    const int lim_x = (int)p.ldx - 4 * XL;
 
-    auto gload = [&](float4 (&rdy)[DY_IT], float4 (&rx)[X_IT], long r0) {
+    auto gload = [&](DYRegs& rdy, XRegs& rx, long r0) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < DY_IT; ++it) {
             const int idx = tid + it * 256;
             const int row = idx / (BMO / 4), c4 = idx % (BMO / 4);
-            const long r = r0 + row;
-            const int col = o0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < rend && col < p.m) {
-                const float* src = p.dy + r * p.lddy + col;
-                if (col + 4 <= p.m) v = *reinterpret_cast<const float4*>(src);
-                else { v.x = src[0]; if (col + 1 < p.m) v.y = src[1]; if (col + 2 < p.m) v.z = src[2]; }
-            }
-            rdy[it] = v;
-            bsum[0] += v.x; bsum[1] += v.y; bsum[2] += v.z; bsum[3] += v.w;
+            const long r = min(r0 + row, (long)cm.rows - 1);
+            rdy[it] = ldg4(p.dy + r * p.lddy + min(o0 + c4 * 4, lim_dy));
         }
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
             const int idx = tid + it * 256;
             const int row = idx / (BNC / 4), c4 = idx % (BNC / 4);
-            const long r = r0 + row - cm.pad;
-            const int col = c0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            // rows outside [0, rows) are zero; rows outside this split's range ARE read (halo of the split)
-            if (row < XROWS && r >= 0 && r < cm.rows && col < p.ca) {
-                if (p.xpro == GLOWTTS_APRO_PAIRMUL) {
-                    const float* src = p.x + r * p.ldx + 2 * col;
-                    if (col + 4 <= p.ca) {
-                        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-                        v = make_float4(a.x * a.y, a.z * a.w, b.x * b.y, b.z * b.w);
-                    } else {
-                        v.x = src[0] * src[1];
-                        if (col + 1 < p.ca) v.y = src[2] * src[3];
-                        if (col + 2 < p.ca) v.z = src[4] * src[5];
-                    }
-                } else {
-                    const float* src = p.x + r * p.ldx + col;
-                    if (col + 4 <= p.ca) v = *reinterpret_cast<const float4*>(src);
-                    else { v.x = src[0]; if (col + 1 < p.ca) v.y = src[1]; if (col + 2 < p.ca) v.z = src[2]; }
-                }
-                if (p.xmask) { const float m = p.xmask[r]; v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
-            }
-            rx[it] = v;
+            long r = r0 + row - cm.pad;
+            r = r < 0 ? 0 : (r >= cm.rows ? cm.rows - 1 : r);
+            const float* src = p.x + r * p.ldx + min((c0 + c4 * 4) * XL, lim_x);
+#pragma unroll
+            for (int j = 0; j < XL; ++j) rx[it][j] = ldg4(src + 4 * j);
         }
     };
-    auto sstore = [&](const float4 (&rdy)[DY_IT], const float4 (&rx)[X_IT], int buf) {
+    auto sstore = [&](const DYRegs& rdy, const XRegs& rx, int buf, long r0) __attribute__((always_inline)) {
         unsigned char* dyb = smem + buf * (DY_BYTES + X_BYTES);
         unsigned char* xb = dyb + DY_BYTES;
 #pragma unroll
         for (int it = 0; it < DY_IT; ++it) {
             const int idx = tid + it * 256;
             const int row = idx / (BMO / 4), c4 = idx % (BMO / 4);
+            const bool ok = (r0 + row < rend) && (o0 + c4 * 4 < p.m);            // m is a multiple of 4 (checked on the host)
+            float4 v = rdy[it];
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+            bsum[0] += v.x; bsum[1] += v.y; bsum[2] += v.z; bsum[3] += v.w;
             if constexpr (ES == 2) {
-                uint2 w = make_uint2(pk_bf16(rdy[it].x, rdy[it].y), pk_bf16(rdy[it].z, rdy[it].w));
+                uint2 w = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
                 *reinterpret_cast<uint2*>(dyb + row * LDY + c4 * 8) = w;
             } else {
-                *reinterpret_cast<float4*>(dyb + row * LDY + c4 * 16) = rdy[it];
+                *reinterpret_cast<float4*>(dyb + row * LDY + c4 * 16) = v;
             }
         }
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
             const int idx = tid + it * 256;
             const int row = idx / (BNC / 4), c4 = idx % (BNC / 4);
-            if (row < XROWS) {
-                if constexpr (ES == 2) {
-                    uint2 w = make_uint2(pk_bf16(rx[it].x, rx[it].y), pk_bf16(rx[it].z, rx[it].w));
-                    *reinterpret_cast<uint2*>(xb + row * LDX + c4 * 8) = w;
-                } else {
-                    *reinterpret_cast<float4*>(xb + row * LDX + c4 * 16) = rx[it];
-                }
+            if (row >= XROWS) continue;
+            const long r = r0 + row - cm.pad;
+            // rows outside [0, rows) are zero; rows outside this split's range ARE used (halo of the split)
+            const bool ok = (r >= 0) && (r < cm.rows) && (c0 + c4 * 4 < p.ca);  // ca is a multiple of 4 (checked on the host)
+            float4 v;
+            if (XPRO == GLOWTTS_APRO_PAIRMUL) v = make_float4(rx[it][0].x * rx[it][0].y, rx[it][0].z * rx[it][0].w, rx[it][XL - 1].x * rx[it][XL - 1].y, rx[it][XL - 1].z * rx[it][XL - 1].w);
+            else v = rx[it][0];
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+            if constexpr (ES == 2) {
+                uint2 w = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+                *reinterpret_cast<uint2*>(xb + row * LDX + c4 * 8) = w;
+            } else {
+                *reinterpret_cast<float4*>(xb + row * LDX + c4 * 16) = v;
             }
         }
     };
 
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const unsigned char* dyb = smem + buf * (DY_BYTES + X_BYTES);
         const unsigned char* xb = dyb + DY_BYTES;
         if constexpr (ES == 2) {
@@ -213,21 +212,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
         }
     };
 
+    // two steps per iteration so that the register sets are selected at compile time; every load is unconditional
+    // (rows past the end are clamped, their contribution is masked to zero when stored)
     gload(rdyA, rxA, rbeg);
-    if (nsteps > 1) gload(rdyB, rxB, rbeg + BK);
-    sstore(rdyA, rxA, 0);
+    gload(rdyB, rxB, rbeg + BK);
+    sstore(rdyA, rxA, 0, rbeg);
     __syncthreads();
     for (int s = 0; s < nsteps; s += 2) {
-        if (s + 2 < nsteps) gload(rdyA, rxA, rbeg + (long)(s + 2) * BK);
-        compute(s & 1);
-        if (s + 1 < nsteps) sstore(rdyB, rxB, (s + 1) & 1);
+        const long rs = rbeg + (long)s * BK;
+        gload(rdyA, rxA, rs + 2 * BK);
+        compute(0);
+        sstore(rdyB, rxB, 1, rs + BK);
         __syncthreads();
-        if (s + 1 < nsteps) {
-            if (s + 3 < nsteps) gload(rdyB, rxB, rbeg + (long)(s + 3) * BK);
-            compute((s + 1) & 1);
-            if (s + 2 < nsteps) sstore(rdyA, rxA, (s + 2) & 1);
-            __syncthreads();
-        }
+        gload(rdyB, rxB, rs + 3 * BK);
+        if (s + 1 < nsteps) compute(1);
+        sstore(rdyA, rxA, 0, rs + 2 * BK);
+        __syncthreads();
     }
 
     // ---- epilogue: dW[o][c][t] ----
@@ -278,16 +278,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
     }
 }
 
-template <typename CT>
-int launch_w(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const WCommon& cm, int taps, dim3 grid, hipStream_t s)
+template <typename CT, int XPRO>
+int launch_x(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const WCommon& cm, int taps, dim3 grid, hipStream_t s)
 {
     switch (taps) {
-        case 1: hipLaunchKernelGGL((wgrad_kernel<CT, 1>), grid, dim3(256), 0, s, one, table, cm); break;
-        case 3: hipLaunchKernelGGL((wgrad_kernel<CT, 3>), grid, dim3(256), 0, s, one, table, cm); break;
-        case 5: hipLaunchKernelGGL((wgrad_kernel<CT, 5>), grid, dim3(256), 0, s, one, table, cm); break;
+        case 1: hipLaunchKernelGGL((wgrad_kernel<CT, 1, XPRO>), grid, dim3(256), 0, s, one, table, cm); break;
+        case 3: hipLaunchKernelGGL((wgrad_kernel<CT, 3, XPRO>), grid, dim3(256), 0, s, one, table, cm); break;
+        case 5: hipLaunchKernelGGL((wgrad_kernel<CT, 5, XPRO>), grid, dim3(256), 0, s, one, table, cm); break;
         default: return GLOWTTS_E_ARG;
     }
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+// all jobs of one launch share the X prologue (`xpro`): grouped launches are formed per (taps, xpro)
+template <typename CT>
+int launch_w(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const WCommon& cm, int taps, int xpro, dim3 grid, hipStream_t s)
+{
+    if (xpro == GLOWTTS_APRO_PAIRMUL) return launch_x<CT, GLOWTTS_APRO_PAIRMUL>(one, table, cm, taps, grid, s);
+    if (xpro == GLOWTTS_APRO_NONE) return launch_x<CT, GLOWTTS_APRO_NONE>(one, table, cm, taps, grid, s);
+    return GLOWTTS_E_ARG;
 }
 
 }  // namespace
@@ -312,13 +320,15 @@ extern "C" int glowtts_wgrad_cl(const glowtts_wgrad_args* args, void* stream)
     WCommon cm{a.rows, a.pad, a.accumulate, 1};
     dim3 grid(tiles, 1, splits);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (a.precision == GLOWTTS_BF16) return launch_w<__bf16>(j, nullptr, cm, a.taps, grid, s);
-    if (a.precision == GLOWTTS_F32) return launch_w<float>(j, nullptr, cm, a.taps, grid, s);
+    if (a.xmask) return GLOWTTS_E_ARG;          // reserved: X row masks must be applied by the producer
+    if ((a.m & 3) || (a.ca & 3) || a.lddy < 4 || a.ldx < (a.xpro == GLOWTTS_APRO_PAIRMUL ? 8 : 4)) return GLOWTTS_E_ARG;
+    if (a.precision == GLOWTTS_BF16) return launch_w<__bf16>(j, nullptr, cm, a.taps, a.xpro, grid, s);
+    if (a.precision == GLOWTTS_F32) return launch_w<float>(j, nullptr, cm, a.taps, a.xpro, grid, s);
     return GLOWTTS_E_ARG;
 }
 
 extern "C" int glowtts_wgrad_grouped(const glowtts_wgrad_job* dev_jobs, int njobs, int total_tiles, int rows, int taps, int pad,
-                                     int precision, int splits, int accumulate, void* stream)
+                                     int xpro, int precision, int splits, int accumulate, void* stream)
 {
     if (!dev_jobs || njobs < 1 || total_tiles < 1 || rows < 1) return GLOWTTS_E_ARG;
     if (splits < 1) splits = 1;
@@ -328,7 +338,7 @@ extern "C" int glowtts_wgrad_grouped(const glowtts_wgrad_job* dev_jobs, int njob
     WCommon cm{rows, pad, accumulate, njobs};
     dim3 grid(total_tiles, 1, splits);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (precision == GLOWTTS_BF16) return launch_w<__bf16>(dummy, dev_jobs, cm, taps, grid, s);
-    if (precision == GLOWTTS_F32) return launch_w<float>(dummy, dev_jobs, cm, taps, grid, s);
+    if (precision == GLOWTTS_BF16) return launch_w<__bf16>(dummy, dev_jobs, cm, taps, xpro, grid, s);
+    if (precision == GLOWTTS_F32) return launch_w<float>(dummy, dev_jobs, cm, taps, xpro, grid, s);
     return GLOWTTS_E_ARG;
 }

@@ -70,7 +70,7 @@ def _L():
         L.glowtts_flow_forward.argtypes = [c_void_p] * 4
         L.glowtts_flow_inverse.argtypes = [c_void_p] * 4
         L.glowtts_flow_backward.argtypes = [c_void_p] * 5
-        L.glowtts_wgrad_grouped.argtypes = [c_void_p] + [c_int] * 8 + [c_void_p]
+        L.glowtts_wgrad_grouped.argtypes = [c_void_p] + [c_int] * 9 + [c_void_p]
         L.glowtts_decoder_logdet.argtypes = [c_void_p, c_i64] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]
         _declared = True
     return L
@@ -87,11 +87,12 @@ class WgradJob(ctypes.Structure):
 class WgradGroup:
     """Collects weight-gradient problems sharing (rows, taps) and runs them as ONE glowtts_wgrad_grouped launch."""
 
-    def __init__(self, rows, taps, precision):
-        self.rows, self.taps, self.precision = rows, taps, precision
+    def __init__(self, rows, taps, precision, xpro=ops.APRO_NONE):
+        self.rows, self.taps, self.precision, self.xpro = rows, taps, precision, xpro
         self.jobs, self.tiles = [], 0
 
-    def add(self, dy, lddy, m, x, ldx, ca, dw, dbias, xpro=ops.APRO_NONE, perm=ops.PERM_NONE, perm_h=0):
+    def add(self, dy, lddy, m, x, ldx, ca, dw, dbias, perm=ops.PERM_NONE, perm_h=0):
+        xpro = self.xpro
         j = WgradJob()
         j.dy, j.x, j.dw, j.dbias, j.lddy, j.ldx = dy, x, dw, dbias, lddy, ldx
         j.m, j.ca, j.xpro, j.perm, j.perm_h = m, ca, xpro, perm, perm_h
@@ -106,7 +107,7 @@ class WgradGroup:
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self.table = host.to(device, non_blocking=False)          # kept alive until the stream has consumed it
         _lib.check(_L().glowtts_wgrad_grouped(self.table.data_ptr(), len(self.jobs), self.tiles, self.rows, self.taps, (self.taps - 1) // 2,
-                                              self.precision, 1, 0, _lib.stream()), "glowtts_wgrad_grouped")
+                                              self.xpro, self.precision, 1, 0, _lib.stream()), "glowtts_wgrad_grouped")
 
 
 class PackedBatch:
@@ -376,8 +377,9 @@ class DecoderFunction(torch.autograd.Function):
         scratch = torch.empty(L.glowtts_actnorm_stats_scratch_floats(R, C), device=dev)
         dcond = torch.zeros_like(prep.cond) if prep.cond is not None else None
         dims = _dims(cfg, B, T)
-        gk = WgradGroup(R, cfg.k, cfg.precision)
-        g1 = gk if cfg.k == 1 else WgradGroup(R, 1, cfg.precision)
+        gk = WgradGroup(R, cfg.k, cfg.precision)                        # In_l (k taps)
+        g1 = gk if cfg.k == 1 else WgradGroup(R, 1, cfg.precision)      # Start / End (1x1)
+        gp = WgradGroup(R, 1, cfg.precision, ops.APRO_PAIRMUL)          # Res_Skip_l (1x1 on tanh*sigmoid)
         C2 = C // 2
         for f in range(F_ - 1, -1, -1):
             g = FlowGrads()
@@ -396,17 +398,17 @@ class DecoderFunction(torch.autograd.Function):
             for l in range(Lw):
                 gates = buf.gates[f, l].data_ptr()
                 if l == Lw - 1:
-                    g1.add(dskip[f].data_ptr(), H, H, gates, 2 * H, H, G["w_rs_last"][f].data_ptr(), G["b_rs_last"][f].data_ptr(), xpro=ops.APRO_PAIRMUL)
+                    gp.add(dskip[f].data_ptr(), H, H, gates, 2 * H, H, G["w_rs_last"][f].data_ptr(), G["b_rs_last"][f].data_ptr())
                 else:
-                    g1.add(dh[f, l + 1].data_ptr(), H, H, gates, 2 * H, H, G["w_rs"][f, l].data_ptr(), G["b_rs"][f, l].data_ptr(), xpro=ops.APRO_PAIRMUL)
-                    g1.add(dskip[f].data_ptr(), H, H, gates, 2 * H, H, G["w_rs"][f, l].data_ptr() + 4 * H * H, G["b_rs"][f, l].data_ptr() + 4 * H,
-                           xpro=ops.APRO_PAIRMUL)
+                    gp.add(dh[f, l + 1].data_ptr(), H, H, gates, 2 * H, H, G["w_rs"][f, l].data_ptr(), G["b_rs"][f, l].data_ptr())
+                    gp.add(dskip[f].data_ptr(), H, H, gates, 2 * H, H, G["w_rs"][f, l].data_ptr() + 4 * H * H, G["b_rs"][f, l].data_ptr() + 4 * H)
                 gk.add(dins[f, l].data_ptr(), prep.ldin, prep.ldin, buf.hs[f, l].data_ptr(), H, H, G["w_in"][f, l].data_ptr(), G["b_in"][f, l].data_ptr(),
                        perm=ops.PERM_PAIR, perm_h=H)
             g1.add(dh[f, 0].data_ptr(), H, H, buf.xmid[f].data_ptr(), C, C2, G["w_start"][f].data_ptr(), G["b_start"][f].data_ptr())
         gk.launch(dev)
         if g1 is not gk:
             g1.launch(dev)
+        gp.launch(dev)
         # log-determinant terms of the parameters (Modules.py:694, 747): logdet_b += (sum logs + logdet(W) C/4) * len_b
         lens = rowmask.view(B, -1).sum(1)
         s = (dld * lens).sum()

@@ -217,8 +217,9 @@ typedef struct glowtts_wgrad_job {
     int tile0, mt, nt;
     int64_t reserved;
 } glowtts_wgrad_job;
+/* every job of one launch uses the same X prologue `xpro` (job.xpro is ignored); m and ca must be multiples of 4 */
 int glowtts_wgrad_grouped(const glowtts_wgrad_job *dev_jobs, int njobs, int total_tiles, int rows, int taps, int pad,
-                          int precision, int splits, int accumulate, void *stream);
+                          int xpro, int precision, int splits, int accumulate, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * One flow step of the decoder = Activation_Norm -> Invertible_1x1_Conv -> Affine_Coupling_Layer
