@@ -26,6 +26,7 @@
 //     coupling, gate derivative (see GLOWTTS_EPI_*).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/glowtts_hip.h"
 
 namespace {
@@ -48,11 +49,12 @@ __device__ __forceinline__ int swz(int row, int q) { return row * 64 + ((q ^ ((r
 
 // EXACT = f32 mode: libm-grade transcendental functions; bf16 mode: hardware exp (v_exp_f32)
 template <bool EXACT> __device__ __forceinline__ float exp_(float x) { return EXACT ? expf(x) : __expf(x); }
-template <bool EXACT> __device__ __forceinline__ float sigmoid_(float x) { return 1.f / (1.f + exp_<EXACT>(-x)); }
+template <bool EXACT> __device__ __forceinline__ float rcp_(float x) { return EXACT ? 1.f / x : __builtin_amdgcn_rcpf(x); }
+template <bool EXACT> __device__ __forceinline__ float sigmoid_(float x) { return rcp_<EXACT>(1.f + exp_<EXACT>(-x)); }
 template <bool EXACT> __device__ __forceinline__ float tanh_(float x) {
     if (EXACT) return tanhf(x);
     const float e = __expf(2.f * x);          // tanh(x) = 1 - 2 / (exp(2x) + 1)
-    return 1.f - 2.f / (e + 1.f);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -110,12 +112,15 @@ template <int N> struct StaticFor {
 };
 template <> struct StaticFor<0> { template <class F> __device__ __forceinline__ static void run(F&&) {} };
 
-// TAPS and APRO are compile-time so that the main loop is straight-line code with a FIXED number of global loads per
-// step: the compiler's s_waitcnt bookkeeping then emits counted waits (vmcnt(N), N > 0) and the loads issued for step
-// s+2 stay in flight across the MFMAs and the barrier of step s.  (With step-dependent `if (s + 2 < S) load` the counts
-// become path dependent and every wait degenerates to vmcnt(0): measured 1700 cycles per 256-cycle MFMA step.)
-// For the same reason every load is unconditional with a clamped address and is kept RAW in registers; validity
-// masks, the fp32->bf16 conversion and the A prologue are applied when the registers are written to LDS two steps later.
+// Pipeline ("super-steps").  TAPS and APRO are compile-time, so one super-step is straight-line code:
+//   * multi-tap conv (TAPS > 1): super-step = one 64-byte K chunk; the A tile [BM + TAPS - 1 rows] is staged once and shared
+//     by the TAPS sub-steps (a tap is a row offset), the TAPS weight tiles of the chunk are staged together.
+//   * 1x1 conv (TAPS == 1): super-step = NSUB consecutive K chunks, each with its own A and weight tile.
+//   Per super-step and wave: NSUB * 2 * MI * NI MFMAs (40 for the k=5 WaveNet conv) between ONE pair of barriers; LDS is
+//   single-buffered, the look-ahead lives in registers: every global load of super-step ss+1 is issued (unconditionally, with
+//   clamped addresses, kept raw) before the MFMAs of super-step ss, and is masked / converted / written to LDS after them.
+//   (History, measured on MI355X: per-tap steps with a barrier each ran ~1800 cycles per 256-cycle MFMA step; step-conditional
+//   loads additionally degrade every s_waitcnt to vmcnt(0).)
 template <typename CT, int MI, int NI, int WM, int WN, int EPI, int TAPS, int APRO>
 __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_conv_args pin)
 {
@@ -129,26 +134,43 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
         p.out0 += bz * p.out_bstride;
     }
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32, NT = WM * WN * 64;
+    constexpr bool T1 = (TAPS == 1);
+    constexpr int NSUB = T1 ? ((APRO == GLOWTTS_APRO_NONE) ? 3 : 2) : TAPS;   // sub-steps per super-step
+    constexpr int NAT = T1 ? NSUB : 1;                                        // A tiles per super-step
     constexpr int AROWS = BM + TAPS - 1;
     constexpr int KC = Prec<CT>::KC, E = Prec<CT>::E;          // channels per 64-B chunk / per 16-B slot
     constexpr bool EX = sizeof(CT) == 4;
     constexpr int A_IT = (AROWS * 4 + NT - 1) / NT;
     constexpr int W_IT = (BN * 4) / NT;
     constexpr int NLD = (APRO == GLOWTTS_APRO_PAIRMUL) ? E / 2 : E / 4;      // float4 loads per 16-B LDS slot
-    constexpr bool T1 = (TAPS == 1);
+    constexpr int A_TILE = AROWS * 64, W_TILE = BN * 64;
     static_assert((BN * 4) % NT == 0, "weight tile must divide evenly");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AROWS * 64 + 2 * BN * 64];
-    unsigned char* As = smem;                         // [2][AROWS][64]
-    unsigned char* Ws = smem + 2 * AROWS * 64;        // [2][BN][64]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NAT * A_TILE + NSUB * W_TILE];
+    unsigned char* As = smem;                         // [NAT][AROWS][64]
+    unsigned char* Ws = smem + NAT * A_TILE;          // [NSUB][BN][64]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // 1-D grid.  Workgroup b runs on XCD b % 8 (observed dispatch order): give every XCD a contiguous range of tiles with the
+    // N tile fastest, so the workgroups that share an A row block (and its halo) hit the same L2.  Speed only, never correctness.
+    int m_tile, n_tile;
+    {
+        const int gy = (p.npad + BN - 1) / BN;
+        const int total = gridDim.x, lin = blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = lin & 7, j = lin >> 3;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        n_tile = t % gy; m_tile = t / gy;
+    }
+    const int m0 = m_tile * BM;
+    const int n0 = n_tile * BN;
     const int KCH = p.kchunks;
-    const int S = KCH * TAPS;
+    const int NSS = T1 ? (KCH + NSUB - 1) / NSUB : KCH;        // super-steps
+    // All workgroups of a launch read the SAME weight tiles; started in lock-step they would all hit the same L2 channel at
+    // the same moment (measured: ~2 us per super-step).  Each workgroup therefore walks the K chunks in a rotated order.
+    const int rot = (int)((m_tile * 5 + n_tile * 3) % NSS);
+    auto ssmap = [&](int ss) __attribute__((always_inline)) { int v = ss + rot; return v >= NSS ? v - NSS : v; };
     const int pad = (TAPS - 1) / 2;
     const int l31 = lane & 31, lhi = lane >> 5;
 
@@ -162,57 +184,68 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
 
     typedef float4 ARegs[A_IT][NLD];
     typedef Chunk16 WRegs[W_IT];
-    ARegs raA, raB;
-    WRegs rwA, rwB;
+    ARegs ra[NAT];
+    WRegs rw[NSUB];
+
+    // ---- per-thread constants of the staging pattern ----
+    const float* arow[A_IT];        // clamped source row of each A item (first source)
+    const float* arow2[A_IT];       // second source (dual-source A), same row
+    bool aok[A_IT];                 // row inside [0, rows)
+    int woff[W_IT];                 // clamped byte offset inside a weight tile slab
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int row = (tid + it * NT) >> 2;
+        const long g = (long)m0 - pad + row;
+        aok[it] = (g >= 0) && (g < p.rows) && (row < AROWS);
+        const long gc = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
+        arow[it] = p.a + gc * p.lda;
+        arow2[it] = p.a2 ? p.a2 + gc * p.lda2 : arow[it];
+    }
+    {
+        const int lim = (p.npad - n0) * 64 - 16;               // last valid 16-B piece of this tile's slab
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) woff[it] = min((tid + it * NT) * 16, lim);
+    }
 
     // ---- global -> registers (raw, unconditional, clamped) ----
-    auto gload_a = [&](ARegs& ra, int kc) __attribute__((always_inline)) {
+    auto gload_a = [&](ARegs& r, int kc) __attribute__((always_inline)) {
         kc = min(kc, KCH - 1);
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int idx = tid + it * NT;
-            const int row = idx >> 2, q = idx & 3;
-            long g = (long)m0 - pad + row;
-            g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
-            const int c = kc * KC + q * E;
+            const int c = kc * KC + ((tid + it * NT) & 3) * E;
             const float* src;
-            if (APRO == GLOWTTS_APRO_PAIRMUL)      src = p.a + g * p.lda + min(2 * c, (int)p.lda - 2 * E);
-            else if (APRO == GLOWTTS_APRO_SQNEG)   src = p.a + g * p.lda + min(c < p.ca1 ? c : c - p.ca1, (int)p.lda - E);
+            if (APRO == GLOWTTS_APRO_PAIRMUL)      src = arow[it] + min(2 * c, (int)p.lda - 2 * E);
+            else if (APRO == GLOWTTS_APRO_SQNEG)   src = arow[it] + min(c < p.ca1 ? c : c - p.ca1, (int)p.lda - E);
             else {
                 const bool second = (p.a2 != nullptr) && (c >= p.ca1);
-                const float* base = second ? p.a2 : p.a;
-                const long ld = second ? p.lda2 : p.lda;
-                src = base + g * ld + min(second ? c - p.ca1 : c, (int)ld - E);
+                src = second ? arow2[it] + min(c - p.ca1, (int)p.lda2 - E) : arow[it] + min(c, (int)p.lda - E);
             }
 #pragma unroll
-            for (int j = 0; j < NLD; ++j) ra[it][j] = *reinterpret_cast<const float4*>(src + 4 * j);
+            for (int j = 0; j < NLD; ++j) r[it][j] = *reinterpret_cast<const float4*>(src + 4 * j);
         }
     };
-    auto gload_w = [&](WRegs& rw, int s) __attribute__((always_inline)) {
-        s = min(s, S - 1);
-        const int kc = s / TAPS, t = s - kc * TAPS;
+    auto gload_w = [&](WRegs& r, int kc, int t) __attribute__((always_inline)) {
+        kc = min(kc, KCH - 1);
         const unsigned char* base = reinterpret_cast<const unsigned char*>(p.w) + ((long)(t * KCH + kc) * p.npad + n0) * 64;
-        const int lim = (p.npad - n0) * 64 - 16;               // last valid 16-B piece of this tile's slab
 #pragma unroll
-        for (int it = 0; it < W_IT; ++it) rw[it] = *reinterpret_cast<const Chunk16*>(base + min((tid + it * NT) * 16, lim));
+        for (int it = 0; it < W_IT; ++it) r[it] = *reinterpret_cast<const Chunk16*>(base + woff[it]);
     };
     // ---- registers -> LDS (mask, prologue, convert) ----
-    auto sstore_a = [&](const ARegs& ra, int buf, int kc) __attribute__((always_inline)) {
+    auto sstore_a = [&](const ARegs& r, int tile, int kc) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int idx = tid + it * NT;
             const int row = idx >> 2, q = idx & 3;
             if (row >= AROWS) continue;
-            const long g = (long)m0 - pad + row;
             const int c = kc * KC + q * E;
-            const bool rowok = (g >= 0) && (g < p.rows) && (kc < KCH);
+            const bool rowok = aok[it] && (kc < KCH);
             float f[E];
             if (APRO == GLOWTTS_APRO_PAIRMUL) {
 #pragma unroll
-                for (int j = 0; j < NLD; ++j) { f[2 * j] = ra[it][j].x * ra[it][j].y; f[2 * j + 1] = ra[it][j].z * ra[it][j].w; }
+                for (int j = 0; j < NLD; ++j) { f[2 * j] = r[it][j].x * r[it][j].y; f[2 * j + 1] = r[it][j].z * r[it][j].w; }
             } else {
 #pragma unroll
-                for (int j = 0; j < NLD; ++j) { f[4 * j] = ra[it][j].x; f[4 * j + 1] = ra[it][j].y; f[4 * j + 2] = ra[it][j].z; f[4 * j + 3] = ra[it][j].w; }
+                for (int j = 0; j < NLD; ++j) { f[4 * j] = r[it][j].x; f[4 * j + 1] = r[it][j].y; f[4 * j + 2] = r[it][j].z; f[4 * j + 3] = r[it][j].w; }
                 if (APRO == GLOWTTS_APRO_SQNEG) {
                     if (c < p.ca1) {
 #pragma unroll
@@ -230,28 +263,28 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(f[e]);
             }
-            *reinterpret_cast<Chunk16*>(As + buf * (AROWS * 64) + swz(row, q)) = o;
+            *reinterpret_cast<Chunk16*>(As + tile * A_TILE + swz(row, q)) = o;
         }
     };
-    auto sstore_w = [&](const WRegs& rw, int buf) __attribute__((always_inline)) {
+    auto sstore_w = [&](const WRegs& r, int tile) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int idx = tid + it * NT;
-            *reinterpret_cast<Chunk16*>(Ws + buf * (BN * 64) + swz(idx >> 2, idx & 3)) = rw[it];
+            *reinterpret_cast<Chunk16*>(Ws + tile * W_TILE + swz(idx >> 2, idx & 3)) = r[it];
         }
     };
 
-    // ---- MFMA over one (chunk, tap) step ----
-    auto compute = [&](int abuf, int wbuf, int tap) __attribute__((always_inline)) {
-        const unsigned char* Ab = As + abuf * (AROWS * 64);
-        const unsigned char* Wb = Ws + wbuf * (BN * 64);
+    // ---- MFMA over one sub-step: A tile `at` with row offset `roff`, weight tile `wt` ----
+    auto compute = [&](int at, int roff, int wt) __attribute__((always_inline)) {
+        const unsigned char* Ab = As + at * A_TILE;
+        const unsigned char* Wb = Ws + wt * W_TILE;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const int q = 2 * s2 + lhi;
             Chunk16 af[MI], bfr[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                af[mi] = *reinterpret_cast<const Chunk16*>(Ab + swz((wm * MI + mi) * 32 + l31 + tap, q));
+                af[mi] = *reinterpret_cast<const Chunk16*>(Ab + swz((wm * MI + mi) * 32 + l31 + roff, q));
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
                 bfr[ni] = *reinterpret_cast<const Chunk16*>(Wb + swz((wn * NI + ni) * 32 + l31, q));
@@ -272,49 +305,44 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
         }
     };
 
-    // ---- main loop: two K chunks (2*TAPS steps) per iteration so that every buffer / register-set index is static ----
-    gload_a(raA, 0);
-    gload_w(rwA, 0);
-    gload_w(rwB, 1);
-    if constexpr (T1) gload_a(raB, 1);
-    sstore_a(raA, 0, 0);
-    sstore_w(rwA, 0);
-    __syncthreads();
-    auto step = [&](WRegs& wl, const WRegs& ws, ARegs& al, const ARegs& as, int half, int par, int tap, int kc) __attribute__((always_inline)) {
-        const int s = kc * TAPS + tap;
-        gload_w(wl, s + 2);                                   // W(s+2) goes into the set that held W(s)
-        if constexpr (T1) {
-            gload_a(al, kc + 2);
-            if (kc < KCH) compute(half, par, 0);
-            sstore_w(ws, par ^ 1);                            // W(s+1), loaded during step s-1
-            sstore_a(as, half ^ 1, kc + 1);
-        } else {
-            if (tap == 0) gload_a(al, kc + 1);
-            if (kc < KCH) compute(half, par, tap);
-            sstore_w(ws, par ^ 1);
-            if (tap == TAPS - 1) sstore_a(al, half ^ 1, kc + 1);
+    // loads / stores / MFMAs of one super-step (all static after unrolling)
+    auto gload_ss = [&](int ss) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) {
+            if constexpr (T1) { gload_w(rw[j], ss * NSUB + j, 0); gload_a(ra[j], ss * NSUB + j); }
+            else              { gload_w(rw[j], ss, j); }
         }
-        __syncthreads();
+        if constexpr (!T1) gload_a(ra[0], ss);
     };
-    // explicit compile-time unrolling (u = step inside the two-chunk group); see STEP_U below
-#define STEP_U(U)                                                                                              \
-    if constexpr ((U) < 2 * TAPS) {                                                                            \
-        constexpr int half_ = (U) / TAPS, tap_ = (U) % TAPS;                                                   \
-        if constexpr (T1) {                                                                                    \
-            if constexpr ((U) & 1) step(rwB, rwA, raB, raA, half_, 1, tap_, kc2 + half_);                      \
-            else                   step(rwA, rwB, raA, raB, half_, 0, tap_, kc2 + half_);                      \
-        } else {                                                                                               \
-            if constexpr ((U) & 1) step(rwB, rwA, raA, raA, half_, 1, tap_, kc2 + half_);                      \
-            else                   step(rwA, rwB, raA, raA, half_, 0, tap_, kc2 + half_);                      \
-        }                                                                                                      \
+    auto sstore_ss = [&](int ss) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) {
+            sstore_w(rw[j], j);
+            if constexpr (T1) sstore_a(ra[j], j, ss * NSUB + j);
+        }
+        if constexpr (!T1) sstore_a(ra[0], 0, ss);
+    };
+    const int abl = p.flags >> 16;                            // debug ablation bits (tools/bench_conv.py)
+    gload_ss(ssmap(0));
+    sstore_ss(ssmap(0));
+    __syncthreads();
+    for (int ss = 0; ss < NSS; ++ss) {
+        const int cur = ssmap(ss), nxt = ssmap(ss + 1 < NSS ? ss + 1 : ss);
+        gload_ss(nxt);                                        // next super-step, in flight during the MFMAs below
+        if (!(abl & 2)) {
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j) {
+                if constexpr (T1) { if (cur * NSUB + j < KCH) compute(j, 0, j); }
+                else              compute(0, j, j);
+            }
+        }
+        __syncthreads();                                      // every wave is done reading the tiles
+        sstore_ss(nxt);
+        __syncthreads();
     }
-    for (int kc2 = 0; kc2 < KCH; kc2 += 2) {
-        STEP_U(0) STEP_U(1) STEP_U(2) STEP_U(3) STEP_U(4) STEP_U(5) STEP_U(6) STEP_U(7) STEP_U(8) STEP_U(9)
-    }
-#undef STEP_U
-    static_assert(2 * TAPS <= 10, "extend the STEP_U list");
 
     // ---- fused epilogue ----
+    if (abl & 1) { if (acc[0][0][0] == 12345.678f) p.out0[0] = 1.f; return; }
     // accumulator element: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31
     const int fl = p.flags;
 #pragma unroll
@@ -409,7 +437,7 @@ template <typename CT, int MI, int NI, int WM, int WN, int EPI, int TAPS, int AP
 int launch_k(const glowtts_conv_args& a, hipStream_t s)
 {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
-    dim3 grid((a.rows + BM - 1) / BM, (a.npad + BN - 1) / BN, a.batch > 1 ? a.batch : 1);
+    dim3 grid(((a.rows + BM - 1) / BM) * ((a.npad + BN - 1) / BN), 1, a.batch > 1 ? a.batch : 1);
     hipLaunchKernelGGL((conv_cl_kernel<CT, MI, NI, WM, WN, EPI, TAPS, APRO>), grid, dim3(WM * WN * 64), 0, s, a);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
@@ -419,7 +447,8 @@ int launch_tile(const glowtts_conv_args& a, hipStream_t s)
 {
     // tile choice: 128x128 by default; 64-row tiles when that is needed to put >= ~256 workgroups on the chip
     const long tiles128 = (long)((a.rows + 127) / 128) * ((a.npad + 127) / 128) * (a.batch > 1 ? a.batch : 1);
-    if (tiles128 >= 256) return launch_k<CT, 2, 2, 2, 2, EPI, TAPS, APRO>(a, s);
+    static const int force = [] { const char* e = getenv("GLOWTTS_TILE_M"); return e ? atoi(e) : 0; }();   // tuning override
+    if (force == 128 || (force != 64 && tiles128 >= 256)) return launch_k<CT, 2, 2, 2, 2, EPI, TAPS, APRO>(a, s);
     return launch_k<CT, 1, 2, 2, 2, EPI, TAPS, APRO>(a, s);
 }
 
@@ -498,12 +527,15 @@ extern "C" int glowtts_conv_cl(const glowtts_conv_args* args, void* stream)
     if (!a.a2 && a.apro != GLOWTTS_APRO_SQNEG) a.ca1 = a.ca;
     if (a.apro == GLOWTTS_APRO_SQNEG && ((a.ca1 % (a.precision == GLOWTTS_BF16 ? 8 : 4)) || a.ca != 2 * a.ca1)) return GLOWTTS_E_ARG;
     if ((a.flags & GLOWTTS_F_COLMASK) && !a.ncols_valid) return GLOWTTS_E_ARG;
-    {   // loads are unconditional 16-byte vectors: rows must be wide enough for the last (possibly partial) K slot
+    {   // loads are unconditional vectors of E floats (E = 8 bf16 / 4 f32 channels = one 16-byte LDS slot): every row must be
+        // wide enough to contain the last, possibly partial, slot:  lda >= round_up(channels read from it, E)
         const int E = a.precision == GLOWTTS_BF16 ? 8 : 4;
+        auto up = [E](int v) { return (v + E - 1) / E * E; };
         if ((a.ca & 3) || a.kchunks * (a.precision == GLOWTTS_BF16 ? 32 : 16) < a.ca) return GLOWTTS_E_ARG;
-        if (a.apro == GLOWTTS_APRO_PAIRMUL) { if (a.lda < 2 * E) return GLOWTTS_E_ARG; }
-        else if (a.lda < E || (a.a2 && a.lda2 < E)) return GLOWTTS_E_ARG;
-        if (a.a2 && (a.ca1 % E)) return GLOWTTS_E_ARG;
+        if (a.apro == GLOWTTS_APRO_PAIRMUL) { if (a.lda < 2 * up(a.ca)) return GLOWTTS_E_ARG; }
+        else if (a.apro == GLOWTTS_APRO_SQNEG) { if (a.lda < up(a.ca1)) return GLOWTTS_E_ARG; }
+        else if (a.a2) { if ((a.ca1 % E) || a.lda < a.ca1 || a.lda2 < up(a.ca - a.ca1)) return GLOWTTS_E_ARG; }
+        else if (a.lda < up(a.ca)) return GLOWTTS_E_ARG;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.precision == GLOWTTS_BF16) return launch_prec<__bf16>(a, s);

@@ -238,7 +238,7 @@ class GlowTTS(torch.nn.Module):
         P = self._params()
         spk, pro = self._conditioning(P, speakers, mels_for_ge2e, mels, mel_lengths)
         token_mask = self.Mask_Generate(token_lengths, tokens.shape[1])
-        mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, self.training)
+        mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, self.training, precision=self.dec_cfg.precision)
         cond = decoder.conditioning(P, self.dec_cfg, spk, pro)
         self._maybe_init_actnorm(P, mels, mel_lengths, cond)
         W = decoder.stack_decoder_weights(P, self.dec_cfg)
@@ -264,7 +264,7 @@ class GlowTTS(torch.nn.Module):
         P = self._params()
         spk, pro = self._conditioning(P, speakers, mels_for_ge2e, mels_for_prosody, mel_lengths_for_prosody)
         token_mask = self.Mask_Generate(token_lengths, tokens.shape[1])
-        mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, False)
+        mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, False, precision=self.dec_cfg.precision)
         if not torch.is_tensor(length_scale):
             length_scale = torch.tensor([float(length_scale)], device=tokens.device)
         ls = length_scale.to(tokens.device).unsqueeze(-1).unsqueeze(-1)                                   # Modules.py:169

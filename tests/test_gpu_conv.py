@@ -11,11 +11,13 @@ TOL = {0: 2e-5, 1: 2e-2}
 
 
 def rows_layout(x):
-    """[B,C,T] -> rows [B*(T+4), C] with 2 zero rows before/after every utterance."""
+    """[B,C,T] -> rows [B*(T+4), Cp] with 2 zero rows before/after every utterance.  Cp = C rounded up to 8: the kernel
+    reads whole 16-byte K slots, so a row must be at least round_up(C, 8) floats wide (include/glowtts_hip.h)."""
     B, C, T = x.shape
-    r = torch.zeros(B, T + 4, C)
-    r[:, 2:T + 2] = x.transpose(1, 2)
-    return r.reshape(B * (T + 4), C)
+    Cp = (C + 7) // 8 * 8
+    r = torch.zeros(B, T + 4, Cp)
+    r[:, 2:T + 2, :C] = x.transpose(1, 2)
+    return r.reshape(B * (T + 4), Cp)
 
 
 def from_rows(r, B, T):
