@@ -59,16 +59,25 @@ def build_model(precision, device):
     return model, MLE_Loss(hp), hp
 
 
-def train_step(model, mle_loss, batch, reducer=None):
+def train_step(model, mle_loss, batch, reducer=None, world=1):
+    """Train.py:193-227 up to (and including) backward, plus the gradient all-reduce when data parallel.
+    Data parallel: every rank scales its MLE loss (a mean over ITS frames, Modules.py:1026) by local/global frames and its
+    duration MSE (a mean over its padded [B,1,Tt]) by 1/world, and gradients are SUMMED: the result is the gradient of the
+    single-process loss on the global batch (tests/test_distributed_cpu.py)."""
+    from glow_tts_amd.distributed import global_frame_weight
     tokens, tl, mels, ml = batch
     z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, _, _ = model(tokens, tl, mels, ml, None, None, None)
-    loss = mle_loss(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=ml) + \
-        torch.nn.functional.mse_loss(log_dur, log_dur_t)                                 # Train.py:203-211
+    mle = mle_loss(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=ml)
+    length = torch.nn.functional.mse_loss(log_dur, log_dur_t)                            # Train.py:203-211
+    if reducer is not None:
+        loss = mle * global_frame_weight(ml.sum()) + length / world
+    else:
+        loss = mle + length
     model.zero_grad(set_to_none=True)
     loss.backward()
     if reducer is not None:
-        reducer.reduce(average=True)
-    return loss
+        reducer.reduce(average=False)
+    return mle + length
 
 
 def dominant_kernel_roofline(precision, B, T, iters=30):
@@ -200,11 +209,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        train_step(model, mle_loss, batch, reducer)
+        train_step(model, mle_loss, batch, reducer, world)
     barrier()
     t0 = time.time()
     for _ in range(args.steps):
-        loss = train_step(model, mle_loss, batch, reducer)
+        loss = train_step(model, mle_loss, batch, reducer, world)
     barrier()
     elapsed = time.time() - t0
     if world > 1:

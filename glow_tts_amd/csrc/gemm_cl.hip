@@ -57,6 +57,13 @@ template <bool EXACT> __device__ __forceinline__ float tanh_(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 
+// dropout keep decision: counter hash (murmur3 finalizer) of (seed, element id) -> 24-bit uniform
+__device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t id, float p, float inv_keep) {
+    uint32_t h = id * 0x9E3779B1u + seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return ((h >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------
@@ -395,6 +402,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
                         float v0 = acc[mi][2 * pi][reg] + p.bias[j];
                         float v1 = acc[mi][2 * pi + 1][reg] + p.bias[p.h + j];
                         if constexpr (EPI == GLOWTTS_EPI_GATE) {
+                            if (p.drop_p > 0.f) {                                  // Modules.py:862 Dropout on the conv output
+                                const float ik = 1.f / (1.f - p.drop_p);
+                                const uint32_t id = (uint32_t)r * (uint32_t)(2 * p.h) + (uint32_t)j;
+                                v0 *= drop_scale(p.seed, id, p.drop_p, ik);
+                                v1 *= drop_scale(p.seed, id + (uint32_t)p.h, p.drop_p, ik);
+                            }
                             if (p.cond) {                                          // Modules.py:863-866 (added after the conv)
                                 const float* cb = p.cond + (long)(r / p.rows_per_utt) * p.ldcond;
                                 v0 += cb[j];
@@ -421,8 +434,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
                         if (j >= p.n) continue;
                         const float d = acc[mi][ni][reg];
                         const float2 g = *reinterpret_cast<const float2*>(p.in0 + (long)r * p.ldi0 + 2 * j);   // (tanh, sigmoid)
-                        const float da = d * g.y * (1.f - g.x * g.x);
-                        const float ds = d * g.x * g.y * (1.f - g.y);
+                        float da = d * g.y * (1.f - g.x * g.x);
+                        float ds = d * g.x * g.y * (1.f - g.y);
+                        if (p.drop_p > 0.f) {                                      // same keep mask as the forward GATE epilogue
+                            const float ik = 1.f / (1.f - p.drop_p);
+                            const uint32_t id = (uint32_t)r * (uint32_t)(2 * p.n) + (uint32_t)j;
+                            da *= drop_scale(p.seed, id, p.drop_p, ik);
+                            ds *= drop_scale(p.seed, id + (uint32_t)p.n, p.drop_p, ik);
+                        }
                         const int pc = (j >> 5) * 64 + (j & 31);
                         p.out0[(long)r * p.ld0 + pc] = da;
                         p.out0[(long)r * p.ld0 + pc + 32] = ds;

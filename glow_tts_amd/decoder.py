@@ -24,7 +24,8 @@ class Packed(ctypes.Structure):
 
 
 class FlowDims(ctypes.Structure):
-    _fields_ = [("B", c_int), ("T", c_int), ("C", c_int), ("H", c_int), ("L", c_int), ("ksize", c_int), ("precision", c_int)]
+    _fields_ = [("B", c_int), ("T", c_int), ("C", c_int), ("H", c_int), ("L", c_int), ("ksize", c_int), ("precision", c_int),
+                ("drop_p", ctypes.c_float), ("seed", ctypes.c_uint32)]
 
 
 class FlowParams(ctypes.Structure):
@@ -207,8 +208,8 @@ class _Prepared:
             self.params.append(p)
 
 
-def _dims(cfg, B, T):
-    return FlowDims(B, T, cfg.C, cfg.H, cfg.L, cfg.k, cfg.precision)
+def _dims(cfg, B, T, drop_p=0.0, seed=0, flow=0):
+    return FlowDims(B, T, cfg.C, cfg.H, cfg.L, cfg.k, cfg.precision, float(drop_p), (int(seed) + 1000003 * flow) & 0xFFFFFFFF)
 
 
 def squeeze_rows(cfg, mels, lengths, want_mask=True):
@@ -254,16 +255,16 @@ class _Buffers:
         return a
 
 
-def _run_forward(cfg, prep, mels, lengths):
+def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=0):
     L = _L()
     B, _, Tm = mels.shape
     x0, rowmask, T = squeeze_rows(cfg, mels, lengths)
     R = x0.shape[0]
     buf = _Buffers(cfg, prep, R, mels.device)
     buf.x[0].copy_(x0)
-    dims = _dims(cfg, B, T)
     for f in range(cfg.F):
         acts = buf.acts(f, cfg.L, rowmask)
+        dims = _dims(cfg, B, T, drop_p, seed, f)
         _lib.check(L.glowtts_flow_forward(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(acts), _lib.stream()),
                    "glowtts_flow_forward")
     z = unsqueeze_rows(cfg, buf.x[cfg.F], lengths, B, Tm)
@@ -343,12 +344,14 @@ class DecoderFunction(torch.autograd.Function):
     """z, logdet = Decoder(mels)   with autograd through the hand-written backward kernels."""
 
     @staticmethod
-    def forward(ctx, cfg, mels, lengths, cond, *weights):
+    def forward(ctx, cfg, mels, lengths, cond, drop_p, *weights):
         W = dict(zip(WEIGHT_KEYS, [w.detach().contiguous() for w in weights]))
         need_bwd = any(w.requires_grad for w in weights) or mels.requires_grad or (cond is not None and cond.requires_grad)
         condc = cond.detach().contiguous() if cond is not None else None
         prep = _Prepared(cfg, W, need_bwd=need_bwd, cond=condc)
-        z, logdet, buf, rowmask, T = _run_forward(cfg, prep, mels.detach(), lengths)
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop_p > 0 else 0      # CPU generator: follows torch.manual_seed
+        z, logdet, buf, rowmask, T = _run_forward(cfg, prep, mels.detach(), lengths, drop_p, seed)
+        ctx.drop = (drop_p, seed)
         if need_bwd:
             ctx.cfg, ctx.prep, ctx.buf, ctx.rowmask, ctx.T = cfg, prep, buf, rowmask, T
             ctx.lengths, ctx.mel_shape = lengths, mels.shape
@@ -376,7 +379,6 @@ class DecoderFunction(torch.autograd.Function):
         dh = torch.empty(F_, Lw, R, H, device=dev)
         scratch = torch.empty(L.glowtts_actnorm_stats_scratch_floats(R, C), device=dev)
         dcond = torch.zeros_like(prep.cond) if prep.cond is not None else None
-        dims = _dims(cfg, B, T)
         gk = WgradGroup(R, cfg.k, cfg.precision)                        # In_l (k taps)
         g1 = gk if cfg.k == 1 else WgradGroup(R, 1, cfg.precision)      # Start / End (1x1)
         gp = WgradGroup(R, 1, cfg.precision, ops.APRO_PAIRMUL)          # Res_Skip_l (1x1 on tanh*sigmoid)
@@ -390,6 +392,7 @@ class DecoderFunction(torch.autograd.Function):
             if dcond is not None:
                 g.dcond = dcond.data_ptr() + 4 * f * Lw * 2 * H
             acts = buf.acts(f, Lw, rowmask)
+            dims = _dims(cfg, B, T, ctx.drop[0], ctx.drop[1], f)
             _lib.check(L.glowtts_flow_backward(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(acts), ctypes.byref(g),
                                                _lib.stream()), "glowtts_flow_backward")
             # weight-gradient problems of this flow (autograd of Modules.py:791,861,871,793)
@@ -417,7 +420,7 @@ class DecoderFunction(torch.autograd.Function):
         winv_t = prep.winfo[:, 16:32].view(F_, 4, 4).transpose(1, 2)
         G["inv_w"] = d_an[:, 2 * C:].view(F_, 4, 4) + s * (C / 4) * winv_t
         dmel = unsqueeze_rows(cfg, dx, ctx.lengths, B, Tm) if ctx.want_dmel else None
-        return (None, dmel, None, dcond) + tuple(G[k].view_as(W[k]) for k in WEIGHT_KEYS)
+        return (None, dmel, None, dcond, None) + tuple(G[k].view_as(W[k]) for k in WEIGHT_KEYS)
 
 
 def _wn(g, v):

@@ -242,7 +242,8 @@ class GlowTTS(torch.nn.Module):
         cond = decoder.conditioning(P, self.dec_cfg, spk, pro)
         self._maybe_init_actnorm(P, mels, mel_lengths, cond)
         W = decoder.stack_decoder_weights(P, self.dec_cfg)
-        z, log_dets = decoder.DecoderFunction.apply(self.dec_cfg, mels, mel_lengths, cond, *W)
+        drop_p = float(hp.Decoder.Affine_Coupling.WaveNet.Dropout_Rate) if self.training else 0.0      # Modules.py:854-862
+        z, log_dets = decoder.DecoderFunction.apply(self.dec_cfg, mels, mel_lengths, cond, drop_p, *W)
         ns = hp.Decoder.Num_Squeeze
         z_len = (mel_lengths // ns) * ns
         attn, idx, _ = alignment.align(mean.detach(), log_std.detach(), z.detach(), token_lengths, z_len)   # Modules.py:107-116

@@ -39,6 +39,7 @@ class ConvArgs(ctypes.Structure):
         ("a_bstride", ctypes.c_int64), ("w_bstride", ctypes.c_int64), ("bias_bstride", ctypes.c_int64),
         ("out_bstride", ctypes.c_int64), ("mask_bstride", ctypes.c_int64),
         ("ncols_valid", c_void_p),
+        ("seed", ctypes.c_uint32), ("drop_p", ctypes.c_float),
     ]
 
 

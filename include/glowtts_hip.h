@@ -134,6 +134,9 @@ typedef struct glowtts_conv_args {
     int batch;
     int64_t a_bstride, w_bstride /* bytes */, bias_bstride, out_bstride, mask_bstride;
     const int32_t *ncols_valid;        /* [batch] for GLOWTTS_F_COLMASK */
+    /* GATE / DGATE: dropout on the conv output before the conditioning is added (Modules.py:861-862), p = drop_p.
+     * The keep mask is a counter hash of (seed, row, channel): the backward regenerates it from the same seed. */
+    uint32_t seed; float drop_p;
 } glowtts_conv_args;
 
 int glowtts_conv_cl(const glowtts_conv_args *args /* host pointer */, void *stream);
@@ -239,6 +242,8 @@ typedef struct glowtts_flow_dims {
     int L;             /* WaveNet.Num_Layers                                (4)   */
     int ksize;         /* WaveNet.Kernel_Size                               (5)   */
     int precision;     /* GLOWTTS_F32 / GLOWTTS_BF16 for the MFMA contractions */
+    float drop_p;      /* WaveNet.Dropout_Rate in training mode, 0 in eval mode          (Modules.py:854-862) */
+    uint32_t seed;     /* dropout seed of this flow step (layer l uses seed + l); same value in forward and backward */
 } glowtts_flow_dims;
 
 typedef struct glowtts_flow_params {

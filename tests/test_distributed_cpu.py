@@ -1,0 +1,77 @@
+"""CPU suite, world_size = 2, gloo: the data-parallel host logic (glow_tts_amd/distributed.py) reproduces the
+single-process global-batch gradient: frame-weighted loss, SUM all-reduce through the flat buckets, ActNorm statistics
+summed over ranks.  (The HIP kernels themselves need a GPU; this covers the N > 1 path the driver runs on 8 GPUs.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _toy_model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 6))
+
+
+def _toy_batch():
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(6, 10, 6, generator=g)                       # 6 "utterances", up to 10 "frames"
+    lengths = torch.tensor([10, 4, 7, 9, 2, 8])
+    return x, lengths
+
+
+def _nll_sum(model, x, lengths):
+    mask = (torch.arange(x.shape[1])[None, :] < lengths[:, None]).float().unsqueeze(-1)
+    return (((model(x) - x) ** 2) * mask).sum()
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from glow_tts_amd.distributed import FlatGradReducer, actnorm_stats_allreduce, global_frame_weight
+    model = _toy_model()
+    x, lengths = _toy_batch()
+    sl = slice(0, 2) if rank == 0 else slice(2, 6)                # uneven shards: 14 vs 26 frames
+    xs, ls = x[sl], lengths[sl]
+    local_frames = ls.sum()
+    # local mean-over-frames loss (what MLE_Loss computes, Modules.py:1026), turned into this rank's share of the global loss
+    loss = _nll_sum(model, xs, ls) / local_frames * global_frame_weight(local_frames)
+    loss.backward()
+    red = FlatGradReducer(list(model.parameters()), bucket_bytes=256)     # tiny buckets: exercises several
+    assert len(red.buckets) > 1
+    red.reduce(average=False)
+    stats = torch.tensor([float(rank + 1), 2.0, float(local_frames)])
+    actnorm_stats_allreduce(stats)
+    if rank == 0:
+        torch.save({"grads": [p.grad.clone() for p in model.parameters()], "stats": stats}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_equal_global_batch(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    model = _toy_model()
+    x, lengths = _toy_batch()
+    (_nll_sum(model, x, lengths) / lengths.sum()).backward()                # single process, global batch
+    for g, p in zip(got["grads"], model.parameters()):
+        assert torch.allclose(g, p.grad, atol=1e-6, rtol=1e-5)
+    assert torch.allclose(got["stats"], torch.tensor([3.0, 4.0, float(lengths.sum())]))
+
+
+def test_single_process_is_a_noop():
+    from glow_tts_amd.distributed import FlatGradReducer, global_frame_weight, is_dist
+    assert not is_dist()
+    m = _toy_model()
+    m(torch.randn(3, 6)).sum().backward()
+    before = [p.grad.clone() for p in m.parameters()]
+    FlatGradReducer(list(m.parameters())).reduce()
+    assert all(torch.equal(a, p.grad) for a, p in zip(before, m.parameters()))
+    assert float(global_frame_weight(torch.tensor(5))) == 1.0

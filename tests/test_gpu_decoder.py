@@ -17,7 +17,7 @@ def dec_cfg(cfg, precision):
     return DecoderConfig(cfg.mel_dim, cfg.n_flows, cfg.n_squeeze, cfg.n_split, cfg.wn_channels, cfg.wn_layers, cfg.wn_kernel, precision)
 
 
-def run_hip_decoder(sd, cfg, mels, lengths, precision, requires_grad=False, cond_vectors=None):
+def run_hip_decoder(sd, cfg, mels, lengths, precision, requires_grad=False, cond_vectors=None, drop_p=0.0):
     from glow_tts_amd import decoder as D
     dc = dec_cfg(cfg, precision)
     P = {k: v.cuda().requires_grad_(requires_grad and v.is_floating_point()) for k, v in sd.items() if "Decoder" in k}
@@ -25,7 +25,7 @@ def run_hip_decoder(sd, cfg, mels, lengths, precision, requires_grad=False, cond
     cond = None
     if cond_vectors is not None:
         cond = D.conditioning(P, dc, speakers=cond_vectors.cuda())
-    z, logdet = D.DecoderFunction.apply(dc, mels.cuda(), lengths.cuda(), cond, *W)
+    z, logdet = D.DecoderFunction.apply(dc, mels.cuda(), lengths.cuda(), cond, drop_p, *W)
     return z, logdet, P, dc
 
 
@@ -160,3 +160,34 @@ def test_full_width_forward(precision, ztol):
     torch.cuda.synchronize()
     assert (z.cpu() - want_z).abs().max() <= ztol
     assert ((logdet.cpu() - want_ld).abs() <= 2e-3 * want_ld.abs().clamp_min(1.0)).all()
+
+
+def test_wavenet_dropout_statistics_and_backward_consistency():
+    """Training-mode dropout inside WaveNet (Modules.py:861-862).  (1) p = 0 is the eval result; (2) with p > 0 the output
+    changes but stays finite and the same seed reproduces it; (3) backward uses the same keep mask: a finite-difference
+    directional derivative along one weight tensor matches the analytic gradient (f32 mode)."""
+    sd, _, r = load_case("tiny_vanilla.npz")
+    cfg = tiny_cfg("Vanilla")
+    mels, ml = torch.from_numpy(r["mels"]), torch.from_numpy(r["mel_lengths"])
+    torch.manual_seed(11)
+    z0, _, _, _ = run_hip_decoder(sd, cfg, mels, ml, 0, drop_p=0.0)
+    torch.manual_seed(11)
+    z1, _, P, _ = run_hip_decoder(sd, cfg, mels, ml, 0, requires_grad=True, drop_p=0.3)
+    torch.manual_seed(11)
+    z2, _, _, _ = run_hip_decoder(sd, cfg, mels, ml, 0, drop_p=0.3)
+    assert torch.isfinite(z1).all() and (z1 - z0).abs().max() > 1e-3 and torch.equal(z1.detach(), z2)
+    key = "layer_Dict.Decoder.layer_Dict.Flows.1.layers.2.layer_Dict.WaveNet.layer_Dict.In_0.weight_v"
+    g = torch.Generator().manual_seed(5)
+    wz = torch.randn(z1.shape, generator=g).cuda()
+    (z1 * wz).sum().backward()
+    direction = torch.randn(sd[key].shape, generator=g)
+    analytic = (P[key].grad.cpu() * direction).sum().item()
+    eps = 1e-2
+    vals = []
+    for sgn in (+1, -1):
+        sd2 = dict(sd); sd2[key] = sd[key] + sgn * eps * direction
+        torch.manual_seed(11)
+        zz, _, _, _ = run_hip_decoder(sd2, cfg, mels, ml, 0, drop_p=0.3)
+        vals.append((zz * wz).sum().item())
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(numeric - analytic) <= 2e-2 * max(1.0, abs(analytic)), (numeric, analytic)
