@@ -177,6 +177,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--ragged", action="store_true", help="Set V (ragged lengths) instead of Set F (fixed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (experimental: on ROCm 7.2 the "
+                    "instantiate of this ~1500-node graph segfaults inside hipStreamEndCapture, so eager launches are the default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -208,12 +210,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        train_step(model, mle_loss, batch, reducer, world)
+    # A step = forward + losses + backward as ONE captured hipGraph (static shapes; the dropout seed is re-drawn on the
+    # device inside the graph), followed - when data parallel - by the flat-bucket gradient all-reduce.
+    from glow_tts_amd.distributed import global_frame_weight
+    mode = "eager"
+    graph = None
+    for _ in range(max(1, args.warmup - 1)):                   # also runs the ActNorm data-dependent init
+        loss = train_step(model, mle_loss, batch, reducer, world)
+    if args.graph:
+        try:
+            wfr = global_frame_weight(batch[3].sum()) if world > 1 else None      # constant for a fixed batch
+
+            def fwd_bwd():
+                tokens, tl, mels, ml = batch
+                z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, _, _ = model(tokens, tl, mels, ml, None, None, None)
+                mle = mle_loss(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=ml)
+                length = torch.nn.functional.mse_loss(log_dur, log_dur_t)
+                total = mle * wfr + length / world if world > 1 else mle + length
+                model.zero_grad(set_to_none=True)
+                total.backward()
+                return (mle + length).detach()
+
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    fwd_bwd()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = fwd_bwd()
+            graph.replay()
+            torch.cuda.synchronize()
+            mode = "hipgraph"
+        except Exception as exc:                               # noqa: BLE001 - fall back to eager launches, say so
+            import traceback
+            traceback.print_exc()
+            print(f"[bench] graph capture failed ({type(exc).__name__}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def one_step():
+        if graph is not None:
+            graph.replay()
+            if reducer is not None:
+                reducer.reduce(average=False)
+            return static_loss
+        return train_step(model, mle_loss, batch, reducer, world)
+
+    one_step()
     barrier()
     t0 = time.time()
     for _ in range(args.steps):
-        loss = train_step(model, mle_loss, batch, reducer, world)
+        loss = one_step()
     barrier()
     elapsed = time.time() - t0
     if world > 1:
@@ -237,7 +287,7 @@ def main():
                                    f"batch={B}/GPU, {'ragged Set V' if args.ragged else 'fixed Set F'}, forward+losses+backward"
                                    + (", RCCL grad all-reduce" if world > 1 else ""),
                        "global_batch": B * world, "mel_frames": Tm, "tokens": Tt, "parallelism": f"dp{world}"},
-            "loss": round(float(loss.item()), 4),
+            "loss": round(float(loss.item()), 4), "launch_mode": mode,
             "model_tflops": round(value * FLOP_PER_FRAME_FWD_BWD / 1e12, 2),
             "mas_us_per_utt": round(mas_us_per_utt(B, Tt, Tm), 3),
             "roofline": dominant_kernel_roofline(args.precision, B, Tm // 2),

@@ -57,7 +57,7 @@ int coupling_net(const Ctx& c, const float* xsrc, float* xdst, bool reverse, boo
         {   // In_l (k taps) + conditioning + tanh*sigmoid                       Modules.py:861-870
             glowtts_conv_args a = base_args(c, p->in[l], c.d->ksize);
             a.a = hin; a.lda = H; a.ca = H; a.n = 2 * H; a.h = H;
-            a.epi = GLOWTTS_EPI_GATE; a.bias = p->b_in[l]; a.drop_p = c.d->drop_p; a.seed = c.d->seed + (uint32_t)l;
+            a.epi = GLOWTTS_EPI_GATE; a.bias = p->b_in[l]; a.drop_p = c.d->drop_p; a.seed = c.d->seed + (uint32_t)l; a.seed_ptr = c.d->seed_ptr;
             if (p->cond) { a.cond = p->cond + (int64_t)l * 2 * H; a.ldcond = p->ldcond; }
             a.out0 = g; a.ld0 = 2 * H;
             CHECK(glowtts_conv_cl(&a, c.s));
@@ -193,7 +193,7 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
             if (last) { q.a = g->dskip; q.lda = H; q.ca = H; }
             else      { q.a = dnext; q.lda = H; q.ca1 = H; q.a2 = g->dskip; q.lda2 = H; q.ca = 2 * H; }
             q.n = H; q.epi = GLOWTTS_EPI_DGATE; q.in0 = a->gates[l]; q.ldi0 = 2 * H; q.out0 = dins; q.ld0 = ldin;
-            q.drop_p = d->drop_p; q.seed = d->seed + (uint32_t)l;
+            q.drop_p = d->drop_p; q.seed = d->seed + (uint32_t)l; q.seed_ptr = d->seed_ptr;
             CHECK(glowtts_conv_cl(&q, stream));
         }
         if (wg) {   // Res_Skip weight gradient: rows [0,H) <- d res, rows [H,2H) <- d skip (last layer: only H rows <- d skip)

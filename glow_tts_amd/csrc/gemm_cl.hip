@@ -140,6 +140,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
         if (p.rowmask) p.rowmask += bz * p.mask_bstride;
         p.out0 += bz * p.out_bstride;
     }
+    if (p.seed_ptr) p.seed += *p.seed_ptr;
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32, NT = WM * WN * 64;
     constexpr bool T1 = (TAPS == 1);
     constexpr int NSUB = T1 ? ((APRO == GLOWTTS_APRO_NONE) ? 3 : 2) : TAPS;   // sub-steps per super-step

@@ -25,7 +25,7 @@ class Packed(ctypes.Structure):
 
 class FlowDims(ctypes.Structure):
     _fields_ = [("B", c_int), ("T", c_int), ("C", c_int), ("H", c_int), ("L", c_int), ("ksize", c_int), ("precision", c_int),
-                ("drop_p", ctypes.c_float), ("seed", ctypes.c_uint32)]
+                ("drop_p", ctypes.c_float), ("seed", ctypes.c_uint32), ("seed_ptr", c_void_p)]
 
 
 class FlowParams(ctypes.Structure):
@@ -85,6 +85,9 @@ class WgradJob(ctypes.Structure):
                 ("tile0", c_int), ("mt", c_int), ("nt", c_int), ("reserved", c_i64)]
 
 
+_PINNED = {}
+
+
 class WgradGroup:
     """Collects weight-gradient problems sharing (rows, taps) and runs them as ONE glowtts_wgrad_grouped launch."""
 
@@ -105,8 +108,20 @@ class WgradGroup:
         if not self.jobs:
             return
         arr = (WgradJob * len(self.jobs))(*self.jobs)
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        self.table = host.to(device, non_blocking=False)          # kept alive until the stream has consumed it
+        raw = bytes(arr)
+        key = (self.taps, self.xpro, len(raw), str(device))
+        pinned = _PINNED.get(key)
+        if pinned is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.GlowTTSHipError("run at least one eager step before capturing a hipGraph (pinned job table not allocated yet)")
+            pinned = _PINNED[key] = torch.empty(len(raw), dtype=torch.uint8).pin_memory()
+        if torch.cuda.is_current_stream_capturing():
+            # the captured copy node re-reads `pinned` at every replay; its content (pointers into graph-private buffers) is static
+            pinned.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            self.table = pinned.to(device, non_blocking=True)
+        else:
+            # eager: the host may run ahead of the stream, so the job table is copied synchronously from a private buffer
+            self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         _lib.check(_L().glowtts_wgrad_grouped(self.table.data_ptr(), len(self.jobs), self.tiles, self.rows, self.taps, (self.taps - 1) // 2,
                                               self.xpro, self.precision, 1, 0, _lib.stream()), "glowtts_wgrad_grouped")
 
@@ -208,8 +223,10 @@ class _Prepared:
             self.params.append(p)
 
 
-def _dims(cfg, B, T, drop_p=0.0, seed=0, flow=0):
-    return FlowDims(B, T, cfg.C, cfg.H, cfg.L, cfg.k, cfg.precision, float(drop_p), (int(seed) + 1000003 * flow) & 0xFFFFFFFF)
+def _dims(cfg, B, T, drop_p=0.0, seed=None, flow=0):
+    """seed: None or a device int32/uint32 tensor with one element (re-drawn on device every step, hipGraph-safe)."""
+    return FlowDims(B, T, cfg.C, cfg.H, cfg.L, cfg.k, cfg.precision, float(drop_p), (1000003 * flow) & 0xFFFFFFFF,
+                    seed.data_ptr() if seed is not None else None)
 
 
 def squeeze_rows(cfg, mels, lengths, want_mask=True):
@@ -255,7 +272,7 @@ class _Buffers:
         return a
 
 
-def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=0):
+def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None):
     L = _L()
     B, _, Tm = mels.shape
     x0, rowmask, T = squeeze_rows(cfg, mels, lengths)
@@ -349,7 +366,8 @@ class DecoderFunction(torch.autograd.Function):
         need_bwd = any(w.requires_grad for w in weights) or mels.requires_grad or (cond is not None and cond.requires_grad)
         condc = cond.detach().contiguous() if cond is not None else None
         prep = _Prepared(cfg, W, need_bwd=need_bwd, cond=condc)
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop_p > 0 else 0      # CPU generator: follows torch.manual_seed
+        # one random word on the device (torch's graph-safe generator); kept for the backward, which regenerates the masks
+        seed = torch.randint(0, 2 ** 31 - 1, (1,), device=mels.device, dtype=torch.int32) if drop_p > 0 else None
         z, logdet, buf, rowmask, T = _run_forward(cfg, prep, mels.detach(), lengths, drop_p, seed)
         ctx.drop = (drop_p, seed)
         if need_bwd:

@@ -40,6 +40,7 @@ class ConvArgs(ctypes.Structure):
         ("out_bstride", ctypes.c_int64), ("mask_bstride", ctypes.c_int64),
         ("ncols_valid", c_void_p),
         ("seed", ctypes.c_uint32), ("drop_p", ctypes.c_float),
+        ("seed_ptr", c_void_p),
     ]
 
 

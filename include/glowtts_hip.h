@@ -137,6 +137,7 @@ typedef struct glowtts_conv_args {
     /* GATE / DGATE: dropout on the conv output before the conditioning is added (Modules.py:861-862), p = drop_p.
      * The keep mask is a counter hash of (seed, row, channel): the backward regenerates it from the same seed. */
     uint32_t seed; float drop_p;
+    const uint32_t *seed_ptr;          /* optional DEVICE word added to `seed` (lets a captured hipGraph draw new masks per replay) */
 } glowtts_conv_args;
 
 int glowtts_conv_cl(const glowtts_conv_args *args /* host pointer */, void *stream);
@@ -244,6 +245,7 @@ typedef struct glowtts_flow_dims {
     int precision;     /* GLOWTTS_F32 / GLOWTTS_BF16 for the MFMA contractions */
     float drop_p;      /* WaveNet.Dropout_Rate in training mode, 0 in eval mode          (Modules.py:854-862) */
     uint32_t seed;     /* dropout seed of this flow step (layer l uses seed + l); same value in forward and backward */
+    const uint32_t *seed_ptr;  /* optional device word added to the seed (graph replay) */
 } glowtts_flow_dims;
 
 typedef struct glowtts_flow_params {
