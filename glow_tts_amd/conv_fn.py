@@ -1,33 +1,47 @@
-"""torch.autograd.Function wrappers around the channels-last MFMA convolution (glowtts_conv_cl), its data gradient
-(same kernel, transposed weight image) and its weight gradient (glowtts_wgrad_cl).
-
-Activations are "rows" tensors [R, C] (R = B * (T + 2*ROW_PAD), channels contiguous, zero pad rows around every
-utterance - include/glowtts_hip.h).  Used by the text encoder; the flow decoder drives the same kernels through the
-per-flow C entry points instead (decoder.py)."""
+"""torch.autograd.Function wrappers around the hand-written encoder / convolution kernels (C ABI in include/glowtts_hip.h):
+  ConvRows       glowtts_conv_cl (+ transposed image for the data gradient) and glowtts_wgrad_cl
+  LayerNormRows  glowtts_layernorm_fwd / _bwd            (LN + residual + ReLU + dropout + mask in one pass)
+  EmbeddingRows  glowtts_embedding_fwd / _bwd
+  RPRAttention   glowtts_rpr_attention_fwd / _bwd         (relative-position self-attention core)
+Activations are "rows" tensors [R, C] (R = B * (T + 2*ROW_PAD), channels contiguous, zero pad rows around every utterance).
+The flow decoder drives the same conv kernels through the per-flow C entry points instead (decoder.py)."""
 import ctypes
+import math
 
 import torch
 
 from . import _lib, ops
 
 _decl = False
+c_i64, c_int, c_f, c_u32, c_p = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_uint32, ctypes.c_void_p
 
 
 class WgradArgs(ctypes.Structure):
     """Mirror of `glowtts_wgrad_args`."""
-    _fields_ = [("dy", ctypes.c_void_p), ("lddy", ctypes.c_int64), ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64),
-                ("xpro", ctypes.c_int), ("xmask", ctypes.c_void_p),
-                ("rows", ctypes.c_int), ("m", ctypes.c_int), ("ca", ctypes.c_int), ("taps", ctypes.c_int), ("pad", ctypes.c_int),
-                ("perm", ctypes.c_int), ("perm_h", ctypes.c_int), ("precision", ctypes.c_int),
-                ("splits", ctypes.c_int), ("accumulate", ctypes.c_int),
-                ("dw", ctypes.c_void_p), ("dbias", ctypes.c_void_p)]
+    _fields_ = [("dy", c_p), ("lddy", c_i64), ("x", c_p), ("ldx", c_i64),
+                ("xpro", c_int), ("xmask", c_p),
+                ("rows", c_int), ("m", c_int), ("ca", c_int), ("taps", c_int), ("pad", c_int),
+                ("perm", c_int), ("perm_h", c_int), ("precision", c_int),
+                ("splits", c_int), ("accumulate", c_int),
+                ("dw", c_p), ("dbias", c_p)]
 
 
 def _L():
     global _decl
     L = _lib.lib()
     if not _decl:
-        L.glowtts_wgrad_cl.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.glowtts_wgrad_cl.argtypes = [c_p, c_p]
+        L.glowtts_layernorm_fwd.argtypes = [c_p] * 8 + [c_i64, c_int, c_f, c_int, c_f, c_u32, c_p, c_p]
+        L.glowtts_layernorm_scratch_floats.argtypes = [c_i64, c_int]
+        L.glowtts_layernorm_scratch_floats.restype = c_i64
+        L.glowtts_layernorm_bwd.argtypes = [c_p] * 9 + [c_i64, c_int, c_int, c_f, c_p]
+        L.glowtts_gate_bwd.argtypes = [c_p] * 4 + [c_i64, c_int, c_f, c_p]
+        L.glowtts_embedding_fwd.argtypes = [c_p] * 4 + [c_int] * 3 + [c_f, c_p]
+        L.glowtts_embedding_bwd.argtypes = [c_p] * 4 + [c_int] * 4 + [c_f, c_p]
+        L.glowtts_rpr_attention_fwd.argtypes = [c_p] * 6 + [c_int] * 5 + [c_f, c_u32, c_p, c_p]
+        L.glowtts_rpr_attention_scratch_floats.argtypes = [c_int] * 5
+        L.glowtts_rpr_attention_scratch_floats.restype = c_i64
+        L.glowtts_rpr_attention_bwd.argtypes = [c_p] * 11 + [c_int] * 5 + [c_f, c_p]
         _decl = True
     return L
 
@@ -46,12 +60,16 @@ def wgrad(dy, x, O, ca, taps, precision, want_bias=True, splits=0):
     return dw, db
 
 
+def _sp(t):
+    return t.data_ptr() if t is not None else None
+
+
 class ConvRows(torch.autograd.Function):
-    """y = [relu]( conv1d_same(x, w) + b ) [+ residual] [* rowmask]   on rows tensors.
+    """y = dropout( relu?( conv1d_same(x, w) + b ) ) [+ residual] [* rowmask]   on rows tensors.
     Mirrors torch.nn.Conv1d(k, padding=(k-1)//2) + the elementwise tail the reference applies after it."""
 
     @staticmethod
-    def forward(ctx, x, w, b, rowmask, residual, relu, mask_out, precision):
+    def forward(ctx, x, w, b, rowmask, residual, relu, mask_out, precision, drop_p, seed, seed_t):
         x = x.contiguous()
         R, Cin = x.shape
         O, Ci2, k = w.shape
@@ -59,27 +77,33 @@ class ConvRows(torch.autograd.Function):
         pw = ops.pack_weight(w.detach(), precision=precision)
         out = torch.empty(R, O, device=x.device)
         flags = (ops.F_BIAS if b is not None else 0) | (ops.F_RELU if relu else 0) | (ops.F_MASK if mask_out else 0) | \
-                (ops.F_ADD_IN0 if residual is not None else 0)
+                (ops.F_ADD_IN0 if residual is not None else 0) | (ops.F_DROPOUT if drop_p > 0 else 0)
         ops.conv_cl(x, pw, Ci2, R, lda=Cin, pad=(k - 1) // 2, epi=ops.EPI_LINEAR, flags=flags, n=O,
                     bias=b.detach().contiguous() if b is not None else None, rowmask=rowmask,
-                    in0=residual.contiguous() if residual is not None else None, ldi0=O, out0=out, ld0=O)
-        ctx.save_for_backward(x, w, out if relu else None, rowmask)
-        ctx.cfg = (relu, mask_out, precision, b is not None, residual is not None, Ci2)
+                    in0=residual.contiguous() if residual is not None else None, ldi0=O, out0=out, ld0=O,
+                    drop_p=drop_p, seed=seed, seed_t=seed_t)
+        gated = relu or drop_p > 0
+        assert not (gated and residual is not None), "gate recovery from the output needs out = gated value"
+        ctx.save_for_backward(x, w, out if gated else None, rowmask)
+        ctx.cfg = (gated, mask_out, precision, b is not None, residual is not None, Ci2, drop_p)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         x, w, out, rowmask = ctx.saved_tensors
-        relu, mask_out, precision, has_b, has_res, Ci2 = ctx.cfg
+        gated, mask_out, precision, has_b, has_res, Ci2, drop_p = ctx.cfg
         R, Cin = x.shape
         O, _, k = w.shape
         dy = dy.contiguous()
-        dres = None
-        if mask_out:
-            dy = dy * rowmask.unsqueeze(1)
-        if has_res and ctx.needs_input_grad[4]:
-            dres = dy
-        dz = dy * (out > 0) if relu else dy                   # d(pre-activation)
+        if gated:                                              # d(pre-activation): relu / dropout cut exactly where out == 0
+            dz = torch.empty_like(dy)
+            _lib.check(_L().glowtts_gate_bwd(dy.data_ptr(), out.data_ptr(), _sp(rowmask) if mask_out else None, dz.data_ptr(), R, O,
+                                             1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0, _lib.stream()), "glowtts_gate_bwd")
+        elif mask_out:
+            dz = dy * rowmask.unsqueeze(1)
+        else:
+            dz = dy
+        dres = dz if (has_res and ctx.needs_input_grad[4]) else None
         dx = None
         if ctx.needs_input_grad[0]:
             pwt = ops.pack_weight(w.detach(), transpose=True, precision=precision)
@@ -88,8 +112,105 @@ class ConvRows(torch.autograd.Function):
         dw = db = None
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             dw, db = wgrad(dz, x, O, Ci2, k, precision, want_bias=has_b, splits=min(4, max(1, R // 512)))
-        return dx, dw, db, None, dres, None, None, None
+        return dx, dw, db, None, dres, None, None, None, None, None, None
 
 
-def conv_rows(x, w, b, rowmask, relu=False, mask_out=False, residual=None, precision=ops.BF16):
-    return ConvRows.apply(x, w, b, rowmask, residual, relu, mask_out, precision)
+def conv_rows(x, w, b, rowmask, relu=False, mask_out=False, residual=None, precision=ops.BF16, drop_p=0.0, seed=0, seed_t=None):
+    return ConvRows.apply(x, w, b, rowmask, residual, relu, mask_out, precision, float(drop_p), seed, seed_t)
+
+
+class LayerNormRows(torch.autograd.Function):
+    """y = rowmask * dropout( relu?( LayerNorm(a [+ b]) * gamma + beta ) ), eps = 1e-4 (Modules.py:472-475)."""
+
+    @staticmethod
+    def forward(ctx, a, b, gamma, beta, rowmask, relu, drop_p, seed, seed_t):
+        a = a.contiguous()
+        R, C = a.shape
+        y = torch.empty_like(a)
+        stats = torch.empty(R, 2, device=a.device)
+        s = torch.empty_like(a) if b is not None else a
+        _lib.check(_L().glowtts_layernorm_fwd(a.data_ptr(), _sp(b.contiguous() if b is not None else None), s.data_ptr() if b is not None else None,
+                                              gamma.data_ptr(), beta.data_ptr(), _sp(rowmask), y.data_ptr(), stats.data_ptr(), R, C, 1e-4,
+                                              int(relu), float(drop_p), int(seed) & 0xFFFFFFFF, _sp(seed_t), _lib.stream()), "glowtts_layernorm_fwd")
+        gated = relu or drop_p > 0
+        ctx.save_for_backward(s, stats, gamma, rowmask, y if gated else None)
+        ctx.cfg = (gated, float(drop_p), b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        s, stats, gamma, rowmask, y = ctx.saved_tensors
+        gated, drop_p, has_b = ctx.cfg
+        R, C = s.shape
+        dy = dy.contiguous()
+        L = _L()
+        ds = torch.empty_like(s)
+        gb = torch.empty(2 * C, device=s.device)
+        scratch = torch.empty(L.glowtts_layernorm_scratch_floats(R, C), device=s.device)
+        _lib.check(L.glowtts_layernorm_bwd(dy.data_ptr(), _sp(y), s.data_ptr(), stats.data_ptr(), gamma.data_ptr(), _sp(rowmask), ds.data_ptr(),
+                                           gb.data_ptr(), scratch.data_ptr(), R, C, int(gated), drop_p, _lib.stream()), "glowtts_layernorm_bwd")
+        return ds, (ds if has_b else None), gb[:C], gb[C:], None, None, None, None, None
+
+
+def layernorm_rows(a, b, gamma, beta, rowmask, relu=False, drop_p=0.0, seed=0, seed_t=None):
+    return LayerNormRows.apply(a, b, gamma, beta, rowmask, relu, float(drop_p), seed, seed_t)
+
+
+class EmbeddingRows(torch.autograd.Function):
+    """rows = table[tokens] * scale * mask on the padded rows layout (Modules.py:267)."""
+
+    @staticmethod
+    def forward(ctx, tokens, table, rowmask, scale):
+        B, T = tokens.shape
+        V, C = table.shape
+        rows = torch.empty(B * (T + 4), C, device=table.device)
+        tokens = tokens.contiguous()
+        _lib.check(_L().glowtts_embedding_fwd(tokens.data_ptr(), table.detach().contiguous().data_ptr(), rowmask.data_ptr(), rows.data_ptr(),
+                                              B, T, C, scale, _lib.stream()), "glowtts_embedding_fwd")
+        ctx.save_for_backward(tokens, rowmask)
+        ctx.cfg = (V, C, scale)
+        return rows
+
+    @staticmethod
+    def backward(ctx, d):
+        tokens, rowmask = ctx.saved_tensors
+        V, C, scale = ctx.cfg
+        B, T = tokens.shape
+        dt = torch.empty(V, C, device=d.device)
+        _lib.check(_L().glowtts_embedding_bwd(tokens.data_ptr(), d.contiguous().data_ptr(), rowmask.data_ptr(), dt.data_ptr(), V, B, T, C, scale,
+                                              _lib.stream()), "glowtts_embedding_bwd")
+        return None, dt, None, None
+
+
+class RPRAttention(torch.autograd.Function):
+    """Attention core of RPR_MHA.py:95-128 on fused QKV rows [B*Tp, 3*H*D] -> [B*Tp, H*D]."""
+
+    @staticmethod
+    def forward(ctx, qkv, relk, relv, rowmask, B, Tp, H, win, drop_p, seed, seed_t):
+        qkv = qkv.contiguous()
+        D = qkv.shape[1] // (3 * H)
+        out = torch.empty(B * Tp, H * D, device=qkv.device)
+        P = torch.empty(B, H, Tp, Tp, device=qkv.device)
+        rk, rv = relk.detach().contiguous(), relv.detach().contiguous()
+        _lib.check(_L().glowtts_rpr_attention_fwd(qkv.data_ptr(), rk.data_ptr(), rv.data_ptr(), rowmask.data_ptr(), out.data_ptr(), P.data_ptr(),
+                                                  B, Tp, H, D, win, float(drop_p), int(seed) & 0xFFFFFFFF, _sp(seed_t), _lib.stream()),
+                   "glowtts_rpr_attention_fwd")
+        ctx.save_for_backward(qkv, rk, rv, rowmask, P)
+        ctx.cfg = (B, Tp, H, D, win, float(drop_p))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, rk, rv, rowmask, P = ctx.saved_tensors
+        B, Tp, H, D, win, drop_p = ctx.cfg
+        L = _L()
+        dev = qkv.device
+        nw = 2 * win + 1
+        dS = torch.empty(B, H, Tp, Tp, device=dev)
+        dqkv = torch.empty_like(qkv)
+        drk, drv = torch.empty(nw, D, device=dev), torch.empty(nw, D, device=dev)
+        scratch = torch.empty(L.glowtts_rpr_attention_scratch_floats(B, Tp, H, D, win) + 2 * nw * D, device=dev)
+        _lib.check(L.glowtts_rpr_attention_bwd(qkv.data_ptr(), rk.data_ptr(), rv.data_ptr(), rowmask.data_ptr(), P.data_ptr(),
+                                               dout.contiguous().data_ptr(), dS.data_ptr(), dqkv.data_ptr(), drk.data_ptr(), drv.data_ptr(),
+                                               scratch.data_ptr(), B, Tp, H, D, win, drop_p, _lib.stream()), "glowtts_rpr_attention_bwd")
+        return dqkv, drk.view(1, nw, D), drv.view(1, nw, D), None, None, None, None, None, None, None, None

@@ -1,0 +1,522 @@
+// Text-encoder kernels that are not convolutions (gfx950): LayerNorm over channels with its fused neighbours
+// (Modules.py:472-489, 523-526, 541-544, 561-571), embedding lookup (Modules.py:242-250, 267), dropout/ReLU backward gating,
+// and the relative-position multi-head self-attention core (RPR_MHA.py:95-128) forward and backward.
+// Layout: rows tensors [B][Tp][C], channels contiguous, zero pad rows (include/glowtts_hip.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/glowtts_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t id, float p, float inv_keep) {
+    uint32_t h = id * 0x9E3779B1u + seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return ((h >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
+}
+
+constexpr int LN_MAXK = 16;          // channels per lane: C <= 1024
+
+// ------------------------------------------------------------------------------------------------
+// y = rowmask * dropout( relu?( LayerNorm(a + b) * gamma + beta ) ),  one wavefront per row.
+// Keeps s = a + b (when b is given) and (mean, rstd) per row for the backward.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ s_out,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ rowmask, float* __restrict__ y, float* __restrict__ stats,
+                                                     long rows, int C, float eps, int relu, float drop_p, uint32_t seed,
+                                                     const uint32_t* __restrict__ seed_ptr)
+{
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    if (seed_ptr) seed += *seed_ptr;
+    const int K = (C + 63) / 64;
+    float v[LN_MAXK];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXK; ++k) {
+        if (k >= K) break;
+        const int c = lane + 64 * k;
+        float x = 0.f;
+        if (c < C) { x = a[r * C + c]; if (b) x += b[r * C + c]; if (s_out) s_out[r * C + c] = x; }
+        v[k] = x; sum += x;
+    }
+    const float mean = wave_sum(sum) / C;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXK; ++k) { if (k >= K) break; const int c = lane + 64 * k; const float d = (c < C) ? v[k] - mean : 0.f; sq += d * d; }
+    const float rstd = rsqrtf(wave_sum(sq) / C + eps);
+    if (lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+    const float m = rowmask ? rowmask[r] : 1.f;
+    const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXK; ++k) {
+        if (k >= K) break;
+        const int c = lane + 64 * k;
+        if (c >= C) continue;
+        float o = (v[k] - mean) * rstd * gamma[c] + beta[c];
+        if (relu) o = fmaxf(o, 0.f);
+        if (drop_p > 0.f) o *= drop_scale(seed, (uint32_t)(r * C + c), drop_p, ik);
+        y[r * C + c] = o * m;
+    }
+}
+
+// backward: dz = dy * mask * gate(y) ; ds = rstd (g dz - mean(g dz) - xhat mean(g dz xhat)) ; partial dgamma / dbeta per block
+// gate(y): relu and/or dropout -> (y != 0) * 1/(1-p)   (y is the forward output: zero exactly where relu / dropout / mask cut)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ s,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     const float* __restrict__ rowmask, float* __restrict__ ds, float* __restrict__ partial,
+                                                     long rows, int C, int gated, float drop_p, int rows_per_block)
+{
+    extern __shared__ float red[];                 // [4 waves][2][C]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int K = (C + 63) / 64;
+    const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    float accg[LN_MAXK], accb[LN_MAXK];
+#pragma unroll
+    for (int k = 0; k < LN_MAXK; ++k) { accg[k] = 0.f; accb[k] = 0.f; }
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    for (long r = r0 + wave; r < r1; r += 4) {
+        const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+        const float m = rowmask ? rowmask[r] : 1.f;
+        float dz[LN_MAXK], xh[LN_MAXK];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXK; ++k) {
+            if (k >= K) break;
+            const int c = lane + 64 * k;
+            float d = 0.f, x = 0.f;
+            if (c < C) {
+                d = dy[r * C + c] * m;
+                if (gated) d = (y[r * C + c] != 0.f) ? d * ik : 0.f;
+                x = (s[r * C + c] - mean) * rstd;
+                accg[k] += d * x; accb[k] += d;
+                d *= gamma[c];
+            }
+            dz[k] = d; xh[k] = x; s1 += d; s2 += d * x;
+        }
+        s1 = wave_sum(s1) / C; s2 = wave_sum(s2) / C;
+#pragma unroll
+        for (int k = 0; k < LN_MAXK; ++k) {
+            if (k >= K) break;
+            const int c = lane + 64 * k;
+            if (c < C) ds[r * C + c] = rstd * (dz[k] - s1 - xh[k] * s2);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LN_MAXK; ++k) {
+        if (k >= K) break;
+        const int c = lane + 64 * k;
+        if (c < C) { red[(wave * 2 + 0) * C + c] = accg[k]; red[(wave * 2 + 1) * C + c] = accb[k]; }
+    }
+    __syncthreads();
+    float* out = partial + (long)blockIdx.x * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i - which * C;
+        out[i] = red[(0 * 2 + which) * C + c] + red[(1 * 2 + which) * C + c] + red[(2 * 2 + which) * C + c] + red[(3 * 2 + which) * C + c];
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int n)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = lane; k < nblk; k += 64) s += partial[(long)k * n + i];
+    s = wave_sum(s);
+    if (lane == 0) out[i] = s;
+}
+
+// dz = dy * (out != 0 ? scale : 0) * rowmask      (backward gate of relu and/or dropout, see ln_bwd_kernel)
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out, const float* __restrict__ rowmask,
+                                                       float* __restrict__ dz, long rows, int C, float scale)
+{
+    const long total = rows * C / 4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = (i * 4) / C;
+        const float m = (rowmask ? rowmask[r] : 1.f) * scale;
+        const float4 d = reinterpret_cast<const float4*>(dy)[i];
+        const float4 o = reinterpret_cast<const float4*>(out)[i];
+        reinterpret_cast<float4*>(dz)[i] = make_float4(o.x != 0.f ? d.x * m : 0.f, o.y != 0.f ? d.y * m : 0.f, o.z != 0.f ? d.z * m : 0.f, o.w != 0.f ? d.w * m : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding: rows[b][PAD + t][c] = E[tok[b][t]][c] * scale * mask ; pad rows zero.   (Modules.py:267)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ E, const float* __restrict__ rowmask,
+                                                        float* __restrict__ rows, int B, int T, int C, float scale)
+{
+    const int Tp = T + 2 * GLOWTTS_ROW_PAD;
+    const long total = (long)B * Tp * C;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / C; const int c = (int)(i - r * C);
+        const int b = (int)(r / Tp), tp = (int)(r - (long)b * Tp) - GLOWTTS_ROW_PAD;
+        float v = 0.f;
+        if (tp >= 0 && tp < T) v = E[tok[(long)b * T + tp] * C + c] * scale * rowmask[r];
+        rows[i] = v;
+    }
+}
+// dE[v][c] = scale * sum over rows whose token is v of d[row][c] * mask     (deterministic: one block per token id)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ d, const float* __restrict__ rowmask,
+                                                        float* __restrict__ dE, int B, int T, int C, float scale)
+{
+    const int v = blockIdx.x;
+    const int Tp = T + 2 * GLOWTTS_ROW_PAD;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < T; ++t)
+                if (tok[(long)b * T + t] == v) { const long r = (long)b * Tp + GLOWTTS_ROW_PAD + t; acc += d[r * C + c] * rowmask[r]; }
+        dE[(long)v * C + c] = acc * scale;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Relative-position self-attention core (RPR_MHA.py:95-128), fp32, one workgroup per (utterance, head, 16-query tile).
+//   scores_ij = (q_i . k_j + [|j-i| <= w] q_i . relK[j-i+w]) / sqrt(D) ; masked_fill(-1e4) ; softmax ; dropout
+//   out_i     = sum_j P_ij v_j + sum_{|d| <= w} P_{i,i+d} relV[d+w]
+// qkv rows: [B][Tp][3][H][D] (Q | K | V thirds of one fused 1x1 conv).  K and V of the (b, h) pair are staged in LDS.
+// P (after dropout, the matrix both PV terms use) is kept for the backward: [B][H][Tp][Tp].
+// ------------------------------------------------------------------------------------------------
+constexpr int ATT_QT = 16;     // queries per workgroup (4 per wavefront)
+
+// K and V are staged one after the other in the SAME LDS buffer (phase 1: scores / softmax with K, phase 2: P V with V), so a
+// 200-token utterance (Tp = 204, D = 96: 79 KB per operand) fits the 160 KB LDS with room for a second workgroup.
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ relk, const float* __restrict__ relv,
+                                                       const float* __restrict__ rowmask, float* __restrict__ out, float* __restrict__ P,
+                                                       int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t* __restrict__ seed_ptr)
+{
+    extern __shared__ float sm[];
+    const int C = H * D, ld = 3 * C;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * ATT_QT;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ldk = D + 1;                                   // padded: lanes walk keys, bank = (key * (D+1)) % 32
+    float* KV = sm;                                          // [Tp][D+1]  K, then V
+    float* Rr = KV + Tp * ldk;                               // [2w+1][D]  relK, then relV
+    float* Qs = Rr + (2 * win + 1) * D;                      // [4 waves][D]
+    float* Ps = Qs + 4 * D;                                  // [ATT_QT][Tp]
+    if (seed_ptr) seed += *seed_ptr;
+    const float* base = qkv + (long)b * Tp * ld + h * D;
+    for (int i = threadIdx.x; i < Tp * D; i += 256) { const int j = i / D, d = i - j * D; KV[j * ldk + d] = base[(long)j * ld + C + d]; }
+    for (int i = threadIdx.x; i < (2 * win + 1) * D; i += 256) Rr[i] = relk[i];
+    __syncthreads();
+    const float* rm = rowmask + (long)b * Tp;
+    const float isd = rsqrtf((float)D);
+    const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (int qi = wave; qi < ATT_QT; qi += 4) {              // phase 1: P rows
+        const int i = q0 + qi;
+        if (i >= Tp) break;                                  // wave-uniform
+        float* q = Qs + wave * D;
+        for (int d = lane; d < D; d += 64) q[d] = base[(long)i * ld + d];
+        float sc[4];
+        float mx = -3.0e38f;
+        const float mi = rm[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = lane + 64 * k;
+            float s = -3.0e38f;
+            if (j < Tp) {
+                float acc = 0.f;
+                const float* kr = KV + j * ldk;
+                const int dd = j - i;
+                if (dd >= -win && dd <= win) { const float* rr = Rr + (dd + win) * D; for (int d = 0; d < D; ++d) acc += q[d] * (kr[d] + rr[d]); }
+                else                         { for (int d = 0; d < D; ++d) acc += q[d] * kr[d]; }
+                s = acc * isd;
+                if (mi * rm[j] == 0.f) s = -1e4f;            // RPR_MHA.py:117
+            }
+            sc[k] = s; mx = fmaxf(mx, s);
+        }
+        mx = wave_max(mx);
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int j = lane + 64 * k; sc[k] = (j < Tp) ? __expf(sc[k] - mx) : 0.f; den += sc[k]; }
+        den = 1.f / wave_sum(den);
+        float* pr = Ps + qi * Tp;
+        float* Pg = P + (((long)b * H + h) * Tp + i) * Tp;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = lane + 64 * k;
+            if (j < Tp) {
+                float p = sc[k] * den;
+                if (drop_p > 0.f) p *= drop_scale(seed, (uint32_t)((((long)b * H + h) * Tp + i) * Tp + j), drop_p, ik);   // RPR_MHA.py:120
+                pr[j] = p; Pg[j] = p;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Tp * D; i += 256) { const int j = i / D, d = i - j * D; KV[j * ldk + d] = base[(long)j * ld + 2 * C + d]; }
+    for (int i = threadIdx.x; i < (2 * win + 1) * D; i += 256) Rr[i] = relv[i];
+    __syncthreads();
+    for (int qi = wave; qi < ATT_QT; qi += 4) {              // phase 2: out_i[d] = sum_j P_ij V[j][d] + sum_dd P_{i,i+dd} relV[dd+w][d]
+        const int i = q0 + qi;
+        if (i >= Tp) break;
+        const float* pr = Ps + qi * Tp;
+        for (int d = lane; d < D; d += 64) {
+            float acc = 0.f;
+            for (int j = 0; j < Tp; ++j) acc += pr[j] * KV[j * ldk + d];
+            for (int dd = -win; dd <= win; ++dd) { const int j = i + dd; if (j >= 0 && j < Tp) acc += pr[j] * Rr[(dd + win) * D + d]; }
+            out[((long)b * Tp + i) * C + h * D + d] = acc;
+        }
+    }
+}
+
+// backward, pass A (per query row).  P holds the DROPPED matrix Pd = P0 * keep / (1 - p) that both P V terms used.
+//   dPd_ij = dO_i . (v_j + [band] relV[j-i+w]) ; D_i = sum_j Pd_ij dPd_ij ; dS_ij = (Pd_ij dPd_ij - P0_ij D_i) / sqrt(D)
+// (P0 dP0 = Pd dPd because dP0 = dPd keep/(1-p).)  P0 is recomputed from the scores when dropout is on.  Phase 1 uses V, phase 2 K.
+__global__ __launch_bounds__(256) void attn_bwd_a_kernel(const float* __restrict__ qkv, const float* __restrict__ relk, const float* __restrict__ relv,
+                                                         const float* __restrict__ rowmask, const float* __restrict__ P, const float* __restrict__ dout,
+                                                         float* __restrict__ dS, float* __restrict__ dqkv,
+                                                         int B, int Tp, int H, int D, int win, float drop_p)
+{
+    extern __shared__ float sm[];
+    const int C = H * D, ld = 3 * C;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * ATT_QT;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ldk = D + 1;
+    float* KV = sm;                                          // [Tp][D+1]  V, then K
+    float* Rr = KV + Tp * ldk;                               // [2w+1][D]  relV, then relK
+    float* Qs = Rr + (2 * win + 1) * D;                      // [4][D]  dO_i (phase 1) / q_i (phase 2)
+    float* Ds = Qs + 4 * D;                                  // [ATT_QT][Tp]  dPd rows, then dS rows
+    const float* base = qkv + (long)b * Tp * ld + h * D;
+    for (int i = threadIdx.x; i < Tp * D; i += 256) { const int j = i / D, d = i - j * D; KV[j * ldk + d] = base[(long)j * ld + 2 * C + d]; }
+    for (int i = threadIdx.x; i < (2 * win + 1) * D; i += 256) Rr[i] = relv[i];
+    __syncthreads();
+    const float* rm = rowmask + (long)b * Tp;
+    const float isd = rsqrtf((float)D);
+    for (int qi = wave; qi < ATT_QT; qi += 4) {              // phase 1: dPd rows
+        const int i = q0 + qi;
+        if (i >= Tp) break;
+        float* go = Qs + wave * D;
+        for (int d = lane; d < D; d += 64) go[d] = dout[((long)b * Tp + i) * C + h * D + d];
+        float* dr = Ds + qi * Tp;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = lane + 64 * k;
+            if (j < Tp) {
+                const float* vr = KV + j * ldk;
+                const int dd = j - i;
+                float a = 0.f;
+                if (dd >= -win && dd <= win) { const float* rv = Rr + (dd + win) * D; for (int d = 0; d < D; ++d) a += go[d] * (vr[d] + rv[d]); }
+                else                         { for (int d = 0; d < D; ++d) a += go[d] * vr[d]; }
+                dr[j] = a;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Tp * D; i += 256) { const int j = i / D, d = i - j * D; KV[j * ldk + d] = base[(long)j * ld + C + d]; }
+    for (int i = threadIdx.x; i < (2 * win + 1) * D; i += 256) Rr[i] = relk[i];
+    __syncthreads();
+    for (int qi = wave; qi < ATT_QT; qi += 4) {              // phase 2: dS rows and dQ
+        const int i = q0 + qi;
+        if (i >= Tp) break;
+        float* q = Qs + wave * D;
+        for (int d = lane; d < D; d += 64) q[d] = base[(long)i * ld + d];
+        const float mi = rm[i];
+        const float* Pg = P + (((long)b * H + h) * Tp + i) * Tp;
+        float* dr = Ds + qi * Tp;
+        float pd[4], dpd[4], p0[4];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = lane + 64 * k;
+            pd[k] = 0.f; dpd[k] = 0.f; p0[k] = -3.0e38f;
+            if (j < Tp) {
+                pd[k] = Pg[j]; dpd[k] = dr[j];
+                if (drop_p > 0.f) {
+                    const float* kr = KV + j * ldk;
+                    const int dd = j - i;
+                    float s = 0.f;
+                    if (dd >= -win && dd <= win) { const float* rk = Rr + (dd + win) * D; for (int d = 0; d < D; ++d) s += q[d] * (kr[d] + rk[d]); }
+                    else                         { for (int d = 0; d < D; ++d) s += q[d] * kr[d]; }
+                    s *= isd;
+                    if (mi * rm[j] == 0.f) s = -1e4f;
+                    p0[k] = s; mx = fmaxf(mx, s);
+                }
+            }
+        }
+        float Di = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Di += pd[k] * dpd[k];
+        Di = wave_sum(Di);
+        if (drop_p > 0.f) {                                  // undropped probabilities from the scores (same arithmetic as the forward)
+            mx = wave_max(mx);
+            float den = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int j = lane + 64 * k; p0[k] = (j < Tp) ? __expf(p0[k] - mx) : 0.f; den += p0[k]; }
+            den = 1.f / wave_sum(den);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p0[k] *= den;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p0[k] = pd[k];
+        }
+        float* dSg = dS + (((long)b * H + h) * Tp + i) * Tp;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = lane + 64 * k;
+            if (j < Tp) {
+                float g = pd[k] * dpd[k] - p0[k] * Di;
+                if (mi * rm[j] == 0.f) g = 0.f;              // masked_fill: no gradient to the masked scores
+                g *= isd;                                    // scores = (q.k + q.relK) / sqrt(D)
+                dr[j] = g; dSg[j] = g;
+            }
+        }
+        // dQ_i[d] = sum_j dS_ij (K[j][d] + [band] relK[j-i+w][d])       (dr written by this wave only; same-wave LDS order suffices)
+        for (int d = lane; d < D; d += 64) {
+            float acc = 0.f;
+            for (int j = 0; j < Tp; ++j) acc += dr[j] * KV[j * ldk + d];
+            for (int dd = -win; dd <= win; ++dd) { const int j = i + dd; if (j >= 0 && j < Tp) acc += dr[j] * Rr[(dd + win) * D + d]; }
+            dqkv[((long)b * Tp + i) * ld + h * D + d] = acc;
+        }
+    }
+}
+
+// backward, pass B (per key row j): dK_j = sum_i dS_ij q_i ; dV_j = sum_i Pd_ij dO_i.  One wavefront per key, lanes walk d.
+__global__ __launch_bounds__(256) void attn_bwd_b_kernel(const float* __restrict__ qkv, const float* __restrict__ P, const float* __restrict__ dS,
+                                                         const float* __restrict__ dout, float* __restrict__ dqkv, int B, int Tp, int H, int D)
+{
+    const int C = H * D, ld = 3 * C;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= Tp) return;
+    const float* Pg = P + ((long)b * H + h) * Tp * Tp + j;
+    const float* Sg = dS + ((long)b * H + h) * Tp * Tp + j;
+    const float* qb = qkv + (long)b * Tp * ld + h * D;
+    const float* ob = dout + (long)b * Tp * C + h * D;
+    for (int d = lane; d < D; d += 64) {
+        float ak = 0.f, av = 0.f;
+        for (int i = 0; i < Tp; ++i) { ak += Sg[(long)i * Tp] * qb[(long)i * ld + d]; av += Pg[(long)i * Tp] * ob[(long)i * C + d]; }
+        dqkv[((long)b * Tp + j) * ld + C + h * D + d] = ak;
+        dqkv[((long)b * Tp + j) * ld + 2 * C + h * D + d] = av;
+    }
+}
+
+// relative embeddings: drelK[dd+w][d] = sum_{b,h,i} dS_{i,i+dd} q_i[d] ; drelV[dd+w][d] = sum_{b,h,i} Pd_{i,i+dd} dO_i[d]
+// grid (2w+1, B*H) -> partial [B*H][2][2w+1][D]; reduced in a fixed order by colsum_final_kernel.
+__global__ __launch_bounds__(128) void attn_bwd_rel_kernel(const float* __restrict__ qkv, const float* __restrict__ P, const float* __restrict__ dS,
+                                                           const float* __restrict__ dout, float* __restrict__ partial, int B, int Tp, int H, int D, int win)
+{
+    const int C = H * D, ld = 3 * C;
+    const int w = blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int dd = w - win;
+    const float* Pg = P + (long)bh * Tp * Tp;
+    const float* Sg = dS + (long)bh * Tp * Tp;
+    const float* qb = qkv + (long)b * Tp * ld + h * D;
+    const float* ob = dout + (long)b * Tp * C + h * D;
+    for (int d = threadIdx.x; d < D; d += 128) {
+        float ak = 0.f, av = 0.f;
+        for (int i = 0; i < Tp; ++i) {
+            const int j = i + dd;
+            if (j < 0 || j >= Tp) continue;
+            ak += Sg[(long)i * Tp + j] * qb[(long)i * ld + d];
+            av += Pg[(long)i * Tp + j] * ob[(long)i * C + d];
+        }
+        const int nw = 2 * win + 1;
+        partial[((long)bh * 2 + 0) * nw * D + w * D + d] = ak;
+        partial[((long)bh * 2 + 1) * nw * D + w * D + d] = av;
+    }
+}
+
+inline int grid_for(long total, int per = 256, int cap = 2048) { long g = (total + per - 1) / per; return (int)(g > cap ? cap : (g < 1 ? 1 : g)); }
+#define RET_LAUNCH() return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH
+
+}  // namespace
+
+extern "C" int glowtts_layernorm_fwd(const float* a, const float* b, float* s_out, const float* gamma, const float* beta, const float* rowmask,
+                                     float* y, float* stats, int64_t rows, int C, float eps, int relu, float drop_p, uint32_t seed,
+                                     const uint32_t* seed_ptr, void* stream)
+{
+    if (!a || !gamma || !beta || !y || !stats || rows < 1 || C < 1 || C > 64 * LN_MAXK || (b && !s_out)) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       a, b, s_out, gamma, beta, rowmask, y, stats, (long)rows, C, eps, relu, drop_p, seed, seed_ptr);
+    RET_LAUNCH();
+}
+
+extern "C" int64_t glowtts_layernorm_scratch_floats(int64_t rows, int C) { return ((rows + 63) / 64) * 2 * (int64_t)C; }
+
+extern "C" int glowtts_layernorm_bwd(const float* dy, const float* y, const float* s, const float* stats, const float* gamma, const float* rowmask,
+                                     float* ds, float* dgamma_dbeta /* [2C] */, float* scratch, int64_t rows, int C, int gated, float drop_p, void* stream)
+{
+    if (!dy || !s || !stats || !gamma || !ds || !dgamma_dbeta || !scratch || rows < 1 || C < 1 || C > 64 * LN_MAXK || (gated && !y)) return GLOWTTS_E_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rpb = 64;
+    const int nblk = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 8 * C * sizeof(float), st, dy, y, s, stats, gamma, rowmask, ds, scratch, (long)rows, C, gated, drop_p, rpb);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, st, scratch, dgamma_dbeta, nblk, 2 * C);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_gate_bwd(const float* dy, const float* out, const float* rowmask, float* dz, int64_t rows, int C, float scale, void* stream)
+{
+    if (!dy || !out || !dz || rows < 1 || C < 4 || (C & 3)) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(rows * C / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, out, rowmask, dz, (long)rows, C, scale);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_embedding_fwd(const int64_t* tokens, const float* table, const float* rowmask, float* rows, int B, int T, int C, float scale, void* stream)
+{
+    if (!tokens || !table || !rowmask || !rows || B < 1 || T < 1 || C < 1) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((long)B * (T + 2 * GLOWTTS_ROW_PAD) * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       tokens, table, rowmask, rows, B, T, C, scale);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_embedding_bwd(const int64_t* tokens, const float* drows, const float* rowmask, float* dtable, int V, int B, int T, int C, float scale, void* stream)
+{
+    if (!tokens || !drows || !rowmask || !dtable || V < 1 || B < 1 || T < 1 || C < 1) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, static_cast<hipStream_t>(stream), tokens, drows, rowmask, dtable, B, T, C, scale);
+    RET_LAUNCH();
+}
+
+static size_t attn_lds_bytes(int Tp, int D, int win, bool)
+{
+    return ((size_t)Tp * (D + 1) + (size_t)(2 * win + 1) * D + 4 * (size_t)D + (size_t)ATT_QT * Tp) * sizeof(float);
+}
+
+extern "C" int glowtts_rpr_attention_fwd(const float* qkv, const float* relk, const float* relv, const float* rowmask, float* out, float* P,
+                                         int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t* seed_ptr, void* stream)
+{
+    if (!qkv || !relk || !relv || !rowmask || !out || !P || B < 1 || Tp < 1 || Tp > 256 || H < 1 || D < 1 || win < 0) return GLOWTTS_E_ARG;
+    const size_t lds = attn_lds_bytes(Tp, D, win, false);
+    if (lds > 160 * 1024) return GLOWTTS_E_ARG;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((Tp + ATT_QT - 1) / ATT_QT, H, B), dim3(256), lds, static_cast<hipStream_t>(stream),
+                       qkv, relk, relv, rowmask, out, P, B, Tp, H, D, win, drop_p, seed, seed_ptr);
+    RET_LAUNCH();
+}
+
+extern "C" int64_t glowtts_rpr_attention_scratch_floats(int B, int Tp, int H, int D, int win) { return (int64_t)B * H * 2 * (2 * win + 1) * D; }
+
+extern "C" int glowtts_rpr_attention_bwd(const float* qkv, const float* relk, const float* relv, const float* rowmask, const float* P, const float* dout,
+                                         float* dS /* [B][H][Tp][Tp] scratch */, float* dqkv, float* drelk, float* drelv, float* scratch,
+                                         int B, int Tp, int H, int D, int win, float drop_p, void* stream)
+{
+    if (!qkv || !relk || !relv || !rowmask || !P || !dout || !dS || !dqkv || !drelk || !drelv || !scratch || Tp > 256) return GLOWTTS_E_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t lds = attn_lds_bytes(Tp, D, win, true);
+    if (lds > 160 * 1024) return GLOWTTS_E_ARG;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_bwd_a_kernel, dim3((Tp + ATT_QT - 1) / ATT_QT, H, B), dim3(256), lds, st, qkv, relk, relv, rowmask, P, dout, dS, dqkv, B, Tp, H, D, win, drop_p);
+    hipLaunchKernelGGL(attn_bwd_b_kernel, dim3((Tp + 3) / 4, H, B), dim3(256), 0, st, qkv, P, dS, dout, dqkv, B, Tp, H, D);
+    const int nw = 2 * win + 1;
+    hipLaunchKernelGGL(attn_bwd_rel_kernel, dim3(nw, B * H), dim3(128), 0, st, qkv, P, dS, dout, scratch, B, Tp, H, D, win);
+    // partial [B*H][2*nw*D] -> [2*nw*D]: drelK then drelV
+    float* both = scratch + (int64_t)B * H * 2 * nw * D;     // the caller's scratch holds B*H*2*nw*D + 2*nw*D floats
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * nw * D + 3) / 4), dim3(256), 0, st, scratch, both, B * H, 2 * nw * D);
+    hipMemcpyAsync(drelk, both, (size_t)nw * D * sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(drelv, both + nw * D, (size_t)nw * D * sizeof(float), hipMemcpyDeviceToDevice, st);
+    RET_LAUNCH();
+}

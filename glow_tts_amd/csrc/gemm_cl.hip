@@ -368,6 +368,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
                     float v = acc[mi][ni][reg];
                     if (fl & GLOWTTS_F_BIAS) v += p.bias[n];
                     if (fl & GLOWTTS_F_RELU) v = fmaxf(v, 0.f);
+                    if (fl & GLOWTTS_F_DROPOUT) v *= drop_scale(p.seed, (uint32_t)r * (uint32_t)p.n + (uint32_t)n, p.drop_p, 1.f / (1.f - p.drop_p));
                     if (fl & GLOWTTS_F_ADD_IN0) v += p.in0[(long)r * p.ldi0 + n];
                     if (fl & GLOWTTS_F_MASK) v *= mask;
                     if ((fl & GLOWTTS_F_COLMASK) && n >= p.ncols_valid[blockIdx.z]) v = 0.f;
@@ -465,11 +466,18 @@ int launch_k(const glowtts_conv_args& a, hipStream_t s)
 template <typename CT, int EPI, int TAPS, int APRO>
 int launch_tile(const glowtts_conv_args& a, hipStream_t s)
 {
-    // tile choice: 128x128 by default; 64-row tiles when that is needed to put >= ~256 workgroups on the chip
-    const long tiles128 = (long)((a.rows + 127) / 128) * ((a.npad + 127) / 128) * (a.batch > 1 ? a.batch : 1);
-    static const int force = [] { const char* e = getenv("GLOWTTS_TILE_M"); return e ? atoi(e) : 0; }();   // tuning override
-    if (force == 128 || (force != 64 && tiles128 >= 256)) return launch_k<CT, 2, 2, 2, 2, EPI, TAPS, APRO>(a, s);
-    return launch_k<CT, 1, 2, 2, 2, EPI, TAPS, APRO>(a, s);
+    // Tile choice.  These GEMMs are short (K <= 1920) and their operands come from L2, so a workgroup spends most of its
+    // life waiting for a load phase or in its epilogue: what matters is how many workgroups are co-resident per CU to
+    // overlap that, not the tile's arithmetic intensity.  GLOWTTS_TILE = 0: 128x128, 1: 64x128, 2: 128x64, 3: 64x64.
+    static const int force = [] { const char* e = getenv("GLOWTTS_TILE"); return e ? atoi(e) : -1; }();
+    int cfg = force;
+    if (cfg < 0) cfg = 3;
+    switch (cfg) {
+        case 0: return launch_k<CT, 2, 2, 2, 2, EPI, TAPS, APRO>(a, s);
+        case 1: return launch_k<CT, 1, 2, 2, 2, EPI, TAPS, APRO>(a, s);
+        case 2: return launch_k<CT, 1, 2, 4, 1, EPI, TAPS, APRO>(a, s);
+        default: return launch_k<CT, 1, 2, 2, 1, EPI, TAPS, APRO>(a, s);
+    }
 }
 
 template <typename CT, int EPI, int APRO>

@@ -11,7 +11,7 @@ F32, BF16 = 0, 1
 PERM_NONE, PERM_PAIR = 0, 1
 APRO_NONE, APRO_PAIRMUL, APRO_SQNEG = 0, 1, 2
 EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_DGATE = 0, 1, 2, 3, 4
-F_BIAS, F_RELU, F_ADD_IN0, F_MASK, F_ACCUM, F_FIRST, F_LAST, F_REVERSE, F_COLMASK = 1, 2, 4, 8, 16, 32, 64, 128, 256
+F_BIAS, F_RELU, F_ADD_IN0, F_MASK, F_ACCUM, F_FIRST, F_LAST, F_REVERSE, F_COLMASK, F_DROPOUT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 
 class ConvArgs(ctypes.Structure):
@@ -69,7 +69,7 @@ def pack_weight(w, transpose=False, perm=PERM_NONE, perm_h=0, precision=BF16):
 
 def conv_cl(a, pw, ca, rows, *, lda=None, a2=None, lda2=0, ca1=0, apro=APRO_NONE, pad=0, epi=EPI_LINEAR, flags=0,
             n=None, h=0, rows_per_utt=1, bias=None, rowmask=None, cond=None, ldcond=0,
-            out0=None, ld0=0, out1=None, ld1=0, in0=None, ldi0=0, out0_off=0, a_off=0):
+            out0=None, ld0=0, out1=None, ld1=0, in0=None, ldi0=0, out0_off=0, a_off=0, drop_p=0.0, seed=0, seed_t=None):
     """Launches glowtts_conv_cl.  Tensors are fp32 device tensors; *_off are element offsets into them
     (to address a channel sub-range of a wider row)."""
     args = ConvArgs()
@@ -92,4 +92,6 @@ def conv_cl(a, pw, ca, rows, *, lda=None, a2=None, lda2=0, ca1=0, apro=APRO_NONE
     args.ld1 = ld1
     args.in0 = in0.data_ptr() if in0 is not None else None
     args.ldi0 = ldi0
+    args.drop_p, args.seed = float(drop_p), int(seed) & 0xFFFFFFFF
+    args.seed_ptr = seed_t.data_ptr() if seed_t is not None else None
     _lib.check(_lib.lib().glowtts_conv_cl(ctypes.byref(args), _lib.stream()), "glowtts_conv_cl")

@@ -109,6 +109,7 @@ int glowtts_pack_weight_batched(const float *w, int batch, int O, int I, int tap
 #define GLOWTTS_F_FIRST   32   /* RESSKIP: skip accumulator is written, not accumulated */
 #define GLOWTTS_F_LAST    64   /* RESSKIP: last WaveNet layer (n = h outputs, all skip, *mask) */
 #define GLOWTTS_F_REVERSE 128  /* COUPLE: inverse coupling x_b = (x_b - m) * exp(-logs) * mask */
+#define GLOWTTS_F_DROPOUT 512  /* LINEAR: dropout(p = drop_p, seed) after the optional ReLU, before residual / mask */
 #define GLOWTTS_F_COLMASK 256  /* LINEAR: zero columns n >= ncols_valid[batch]  (attention mask, Modules.py:102) */
 
 typedef struct glowtts_conv_args {
@@ -297,6 +298,33 @@ int glowtts_flow_backward(const glowtts_flow_dims *d, const glowtts_flow_params 
 /* per-utterance column sums: out[b][n] = sum over the rows of utterance b of x[r][col(n)]  (conditioning grads) */
 int glowtts_utt_colsum(const float *x, int64_t ldx, float *out, int64_t ldout, int B, int rows_per_utt, int n,
                        int perm, int perm_h, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Text-encoder kernels that are not convolutions (rows layout).
+ */
+/* y = rowmask * dropout( relu?( LayerNorm_C(a + b) * gamma + beta ) )   (Modules.py:485-487, 561-562, 569-571; eps 1e-4).
+ * b may be NULL; when given, s_out receives a + b (the LayerNorm input the backward needs).  stats [rows][2] = (mean, rstd). */
+int glowtts_layernorm_fwd(const float *a, const float *b, float *s_out, const float *gamma, const float *beta, const float *rowmask,
+                          float *y, float *stats, int64_t rows, int C, float eps, int relu, float drop_p, uint32_t seed,
+                          const uint32_t *seed_ptr, void *stream);
+int64_t glowtts_layernorm_scratch_floats(int64_t rows, int C);
+/* ds = dL/d(a + b); dgamma_dbeta [2C].  gated != 0: the forward applied relu and/or dropout, y is its output (zero where cut). */
+int glowtts_layernorm_bwd(const float *dy, const float *y, const float *s, const float *stats, const float *gamma, const float *rowmask,
+                          float *ds, float *dgamma_dbeta, float *scratch, int64_t rows, int C, int gated, float drop_p, void *stream);
+/* dz = dy * (out != 0 ? scale : 0) * rowmask : backward gate of relu / dropout given the forward output */
+int glowtts_gate_bwd(const float *dy, const float *out, const float *rowmask, float *dz, int64_t rows, int C, float scale, void *stream);
+/* rows[b][PAD+t][:] = table[tokens[b][t]][:] * scale * mask (Modules.py:267), and its gradient (deterministic) */
+int glowtts_embedding_fwd(const int64_t *tokens, const float *table, const float *rowmask, float *rows, int B, int T, int C, float scale, void *stream);
+int glowtts_embedding_bwd(const int64_t *tokens, const float *drows, const float *rowmask, float *dtable, int V, int B, int T, int C, float scale, void *stream);
+/* Relative-position multi-head self-attention core (RPR_MHA.py:95-128; window `win`, embeddings shared over heads).
+ * qkv rows [B][Tp][3*H*D] (Q | K | V); out rows [B][Tp][H*D]; P [B][H][Tp][Tp] keeps the (dropped) probabilities. Tp <= 256. */
+int glowtts_rpr_attention_fwd(const float *qkv, const float *relk, const float *relv, const float *rowmask, float *out, float *P,
+                              int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t *seed_ptr, void *stream);
+int64_t glowtts_rpr_attention_scratch_floats(int B, int Tp, int H, int D, int win);
+/* scratch: glowtts_rpr_attention_scratch_floats(...) + 2*(2*win+1)*D floats; dS: [B][H][Tp][Tp] floats */
+int glowtts_rpr_attention_bwd(const float *qkv, const float *relk, const float *relv, const float *rowmask, const float *P, const float *dout,
+                              float *dS, float *dqkv, float *drelk, float *drelv, float *scratch,
+                              int B, int Tp, int H, int D, int win, float drop_p, void *stream);
 
 #ifdef __cplusplus
 }
