@@ -172,13 +172,33 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ d, const float* __restrict__ rowmask,
                                                         float* __restrict__ dE, int B, int T, int C, float scale)
 {
+    // one workgroup per token id: (1) every thread scans a contiguous slice of the token array and the matching rows are
+    // compacted into LDS in position order (prefix sum over per-thread counts -> deterministic order), (2) threads walk channels.
+    extern __shared__ int lst[];                               // [256 counts/offsets] + [B*T rows]
+    int* cnt = lst;
+    int* rowsl = lst + 256;
     const int v = blockIdx.x;
     const int Tp = T + 2 * GLOWTTS_ROW_PAD;
+    const int N = B * T;
+    const int per = (N + 255) / 256;
+    const int lo = threadIdx.x * per, hi = min(N, lo + per);
+    int c0 = 0;
+    for (int i = lo; i < hi; ++i) c0 += (tok[i] == v);
+    cnt[threadIdx.x] = c0;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 256; ++i) { const int t = cnt[i]; cnt[i] = run; run += t; } }
+    __syncthreads();
+    int pos = cnt[threadIdx.x];
+    for (int i = lo; i < hi; ++i) if (tok[i] == v) { const int b = i / T, t = i - b * T; rowsl[pos++] = b * Tp + GLOWTTS_ROW_PAD + t; }
+    __syncthreads();
+    const int total = cnt[255] + ((255 * per < N) ? 0 : 0);
+    // number of matches = offset of the last thread + its own count
+    int n = 0;
+    { const int lo2 = 255 * per, hi2 = min(N, lo2 + per); int c1 = 0; for (int i = lo2; i < hi2; ++i) c1 += (tok[i] == v); n = cnt[255] + c1; }
+    (void)total;
     for (int c = threadIdx.x; c < C; c += 256) {
         float acc = 0.f;
-        for (int b = 0; b < B; ++b)
-            for (int t = 0; t < T; ++t)
-                if (tok[(long)b * T + t] == v) { const long r = (long)b * Tp + GLOWTTS_ROW_PAD + t; acc += d[r * C + c] * rowmask[r]; }
+        for (int k = 0; k < n; ++k) { const long r = rowsl[k]; acc += d[r * C + c] * rowmask[r]; }
         dE[(long)v * C + c] = acc * scale;
     }
 }
@@ -231,8 +251,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
                 float acc = 0.f;
                 const float* kr = KV + j * ldk;
                 const int dd = j - i;
-                if (dd >= -win && dd <= win) { const float* rr = Rr + (dd + win) * D; for (int d = 0; d < D; ++d) acc += q[d] * (kr[d] + rr[d]); }
-                else                         { for (int d = 0; d < D; ++d) acc += q[d] * kr[d]; }
+                if (dd >= -win && dd <= win) { const float* rr = Rr + (dd + win) * D;
+#pragma unroll 8
+                                               for (int d = 0; d < D; ++d) acc += q[d] * (kr[d] + rr[d]); }
+                else                         {
+#pragma unroll 8
+                                               for (int d = 0; d < D; ++d) acc += q[d] * kr[d]; }
                 s = acc * isd;
                 if (mi * rm[j] == 0.f) s = -1e4f;            // RPR_MHA.py:117
             }
@@ -445,14 +469,14 @@ extern "C" int glowtts_layernorm_fwd(const float* a, const float* b, float* s_ou
     RET_LAUNCH();
 }
 
-extern "C" int64_t glowtts_layernorm_scratch_floats(int64_t rows, int C) { return ((rows + 63) / 64) * 2 * (int64_t)C; }
+extern "C" int64_t glowtts_layernorm_scratch_floats(int64_t rows, int C) { return ((rows + 15) / 16) * 2 * (int64_t)C; }
 
 extern "C" int glowtts_layernorm_bwd(const float* dy, const float* y, const float* s, const float* stats, const float* gamma, const float* rowmask,
                                      float* ds, float* dgamma_dbeta /* [2C] */, float* scratch, int64_t rows, int C, int gated, float drop_p, void* stream)
 {
     if (!dy || !s || !stats || !gamma || !ds || !dgamma_dbeta || !scratch || rows < 1 || C < 1 || C > 64 * LN_MAXK || (gated && !y)) return GLOWTTS_E_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int rpb = 64;
+    const int rpb = 16;
     const int nblk = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 8 * C * sizeof(float), st, dy, y, s, stats, gamma, rowmask, ds, scratch, (long)rows, C, gated, drop_p, rpb);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, st, scratch, dgamma_dbeta, nblk, 2 * C);
@@ -477,7 +501,10 @@ extern "C" int glowtts_embedding_fwd(const int64_t* tokens, const float* table, 
 extern "C" int glowtts_embedding_bwd(const int64_t* tokens, const float* drows, const float* rowmask, float* dtable, int V, int B, int T, int C, float scale, void* stream)
 {
     if (!tokens || !drows || !rowmask || !dtable || V < 1 || B < 1 || T < 1 || C < 1) return GLOWTTS_E_ARG;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, static_cast<hipStream_t>(stream), tokens, drows, rowmask, dtable, B, T, C, scale);
+    const size_t lds = (256 + (size_t)B * T) * sizeof(int);
+    if (lds > 160 * 1024) return GLOWTTS_E_ARG;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), lds, static_cast<hipStream_t>(stream), tokens, drows, rowmask, dtable, B, T, C, scale);
     RET_LAUNCH();
 }
 

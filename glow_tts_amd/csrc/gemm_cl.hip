@@ -351,6 +351,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
 
     // ---- fused epilogue ----
     if (abl & 1) { if (acc[0][0][0] == 12345.678f) p.out0[0] = 1.f; return; }
+    float pb0[(NI + 1) / 2], pb1[(NI + 1) / 2];              // PAIR epilogues: the two bias values of each pair, loaded once
+    if constexpr (EPI == GLOWTTS_EPI_GATE || EPI == GLOWTTS_EPI_COUPLE) {
+#pragma unroll
+        for (int pi = 0; pi < NI / 2; ++pi) {
+            const int j = ((n0 + (wn * NI + 2 * pi) * 32) >> 6) * 32 + l31;
+            pb0[pi] = (j < p.h) ? p.bias[j] : 0.f;
+            pb1[pi] = (j < p.h) ? p.bias[p.h + j] : 0.f;
+        }
+    }
     // accumulator element: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31
     const int fl = p.flags;
 #pragma unroll
@@ -401,8 +410,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
                         const int pcol = n0 + (wn * NI + 2 * pi) * 32;           // packed column of the first half
                         const int j = (pcol >> 6) * 32 + l31;                     // channel inside a half
                         if (j >= p.h) continue;
-                        float v0 = acc[mi][2 * pi][reg] + p.bias[j];
-                        float v1 = acc[mi][2 * pi + 1][reg] + p.bias[p.h + j];
+                        float v0 = acc[mi][2 * pi][reg] + pb0[pi];
+                        float v1 = acc[mi][2 * pi + 1][reg] + pb1[pi];
                         if constexpr (EPI == GLOWTTS_EPI_GATE) {
                             if (p.drop_p > 0.f) {                                  // Modules.py:862 Dropout on the conv output
                                 const float ik = 1.f / (1.f - p.drop_p);
@@ -471,7 +480,7 @@ int launch_tile(const glowtts_conv_args& a, hipStream_t s)
     // overlap that, not the tile's arithmetic intensity.  GLOWTTS_TILE = 0: 128x128, 1: 64x128, 2: 128x64, 3: 64x64.
     static const int force = [] { const char* e = getenv("GLOWTTS_TILE"); return e ? atoi(e) : -1; }();
     int cfg = force;
-    if (cfg < 0) cfg = 3;
+    if (cfg < 0) cfg = 2;                  // 128 x 64: best of the four on the B = 32 WaveNet shapes (tools/bench_conv.py)
     switch (cfg) {
         case 0: return launch_k<CT, 2, 2, 2, 2, EPI, TAPS, APRO>(a, s);
         case 1: return launch_k<CT, 1, 2, 2, 2, EPI, TAPS, APRO>(a, s);
