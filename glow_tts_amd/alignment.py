@@ -18,6 +18,11 @@ def _lib2():
     L = _L()
     if not _decl:
         L.glowtts_mas_dp_f32_t.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_void_p]
+        L.glowtts_expand_fwd.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        L.glowtts_expand_bwd.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        L.glowtts_duration_targets.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+        L.glowtts_mle_loss_fwd.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.glowtts_mle_loss_bwd.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_void_p]
         _decl = True
     return L
 
@@ -58,6 +63,67 @@ def maximum_path_t(value_t, token_lengths, mel_lengths, max_neg_val=-1e9):
     _lib.check(_lib2().glowtts_mas_dp_f32_t(_lib.ptr(value_t), _lib.ptr(tx), _lib.ptr(ty), _lib.ptr(idx), None, B, Tx, Ty,
                                             max_neg_val, _lib.stream()), "glowtts_mas_dp_f32_t")
     return idx
+
+
+class ExpandPrior(torch.autograd.Function):
+    """src @ attentions for one-hot-per-frame attentions (Modules.py:120-121): gather by the MAS token index."""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        src = src.contiguous()
+        B, C, Tx = src.shape
+        Ty = idx.shape[1]
+        out = torch.empty(B, C, Ty, device=src.device)
+        _lib.check(_lib2().glowtts_expand_fwd(_lib.ptr(src), _lib.ptr(idx), _lib.ptr(out), B, C, Tx, Ty, _lib.stream()), "glowtts_expand_fwd")
+        ctx.save_for_backward(idx)
+        ctx.Tx = Tx
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, C, Ty = dout.shape
+        dsrc = torch.empty(B, C, ctx.Tx, device=dout.device)
+        _lib.check(_lib2().glowtts_expand_bwd(_lib.ptr(dout), _lib.ptr(idx), _lib.ptr(dsrc), B, C, ctx.Tx, Ty, _lib.stream()), "glowtts_expand_bwd")
+        return dsrc, None
+
+
+@torch.no_grad()
+def duration_targets(idx, token_lengths, Tx):
+    """log(sum_t attentions + 1e-7) * token_mask (Modules.py:122) -> [B,1,Tx]."""
+    B, Ty = idx.shape
+    out = torch.empty(B, Tx, device=idx.device)
+    _lib.check(_lib2().glowtts_duration_targets(_lib.ptr(idx), _lib.ptr(token_lengths.contiguous()), _lib.ptr(out), B, Tx, Ty, _lib.stream()),
+               "glowtts_duration_targets")
+    return out.unsqueeze(1)
+
+
+class MLELoss(torch.autograd.Function):
+    """Modules.py:1020-1029 as one reduction + one elementwise backward kernel."""
+
+    @staticmethod
+    def forward(ctx, z, mean, log_std, log_dets, lengths, n_squeeze, mel_dim):
+        z, mean, log_std, log_dets = z.contiguous(), mean.contiguous(), log_std.contiguous(), log_dets.contiguous()
+        dev = z.device
+        loss, inv = torch.empty((), device=dev), torch.empty(1, device=dev)
+        scratch = torch.empty(1024, device=dev)
+        _lib.check(_lib2().glowtts_mle_loss_fwd(_lib.ptr(z), _lib.ptr(mean), _lib.ptr(log_std), _lib.ptr(log_dets), _lib.ptr(lengths.contiguous()),
+                                                loss.data_ptr(), inv.data_ptr(), _lib.ptr(scratch), z.numel(), z.shape[0], n_squeeze, mel_dim,
+                                                _lib.stream()), "glowtts_mle_loss_fwd")
+        ctx.save_for_backward(z, mean, log_std, inv)
+        ctx.B = z.shape[0]
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        z, mean, log_std, inv = ctx.saved_tensors
+        dz, dm, dl = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+        dl_ = dloss.contiguous().reshape(1)
+        _lib.check(_lib2().glowtts_mle_loss_bwd(_lib.ptr(z), _lib.ptr(mean), _lib.ptr(log_std), _lib.ptr(dl_), _lib.ptr(inv), _lib.ptr(dz),
+                                                _lib.ptr(dm), _lib.ptr(dl), z.numel(), _lib.stream()), "glowtts_mle_loss_bwd")
+        dlogdet = (-dl_ * inv).expand(ctx.B).contiguous()
+        return dz, dm, dl, dlogdet, None, None, None
 
 
 @torch.no_grad()

@@ -1,0 +1,147 @@
+// Alignment expansion and likelihood loss of the Glow-TTS training graph for gfx950:
+//   expand   mel_Mean = mean @ attentions, mel_Log_Std = log_Std @ attentions (Modules.py:120-121): attentions has exactly one 1
+//            per valid frame, so the batched matmul is a gather by the MAS token index; its gradient is a segment sum.
+//   targets  log_Duration_Targets = log(sum_t attentions + 1e-7) * token_mask (Modules.py:122): run lengths of the index.
+//   mle      MLE_Loss (Modules.py:1020-1029) and its gradient.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/glowtts_hip.h"
+
+namespace {
+
+// src [B][C][Tx] -> out [B][C][Ty], out[b][c][y] = idx[b][y] >= 0 ? src[b][c][idx[b][y]] : 0
+__global__ __launch_bounds__(256) void expand_fwd_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, float* __restrict__ out,
+                                                         int C, int Tx, int Ty)
+{
+    const int b = blockIdx.z, c = blockIdx.y;
+    const float* s = src + ((long)b * C + c) * Tx;
+    float* o = out + ((long)b * C + c) * Ty;
+    const int32_t* ib = idx + (long)b * Ty;
+    for (int y = blockIdx.x * 256 + threadIdx.x; y < Ty; y += gridDim.x * 256) { const int x = ib[y]; o[y] = x >= 0 ? s[x] : 0.f; }
+}
+// dsrc[b][c][x] = sum_{y : idx[b][y] == x} dout[b][c][y].  idx is non-decreasing over the valid frames, so the frames of token x are
+// the contiguous range [first[x], first[x+1]); one thread per (b, c, x), `first` from a per-utterance scan kept in LDS.
+__global__ __launch_bounds__(256) void expand_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ idx, float* __restrict__ dsrc,
+                                                         int C, int Tx, int Ty)
+{
+    extern __shared__ int first[];                       // [Tx + 1]
+    const int b = blockIdx.y;
+    const int32_t* ib = idx + (long)b * Ty;
+    for (int x = threadIdx.x; x <= Tx; x += 256) first[x] = -1;
+    __syncthreads();
+    for (int y = threadIdx.x; y < Ty; y += 256) {
+        const int x = ib[y];
+        if (x >= 0 && (y == 0 || ib[y - 1] != x)) first[x] = y;
+        if (x >= 0 && (y == Ty - 1 || ib[y + 1] < 0)) first[Tx] = y + 1;      // one past the last valid frame (written once)
+    }
+    __syncthreads();
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < C * Tx; i += gridDim.x * 256) {
+        const int c = i / Tx, x = i - c * Tx;
+        float acc = 0.f;
+        const int y0 = first[x];
+        if (y0 >= 0) {
+            const float* d = dout + ((long)b * C + c) * Ty;
+            for (int y = y0; y < Ty && ib[y] == x; ++y) acc += d[y];
+        }
+        dsrc[((long)b * C + c) * Tx + x] = acc;
+    }
+}
+// target[b][x] = log(count_x + 1e-7) * (x < t_x[b])
+__global__ __launch_bounds__(256) void dur_target_kernel(const int32_t* __restrict__ idx, const int64_t* __restrict__ t_x, float* __restrict__ out, int Tx, int Ty)
+{
+    extern __shared__ int cnt[];
+    const int b = blockIdx.x;
+    for (int x = threadIdx.x; x < Tx; x += 256) cnt[x] = 0;
+    __syncthreads();
+    const int32_t* ib = idx + (long)b * Ty;
+    for (int y = threadIdx.x; y < Ty; y += 256) { const int x = ib[y]; if (x >= 0) atomicAdd(&cnt[x], 1); }    // integer LDS atomics: exact
+    __syncthreads();
+    const int tx = (int)t_x[b];
+    for (int x = threadIdx.x; x < Tx; x += 256) out[(long)b * Tx + x] = (x < tx) ? logf((float)cnt[x] + 1e-7f) : 0.f;
+}
+
+// MLE_Loss (Modules.py:1025): partial sums of  log_std + 0.5 * exp(-2 log_std) * (z - mean)^2  (two-stage, deterministic)
+__global__ __launch_bounds__(256) void mle_partial_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ ls,
+                                                          float* __restrict__ partial, long n)
+{
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float d = z[i] - mean[i];
+        acc += ls[i] + 0.5f * expf(-2.f * ls[i]) * d * d;
+    }
+    red[threadIdx.x] = acc; __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+// loss = (sum partial - sum logdet) / (sum(len // ns) * ns * mel_dim) + 0.5 log(2 pi);  also writes 1/denominator for the backward
+__global__ __launch_bounds__(256) void mle_final_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ logdet, const int64_t* __restrict__ lengths,
+                                                        int B, int ns, int mel_dim, float* __restrict__ loss, float* __restrict__ inv_denom)
+{
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) acc += partial[i];
+    for (int i = threadIdx.x; i < B; i += 256) acc -= logdet[i];
+    red[threadIdx.x] = acc; __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        long frames = 0;
+        for (int i = 0; i < B; ++i) frames += (lengths[i] / ns) * ns;
+        const double den = (double)frames * mel_dim;
+        *loss = (float)(red[0] / den + 0.5 * 1.8378770664093453);
+        *inv_denom = (float)(1.0 / den);
+    }
+}
+// gradients: dz = g e (z - m), dmean = -dz, dls = g (1 - e (z - m)^2), with e = exp(-2 ls), g = dloss / denom
+__global__ __launch_bounds__(256) void mle_bwd_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ ls,
+                                                      const float* __restrict__ dloss, const float* __restrict__ inv_denom,
+                                                      float* __restrict__ dz, float* __restrict__ dmean, float* __restrict__ dls, long n)
+{
+    const float g = dloss[0] * inv_denom[0];
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float d = z[i] - mean[i], e = expf(-2.f * ls[i]);
+        const float t = g * e * d;
+        dz[i] = t; dmean[i] = -t; dls[i] = g * (1.f - e * d * d);
+    }
+}
+
+#define RET_LAUNCH() return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH
+}  // namespace
+
+extern "C" int glowtts_expand_fwd(const float* src, const int32_t* idx, float* out, int B, int C, int Tx, int Ty, void* stream)
+{
+    if (!src || !idx || !out || B < 1 || C < 1 || Tx < 1 || Ty < 1) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(expand_fwd_kernel, dim3((Ty + 255) / 256, C, B), dim3(256), 0, static_cast<hipStream_t>(stream), src, idx, out, C, Tx, Ty);
+    RET_LAUNCH();
+}
+extern "C" int glowtts_expand_bwd(const float* dout, const int32_t* idx, float* dsrc, int B, int C, int Tx, int Ty, void* stream)
+{
+    if (!dout || !idx || !dsrc || B < 1 || C < 1 || Tx < 1 || Ty < 1) return GLOWTTS_E_ARG;
+    const int gx = (C * Tx + 255) / 256 > 64 ? 64 : (C * Tx + 255) / 256;
+    hipLaunchKernelGGL(expand_bwd_kernel, dim3(gx, B), dim3(256), (Tx + 1) * sizeof(int), static_cast<hipStream_t>(stream), dout, idx, dsrc, C, Tx, Ty);
+    RET_LAUNCH();
+}
+extern "C" int glowtts_duration_targets(const int32_t* idx, const int64_t* token_lengths, float* out, int B, int Tx, int Ty, void* stream)
+{
+    if (!idx || !token_lengths || !out || B < 1 || Tx < 1 || Ty < 1) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(dur_target_kernel, dim3(B), dim3(256), Tx * sizeof(int), static_cast<hipStream_t>(stream), idx, token_lengths, out, Tx, Ty);
+    RET_LAUNCH();
+}
+extern "C" int glowtts_mle_loss_fwd(const float* z, const float* mean, const float* log_std, const float* log_dets, const int64_t* lengths,
+                                    float* loss, float* inv_denom, float* scratch /* 1024 floats */, int64_t n, int B, int n_squeeze, int mel_dim, void* stream)
+{
+    if (!z || !mean || !log_std || !log_dets || !lengths || !loss || !inv_denom || !scratch || n < 1 || B < 1) return GLOWTTS_E_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nblk = (int)((n + 4095) / 4096 > 1024 ? 1024 : (n + 4095) / 4096);
+    hipLaunchKernelGGL(mle_partial_kernel, dim3(nblk), dim3(256), 0, s, z, mean, log_std, scratch, (long)n);
+    hipLaunchKernelGGL(mle_final_kernel, dim3(1), dim3(256), 0, s, scratch, nblk, log_dets, lengths, B, n_squeeze, mel_dim, loss, inv_denom);
+    RET_LAUNCH();
+}
+extern "C" int glowtts_mle_loss_bwd(const float* z, const float* mean, const float* log_std, const float* dloss, const float* inv_denom,
+                                    float* dz, float* dmean, float* dlog_std, int64_t n, void* stream)
+{
+    if (!z || !mean || !log_std || !dloss || !inv_denom || !dz || !dmean || !dlog_std || n < 1) return GLOWTTS_E_ARG;
+    const long g = (n + 255) / 256;
+    hipLaunchKernelGGL(mle_bwd_kernel, dim3((int)(g > 2048 ? 2048 : g)), dim3(256), 0, static_cast<hipStream_t>(stream), z, mean, log_std, dloss, inv_denom, dz, dmean, dlog_std, (long)n);
+    RET_LAUNCH();
+}

@@ -250,9 +250,11 @@ class GlowTTS(torch.nn.Module):
         attn, idx, _ = alignment.align(mean.detach(), log_std.detach(), z.detach(), token_lengths, z_len)   # Modules.py:107-116
         if z.shape[2] != attn.shape[2]:
             attn = attn[:, :, :z.shape[2]]
-        mel_mean = mean @ attn                                                                       # Modules.py:120
-        mel_log_std = log_std @ attn                                                                 # Modules.py:121
-        log_dur_targets = torch.log(attn.unsqueeze(1).sum(-1) + 1e-7) * token_mask                   # Modules.py:122
+        if idx.shape[1] != z.shape[2]:
+            idx = idx[:, :z.shape[2]].contiguous()
+        mel_mean = alignment.ExpandPrior.apply(mean, idx)                                            # Modules.py:120 (gather by the MAS index)
+        mel_log_std = alignment.ExpandPrior.apply(log_std, idx)                                      # Modules.py:121
+        log_dur_targets = alignment.duration_targets(idx, token_lengths, tokens.shape[1])            # Modules.py:122
         classified = None
         return z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_targets, attn, classified
 
@@ -303,6 +305,4 @@ class MLE_Loss(torch.nn.modules.loss._Loss):
 
     def forward(self, z, mean, std, log_dets, lengths):
         hp = self.hp
-        loss = torch.sum(std) + 0.5 * torch.sum(torch.exp(-2 * std) * (z - mean) ** 2) - torch.sum(log_dets)
-        loss = loss / (torch.sum(lengths // hp.Decoder.Num_Squeeze) * hp.Decoder.Num_Squeeze * hp.Sound.Mel_Dim)
-        return loss + 0.5 * math.log(2 * math.pi)
+        return alignment.MLELoss.apply(z, mean, std, log_dets, lengths, int(hp.Decoder.Num_Squeeze), int(hp.Sound.Mel_Dim))

@@ -326,6 +326,21 @@ int glowtts_rpr_attention_bwd(const float *qkv, const float *relk, const float *
                               float *dS, float *dqkv, float *drelk, float *drelv, float *scratch,
                               int B, int Tp, int H, int D, int win, float drop_p, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Alignment expansion and likelihood loss.
+ */
+/* out[b][c][y] = idx[b][y] >= 0 ? src[b][c][idx[b][y]] : 0   ==  src @ attentions (Modules.py:120-121), attentions one-hot per frame */
+int glowtts_expand_fwd(const float *src, const int32_t *idx, float *out, int B, int C, int Tx, int Ty, void *stream);
+/* its gradient w.r.t. src: a segment sum over the (contiguous) frames of each token */
+int glowtts_expand_bwd(const float *dout, const int32_t *idx, float *dsrc, int B, int C, int Tx, int Ty, void *stream);
+/* log_Duration_Targets = log(frames per token + 1e-7) * token_mask   (Modules.py:122); out [B][Tx] */
+int glowtts_duration_targets(const int32_t *idx, const int64_t *token_lengths, float *out, int B, int Tx, int Ty, void *stream);
+/* MLE_Loss (Modules.py:1020-1029) over n = B*mel_dim*T_mel elements; loss and inv_denom are device scalars; scratch 1024 floats */
+int glowtts_mle_loss_fwd(const float *z, const float *mean, const float *log_std, const float *log_dets, const int64_t *lengths,
+                         float *loss, float *inv_denom, float *scratch, int64_t n, int B, int n_squeeze, int mel_dim, void *stream);
+int glowtts_mle_loss_bwd(const float *z, const float *mean, const float *log_std, const float *dloss, const float *inv_denom,
+                         float *dz, float *dmean, float *dlog_std, int64_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
