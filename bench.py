@@ -177,6 +177,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--ragged", action="store_true", help="Set V (ragged lengths) instead of Set F (fixed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to smoke-test the "
+                    "multi-rank code path on a single-GPU box together with GLOWTTS_BENCH_ONE_DEVICE=1)")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (experimental: on ROCm 7.2 the "
                     "instantiate of this ~1500-node graph segfaults inside hipStreamEndCapture, so eager launches are the default)")
     args = ap.parse_args()
@@ -186,11 +188,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if os.environ.get("GLOWTTS_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from glow_tts_amd.distributed import FlatGradReducer, actnorm_stats_allreduce
     model, mle_loss, hp = build_model(args.precision, dev)

@@ -46,35 +46,24 @@ class FlatGradReducer:
                 cur, size = [], 0
         if cur:
             self.buckets.append(cur)
-        self.flat = None
 
     def reduce(self, average=False):
+        """SUM (or mean) all-reduce of every parameter gradient.  Per bucket: one concatenation kernel, one asynchronous
+        all-reduce, and the parameters' .grad become VIEWS of the reduced flat buffer (no copy back)."""
         if not is_dist():
             return
         ws = dist.get_world_size()
-        if self.flat is None:
-            dev = self.params[0].device
-            self.flat = [torch.empty(sum(p.numel() for p in b), device=dev) for b in self.buckets]
-        works = []
-        for b, flat in zip(self.buckets, self.flat):
-            off = 0
-            for p in b:
-                n = p.numel()
-                if p.grad is None:
-                    flat[off:off + n].zero_()
-                else:
-                    flat[off:off + n].copy_(p.grad.reshape(-1))
-                off += n
+        flats, works = [], []
+        for b in self.buckets:
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b])
+            flats.append(flat)
             works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
-        for b, flat, w in zip(self.buckets, self.flat, works):
+        for b, flat, w in zip(self.buckets, flats, works):
             w.wait()
             if average:
                 flat.div_(ws)
             off = 0
             for p in b:
                 n = p.numel()
-                if p.grad is None:
-                    p.grad = flat[off:off + n].view_as(p).clone()
-                else:
-                    p.grad.copy_(flat[off:off + n].view_as(p))
+                p.grad = flat[off:off + n].view_as(p)
                 off += n
