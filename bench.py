@@ -179,8 +179,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to smoke-test the "
                     "multi-rank code path on a single-GPU box together with GLOWTTS_BENCH_ONE_DEVICE=1)")
-    ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (experimental: on ROCm 7.2 the "
-                    "instantiate of this ~1500-node graph segfaults inside hipStreamEndCapture, so eager launches are the default)")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel eagerly instead of replaying the "
+                    "captured hipGraph of the step (default: graph replay; at B = 32 the eager step is bound by ~17 ms of host launch work)")
+    ap.set_defaults(graph=True)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -219,8 +220,19 @@ def main():
     from glow_tts_amd.distributed import global_frame_weight
     mode = "eager"
     graph = None
-    for _ in range(max(1, args.warmup - 1)):                   # also runs the ActNorm data-dependent init
-        loss = train_step(model, mle_loss, batch, reducer, world)
+    side = torch.cuda.Stream() if args.graph else None
+    if args.graph:
+        # every eager step that precedes the capture runs on the side stream too: a backward that ran on the default stream
+        # first makes the captured AccumulateGrad nodes hop streams, which crashes hipStreamEndCapture on ROCm 7.2
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, args.warmup - 1)):
+                loss = train_step(model, mle_loss, batch, reducer, world)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+    else:
+        for _ in range(max(1, args.warmup - 1)):               # also runs the ActNorm data-dependent init
+            loss = train_step(model, mle_loss, batch, reducer, world)
     if args.graph:
         try:
             wfr = global_frame_weight(batch[3].sum()) if world > 1 else None      # constant for a fixed batch
@@ -235,7 +247,6 @@ def main():
                 total.backward()
                 return (mle + length).detach()
 
-            side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
@@ -243,7 +254,7 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
                 static_loss = fwd_bwd()
             graph.replay()
             torch.cuda.synchronize()

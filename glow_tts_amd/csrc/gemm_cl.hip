@@ -479,8 +479,10 @@ int launch_tile(const glowtts_conv_args& a, hipStream_t s)
     // life waiting for a load phase or in its epilogue: what matters is how many workgroups are co-resident per CU to
     // overlap that, not the tile's arithmetic intensity.  GLOWTTS_TILE = 0: 128x128, 1: 64x128, 2: 128x64, 3: 64x64.
     static const int force = [] { const char* e = getenv("GLOWTTS_TILE"); return e ? atoi(e) : -1; }();
-    int cfg = force;
-    if (cfg < 0) cfg = 2;                  // 128 x 64: best of the four on the B = 32 WaveNet shapes (tools/bench_conv.py)
+    static const int force_t1 = [] { const char* e = getenv("GLOWTTS_TILE_T1"); return e ? atoi(e) : -1; }();
+    int cfg = (TAPS == 1 && force_t1 >= 0) ? force_t1 : force;
+    if (cfg < 0) cfg = (TAPS == 1) ? 1 : 2;   // measured at B = 32: 128 x 64 for the k-tap convs (tools/bench_conv.py), 64 x 128 for the 1x1
+                                              // convs whose wide fp32 A rows would otherwise be re-read by six N tiles (bench.py: 21.9 -> 20.3 ms)
     switch (cfg) {
         case 0: return launch_k<CT, 2, 2, 2, 2, EPI, TAPS, APRO>(a, s);
         case 1: return launch_k<CT, 1, 2, 2, 2, EPI, TAPS, APRO>(a, s);

@@ -5,6 +5,7 @@ parameters from ./Hyper_Parameters.yaml), call signatures, return tuples, attrib
 HIP library (glow_tts_amd/csrc) or, for the parts still marked interim in DESIGN.md, in PyTorch-ROCm device ops.
 """
 import math
+import os
 
 import torch
 
@@ -185,6 +186,8 @@ class GlowTTS(torch.nn.Module):
         self.dec_cfg = decoder.DecoderConfig(hp.Sound.Mel_Dim, hp.Decoder.Stack, hp.Decoder.Num_Squeeze, hp.Decoder.Num_Split,
                                              hp.Decoder.Affine_Coupling.Calc_Channels, wn.Num_Layers, wn.Kernel_Size, prec)
         self.actnorm_allreduce = None     # set by the data-parallel wrapper (glow_tts_amd.distributed)
+        self._enc_stream = None
+        self.overlap_encoder = os.environ.get("GLOWTTS_ENCODER_OVERLAP", "1") == "1"
 
     # ---------------------------------------------------------------- helpers
     def _params(self):
@@ -239,12 +242,25 @@ class GlowTTS(torch.nn.Module):
         P = self._params()
         spk, pro = self._conditioning(P, speakers, mels_for_ge2e, mels, mel_lengths)
         token_mask = self.Mask_Generate(token_lengths, tokens.shape[1])
-        mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, self.training, precision=self.dec_cfg.precision)
+        # Encoder and decoder are independent until the log-prior: the encoder runs on its own HIP stream, concurrently with the
+        # flow decoder whose latency-bound kernels leave CUs idle.  autograd replays each backward on its forward stream, so the
+        # two backward passes overlap as well.
+        main = torch.cuda.current_stream()
+        if self._enc_stream is None:
+            self._enc_stream = torch.cuda.Stream()
+        side = self._enc_stream if self.overlap_encoder else main
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, self.training, precision=self.dec_cfg.precision)
         cond = decoder.conditioning(P, self.dec_cfg, spk, pro)
         self._maybe_init_actnorm(P, mels, mel_lengths, cond)
         W = decoder.stack_decoder_weights(P, self.dec_cfg)
         drop_p = float(hp.Decoder.Affine_Coupling.WaveNet.Dropout_Rate) if self.training else 0.0      # Modules.py:854-862
         z, log_dets = decoder.DecoderFunction.apply(self.dec_cfg, mels, mel_lengths, cond, drop_p, *W)
+        if side is not main:
+            main.wait_stream(side)
+            for t_ in (mean, log_std, log_dur):
+                t_.record_stream(main)
         ns = hp.Decoder.Num_Squeeze
         z_len = (mel_lengths // ns) * ns
         attn, idx, _ = alignment.align(mean.detach(), log_std.detach(), z.detach(), token_lengths, z_len)   # Modules.py:107-116
