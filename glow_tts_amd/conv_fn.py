@@ -23,7 +23,7 @@ class WgradArgs(ctypes.Structure):
                 ("rows", c_int), ("m", c_int), ("ca", c_int), ("taps", c_int), ("pad", c_int),
                 ("perm", c_int), ("perm_h", c_int), ("precision", c_int),
                 ("splits", c_int), ("accumulate", c_int),
-                ("dw", c_p), ("dbias", c_p)]
+                ("dw", c_p), ("dbias", c_p), ("io_flags", c_int)]
 
 
 def _L():
@@ -46,7 +46,7 @@ def _L():
     return L
 
 
-def wgrad(dy, x, O, ca, taps, precision, want_bias=True, splits=0):
+def wgrad(dy, x, O, ca, taps, precision, want_bias=True, splits=0, xpro=0, io_flags=0):
     """dW [O, ca, taps], db [O] from dy rows [R, >=O] and x rows [R, >=ca]."""
     R = dy.shape[0]
     dw = torch.zeros(O, ca, taps, device=dy.device)
@@ -55,6 +55,7 @@ def wgrad(dy, x, O, ca, taps, precision, want_bias=True, splits=0):
     a.dy, a.lddy, a.x, a.ldx = dy.data_ptr(), dy.shape[1], x.data_ptr(), x.shape[1]
     a.rows, a.m, a.ca, a.taps, a.pad = R, O, ca, taps, (taps - 1) // 2
     a.precision, a.splits, a.accumulate = precision, splits, 1
+    a.xpro, a.io_flags = xpro, io_flags
     a.dw, a.dbias = dw.data_ptr(), (db.data_ptr() if db is not None else None)
     _lib.check(_L().glowtts_wgrad_cl(ctypes.byref(a), _lib.stream()), "glowtts_wgrad_cl")
     return dw, db

@@ -26,6 +26,7 @@ int check_dims(const glowtts_flow_dims* d) {
     if (!d || d->B < 1 || d->T < 1 || d->C < 4 || (d->C & 3) || d->H < 1 || (d->H & 3) || d->L < 1 || d->L > GLOWTTS_MAX_WN_LAYERS) return GLOWTTS_E_ARG;
     if (d->ksize != 1 && d->ksize != 3 && d->ksize != 5) return GLOWTTS_E_ARG;
     if ((d->ksize - 1) / 2 > GLOWTTS_ROW_PAD) return GLOWTTS_E_ARG;
+    if (d->act_bf16 && (d->precision != GLOWTTS_BF16 || (d->H & 7))) return GLOWTTS_E_ARG;
     return GLOWTTS_OK;
 }
 
@@ -42,12 +43,13 @@ glowtts_conv_args base_args(const Ctx& c, const glowtts_packed& w, int taps) {
 int coupling_net(const Ctx& c, const float* xsrc, float* xdst, bool reverse, bool keep) {
     const glowtts_flow_params* p = c.p; const glowtts_flow_acts* A = c.a;
     const int H = c.H, L = c.d->L;
+    const bool bf = c.d->act_bf16 != 0;          // hs / gates stored as bf16
     // Start: h0 = (W x_a + b) * mask                                         Modules.py:791
     {
         glowtts_conv_args a = base_args(c, p->start, 1);
         a.a = xsrc; a.lda = c.d->C; a.ca = c.C2; a.n = H;
         a.epi = GLOWTTS_EPI_LINEAR; a.flags = GLOWTTS_F_BIAS | GLOWTTS_F_MASK; a.bias = p->b_start;
-        a.out0 = A->hs[0]; a.ld0 = H;
+        a.out0 = A->hs[0]; a.ld0 = H; a.io_flags = bf ? GLOWTTS_IO_OUT0_BF16 : 0;
         CHECK(glowtts_conv_cl(&a, c.s));
     }
     for (int l = 0; l < L; ++l) {
@@ -59,7 +61,7 @@ int coupling_net(const Ctx& c, const float* xsrc, float* xdst, bool reverse, boo
             a.a = hin; a.lda = H; a.ca = H; a.n = 2 * H; a.h = H;
             a.epi = GLOWTTS_EPI_GATE; a.bias = p->b_in[l]; a.drop_p = c.d->drop_p; a.seed = c.d->seed + (uint32_t)l; a.seed_ptr = c.d->seed_ptr;
             if (p->cond) { a.cond = p->cond + (int64_t)l * 2 * H; a.ldcond = p->ldcond; }
-            a.out0 = g; a.ld0 = 2 * H;
+            a.out0 = g; a.ld0 = 2 * H; a.io_flags = bf ? (GLOWTTS_IO_A_BF16 | GLOWTTS_IO_OUT0_BF16) : 0;
             CHECK(glowtts_conv_cl(&a, c.s));
         }
         {   // Res_Skip_l on acts = tanh*sigmoid                                 Modules.py:871-881
@@ -70,6 +72,7 @@ int coupling_net(const Ctx& c, const float* xsrc, float* xdst, bool reverse, boo
             a.epi = GLOWTTS_EPI_RESSKIP; a.flags = (l == 0 ? GLOWTTS_F_FIRST : 0) | (last ? GLOWTTS_F_LAST : 0);
             a.bias = p->b_rs[l];
             a.in0 = hin; a.ldi0 = H; a.out0 = last ? A->skip : hout; a.ld0 = H; a.out1 = A->skip; a.ld1 = H;
+            a.io_flags = bf ? (GLOWTTS_IO_A_BF16 | GLOWTTS_IO_IN0_BF16 | GLOWTTS_IO_OUT0_BF16) : 0;     // (last layer: out0 is unused)
             CHECK(glowtts_conv_cl(&a, c.s));
         }
     }
@@ -103,7 +106,8 @@ int copy_half(const float* src, float* dst, long rows, int C, int n, void* s) {
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
-__global__ __launch_bounds__(256) void utt_colsum_kernel(const float* __restrict__ x, long ldx, float* __restrict__ out, long ldout,
+template <typename XT>
+__global__ __launch_bounds__(256) void utt_colsum_kernel(const XT* __restrict__ x, long ldx, float* __restrict__ out, long ldout,
                                                          int rows_per_utt, int n, int perm, int perm_h)
 {
     const int b = blockIdx.y;
@@ -111,10 +115,20 @@ __global__ __launch_bounds__(256) void utt_colsum_kernel(const float* __restrict
     if (col >= n) return;
     int pc = col;
     if (perm == GLOWTTS_PERM_PAIR) { const int hs = col / perm_h, j = col - hs * perm_h; pc = (j >> 5) * 64 + hs * 32 + (j & 31); }
-    const float* xb = x + (long)b * rows_per_utt * ldx + pc;
+    const XT* xb = x + (long)b * rows_per_utt * ldx + pc;
     float s = 0.f;
-    for (int r = 0; r < rows_per_utt; ++r) s += xb[(long)r * ldx];
+    for (int r = 0; r < rows_per_utt; ++r) s += (float)xb[(long)r * ldx];
     out[(long)b * ldout + col] = s;
+}
+
+int utt_colsum(const float* x, int64_t ldx, float* out, int64_t ldout, int B, int rows_per_utt, int n, int perm, int perm_h, bool x_bf16, void* stream)
+{
+    if (!x || !out || B < 1 || rows_per_utt < 1 || n < 1) return GLOWTTS_E_ARG;
+    const dim3 grid((n + 255) / 256, B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (x_bf16) hipLaunchKernelGGL(utt_colsum_kernel<__bf16>, grid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(x), (long)ldx, out, (long)ldout, rows_per_utt, n, perm, perm_h);
+    else hipLaunchKernelGGL(utt_colsum_kernel<float>, grid, dim3(256), 0, s, x, (long)ldx, out, (long)ldout, rows_per_utt, n, perm, perm_h);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
 }  // namespace
@@ -122,10 +136,7 @@ __global__ __launch_bounds__(256) void utt_colsum_kernel(const float* __restrict
 extern "C" int glowtts_utt_colsum(const float* x, int64_t ldx, float* out, int64_t ldout, int B, int rows_per_utt, int n,
                                   int perm, int perm_h, void* stream)
 {
-    if (!x || !out || B < 1 || rows_per_utt < 1 || n < 1) return GLOWTTS_E_ARG;
-    hipLaunchKernelGGL(utt_colsum_kernel, dim3((n + 255) / 256, B), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       x, (long)ldx, out, (long)ldout, rows_per_utt, n, perm, perm_h);
-    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+    return utt_colsum(x, ldx, out, ldout, B, rows_per_utt, n, perm, perm_h, false, stream);
 }
 
 extern "C" int glowtts_flow_forward(const glowtts_flow_dims* d, const glowtts_flow_params* p, const glowtts_flow_acts* a, void* stream)
@@ -166,6 +177,7 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
         w.precision = d->precision; w.splits = 0; w.accumulate = 1; w.dw = dw; w.dbias = db;
         return w;
     };
+    const bool bf = d->act_bf16 != 0;         // gates / hs / dins stored as bf16
 
     // 1. affine coupling backward                                               autograd of Modules.py:805-806
     CHECK(glowtts_coupling_bwd(g->dx, a->xmid, a->outs, g->douts, a->rowmask, g->dlogdet, R, C, ldo, c.Tp, stream));
@@ -194,19 +206,20 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
             else      { q.a = dnext; q.lda = H; q.ca1 = H; q.a2 = g->dskip; q.lda2 = H; q.ca = 2 * H; }
             q.n = H; q.epi = GLOWTTS_EPI_DGATE; q.in0 = a->gates[l]; q.ldi0 = 2 * H; q.out0 = dins; q.ld0 = ldin;
             q.drop_p = d->drop_p; q.seed = d->seed + (uint32_t)l; q.seed_ptr = d->seed_ptr;
+            q.io_flags = bf ? (GLOWTTS_IO_IN0_BF16 | GLOWTTS_IO_OUT0_BF16) : 0;
             CHECK(glowtts_conv_cl(&q, stream));
         }
         if (wg) {   // Res_Skip weight gradient: rows [0,H) <- d res, rows [H,2H) <- d skip (last layer: only H rows <- d skip)
             if (last) {
                 glowtts_wgrad_args w = wargs(g->dskip, H, H, a->gates[l], 2 * H, H, 1, g->dw_rs[l], g->db_rs[l]);
-                w.xpro = GLOWTTS_APRO_PAIRMUL;
+                w.xpro = GLOWTTS_APRO_PAIRMUL; w.io_flags = bf ? GLOWTTS_WIO_X_BF16 : 0;
                 CHECK(glowtts_wgrad_cl(&w, stream));
             } else {
                 glowtts_wgrad_args w = wargs(dnext, H, H, a->gates[l], 2 * H, H, 1, g->dw_rs[l], g->db_rs[l]);
-                w.xpro = GLOWTTS_APRO_PAIRMUL;
+                w.xpro = GLOWTTS_APRO_PAIRMUL; w.io_flags = bf ? GLOWTTS_WIO_X_BF16 : 0;
                 CHECK(glowtts_wgrad_cl(&w, stream));
                 glowtts_wgrad_args w2 = wargs(g->dskip, H, H, a->gates[l], 2 * H, H, 1, g->dw_rs[l] + (int64_t)H * H, g->db_rs[l] + H);
-                w2.xpro = GLOWTTS_APRO_PAIRMUL;
+                w2.xpro = GLOWTTS_APRO_PAIRMUL; w2.io_flags = bf ? GLOWTTS_WIO_X_BF16 : 0;
                 CHECK(glowtts_wgrad_cl(&w2, stream));
             }
         }
@@ -214,16 +227,16 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
             glowtts_conv_args q = base_args(c, p->in_t[l], d->ksize);
             q.a = dins; q.lda = ldin; q.ca = ldin; q.n = H; q.epi = GLOWTTS_EPI_LINEAR;
             q.flags = GLOWTTS_F_MASK | (last ? 0 : GLOWTTS_F_ADD_IN0);
-            q.in0 = last ? nullptr : dnext; q.ldi0 = H; q.out0 = dthis; q.ld0 = H;
+            q.in0 = last ? nullptr : dnext; q.ldi0 = H; q.out0 = dthis; q.ld0 = H; q.io_flags = bf ? GLOWTTS_IO_A_BF16 : 0;
             CHECK(glowtts_conv_cl(&q, stream));
         }
         if (wg) {   // In_l weight gradient
             glowtts_wgrad_args w = wargs(dins, ldin, ldin, a->hs[l], H, H, d->ksize, g->dw_in[l], g->db_in[l]);
-            w.perm = GLOWTTS_PERM_PAIR; w.perm_h = H;
+            w.perm = GLOWTTS_PERM_PAIR; w.perm_h = H; w.io_flags = bf ? (GLOWTTS_WIO_DY_BF16 | GLOWTTS_WIO_X_BF16) : 0;
             CHECK(glowtts_wgrad_cl(&w, stream));
         }
         if (g->dcond && p->cond)   // conditioning gradient: sum over the frames of each utterance   (autograd of Modules.py:863-866)
-            CHECK(glowtts_utt_colsum(dins, ldin, g->dcond + (int64_t)l * 2 * H, p->ldcond, d->B, c.Tp, 2 * H, GLOWTTS_PERM_PAIR, H, stream));
+            CHECK(utt_colsum(dins, ldin, g->dcond + (int64_t)l * 2 * H, p->ldcond, d->B, c.Tp, 2 * H, GLOWTTS_PERM_PAIR, H, bf, stream));
     }
     float* dh0 = g->dh[0];                    // d h0 * mask
     // 4. Start conv: data gradient accumulates into d x_a, weight gradient

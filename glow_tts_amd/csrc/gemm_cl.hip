@@ -128,7 +128,9 @@ template <> struct StaticFor<0> { template <class F> __device__ __forceinline__ 
 //   clamped addresses, kept raw) before the MFMAs of super-step ss, and is masked / converted / written to LDS after them.
 //   (History, measured on MI355X: per-tap steps with a barrier each ran ~1800 cycles per 256-cycle MFMA step; step-conditional
 //   loads additionally degrade every s_waitcnt to vmcnt(0).)
-template <typename CT, int MI, int NI, int WM, int WN, int EPI, int TAPS, int APRO>
+// ABF: the A operand (and A2) is stored as bf16 in HBM (GLOWTTS_IO_A_BF16; bf16 precision only): staging is then a raw 16-byte
+// copy per LDS slot - half the bytes, no conversion in the loop.
+template <typename CT, int MI, int NI, int WM, int WN, int EPI, int TAPS, int APRO, bool ABF>
 __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_conv_args pin)
 {
     glowtts_conv_args p = pin;
@@ -150,7 +152,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
     constexpr bool EX = sizeof(CT) == 4;
     constexpr int A_IT = (AROWS * 4 + NT - 1) / NT;
     constexpr int W_IT = (BN * 4) / NT;
-    constexpr int NLD = (APRO == GLOWTTS_APRO_PAIRMUL) ? E / 2 : E / 4;      // float4 loads per 16-B LDS slot
+    static_assert(!ABF || sizeof(CT) == 2, "bf16 activation storage needs bf16 precision");
+    constexpr int AES = ABF ? 2 : 4;                                         // bytes per stored A element
+    constexpr int AEL = (APRO == GLOWTTS_APRO_PAIRMUL) ? 2 * E : E;          // A elements loaded per 16-B LDS slot
+    constexpr int NLD = AEL * AES / 16;                                      // 16-byte loads per LDS slot
     constexpr int A_TILE = AROWS * 64, W_TILE = BN * 64;
     static_assert((BN * 4) % NT == 0, "weight tile must divide evenly");
 
@@ -190,14 +195,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    typedef float4 ARegs[A_IT][NLD];
+    typedef Chunk16 ARegs[A_IT][NLD];
     typedef Chunk16 WRegs[W_IT];
     ARegs ra[NAT];
     WRegs rw[NSUB];
 
     // ---- per-thread constants of the staging pattern ----
-    const float* arow[A_IT];        // clamped source row of each A item (first source)
-    const float* arow2[A_IT];       // second source (dual-source A), same row
+    const unsigned char* arow[A_IT];    // clamped source row of each A item (first source), as a byte pointer
+    const unsigned char* arow2[A_IT];   // second source (dual-source A), same row
     bool aok[A_IT];                 // row inside [0, rows)
     int woff[W_IT];                 // clamped byte offset inside a weight tile slab
 #pragma unroll
@@ -206,8 +211,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
         const long g = (long)m0 - pad + row;
         aok[it] = (g >= 0) && (g < p.rows) && (row < AROWS);
         const long gc = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
-        arow[it] = p.a + gc * p.lda;
-        arow2[it] = p.a2 ? p.a2 + gc * p.lda2 : arow[it];
+        arow[it] = reinterpret_cast<const unsigned char*>(p.a) + gc * p.lda * AES;
+        arow2[it] = p.a2 ? reinterpret_cast<const unsigned char*>(p.a2) + gc * p.lda2 * AES : arow[it];
     }
     {
         const int lim = (p.npad - n0) * 64 - 16;               // last valid 16-B piece of this tile's slab
@@ -221,15 +226,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int c = kc * KC + ((tid + it * NT) & 3) * E;
-            const float* src;
-            if (APRO == GLOWTTS_APRO_PAIRMUL)      src = arow[it] + min(2 * c, (int)p.lda - 2 * E);
-            else if (APRO == GLOWTTS_APRO_SQNEG)   src = arow[it] + min(c < p.ca1 ? c : c - p.ca1, (int)p.lda - E);
+            const unsigned char* src;                   // column offsets in A elements, clamped so that the AEL-element load stays inside the row
+            if (APRO == GLOWTTS_APRO_PAIRMUL)      src = arow[it] + (long)min(2 * c, (int)p.lda - AEL) * AES;
+            else if (APRO == GLOWTTS_APRO_SQNEG)   src = arow[it] + (long)min(c < p.ca1 ? c : c - p.ca1, (int)p.lda - AEL) * AES;
             else {
                 const bool second = (p.a2 != nullptr) && (c >= p.ca1);
-                src = second ? arow2[it] + min(c - p.ca1, (int)p.lda2 - E) : arow[it] + min(c, (int)p.lda - E);
+                src = second ? arow2[it] + (long)min(c - p.ca1, (int)p.lda2 - AEL) * AES : arow[it] + (long)min(c, (int)p.lda - AEL) * AES;
             }
 #pragma unroll
-            for (int j = 0; j < NLD; ++j) r[it][j] = *reinterpret_cast<const float4*>(src + 4 * j);
+            for (int j = 0; j < NLD; ++j) r[it][j] = *reinterpret_cast<const Chunk16*>(src + 16 * j);
         }
     };
     auto gload_w = [&](WRegs& r, int kc, int t) __attribute__((always_inline)) {
@@ -247,29 +252,42 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
             if (row >= AROWS) continue;
             const int c = kc * KC + q * E;
             const bool rowok = aok[it] && (kc < KCH);
-            float f[E];
-            if (APRO == GLOWTTS_APRO_PAIRMUL) {
+            Chunk16 o;
+            if constexpr (ABF && APRO == GLOWTTS_APRO_NONE) {
+                // raw copy; a slot is valid or not as a whole (ca is a multiple of 8 on this path, checked on the host)
+                const bool ok = rowok && (c < p.ca);
 #pragma unroll
-                for (int j = 0; j < NLD; ++j) { f[2 * j] = r[it][j].x * r[it][j].y; f[2 * j + 1] = r[it][j].z * r[it][j].w; }
+                for (int e = 0; e < 4; ++e) o[e] = ok ? r[it][0][e] : 0u;
             } else {
+                float f[E];
+                if constexpr (ABF) {                           // PAIRMUL on bf16 pairs: word = (tanh, sigmoid)
 #pragma unroll
-                for (int j = 0; j < NLD; ++j) { f[4 * j] = r[it][j].x; f[4 * j + 1] = r[it][j].y; f[4 * j + 2] = r[it][j].z; f[4 * j + 3] = r[it][j].w; }
-                if (APRO == GLOWTTS_APRO_SQNEG) {
-                    if (c < p.ca1) {
+                    for (int e = 0; e < E; ++e) {
+                        const uint32_t w = r[it][e / 4][e % 4];
+                        f[e] = __uint_as_float(w << 16) * __uint_as_float(w & 0xFFFF0000u);
+                    }
+                } else if (APRO == GLOWTTS_APRO_PAIRMUL) {
 #pragma unroll
-                        for (int e = 0; e < E; ++e) f[e] = -0.5f * f[e] * f[e];
+                    for (int j = 0; j < NLD; ++j) { f[2 * j] = __uint_as_float(r[it][j][0]) * __uint_as_float(r[it][j][1]); f[2 * j + 1] = __uint_as_float(r[it][j][2]) * __uint_as_float(r[it][j][3]); }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NLD; ++j) { f[4 * j] = __uint_as_float(r[it][j][0]); f[4 * j + 1] = __uint_as_float(r[it][j][1]); f[4 * j + 2] = __uint_as_float(r[it][j][2]); f[4 * j + 3] = __uint_as_float(r[it][j][3]); }
+                    if (APRO == GLOWTTS_APRO_SQNEG) {
+                        if (c < p.ca1) {
+#pragma unroll
+                            for (int e = 0; e < E; ++e) f[e] = -0.5f * f[e] * f[e];
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int e = 0; e < E; ++e) f[e] = (rowok && (c + e < p.ca)) ? f[e] : 0.f;
-            Chunk16 o;
-            if constexpr (sizeof(CT) == 2) {
+                for (int e = 0; e < E; ++e) f[e] = (rowok && (c + e < p.ca)) ? f[e] : 0.f;
+                if constexpr (sizeof(CT) == 2) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);
-            } else {
+                    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(f[e]);
+                    for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(f[e]);
+                }
             }
             *reinterpret_cast<Chunk16*>(As + tile * A_TILE + swz(row, q)) = o;
         }
@@ -350,6 +368,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
     }
 
     // ---- fused epilogue ----
+    const bool in0_bf = (p.io_flags & GLOWTTS_IO_IN0_BF16) != 0, out0_bf = (p.io_flags & GLOWTTS_IO_OUT0_BF16) != 0;
+    typedef __bf16 bfs;
     if (abl & 1) { if (acc[0][0][0] == 12345.678f) p.out0[0] = 1.f; return; }
     float pb0[(NI + 1) / 2], pb1[(NI + 1) / 2];              // PAIR epilogues: the two bias values of each pair, loaded once
     if constexpr (EPI == GLOWTTS_EPI_GATE || EPI == GLOWTTS_EPI_COUPLE) {
@@ -381,6 +401,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
                     if (fl & GLOWTTS_F_ADD_IN0) v += p.in0[(long)r * p.ldi0 + n];
                     if (fl & GLOWTTS_F_MASK) v *= mask;
                     if ((fl & GLOWTTS_F_COLMASK) && n >= p.ncols_valid[blockIdx.z]) v = 0.f;
+                    if (out0_bf) { reinterpret_cast<bfs*>(p.out0)[(long)r * p.ld0 + n] = (bfs)v; continue; }    // (no ACCUM on bf16 outputs: host-checked)
                     float* o = p.out0 + (long)r * p.ld0 + n;
                     if (fl & GLOWTTS_F_ACCUM) v += *o;
                     *o = v;
@@ -395,7 +416,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
                         float* o = p.out1 + (long)r * p.ld1 + n;
                         *o = (((fl & GLOWTTS_F_FIRST) ? 0.f : *o) + v) * mask;
                     } else if (n < p.h) {                           // Modules.py:878: x = (x + res) * mask
-                        p.out0[(long)r * p.ld0 + n] = (p.in0[(long)r * p.ldi0 + n] + v) * mask;
+                        const float xin = in0_bf ? (float)reinterpret_cast<const bfs*>(p.in0)[(long)r * p.ldi0 + n] : p.in0[(long)r * p.ldi0 + n];
+                        const float xo = (xin + v) * mask;
+                        if (out0_bf) reinterpret_cast<bfs*>(p.out0)[(long)r * p.ld0 + n] = (bfs)xo; else p.out0[(long)r * p.ld0 + n] = xo;
                     } else {                                        // Modules.py:879: output += outs
                         float* o = p.out1 + (long)r * p.ld1 + (n - p.h);
                         *o = ((fl & GLOWTTS_F_FIRST) ? 0.f : *o) + v;
@@ -425,7 +448,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
                                 v1 += cb[p.h + j];
                             }
                             float2 g = make_float2(tanh_<EX>(v0), sigmoid_<EX>(v1));  // Modules.py:885-887
-                            *reinterpret_cast<float2*>(p.out0 + (long)r * p.ld0 + 2 * j) = g;
+                            if (out0_bf) reinterpret_cast<uint32_t*>(p.out0)[((long)r * p.ld0 + 2 * j) >> 1] = pack_bf16x2(g.x, g.y);
+                            else *reinterpret_cast<float2*>(p.out0 + (long)r * p.ld0 + 2 * j) = g;
                         } else {
                             // v0 = m, v1 = logs                                     Modules.py:795-806
                             float* xb = p.out0 + (long)r * p.ld0 + j;
@@ -444,7 +468,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
                         const int j = n0 + (wn * NI + ni) * 32 + l31;             // gate channel (natural order)
                         if (j >= p.n) continue;
                         const float d = acc[mi][ni][reg];
-                        const float2 g = *reinterpret_cast<const float2*>(p.in0 + (long)r * p.ldi0 + 2 * j);   // (tanh, sigmoid)
+                        float2 g;                                                  // (tanh, sigmoid)
+                        if (in0_bf) { const uint32_t w = reinterpret_cast<const uint32_t*>(p.in0)[((long)r * p.ldi0 + 2 * j) >> 1];
+                                      g = make_float2(__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u)); }
+                        else g = *reinterpret_cast<const float2*>(p.in0 + (long)r * p.ldi0 + 2 * j);
                         float da = d * g.y * (1.f - g.x * g.x);
                         float ds = d * g.x * g.y * (1.f - g.y);
                         if (p.drop_p > 0.f) {                                      // same keep mask as the forward GATE epilogue
@@ -454,8 +481,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
                             ds *= drop_scale(p.seed, id + (uint32_t)p.n, p.drop_p, ik);
                         }
                         const int pc = (j >> 5) * 64 + (j & 31);
-                        p.out0[(long)r * p.ld0 + pc] = da;
-                        p.out0[(long)r * p.ld0 + pc + 32] = ds;
+                        if (out0_bf) { bfs* o = reinterpret_cast<bfs*>(p.out0) + (long)r * p.ld0 + pc; o[0] = (bfs)da; o[32] = (bfs)ds; }
+                        else { p.out0[(long)r * p.ld0 + pc] = da; p.out0[(long)r * p.ld0 + pc + 32] = ds; }
                     }
                 }
             }
@@ -463,16 +490,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
     }
 }
 
-template <typename CT, int MI, int NI, int WM, int WN, int EPI, int TAPS, int APRO>
+template <typename CT, int MI, int NI, int WM, int WN, int EPI, int TAPS, int APRO, bool ABF>
 int launch_k(const glowtts_conv_args& a, hipStream_t s)
 {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     dim3 grid(((a.rows + BM - 1) / BM) * ((a.npad + BN - 1) / BN), 1, a.batch > 1 ? a.batch : 1);
-    hipLaunchKernelGGL((conv_cl_kernel<CT, MI, NI, WM, WN, EPI, TAPS, APRO>), grid, dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((conv_cl_kernel<CT, MI, NI, WM, WN, EPI, TAPS, APRO, ABF>), grid, dim3(WM * WN * 64), 0, s, a);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
-template <typename CT, int EPI, int TAPS, int APRO>
+template <typename CT, int EPI, int TAPS, int APRO, bool ABF = false>
 int launch_tile(const glowtts_conv_args& a, hipStream_t s)
 {
     // Tile choice.  These GEMMs are short (K <= 1920) and their operands come from L2, so a workgroup spends most of its
@@ -484,20 +511,20 @@ int launch_tile(const glowtts_conv_args& a, hipStream_t s)
     if (cfg < 0) cfg = (TAPS == 1) ? 1 : 2;   // measured at B = 32: 128 x 64 for the k-tap convs (tools/bench_conv.py), 64 x 128 for the 1x1
                                               // convs whose wide fp32 A rows would otherwise be re-read by six N tiles (bench.py: 21.9 -> 20.3 ms)
     switch (cfg) {
-        case 0: return launch_k<CT, 2, 2, 2, 2, EPI, TAPS, APRO>(a, s);
-        case 1: return launch_k<CT, 1, 2, 2, 2, EPI, TAPS, APRO>(a, s);
-        case 2: return launch_k<CT, 1, 2, 4, 1, EPI, TAPS, APRO>(a, s);
-        default: return launch_k<CT, 1, 2, 2, 1, EPI, TAPS, APRO>(a, s);
+        case 0: return launch_k<CT, 2, 2, 2, 2, EPI, TAPS, APRO, ABF>(a, s);
+        case 1: return launch_k<CT, 1, 2, 2, 2, EPI, TAPS, APRO, ABF>(a, s);
+        case 2: return launch_k<CT, 1, 2, 4, 1, EPI, TAPS, APRO, ABF>(a, s);
+        default: return launch_k<CT, 1, 2, 2, 1, EPI, TAPS, APRO, ABF>(a, s);
     }
 }
 
-template <typename CT, int EPI, int APRO>
+template <typename CT, int EPI, int APRO, bool ABF = false>
 int launch_taps(const glowtts_conv_args& a, hipStream_t s)
 {
     switch (a.taps) {
-        case 1: return launch_tile<CT, EPI, 1, APRO>(a, s);
-        case 3: return launch_tile<CT, EPI, 3, APRO>(a, s);
-        case 5: return launch_tile<CT, EPI, 5, APRO>(a, s);
+        case 1: return launch_tile<CT, EPI, 1, APRO, ABF>(a, s);
+        case 3: return launch_tile<CT, EPI, 3, APRO, ABF>(a, s);
+        case 5: return launch_tile<CT, EPI, 5, APRO, ABF>(a, s);
         default: return GLOWTTS_E_ARG;
     }
 }
@@ -507,6 +534,14 @@ template <typename CT>
 int launch_prec(const glowtts_conv_args& a, hipStream_t s)
 {
     const int N = GLOWTTS_APRO_NONE, PM = GLOWTTS_APRO_PAIRMUL;
+    if constexpr (sizeof(CT) == 2) {
+        if (a.io_flags & GLOWTTS_IO_A_BF16) {      // bf16-stored A operand: the WaveNet state / gates / gate gradients
+            if (a.epi == GLOWTTS_EPI_GATE && a.apro == N) return launch_taps<CT, GLOWTTS_EPI_GATE, GLOWTTS_APRO_NONE, true>(a, s);
+            if (a.epi == GLOWTTS_EPI_LINEAR && a.apro == N) return launch_taps<CT, GLOWTTS_EPI_LINEAR, GLOWTTS_APRO_NONE, true>(a, s);
+            if (a.epi == GLOWTTS_EPI_RESSKIP && a.apro == PM && a.taps == 1) return launch_tile<CT, GLOWTTS_EPI_RESSKIP, 1, GLOWTTS_APRO_PAIRMUL, true>(a, s);
+            return GLOWTTS_E_ARG;
+        }
+    } else if (a.io_flags) return GLOWTTS_E_ARG;   // fp32 precision keeps every activation in fp32
     switch (a.epi) {
         case GLOWTTS_EPI_LINEAR:
             if (a.apro == N) return launch_taps<CT, GLOWTTS_EPI_LINEAR, GLOWTTS_APRO_NONE>(a, s);
@@ -560,17 +595,20 @@ extern "C" int glowtts_pack_weight(const float* w, int O, int I, int taps, int t
 extern "C" int glowtts_conv_cl(const glowtts_conv_args* args, void* stream)
 {
     if (!args || !args->a || !args->w || !args->out0 || args->rows < 1 || args->taps < 1 || args->taps > MAX_TAPS) return GLOWTTS_E_ARG;
-    if ((args->lda & 3) || (reinterpret_cast<uintptr_t>(args->a) & 15)) return GLOWTTS_E_ARG;
+    if ((args->lda & 3) || (reinterpret_cast<uintptr_t>(args->a) & 15)) return GLOWTTS_E_ARG;      // rows start 16-byte aligned (lda % 8 for bf16 A, below)
     if (args->a2 && ((args->lda2 & 3) || (reinterpret_cast<uintptr_t>(args->a2) & 15))) return GLOWTTS_E_ARG;
     glowtts_conv_args a = *args;
     if (!a.a2 && a.apro != GLOWTTS_APRO_SQNEG) a.ca1 = a.ca;
     if (a.apro == GLOWTTS_APRO_SQNEG && ((a.ca1 % (a.precision == GLOWTTS_BF16 ? 8 : 4)) || a.ca != 2 * a.ca1)) return GLOWTTS_E_ARG;
     if ((a.flags & GLOWTTS_F_COLMASK) && !a.ncols_valid) return GLOWTTS_E_ARG;
-    {   // loads are unconditional vectors of E floats (E = 8 bf16 / 4 f32 channels = one 16-byte LDS slot): every row must be
-        // wide enough to contain the last, possibly partial, slot:  lda >= round_up(channels read from it, E)
+    {   // loads are unconditional 16-byte vectors covering one LDS slot (E = 8 bf16 / 4 f32 channels): every row must be wide enough
+        // to contain the last, possibly partial, slot:  lda >= round_up(channels read from it, E)   (lda in A elements)
         const int E = a.precision == GLOWTTS_BF16 ? 8 : 4;
         auto up = [E](int v) { return (v + E - 1) / E * E; };
+        const bool abf = (a.io_flags & GLOWTTS_IO_A_BF16) != 0;
         if ((a.ca & 3) || a.kchunks * (a.precision == GLOWTTS_BF16 ? 32 : 16) < a.ca) return GLOWTTS_E_ARG;
+        if ((a.io_flags & GLOWTTS_IO_OUT0_BF16) && (a.flags & GLOWTTS_F_ACCUM)) return GLOWTTS_E_ARG;
+        if (abf && ((a.ca & 7) || (a.lda & 7) || (a.a2 && ((a.lda2 & 7) || (a.ca1 & 7))))) return GLOWTTS_E_ARG;
         if (a.apro == GLOWTTS_APRO_PAIRMUL) { if (a.lda < 2 * up(a.ca)) return GLOWTTS_E_ARG; }
         else if (a.apro == GLOWTTS_APRO_SQNEG) { if (a.lda < up(a.ca1)) return GLOWTTS_E_ARG; }
         else if (a.a2) { if ((a.ca1 % E) || a.lda < a.ca1 || a.lda2 < up(a.ca - a.ca1)) return GLOWTTS_E_ARG; }

@@ -47,8 +47,26 @@ __device__ __forceinline__ float4 ldg4(const float* p) {
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// NW 32-bit words from a global byte address (8-byte aligned for NW == 2, 16-byte otherwise)
+typedef uint32_t u32x2n __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4n __attribute__((ext_vector_type(4)));
+template <int NW>
+__device__ __forceinline__ void ldgw(uint32_t* dst, const unsigned char* src) {
+    if constexpr (NW == 2) {
+        const u32x2n v = *(const u32x2n __attribute__((address_space(1)))*)(src);
+        dst[0] = v[0]; dst[1] = v[1];
+    } else {
+#pragma unroll
+        for (int j = 0; j < NW / 4; ++j) {
+            const u32x4n v = *(const u32x4n __attribute__((address_space(1)))*)(src + 16 * j);
+            dst[4 * j] = v[0]; dst[4 * j + 1] = v[1]; dst[4 * j + 2] = v[2]; dst[4 * j + 3] = v[3];
+        }
+    }
+}
+
 // job of this workgroup: p (by value when there is a single problem, else looked up in the device table by tile index)
-template <typename CT, int TAPS, int XPRO>
+// DYBF / XBF: DY / X are stored as bf16 in HBM (bf16 precision only; glowtts_wgrad_args.io_flags) - then staging is a raw copy.
+template <typename CT, int TAPS, int XPRO, bool DYBF, bool XBF>
 __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job single, const glowtts_wgrad_job* __restrict__ table, const WCommon cm)
 {
     glowtts_wgrad_job p = single;
@@ -94,8 +112,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
     constexpr int DY_IT = (BK * BMO / 4) / 256;               // float4 per thread for the DY tile (= 4)
     constexpr int X_IT = (XROWS * BNC / 4 + 255) / 256;       // 4-channel groups per thread for the X tile
     constexpr int XL = (XPRO == GLOWTTS_APRO_PAIRMUL) ? 2 : 1;
-    typedef float4 DYRegs[DY_IT];
-    typedef float4 XRegs[X_IT][XL];
+    static_assert(!(DYBF || XBF) || ES == 2, "bf16 activation storage needs bf16 precision");
+    // raw register image of one item = 4 (x XL) stored elements: 16 B (f32) / 8 B (bf16) per 4 elements
+    constexpr int DYW = DYBF ? 2 : 4;                         // 32-bit words per DY item
+    constexpr int XW = (XBF ? 2 : 4) * XL;                    // 32-bit words per X item
+    typedef uint32_t DYRegs[DY_IT][DYW];
+    typedef uint32_t XRegs[X_IT][XW];
     DYRegs rdyA, rdyB;
     XRegs rxA, rxB;
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -109,7 +131,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
             const int idx = tid + it * 256;
             const int row = idx / (BMO / 4), c4 = idx % (BMO / 4);
             const long r = min(r0 + row, (long)cm.rows - 1);
-            rdy[it] = ldg4(p.dy + r * p.lddy + min(o0 + c4 * 4, lim_dy));
+            ldgw<DYW>(rdy[it], reinterpret_cast<const unsigned char*>(p.dy) + (r * p.lddy + min(o0 + c4 * 4, lim_dy)) * (DYBF ? 2 : 4));
         }
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
@@ -117,11 +139,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
             const int row = idx / (BNC / 4), c4 = idx % (BNC / 4);
             long r = r0 + row - cm.pad;
             r = r < 0 ? 0 : (r >= cm.rows ? cm.rows - 1 : r);
-            const float* src = p.x + r * p.ldx + min((c0 + c4 * 4) * XL, lim_x);
-#pragma unroll
-            for (int j = 0; j < XL; ++j) rx[it][j] = ldg4(src + 4 * j);
+            ldgw<XW>(rx[it], reinterpret_cast<const unsigned char*>(p.x) + (r * p.ldx + min((c0 + c4 * 4) * XL, lim_x)) * (XBF ? 2 : 4));
         }
     };
+    auto bf_lo = [](uint32_t w) { return __uint_as_float(w << 16); };
+    auto bf_hi = [](uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); };
     auto sstore = [&](const DYRegs& rdy, const XRegs& rx, int buf, long r0) __attribute__((always_inline)) {
         unsigned char* dyb = smem + buf * (DY_BYTES + X_BYTES);
         unsigned char* xb = dyb + DY_BYTES;
@@ -130,14 +152,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
             const int idx = tid + it * 256;
             const int row = idx / (BMO / 4), c4 = idx % (BMO / 4);
             const bool ok = (r0 + row < rend) && (o0 + c4 * 4 < p.m);            // m is a multiple of 4 (checked on the host)
-            float4 v = rdy[it];
-            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-            bsum[0] += v.x; bsum[1] += v.y; bsum[2] += v.z; bsum[3] += v.w;
-            if constexpr (ES == 2) {
-                uint2 w = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
-                *reinterpret_cast<uint2*>(dyb + row * LDY + c4 * 8) = w;
+            if constexpr (DYBF) {
+                const uint32_t w0 = ok ? rdy[it][0] : 0u, w1 = ok ? rdy[it][1] : 0u;
+                bsum[0] += bf_lo(w0); bsum[1] += bf_hi(w0); bsum[2] += bf_lo(w1); bsum[3] += bf_hi(w1);
+                *reinterpret_cast<uint2*>(dyb + row * LDY + c4 * 8) = make_uint2(w0, w1);
             } else {
-                *reinterpret_cast<float4*>(dyb + row * LDY + c4 * 16) = v;
+                float4 v = make_float4(__uint_as_float(rdy[it][0]), __uint_as_float(rdy[it][1]), __uint_as_float(rdy[it][2]), __uint_as_float(rdy[it][3]));
+                v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+                bsum[0] += v.x; bsum[1] += v.y; bsum[2] += v.z; bsum[3] += v.w;
+                if constexpr (ES == 2) {
+                    uint2 w = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+                    *reinterpret_cast<uint2*>(dyb + row * LDY + c4 * 8) = w;
+                } else {
+                    *reinterpret_cast<float4*>(dyb + row * LDY + c4 * 16) = v;
+                }
             }
         }
 #pragma unroll
@@ -148,15 +176,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
             const long r = r0 + row - cm.pad;
             // rows outside [0, rows) are zero; rows outside this split's range ARE used (halo of the split)
             const bool ok = (r >= 0) && (r < cm.rows) && (c0 + c4 * 4 < p.ca);  // ca is a multiple of 4 (checked on the host)
-            float4 v;
-            if (XPRO == GLOWTTS_APRO_PAIRMUL) v = make_float4(rx[it][0].x * rx[it][0].y, rx[it][0].z * rx[it][0].w, rx[it][XL - 1].x * rx[it][XL - 1].y, rx[it][XL - 1].z * rx[it][XL - 1].w);
-            else v = rx[it][0];
-            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-            if constexpr (ES == 2) {
-                uint2 w = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
-                *reinterpret_cast<uint2*>(xb + row * LDX + c4 * 8) = w;
+            if constexpr (XBF && XPRO == GLOWTTS_APRO_NONE) {
+                *reinterpret_cast<uint2*>(xb + row * LDX + c4 * 8) = make_uint2(ok ? rx[it][0] : 0u, ok ? rx[it][1] : 0u);
             } else {
-                *reinterpret_cast<float4*>(xb + row * LDX + c4 * 16) = v;
+                float4 v;
+                if constexpr (XBF) {          // PAIRMUL on bf16 (tanh, sigmoid) words
+                    v = make_float4(bf_lo(rx[it][0]) * bf_hi(rx[it][0]), bf_lo(rx[it][1]) * bf_hi(rx[it][1]), bf_lo(rx[it][2]) * bf_hi(rx[it][2]), bf_lo(rx[it][3]) * bf_hi(rx[it][3]));
+                } else if constexpr (XPRO == GLOWTTS_APRO_PAIRMUL) {
+                    v = make_float4(__uint_as_float(rx[it][0]) * __uint_as_float(rx[it][1]), __uint_as_float(rx[it][2]) * __uint_as_float(rx[it][3]),
+                                    __uint_as_float(rx[it][XW - 4]) * __uint_as_float(rx[it][XW - 3]), __uint_as_float(rx[it][XW - 2]) * __uint_as_float(rx[it][XW - 1]));
+                } else {
+                    v = make_float4(__uint_as_float(rx[it][0]), __uint_as_float(rx[it][1]), __uint_as_float(rx[it][2]), __uint_as_float(rx[it][3]));
+                }
+                v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+                if constexpr (ES == 2) {
+                    uint2 w = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+                    *reinterpret_cast<uint2*>(xb + row * LDX + c4 * 8) = w;
+                } else {
+                    *reinterpret_cast<float4*>(xb + row * LDX + c4 * 16) = v;
+                }
             }
         }
     };
@@ -278,23 +316,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
     }
 }
 
-template <typename CT, int XPRO>
+template <typename CT, int XPRO, bool DYBF, bool XBF>
 int launch_x(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const WCommon& cm, int taps, dim3 grid, hipStream_t s)
 {
     switch (taps) {
-        case 1: hipLaunchKernelGGL((wgrad_kernel<CT, 1, XPRO>), grid, dim3(256), 0, s, one, table, cm); break;
-        case 3: hipLaunchKernelGGL((wgrad_kernel<CT, 3, XPRO>), grid, dim3(256), 0, s, one, table, cm); break;
-        case 5: hipLaunchKernelGGL((wgrad_kernel<CT, 5, XPRO>), grid, dim3(256), 0, s, one, table, cm); break;
+        case 1: hipLaunchKernelGGL((wgrad_kernel<CT, 1, XPRO, DYBF, XBF>), grid, dim3(256), 0, s, one, table, cm); break;
+        case 3: hipLaunchKernelGGL((wgrad_kernel<CT, 3, XPRO, DYBF, XBF>), grid, dim3(256), 0, s, one, table, cm); break;
+        case 5: hipLaunchKernelGGL((wgrad_kernel<CT, 5, XPRO, DYBF, XBF>), grid, dim3(256), 0, s, one, table, cm); break;
         default: return GLOWTTS_E_ARG;
     }
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
-// all jobs of one launch share the X prologue (`xpro`): grouped launches are formed per (taps, xpro)
+// all jobs of one launch share the X prologue (`xpro`) and the storage types (`io`): grouped launches are formed per class.
+// bf16 storage combinations the Glow-TTS path uses: (DY, X) both bf16 with no prologue (In conv: gate gradients x WaveNet state)
+// and X alone with PAIRMUL (Res_Skip conv: fp32 gradients x gates).
 template <typename CT>
-int launch_w(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const WCommon& cm, int taps, int xpro, dim3 grid, hipStream_t s)
+int launch_w(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const WCommon& cm, int taps, int xpro, int io, dim3 grid, hipStream_t s)
 {
-    if (xpro == GLOWTTS_APRO_PAIRMUL) return launch_x<CT, GLOWTTS_APRO_PAIRMUL>(one, table, cm, taps, grid, s);
-    if (xpro == GLOWTTS_APRO_NONE) return launch_x<CT, GLOWTTS_APRO_NONE>(one, table, cm, taps, grid, s);
+    if constexpr (sizeof(CT) == 2) {
+        if (io == (GLOWTTS_WIO_DY_BF16 | GLOWTTS_WIO_X_BF16) && xpro == GLOWTTS_APRO_NONE) return launch_x<CT, GLOWTTS_APRO_NONE, true, true>(one, table, cm, taps, grid, s);
+        if (io == GLOWTTS_WIO_X_BF16 && xpro == GLOWTTS_APRO_PAIRMUL) return launch_x<CT, GLOWTTS_APRO_PAIRMUL, false, true>(one, table, cm, taps, grid, s);
+    }
+    if (io) return GLOWTTS_E_ARG;
+    if (xpro == GLOWTTS_APRO_PAIRMUL) return launch_x<CT, GLOWTTS_APRO_PAIRMUL, false, false>(one, table, cm, taps, grid, s);
+    if (xpro == GLOWTTS_APRO_NONE) return launch_x<CT, GLOWTTS_APRO_NONE, false, false>(one, table, cm, taps, grid, s);
     return GLOWTTS_E_ARG;
 }
 
@@ -322,13 +367,19 @@ extern "C" int glowtts_wgrad_cl(const glowtts_wgrad_args* args, void* stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.xmask) return GLOWTTS_E_ARG;          // reserved: X row masks must be applied by the producer
     if ((a.m & 3) || (a.ca & 3) || a.lddy < 4 || a.ldx < (a.xpro == GLOWTTS_APRO_PAIRMUL ? 8 : 4)) return GLOWTTS_E_ARG;
-    if (a.precision == GLOWTTS_BF16) return launch_w<__bf16>(j, nullptr, cm, a.taps, a.xpro, grid, s);
-    if (a.precision == GLOWTTS_F32) return launch_w<float>(j, nullptr, cm, a.taps, a.xpro, grid, s);
+    if (a.precision == GLOWTTS_BF16) return launch_w<__bf16>(j, nullptr, cm, a.taps, a.xpro, a.io_flags, grid, s);
+    if (a.precision == GLOWTTS_F32) return launch_w<float>(j, nullptr, cm, a.taps, a.xpro, a.io_flags, grid, s);
     return GLOWTTS_E_ARG;
 }
 
 extern "C" int glowtts_wgrad_grouped(const glowtts_wgrad_job* dev_jobs, int njobs, int total_tiles, int rows, int taps, int pad,
                                      int xpro, int precision, int splits, int accumulate, void* stream)
+{
+    return glowtts_wgrad_grouped_io(dev_jobs, njobs, total_tiles, rows, taps, pad, xpro, precision, splits, accumulate, 0, stream);
+}
+
+extern "C" int glowtts_wgrad_grouped_io(const glowtts_wgrad_job* dev_jobs, int njobs, int total_tiles, int rows, int taps, int pad,
+                                        int xpro, int precision, int splits, int accumulate, int io_flags, void* stream)
 {
     if (!dev_jobs || njobs < 1 || total_tiles < 1 || rows < 1) return GLOWTTS_E_ARG;
     if (splits < 1) splits = 1;
@@ -338,7 +389,7 @@ extern "C" int glowtts_wgrad_grouped(const glowtts_wgrad_job* dev_jobs, int njob
     WCommon cm{rows, pad, accumulate, njobs};
     dim3 grid(total_tiles, 1, splits);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (precision == GLOWTTS_BF16) return launch_w<__bf16>(dummy, dev_jobs, cm, taps, xpro, grid, s);
-    if (precision == GLOWTTS_F32) return launch_w<float>(dummy, dev_jobs, cm, taps, xpro, grid, s);
+    if (precision == GLOWTTS_BF16) return launch_w<__bf16>(dummy, dev_jobs, cm, taps, xpro, io_flags, grid, s);
+    if (precision == GLOWTTS_F32) return launch_w<float>(dummy, dev_jobs, cm, taps, xpro, io_flags, grid, s);
     return GLOWTTS_E_ARG;
 }

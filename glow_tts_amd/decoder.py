@@ -26,7 +26,7 @@ class Packed(ctypes.Structure):
 
 class FlowDims(ctypes.Structure):
     _fields_ = [("B", c_int), ("T", c_int), ("C", c_int), ("H", c_int), ("L", c_int), ("ksize", c_int), ("precision", c_int),
-                ("drop_p", ctypes.c_float), ("seed", ctypes.c_uint32), ("seed_ptr", c_void_p)]
+                ("drop_p", ctypes.c_float), ("seed", ctypes.c_uint32), ("seed_ptr", c_void_p), ("act_bf16", c_int)]
 
 
 class FlowParams(ctypes.Structure):
@@ -73,6 +73,7 @@ def _L():
         L.glowtts_flow_inverse.argtypes = [c_void_p] * 4
         L.glowtts_flow_backward.argtypes = [c_void_p] * 5
         L.glowtts_wgrad_grouped.argtypes = [c_void_p] + [c_int] * 9 + [c_void_p]
+        L.glowtts_wgrad_grouped_io.argtypes = [c_void_p] + [c_int] * 10 + [c_void_p]
         L.glowtts_decoder_logdet.argtypes = [c_void_p, c_i64] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]
         _declared = True
     return L
@@ -101,8 +102,8 @@ class WgradGroup:
     """Weight-gradient problems sharing (rows, taps, X prologue).  Problems are added in *segments* (one per flow); the whole
     job table is uploaded once and every segment is one glowtts_wgrad_grouped launch (tile indices restart per segment)."""
 
-    def __init__(self, rows, taps, precision, xpro=ops.APRO_NONE):
-        self.rows, self.taps, self.precision, self.xpro = rows, taps, precision, xpro
+    def __init__(self, rows, taps, precision, xpro=ops.APRO_NONE, io_flags=0):
+        self.rows, self.taps, self.precision, self.xpro, self.io_flags = rows, taps, precision, xpro, io_flags
         self.jobs, self.segments, self._tiles, self._start = [], [], 0, 0
         self.table = None
 
@@ -141,8 +142,9 @@ class WgradGroup:
         start, n, tiles = self.segments[i]
         if n == 0:
             return
-        _lib.check(_L().glowtts_wgrad_grouped(self.table.data_ptr() + start * ctypes.sizeof(WgradJob), n, tiles, self.rows, self.taps,
-                                              (self.taps - 1) // 2, self.xpro, self.precision, 1, 0, _lib.stream()), "glowtts_wgrad_grouped")
+        _lib.check(_L().glowtts_wgrad_grouped_io(self.table.data_ptr() + start * ctypes.sizeof(WgradJob), n, tiles, self.rows, self.taps,
+                                                 (self.taps - 1) // 2, self.xpro, self.precision, 1, 0, self.io_flags, _lib.stream()),
+                   "glowtts_wgrad_grouped_io")
 
 
 class PackedBatch:
@@ -173,6 +175,10 @@ class DecoderConfig:
         self.C = mel_dim * n_squeeze
         self.precision = precision
         assert n_layers <= MAXL and self.C % 4 == 0 and hidden % 4 == 0
+        # bf16 precision: the GEMM-only activations (WaveNet state, gates, gate gradients) live in HBM as bf16
+        # (glowtts_flow_dims.act_bf16); GLOWTTS_ACT_BF16=0 keeps them fp32 (same MFMA inputs, twice the traffic)
+        self.act_bf16 = precision == ops.BF16 and hidden % 8 == 0 and os.environ.get("GLOWTTS_ACT_BF16", "1") != "0"
+        self.act_dtype = torch.bfloat16 if self.act_bf16 else torch.float32
 
 
 WEIGHT_KEYS = ("an_logs", "an_bias", "inv_w", "w_start", "b_start", "w_in", "b_in", "w_rs", "b_rs",
@@ -245,7 +251,7 @@ class _Prepared:
 def _dims(cfg, B, T, drop_p=0.0, seed=None, flow=0):
     """seed: None or a device int32/uint32 tensor with one element (re-drawn on device every step, hipGraph-safe)."""
     return FlowDims(B, T, cfg.C, cfg.H, cfg.L, cfg.k, cfg.precision, float(drop_p), (1000003 * flow) & 0xFFFFFFFF,
-                    seed.data_ptr() if seed is not None else None)
+                    seed.data_ptr() if seed is not None else None, int(cfg.act_bf16))
 
 
 def squeeze_rows(cfg, mels, lengths, want_mask=True):
@@ -276,8 +282,8 @@ class _Buffers:
         F_, L, H, C = cfg.F, cfg.L, cfg.H, cfg.C
         self.x = torch.empty(F_ + 1, R, C, device=dev)
         self.xmid = torch.empty(F_, R, C, device=dev)
-        self.hs = torch.empty(F_, L, R, H, device=dev)
-        self.gates = torch.empty(F_, L, R, 2 * H, device=dev)
+        self.hs = torch.empty(F_, L, R, H, device=dev, dtype=cfg.act_dtype)
+        self.gates = torch.empty(F_, L, R, 2 * H, device=dev, dtype=cfg.act_dtype)
         self.skip = torch.empty(F_, R, H, device=dev)
         self.outs = torch.empty(F_, R, prep.ldo, device=dev)
 
@@ -322,8 +328,8 @@ def decoder_inverse(cfg, W, z, lengths, cond=None, fill=None):
     dev = z.device
     other = torch.empty_like(x)
     xmid = torch.empty_like(x)
-    hs = torch.empty(2, R, cfg.H, device=dev)
-    gates = torch.empty(R, 2 * cfg.H, device=dev)
+    hs = torch.empty(2, R, cfg.H, device=dev, dtype=cfg.act_dtype)
+    gates = torch.empty(R, 2 * cfg.H, device=dev, dtype=cfg.act_dtype)
     skip = torch.empty(R, cfg.H, device=dev)
     dims = _dims(cfg, B, T)
     cur, nxt = x, other
@@ -354,8 +360,8 @@ def actnorm_data_init(cfg, W, mels, lengths, cond=None, allreduce=None):
         scratch = torch.empty(L.glowtts_actnorm_stats_scratch_floats(R, cfg.C), device=dev)
         bufs = [x, torch.empty_like(x)]
         xmid = torch.empty_like(x)
-        hs = torch.empty(cfg.L, R, cfg.H, device=dev)
-        gates = torch.empty(cfg.L, R, 2 * cfg.H, device=dev)
+        hs = torch.empty(cfg.L, R, cfg.H, device=dev, dtype=cfg.act_dtype)
+        gates = torch.empty(cfg.L, R, 2 * cfg.H, device=dev, dtype=cfg.act_dtype)
         skip = torch.empty(R, cfg.H, device=dev)
         for f in range(cfg.F):
             _lib.check(L.glowtts_actnorm_stats(_lib.ptr(bufs[0]), _lib.ptr(rowmask), _lib.ptr(stats), _lib.ptr(scratch), R, cfg.C,
@@ -411,14 +417,15 @@ class DecoderFunction(torch.autograd.Function):
         # every flow / layer keeps its own gradient buffers: the weight gradients of ALL flows are computed afterwards by
         # two grouped launches (k-tap problems, 1x1 problems) whose tiles fill the chip without split-K or atomics
         douts = torch.zeros(F_, R, prep.ldo, device=dev)
-        dins = (torch.empty if prep.ldin == 2 * H else torch.zeros)(F_, Lw, R, prep.ldin, device=dev)    # only pad columns need zeros
+        dins = (torch.empty if prep.ldin == 2 * H else torch.zeros)(F_, Lw, R, prep.ldin, device=dev, dtype=cfg.act_dtype)    # only pad columns need zeros
         dskip = torch.empty(F_, R, H, device=dev)
         dh = torch.empty(F_, Lw, R, H, device=dev)
         scratch = torch.empty(L.glowtts_actnorm_stats_scratch_floats(R, C), device=dev)
         dcond = torch.zeros_like(prep.cond) if prep.cond is not None else None
-        gk = WgradGroup(R, cfg.k, cfg.precision)                        # In_l (k taps)
+        bf = cfg.act_bf16
+        gk = WgradGroup(R, cfg.k, cfg.precision, io_flags=(ops.WIO_DY_BF16 | ops.WIO_X_BF16) if bf else 0)     # In_l (k taps)
         g1 = WgradGroup(R, 1, cfg.precision)                            # Start / End (1x1)
-        gp = WgradGroup(R, 1, cfg.precision, ops.APRO_PAIRMUL)          # Res_Skip_l (1x1 on tanh*sigmoid)
+        gp = WgradGroup(R, 1, cfg.precision, ops.APRO_PAIRMUL, io_flags=ops.WIO_X_BF16 if bf else 0)          # Res_Skip_l (1x1 on tanh*sigmoid)
         C2 = C // 2
         order = list(range(F_ - 1, -1, -1))
         for f in order:       # weight-gradient problems of every flow (autograd of Modules.py:791,861,871,793): all pointers are known up front

@@ -11,6 +11,8 @@ F32, BF16 = 0, 1
 PERM_NONE, PERM_PAIR = 0, 1
 APRO_NONE, APRO_PAIRMUL, APRO_SQNEG = 0, 1, 2
 EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_DGATE = 0, 1, 2, 3, 4
+IO_A_BF16, IO_IN0_BF16, IO_OUT0_BF16 = 1, 2, 4      # glowtts_conv_args.io_flags
+WIO_DY_BF16, WIO_X_BF16 = 1, 2                       # glowtts_wgrad_args.io_flags
 F_BIAS, F_RELU, F_ADD_IN0, F_MASK, F_ACCUM, F_FIRST, F_LAST, F_REVERSE, F_COLMASK, F_DROPOUT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 
@@ -41,6 +43,7 @@ class ConvArgs(ctypes.Structure):
         ("ncols_valid", c_void_p),
         ("seed", ctypes.c_uint32), ("drop_p", ctypes.c_float),
         ("seed_ptr", c_void_p),
+        ("io_flags", c_int),
     ]
 
 
@@ -69,9 +72,9 @@ def pack_weight(w, transpose=False, perm=PERM_NONE, perm_h=0, precision=BF16):
 
 def conv_cl(a, pw, ca, rows, *, lda=None, a2=None, lda2=0, ca1=0, apro=APRO_NONE, pad=0, epi=EPI_LINEAR, flags=0,
             n=None, h=0, rows_per_utt=1, bias=None, rowmask=None, cond=None, ldcond=0,
-            out0=None, ld0=0, out1=None, ld1=0, in0=None, ldi0=0, out0_off=0, a_off=0, drop_p=0.0, seed=0, seed_t=None):
+            out0=None, ld0=0, out1=None, ld1=0, in0=None, ldi0=0, out0_off=0, a_off=0, drop_p=0.0, seed=0, seed_t=None, io_flags=0):
     """Launches glowtts_conv_cl.  Tensors are fp32 device tensors; *_off are element offsets into them
-    (to address a channel sub-range of a wider row)."""
+    (to address a channel sub-range of a wider row).  io_flags (IO_*): a / in0 / out0 are bf16 tensors instead."""
     args = ConvArgs()
     args.a = a.data_ptr() + 4 * a_off
     args.lda = lda if lda is not None else a.shape[-1]
@@ -94,4 +97,6 @@ def conv_cl(a, pw, ca, rows, *, lda=None, a2=None, lda2=0, ca1=0, apro=APRO_NONE
     args.ldi0 = ldi0
     args.drop_p, args.seed = float(drop_p), int(seed) & 0xFFFFFFFF
     args.seed_ptr = seed_t.data_ptr() if seed_t is not None else None
+    args.io_flags = io_flags
+    assert not (io_flags and (a_off or out0_off))
     _lib.check(_lib.lib().glowtts_conv_cl(ctypes.byref(args), _lib.stream()), "glowtts_conv_cl")

@@ -109,6 +109,9 @@ int glowtts_pack_weight_batched(const float *w, int batch, int O, int I, int tap
 #define GLOWTTS_F_FIRST   32   /* RESSKIP: skip accumulator is written, not accumulated */
 #define GLOWTTS_F_LAST    64   /* RESSKIP: last WaveNet layer (n = h outputs, all skip, *mask) */
 #define GLOWTTS_F_REVERSE 128  /* COUPLE: inverse coupling x_b = (x_b - m) * exp(-logs) * mask */
+#define GLOWTTS_IO_A_BF16    1
+#define GLOWTTS_IO_IN0_BF16  2
+#define GLOWTTS_IO_OUT0_BF16 4
 #define GLOWTTS_F_DROPOUT 512  /* LINEAR: dropout(p = drop_p, seed) after the optional ReLU, before residual / mask */
 #define GLOWTTS_F_COLMASK 256  /* LINEAR: zero columns n >= ncols_valid[batch]  (attention mask, Modules.py:102) */
 
@@ -139,6 +142,10 @@ typedef struct glowtts_conv_args {
      * The keep mask is a counter hash of (seed, row, channel): the backward regenerates it from the same seed. */
     uint32_t seed; float drop_p;
     const uint32_t *seed_ptr;          /* optional DEVICE word added to `seed` (lets a captured hipGraph draw new masks per replay) */
+    /* bf16 activation storage (GLOWTTS_BF16 precision only): which of the `const float*` tensors actually hold bf16 elements
+     * (strides then count bf16 elements).  A_BF16: a / a2 (GATE, RESSKIP+PAIRMUL, LINEAR only; ca, lda multiples of 8);
+     * IN0_BF16: in0 (RESSKIP residual, DGATE gates); OUT0_BF16: out0 (GATE gates, RESSKIP state, DGATE gate gradients). */
+    int io_flags;
 } glowtts_conv_args;
 
 int glowtts_conv_cl(const glowtts_conv_args *args /* host pointer */, void *stream);
@@ -208,7 +215,11 @@ typedef struct glowtts_wgrad_args {
     int splits, accumulate;
     float *dw;                         /* [O][ca][taps] */
     float *dbias;                      /* [O] or NULL */
+    int io_flags;                      /* GLOWTTS_WIO_*: dy / x hold bf16 elements (bf16 precision only; strides count elements).
+                                        * Supported: DY|X with no prologue, X alone with PAIRMUL. */
 } glowtts_wgrad_args;
+#define GLOWTTS_WIO_DY_BF16 1
+#define GLOWTTS_WIO_X_BF16  2
 int glowtts_wgrad_cl(const glowtts_wgrad_args *args /* host pointer */, void *stream);
 
 /* Grouped form: many weight-gradient problems that share (rows, taps, pad, precision) in ONE launch, so that the
@@ -225,6 +236,9 @@ typedef struct glowtts_wgrad_job {
 /* every job of one launch uses the same X prologue `xpro` (job.xpro is ignored); m and ca must be multiples of 4 */
 int glowtts_wgrad_grouped(const glowtts_wgrad_job *dev_jobs, int njobs, int total_tiles, int rows, int taps, int pad,
                           int xpro, int precision, int splits, int accumulate, void *stream);
+/* same, with the storage types of DY / X (GLOWTTS_WIO_*) shared by every job of the launch */
+int glowtts_wgrad_grouped_io(const glowtts_wgrad_job *dev_jobs, int njobs, int total_tiles, int rows, int taps, int pad,
+                             int xpro, int precision, int splits, int accumulate, int io_flags, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * One flow step of the decoder = Activation_Norm -> Invertible_1x1_Conv -> Affine_Coupling_Layer
@@ -247,6 +261,8 @@ typedef struct glowtts_flow_dims {
     float drop_p;      /* WaveNet.Dropout_Rate in training mode, 0 in eval mode          (Modules.py:854-862) */
     uint32_t seed;     /* dropout seed of this flow step (layer l uses seed + l); same value in forward and backward */
     const uint32_t *seed_ptr;  /* optional device word added to the seed (graph replay) */
+    int act_bf16;      /* 1 (bf16 precision only): the GEMM-only activations - WaveNet states hs[], gates[], gate gradients dins[] -
+                        * are bf16 tensors (same shapes; halves their HBM traffic).  skip, outs, dh, dskip, the flow variable stay fp32. */
 } glowtts_flow_dims;
 
 typedef struct glowtts_flow_params {

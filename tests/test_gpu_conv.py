@@ -109,3 +109,63 @@ def test_gate_epilogue_and_pairmul(prec, H, C):
     s = TOL[prec] * rs.abs().max().item()
     assert (from_rows(xo.cpu(), B, T) - want_x).abs().max() <= s
     assert (from_rows(skip.cpu(), B, T) - want_skip).abs().max() <= s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,K", [(192, 5), (64, 3), (40, 1)])
+def test_bf16_activation_storage_matches_fp32_storage(H, K):
+    """glowtts_conv_args.io_flags / glowtts_wgrad_args.io_flags: the same bf16 MFMA contraction with the activations stored
+    as bf16 tensors.  Inputs are pre-rounded to bf16, so only the stored OUTPUT may differ - by one bf16 rounding."""
+    from glow_tts_amd import ops
+    from glow_tts_amd.conv_fn import wgrad
+    g = torch.Generator().manual_seed(H * 7 + K)
+    B, T = 3, 61
+    R = B * (T + 4)
+    bf = lambda t: t.to(torch.bfloat16)
+    rowmask = torch.zeros(B, T + 4); rowmask[:, 2:T + 2] = 1; rowmask[1, T - 9:] = 0
+    rm = rowmask.reshape(-1).cuda()
+    hs = (torch.randn(R, H, generator=g).cuda() * rm[:, None]).to(torch.bfloat16)
+    w_in = (torch.randn(2 * H, H, K, generator=g) / (H * K) ** 0.5).cuda()
+    b_in = (torch.randn(2 * H, generator=g) * 0.1).cuda()
+    pw = ops.pack_weight(w_in, perm=ops.PERM_PAIR, perm_h=H, precision=ops.BF16)
+    # GATE: A bf16 -> gates bf16
+    G32 = torch.zeros(R, 2 * H, device="cuda")
+    G16 = torch.zeros(R, 2 * H, device="cuda", dtype=torch.bfloat16)
+    kw = dict(pad=(K - 1) // 2, epi=ops.EPI_GATE, h=H, n=2 * H, rows_per_utt=T + 4, bias=b_in, ld0=2 * H)
+    ops.conv_cl(hs.float(), pw, H, R, out0=G32, **kw)
+    ops.conv_cl(hs, pw, H, R, out0=G16, io_flags=ops.IO_A_BF16 | ops.IO_OUT0_BF16, **kw)
+    assert torch.equal(bf(G32), G16)
+    # RESSKIP: gates bf16 (PAIRMUL), residual in / out bf16, skip fp32
+    w_rs = (torch.randn(2 * H, H, 1, generator=g) / H ** 0.5).cuda()
+    b_rs = (torch.randn(2 * H, generator=g) * 0.1).cuda()
+    pw2 = ops.pack_weight(w_rs, precision=ops.BF16)
+    x32, s32 = torch.zeros(R, H, device="cuda"), torch.zeros(R, H, device="cuda")
+    x16, s16 = torch.zeros(R, H, device="cuda", dtype=torch.bfloat16), torch.zeros(R, H, device="cuda")
+    kw = dict(lda=2 * H, apro=ops.APRO_PAIRMUL, epi=ops.EPI_RESSKIP, flags=ops.F_FIRST, h=H, n=2 * H, bias=b_rs, rowmask=rm, ld0=H, ld1=H, ldi0=H)
+    ops.conv_cl(G16.float(), pw2, H, R, out0=x32, out1=s32, in0=hs.float(), **kw)
+    ops.conv_cl(G16, pw2, H, R, out0=x16, out1=s16, in0=hs, io_flags=ops.IO_A_BF16 | ops.IO_IN0_BF16 | ops.IO_OUT0_BF16, **kw)
+    assert torch.equal(bf(x32), x16) and torch.equal(s32, s16)
+    # DGATE: gates read as bf16, gate gradients written as bf16
+    pw3 = ops.pack_weight(w_rs, transpose=True, precision=ops.BF16)
+    dres, dskip = torch.randn(R, H, generator=g).cuda(), torch.randn(R, H, generator=g).cuda()
+    d32 = torch.zeros(R, pw.npad, device="cuda")
+    d16 = torch.zeros(R, pw.npad, device="cuda", dtype=torch.bfloat16)
+    kw = dict(a2=dskip, lda2=H, ca1=H, epi=ops.EPI_DGATE, n=H, h=H, ldi0=2 * H, ld0=pw.npad)
+    ops.conv_cl(dres, pw3, 2 * H, R, out0=d32, in0=G16.float(), **kw)
+    ops.conv_cl(dres, pw3, 2 * H, R, out0=d16, in0=G16, io_flags=ops.IO_IN0_BF16 | ops.IO_OUT0_BF16, **kw)
+    assert torch.equal(bf(d32), d16)
+    # In data gradient: A = gate gradients bf16
+    pw4 = ops.pack_weight(w_in, transpose=True, perm=ops.PERM_PAIR, perm_h=H, precision=ops.BF16)
+    o32, o16 = torch.zeros(R, H, device="cuda"), torch.zeros(R, H, device="cuda")
+    kw = dict(pad=(K - 1) // 2, epi=ops.EPI_LINEAR, flags=ops.F_MASK, n=H, rowmask=rm, ld0=H)
+    ops.conv_cl(d16.float(), pw4, pw.npad, R, out0=o32, **kw)
+    ops.conv_cl(d16, pw4, pw.npad, R, out0=o16, io_flags=ops.IO_A_BF16, **kw)
+    assert torch.equal(o32, o16)
+    # weight gradients: (DY, X) = (gate gradients, state) bf16; X = gates bf16 with PAIRMUL
+    a32 = wgrad(d16.float(), hs.float(), pw.npad, H, K, ops.BF16, splits=1)
+    a16 = wgrad(d16, hs, pw.npad, H, K, ops.BF16, splits=1, io_flags=ops.WIO_DY_BF16 | ops.WIO_X_BF16)
+    assert torch.equal(a32[0], a16[0]) and torch.allclose(a32[1], a16[1], rtol=1e-6, atol=1e-5)
+    b32 = wgrad(dskip, G16.float(), H, H, 1, ops.BF16, splits=1, xpro=ops.APRO_PAIRMUL)
+    b16 = wgrad(dskip, G16, H, H, 1, ops.BF16, splits=1, xpro=ops.APRO_PAIRMUL, io_flags=ops.WIO_X_BF16)
+    assert torch.equal(b32[0], b16[0]) and torch.equal(b32[1], b16[1])
+    torch.cuda.synchronize()
