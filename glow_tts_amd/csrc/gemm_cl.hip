@@ -25,6 +25,7 @@
 //   * epilogues are fused: bias, conditioning, tanh*sigmoid gate, residual/skip update, affine
 //     coupling, gate derivative (see GLOWTTS_EPI_*).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include <stdlib.h>
 #include "../../include/glowtts_hip.h"
@@ -57,7 +58,22 @@ template <bool EXACT> __device__ __forceinline__ float tanh_(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 
-// dropout keep decision: counter hash (murmur3 finalizer) of (seed, element id) -> 24-bit uniform
+typedef __amdgpu_buffer_rsrc_t Rsrc;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// Dropout of the WaveNet gate pre-activations (Modules.py:862).  The GATE (forward) and DGATE (backward) epilogues must draw the
+// same mask, and integer multiplies are quarter rate, so: one key per row (2 multiplies), one 32-bit draw per (row, channel
+// pair) (1 multiply) whose low / high 16 bits decide the tanh / the sigmoid channel.  keep <=> half >= thr, thr = round(p * 2^16);
+// kept values are scaled by 2^16 / (2^16 - thr), the exact inverse keep rate of that threshold.
+__device__ __forceinline__ uint32_t drop_threshold(float p) { return p > 0.f ? (uint32_t)(p * 65536.f + 0.5f) : 0u; }
+__device__ __forceinline__ float drop_inv_keep(uint32_t thr) { return 65536.f / (65536.f - (float)thr); }
+__device__ __forceinline__ uint32_t drop_rowkey(uint32_t seed, uint32_t r) { uint32_t x = r * 0x9E3779B1u + seed; x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; return x; }
+__device__ __forceinline__ uint32_t drop_colkey(uint32_t j) { return (j + 1u) * 0x27D4EB2Fu; }
+__device__ __forceinline__ uint32_t drop_draw(uint32_t rowkey, uint32_t colkey) { const uint32_t x = (rowkey ^ colkey) * 0xC2B2AE35u; return x ^ (x >> 16); }
+__device__ __forceinline__ float drop_keep_lo(uint32_t d, uint32_t thr, float ik) { return (d & 0xFFFFu) >= thr ? ik : 0.f; }
+__device__ __forceinline__ float drop_keep_hi(uint32_t d, uint32_t thr, float ik) { return (d >> 16) >= thr ? ik : 0.f; }
+
+// dropout keep decision of the LINEAR epilogue: counter hash (murmur3 finalizer) of (seed, element id) -> 24-bit uniform
 __device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t id, float p, float inv_keep) {
     uint32_t h = id * 0x9E3779B1u + seed;
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
@@ -349,9 +365,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
         if constexpr (!T1) sstore_a(ra[0], 0, ss);
     };
     const int abl = p.flags >> 16;                            // debug ablation bits (tools/bench_conv.py)
+    // tools/build_tl.sh builds with GLOWTTS_TIMELINE: thread 0 of every workgroup logs shader-clock stamps into the
+    // buffer passed through p.ncols_valid ([workgroups][32] int64) - never defined in the product build
+#ifdef GLOWTTS_TIMELINE
+    long long* tlbuf = reinterpret_cast<long long*>(const_cast<int*>(p.ncols_valid)) + (long)blockIdx.x * 32;
+#define TL(i) do { if (tid == 0) tlbuf[(i)] = (long long)__builtin_readcyclecounter(); } while (0)
+    if (tid == 0) { tlbuf[30] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); tlbuf[31] = (long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); }
+#else
+#define TL(i)
+#endif
+    TL(0);
     gload_ss(ssmap(0));
+    TL(1);
     sstore_ss(ssmap(0));
+    TL(2);
     __syncthreads();
+    TL(3);
     for (int ss = 0; ss < NSS; ++ss) {
         const int cur = ssmap(ss), nxt = ssmap(ss + 1 < NSS ? ss + 1 : ss);
         gload_ss(nxt);                                        // next super-step, in flight during the MFMAs below
@@ -362,132 +391,381 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
                 else              compute(0, j, j);
             }
         }
+        TL(4 + 3 * ss);
         __syncthreads();                                      // every wave is done reading the tiles
+        TL(5 + 3 * ss);
         sstore_ss(nxt);
         __syncthreads();
+        TL(6 + 3 * ss);
     }
 
     // ---- fused epilogue ----
+    // accumulator element: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31.
+    // Every global access goes through a buffer descriptor: rows >= p.rows (last tile) and invalid columns (voffset = OOB)
+    // are dropped / read as 0 by the hardware bounds check, so the row loops carry no branches and a row's address is one
+    // scalar offset on a per-thread voffset.  The loads of an 8-row block are issued together before its arithmetic (in / out
+    // tensors may alias for all the compiler knows, so it cannot hoist them over the stores itself).  The epilogue is VALU-issue
+    // bound (tools/conv_timeline.py): instruction count per element is what matters here.
     const bool in0_bf = (p.io_flags & GLOWTTS_IO_IN0_BF16) != 0, out0_bf = (p.io_flags & GLOWTTS_IO_OUT0_BF16) != 0;
-    typedef __bf16 bfs;
     if (abl & 1) { if (acc[0][0][0] == 12345.678f) p.out0[0] = 1.f; return; }
-    float pb0[(NI + 1) / 2], pb1[(NI + 1) / 2];              // PAIR epilogues: the two bias values of each pair, loaded once
-    if constexpr (EPI == GLOWTTS_EPI_GATE || EPI == GLOWTTS_EPI_COUPLE) {
+    const int fl = p.flags;
+    constexpr uint32_t OOB = 0x80000000u;
+    const int rb = m0 + wm * MI * 32 + 4 * lhi;               // row of (mi = 0, reg = 0)
+    auto roff = [](int mi, int reg) { return mi * 32 + (reg & 3) + 8 * (reg >> 2); };
+    auto mk = [](const void* ptr, long bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000); };
+    auto ld32 = [](Rsrc r, uint32_t vo, uint32_t so) { return __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0); };
+    auto ldf = [&](Rsrc r, uint32_t vo, uint32_t so) { return __uint_as_float(ld32(r, vo, so)); };
+    auto ldh = [](Rsrc r, uint32_t vo, uint32_t so) { return __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, vo, so, 0) << 16); };
+    auto st32 = [](uint32_t v, Rsrc r, uint32_t vo, uint32_t so) { __builtin_amdgcn_raw_buffer_store_b32(v, r, vo, so, 0); };
+    auto stf = [&](float v, Rsrc r, uint32_t vo, uint32_t so) { st32(__float_as_uint(v), r, vo, so); };
+    auto sth = [](float v, Rsrc r, uint32_t vo, uint32_t so) {
+        const __bf16 b = (__bf16)v;
+        __builtin_amdgcn_raw_buffer_store_b16(*reinterpret_cast<const unsigned short*>(&b), r, vo, so, 0);
+    };
+    const Rsrc rmk = mk(p.rowmask, (long)p.rows * 4);
+    TL(22);
+
+    if constexpr (EPI == GLOWTTS_EPI_LINEAR) {
+        const uint32_t esz = out0_bf ? 2 : 4;
+        const Rsrc ro = mk(p.out0, (long)p.rows * p.ld0 * esz), ri = mk(p.in0, (long)p.rows * p.ldi0 * 4);
+        const int ncv = (fl & GLOWTTS_F_COLMASK) ? p.ncols_valid[blockIdx.z] : 0x7FFFFFFF;
+        uint32_t vo[NI], vi[NI], idn[NI]; float bs[NI]; bool cz[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + (wn * NI + ni) * 32 + l31;
+            const bool ok = n < p.n;
+            vo[ni] = ok ? (uint32_t)(rb * (int)p.ld0 + n) * esz : OOB;
+            vi[ni] = ok ? (uint32_t)(rb * (int)p.ldi0 + n) * 4u : OOB;
+            bs[ni] = ((fl & GLOWTTS_F_BIAS) && ok) ? p.bias[n] : 0.f;
+            cz[ni] = n >= ncv;
+            idn[ni] = (uint32_t)rb * (uint32_t)p.n + (uint32_t)n;
+        }
+        const float ikl = 1.f / (1.f - p.drop_p);
+        const float floor_ = (fl & GLOWTTS_F_RELU) ? 0.f : -__builtin_inff();
+        const bool want_mask = (fl & GLOWTTS_F_MASK) && p.rowmask;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                // flag tests are hoisted out of the element loops: neutral elements make the arithmetic unconditional
+                float xin[8][NI], xold[8][NI], mk8[8], v[8][NI];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    mk8[q] = 1.f;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) { xin[q][ni] = 0.f; xold[q][ni] = 0.f; }
+                }
+                if (want_mask) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) mk8[q] = ldf(rmk, (uint32_t)rb * 4u, roff(mi, hb * 8 + q) * 4);
+                }
+                if (fl & GLOWTTS_F_ADD_IN0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) xin[q][ni] = ldf(ri, vi[ni], roff(mi, hb * 8 + q) * (int)p.ldi0 * 4);
+                }
+                if (fl & GLOWTTS_F_ACCUM) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) xold[q][ni] = ldf(ro, vo[ni], roff(mi, hb * 8 + q) * (int)p.ld0 * 4);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) v[q][ni] = fmaxf(acc[mi][ni][hb * 8 + q] + bs[ni], floor_);
+                if (fl & GLOWTTS_F_DROPOUT) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            v[q][ni] *= drop_scale(p.seed, idn[ni] + (uint32_t)roff(mi, hb * 8 + q) * (uint32_t)p.n, p.drop_p, ikl);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const float t = (v[q][ni] + xin[q][ni]) * mk8[q];
+                        v[q][ni] = (cz[ni] ? 0.f : t) + xold[q][ni];
+                    }
+                if (out0_bf) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) sth(v[q][ni], ro, vo[ni], roff(mi, hb * 8 + q) * (int)p.ld0 * 2);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) stf(v[q][ni], ro, vo[ni], roff(mi, hb * 8 + q) * (int)p.ld0 * 4);
+                }
+            }
+        }
+    } else if constexpr (EPI == GLOWTTS_EPI_RESSKIP) {
+        // Modules.py:871-883.  Columns [0, h): x = (x + res) * mask -> out0; columns [h, 2h): output += skip -> out1;
+        // last layer (n = h): output = (output + res_skip) * mask -> out1.
+        const bool last = (fl & GLOWTTS_F_LAST) != 0, first = (fl & GLOWTTS_F_FIRST) != 0;
+        const uint32_t e0 = out0_bf ? 2 : 4, ei = in0_bf ? 2 : 4;
+        const Rsrc ro0 = mk(p.out0, (long)p.rows * p.ld0 * e0), rin = mk(p.in0, (long)p.rows * p.ldi0 * ei), ro1 = mk(p.out1, (long)p.rows * p.ld1 * 4);
+        uint32_t v0[NI], vin[NI], v1[NI]; float bs[NI]; bool anyres[NI], anyskip[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int nb = n0 + (wn * NI + ni) * 32, n = nb + l31;
+            const bool ok = n < p.n, res = !last && n < p.h;
+            bs[ni] = ok ? p.bias[n] : 0.f;
+            v0[ni] = (ok && res) ? (uint32_t)(rb * (int)p.ld0 + n) * e0 : OOB;
+            vin[ni] = (ok && res) ? (uint32_t)(rb * (int)p.ldi0 + n) * ei : OOB;
+            v1[ni] = (ok && !res) ? (uint32_t)(rb * (int)p.ld1 + (last ? n : n - p.h)) * 4u : OOB;
+            anyres[ni] = !last && nb < p.h;                   // wave-uniform: does this fragment hold residual / skip columns at all
+            anyskip[ni] = last || nb + 31 >= p.h;
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                float mk8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) mk8[q] = 1.f;
+                if (p.rowmask) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) mk8[q] = ldf(rmk, (uint32_t)rb * 4u, roff(mi, hb * 8 + q) * 4);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    // wave-uniform tests per fragment; the loads of the 8 rows are in flight together
+                    float xin[8], xold[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { xin[q] = 0.f; xold[q] = 0.f; }
+                    if (anyres[ni]) {
+                        if (in0_bf) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) xin[q] = ldh(rin, vin[ni], roff(mi, hb * 8 + q) * (int)p.ldi0 * 2);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) xin[q] = ldf(rin, vin[ni], roff(mi, hb * 8 + q) * (int)p.ldi0 * 4);
+                        }
+                    }
+                    if (anyskip[ni] && !first) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) xold[q] = ldf(ro1, v1[ni], roff(mi, hb * 8 + q) * (int)p.ld1 * 4);
+                    }
+                    if (anyres[ni]) {
+                        if (out0_bf) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                sth((xin[q] + acc[mi][ni][hb * 8 + q] + bs[ni]) * mk8[q], ro0, v0[ni], roff(mi, hb * 8 + q) * (int)p.ld0 * 2);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                stf((xin[q] + acc[mi][ni][hb * 8 + q] + bs[ni]) * mk8[q], ro0, v0[ni], roff(mi, hb * 8 + q) * (int)p.ld0 * 4);
+                        }
+                    }
+                    if (anyskip[ni]) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const float so = xold[q] + acc[mi][ni][hb * 8 + q] + bs[ni];
+                            stf(last ? so * mk8[q] : so, ro1, v1[ni], roff(mi, hb * 8 + q) * (int)p.ld1 * 4);
+                        }
+                    }
+                }
+            }
+        }
+    } else if constexpr (EPI == GLOWTTS_EPI_GATE) {
+        // In_l + dropout + conditioning + tanh / sigmoid (Modules.py:861-870, 885-887); PAIR-packed columns: fragment 2*pi holds
+        // the tanh half, 2*pi+1 the sigmoid half of 32 channels.  Output: interleaved (tanh, sigmoid) pairs.
+        static_assert(NI % 2 == 0, "pair epilogues need NI even");
+        const uint32_t esz = out0_bf ? 2 : 4;
+        const Rsrc ro = mk(p.out0, (long)p.rows * p.ld0 * esz);
+        const int Tp = p.rows_per_utt > 0 ? p.rows_per_utt : 1;
+        const int nutt = p.rows / Tp;
+        const Rsrc rc = mk(p.cond, (long)nutt * p.ldcond * 4);
+        const bool drop = p.drop_p > 0.f, cnd = p.cond != nullptr;
+        const uint32_t thr = drop_threshold(p.drop_p);
+        const float ik = drop_inv_keep(thr);
+        const int u0 = m0 / Tp, rnext = (u0 + 1) * Tp;
+        const bool two = m0 + BM <= rnext + Tp;               // the tile touches at most two utterances: their cond rows are kept in registers
+        uint32_t vo[NI / 2], jkey[NI / 2], vc[NI / 2];
+        float b0[NI / 2], b1[NI / 2];                                   // bias of the (tanh, sigmoid) channel
+        float ca0[NI / 2], ca1[NI / 2], cb0[NI / 2], cb1[NI / 2];       // conditioning of utterance u0 / u0 + 1
+        float sa0[NI / 2], sa1[NI / 2], sb0[NI / 2], sb1[NI / 2];       // bias + conditioning
 #pragma unroll
         for (int pi = 0; pi < NI / 2; ++pi) {
             const int j = ((n0 + (wn * NI + 2 * pi) * 32) >> 6) * 32 + l31;
-            pb0[pi] = (j < p.h) ? p.bias[j] : 0.f;
-            pb1[pi] = (j < p.h) ? p.bias[p.h + j] : 0.f;
+            const bool ok = j < p.h;
+            vo[pi] = ok ? (uint32_t)(rb * (int)p.ld0 + 2 * j) * esz : OOB;
+            vc[pi] = ok ? (uint32_t)j * 4u : OOB;
+            jkey[pi] = drop_colkey((uint32_t)j);
+            b0[pi] = ok ? p.bias[j] : 0.f;
+            b1[pi] = ok ? p.bias[p.h + j] : 0.f;
+            ca0[pi] = ca1[pi] = cb0[pi] = cb1[pi] = 0.f;
+            if (cnd && two) {
+                ca0[pi] = ldf(rc, vc[pi], u0 * (int)p.ldcond * 4);       ca1[pi] = ldf(rc, vc[pi] + (uint32_t)p.h * 4u, u0 * (int)p.ldcond * 4);
+                cb0[pi] = ldf(rc, vc[pi], (u0 + 1) * (int)p.ldcond * 4); cb1[pi] = ldf(rc, vc[pi] + (uint32_t)p.h * 4u, (u0 + 1) * (int)p.ldcond * 4);
+            }
+            sa0[pi] = ca0[pi] + b0[pi]; sa1[pi] = ca1[pi] + b1[pi]; sb0[pi] = cb0[pi] + b0[pi]; sb1[pi] = cb1[pi] + b1[pi];
         }
-    }
-    // accumulator element: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31
-    const int fl = p.flags;
+        // three straight-line variants, chosen once: MODE 0 = no dropout, 1 = dropout (both with the <= 2-utterance conditioning
+        // registers), 2 = general (conditioning row looked up per row; short utterances)
+        auto rows_loop = [&](auto MODE_, auto OBF_) __attribute__((always_inline)) {
+            constexpr int MODE = decltype(MODE_)::value;
+            constexpr bool OBF = decltype(OBF_)::value != 0;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+            for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int r = m0 + (wm * MI + mi) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
-            if (r >= p.rows) continue;
-            const float mask = p.rowmask ? p.rowmask[r] : 1.f;
-            if constexpr (EPI == GLOWTTS_EPI_LINEAR) {
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int n = n0 + (wn * NI + ni) * 32 + l31;
-                    if (n >= p.n) continue;
-                    float v = acc[mi][ni][reg];
-                    if (fl & GLOWTTS_F_BIAS) v += p.bias[n];
-                    if (fl & GLOWTTS_F_RELU) v = fmaxf(v, 0.f);
-                    if (fl & GLOWTTS_F_DROPOUT) v *= drop_scale(p.seed, (uint32_t)r * (uint32_t)p.n + (uint32_t)n, p.drop_p, 1.f / (1.f - p.drop_p));
-                    if (fl & GLOWTTS_F_ADD_IN0) v += p.in0[(long)r * p.ldi0 + n];
-                    if (fl & GLOWTTS_F_MASK) v *= mask;
-                    if ((fl & GLOWTTS_F_COLMASK) && n >= p.ncols_valid[blockIdx.z]) v = 0.f;
-                    if (out0_bf) { reinterpret_cast<bfs*>(p.out0)[(long)r * p.ld0 + n] = (bfs)v; continue; }    // (no ACCUM on bf16 outputs: host-checked)
-                    float* o = p.out0 + (long)r * p.ld0 + n;
-                    if (fl & GLOWTTS_F_ACCUM) v += *o;
-                    *o = v;
-                }
-            } else if constexpr (EPI == GLOWTTS_EPI_RESSKIP) {
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int n = n0 + (wn * NI + ni) * 32 + l31;
-                    if (n >= p.n) continue;
-                    const float v = acc[mi][ni][reg] + p.bias[n];
-                    if (fl & GLOWTTS_F_LAST) {                      // Modules.py:880-883: output += res_skips; return output * mask
-                        float* o = p.out1 + (long)r * p.ld1 + n;
-                        *o = (((fl & GLOWTTS_F_FIRST) ? 0.f : *o) + v) * mask;
-                    } else if (n < p.h) {                           // Modules.py:878: x = (x + res) * mask
-                        const float xin = in0_bf ? (float)reinterpret_cast<const bfs*>(p.in0)[(long)r * p.ldi0 + n] : p.in0[(long)r * p.ldi0 + n];
-                        const float xo = (xin + v) * mask;
-                        if (out0_bf) reinterpret_cast<bfs*>(p.out0)[(long)r * p.ld0 + n] = (bfs)xo; else p.out0[(long)r * p.ld0 + n] = xo;
-                    } else {                                        // Modules.py:879: output += outs
-                        float* o = p.out1 + (long)r * p.ld1 + (n - p.h);
-                        *o = ((fl & GLOWTTS_F_FIRST) ? 0.f : *o) + v;
-                    }
-                }
-            } else {
-                // PAIR-packed columns: fragment 2*pi holds the first half, 2*pi+1 the second half of 32 channels
-                static_assert(EPI == GLOWTTS_EPI_LINEAR || EPI == GLOWTTS_EPI_RESSKIP || NI % 2 == 0 || EPI == GLOWTTS_EPI_DGATE, "pair epilogues need NI even");
-                if constexpr (EPI == GLOWTTS_EPI_GATE || EPI == GLOWTTS_EPI_COUPLE) {
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int ro_ = roff(mi, reg), r = rb + ro_;
+                    if (mi == 0 && reg == 4) TL(23);
+                    if (mi == 0 && reg == 8) TL(24);
+                    const uint32_t rk = (MODE == 1 || (MODE == 2 && drop)) ? drop_rowkey(p.seed, (uint32_t)r) : 0u;
+                    const bool sel = r >= rnext;
 #pragma unroll
                     for (int pi = 0; pi < NI / 2; ++pi) {
-                        const int pcol = n0 + (wn * NI + 2 * pi) * 32;           // packed column of the first half
-                        const int j = (pcol >> 6) * 32 + l31;                     // channel inside a half
-                        if (j >= p.h) continue;
-                        float v0 = acc[mi][2 * pi][reg] + pb0[pi];
-                        float v1 = acc[mi][2 * pi + 1][reg] + pb1[pi];
-                        if constexpr (EPI == GLOWTTS_EPI_GATE) {
-                            if (p.drop_p > 0.f) {                                  // Modules.py:862 Dropout on the conv output
-                                const float ik = 1.f / (1.f - p.drop_p);
-                                const uint32_t id = (uint32_t)r * (uint32_t)(2 * p.h) + (uint32_t)j;
-                                v0 *= drop_scale(p.seed, id, p.drop_p, ik);
-                                v1 *= drop_scale(p.seed, id + (uint32_t)p.h, p.drop_p, ik);
+                        float x0 = acc[mi][2 * pi][reg], x1 = acc[mi][2 * pi + 1][reg];
+                        if constexpr (MODE == 2) {
+                            x0 += b0[pi]; x1 += b1[pi];
+                            if (drop) { const uint32_t d = drop_draw(rk, jkey[pi]); x0 *= drop_keep_lo(d, thr, ik); x1 *= drop_keep_hi(d, thr, ik); }
+                            if (cnd) {
+                                const uint32_t uo = (uint32_t)((r / Tp) * (int)p.ldcond) * 4u;     // per-lane row: goes into the voffset
+                                x0 += ldf(rc, vc[pi] + uo, 0);
+                                x1 += ldf(rc, vc[pi] + uo + (uint32_t)p.h * 4u, 0);
                             }
-                            if (p.cond) {                                          // Modules.py:863-866 (added after the conv)
-                                const float* cb = p.cond + (long)(r / p.rows_per_utt) * p.ldcond;
-                                v0 += cb[j];
-                                v1 += cb[p.h + j];
-                            }
-                            float2 g = make_float2(tanh_<EX>(v0), sigmoid_<EX>(v1));  // Modules.py:885-887
-                            if (out0_bf) reinterpret_cast<uint32_t*>(p.out0)[((long)r * p.ld0 + 2 * j) >> 1] = pack_bf16x2(g.x, g.y);
-                            else *reinterpret_cast<float2*>(p.out0 + (long)r * p.ld0 + 2 * j) = g;
+                        } else if constexpr (MODE == 1) {                          // dropout acts on conv + bias, the conditioning is added after it
+                            const uint32_t d = drop_draw(rk, jkey[pi]);
+                            x0 = (x0 + b0[pi]) * drop_keep_lo(d, thr, ik) + (sel ? cb0[pi] : ca0[pi]);
+                            x1 = (x1 + b1[pi]) * drop_keep_hi(d, thr, ik) + (sel ? cb1[pi] : ca1[pi]);
                         } else {
-                            // v0 = m, v1 = logs                                     Modules.py:795-806
-                            float* xb = p.out0 + (long)r * p.ld0 + j;
-                            const float x = p.in0 ? p.in0[(long)r * p.ldi0 + j] : *xb;     // x_b read from the kept coupling input when given
-                            if (fl & GLOWTTS_F_REVERSE) *xb = (x - v0) * exp_<EX>(-v1) * mask;
-                            else                        *xb = (v0 + exp_<EX>(v1) * x) * mask;
-                            if (p.out1) {
-                                p.out1[(long)r * p.ld1 + pcol + l31] = v0;
-                                p.out1[(long)r * p.ld1 + pcol + 32 + l31] = v1;
-                            }
+                            x0 += sel ? sb0[pi] : sa0[pi];
+                            x1 += sel ? sb1[pi] : sa1[pi];
+                        }
+                        float2 g = make_float2(tanh_<EX>(x0), sigmoid_<EX>(x1));
+#ifdef GLOWTTS_TIMELINE
+                        if (abl & 8) g = make_float2(x0, x1);
+                        if (abl & 4) { if (g.x == 12345.678f) p.out0[0] = 1.f; continue; }
+#endif
+                        if constexpr (OBF) st32(pack_bf16x2(g.x, g.y), ro, vo[pi], ro_ * (int)p.ld0 * 2);
+                        else {
+                            u32x2 w; w[0] = __float_as_uint(g.x); w[1] = __float_as_uint(g.y);
+                            __builtin_amdgcn_raw_buffer_store_b64(w, ro, vo[pi], ro_ * (int)p.ld0 * 4, 0);
                         }
                     }
-                } else if constexpr (EPI == GLOWTTS_EPI_DGATE) {
+                }
+            }
+        };
+        auto run_mode = [&](auto OBF_) __attribute__((always_inline)) {
+            if (cnd && !two) rows_loop(IC<2>{}, OBF_);
+            else if (drop)   rows_loop(IC<1>{}, OBF_);
+            else             rows_loop(IC<0>{}, OBF_);
+        };
+        if constexpr (sizeof(CT) == 2) { if (out0_bf) run_mode(IC<1>{}); else run_mode(IC<0>{}); }      // (io_flags are bf16-precision only)
+        else run_mode(IC<0>{});
+    } else if constexpr (EPI == GLOWTTS_EPI_DGATE) {
+        // d gate pre-activations from d acts and the kept gates (autograd of Modules.py:885-887 and of the Dropout at :862)
+        const uint32_t esz = out0_bf ? 2 : 4, ei = in0_bf ? 2 : 4;
+        const Rsrc ro = mk(p.out0, (long)p.rows * p.ld0 * esz), rg = mk(p.in0, (long)p.rows * p.ldi0 * ei);
+        const bool drop = p.drop_p > 0.f;
+        const uint32_t thr = drop_threshold(p.drop_p);
+        const float ik = drop_inv_keep(thr);
+        uint32_t vo[NI], vg[NI], jkey[NI];
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        const int j = n0 + (wn * NI + ni) * 32 + l31;             // gate channel (natural order)
-                        if (j >= p.n) continue;
-                        const float d = acc[mi][ni][reg];
-                        float2 g;                                                  // (tanh, sigmoid)
-                        if (in0_bf) { const uint32_t w = reinterpret_cast<const uint32_t*>(p.in0)[((long)r * p.ldi0 + 2 * j) >> 1];
-                                      g = make_float2(__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u)); }
-                        else g = *reinterpret_cast<const float2*>(p.in0 + (long)r * p.ldi0 + 2 * j);
-                        float da = d * g.y * (1.f - g.x * g.x);
-                        float ds = d * g.x * g.y * (1.f - g.y);
-                        if (p.drop_p > 0.f) {                                      // same keep mask as the forward GATE epilogue
-                            const float ik = 1.f / (1.f - p.drop_p);
-                            const uint32_t id = (uint32_t)r * (uint32_t)(2 * p.n) + (uint32_t)j;
-                            da *= drop_scale(p.seed, id, p.drop_p, ik);
-                            ds *= drop_scale(p.seed, id + (uint32_t)p.n, p.drop_p, ik);
+        for (int ni = 0; ni < NI; ++ni) {
+            const int j = n0 + (wn * NI + ni) * 32 + l31;                          // gate channel (natural order)
+            const bool ok = j < p.n;
+            const int pc = (j >> 5) * 64 + (j & 31);
+            vo[ni] = ok ? (uint32_t)(rb * (int)p.ld0 + pc) * esz : OOB;
+            vg[ni] = ok ? (uint32_t)(rb * (int)p.ldi0 + 2 * j) * ei : OOB;
+            jkey[ni] = drop_colkey((uint32_t)j);
+        }
+        auto rows_loop = [&](auto DROP_) __attribute__((always_inline)) {
+            constexpr bool DROP = decltype(DROP_)::value != 0;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    float gt[8][NI], gs[8][NI];
+                    if (in0_bf) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni) {
+                                const uint32_t w = ld32(rg, vg[ni], roff(mi, hb * 8 + q) * (int)p.ldi0 * 2);
+                                gt[q][ni] = __uint_as_float(w << 16); gs[q][ni] = __uint_as_float(w & 0xFFFF0000u);
+                            }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni) {
+                                const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rg, vg[ni], roff(mi, hb * 8 + q) * (int)p.ldi0 * 4, 0);
+                                gt[q][ni] = __uint_as_float(w[0]); gs[q][ni] = __uint_as_float(w[1]);
+                            }
+                    }
+                    float da[8][NI], ds[8][NI];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int reg = hb * 8 + q;
+                        const uint32_t rk = DROP ? drop_rowkey(p.seed, (uint32_t)(rb + roff(mi, reg))) : 0u;
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            const float d = acc[mi][ni][reg], t = gt[q][ni], sg = gs[q][ni];
+                            const float dsg = d * sg;
+                            da[q][ni] = dsg * (1.f - t * t);
+                            ds[q][ni] = dsg * t * (1.f - sg);
+                            if constexpr (DROP) { const uint32_t w = drop_draw(rk, jkey[ni]); da[q][ni] *= drop_keep_lo(w, thr, ik); ds[q][ni] *= drop_keep_hi(w, thr, ik); }
                         }
-                        const int pc = (j >> 5) * 64 + (j & 31);
-                        if (out0_bf) { bfs* o = reinterpret_cast<bfs*>(p.out0) + (long)r * p.ld0 + pc; o[0] = (bfs)da; o[32] = (bfs)ds; }
-                        else { p.out0[(long)r * p.ld0 + pc] = da; p.out0[(long)r * p.ld0 + pc + 32] = ds; }
+                    }
+                    if (out0_bf) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni) {
+                                const int so = roff(mi, hb * 8 + q) * (int)p.ld0 * 2;
+                                sth(da[q][ni], ro, vo[ni], so); sth(ds[q][ni], ro, vo[ni] + 64u, so);
+                            }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni) {
+                                const int so = roff(mi, hb * 8 + q) * (int)p.ld0 * 4;
+                                stf(da[q][ni], ro, vo[ni], so); stf(ds[q][ni], ro, vo[ni] + 128u, so);
+                            }
+                    }
+                }
+            }
+        };
+        if (drop) rows_loop(IC<1>{}); else rows_loop(IC<0>{});
+    } else {
+        // affine coupling on (m, logs) = End conv output (Modules.py:795-806); PAIR-packed like GATE
+        static_assert(EPI == GLOWTTS_EPI_COUPLE && NI % 2 == 0, "pair epilogues need NI even");
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = rb + roff(mi, reg);
+                if (r >= p.rows) continue;
+                const float mask = p.rowmask ? p.rowmask[r] : 1.f;
+#pragma unroll
+                for (int pi = 0; pi < NI / 2; ++pi) {
+                    const int pcol = n0 + (wn * NI + 2 * pi) * 32;               // packed column of the first half
+                    const int j = (pcol >> 6) * 32 + l31;                         // channel inside a half
+                    if (j >= p.h) continue;
+                    const float v0 = acc[mi][2 * pi][reg] + p.bias[j];            // m
+                    const float v1 = acc[mi][2 * pi + 1][reg] + p.bias[p.h + j];  // logs
+                    float* xb = p.out0 + (long)r * p.ld0 + j;
+                    const float x = p.in0 ? p.in0[(long)r * p.ldi0 + j] : *xb;     // x_b read from the kept coupling input when given
+                    if (fl & GLOWTTS_F_REVERSE) *xb = (x - v0) * exp_<EX>(-v1) * mask;
+                    else                        *xb = (v0 + exp_<EX>(v1) * x) * mask;
+                    if (p.out1) {
+                        p.out1[(long)r * p.ld1 + pcol + l31] = v0;
+                        p.out1[(long)r * p.ld1 + pcol + 32 + l31] = v1;
                     }
                 }
             }
         }
     }
+    TL(29);
+#undef TL
 }
 
 template <typename CT, int MI, int NI, int WM, int WN, int EPI, int TAPS, int APRO, bool ABF>
@@ -533,6 +811,14 @@ int launch_taps(const glowtts_conv_args& a, hipStream_t s)
 template <typename CT>
 int launch_prec(const glowtts_conv_args& a, hipStream_t s)
 {
+#ifdef GLOWTTS_TOOLS_MIN     // tools/build_tl.sh: only the dominant kernel, for fast experiment builds
+    if constexpr (sizeof(CT) == 2) {
+        if (a.epi == GLOWTTS_EPI_GATE && a.taps == 5)
+            return (a.io_flags & GLOWTTS_IO_A_BF16) ? launch_tile<CT, GLOWTTS_EPI_GATE, 5, GLOWTTS_APRO_NONE, true>(a, s)
+                                                    : launch_tile<CT, GLOWTTS_EPI_GATE, 5, GLOWTTS_APRO_NONE, false>(a, s);
+    }
+    return GLOWTTS_E_ARG;
+#else
     const int N = GLOWTTS_APRO_NONE, PM = GLOWTTS_APRO_PAIRMUL;
     if constexpr (sizeof(CT) == 2) {
         if (a.io_flags & GLOWTTS_IO_A_BF16) {      // bf16-stored A operand: the WaveNet state / gates / gate gradients
@@ -556,6 +842,7 @@ int launch_prec(const glowtts_conv_args& a, hipStream_t s)
         case GLOWTTS_EPI_DGATE:   return (a.apro == N && a.taps == 1) ? launch_tile<CT, GLOWTTS_EPI_DGATE, 1, GLOWTTS_APRO_NONE>(a, s) : GLOWTTS_E_ARG;
         default: return GLOWTTS_E_ARG;
     }
+#endif
 }
 
 }  // namespace
@@ -608,6 +895,9 @@ extern "C" int glowtts_conv_cl(const glowtts_conv_args* args, void* stream)
         const bool abf = (a.io_flags & GLOWTTS_IO_A_BF16) != 0;
         if ((a.ca & 3) || a.kchunks * (a.precision == GLOWTTS_BF16 ? 32 : 16) < a.ca) return GLOWTTS_E_ARG;
         if ((a.io_flags & GLOWTTS_IO_OUT0_BF16) && (a.flags & GLOWTTS_F_ACCUM)) return GLOWTTS_E_ARG;
+        // the epilogue addresses out0 / out1 / in0 / cond with 32-bit byte offsets (buffer descriptors)
+        const int64_t ldmax = std::max(std::max(a.ld0, a.ld1), std::max(a.ldi0, a.ldcond));
+        if ((int64_t)a.rows * ldmax * 4 >= (int64_t)1 << 31) return GLOWTTS_E_ARG;
         if (abf && ((a.ca & 7) || (a.lda & 7) || (a.a2 && ((a.lda2 & 7) || (a.ca1 & 7))))) return GLOWTTS_E_ARG;
         if (a.apro == GLOWTTS_APRO_PAIRMUL) { if (a.lda < 2 * up(a.ca)) return GLOWTTS_E_ARG; }
         else if (a.apro == GLOWTTS_APRO_SQNEG) { if (a.lda < up(a.ca1)) return GLOWTTS_E_ARG; }

@@ -169,3 +169,37 @@ def test_bf16_activation_storage_matches_fp32_storage(H, K):
     b16 = wgrad(dskip, G16, H, H, 1, ops.BF16, splits=1, xpro=ops.APRO_PAIRMUL, io_flags=ops.WIO_X_BF16)
     assert torch.equal(b32[0], b16[0]) and torch.equal(b32[1], b16[1])
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [0, 1])
+def test_epilogue_stores_stay_inside_rows(prec):
+    """The epilogues rely on the buffer-descriptor bounds check for the rows of the last tile that lie past `rows`:
+    nothing beyond rows * ld may be written (LINEAR, GATE, RESSKIP, DGATE)."""
+    from glow_tts_amd import ops
+    g = torch.Generator().manual_seed(5)
+    H, K, Rbuf, R = 64, 3, 400, 301                      # 301 rows: the last 128-row tile is partial
+    S = 7.0
+    a = torch.randn(Rbuf, H, generator=g).cuda()
+    w = (torch.randn(2 * H, H, K, generator=g) / (H * K) ** 0.5).cuda()
+    b = torch.randn(2 * H, generator=g).cuda()
+    rm = torch.ones(Rbuf, device="cuda")
+    pw = ops.pack_weight(w, perm=ops.PERM_PAIR, perm_h=H, precision=prec)
+    G = torch.full((Rbuf, 2 * H), S, device="cuda")
+    ops.conv_cl(a, pw, H, R, pad=1, epi=ops.EPI_GATE, h=H, n=2 * H, rows_per_utt=R, bias=b, out0=G, ld0=2 * H)
+    assert torch.all(G[R:] == S) and not torch.any(G[:R] == S)
+    pwl = ops.pack_weight(w, precision=prec)
+    Y = torch.full((Rbuf, 2 * H), S, device="cuda")
+    ops.conv_cl(a, pwl, H, R, pad=1, flags=ops.F_BIAS | ops.F_MASK, bias=b, rowmask=rm, out0=Y, ld0=2 * H)
+    assert torch.all(Y[R:] == S) and not torch.any(Y[:R] == S)
+    w2 = (torch.randn(2 * H, H, 1, generator=g) / H ** 0.5).cuda()
+    pw2 = ops.pack_weight(w2, precision=prec)
+    xo, sk = torch.full((Rbuf, H), S, device="cuda"), torch.full((Rbuf, H), S, device="cuda")
+    ops.conv_cl(G, pw2, H, R, lda=2 * H, apro=ops.APRO_PAIRMUL, epi=ops.EPI_RESSKIP, flags=ops.F_FIRST, h=H, n=2 * H, bias=b, rowmask=rm,
+                out0=xo, ld0=H, out1=sk, ld1=H, in0=a, ldi0=H)
+    assert torch.all(xo[R:] == S) and torch.all(sk[R:] == S) and not torch.any(xo[:R] == S) and not torch.any(sk[:R] == S)
+    pw3 = ops.pack_weight(w2, transpose=True, precision=prec)
+    d = torch.full((Rbuf, pw.npad), S, device="cuda")
+    ops.conv_cl(a, pw3, 2 * H, R, a2=a, lda2=H, ca1=H, epi=ops.EPI_DGATE, n=H, h=H, in0=G, ldi0=2 * H, out0=d, ld0=pw.npad)
+    assert torch.all(d[R:] == S) and not torch.any(d[:R, :2 * H] == S)
+    torch.cuda.synchronize()

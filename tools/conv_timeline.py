@@ -1,0 +1,64 @@
+"""In-kernel timeline of the dominant conv kernel (WaveNet In_i k=5, gate epilogue), built by tools/build_tl.sh.
+Prints the kernel time and, per stamp, the median shader-clock offset from the workgroup's own start."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from glow_tts_amd import ops, _lib
+B, T, H, k = 32, 400, 192, 5
+R = B * (T + 4)
+tl_lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libconv_tl.so"))
+tl_lib.glowtts_conv_cl.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+bf = "f32a" not in sys.argv
+a = torch.randn(R, H, device="cuda")
+if bf:
+    a = a.to(torch.bfloat16)
+w = torch.randn(2 * H, H, k, device="cuda") / (H * k) ** 0.5
+pw = ops.pack_weight(w, perm=ops.PERM_PAIR, perm_h=H, precision=ops.BF16)
+bias = torch.zeros(2 * H, device="cuda")
+G = torch.empty(R, 2 * H, device="cuda", dtype=torch.bfloat16 if bf else torch.float32)
+NWG = 4096
+tl = torch.zeros(NWG, 32, dtype=torch.int64, device="cuda")
+args = ops.ConvArgs()
+args.a, args.lda, args.ca, args.rows = a.data_ptr(), H, H, R
+args.w, args.n, args.npad, args.kchunks, args.taps, args.pad, args.precision = pw.data.data_ptr(), 2 * H, pw.npad, pw.kchunks, 5, 2, ops.BF16
+args.epi, args.flags, args.h, args.rows_per_utt = ops.EPI_GATE, int(os.environ.get("ABL", "0")) << 16, H, T + 4
+args.bias, args.out0, args.ld0 = bias.data_ptr(), G.data_ptr(), 2 * H
+args.ncols_valid = tl.data_ptr()
+args.io_flags = (ops.IO_A_BF16 | ops.IO_OUT0_BF16) if bf else 0
+run = lambda: _lib.check(tl_lib.glowtts_conv_cl(ctypes.byref(args), _lib.stream()), "conv")
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+n = 20
+e0.record()
+for _ in range(n):
+    run()
+e1.record(); torch.cuda.synchronize()
+print(f"tile={os.environ.get('GLOWTTS_TILE', 'default')} {e0.elapsed_time(e1) * 1e3 / n:.1f} us/launch")
+t = tl.cpu().numpy()
+used = t[:, 0] != 0
+t = t[used]
+print("workgroups:", len(t))
+t0 = t[:, 0].min()
+rel = t[:, :30] - t[:, :1]
+names = {0: "start", 1: "first loads issued", 2: "first tiles stored", 3: "sync"}
+for ss in range(8):
+    names[4 + 3 * ss] = f"ss{ss} compute done"; names[5 + 3 * ss] = f"ss{ss} sync"; names[6 + 3 * ss] = f"ss{ss} next tiles stored+sync"
+names[22] = "epilogue: biases loaded"; names[23] = "epilogue: 4 rows done"; names[24] = "epilogue: 8 rows done"; names[29] = "epilogue done"
+prev = 0
+for i in range(30):
+    if t[0, i] == 0:
+        continue
+    med = np.median(rel[:, i])
+    print(f"  [{i:2d}] {names.get(i, ''):32s} median +{med:8.0f} clk  (step {med - prev:7.0f})   p10 {np.percentile(rel[:, i], 10):7.0f}  p90 {np.percentile(rel[:, i], 90):7.0f}")
+    prev = med
+start = t[:, 0] - t0
+end = t[:, 29] - t0
+print(f"start offsets: median {np.median(start):.0f}  p90 {np.percentile(start, 90):.0f}  max {start.max():.0f};  end: median {np.median(end):.0f}  max {end.max():.0f} clk")
+hw, xcc = t[:, 30], t[:, 31] & 0xF
+cu = (hw >> 8) & 0xF; se = (hw >> 13) & 0x7
+key = xcc * 1000 + se * 16 + cu
+u, c = np.unique(key, return_counts=True)
+print(f"distinct (xcc,se,cu): {len(u)}; workgroups per CU: " + ", ".join(f"{v}x{(c == v).sum()}" for v in sorted(set(c))))
