@@ -135,271 +135,24 @@ template <int N> struct StaticFor {
 };
 template <> struct StaticFor<0> { template <class F> __device__ __forceinline__ static void run(F&&) {} };
 
-// Pipeline ("super-steps").  TAPS and APRO are compile-time, so one super-step is straight-line code:
-//   * multi-tap conv (TAPS > 1): super-step = one 64-byte K chunk; the A tile [BM + TAPS - 1 rows] is staged once and shared
-//     by the TAPS sub-steps (a tap is a row offset), the TAPS weight tiles of the chunk are staged together.
-//   * 1x1 conv (TAPS == 1): super-step = NSUB consecutive K chunks, each with its own A and weight tile.
-//   Per super-step and wave: NSUB * 2 * MI * NI MFMAs (40 for the k=5 WaveNet conv) between ONE pair of barriers; LDS is
-//   single-buffered, the look-ahead lives in registers: every global load of super-step ss+1 is issued (unconditionally, with
-//   clamped addresses, kept raw) before the MFMAs of super-step ss, and is masked / converted / written to LDS after them.
-//   (History, measured on MI355X: per-tap steps with a barrier each ran ~1800 cycles per 256-cycle MFMA step; step-conditional
-//   loads additionally degrade every s_waitcnt to vmcnt(0).)
-// ABF: the A operand (and A2) is stored as bf16 in HBM (GLOWTTS_IO_A_BF16; bf16 precision only): staging is then a raw 16-byte
-// copy per LDS slot - half the bytes, no conversion in the loop.
-template <typename CT, int MI, int NI, int WM, int WN, int EPI, int TAPS, int APRO, bool ABF>
-__global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_conv_args pin)
-{
-    glowtts_conv_args p = pin;
-    if (p.batch > 1) {                      // batched problems: shift every base pointer
-        const long bz = blockIdx.z;
-        p.a += bz * p.a_bstride;
-        p.w = reinterpret_cast<const unsigned char*>(p.w) + bz * p.w_bstride;
-        if (p.bias) p.bias += bz * p.bias_bstride;
-        if (p.rowmask) p.rowmask += bz * p.mask_bstride;
-        p.out0 += bz * p.out_bstride;
-    }
-    if (p.seed_ptr) p.seed += *p.seed_ptr;
-    constexpr int BM = WM * MI * 32, BN = WN * NI * 32, NT = WM * WN * 64;
-    constexpr bool T1 = (TAPS == 1);
-    constexpr int NSUB = T1 ? ((APRO == GLOWTTS_APRO_NONE) ? 3 : 2) : TAPS;   // sub-steps per super-step
-    constexpr int NAT = T1 ? NSUB : 1;                                        // A tiles per super-step
-    constexpr int AROWS = BM + TAPS - 1;
-    constexpr int KC = Prec<CT>::KC, E = Prec<CT>::E;          // channels per 64-B chunk / per 16-B slot
-    constexpr bool EX = sizeof(CT) == 4;
-    constexpr int A_IT = (AROWS * 4 + NT - 1) / NT;
-    constexpr int W_IT = (BN * 4) / NT;
-    static_assert(!ABF || sizeof(CT) == 2, "bf16 activation storage needs bf16 precision");
-    constexpr int AES = ABF ? 2 : 4;                                         // bytes per stored A element
-    constexpr int AEL = (APRO == GLOWTTS_APRO_PAIRMUL) ? 2 * E : E;          // A elements loaded per 16-B LDS slot
-    constexpr int NLD = AEL * AES / 16;                                      // 16-byte loads per LDS slot
-    constexpr int A_TILE = AROWS * 64, W_TILE = BN * 64;
-    static_assert((BN * 4) % NT == 0, "weight tile must divide evenly");
-
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NAT * A_TILE + NSUB * W_TILE];
-    unsigned char* As = smem;                         // [NAT][AROWS][64]
-    unsigned char* Ws = smem + NAT * A_TILE;          // [NSUB][BN][64]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    // 1-D grid.  Workgroup b runs on XCD b % 8 (observed dispatch order): give every XCD a contiguous range of tiles with the
-    // N tile fastest, so the workgroups that share an A row block (and its halo) hit the same L2.  Speed only, never correctness.
-    int m_tile, n_tile;
-    {
-        const int gy = (p.npad + BN - 1) / BN;
-        const int total = gridDim.x, lin = blockIdx.x;
-        const int q = total >> 3, r = total & 7, xcd = lin & 7, j = lin >> 3;
-        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-        n_tile = t % gy; m_tile = t / gy;
-    }
-    const int m0 = m_tile * BM;
-    const int n0 = n_tile * BN;
-    const int KCH = p.kchunks;
-    const int NSS = T1 ? (KCH + NSUB - 1) / NSUB : KCH;        // super-steps
-    // All workgroups of a launch read the SAME weight tiles; started in lock-step they would all hit the same L2 channel at
-    // the same moment (measured: ~2 us per super-step).  Each workgroup therefore walks the K chunks in a rotated order.
-    const int rot = (int)((m_tile * 5 + n_tile * 3) % NSS);
-    auto ssmap = [&](int ss) __attribute__((always_inline)) { int v = ss + rot; return v >= NSS ? v - NSS : v; };
-    const int pad = (TAPS - 1) / 2;
-    const int l31 = lane & 31, lhi = lane >> 5;
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    typedef Chunk16 ARegs[A_IT][NLD];
-    typedef Chunk16 WRegs[W_IT];
-    ARegs ra[NAT];
-    WRegs rw[NSUB];
-
-    // ---- per-thread constants of the staging pattern ----
-    const unsigned char* arow[A_IT];    // clamped source row of each A item (first source), as a byte pointer
-    const unsigned char* arow2[A_IT];   // second source (dual-source A), same row
-    bool aok[A_IT];                 // row inside [0, rows)
-    int woff[W_IT];                 // clamped byte offset inside a weight tile slab
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-        const int row = (tid + it * NT) >> 2;
-        const long g = (long)m0 - pad + row;
-        aok[it] = (g >= 0) && (g < p.rows) && (row < AROWS);
-        const long gc = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
-        arow[it] = reinterpret_cast<const unsigned char*>(p.a) + gc * p.lda * AES;
-        arow2[it] = p.a2 ? reinterpret_cast<const unsigned char*>(p.a2) + gc * p.lda2 * AES : arow[it];
-    }
-    {
-        const int lim = (p.npad - n0) * 64 - 16;               // last valid 16-B piece of this tile's slab
-#pragma unroll
-        for (int it = 0; it < W_IT; ++it) woff[it] = min((tid + it * NT) * 16, lim);
-    }
-
-    // ---- global -> registers (raw, unconditional, clamped) ----
-    auto gload_a = [&](ARegs& r, int kc) __attribute__((always_inline)) {
-        kc = min(kc, KCH - 1);
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int c = kc * KC + ((tid + it * NT) & 3) * E;
-            const unsigned char* src;                   // column offsets in A elements, clamped so that the AEL-element load stays inside the row
-            if (APRO == GLOWTTS_APRO_PAIRMUL)      src = arow[it] + (long)min(2 * c, (int)p.lda - AEL) * AES;
-            else if (APRO == GLOWTTS_APRO_SQNEG)   src = arow[it] + (long)min(c < p.ca1 ? c : c - p.ca1, (int)p.lda - AEL) * AES;
-            else {
-                const bool second = (p.a2 != nullptr) && (c >= p.ca1);
-                src = second ? arow2[it] + (long)min(c - p.ca1, (int)p.lda2 - AEL) * AES : arow[it] + (long)min(c, (int)p.lda - AEL) * AES;
-            }
-#pragma unroll
-            for (int j = 0; j < NLD; ++j) r[it][j] = *reinterpret_cast<const Chunk16*>(src + 16 * j);
-        }
-    };
-    auto gload_w = [&](WRegs& r, int kc, int t) __attribute__((always_inline)) {
-        kc = min(kc, KCH - 1);
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(p.w) + ((long)(t * KCH + kc) * p.npad + n0) * 64;
-#pragma unroll
-        for (int it = 0; it < W_IT; ++it) r[it] = *reinterpret_cast<const Chunk16*>(base + woff[it]);
-    };
-    // ---- registers -> LDS (mask, prologue, convert) ----
-    auto sstore_a = [&](const ARegs& r, int tile, int kc) __attribute__((always_inline)) {
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int idx = tid + it * NT;
-            const int row = idx >> 2, q = idx & 3;
-            if (row >= AROWS) continue;
-            const int c = kc * KC + q * E;
-            const bool rowok = aok[it] && (kc < KCH);
-            Chunk16 o;
-            if constexpr (ABF && APRO == GLOWTTS_APRO_NONE) {
-                // raw copy; a slot is valid or not as a whole (ca is a multiple of 8 on this path, checked on the host)
-                const bool ok = rowok && (c < p.ca);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = ok ? r[it][0][e] : 0u;
-            } else {
-                float f[E];
-                if constexpr (ABF) {                           // PAIRMUL on bf16 pairs: word = (tanh, sigmoid)
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const uint32_t w = r[it][e / 4][e % 4];
-                        f[e] = __uint_as_float(w << 16) * __uint_as_float(w & 0xFFFF0000u);
-                    }
-                } else if (APRO == GLOWTTS_APRO_PAIRMUL) {
-#pragma unroll
-                    for (int j = 0; j < NLD; ++j) { f[2 * j] = __uint_as_float(r[it][j][0]) * __uint_as_float(r[it][j][1]); f[2 * j + 1] = __uint_as_float(r[it][j][2]) * __uint_as_float(r[it][j][3]); }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NLD; ++j) { f[4 * j] = __uint_as_float(r[it][j][0]); f[4 * j + 1] = __uint_as_float(r[it][j][1]); f[4 * j + 2] = __uint_as_float(r[it][j][2]); f[4 * j + 3] = __uint_as_float(r[it][j][3]); }
-                    if (APRO == GLOWTTS_APRO_SQNEG) {
-                        if (c < p.ca1) {
-#pragma unroll
-                            for (int e = 0; e < E; ++e) f[e] = -0.5f * f[e] * f[e];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < E; ++e) f[e] = (rowok && (c + e < p.ca)) ? f[e] : 0.f;
-                if constexpr (sizeof(CT) == 2) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(f[e]);
-                }
-            }
-            *reinterpret_cast<Chunk16*>(As + tile * A_TILE + swz(row, q)) = o;
-        }
-    };
-    auto sstore_w = [&](const WRegs& r, int tile) __attribute__((always_inline)) {
-#pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
-            const int idx = tid + it * NT;
-            *reinterpret_cast<Chunk16*>(Ws + tile * W_TILE + swz(idx >> 2, idx & 3)) = r[it];
-        }
-    };
-
-    // ---- MFMA over one sub-step: A tile `at` with row offset `roff`, weight tile `wt` ----
-    auto compute = [&](int at, int roff, int wt) __attribute__((always_inline)) {
-        const unsigned char* Ab = As + at * A_TILE;
-        const unsigned char* Wb = Ws + wt * W_TILE;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int q = 2 * s2 + lhi;
-            Chunk16 af[MI], bfr[NI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                af[mi] = *reinterpret_cast<const Chunk16*>(Ab + swz((wm * MI + mi) * 32 + l31 + roff, q));
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                bfr[ni] = *reinterpret_cast<const Chunk16*>(Wb + swz((wn * NI + ni) * 32 + l31, q));
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    if constexpr (sizeof(CT) == 2) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            *reinterpret_cast<const bf16x8*>(&af[mi]), *reinterpret_cast<const bf16x8*>(&bfr[ni]), acc[mi][ni], 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                __uint_as_float(af[mi][e]), __uint_as_float(bfr[ni][e]), acc[mi][ni], 0, 0, 0);
-                    }
-                }
-        }
-    };
-
-    // loads / stores / MFMAs of one super-step (all static after unrolling)
-    auto gload_ss = [&](int ss) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < NSUB; ++j) {
-            if constexpr (T1) { gload_w(rw[j], ss * NSUB + j, 0); gload_a(ra[j], ss * NSUB + j); }
-            else              { gload_w(rw[j], ss, j); }
-        }
-        if constexpr (!T1) gload_a(ra[0], ss);
-    };
-    auto sstore_ss = [&](int ss) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < NSUB; ++j) {
-            sstore_w(rw[j], j);
-            if constexpr (T1) sstore_a(ra[j], j, ss * NSUB + j);
-        }
-        if constexpr (!T1) sstore_a(ra[0], 0, ss);
-    };
-    const int abl = p.flags >> 16;                            // debug ablation bits (tools/bench_conv.py)
-    // tools/build_tl.sh builds with GLOWTTS_TIMELINE: thread 0 of every workgroup logs shader-clock stamps into the
-    // buffer passed through p.ncols_valid ([workgroups][32] int64) - never defined in the product build
+// tools/build_tl.sh builds with GLOWTTS_TIMELINE: thread 0 of every workgroup logs shader-clock stamps into `tlbuf`
 #ifdef GLOWTTS_TIMELINE
-    long long* tlbuf = reinterpret_cast<long long*>(const_cast<int*>(p.ncols_valid)) + (long)blockIdx.x * 32;
 #define TL(i) do { if (tid == 0) tlbuf[(i)] = (long long)__builtin_readcyclecounter(); } while (0)
-    if (tid == 0) { tlbuf[30] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); tlbuf[31] = (long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); }
 #else
 #define TL(i)
 #endif
-    TL(0);
-    gload_ss(ssmap(0));
-    TL(1);
-    sstore_ss(ssmap(0));
-    TL(2);
-    __syncthreads();
-    TL(3);
-    for (int ss = 0; ss < NSS; ++ss) {
-        const int cur = ssmap(ss), nxt = ssmap(ss + 1 < NSS ? ss + 1 : ss);
-        gload_ss(nxt);                                        // next super-step, in flight during the MFMAs below
-        if (!(abl & 2)) {
-#pragma unroll
-            for (int j = 0; j < NSUB; ++j) {
-                if constexpr (T1) { if (cur * NSUB + j < KCH) compute(j, 0, j); }
-                else              compute(0, j, j);
-            }
-        }
-        TL(4 + 3 * ss);
-        __syncthreads();                                      // every wave is done reading the tiles
-        TL(5 + 3 * ss);
-        sstore_ss(nxt);
-        __syncthreads();
-        TL(6 + 3 * ss);
-    }
 
-    // ---- fused epilogue ----
+// ------------------------------------------------------------------------------------------------
+// the fused epilogues (shared by conv_cl_kernel and conv_dma_kernel).  acc[mi][ni] = 32x32 fragments of the wave's
+// (MI*32) x (NI*32) tile whose first row / column is (m0 + wm*MI*32, n0 + wn*NI*32); BM = rows of the workgroup tile.
+// ------------------------------------------------------------------------------------------------
+template <typename CT, int MI, int NI, int EPI>
+__device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16 (&acc)[MI][NI], const int m0, const int n0, const int BM,
+                                              const int wm, const int wn, const int lane, const int tid, long long* tlbuf)
+{
+    constexpr bool EX = sizeof(CT) == 4;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int abl = p.flags >> 16;                            // debug ablation bits (tools/bench_conv.py)
     // accumulator element: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31.
     // Every global access goes through a buffer descriptor: rows >= p.rows (last tile) and invalid columns (voffset = OOB)
     // are dropped / read as 0 by the hardware bounds check, so the row loops carry no branches and a row's address is one
@@ -764,8 +517,449 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
             }
         }
     }
+}
+
+// Pipeline ("super-steps").  TAPS and APRO are compile-time, so one super-step is straight-line code:
+//   * multi-tap conv (TAPS > 1): super-step = one 64-byte K chunk; the A tile [BM + TAPS - 1 rows] is staged once and shared
+//     by the TAPS sub-steps (a tap is a row offset), the TAPS weight tiles of the chunk are staged together.
+//   * 1x1 conv (TAPS == 1): super-step = NSUB consecutive K chunks, each with its own A and weight tile.
+//   Per super-step and wave: NSUB * 2 * MI * NI MFMAs (40 for the k=5 WaveNet conv) between ONE pair of barriers; LDS is
+//   single-buffered, the look-ahead lives in registers: every global load of super-step ss+1 is issued (unconditionally, with
+//   clamped addresses, kept raw) before the MFMAs of super-step ss, and is masked / converted / written to LDS after them.
+//   (History, measured on MI355X: per-tap steps with a barrier each ran ~1800 cycles per 256-cycle MFMA step; step-conditional
+//   loads additionally degrade every s_waitcnt to vmcnt(0).)
+// ABF: the A operand (and A2) is stored as bf16 in HBM (GLOWTTS_IO_A_BF16; bf16 precision only): staging is then a raw 16-byte
+// copy per LDS slot - half the bytes, no conversion in the loop.
+template <typename CT, int MI, int NI, int WM, int WN, int EPI, int TAPS, int APRO, bool ABF>
+__global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_conv_args pin)
+{
+    glowtts_conv_args p = pin;
+    if (p.batch > 1) {                      // batched problems: shift every base pointer
+        const long bz = blockIdx.z;
+        p.a += bz * p.a_bstride;
+        p.w = reinterpret_cast<const unsigned char*>(p.w) + bz * p.w_bstride;
+        if (p.bias) p.bias += bz * p.bias_bstride;
+        if (p.rowmask) p.rowmask += bz * p.mask_bstride;
+        p.out0 += bz * p.out_bstride;
+    }
+    if (p.seed_ptr) p.seed += *p.seed_ptr;
+    constexpr int BM = WM * MI * 32, BN = WN * NI * 32, NT = WM * WN * 64;
+    constexpr bool T1 = (TAPS == 1);
+    constexpr int NSUB = T1 ? ((APRO == GLOWTTS_APRO_NONE) ? 3 : 2) : TAPS;   // sub-steps per super-step
+    constexpr int NAT = T1 ? NSUB : 1;                                        // A tiles per super-step
+    constexpr int AROWS = BM + TAPS - 1;
+    constexpr int KC = Prec<CT>::KC, E = Prec<CT>::E;          // channels per 64-B chunk / per 16-B slot
+    constexpr int A_IT = (AROWS * 4 + NT - 1) / NT;
+    constexpr int W_IT = (BN * 4) / NT;
+    static_assert(!ABF || sizeof(CT) == 2, "bf16 activation storage needs bf16 precision");
+    constexpr int AES = ABF ? 2 : 4;                                         // bytes per stored A element
+    constexpr int AEL = (APRO == GLOWTTS_APRO_PAIRMUL) ? 2 * E : E;          // A elements loaded per 16-B LDS slot
+    constexpr int NLD = AEL * AES / 16;                                      // 16-byte loads per LDS slot
+    constexpr int A_TILE = AROWS * 64, W_TILE = BN * 64;
+    static_assert((BN * 4) % NT == 0, "weight tile must divide evenly");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NAT * A_TILE + NSUB * W_TILE];
+    unsigned char* As = smem;                         // [NAT][AROWS][64]
+    unsigned char* Ws = smem + NAT * A_TILE;          // [NSUB][BN][64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    // 1-D grid.  Workgroup b runs on XCD b % 8 (observed dispatch order): give every XCD a contiguous range of tiles with the
+    // N tile fastest, so the workgroups that share an A row block (and its halo) hit the same L2.  Speed only, never correctness.
+    int m_tile, n_tile;
+    {
+        const int gy = (p.npad + BN - 1) / BN;
+        const int total = gridDim.x, lin = blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = lin & 7, j = lin >> 3;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        n_tile = t % gy; m_tile = t / gy;
+    }
+    const int m0 = m_tile * BM;
+    const int n0 = n_tile * BN;
+    const int KCH = p.kchunks;
+    const int NSS = T1 ? (KCH + NSUB - 1) / NSUB : KCH;        // super-steps
+    // All workgroups of a launch read the SAME weight tiles; started in lock-step they would all hit the same L2 channel at
+    // the same moment (measured: ~2 us per super-step).  Each workgroup therefore walks the K chunks in a rotated order.
+    const int rot = (int)((m_tile * 5 + n_tile * 3) % NSS);
+    auto ssmap = [&](int ss) __attribute__((always_inline)) { int v = ss + rot; return v >= NSS ? v - NSS : v; };
+    const int pad = (TAPS - 1) / 2;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    typedef Chunk16 ARegs[A_IT][NLD];
+    typedef Chunk16 WRegs[W_IT];
+    ARegs ra[NAT];
+    WRegs rw[NSUB];
+
+    // ---- per-thread constants of the staging pattern ----
+    const unsigned char* arow[A_IT];    // clamped source row of each A item (first source), as a byte pointer
+    const unsigned char* arow2[A_IT];   // second source (dual-source A), same row
+    bool aok[A_IT];                 // row inside [0, rows)
+    int woff[W_IT];                 // clamped byte offset inside a weight tile slab
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int row = (tid + it * NT) >> 2;
+        const long g = (long)m0 - pad + row;
+        aok[it] = (g >= 0) && (g < p.rows) && (row < AROWS);
+        const long gc = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
+        arow[it] = reinterpret_cast<const unsigned char*>(p.a) + gc * p.lda * AES;
+        arow2[it] = p.a2 ? reinterpret_cast<const unsigned char*>(p.a2) + gc * p.lda2 * AES : arow[it];
+    }
+    {
+        const int lim = (p.npad - n0) * 64 - 16;               // last valid 16-B piece of this tile's slab
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) woff[it] = min((tid + it * NT) * 16, lim);
+    }
+
+    // ---- global -> registers (raw, unconditional, clamped) ----
+    auto gload_a = [&](ARegs& r, int kc) __attribute__((always_inline)) {
+        kc = min(kc, KCH - 1);
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int c = kc * KC + ((tid + it * NT) & 3) * E;
+            const unsigned char* src;                   // column offsets in A elements, clamped so that the AEL-element load stays inside the row
+            if (APRO == GLOWTTS_APRO_PAIRMUL)      src = arow[it] + (long)min(2 * c, (int)p.lda - AEL) * AES;
+            else if (APRO == GLOWTTS_APRO_SQNEG)   src = arow[it] + (long)min(c < p.ca1 ? c : c - p.ca1, (int)p.lda - AEL) * AES;
+            else {
+                const bool second = (p.a2 != nullptr) && (c >= p.ca1);
+                src = second ? arow2[it] + (long)min(c - p.ca1, (int)p.lda2 - AEL) * AES : arow[it] + (long)min(c, (int)p.lda - AEL) * AES;
+            }
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) r[it][j] = *reinterpret_cast<const Chunk16*>(src + 16 * j);
+        }
+    };
+    auto gload_w = [&](WRegs& r, int kc, int t) __attribute__((always_inline)) {
+        kc = min(kc, KCH - 1);
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(p.w) + ((long)(t * KCH + kc) * p.npad + n0) * 64;
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) r[it] = *reinterpret_cast<const Chunk16*>(base + woff[it]);
+    };
+    // ---- registers -> LDS (mask, prologue, convert) ----
+    auto sstore_a = [&](const ARegs& r, int tile, int kc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int idx = tid + it * NT;
+            const int row = idx >> 2, q = idx & 3;
+            if (row >= AROWS) continue;
+            const int c = kc * KC + q * E;
+            const bool rowok = aok[it] && (kc < KCH);
+            Chunk16 o;
+            if constexpr (ABF && APRO == GLOWTTS_APRO_NONE) {
+                // raw copy; a slot is valid or not as a whole (ca is a multiple of 8 on this path, checked on the host)
+                const bool ok = rowok && (c < p.ca);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = ok ? r[it][0][e] : 0u;
+            } else {
+                float f[E];
+                if constexpr (ABF) {                           // PAIRMUL on bf16 pairs: word = (tanh, sigmoid)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const uint32_t w = r[it][e / 4][e % 4];
+                        f[e] = __uint_as_float(w << 16) * __uint_as_float(w & 0xFFFF0000u);
+                    }
+                } else if (APRO == GLOWTTS_APRO_PAIRMUL) {
+#pragma unroll
+                    for (int j = 0; j < NLD; ++j) { f[2 * j] = __uint_as_float(r[it][j][0]) * __uint_as_float(r[it][j][1]); f[2 * j + 1] = __uint_as_float(r[it][j][2]) * __uint_as_float(r[it][j][3]); }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NLD; ++j) { f[4 * j] = __uint_as_float(r[it][j][0]); f[4 * j + 1] = __uint_as_float(r[it][j][1]); f[4 * j + 2] = __uint_as_float(r[it][j][2]); f[4 * j + 3] = __uint_as_float(r[it][j][3]); }
+                    if (APRO == GLOWTTS_APRO_SQNEG) {
+                        if (c < p.ca1) {
+#pragma unroll
+                            for (int e = 0; e < E; ++e) f[e] = -0.5f * f[e] * f[e];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) f[e] = (rowok && (c + e < p.ca)) ? f[e] : 0.f;
+                if constexpr (sizeof(CT) == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(f[e]);
+                }
+            }
+            *reinterpret_cast<Chunk16*>(As + tile * A_TILE + swz(row, q)) = o;
+        }
+    };
+    auto sstore_w = [&](const WRegs& r, int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int idx = tid + it * NT;
+            *reinterpret_cast<Chunk16*>(Ws + tile * W_TILE + swz(idx >> 2, idx & 3)) = r[it];
+        }
+    };
+
+    // ---- MFMA over one sub-step: A tile `at` with row offset `roff`, weight tile `wt` ----
+    auto compute = [&](int at, int roff, int wt) __attribute__((always_inline)) {
+        const unsigned char* Ab = As + at * A_TILE;
+        const unsigned char* Wb = Ws + wt * W_TILE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int q = 2 * s2 + lhi;
+            Chunk16 af[MI], bfr[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                af[mi] = *reinterpret_cast<const Chunk16*>(Ab + swz((wm * MI + mi) * 32 + l31 + roff, q));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                bfr[ni] = *reinterpret_cast<const Chunk16*>(Wb + swz((wn * NI + ni) * 32 + l31, q));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    if constexpr (sizeof(CT) == 2) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            *reinterpret_cast<const bf16x8*>(&af[mi]), *reinterpret_cast<const bf16x8*>(&bfr[ni]), acc[mi][ni], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                __uint_as_float(af[mi][e]), __uint_as_float(bfr[ni][e]), acc[mi][ni], 0, 0, 0);
+                    }
+                }
+        }
+    };
+
+    // loads / stores / MFMAs of one super-step (all static after unrolling)
+    auto gload_ss = [&](int ss) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) {
+            if constexpr (T1) { gload_w(rw[j], ss * NSUB + j, 0); gload_a(ra[j], ss * NSUB + j); }
+            else              { gload_w(rw[j], ss, j); }
+        }
+        if constexpr (!T1) gload_a(ra[0], ss);
+    };
+    auto sstore_ss = [&](int ss) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) {
+            sstore_w(rw[j], j);
+            if constexpr (T1) sstore_a(ra[j], j, ss * NSUB + j);
+        }
+        if constexpr (!T1) sstore_a(ra[0], 0, ss);
+    };
+    const int abl = p.flags >> 16;                            // debug ablation bits (tools/bench_conv.py)
+    // tools/build_tl.sh builds with GLOWTTS_TIMELINE: thread 0 of every workgroup logs shader-clock stamps into the
+    // buffer passed through p.ncols_valid ([workgroups][32] int64) - never defined in the product build
+#ifdef GLOWTTS_TIMELINE
+    long long* tlbuf = reinterpret_cast<long long*>(const_cast<int*>(p.ncols_valid)) + (long)blockIdx.x * 32;
+    if (tid == 0) { tlbuf[30] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); tlbuf[31] = (long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); }
+#endif
+    TL(0);
+    gload_ss(ssmap(0));
+    TL(1);
+    sstore_ss(ssmap(0));
+    TL(2);
+    __syncthreads();
+    TL(3);
+    for (int ss = 0; ss < NSS; ++ss) {
+        const int cur = ssmap(ss), nxt = ssmap(ss + 1 < NSS ? ss + 1 : ss);
+        gload_ss(nxt);                                        // next super-step, in flight during the MFMAs below
+        if (!(abl & 2)) {
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j) {
+                if constexpr (T1) { if (cur * NSUB + j < KCH) compute(j, 0, j); }
+                else              compute(0, j, j);
+            }
+        }
+        TL(4 + 3 * ss);
+        __syncthreads();                                      // every wave is done reading the tiles
+        TL(5 + 3 * ss);
+        sstore_ss(nxt);
+        __syncthreads();
+        TL(6 + 3 * ss);
+    }
+
+    // ---- fused epilogue ----
+#ifdef GLOWTTS_TIMELINE
+    conv_epilogue<CT, MI, NI, EPI>(p, acc, m0, n0, BM, wm, wn, lane, tid, tlbuf);
+#else
+    conv_epilogue<CT, MI, NI, EPI>(p, acc, m0, n0, BM, wm, wn, lane, tid, nullptr);
+#endif
     TL(29);
-#undef TL
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_dma_kernel: the multi-tap bf16 convolution over bf16-STORED activations (GLOWTTS_IO_A_BF16, no A prologue), staged
+// with LDS-DMA.  Why a second kernel (tools/conv_timeline.py on conv_cl_kernel, B = 32 WaveNet In conv): with 2-3 small
+// workgroups per CU all in the same phase, the register-staged kernel spends a third of every super-step writing the SAME
+// weight tiles into each workgroup's LDS (ds_write_b128 moves ~79 B/clk/CU) between two barriers, MFMA pipes idle.  Here:
+//   * ONE fat workgroup per CU: WMR waves (4..16, chosen by the host so that all tiles fit the chip in one round), each wave
+//     a 32-row x 64-column strip, so a weight tile is staged once per CU instead of once per 128 rows;
+//   * staging is global_load_lds_dwordx4 (no VGPR round trip, no ds_write): 1 KiB per wave-instruction into a linear LDS
+//     image; the XOR swizzle the fragment reads expect is applied to the per-lane SOURCE address (same involution);
+//   * two LDS stages, one barrier per K chunk: chunk ss+1 streams in while the 2*TAPS*2*NI MFMAs of chunk ss run.
+// Rows outside [0, rows) are clamped, not zeroed: they only feed outputs of rows outside the tensor (dropped by the epilogue's
+// bounds check) and of the first / last utterance's outermost pad rows, which every consumer masks.
+// ------------------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(1024))) unsigned char dma_smem[];
+
+template <int EPI, int TAPS>
+__global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args pin)
+{
+    typedef __bf16 CT;
+    constexpr int NI = 2, BN = 64, KC = 32;
+    glowtts_conv_args p = pin;
+    if (p.seed_ptr) p.seed += *p.seed_ptr;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // scalar: unit indices, LDS bases and branches below are wave-uniform
+    const int WMR = blockDim.x >> 6, BM = WMR * 32;
+    const int AU = (BM + TAPS - 1 + 15) >> 4;                 // 16-row (1 KiB) DMA units of the A tile
+    constexpr int WU = TAPS * 4;                              // 16-column units of the TAPS weight tiles of one K chunk
+    const int A_BYTES = AU * 1024, STAGE = A_BYTES + WU * 1024;
+    int m_tile, n_tile;
+    {   // XCD-aware tile order (see conv_cl_kernel)
+        const int gy = p.npad / BN;
+        const int total = gridDim.x, lin = blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = lin & 7, j = lin >> 3;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        n_tile = t % gy; m_tile = t / gy;
+    }
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int KCH = p.kchunks;
+    const int rot = (int)((m_tile * 5 + n_tile * 3) % KCH);
+    auto ssmap = [&](int ss) __attribute__((always_inline)) { int v = ss + rot; return v >= KCH ? v - KCH : v; };
+    constexpr int pad = (TAPS - 1) / 2;
+    const int l31 = lane & 31, lhi = lane >> 5;
+#ifdef GLOWTTS_TIMELINE
+    long long* tlbuf = reinterpret_cast<long long*>(const_cast<int*>(p.ncols_valid)) + (long)blockIdx.x * 32;
+    if (tid == 0) { tlbuf[30] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); tlbuf[31] = (long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); }
+#endif
+    TL(0);
+
+    f32x16 acc[1][NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][ni][r] = 0.f;
+
+    // lane -> (row or column inside a 16-unit, logical 16-byte slot): LDS position `lane` of a unit holds slot q of row lane >> 2
+    const int lrow = lane >> 2, qa = (lane & 3) ^ ((lane >> 4) & 3);
+    // DMA units of this wave: u = wave + i * WMR.  Their chunk-0 source addresses are computed once; a K chunk is a uniform
+    // byte step (64 B along an A row, one [npad][64 B] slab of the packed weights).
+    constexpr int MAXU = 8;                                   // >= ceil((AU + WU) / WMR) for every WMR >= 4
+    const int nun = AU + WU;
+    const unsigned char* usrc[MAXU];
+    int ukstep[MAXU];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+        const int u = wave + i * WMR;                         // wave-uniform (wave comes from readfirstlane)
+        if (u < AU) {
+            long g = (long)m0 - pad + u * 16 + lrow;
+            g = g < 0 ? 0 : (g >= p.rows ? (long)p.rows - 1 : g);
+            usrc[i] = reinterpret_cast<const unsigned char*>(p.a) + g * (p.lda * 2) + qa * 16;
+            ukstep[i] = KC * 2;
+        } else {
+            const int w = u - AU, t = w >> 2, cg = w & 3;
+            usrc[i] = reinterpret_cast<const unsigned char*>(p.w) + (((long)t * KCH) * p.npad + n0 + cg * 16 + lrow) * 64 + qa * 16;
+            ukstep[i] = p.npad * 64;
+        }
+    }
+    auto issue_unit = [&](auto I_, int buf, int kc) __attribute__((always_inline)) {
+        constexpr int i = decltype(I_)::value;
+        if constexpr (i < MAXU) {
+            const int u = wave + i * WMR;
+            if (u < nun) {
+                const unsigned char* src = usrc[i] + (long)kc * ukstep[i];
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                                 (void __attribute__((address_space(3)))*)(dma_smem + buf * STAGE + u * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // MFMAs of K chunk `buf`; when `nbuf >= 0` the DMAs of the next chunk are issued between the taps (two units per tap), so
+    // that their issue cost hides under the matrix pipe instead of serialising after the barrier
+    auto compute = [&](int buf, int nbuf, int nkc) __attribute__((always_inline)) {
+        const unsigned char* Ab = dma_smem + buf * STAGE;
+        const unsigned char* Wb = Ab + A_BYTES;
+        StaticFor<TAPS>::run([&](auto T_) __attribute__((always_inline)) {
+            constexpr int t = decltype(T_)::value;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int q = 2 * s2 + lhi;
+                const Chunk16 af = *reinterpret_cast<const Chunk16*>(Ab + swz(wave * 32 + l31 + t, q));
+                Chunk16 bfr[NI];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const Chunk16*>(Wb + t * 4096 + swz(ni * 32 + l31, q));
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&af), *reinterpret_cast<const bf16x8*>(&bfr[ni]),
+                                                                        acc[0][ni], 0, 0, 0);
+            }
+            if (nbuf >= 0) {
+                constexpr int PER = (MAXU + TAPS - 1) / TAPS;
+                StaticFor<PER>::run([&](auto J_) __attribute__((always_inline)) { issue_unit(IC<t * PER + decltype(J_)::value>{}, nbuf, nkc); });
+            }
+        });
+    };
+
+    const int abl = p.flags >> 16;
+    StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 0, ssmap(0)); });
+    TL(1);
+    for (int ss = 0; ss < KCH; ++ss) {
+        // own DMAs of chunk ss have landed (vmcnt(0)); after the barrier so have everyone's, and every wave is done reading
+        // the other stage (chunk ss-1), which can therefore be refilled while chunk ss is multiplied
+        __syncthreads();
+        TL(3 + 3 * ss);
+        const bool more = ss + 1 < KCH;
+        if (!(abl & 2)) compute(ss & 1, more ? ((ss + 1) & 1) : -1, more ? ssmap(ss + 1) : 0);
+        TL(5 + 3 * ss);
+    }
+#ifdef GLOWTTS_TIMELINE
+    conv_epilogue<CT, 1, NI, EPI>(p, acc, m0, n0, BM, wave, 0, lane, tid, tlbuf);
+#else
+    conv_epilogue<CT, 1, NI, EPI>(p, acc, m0, n0, BM, wave, 0, lane, tid, nullptr);
+#endif
+    TL(29);
+}
+
+int num_cus()
+{
+    static const int n = [] { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+                              return pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }();
+    return n;
+}
+
+// is the LDS-DMA kernel applicable to this problem?
+bool dma_ok(const glowtts_conv_args& a)
+{
+    static const bool enabled = [] { const char* e = getenv("GLOWTTS_DMA"); return !(e && e[0] == '0'); }();
+    return enabled && a.precision == GLOWTTS_BF16 && (a.io_flags & GLOWTTS_IO_A_BF16) && a.apro == GLOWTTS_APRO_NONE && !a.a2 &&
+           a.taps > 1 && a.batch <= 1 && a.kchunks * 32 == a.ca && (a.npad % 64) == 0 && a.rows >= 128;
+}
+
+template <int EPI, int TAPS>
+int launch_dma(const glowtts_conv_args& a, hipStream_t s)
+{
+    // waves per workgroup: all tiles resident at once (one workgroup per CU) if possible, else the fewest rounds
+    static const int force = [] { const char* e = getenv("GLOWTTS_DMA_WAVES"); return e ? atoi(e) : 0; }();
+    const int gy = a.npad / 64, ncu = num_cus(), frags = (a.rows + 31) / 32;
+    int best = 4; long best_cost = -1;
+    for (int w = 4; w <= 16; ++w) {
+        const long tiles = (long)((frags + w - 1) / w) * gy;
+        const long cost = ((tiles + ncu - 1) / ncu) * (w + 4);      // rounds x (strip work + fixed prologue / epilogue share)
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = w; }
+    }
+    if (force >= 1 && force <= 16) best = force;
+    const int BM = best * 32;
+    const int lds = 2 * ((((BM + TAPS - 1 + 15) >> 4) + TAPS * 4) * 1024);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<EPI, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return GLOWTTS_E_LAUNCH;
+        attr_done = true;
+    }
+    dim3 grid(((a.rows + BM - 1) / BM) * gy);
+    hipLaunchKernelGGL((conv_dma_kernel<EPI, TAPS>), grid, dim3(best * 64), lds, s, a);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
 template <typename CT, int MI, int NI, int WM, int WN, int EPI, int TAPS, int APRO, bool ABF>
@@ -813,6 +1007,7 @@ int launch_prec(const glowtts_conv_args& a, hipStream_t s)
 {
 #ifdef GLOWTTS_TOOLS_MIN     // tools/build_tl.sh: only the dominant kernel, for fast experiment builds
     if constexpr (sizeof(CT) == 2) {
+        if (dma_ok(a) && a.epi == GLOWTTS_EPI_GATE && a.taps == 5) return launch_dma<GLOWTTS_EPI_GATE, 5>(a, s);
         if (a.epi == GLOWTTS_EPI_GATE && a.taps == 5)
             return (a.io_flags & GLOWTTS_IO_A_BF16) ? launch_tile<CT, GLOWTTS_EPI_GATE, 5, GLOWTTS_APRO_NONE, true>(a, s)
                                                     : launch_tile<CT, GLOWTTS_EPI_GATE, 5, GLOWTTS_APRO_NONE, false>(a, s);
@@ -821,6 +1016,12 @@ int launch_prec(const glowtts_conv_args& a, hipStream_t s)
 #else
     const int N = GLOWTTS_APRO_NONE, PM = GLOWTTS_APRO_PAIRMUL;
     if constexpr (sizeof(CT) == 2) {
+        if (dma_ok(a)) {
+            if (a.epi == GLOWTTS_EPI_GATE && a.taps == 5) return launch_dma<GLOWTTS_EPI_GATE, 5>(a, s);
+            if (a.epi == GLOWTTS_EPI_LINEAR && a.taps == 5) return launch_dma<GLOWTTS_EPI_LINEAR, 5>(a, s);
+            if (a.epi == GLOWTTS_EPI_GATE && a.taps == 3) return launch_dma<GLOWTTS_EPI_GATE, 3>(a, s);
+            if (a.epi == GLOWTTS_EPI_LINEAR && a.taps == 3) return launch_dma<GLOWTTS_EPI_LINEAR, 3>(a, s);
+        }
         if (a.io_flags & GLOWTTS_IO_A_BF16) {      // bf16-stored A operand: the WaveNet state / gates / gate gradients
             if (a.epi == GLOWTTS_EPI_GATE && a.apro == N) return launch_taps<CT, GLOWTTS_EPI_GATE, GLOWTTS_APRO_NONE, true>(a, s);
             if (a.epi == GLOWTTS_EPI_LINEAR && a.apro == N) return launch_taps<CT, GLOWTTS_EPI_LINEAR, GLOWTTS_APRO_NONE, true>(a, s);

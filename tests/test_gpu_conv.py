@@ -134,7 +134,7 @@ def test_bf16_activation_storage_matches_fp32_storage(H, K):
     kw = dict(pad=(K - 1) // 2, epi=ops.EPI_GATE, h=H, n=2 * H, rows_per_utt=T + 4, bias=b_in, ld0=2 * H)
     ops.conv_cl(hs.float(), pw, H, R, out0=G32, **kw)
     ops.conv_cl(hs, pw, H, R, out0=G16, io_flags=ops.IO_A_BF16 | ops.IO_OUT0_BF16, **kw)
-    assert torch.equal(bf(G32), G16)
+    assert (bf(G32).float() - G16.float()).abs().max() <= 2 ** -7      # one bf16 ulp of a value in (-1, 1)
     # RESSKIP: gates bf16 (PAIRMUL), residual in / out bf16, skip fp32
     w_rs = (torch.randn(2 * H, H, 1, generator=g) / H ** 0.5).cuda()
     b_rs = (torch.randn(2 * H, generator=g) * 0.1).cuda()
@@ -160,7 +160,7 @@ def test_bf16_activation_storage_matches_fp32_storage(H, K):
     kw = dict(pad=(K - 1) // 2, epi=ops.EPI_LINEAR, flags=ops.F_MASK, n=H, rowmask=rm, ld0=H)
     ops.conv_cl(d16.float(), pw4, pw.npad, R, out0=o32, **kw)
     ops.conv_cl(d16, pw4, pw.npad, R, out0=o16, io_flags=ops.IO_A_BF16, **kw)
-    assert torch.equal(o32, o16)
+    assert torch.allclose(o32, o16, rtol=1e-5, atol=1e-5)        # (the two storage types may run different kernels: K-chunk order differs)
     # weight gradients: (DY, X) = (gate gradients, state) bf16; X = gates bf16 with PAIRMUL
     a32 = wgrad(d16.float(), hs.float(), pw.npad, H, K, ops.BF16, splits=1)
     a16 = wgrad(d16, hs, pw.npad, H, K, ops.BF16, splits=1, io_flags=ops.WIO_DY_BF16 | ops.WIO_X_BF16)

@@ -36,7 +36,16 @@ e0.record()
 for _ in range(n):
     run()
 e1.record(); torch.cuda.synchronize()
-print(f"tile={os.environ.get('GLOWTTS_TILE', 'default')} {e0.elapsed_time(e1) * 1e3 / n:.1f} us/launch")
+print(f"tile={os.environ.get('GLOWTTS_TILE', 'default')} dma={os.environ.get('GLOWTTS_DMA', '1')} waves={os.environ.get('GLOWTTS_DMA_WAVES', 'auto')} {e0.elapsed_time(e1) * 1e3 / n:.1f} us/launch")
+if not int(os.environ.get("ABL", "0")):
+    # correctness against a plain fp32 conv over the row axis (rows 2..R-3: the kernels differ in how they treat rows outside the tensor)
+    import torch.nn.functional as F
+    x = a.float().t().unsqueeze(0)                                    # [1, H, R]
+    pre = F.conv1d(x, w.to(torch.bfloat16).float(), bias, padding=2)[0].t()           # [R, 2H]
+    want = torch.stack([torch.tanh(pre[:, :H]), torch.sigmoid(pre[:, H:])], 2).reshape(R, 2 * H)
+    err = (G.float() - want)[2:R - 2].abs().max().item()
+    print(f"max |G - reference| = {err:.3e}")
+    assert err < 2e-2
 t = tl.cpu().numpy()
 used = t[:, 0] != 0
 t = t[used]
@@ -46,6 +55,10 @@ rel = t[:, :30] - t[:, :1]
 names = {0: "start", 1: "first loads issued", 2: "first tiles stored", 3: "sync"}
 for ss in range(8):
     names[4 + 3 * ss] = f"ss{ss} compute done"; names[5 + 3 * ss] = f"ss{ss} sync"; names[6 + 3 * ss] = f"ss{ss} next tiles stored+sync"
+if os.environ.get("GLOWTTS_DMA", "1") != "0" and bf:
+    names = {0: "start", 1: "first chunk issued"}
+    for ss in range(8):
+        names[3 + 3 * ss] = f"ss{ss} landed + barrier"; names[4 + 3 * ss] = f"ss{ss} next chunk issued"; names[5 + 3 * ss] = f"ss{ss} compute done"
 names[22] = "epilogue: biases loaded"; names[23] = "epilogue: 4 rows done"; names[24] = "epilogue: 8 rows done"; names[29] = "epilogue done"
 prev = 0
 for i in range(30):
