@@ -153,6 +153,10 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
     constexpr bool EX = sizeof(CT) == 4;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int abl = p.flags >> 16;                            // debug ablation bits (tools/bench_conv.py)
+    // dropout seed: the device word (graph replays) is read here, not at kernel start, where the scalar load would sit in front
+    // of the first tile loads
+    uint32_t seed = p.seed;
+    if (p.seed_ptr && p.drop_p > 0.f) seed += *p.seed_ptr;
     // accumulator element: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31.
     // Every global access goes through a buffer descriptor: rows >= p.rows (last tile) and invalid columns (voffset = OOB)
     // are dropped / read as 0 by the hardware bounds check, so the row loops carry no branches and a row's address is one
@@ -233,7 +237,7 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
                     for (int q = 0; q < 8; ++q)
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni)
-                            v[q][ni] *= drop_scale(p.seed, idn[ni] + (uint32_t)roff(mi, hb * 8 + q) * (uint32_t)p.n, p.drop_p, ikl);
+                            v[q][ni] *= drop_scale(seed, idn[ni] + (uint32_t)roff(mi, hb * 8 + q) * (uint32_t)p.n, p.drop_p, ikl);
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
@@ -370,7 +374,7 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
                     const int ro_ = roff(mi, reg), r = rb + ro_;
                     if (mi == 0 && reg == 4) TL(23);
                     if (mi == 0 && reg == 8) TL(24);
-                    const uint32_t rk = (MODE == 1 || (MODE == 2 && drop)) ? drop_rowkey(p.seed, (uint32_t)r) : 0u;
+                    const uint32_t rk = (MODE == 1 || (MODE == 2 && drop)) ? drop_rowkey(seed, (uint32_t)r) : 0u;
                     const bool sel = r >= rnext;
 #pragma unroll
                     for (int pi = 0; pi < NI / 2; ++pi) {
@@ -457,7 +461,7 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const int reg = hb * 8 + q;
-                        const uint32_t rk = DROP ? drop_rowkey(p.seed, (uint32_t)(rb + roff(mi, reg))) : 0u;
+                        const uint32_t rk = DROP ? drop_rowkey(seed, (uint32_t)(rb + roff(mi, reg))) : 0u;
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni) {
                             const float d = acc[mi][ni][reg], t = gt[q][ni], sg = gs[q][ni];
@@ -542,7 +546,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
         if (p.rowmask) p.rowmask += bz * p.mask_bstride;
         p.out0 += bz * p.out_bstride;
     }
-    if (p.seed_ptr) p.seed += *p.seed_ptr;
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32, NT = WM * WN * 64;
     constexpr bool T1 = (TAPS == 1);
     constexpr int NSUB = T1 ? ((APRO == GLOWTTS_APRO_NONE) ? 3 : 2) : TAPS;   // sub-steps per super-step
@@ -797,7 +800,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
 //     a 32-row x 64-column strip, so a weight tile is staged once per CU instead of once per 128 rows;
 //   * staging is global_load_lds_dwordx4 (no VGPR round trip, no ds_write): 1 KiB per wave-instruction into a linear LDS
 //     image; the XOR swizzle the fragment reads expect is applied to the per-lane SOURCE address (same involution);
-//   * two LDS stages, one barrier per K chunk: chunk ss+1 streams in while the 2*TAPS*2*NI MFMAs of chunk ss run.
+//   * three LDS stages, one barrier per K chunk: chunks ss+1 and ss+2 stream in while the 2*TAPS*NI MFMAs of chunk ss run
+//     (counted vmcnt waits, raw s_barrier: __syncthreads() would drain the DMA queue).
 // Rows outside [0, rows) are clamped, not zeroed: they only feed outputs of rows outside the tensor (dropped by the epilogue's
 // bounds check) and of the first / last utterance's outermost pad rows, which every consumer masks.
 // ------------------------------------------------------------------------------------------------
@@ -809,7 +813,6 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
     typedef __bf16 CT;
     constexpr int NI = 2, BN = 64, KC = 32;
     glowtts_conv_args p = pin;
-    if (p.seed_ptr) p.seed += *p.seed_ptr;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // scalar: unit indices, LDS bases and branches below are wave-uniform
     const int WMR = blockDim.x >> 6, BM = WMR * 32;
@@ -848,28 +851,29 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
     // byte step (64 B along an A row, one [npad][64 B] slab of the packed weights).
     constexpr int MAXU = 8;                                   // >= ceil((AU + WU) / WMR) for every WMR >= 4
     const int nun = AU + WU;
-    const unsigned char* usrc[MAXU];
-    int ukstep[MAXU];
+    uint32_t uoff[MAXU];                                      // 32-bit byte offsets from p.a / p.w (host-checked < 2^31)
 #pragma unroll
     for (int i = 0; i < MAXU; ++i) {
         const int u = wave + i * WMR;                         // wave-uniform (wave comes from readfirstlane)
         if (u < AU) {
-            long g = (long)m0 - pad + u * 16 + lrow;
-            g = g < 0 ? 0 : (g >= p.rows ? (long)p.rows - 1 : g);
-            usrc[i] = reinterpret_cast<const unsigned char*>(p.a) + g * (p.lda * 2) + qa * 16;
-            ukstep[i] = KC * 2;
+            int g = m0 - pad + u * 16 + lrow;
+            g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
+            uoff[i] = (uint32_t)g * (uint32_t)(p.lda * 2) + (uint32_t)(qa * 16);
         } else {
             const int w = u - AU, t = w >> 2, cg = w & 3;
-            usrc[i] = reinterpret_cast<const unsigned char*>(p.w) + (((long)t * KCH) * p.npad + n0 + cg * 16 + lrow) * 64 + qa * 16;
-            ukstep[i] = p.npad * 64;
+            uoff[i] = (uint32_t)((t * KCH) * p.npad + n0 + cg * 16 + lrow) * 64u + (uint32_t)(qa * 16);
         }
     }
+    const int nmine = (nun - wave + WMR - 1) / WMR;           // DMA instructions this wave issues per K chunk
+    const unsigned char* const abase = reinterpret_cast<const unsigned char*>(p.a);
+    const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(p.w);
+    const uint32_t wkstep = (uint32_t)p.npad * 64u;
     auto issue_unit = [&](auto I_, int buf, int kc) __attribute__((always_inline)) {
         constexpr int i = decltype(I_)::value;
         if constexpr (i < MAXU) {
             const int u = wave + i * WMR;
             if (u < nun) {
-                const unsigned char* src = usrc[i] + (long)kc * ukstep[i];
+                const unsigned char* src = (u < AU) ? abase + (uoff[i] + (uint32_t)kc * (KC * 2)) : wbase + (uoff[i] + (uint32_t)kc * wkstep);
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                                  (void __attribute__((address_space(3)))*)(dma_smem + buf * STAGE + u * 1024), 16, 0, 0);
             }
@@ -877,23 +881,32 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
     };
     // MFMAs of K chunk `buf`; when `nbuf >= 0` the DMAs of the next chunk are issued between the taps (two units per tap), so
     // that their issue cost hides under the matrix pipe instead of serialising after the barrier
+    // Fragment reads run one tap ahead of the MFMAs in a second register set (a wave's next MFMA otherwise waits a full LDS
+    // round trip: measured 3000 instead of 1920 clk per chunk at 3 waves per SIMD).
+    Chunk16 fa[2][2], fb[2][2][NI];                           // [set][k half][fragment]
     auto compute = [&](int buf, int nbuf, int nkc) __attribute__((always_inline)) {
         const unsigned char* Ab = dma_smem + buf * STAGE;
         const unsigned char* Wb = Ab + A_BYTES;
-        StaticFor<TAPS>::run([&](auto T_) __attribute__((always_inline)) {
-            constexpr int t = decltype(T_)::value;
+        auto load_frags = [&](auto T_) __attribute__((always_inline)) {
+            constexpr int t = decltype(T_)::value, set = t & 1;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int q = 2 * s2 + lhi;
-                const Chunk16 af = *reinterpret_cast<const Chunk16*>(Ab + swz(wave * 32 + l31 + t, q));
-                Chunk16 bfr[NI];
+                fa[set][s2] = *reinterpret_cast<const Chunk16*>(Ab + swz(wave * 32 + l31 + t, q));
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const Chunk16*>(Wb + t * 4096 + swz(ni * 32 + l31, q));
+                for (int ni = 0; ni < NI; ++ni) fb[set][s2][ni] = *reinterpret_cast<const Chunk16*>(Wb + t * 4096 + swz(ni * 32 + l31, q));
+            }
+        };
+        load_frags(IC<0>{});
+        StaticFor<TAPS>::run([&](auto T_) __attribute__((always_inline)) {
+            constexpr int t = decltype(T_)::value, set = t & 1;
+            if constexpr (t + 1 < TAPS) load_frags(IC<t + 1>{});
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                    acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&af), *reinterpret_cast<const bf16x8*>(&bfr[ni]),
-                                                                        acc[0][ni], 0, 0, 0);
-            }
+                    acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&fa[set][s2]),
+                                                                        *reinterpret_cast<const bf16x8*>(&fb[set][s2][ni]), acc[0][ni], 0, 0, 0);
             if (nbuf >= 0) {
                 constexpr int PER = (MAXU + TAPS - 1) / TAPS;
                 StaticFor<PER>::run([&](auto J_) __attribute__((always_inline)) { issue_unit(IC<t * PER + decltype(J_)::value>{}, nbuf, nkc); });
@@ -902,17 +915,37 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
     };
 
     const int abl = p.flags >> 16;
+    // Three LDS stages, chunks ss+1 and ss+2 in flight while chunk ss is multiplied.  s_waitcnt takes an immediate, the number of
+    // DMAs a wave has outstanding per chunk (nmine) is uniform but only known at run time: dispatch once per wait.
+    auto wait_keep = [&](int keep) __attribute__((always_inline)) {        // wait until at most `keep` of this wave's DMAs are outstanding, then barrier
+        switch (keep) {
+            case 0:  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+            case 1:  asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+            case 2:  asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+            case 3:  asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+            case 4:  asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+            case 5:  asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+            case 6:  asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+            case 7:  asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        }
+    };
     StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 0, ssmap(0)); });
+    if (KCH > 1) StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 1, ssmap(1)); });
     TL(1);
+    int cur = 0;                                              // stage of chunk ss (ss % 3)
     for (int ss = 0; ss < KCH; ++ss) {
-        // own DMAs of chunk ss have landed (vmcnt(0)); after the barrier so have everyone's, and every wave is done reading
-        // the other stage (chunk ss-1), which can therefore be refilled while chunk ss is multiplied
-        __syncthreads();
+        // this wave's DMAs of chunk ss have landed (those of chunk ss+1 may still fly); after the barrier so have everyone's,
+        // and every wave is done reading the stage of chunk ss-1, which is refilled with chunk ss+2 during the MFMAs below
+        wait_keep(ss + 1 < KCH ? nmine : 0);
         TL(3 + 3 * ss);
-        const bool more = ss + 1 < KCH;
-        if (!(abl & 2)) compute(ss & 1, more ? ((ss + 1) & 1) : -1, more ? ssmap(ss + 1) : 0);
+        const bool more = ss + 2 < KCH;
+        const int nxt = cur == 0 ? 2 : cur - 1;               // (ss + 2) % 3
+        if (!(abl & 2)) compute(cur, more ? nxt : -1, more ? ssmap(ss + 2) : 0);
         TL(5 + 3 * ss);
+        cur = cur == 2 ? 0 : cur + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef GLOWTTS_TIMELINE
     conv_epilogue<CT, 1, NI, EPI>(p, acc, m0, n0, BM, wave, 0, lane, tid, tlbuf);
 #else
@@ -950,7 +983,7 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
     }
     if (force >= 1 && force <= 16) best = force;
     const int BM = best * 32;
-    const int lds = 2 * ((((BM + TAPS - 1 + 15) >> 4) + TAPS * 4) * 1024);
+    const int lds = 3 * ((((BM + TAPS - 1 + 15) >> 4) + TAPS * 4) * 1024);     // three stages: <= 159 KiB at 16 waves, 5 taps
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<EPI, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
