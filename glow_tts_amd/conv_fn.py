@@ -49,8 +49,9 @@ def _L():
 def wgrad(dy, x, O, ca, taps, precision, want_bias=True, splits=0, xpro=0, io_flags=0):
     """dW [O, ca, taps], db [O] from dy rows [R, >=O] and x rows [R, >=ca]."""
     R = dy.shape[0]
-    dw = torch.zeros(O, ca, taps, device=dy.device)
-    db = torch.zeros(O, device=dy.device) if want_bias else None
+    buf = torch.zeros(O * ca * taps + (O if want_bias else 0), device=dy.device)      # one fill for both (split-K adds atomically)
+    dw = buf[:O * ca * taps].view(O, ca, taps)
+    db = buf[O * ca * taps:] if want_bias else None
     a = WgradArgs()
     a.dy, a.lddy, a.x, a.ldx = dy.data_ptr(), dy.shape[1], x.data_ptr(), x.shape[1]
     a.rows, a.m, a.ca, a.taps, a.pad = R, O, ca, taps, (taps - 1) // 2

@@ -74,6 +74,8 @@ def _L():
         L.glowtts_flow_backward.argtypes = [c_void_p] * 5
         L.glowtts_wgrad_grouped.argtypes = [c_void_p] + [c_int] * 9 + [c_void_p]
         L.glowtts_wgrad_grouped_io.argtypes = [c_void_p] + [c_int] * 10 + [c_void_p]
+        L.glowtts_weightnorm_fwd.argtypes = [c_void_p] * 4 + [c_i64, c_int, c_void_p]
+        L.glowtts_weightnorm_bwd.argtypes = [c_void_p] * 6 + [c_i64, c_int, c_void_p]
         L.glowtts_decoder_logdet.argtypes = [c_void_p, c_i64] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]
         _declared = True
     return L
@@ -412,7 +414,7 @@ class DecoderFunction(torch.autograd.Function):
         dx, _, _ = squeeze_rows(cfg, dz.contiguous(), ctx.lengths, want_mask=False)
         R = dx.shape[0]
         dld = dlogdet.contiguous() if dlogdet is not None else torch.zeros(B, device=dev)
-        G = {k: torch.zeros_like(W[k]) for k in WEIGHT_KEYS}
+        G = {k: torch.empty_like(W[k]) for k in WEIGHT_KEYS}      # every entry is fully written below (weight-gradient launches store, not accumulate)
         d_an = torch.empty(F_, 2 * C + 16, device=dev)
         # every flow / layer keeps its own gradient buffers: the weight gradients of ALL flows are computed afterwards by
         # two grouped launches (k-tap problems, 1x1 problems) whose tiles fill the chip without split-K or atomics
@@ -520,6 +522,133 @@ def stack_decoder_weights(P, cfg, prefix="layer_Dict.Decoder.layer_Dict.Flows"):
     w_end = torch.stack([P[f"{fl(f)}.2.layer_Dict.End.weight"] for f in range(F_)])
     b_end = torch.stack([P[f"{fl(f)}.2.layer_Dict.End.bias"] for f in range(F_)])
     return (an_logs, an_bias, inv_w, w_start, b_start, w_in, b_in, w_rs, b_rs, w_rs_last, b_rs_last, w_end, b_end)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Stacked parameter storage.  The decoder launches take every flow's / layer's weights as ONE tensor.  Building that with
+# torch.stack costs ~100 copy launches per step (and a split in the backward); instead the reference-named leaf Parameters are
+# re-pointed once to be views into one flat tensor per weight class (the flat-parameter technique of data-parallel wrappers):
+# the stacked tensor then exists without any copy, and the backward hands every leaf a view of the stacked gradient.
+# --------------------------------------------------------------------------------------------------------------------
+class _StackedLeaves(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flat, *leaves):
+        ctx.n, ctx.leaf_shape = len(leaves), leaves[0].shape
+        return flat.detach()                              # same storage as the leaves, fresh autograd identity
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().view(ctx.n, *ctx.leaf_shape)
+        return (None,) + tuple(g.unbind(0))               # views: AccumulateGrad keeps them as the leaves' .grad without a copy
+
+
+class LeafStack:
+    """A list of equally shaped leaf tensors (Parameters) kept as views of one flat tensor of shape lead + leaf_shape."""
+
+    def __init__(self, leaves, lead):
+        self.leaves, self.lead = list(leaves), tuple(lead)
+        assert len(self.leaves) == int(torch.tensor(self.lead).prod()) and len({tuple(t.shape) for t in self.leaves}) == 1
+        self.flat = None
+
+    def _aliased(self):
+        f = self.flat
+        if f is None or f.device != self.leaves[0].device:
+            return False
+        base, step = f.data_ptr(), self.leaves[0].numel() * f.element_size()
+        return all(t.data_ptr() == base + i * step and t.is_contiguous() for i, t in enumerate(self.leaves))
+
+    def tensor(self):
+        if not self._aliased():                           # first use, or the leaves were moved (model.to(...)): one-time re-pointing
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.GlowTTSHipError("run one eager step before capturing a hipGraph (parameter storage not flattened yet)")
+            with torch.no_grad():
+                flat = torch.stack([t.detach() for t in self.leaves]).contiguous()
+                for i, t in enumerate(self.leaves):
+                    t.data = flat[i]
+                self.flat = flat.view(self.lead + tuple(self.leaves[0].shape))
+        if torch.is_grad_enabled() and any(t.requires_grad for t in self.leaves):
+            return _StackedLeaves.apply(self.flat, *self.leaves)
+        return self.flat
+
+
+class WeightNorm(torch.autograd.Function):
+    """w = g * v / ||v||  (old-style torch weight_norm, norm over (in, k) per output channel) on stacked tensors [..., O, I, k]."""
+
+    @staticmethod
+    def forward(ctx, g, v):
+        v, g = v.contiguous(), g.contiguous()
+        rows, cols = v.numel() // (v.shape[-1] * v.shape[-2]), v.shape[-1] * v.shape[-2]
+        w, inv = torch.empty_like(v), torch.empty(rows, device=v.device)
+        L = _L()
+        _lib.check(L.glowtts_weightnorm_fwd(v.data_ptr(), g.data_ptr(), w.data_ptr(), inv.data_ptr(), rows, cols, _lib.stream()), "glowtts_weightnorm_fwd")
+        ctx.save_for_backward(g, v, inv)
+        ctx.dims = (rows, cols)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        g, v, inv = ctx.saved_tensors
+        rows, cols = ctx.dims
+        dw = dw.contiguous()
+        dv, dg = torch.empty_like(v), torch.empty_like(g)
+        _lib.check(_L().glowtts_weightnorm_bwd(dw.data_ptr(), v.data_ptr(), g.data_ptr(), inv.data_ptr(), dv.data_ptr(), dg.data_ptr(), rows, cols,
+                                               _lib.stream()), "glowtts_weightnorm_bwd")
+        return dg, dv
+
+
+class DecoderStacks:
+    """Leaf stacks of the decoder's parameters, built once per model from the reference-named parameter dict."""
+
+    def __init__(self, P, cfg, prefix="layer_Dict.Decoder.layer_Dict.Flows"):
+        F_, L = cfg.F, cfg.L
+        self.cfg = cfg
+        fl = lambda f: f"{prefix}.{f}.layers"
+        S = {}
+        S["an_logs"] = LeafStack([P[f"{fl(f)}.0.logs"] for f in range(F_)], (F_,))
+        S["an_bias"] = LeafStack([P[f"{fl(f)}.0.bias"] for f in range(F_)], (F_,))
+        S["inv_w"] = LeafStack([P[f"{fl(f)}.1.weight"] for f in range(F_)], (F_,))
+
+        def wn3(tag, names, lead):
+            for part, key in (("g", "weight_g"), ("v", "weight_v"), ("b", "bias")):
+                S[f"{tag}_{part}"] = LeafStack([P[f"{n}.{key}"] for n in names], lead)
+        wn3("start", [f"{fl(f)}.2.layer_Dict.Start" for f in range(F_)], (F_,))
+        wn3("in", [f"{fl(f)}.2.layer_Dict.WaveNet.layer_Dict.In_{l}" for f in range(F_) for l in range(L)], (F_, L))
+        if L > 1:
+            wn3("rs", [f"{fl(f)}.2.layer_Dict.WaveNet.layer_Dict.Res_Skip_{l}" for f in range(F_) for l in range(L - 1)], (F_, L - 1))
+        wn3("rsl", [f"{fl(f)}.2.layer_Dict.WaveNet.layer_Dict.Res_Skip_{L - 1}" for f in range(F_)], (F_,))
+        S["end_w"] = LeafStack([P[f"{fl(f)}.2.layer_Dict.End.weight"] for f in range(F_)], (F_,))
+        S["end_b"] = LeafStack([P[f"{fl(f)}.2.layer_Dict.End.bias"] for f in range(F_)], (F_,))
+        for kind in ("Speaker", "Prosody"):
+            if f"{fl(0)}.2.layer_Dict.WaveNet.layer_Dict.{kind}_0.weight_v" in P:
+                wn3(kind, [f"{fl(f)}.2.layer_Dict.WaveNet.layer_Dict.{kind}_{l}" for f in range(F_) for l in range(L)], (F_ * L,))
+        self.S = S
+
+    def weights(self):
+        """The stacked effective weights in WEIGHT_KEYS order (differentiable w.r.t. the leaves)."""
+        S, cfg = self.S, self.cfg
+        F_, L = cfg.F, cfg.L
+        t = lambda k: S[k].tensor()
+        wn = lambda tag: WeightNorm.apply(t(tag + "_g"), t(tag + "_v"))
+        if L > 1:
+            w_rs, b_rs = wn("rs"), t("rs_b")
+        else:
+            dev = S["in_v"].leaves[0].device
+            w_rs, b_rs = torch.zeros(F_, 0, 2 * cfg.H, cfg.H, 1, device=dev), torch.zeros(F_, 0, 2 * cfg.H, device=dev)
+        return (t("an_logs").view(F_, -1), t("an_bias").view(F_, -1), t("inv_w"), wn("start"), t("start_b"), wn("in"), t("in_b"),
+                w_rs, b_rs, wn("rsl"), t("rsl_b"), t("end_w"), t("end_b"))
+
+    def conditioning(self, speakers=None, prosodies=None):
+        """cond[b, f, l, :] = Speaker_l(spk_b) + Prosody_l(pro_b)  (Modules.py:863-866), one batched matmul each."""
+        cond = None
+        for kind, vec in (("Speaker", speakers), ("Prosody", prosodies)):
+            if vec is None:
+                continue
+            w = WeightNorm.apply(self.S[kind + "_g"].tensor(), self.S[kind + "_v"].tensor()).squeeze(-1)
+            c = torch.einsum("nod,bd->bno", w, vec) + self.S[kind + "_b"].tensor()
+            cond = c if cond is None else cond + c
+        if cond is None:
+            return None
+        return cond.view(cond.shape[0], self.cfg.F, self.cfg.L, 2 * self.cfg.H).contiguous()
 
 
 def stack_cond_weights(P, cfg, kind, prefix="layer_Dict.Decoder.layer_Dict.Flows"):

@@ -26,7 +26,7 @@ def from_rows(rows_btc):
 
 
 def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training=False, prefix="layer_Dict.Encoder",
-                    precision=1):
+                    precision=1, cache=None):
     """Modules.py:262-284 -> mean [B,mel,T], log_std [B,mel,T], log_durations [B,1,T] (channel-first, like the reference)."""
     e = hp.Encoder
     C = e.Channels
@@ -64,8 +64,16 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
     for i in range(e.Transformer.Stacks):
         q = f"{prefix}.layer_Dict.Transformer.layer_Dict.ANCRDCN_{i}.layer_Dict"
         a = q + ".Attention"
-        wqkv = torch.cat([P[a + ".layer_Dict.Query.weight"], P[a + ".layer_Dict.Key.weight"], P[a + ".layer_Dict.Value.weight"]], 0)
-        bqkv = torch.cat([P[a + ".layer_Dict.Query.bias"], P[a + ".layer_Dict.Key.bias"], P[a + ".layer_Dict.Value.bias"]], 0)
+        # Query / Key / Value run as one 1x1 conv with 3C outputs.  With a `cache` (the model's) the three leaves are views of
+        # one flat tensor (decoder.LeafStack): no concatenation per step
+        names = [a + ".layer_Dict." + n for n in ("Query", "Key", "Value")]
+        if cache is not None:
+            if a not in cache:
+                from .decoder import LeafStack
+                cache[a] = (LeafStack([P[n + ".weight"] for n in names], (3,)), LeafStack([P[n + ".bias"] for n in names], (3,)))
+            wqkv, bqkv = cache[a][0].tensor().view(3 * C, C, 1), cache[a][1].tensor().view(3 * C)
+        else:
+            wqkv, bqkv = torch.cat([P[n + ".weight"] for n in names], 0), torch.cat([P[n + ".bias"] for n in names], 0)
         qkv = conv_rows(x, wqkv, bqkv, rmf, precision=precision)                                             # RPR_MHA.py:82-84
         att = RPRAttention.apply(qkv, P[a + ".weight_K"], P[a + ".weight_V"], rmf, B, Tp, H, win,
                                  float(dr) if training else 0.0, nseed(), seed_t)                            # RPR_MHA.py:95-128

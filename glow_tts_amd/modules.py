@@ -156,6 +156,15 @@ def _build_encoder(hp):
     return enc
 
 
+def _unshare_state_dict(module, state_dict, prefix, local_metadata):
+    """Leaves that live in a flat per-class storage (decoder.LeafStack) are views of a larger tensor; torch.save would write the
+    whole storage once per key.  Checkpoints get private copies (same keys, shapes and values as the reference's)."""
+    for k, v in list(state_dict.items()):
+        if torch.is_tensor(v) and v.untyped_storage().nbytes() > v.numel() * v.element_size():
+            state_dict[k] = v.clone()
+    return state_dict
+
+
 class GlowTTS(torch.nn.Module):
     """Drop-in for Modules.GlowTTS (Modules.py:16-229)."""
 
@@ -187,11 +196,19 @@ class GlowTTS(torch.nn.Module):
                                              hp.Decoder.Affine_Coupling.Calc_Channels, wn.Num_Layers, wn.Kernel_Size, prec)
         self.actnorm_allreduce = None     # set by the data-parallel wrapper (glow_tts_amd.distributed)
         self._enc_stream = None
+        self._dec_stacks = None           # decoder.DecoderStacks: flat per-class parameter storage, built on first use
+        self._enc_cache = {}              # encoder leaf stacks (fused Query/Key/Value weights)
+        self._register_state_dict_hook(_unshare_state_dict)
         self.overlap_encoder = os.environ.get("GLOWTTS_ENCODER_OVERLAP", "1") == "1"
 
     # ---------------------------------------------------------------- helpers
     def _params(self):
         return dict(self.named_parameters())
+
+    def _stacks(self, P):
+        if self._dec_stacks is None:
+            self._dec_stacks = decoder.DecoderStacks(P, self.dec_cfg)
+        return self._dec_stacks
 
     def _flows(self):
         return self.layer_Dict["Decoder"].layer_Dict["Flows"]
@@ -251,10 +268,12 @@ class GlowTTS(torch.nn.Module):
         side = self._enc_stream if self.overlap_encoder else main
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, self.training, precision=self.dec_cfg.precision)
-        cond = decoder.conditioning(P, self.dec_cfg, spk, pro)
+            mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, self.training, precision=self.dec_cfg.precision,
+                                                             cache=self._enc_cache)
+        stacks = self._stacks(P)
+        cond = stacks.conditioning(spk, pro)
         self._maybe_init_actnorm(P, mels, mel_lengths, cond)
-        W = decoder.stack_decoder_weights(P, self.dec_cfg)
+        W = stacks.weights()
         drop_p = float(hp.Decoder.Affine_Coupling.WaveNet.Dropout_Rate) if self.training else 0.0      # Modules.py:854-862
         z, log_dets = decoder.DecoderFunction.apply(self.dec_cfg, mels, mel_lengths, cond, drop_p, *W)
         if side is not main:
@@ -284,7 +303,7 @@ class GlowTTS(torch.nn.Module):
         P = self._params()
         spk, pro = self._conditioning(P, speakers, mels_for_ge2e, mels_for_prosody, mel_lengths_for_prosody)
         token_mask = self.Mask_Generate(token_lengths, tokens.shape[1])
-        mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, False, precision=self.dec_cfg.precision)
+        mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, False, precision=self.dec_cfg.precision, cache=self._enc_cache)
         if not torch.is_tensor(length_scale):
             length_scale = torch.tensor([float(length_scale)], device=tokens.device)
         ls = length_scale.to(tokens.device).unsqueeze(-1).unsqueeze(-1)                                   # Modules.py:169
@@ -298,8 +317,9 @@ class GlowTTS(torch.nn.Module):
         if noises is None:
             noises = torch.randn_like(mel_mean)
         z = (mel_mean + torch.exp(mel_log_std) * noises[:, :, :mel_mean.shape[2]] * noise_scale) * mel_mask   # :187-191
-        cond = decoder.conditioning(P, self.dec_cfg, spk, pro)
-        W = dict(zip(decoder.WEIGHT_KEYS, [w.contiguous() for w in decoder.stack_decoder_weights(P, self.dec_cfg)]))
+        stacks = self._stacks(P)
+        cond = stacks.conditioning(spk, pro)
+        W = dict(zip(decoder.WEIGHT_KEYS, [w.contiguous() for w in stacks.weights()]))
         mels = decoder.decoder_inverse(self.dec_cfg, W, z.contiguous(), mel_lengths, cond=cond, fill=-float(hp.Sound.Max_Abs_Mel))   # :198-202
         return mels, mel_lengths, attn
 

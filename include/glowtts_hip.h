@@ -357,6 +357,16 @@ int glowtts_mle_loss_fwd(const float *z, const float *mean, const float *log_std
 int glowtts_mle_loss_bwd(const float *z, const float *mean, const float *log_std, const float *dloss, const float *inv_denom,
                          float *dz, float *dmean, float *dlog_std, int64_t n, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Old-style weight normalisation of the WaveNet convolutions (Modules.py:766,818,825,838,845: torch.nn.utils.weight_norm,
+ * norm over (in, k) per output channel) for a whole stack of convs per launch.
+ *   v [rows][cols], g [rows]  ->  w = g * v / ||v||  [rows][cols],  inv_norm [rows] = 1 / ||v||   (kept for the backward)
+ *   backward: dg = <dw, v> / ||v||,  dv = g / ||v|| * (dw - v <dw, v> / ||v||^2)
+ * rows = stacked convs x output channels, cols = in * k.  All pointers fp32 device tensors. */
+int glowtts_weightnorm_fwd(const float *v, const float *g, float *w, float *inv_norm, int64_t rows, int cols, void *stream);
+int glowtts_weightnorm_bwd(const float *dw, const float *v, const float *g, const float *inv_norm, float *dv, float *dg,
+                           int64_t rows, int cols, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,3 +75,25 @@ def test_single_process_is_a_noop():
     FlatGradReducer(list(m.parameters())).reduce()
     assert all(torch.equal(a, p.grad) for a, p in zip(before, m.parameters()))
     assert float(global_frame_weight(torch.tensor(5))) == 1.0
+
+
+def test_leaf_stack_aliases_leaves_and_routes_grads():
+    """decoder.LeafStack: the stacked tensor shares storage with the leaf Parameters (no per-step copy), the backward hands every
+    leaf its slice, in-place updates of a leaf are seen by the stack, and replaced leaves are re-pointed."""
+    from glow_tts_amd.decoder import LeafStack
+    torch.manual_seed(0)
+    leaves = [torch.nn.Parameter(torch.randn(3, 2)) for _ in range(6)]
+    before = [p.detach().clone() for p in leaves]
+    st = LeafStack(leaves, (2, 3))
+    t = st.tensor()
+    assert t.shape == (2, 3, 3, 2) and all(torch.equal(p.detach(), b) for p, b in zip(leaves, before))
+    assert all(p.data_ptr() == st.flat.data_ptr() + i * 6 * 4 for i, p in enumerate(leaves))
+    w = torch.randn(2, 3, 3, 2)
+    (t * w).sum().backward()
+    assert all(torch.equal(p.grad, w.view(6, 3, 2)[i]) for i, p in enumerate(leaves))
+    with torch.no_grad():
+        leaves[4].add_(1.0)                                   # optimizer-style in-place update
+    assert torch.equal(st.tensor().detach().view(6, 3, 2)[4], before[4] + 1.0)
+    leaves[2].data = leaves[2].data.clone()                   # e.g. model.to(...): the leaf left the flat storage
+    t2 = st.tensor()
+    assert leaves[2].data_ptr() == st.flat.data_ptr() + 2 * 6 * 4 and torch.equal(t2.detach().view(6, 3, 2)[2], before[2])

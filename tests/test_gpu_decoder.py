@@ -192,3 +192,21 @@ def test_wavenet_dropout_statistics_and_backward_consistency():
         return (vals[0] - vals[1]) / (2 * eps)
     numeric = (4 * central(5e-3) - central(1e-2)) / 3          # Richardson: removes the eps^2 term of the central difference
     assert abs(numeric - analytic) <= 2e-2 * max(1.0, abs(analytic)), (numeric, analytic)
+
+
+def test_fused_weightnorm_matches_torch():
+    """glowtts_weightnorm_fwd / _bwd vs the torch expression of old-style weight_norm (Modules.py:766): g * v / ||v||."""
+    from glow_tts_amd.decoder import WeightNorm, _wn
+    g_ = torch.Generator().manual_seed(3)
+    for shape in [(12, 4, 384, 192, 5), (12, 192, 80, 1), (5, 40, 2100, 1)]:
+        v = torch.randn(*shape, generator=g_).cuda().requires_grad_(True)
+        g = (torch.rand(*shape[:-2], 1, 1, generator=g_) + 0.5).cuda().requires_grad_(True)
+        dw = torch.randn(*shape, generator=g_).cuda()
+        w = WeightNorm.apply(g, v)
+        w.backward(dw)
+        got = (w.detach(), g.grad.clone(), v.grad.clone())
+        g.grad = v.grad = None
+        w2 = _wn(g, v)
+        w2.backward(dw)
+        for a, b in zip(got, (w2.detach(), g.grad, v.grad)):
+            assert (a - b).abs().max() <= 1e-5 * max(1.0, b.abs().max().item())
