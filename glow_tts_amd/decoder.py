@@ -559,7 +559,7 @@ class LeafStack:
 
     def tensor(self):
         if not self._aliased():                           # first use, or the leaves were moved (model.to(...)): one-time re-pointing
-            if torch.cuda.is_current_stream_capturing():
+            if self.leaves[0].is_cuda and torch.cuda.is_current_stream_capturing():
                 raise _lib.GlowTTSHipError("run one eager step before capturing a hipGraph (parameter storage not flattened yet)")
             with torch.no_grad():
                 flat = torch.stack([t.detach() for t in self.leaves]).contiguous()
