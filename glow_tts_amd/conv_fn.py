@@ -41,7 +41,7 @@ def _L():
         L.glowtts_rpr_attention_fwd.argtypes = [c_p] * 6 + [c_int] * 5 + [c_f, c_u32, c_p, c_p]
         L.glowtts_rpr_attention_scratch_floats.argtypes = [c_int] * 5
         L.glowtts_rpr_attention_scratch_floats.restype = c_i64
-        L.glowtts_rpr_attention_bwd.argtypes = [c_p] * 11 + [c_int] * 5 + [c_f, c_p]
+        L.glowtts_rpr_attention_bwd.argtypes = [c_p] * 11 + [c_int] * 5 + [c_f, c_u32, c_p, c_p]
         _decl = True
     return L
 
@@ -197,22 +197,23 @@ class RPRAttention(torch.autograd.Function):
         _lib.check(_L().glowtts_rpr_attention_fwd(qkv.data_ptr(), rk.data_ptr(), rv.data_ptr(), rowmask.data_ptr(), out.data_ptr(), P.data_ptr(),
                                                   B, Tp, H, D, win, float(drop_p), int(seed) & 0xFFFFFFFF, _sp(seed_t), _lib.stream()),
                    "glowtts_rpr_attention_fwd")
-        ctx.save_for_backward(qkv, rk, rv, rowmask, P)
-        ctx.cfg = (B, Tp, H, D, win, float(drop_p))
+        ctx.save_for_backward(qkv, rk, rv, rowmask, P, seed_t)
+        ctx.cfg = (B, Tp, H, D, win, float(drop_p), int(seed) & 0xFFFFFFFF)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, rk, rv, rowmask, P = ctx.saved_tensors
-        B, Tp, H, D, win, drop_p = ctx.cfg
+        qkv, rk, rv, rowmask, P, seed_t = ctx.saved_tensors
+        B, Tp, H, D, win, drop_p, seed = ctx.cfg
         L = _L()
         dev = qkv.device
         nw = 2 * win + 1
         dS = torch.empty(B, H, Tp, Tp, device=dev)
         dqkv = torch.empty_like(qkv)
-        drk, drv = torch.empty(nw, D, device=dev), torch.empty(nw, D, device=dev)
+        drel = torch.empty(2, nw, D, device=dev)
+        drk, drv = drel[0], drel[1]
         scratch = torch.empty(L.glowtts_rpr_attention_scratch_floats(B, Tp, H, D, win) + 2 * nw * D, device=dev)
         _lib.check(L.glowtts_rpr_attention_bwd(qkv.data_ptr(), rk.data_ptr(), rv.data_ptr(), rowmask.data_ptr(), P.data_ptr(),
                                                dout.contiguous().data_ptr(), dS.data_ptr(), dqkv.data_ptr(), drk.data_ptr(), drv.data_ptr(),
-                                               scratch.data_ptr(), B, Tp, H, D, win, drop_p, _lib.stream()), "glowtts_rpr_attention_bwd")
+                                               scratch.data_ptr(), B, Tp, H, D, win, drop_p, seed, _sp(seed_t), _lib.stream()), "glowtts_rpr_attention_bwd")
         return dqkv, drk.view(1, nw, D), drv.view(1, nw, D), None, None, None, None, None, None, None, None

@@ -4,6 +4,7 @@
 // Layout: rows tensors [B][Tp][C], channels contiguous, zero pad rows (include/glowtts_hip.h).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/glowtts_hip.h"
 
 namespace {
@@ -508,6 +509,335 @@ extern "C" int glowtts_embedding_bwd(const int64_t* tokens, const float* drows, 
     RET_LAUNCH();
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA attention core (Tp <= 128, D in {64, 96}, 2*win+1 <= 32): one workgroup per (utterance, head), wave w owns the
+// queries [32w, 32w+32).  All contractions run on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate: the f32 mode stays
+// exact; the problem is far too small for the precision of the operands to matter for speed):
+//   S = Q K^T (+ Q relK^T on the band) -> masked softmax -> P0 (kept for the backward) -> dropout -> O = Pd V + Pd_band relV.
+// MFMA operand element of lane (l31, lhi) at step ks: A[row l31][k = 2 ks + lhi], B[k = 2 ks + lhi][col l31]; the
+// accumulator holds C[row (reg & 3) + 8 (reg >> 2) + 4 lhi][col l31].  LDS rows have odd strides (D + 1, 129): the 32 lanes
+// of a half-wave then hit 32 different banks whether they walk rows (A / K-as-B operands) or columns (V-as-B operand).
+// P stores the probabilities BEFORE dropout (the backward regenerates the keep mask from the same hash).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int AT_TP = 128, AT_LDP = AT_TP + 1;
+
+__device__ __forceinline__ float half_max(float v) {          // over the 32 lanes that share lane >> 5
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int acc_row(int reg, int lhi) { return (reg & 3) + 8 * (reg >> 2) + 4 * lhi; }
+
+// rows [0, nrows) x D floats of a [*, ld]-strided global tile -> LDS [128 or 32][LD] (rows >= nrows zero), all 256 threads
+template <int D, int LD, int ROWS>
+__device__ __forceinline__ void stage_rows(float* dst, const float* src, long ld, int nrows, int tid)
+{
+    constexpr int Q4 = D / 4;
+    for (int i = tid; i < ROWS * Q4; i += 256) {
+        const int r = i / Q4, c = (i - r * Q4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < nrows) v = *reinterpret_cast<const float4*>(src + (long)r * ld + c);
+        float* o = dst + r * LD + c;
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+}
+
+template <int ND>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ relk, const float* __restrict__ relv,
+                                                            const float* __restrict__ rowmask, float* __restrict__ out, float* __restrict__ P,
+                                                            int B, int Tp, int H, int win, float drop_p, uint32_t seed, const uint32_t* __restrict__ seed_ptr)
+{
+    constexpr int D = ND * 32, LD = D + 1, KS = D / 2;
+    extern __shared__ float sm[];
+    float* KV = sm;                               // [128][LD]   K, then V
+    float* RL = KV + AT_TP * LD;                  // [32][LD]    relK, then relV (rows >= 2 win + 1 are zero)
+    float* PT = RL + 32 * LD;                     // [4][32][129] per wave: Q staging, then the (dropped) probabilities
+    float* RQ = PT + 4 * 32 * AT_LDP;             // [4][32][33]  per wave: q_i . relK[dd]
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int C = H * D, ld = 3 * C, nw = 2 * win + 1;
+    const float* base = qkv + (long)b * Tp * ld + h * D;
+    if (seed_ptr && drop_p > 0.f) seed += *seed_ptr;
+    float* myP = PT + wave * 32 * AT_LDP;
+    float* myR = RQ + wave * 32 * 33;
+
+    stage_rows<D, LD, AT_TP>(KV, base + C, ld, Tp, tid);
+    stage_rows<D, LD, 32>(RL, relk, D, nw, tid);
+    {   // this wave's 32 query rows -> A fragments (through its own P region)
+        constexpr int Q4 = D / 4;
+        for (int i = lane; i < 32 * Q4; i += 64) {
+            const int r = i / Q4, c = (i - r * Q4) * 4, qi = wave * 32 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qi < Tp) v = *reinterpret_cast<const float4*>(base + (long)qi * ld + c);
+            float* o = myP + r * LD + c;
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        }
+    }
+    __syncthreads();
+    // ---- phase 1: scores ----
+    f32x16 S[4], R;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { S[0][r] = 0.f; S[1][r] = 0.f; S[2][r] = 0.f; S[3][r] = 0.f; R[r] = 0.f; }
+#pragma unroll 4
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = 2 * ks + lhi;
+        const float a = myP[l31 * LD + k];                     // Q fragment (staged with row stride LD)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) S[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[(32 * nt + l31) * LD + k], S[nt], 0, 0, 0);
+        R = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RL[l31 * LD + k], R, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) myR[acc_row(reg, lhi) * 33 + l31] = R[reg];
+    __syncthreads();                              // RQ visible; every wave is done with K / relK and with its Q staging
+
+    const float isd = rsqrtf((float)D);
+    const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const float* rm = rowmask + (long)b * Tp;
+    float mj[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { const int j = 32 * nt + l31; mj[nt] = j < Tp ? rm[j] : 0.f; }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = acc_row(reg, lhi), i = 32 * wave + row;
+        const float mi = i < Tp ? rm[i] : 0.f;
+        float sc[4], mx = -3.0e38f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int j = 32 * nt + l31, dd = j - i + win;
+            float v = S[nt][reg];
+            if (dd >= 0 && dd < nw) v += myR[row * 33 + dd];
+            v *= isd;
+            if (mi * mj[nt] == 0.f) v = -1e4f;                        // RPR_MHA.py:117
+            if (j >= Tp) v = -3.0e38f;
+            sc[nt] = v; mx = fmaxf(mx, v);
+        }
+        mx = half_max(mx);
+        float den = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { sc[nt] = (32 * nt + l31 < Tp) ? __expf(sc[nt] - mx) : 0.f; den += sc[nt]; }
+        den = 1.f / half_sum(den);
+        float* Pg = P + (((long)b * H + h) * Tp + i) * Tp;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int j = 32 * nt + l31;
+            float p = sc[nt] * den;
+            if (i < Tp && j < Tp) Pg[j] = p;
+            if (drop_p > 0.f) p *= drop_scale(seed, (uint32_t)((((long)b * H + h) * Tp + i) * Tp + j), drop_p, ik);   // RPR_MHA.py:120
+            myP[row * AT_LDP + j] = p;
+        }
+    }
+    // ---- phase 2: O = Pd V + Pd_band relV ----
+    stage_rows<D, LD, AT_TP>(KV, base + 2 * C, ld, Tp, tid);
+    stage_rows<D, LD, 32>(RL, relv, D, nw, tid);
+    __syncthreads();
+    f32x16 O[ND];
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[nd][r] = 0.f;
+#pragma unroll 4
+    for (int ks = 0; ks < AT_TP / 2; ++ks) {
+        const int k = 2 * ks + lhi;
+        const float a = myP[l31 * AT_LDP + k];
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd) O[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[k * LD + 32 * nd + l31], O[nd], 0, 0, 0);
+    }
+    {
+        const int i = 32 * wave + l31;
+        for (int ks = 0; ks < (nw + 1) / 2; ++ks) {
+            const int dd = 2 * ks + lhi, j = i + dd - win;
+            const float a = (dd < nw && j >= 0 && j < Tp) ? myP[l31 * AT_LDP + j] : 0.f;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) O[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RL[dd * LD + 32 * nd + l31], O[nd], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int i = 32 * wave + acc_row(reg, lhi);
+        if (i >= Tp) continue;
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd) out[((long)b * Tp + i) * C + h * D + 32 * nd + l31] = O[nd][reg];
+    }
+}
+
+// Backward of the MFMA attention core, one workgroup per (utterance, head), wave w owns query rows AND key rows [32w, 32w+32).
+//   dPd = dO V^T (+ dO relV^T on the band);  Pd = P0 keep / (1-p);  D_i = sum_j Pd dPd;  dS = P0 (keep/(1-p) dPd - D_i) / sqrt(D)
+//   dV = Pd^T dO   drelV[dd] = sum_i Pd[i][i+dd-w] dO_i      dQ = dS K + dS_band relK      dK = dS^T Q   drelK[dd] = sum_i dS[i][i+dd-w] q_i
+// The 128 x 128 matrices Pd and dS pass through LDS (PT) so that they can be read both row-wise (A operand of dQ) and
+// column-wise (A operand of dV / dK); the 128 x D operands are staged one after the other into the same LDS buffer.
+// drelK / drelV: per-wave partial sums -> part[(bh * 4 + wave)][2][nw][D] (summed by colsum_final_kernel; deterministic).
+template <int ND>
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ relk, const float* __restrict__ relv,
+                                                            const float* __restrict__ rowmask, const float* __restrict__ P, const float* __restrict__ dout,
+                                                            float* __restrict__ dqkv, float* __restrict__ part,
+                                                            int B, int Tp, int H, int win, float drop_p, uint32_t seed, const uint32_t* __restrict__ seed_ptr)
+{
+    constexpr int D = ND * 32, LD = D + 1, KS = D / 2;
+    extern __shared__ float sm[];
+    float* KV = sm;                               // [128][LD]   V, dO, K, Q in turn
+    float* RL = KV + AT_TP * LD;                  // [32][LD]    relV, then relK
+    float* PT = RL + 32 * LD;                     // [128][129]  dO staging (per wave), then Pd, then dS
+    float* RQ = PT + 4 * 32 * AT_LDP;             // [4][32][33] per wave: dO_i . relV[dd]
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int C = H * D, ld = 3 * C, nw = 2 * win + 1;
+    const float* base = qkv + (long)b * Tp * ld + h * D;
+    const float* dob = dout + (long)b * Tp * C + h * D;
+    float* dbase = dqkv + (long)b * Tp * ld + h * D;
+    if (seed_ptr && drop_p > 0.f) seed += *seed_ptr;
+    float* myP = PT + wave * 32 * AT_LDP;
+    float* myR = RQ + wave * 32 * 33;
+    float* mypart = part + ((long)(b * H + h) * 4 + wave) * 2 * nw * D;
+
+    // ---- phase 1: dPd, D_i, dS (registers), Pd (LDS) ----
+    stage_rows<D, LD, AT_TP>(KV, base + 2 * C, ld, Tp, tid);
+    stage_rows<D, LD, 32>(RL, relv, D, nw, tid);
+    {
+        constexpr int Q4 = D / 4;
+        for (int i = lane; i < 32 * Q4; i += 64) {
+            const int r = i / Q4, c = (i - r * Q4) * 4, qi = wave * 32 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qi < Tp) v = *reinterpret_cast<const float4*>(dob + (long)qi * C + c);
+            float* o = myP + r * LD + c;
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        }
+    }
+    __syncthreads();
+    f32x16 S[4], R;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { S[0][r] = 0.f; S[1][r] = 0.f; S[2][r] = 0.f; S[3][r] = 0.f; R[r] = 0.f; }
+#pragma unroll 4
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = 2 * ks + lhi;
+        const float a = myP[l31 * LD + k];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) S[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[(32 * nt + l31) * LD + k], S[nt], 0, 0, 0);
+        R = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RL[l31 * LD + k], R, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) myR[acc_row(reg, lhi) * 33 + l31] = R[reg];
+    __syncthreads();
+    const float isd = rsqrtf((float)D);
+    const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = acc_row(reg, lhi), i = 32 * wave + row;
+        const float* Pg = P + (((long)b * H + h) * Tp + i) * Tp;
+        float p0[4], kd[4], dsum = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int j = 32 * nt + l31, dd = j - i + win;
+            float dpd = S[nt][reg];
+            if (dd >= 0 && dd < nw) dpd += myR[row * 33 + dd];
+            p0[nt] = (i < Tp && j < Tp) ? Pg[j] : 0.f;
+            float keep = 1.f;
+            if (drop_p > 0.f) keep = drop_scale(seed, (uint32_t)((((long)b * H + h) * Tp + i) * Tp + j), drop_p, ik);
+            kd[nt] = keep * dpd;
+            dsum += p0[nt] * kd[nt];                                  // Pd dPd
+            myP[row * AT_LDP + j] = p0[nt] * keep;                    // Pd
+        }
+        dsum = half_sum(dsum);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) S[nt][reg] = p0[nt] * (kd[nt] - dsum) * isd;     // dS
+    }
+    __syncthreads();                              // Pd complete; V / relV no longer needed
+
+    // column-block products with a full 128-row operand in KV:  out[j in own block][d] = sum_i PT[i][j] KV[i][d], plus the
+    // relative-embedding gradient of the own query rows:        rel[dd][d]          = sum_{i own} PT[i][i + dd - w] KV[i][d]
+    auto col_products = [&](float* dst /* rows j */, float* relpart) __attribute__((always_inline)) {
+        f32x16 O[ND], RV[ND];
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { O[nd][r] = 0.f; RV[nd][r] = 0.f; }
+#pragma unroll 4
+        for (int ks = 0; ks < AT_TP / 2; ++ks) {
+            const int i = 2 * ks + lhi;
+            const float a = PT[i * AT_LDP + 32 * wave + l31];
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) O[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[i * LD + 32 * nd + l31], O[nd], 0, 0, 0);
+        }
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+            const int i = 32 * wave + 2 * ks + lhi, j = i + l31 - win;
+            const float a = (l31 < nw && j >= 0 && j < Tp) ? PT[i * AT_LDP + j] : 0.f;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) RV[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[i * LD + 32 * nd + l31], RV[nd], 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = acc_row(reg, lhi), j = 32 * wave + row;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) {
+                if (j < Tp) dst[(long)j * ld + 32 * nd + l31] = O[nd][reg];
+                if (row < nw) relpart[row * D + 32 * nd + l31] = RV[nd][reg];
+            }
+        }
+    };
+
+    // ---- phase 2: dV, drelV ----
+    stage_rows<D, LD, AT_TP>(KV, dob, C, Tp, tid);
+    __syncthreads();
+    col_products(dbase + 2 * C, mypart + nw * D);
+    __syncthreads();                              // everyone is done with Pd and dO
+    // ---- phase 3: dS -> LDS; dQ = dS K + dS_band relK ----
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = acc_row(reg, lhi);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) myP[row * AT_LDP + 32 * nt + l31] = S[nt][reg];
+    }
+    stage_rows<D, LD, AT_TP>(KV, base + C, ld, Tp, tid);
+    stage_rows<D, LD, 32>(RL, relk, D, nw, tid);
+    __syncthreads();
+    {
+        f32x16 O[ND];
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[nd][r] = 0.f;
+#pragma unroll 4
+        for (int ks = 0; ks < AT_TP / 2; ++ks) {
+            const int k = 2 * ks + lhi;
+            const float a = myP[l31 * AT_LDP + k];
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) O[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[k * LD + 32 * nd + l31], O[nd], 0, 0, 0);
+        }
+        const int i = 32 * wave + l31;
+        for (int ks = 0; ks < (nw + 1) / 2; ++ks) {
+            const int dd = 2 * ks + lhi, j = i + dd - win;
+            const float a = (dd < nw && j >= 0 && j < Tp) ? myP[l31 * AT_LDP + j] : 0.f;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) O[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RL[dd * LD + 32 * nd + l31], O[nd], 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int qi = 32 * wave + acc_row(reg, lhi);
+            if (qi >= Tp) continue;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) dbase[(long)qi * ld + 32 * nd + l31] = O[nd][reg];
+        }
+    }
+    __syncthreads();                              // everyone is done with K
+    // ---- phase 4: dK, drelK ----
+    stage_rows<D, LD, AT_TP>(KV, base, ld, Tp, tid);
+    __syncthreads();
+    col_products(dbase + C, mypart);
+}
+
+static bool attn_mfma_ok(int Tp, int D, int win)
+{
+    static const bool enabled = [] { const char* e = getenv("GLOWTTS_ATTN_MFMA"); return !(e && e[0] == '0'); }();
+    return enabled && Tp <= AT_TP && (D == 64 || D == 96) && 2 * win + 1 <= 32;
+}
+static size_t attn_mfma_lds(int D) { return ((size_t)(AT_TP + 32) * (D + 1) + 4 * 32 * AT_LDP + 4 * 32 * 33) * sizeof(float); }
+
 static size_t attn_lds_bytes(int Tp, int D, int win, bool)
 {
     return ((size_t)Tp * (D + 1) + (size_t)(2 * win + 1) * D + 4 * (size_t)D + (size_t)ATT_QT * Tp) * sizeof(float);
@@ -517,6 +847,18 @@ extern "C" int glowtts_rpr_attention_fwd(const float* qkv, const float* relk, co
                                          int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t* seed_ptr, void* stream)
 {
     if (!qkv || !relk || !relv || !rowmask || !out || !P || B < 1 || Tp < 1 || Tp > 256 || H < 1 || D < 1 || win < 0) return GLOWTTS_E_ARG;
+    if (attn_mfma_ok(Tp, D, win)) {
+        const size_t l2 = attn_mfma_lds(D);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        if (D == 96) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+            hipLaunchKernelGGL(attn_fwd_mfma_kernel<3>, dim3(H, B), dim3(256), l2, st, qkv, relk, relv, rowmask, out, P, B, Tp, H, win, drop_p, seed, seed_ptr);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+            hipLaunchKernelGGL(attn_fwd_mfma_kernel<2>, dim3(H, B), dim3(256), l2, st, qkv, relk, relv, rowmask, out, P, B, Tp, H, win, drop_p, seed, seed_ptr);
+        }
+        RET_LAUNCH();
+    }
     const size_t lds = attn_lds_bytes(Tp, D, win, false);
     if (lds > 160 * 1024) return GLOWTTS_E_ARG;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -525,25 +867,43 @@ extern "C" int glowtts_rpr_attention_fwd(const float* qkv, const float* relk, co
     RET_LAUNCH();
 }
 
-extern "C" int64_t glowtts_rpr_attention_scratch_floats(int B, int Tp, int H, int D, int win) { return (int64_t)B * H * 2 * (2 * win + 1) * D; }
+extern "C" int64_t glowtts_rpr_attention_scratch_floats(int B, int Tp, int H, int D, int win) { return (int64_t)B * H * 4 * 2 * (2 * win + 1) * D; }
 
 extern "C" int glowtts_rpr_attention_bwd(const float* qkv, const float* relk, const float* relv, const float* rowmask, const float* P, const float* dout,
                                          float* dS /* [B][H][Tp][Tp] scratch */, float* dqkv, float* drelk, float* drelv, float* scratch,
-                                         int B, int Tp, int H, int D, int win, float drop_p, void* stream)
+                                         int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t* seed_ptr, void* stream)
 {
     if (!qkv || !relk || !relv || !rowmask || !P || !dout || !dS || !dqkv || !drelk || !drelv || !scratch || Tp > 256) return GLOWTTS_E_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t lds = attn_lds_bytes(Tp, D, win, true);
-    if (lds > 160 * 1024) return GLOWTTS_E_ARG;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_bwd_a_kernel, dim3((Tp + ATT_QT - 1) / ATT_QT, H, B), dim3(256), lds, st, qkv, relk, relv, rowmask, P, dout, dS, dqkv, B, Tp, H, D, win, drop_p);
-    hipLaunchKernelGGL(attn_bwd_b_kernel, dim3((Tp + 3) / 4, H, B), dim3(256), 0, st, qkv, P, dS, dout, dqkv, B, Tp, H, D);
     const int nw = 2 * win + 1;
-    hipLaunchKernelGGL(attn_bwd_rel_kernel, dim3(nw, B * H), dim3(128), 0, st, qkv, P, dS, dout, scratch, B, Tp, H, D, win);
-    // partial [B*H][2*nw*D] -> [2*nw*D]: drelK then drelV
-    float* both = scratch + (int64_t)B * H * 2 * nw * D;     // the caller's scratch holds B*H*2*nw*D + 2*nw*D floats
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * nw * D + 3) / 4), dim3(256), 0, st, scratch, both, B * H, 2 * nw * D);
-    hipMemcpyAsync(drelk, both, (size_t)nw * D * sizeof(float), hipMemcpyDeviceToDevice, st);
-    hipMemcpyAsync(drelv, both + nw * D, (size_t)nw * D * sizeof(float), hipMemcpyDeviceToDevice, st);
+    // per-(utterance, head[, wave]) partials of drelK | drelV, summed into `both`; when the caller's drelk / drelv are adjacent
+    // (one [2][nw][D] tensor) the sum is written in place
+    int prow;
+    if (attn_mfma_ok(Tp, D, win)) {
+        const size_t l2 = attn_mfma_lds(D);
+        if (D == 96) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+            hipLaunchKernelGGL(attn_bwd_mfma_kernel<3>, dim3(H, B), dim3(256), l2, st, qkv, relk, relv, rowmask, P, dout, dqkv, scratch, B, Tp, H, win, drop_p, seed, seed_ptr);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+            hipLaunchKernelGGL(attn_bwd_mfma_kernel<2>, dim3(H, B), dim3(256), l2, st, qkv, relk, relv, rowmask, P, dout, dqkv, scratch, B, Tp, H, win, drop_p, seed, seed_ptr);
+        }
+        prow = B * H * 4;
+    } else {
+        const size_t lds = attn_lds_bytes(Tp, D, win, true);
+        if (lds > 160 * 1024) return GLOWTTS_E_ARG;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(attn_bwd_a_kernel, dim3((Tp + ATT_QT - 1) / ATT_QT, H, B), dim3(256), lds, st, qkv, relk, relv, rowmask, P, dout, dS, dqkv, B, Tp, H, D, win, drop_p);
+        hipLaunchKernelGGL(attn_bwd_b_kernel, dim3((Tp + 3) / 4, H, B), dim3(256), 0, st, qkv, P, dS, dout, dqkv, B, Tp, H, D);
+        hipLaunchKernelGGL(attn_bwd_rel_kernel, dim3(nw, B * H), dim3(128), 0, st, qkv, P, dS, dout, scratch, B, Tp, H, D, win);
+        prow = B * H;
+    }
+    const bool adjacent = (drelv == drelk + (size_t)nw * D);
+    float* both = adjacent ? drelk : scratch + glowtts_rpr_attention_scratch_floats(B, Tp, H, D, win);   // else the caller's scratch has 2*nw*D more floats
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * nw * D + 3) / 4), dim3(256), 0, st, scratch, both, prow, 2 * nw * D);
+    if (!adjacent) {
+        if (hipMemcpyAsync(drelk, both, (size_t)nw * D * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return GLOWTTS_E_LAUNCH;
+        if (hipMemcpyAsync(drelv, both + nw * D, (size_t)nw * D * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return GLOWTTS_E_LAUNCH;
+    }
     RET_LAUNCH();
 }

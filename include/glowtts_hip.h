@@ -333,14 +333,17 @@ int glowtts_gate_bwd(const float *dy, const float *out, const float *rowmask, fl
 int glowtts_embedding_fwd(const int64_t *tokens, const float *table, const float *rowmask, float *rows, int B, int T, int C, float scale, void *stream);
 int glowtts_embedding_bwd(const int64_t *tokens, const float *drows, const float *rowmask, float *dtable, int V, int B, int T, int C, float scale, void *stream);
 /* Relative-position multi-head self-attention core (RPR_MHA.py:95-128; window `win`, embeddings shared over heads).
- * qkv rows [B][Tp][3*H*D] (Q | K | V); out rows [B][Tp][H*D]; P [B][H][Tp][Tp] keeps the (dropped) probabilities. Tp <= 256. */
+ * qkv rows [B][Tp][3*H*D] (Q | K | V); out rows [B][Tp][H*D]; P [B][H][Tp][Tp] is kept for the backward (opaque to the caller:
+ * the MFMA path - Tp <= 128, D in {64, 96}, win <= 15 - stores the probabilities before dropout, the general path after). Tp <= 256.
+ * The backward takes the forward's (seed, seed_ptr): it regenerates the dropout keep mask. */
 int glowtts_rpr_attention_fwd(const float *qkv, const float *relk, const float *relv, const float *rowmask, float *out, float *P,
                               int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t *seed_ptr, void *stream);
 int64_t glowtts_rpr_attention_scratch_floats(int B, int Tp, int H, int D, int win);
-/* scratch: glowtts_rpr_attention_scratch_floats(...) + 2*(2*win+1)*D floats; dS: [B][H][Tp][Tp] floats */
+/* scratch: glowtts_rpr_attention_scratch_floats(...) + 2*(2*win+1)*D floats; dS: [B][H][Tp][Tp] floats (general path only);
+ * drelk / drelv [2*win+1][D] each; passing them adjacent (one [2][2*win+1][D] tensor) saves two copies */
 int glowtts_rpr_attention_bwd(const float *qkv, const float *relk, const float *relv, const float *rowmask, const float *P, const float *dout,
                               float *dS, float *dqkv, float *drelk, float *drelv, float *scratch,
-                              int B, int Tp, int H, int D, int win, float drop_p, void *stream);
+                              int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t *seed_ptr, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Alignment expansion and likelihood loss.

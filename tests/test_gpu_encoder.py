@@ -1,0 +1,90 @@
+"""Encoder kernels against plain PyTorch references of the same ops (fp32)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def attention_core_ref(qkv, relk, relv, rowmask, B, Tp, H, win):
+    """RPR_MHA.py:95-128 on fused rows [B*Tp, 3*H*D] (Q | K | V), every row a position, rowmask 0 on padding."""
+    C3 = qkv.shape[1]
+    D = C3 // (3 * H)
+    x = qkv.view(B, Tp, 3, H, D)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))                      # [B,H,Tp,D]
+    scores = q @ k.transpose(2, 3)
+    qr = q @ relk.t()                                                             # [B,H,Tp,2w+1]
+    idx = torch.arange(Tp, device=qkv.device)
+    dmat = idx[None, :] - idx[:, None]
+    band = (dmat.abs() <= win)
+    gather = (dmat.clamp(-win, win) + win)
+    rel = torch.gather(qr, 3, gather.view(1, 1, Tp, Tp).expand(B, H, Tp, Tp)) * band
+    scores = (scores + rel) / math.sqrt(D)
+    m = rowmask.view(B, Tp)
+    scores = scores.masked_fill((m[:, :, None] * m[:, None, :]).unsqueeze(1) == 0, -1e4)
+    pr = torch.softmax(scores, dim=-1)
+    out = pr @ v
+    pb = torch.zeros(B, H, Tp, 2 * win + 1, device=qkv.device, dtype=qkv.dtype)
+    for d in range(-win, win + 1):
+        lo, hi = max(0, -d), min(Tp, Tp - d)
+        ii = torch.arange(lo, hi, device=qkv.device)
+        pb[:, :, ii, d + win] = pr[:, :, ii, ii + d]
+    out = out + pb @ relv
+    return out.transpose(1, 2).reshape(B * Tp, H * D)
+
+
+@pytest.mark.parametrize("T,D", [(120, 96), (57, 96), (100, 64), (150, 96), (40, 16)])
+def test_rpr_attention_core_forward_backward(T, D):
+    """MFMA path (Tp <= 128, D in {64, 96}) and the general path, forward and all four gradients."""
+    from glow_tts_amd.conv_fn import RPRAttention
+    B, H, win = 3, 2, 4
+    Tp = T + 4
+    g = torch.Generator().manual_seed(T + D)
+    lens = torch.tensor([T, T - 9, max(5, T // 3)])
+    rowmask = torch.zeros(B, Tp)
+    for b in range(B):
+        rowmask[b, 2:2 + lens[b]] = 1.0
+    rowmask = rowmask.reshape(-1).cuda()
+    qkv = (torch.randn(B * Tp, 3 * H * D, generator=g) * 0.5).cuda().requires_grad_(True)
+    relk = (torch.randn(1, 2 * win + 1, D, generator=g) * D ** -0.5).cuda().requires_grad_(True)
+    relv = (torch.randn(1, 2 * win + 1, D, generator=g) * D ** -0.5).cuda().requires_grad_(True)
+    dout = torch.randn(B * Tp, H * D, generator=g).cuda() * rowmask[:, None]
+    out = RPRAttention.apply(qkv, relk, relv, rowmask, B, Tp, H, win, 0.0, 0, None)
+    out.backward(dout)
+    got = [out.detach(), qkv.grad.clone(), relk.grad.clone(), relv.grad.clone()]
+    qkv.grad = relk.grad = relv.grad = None
+    ref = attention_core_ref(qkv.double(), relk[0].double(), relv[0].double(), rowmask.double(), B, Tp, H, win)
+    ref.backward(dout.double())
+    want = [ref.detach(), qkv.grad, relk.grad, relv.grad]
+    valid = rowmask[:, None] > 0
+    for name, a, b_ in zip(("out", "dqkv", "drelK", "drelV"), got, want):
+        a, b_ = a.double(), b_.double()
+        if name in ("out", "dqkv"):
+            a, b_ = a * valid, b_ * valid               # padding rows carry no signal in the model
+        err = (a - b_).abs().max().item() / max(1.0, b_.abs().max().item())
+        assert err < 2e-5, (name, err)
+
+
+def test_rpr_attention_dropout_mask_consistency():
+    """p > 0: output changes, same seed reproduces it, and the backward uses the forward's keep mask (linear in V: exact check)."""
+    from glow_tts_amd.conv_fn import RPRAttention
+    B, H, win, T, D = 2, 2, 4, 120, 96
+    Tp = T + 4
+    g = torch.Generator().manual_seed(1)
+    rowmask = torch.zeros(B, Tp); rowmask[:, 2:T + 2] = 1.0
+    rowmask = rowmask.reshape(-1).cuda()
+    qkv = (torch.randn(B * Tp, 3 * H * D, generator=g) * 0.5).cuda().requires_grad_(True)
+    relk = (torch.randn(1, 2 * win + 1, D, generator=g) * 0.1).cuda()
+    relv = (torch.randn(1, 2 * win + 1, D, generator=g) * 0.1).cuda()
+    run = lambda x, p: RPRAttention.apply(x, relk, relv, rowmask, B, Tp, H, win, p, 1234, None)
+    o0, o1, o2 = run(qkv, 0.0), run(qkv, 0.3), run(qkv, 0.3)
+    assert torch.equal(o1, o2) and (o1 - o0).abs().max() > 1e-3 and torch.isfinite(o1).all()
+    # the output is linear in V for a fixed mask: <dout, out(V + dV) - out(V)> == <dV-gradient, dV> exactly (up to rounding)
+    dout = torch.randn(B * Tp, H * D, generator=g).cuda()
+    (o1 * dout).sum().backward()
+    dv = torch.zeros_like(qkv); dv[:, 2 * H * D:] = torch.randn(B * Tp, H * D, generator=g).cuda()
+    with torch.no_grad():
+        delta = ((run(qkv + dv, 0.3) - o1) * dout).sum().item()
+    pred = (qkv.grad * dv).sum().item()
+    assert abs(delta - pred) <= 1e-3 * max(1.0, abs(pred)), (delta, pred)
