@@ -80,6 +80,9 @@ def train_step(model, mle_loss, batch, reducer=None, world=1):
     return mle + length
 
 
+TRAFFIC_BF16_B32 = 21.1e6    # FETCH_SIZE x 2 + WRITE_SIZE of conv_dma_kernel at B = 32 (profiles/r01_conv_pmc.txt)
+
+
 def dominant_kernel_roofline(precision, B, T, iters=30):
     """The WaveNet In_i k=5 conv (Modules.py:861), the kernel that carries most of the FLOPs: timed alone with HIP events
     on the launch stream.  Algorithmic FLOPs per launch = 2 * rows * 384 * 192 * 5."""
@@ -88,12 +91,16 @@ def dominant_kernel_roofline(precision, B, T, iters=30):
     H, k = 192, 5
     R = B * (T + 4)
     prec = ops.BF16 if precision == "bf16" else ops.F32
+    bf = prec == ops.BF16                           # bf16 mode: state and gates are stored as bf16 (what the training step runs)
     a = torch.randn(R, H, device=dev)
     w = torch.randn(2 * H, H, k, device=dev) / (H * k) ** 0.5
     pw = ops.pack_weight(w, perm=ops.PERM_PAIR, perm_h=H, precision=prec)
     bias = torch.zeros(2 * H, device=dev)
-    G = torch.empty(R, 2 * H, device=dev)
-    run = lambda: ops.conv_cl(a, pw, H, R, pad=2, epi=ops.EPI_GATE, h=H, n=2 * H, rows_per_utt=T + 4, bias=bias, out0=G, ld0=2 * H)
+    if bf:
+        a = a.to(torch.bfloat16)
+    G = torch.empty(R, 2 * H, device=dev, dtype=a.dtype)
+    io = (ops.IO_A_BF16 | ops.IO_OUT0_BF16) if bf else 0
+    run = lambda: ops.conv_cl(a, pw, H, R, pad=2, epi=ops.EPI_GATE, h=H, n=2 * H, rows_per_utt=T + 4, bias=bias, out0=G, ld0=2 * H, io_flags=io)
     for _ in range(5):
         run()
     torch.cuda.synchronize()
@@ -107,11 +114,12 @@ def dominant_kernel_roofline(precision, B, T, iters=30):
     flops = 2.0 * B * T * (2 * H) * H * k              # valid rows only
     peak = 2500.0 if precision == "bf16" else 157.3
     ach = flops / sec / 1e12
-    return {"bound": "mfma", "kernel": "conv_cl_kernel<EPI_GATE> (WaveNet In_i k=5, 192->384)", "achieved": round(ach, 1), "peak": peak,
+    name = "conv_dma_kernel<EPI_GATE, 5>" if bf else "conv_cl_kernel<float, EPI_GATE, 5>"
+    return {"bound": "mfma", "kernel": name + " (WaveNet In_i k=5, 192->384)", "achieved": round(ach, 1), "peak": peak,
             "unit": "TFLOP/s", "frac": round(ach / peak, 4), "us_per_launch": round(sec * 1e6, 2),
             # HBM bytes per launch of this kernel at this shape from separate rocprofv3 --pmc passes (FETCH_SIZE x 2 per the gfx950
-            # correction + WRITE_SIZE; profiles/r01_conv_pmc.txt), not re-measured live; algorithmic bytes are 30.6e6
-            "traffic": 36.1e6 if (precision == "bf16" and B == 32 and T == 400) else None}
+            # correction + WRITE_SIZE; profiles/r01_conv_pmc.txt), not re-measured live; algorithmic bytes are 15.6e6
+            "traffic": TRAFFIC_BF16_B32 if (precision == "bf16" and B == 32 and T == 400) else None}
 
 
 def mas_us_per_utt(B, Tx, Ty, iters=30):

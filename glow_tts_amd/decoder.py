@@ -443,11 +443,15 @@ class DecoderFunction(torch.autograd.Function):
                 gk.add(dins[f, l].data_ptr(), prep.ldin, prep.ldin, buf.hs[f, l].data_ptr(), H, H, G["w_in"][f, l].data_ptr(), G["b_in"][f, l].data_ptr(),
                        perm=ops.PERM_PAIR, perm_h=H)
             g1.add(dh[f, 0].data_ptr(), H, H, buf.xmid[f].data_ptr(), C, C2, G["w_start"][f].data_ptr(), G["b_start"][f].data_ptr())
-            # splitting the weight gradients in two halves with the first half on a second stream was measured SLOWER (16.4 vs 13.6 ms/step:
-            # the extra workgroups slow the latency-bound data-gradient chain more than the overlap buys); kept behind an env switch
-            if os.environ.get("GLOWTTS_WGRAD_SPLIT") == "1" and len(order) >= 8 and f == order[len(order) // 2 - 1]:
-                for grp in (gk, g1, gp):
-                    grp.end_segment()  # first half of the flows: launched on a second stream while the second half's chain runs
+            # GLOWTTS_WGRAD_SPLIT=n: weight gradients in n segments, each launched on a second stream as soon as its flows' chain is
+            # done (default 1: one launch per class after the chain; see DESIGN.md for the measurements)
+            nseg = int(os.environ.get("GLOWTTS_WGRAD_SPLIT", "1"))
+            if nseg > 1:
+                per = -(-len(order) // nseg)
+                pos = order.index(f) + 1
+                if pos % per == 0 and pos < len(order):
+                    for grp in (gk, g1, gp):
+                        grp.end_segment()
         # Few, large launches: 216-432 k-tap tiles per launch fill the chip without split-K (per-flow launches of 36 tiles were
         # measured 3x slower in total, even on a second stream).
         for grp in (gk, g1, gp):
@@ -468,15 +472,23 @@ class DecoderFunction(torch.autograd.Function):
             dims = _dims(cfg, B, T, ctx.drop[0], ctx.drop[1], f)
             _lib.check(L.glowtts_flow_backward(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(acts), ctypes.byref(g),
                                                _lib.stream()), "glowtts_flow_backward")
-            if halves == 2 and f == order[len(order) // 2 - 1]:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    for grp in (gk, gp, g1):
-                        grp.launch_segment(0)
-        for grp in (gk, gp, g1):
-            grp.launch_segment(halves - 1)
-        if halves == 2:
+            if halves > 1:
+                per = -(-len(order) // halves)
+                pos = order.index(f) + 1
+                if pos % per == 0 and pos < len(order):
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        for grp in (gk, gp, g1):
+                            grp.launch_segment(pos // per - 1)
+        if halves > 1:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for grp in (gk, gp, g1):
+                    grp.launch_segment(halves - 1)
             main.wait_stream(side)
+        else:
+            for grp in (gk, gp, g1):
+                grp.launch_segment(0)
         # log-determinant terms of the parameters (Modules.py:694, 747): logdet_b += (sum logs + logdet(W) C/4) * len_b
         lens = rowmask.view(B, -1).sum(1)
         s = (dld * lens).sum()
