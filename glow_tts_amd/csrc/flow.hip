@@ -56,18 +56,21 @@ int coupling_net(const Ctx& c, const float* xsrc, float* xdst, bool reverse, boo
         float* hin = keep ? A->hs[l] : A->hs[l & 1];
         float* hout = keep ? (l + 1 < L ? A->hs[l + 1] : nullptr) : A->hs[(l + 1) & 1];
         float* g = keep ? A->gates[l] : A->gates[0];
+        float* acts = bf ? (keep ? A->acts[l] : A->acts[0]) : nullptr;
         {   // In_l (k taps) + conditioning + tanh*sigmoid                       Modules.py:861-870
             glowtts_conv_args a = base_args(c, p->in[l], c.d->ksize);
             a.a = hin; a.lda = H; a.ca = H; a.n = 2 * H; a.h = H;
             a.epi = GLOWTTS_EPI_GATE; a.bias = p->b_in[l]; a.drop_p = c.d->drop_p; a.seed = c.d->seed + (uint32_t)l; a.seed_ptr = c.d->seed_ptr;
             if (p->cond) { a.cond = p->cond + (int64_t)l * 2 * H; a.ldcond = p->ldcond; }
             a.out0 = g; a.ld0 = 2 * H; a.io_flags = bf ? (GLOWTTS_IO_A_BF16 | GLOWTTS_IO_OUT0_BF16) : 0;
+            if (acts) { a.out1 = acts; a.ld1 = H; }              // bf16 tanh * sigmoid for the Res_Skip conv below
             CHECK(glowtts_conv_cl(&a, c.s));
         }
         {   // Res_Skip_l on acts = tanh*sigmoid                                 Modules.py:871-881
             const bool last = (l == L - 1);
             glowtts_conv_args a = base_args(c, p->rs[l], 1);
-            a.a = g; a.lda = 2 * H; a.ca = H; a.apro = GLOWTTS_APRO_PAIRMUL;
+            if (acts) { a.a = acts; a.lda = H; a.ca = H; }                                          // plain bf16 operand: LDS-DMA kernel
+            else      { a.a = g; a.lda = 2 * H; a.ca = H; a.apro = GLOWTTS_APRO_PAIRMUL; }
             a.n = last ? H : 2 * H; a.h = H;
             a.epi = GLOWTTS_EPI_RESSKIP; a.flags = (l == 0 ? GLOWTTS_F_FIRST : 0) | (last ? GLOWTTS_F_LAST : 0);
             a.bias = p->b_rs[l];
@@ -143,6 +146,7 @@ extern "C" int glowtts_flow_forward(const glowtts_flow_dims* d, const glowtts_fl
 {
     CHECK(check_dims(d));
     if (!p || !a || !a->xin || !a->xmid || !a->xout || !a->rowmask || !a->skip || !a->outs) return GLOWTTS_E_ARG;
+    if (d->act_bf16) for (int l = 0; l < d->L; ++l) if (!a->acts[l]) return GLOWTTS_E_ARG;
     const Ctx c = make_ctx(d, p, a, stream);
     // ActNorm + invertible 1x1                                                 Modules.py:693-694, 738-756
     CHECK(glowtts_actnorm_inv1x1(a->xin, a->xmid, p->an_logs, p->an_bias, p->winfo, a->rowmask, c.R, d->C, 0, stream));
@@ -155,6 +159,7 @@ extern "C" int glowtts_flow_inverse(const glowtts_flow_dims* d, const glowtts_fl
 {
     CHECK(check_dims(d));
     if (!p || !a || !a->xin || !a->xmid || !a->xout || !a->rowmask || !a->skip || !a->hs[0] || !a->hs[1] || !a->gates[0]) return GLOWTTS_E_ARG;
+    if (d->act_bf16 && !a->acts[0]) return GLOWTTS_E_ARG;
     const Ctx c = make_ctx(d, p, a, stream);
     // reversed layer order (Modules.py:664): coupling^-1, then inv-1x1^-1, then ActNorm^-1
     CHECK(copy_half(a->xout, a->xmid, c.R, d->C, c.C2, stream));
@@ -211,15 +216,18 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
         }
         if (wg) {   // Res_Skip weight gradient: rows [0,H) <- d res, rows [H,2H) <- d skip (last layer: only H rows <- d skip)
             if (last) {
-                glowtts_wgrad_args w = wargs(g->dskip, H, H, a->gates[l], 2 * H, H, 1, g->dw_rs[l], g->db_rs[l]);
-                w.xpro = GLOWTTS_APRO_PAIRMUL; w.io_flags = bf ? GLOWTTS_WIO_X_BF16 : 0;
+                glowtts_wgrad_args w = bf ? wargs(g->dskip, H, H, a->acts[l], H, H, 1, g->dw_rs[l], g->db_rs[l])
+                                          : wargs(g->dskip, H, H, a->gates[l], 2 * H, H, 1, g->dw_rs[l], g->db_rs[l]);
+                w.xpro = bf ? GLOWTTS_APRO_NONE : GLOWTTS_APRO_PAIRMUL; w.io_flags = bf ? GLOWTTS_WIO_X_BF16 : 0;
                 CHECK(glowtts_wgrad_cl(&w, stream));
             } else {
-                glowtts_wgrad_args w = wargs(dnext, H, H, a->gates[l], 2 * H, H, 1, g->dw_rs[l], g->db_rs[l]);
-                w.xpro = GLOWTTS_APRO_PAIRMUL; w.io_flags = bf ? GLOWTTS_WIO_X_BF16 : 0;
+                glowtts_wgrad_args w = bf ? wargs(dnext, H, H, a->acts[l], H, H, 1, g->dw_rs[l], g->db_rs[l])
+                                          : wargs(dnext, H, H, a->gates[l], 2 * H, H, 1, g->dw_rs[l], g->db_rs[l]);
+                w.xpro = bf ? GLOWTTS_APRO_NONE : GLOWTTS_APRO_PAIRMUL; w.io_flags = bf ? GLOWTTS_WIO_X_BF16 : 0;
                 CHECK(glowtts_wgrad_cl(&w, stream));
-                glowtts_wgrad_args w2 = wargs(g->dskip, H, H, a->gates[l], 2 * H, H, 1, g->dw_rs[l] + (int64_t)H * H, g->db_rs[l] + H);
-                w2.xpro = GLOWTTS_APRO_PAIRMUL; w2.io_flags = bf ? GLOWTTS_WIO_X_BF16 : 0;
+                glowtts_wgrad_args w2 = bf ? wargs(g->dskip, H, H, a->acts[l], H, H, 1, g->dw_rs[l] + (int64_t)H * H, g->db_rs[l] + H)
+                                           : wargs(g->dskip, H, H, a->gates[l], 2 * H, H, 1, g->dw_rs[l] + (int64_t)H * H, g->db_rs[l] + H);
+                w2.xpro = bf ? GLOWTTS_APRO_NONE : GLOWTTS_APRO_PAIRMUL; w2.io_flags = bf ? GLOWTTS_WIO_X_BF16 : 0;
                 CHECK(glowtts_wgrad_cl(&w2, stream));
             }
         }

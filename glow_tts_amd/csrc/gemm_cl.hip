@@ -334,6 +334,10 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
         static_assert(NI % 2 == 0, "pair epilogues need NI even");
         const uint32_t esz = out0_bf ? 2 : 4;
         const Rsrc ro = mk(p.out0, (long)p.rows * p.ld0 * esz);
+        // optional second output (bf16 storage only): acts = tanh * sigmoid as plain bf16 rows [rows][ld1], the A operand of the
+        // Res_Skip conv and the X operand of its weight gradient (both then need no prologue).  No out1: zero-sized descriptor,
+        // the stores are dropped by the bounds check.
+        const Rsrc ra = mk(p.out1, p.out1 ? (long)p.rows * p.ld1 * 2 : 0);
         const int Tp = p.rows_per_utt > 0 ? p.rows_per_utt : 1;
         const int nutt = p.rows / Tp;
         const Rsrc rc = mk(p.cond, (long)nutt * p.ldcond * 4);
@@ -342,7 +346,7 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
         const float ik = drop_inv_keep(thr);
         const int u0 = m0 / Tp, rnext = (u0 + 1) * Tp;
         const bool two = m0 + BM <= rnext + Tp;               // the tile touches at most two utterances: their cond rows are kept in registers
-        uint32_t vo[NI / 2], jkey[NI / 2], vc[NI / 2];
+        uint32_t vo[NI / 2], jkey[NI / 2], vc[NI / 2], va[NI / 2];
         float b0[NI / 2], b1[NI / 2];                                   // bias of the (tanh, sigmoid) channel
         float ca0[NI / 2], ca1[NI / 2], cb0[NI / 2], cb1[NI / 2];       // conditioning of utterance u0 / u0 + 1
         float sa0[NI / 2], sa1[NI / 2], sb0[NI / 2], sb1[NI / 2];       // bias + conditioning
@@ -352,6 +356,7 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
             const bool ok = j < p.h;
             vo[pi] = ok ? (uint32_t)(rb * (int)p.ld0 + 2 * j) * esz : OOB;
             vc[pi] = ok ? (uint32_t)j * 4u : OOB;
+            va[pi] = ok ? (uint32_t)(rb * (int)p.ld1 + j) * 2u : OOB;
             jkey[pi] = drop_colkey((uint32_t)j);
             b0[pi] = ok ? p.bias[j] : 0.f;
             b1[pi] = ok ? p.bias[p.h + j] : 0.f;
@@ -400,7 +405,7 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
                         if (abl & 8) g = make_float2(x0, x1);
                         if (abl & 4) { if (g.x == 12345.678f) p.out0[0] = 1.f; continue; }
 #endif
-                        if constexpr (OBF) st32(pack_bf16x2(g.x, g.y), ro, vo[pi], ro_ * (int)p.ld0 * 2);
+                        if constexpr (OBF) { st32(pack_bf16x2(g.x, g.y), ro, vo[pi], ro_ * (int)p.ld0 * 2); sth(g.x * g.y, ra, va[pi], ro_ * (int)p.ld1 * 2); }
                         else {
                             u32x2 w; w[0] = __float_as_uint(g.x); w[1] = __float_as_uint(g.y);
                             __builtin_amdgcn_raw_buffer_store_b64(w, ro, vo[pi], ro_ * (int)p.ld0 * 4, 0);
@@ -806,19 +811,25 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
 // bounds check) and of the first / last utterance's outermost pad rows, which every consumer masks.
 // ------------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(1024))) unsigned char dma_smem[];
+constexpr int DMA1_CPS = 2;             // 1x1 convs: K chunks per pipeline stage
 
 template <int EPI, int TAPS>
 __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args pin)
 {
     typedef __bf16 CT;
     constexpr int NI = 2, BN = 64, KC = 32;
+    // A stage holds SUB sub-steps.  Multi-tap: one K chunk = one A tile (with its TAPS - 1 halo rows) shared by the TAPS weight
+    // tiles.  1x1 (TAPS == 1): DMA1_CPS consecutive K chunks, each with its own A tile and weight tile.
+    constexpr bool T1 = (TAPS == 1);
+    constexpr int SUB = T1 ? DMA1_CPS : TAPS;
+    constexpr int NAT = T1 ? DMA1_CPS : 1;
     glowtts_conv_args p = pin;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // scalar: unit indices, LDS bases and branches below are wave-uniform
     const int WMR = blockDim.x >> 6, BM = WMR * 32;
-    const int AU = (BM + TAPS - 1 + 15) >> 4;                 // 16-row (1 KiB) DMA units of the A tile
-    constexpr int WU = TAPS * 4;                              // 16-column units of the TAPS weight tiles of one K chunk
-    const int A_BYTES = AU * 1024, STAGE = A_BYTES + WU * 1024;
+    const int AU = (BM + TAPS - 1 + 15) >> 4;                 // 16-row (1 KiB) DMA units of one A tile
+    constexpr int WU = SUB * 4;                               // 16-column units of the SUB weight tiles
+    const int A_BYTES = NAT * AU * 1024, STAGE = A_BYTES + WU * 1024;
     int m_tile, n_tile;
     {   // XCD-aware tile order (see conv_cl_kernel)
         const int gy = p.npad / BN;
@@ -829,8 +840,10 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
     }
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     const int KCH = p.kchunks;
-    const int rot = (int)((m_tile * 5 + n_tile * 3) % KCH);
-    auto ssmap = [&](int ss) __attribute__((always_inline)) { int v = ss + rot; return v >= KCH ? v - KCH : v; };
+    const int NSS = T1 ? KCH / DMA1_CPS : KCH;                // stages (host: KCH % DMA1_CPS == 0 on the 1x1 path)
+    const int NSS1 = (T1 && p.a2) ? (p.ca1 / KC) / DMA1_CPS : NSS;      // stages that read the first A source (dual-source 1x1)
+    const int rot = (T1 && p.a2) ? 0 : (int)((m_tile * 5 + n_tile * 3) % NSS);
+    auto ssmap = [&](int ss) __attribute__((always_inline)) { int v = ss + rot; return v >= NSS ? v - NSS : v; };
     constexpr int pad = (TAPS - 1) / 2;
     const int l31 = lane & 31, lhi = lane >> 5;
 #ifdef GLOWTTS_TIMELINE
@@ -847,60 +860,67 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
 
     // lane -> (row or column inside a 16-unit, logical 16-byte slot): LDS position `lane` of a unit holds slot q of row lane >> 2
     const int lrow = lane >> 2, qa = (lane & 3) ^ ((lane >> 4) & 3);
-    // DMA units of this wave: u = wave + i * WMR.  Their chunk-0 source addresses are computed once; a K chunk is a uniform
-    // byte step (64 B along an A row, one [npad][64 B] slab of the packed weights).
-    constexpr int MAXU = 8;                                   // >= ceil((AU + WU) / WMR) for every WMR >= 4
-    const int nun = AU + WU;
-    uint32_t uoff[MAXU];                                      // 32-bit byte offsets from p.a / p.w (host-checked < 2^31)
+    // DMA units of this wave: u = wave + i * WMR.  Their stage-0 source offsets are computed once; a stage is a uniform byte step
+    // (SUB-or-1 x 64 B along an A row, SUB-or-1 [npad][64 B] slabs of the packed weights).
+    constexpr int MAXU = 8;                                   // >= ceil(units / WMR) for every WMR >= 4
+    const int nau = NAT * AU, nun = nau + WU;
+    uint32_t uoff[MAXU];                                      // 32-bit byte offsets from p.a (p.a2) / p.w (host-checked < 2^31)
 #pragma unroll
     for (int i = 0; i < MAXU; ++i) {
         const int u = wave + i * WMR;                         // wave-uniform (wave comes from readfirstlane)
-        if (u < AU) {
-            int g = m0 - pad + u * 16 + lrow;
+        if (u < nau) {
+            const int ja = T1 ? u / AU : 0, ur = u - ja * AU;
+            int g = m0 - pad + ur * 16 + lrow;
             g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
-            uoff[i] = (uint32_t)g * (uint32_t)(p.lda * 2) + (uint32_t)(qa * 16);
+            uoff[i] = (uint32_t)g * (uint32_t)(p.lda * 2) + (uint32_t)(qa * 16 + ja * (KC * 2));
         } else {
-            const int w = u - AU, t = w >> 2, cg = w & 3;
-            uoff[i] = (uint32_t)((t * KCH) * p.npad + n0 + cg * 16 + lrow) * 64u + (uint32_t)(qa * 16);
+            const int w = u - nau, t = w >> 2, cg = w & 3;    // t: tap (multi-tap) or chunk inside the stage (1x1)
+            uoff[i] = (uint32_t)((T1 ? t : t * KCH) * p.npad + n0 + cg * 16 + lrow) * 64u + (uint32_t)(qa * 16);
         }
     }
-    const int nmine = (nun - wave + WMR - 1) / WMR;           // DMA instructions this wave issues per K chunk
+    const int nmine = (nun - wave + WMR - 1) / WMR;           // DMA instructions this wave issues per stage
     const unsigned char* const abase = reinterpret_cast<const unsigned char*>(p.a);
+    const unsigned char* const a2base = reinterpret_cast<const unsigned char*>(p.a2);
     const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(p.w);
-    const uint32_t wkstep = (uint32_t)p.npad * 64u;
-    auto issue_unit = [&](auto I_, int buf, int kc) __attribute__((always_inline)) {
+    const uint32_t wkstep = (uint32_t)p.npad * 64u * (T1 ? DMA1_CPS : 1);
+    constexpr uint32_t akstep = KC * 2 * (T1 ? DMA1_CPS : 1);
+    auto issue_unit = [&](auto I_, int buf, int st) __attribute__((always_inline)) {
         constexpr int i = decltype(I_)::value;
         if constexpr (i < MAXU) {
             const int u = wave + i * WMR;
             if (u < nun) {
-                const unsigned char* src = (u < AU) ? abase + (uoff[i] + (uint32_t)kc * (KC * 2)) : wbase + (uoff[i] + (uint32_t)kc * wkstep);
+                const unsigned char* src;
+                if (u >= nau)       src = wbase + (uoff[i] + (uint32_t)st * wkstep);
+                else if (st < NSS1) src = abase + (uoff[i] + (uint32_t)st * akstep);
+                else                src = a2base + (uoff[i] + (uint32_t)(st - NSS1) * akstep);
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                                  (void __attribute__((address_space(3)))*)(dma_smem + buf * STAGE + u * 1024), 16, 0, 0);
             }
         }
     };
-    // MFMAs of K chunk `buf`; when `nbuf >= 0` the DMAs of the next chunk are issued between the taps (two units per tap), so
-    // that their issue cost hides under the matrix pipe instead of serialising after the barrier
-    // Fragment reads run one tap ahead of the MFMAs in a second register set (a wave's next MFMA otherwise waits a full LDS
+    // MFMAs of stage `buf`; when `nbuf >= 0` the DMAs of a later stage are issued between the sub-steps, so that their issue cost
+    // hides under the matrix pipe instead of serialising after the barrier.
+    // Fragment reads run one sub-step ahead of the MFMAs in a second register set (a wave's next MFMA otherwise waits a full LDS
     // round trip: measured 3000 instead of 1920 clk per chunk at 3 waves per SIMD).
     Chunk16 fa[2][2], fb[2][2][NI];                           // [set][k half][fragment]
-    auto compute = [&](int buf, int nbuf, int nkc) __attribute__((always_inline)) {
+    auto compute = [&](int buf, int nbuf, int nst) __attribute__((always_inline)) {
         const unsigned char* Ab = dma_smem + buf * STAGE;
         const unsigned char* Wb = Ab + A_BYTES;
         auto load_frags = [&](auto T_) __attribute__((always_inline)) {
             constexpr int t = decltype(T_)::value, set = t & 1;
+            const unsigned char* At = T1 ? Ab + t * (AU * 1024) : Ab;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int q = 2 * s2 + lhi;
-                fa[set][s2] = *reinterpret_cast<const Chunk16*>(Ab + swz(wave * 32 + l31 + t, q));
+                fa[set][s2] = *reinterpret_cast<const Chunk16*>(At + swz(wave * 32 + l31 + (T1 ? 0 : t), q));
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) fb[set][s2][ni] = *reinterpret_cast<const Chunk16*>(Wb + t * 4096 + swz(ni * 32 + l31, q));
             }
         };
         load_frags(IC<0>{});
-        StaticFor<TAPS>::run([&](auto T_) __attribute__((always_inline)) {
+        StaticFor<SUB>::run([&](auto T_) __attribute__((always_inline)) {
             constexpr int t = decltype(T_)::value, set = t & 1;
-            if constexpr (t + 1 < TAPS) load_frags(IC<t + 1>{});
+            if constexpr (t + 1 < SUB) load_frags(IC<t + 1>{});
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -908,15 +928,15 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
                     acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&fa[set][s2]),
                                                                         *reinterpret_cast<const bf16x8*>(&fb[set][s2][ni]), acc[0][ni], 0, 0, 0);
             if (nbuf >= 0) {
-                constexpr int PER = (MAXU + TAPS - 1) / TAPS;
-                StaticFor<PER>::run([&](auto J_) __attribute__((always_inline)) { issue_unit(IC<t * PER + decltype(J_)::value>{}, nbuf, nkc); });
+                constexpr int PER = (MAXU + SUB - 1) / SUB;
+                StaticFor<PER>::run([&](auto J_) __attribute__((always_inline)) { issue_unit(IC<t * PER + decltype(J_)::value>{}, nbuf, nst); });
             }
         });
     };
 
     const int abl = p.flags >> 16;
-    // Three LDS stages, chunks ss+1 and ss+2 in flight while chunk ss is multiplied.  s_waitcnt takes an immediate, the number of
-    // DMAs a wave has outstanding per chunk (nmine) is uniform but only known at run time: dispatch once per wait.
+    // Three LDS stages, stages ss+1 and ss+2 in flight while stage ss is multiplied.  s_waitcnt takes an immediate, the number of
+    // DMAs a wave has outstanding per stage (nmine) is uniform but only known at run time: dispatch once per wait.
     auto wait_keep = [&](int keep) __attribute__((always_inline)) {        // wait until at most `keep` of this wave's DMAs are outstanding, then barrier
         switch (keep) {
             case 0:  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
@@ -931,15 +951,15 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
         }
     };
     StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 0, ssmap(0)); });
-    if (KCH > 1) StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 1, ssmap(1)); });
+    if (NSS > 1) StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 1, ssmap(1)); });
     TL(1);
-    int cur = 0;                                              // stage of chunk ss (ss % 3)
-    for (int ss = 0; ss < KCH; ++ss) {
-        // this wave's DMAs of chunk ss have landed (those of chunk ss+1 may still fly); after the barrier so have everyone's,
-        // and every wave is done reading the stage of chunk ss-1, which is refilled with chunk ss+2 during the MFMAs below
-        wait_keep(ss + 1 < KCH ? nmine : 0);
+    int cur = 0;                                              // LDS stage of pipeline stage ss (ss % 3)
+    for (int ss = 0; ss < NSS; ++ss) {
+        // this wave's DMAs of stage ss have landed (those of stage ss+1 may still fly); after the barrier so have everyone's,
+        // and every wave is done reading the LDS stage of ss-1, which is refilled with stage ss+2 during the MFMAs below
+        wait_keep(ss + 1 < NSS ? nmine : 0);
         TL(3 + 3 * ss);
-        const bool more = ss + 2 < KCH;
+        const bool more = ss + 2 < NSS;
         const int nxt = cur == 0 ? 2 : cur - 1;               // (ss + 2) % 3
         if (!(abl & 2)) compute(cur, more ? nxt : -1, more ? ssmap(ss + 2) : 0);
         TL(5 + 3 * ss);
@@ -965,8 +985,12 @@ int num_cus()
 bool dma_ok(const glowtts_conv_args& a)
 {
     static const bool enabled = [] { const char* e = getenv("GLOWTTS_DMA"); return !(e && e[0] == '0'); }();
-    return enabled && a.precision == GLOWTTS_BF16 && (a.io_flags & GLOWTTS_IO_A_BF16) && a.apro == GLOWTTS_APRO_NONE && !a.a2 &&
-           a.taps > 1 && a.batch <= 1 && a.kchunks * 32 == a.ca && (a.npad % 64) == 0 && a.rows >= 128;
+    if (!(enabled && a.precision == GLOWTTS_BF16 && (a.io_flags & GLOWTTS_IO_A_BF16) && a.apro == GLOWTTS_APRO_NONE &&
+          a.batch <= 1 && a.kchunks * 32 == a.ca && (a.npad % 64) == 0 && a.rows >= 128)) return false;
+    if (a.taps > 1) return !a.a2;
+    // 1x1: whole stages of DMA1_CPS chunks; a second source must start on a stage boundary and share the row stride
+    if (a.kchunks % DMA1_CPS) return false;
+    return !a.a2 || ((a.ca1 % (32 * DMA1_CPS)) == 0 && a.lda2 == a.lda);
 }
 
 template <int EPI, int TAPS>
@@ -976,14 +1000,16 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
     static const int force = [] { const char* e = getenv("GLOWTTS_DMA_WAVES"); return e ? atoi(e) : 0; }();
     const int gy = a.npad / 64, ncu = num_cus(), frags = (a.rows + 31) / 32;
     int best = 4; long best_cost = -1;
-    for (int w = 4; w <= 16; ++w) {
+    constexpr int WMAX = TAPS == 1 ? 10 : 16;             // three LDS stages must fit 160 KiB
+    for (int w = 4; w <= WMAX; ++w) {
         const long tiles = (long)((frags + w - 1) / w) * gy;
         const long cost = ((tiles + ncu - 1) / ncu) * (w + 4);      // rounds x (strip work + fixed prologue / epilogue share)
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = w; }
     }
-    if (force >= 1 && force <= 16) best = force;
+    if (force >= 4 && force <= WMAX) best = force;
     const int BM = best * 32;
-    const int lds = 3 * ((((BM + TAPS - 1 + 15) >> 4) + TAPS * 4) * 1024);     // three stages: <= 159 KiB at 16 waves, 5 taps
+    const int nat = TAPS == 1 ? DMA1_CPS : 1, sub = TAPS == 1 ? DMA1_CPS : TAPS;
+    const int lds = 3 * ((nat * ((BM + TAPS - 1 + 15) >> 4) + sub * 4) * 1024);     // three stages: <= 159 KiB (16 waves x 5 taps, 10 waves 1x1)
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<EPI, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -1054,11 +1080,16 @@ int launch_prec(const glowtts_conv_args& a, hipStream_t s)
             if (a.epi == GLOWTTS_EPI_LINEAR && a.taps == 5) return launch_dma<GLOWTTS_EPI_LINEAR, 5>(a, s);
             if (a.epi == GLOWTTS_EPI_GATE && a.taps == 3) return launch_dma<GLOWTTS_EPI_GATE, 3>(a, s);
             if (a.epi == GLOWTTS_EPI_LINEAR && a.taps == 3) return launch_dma<GLOWTTS_EPI_LINEAR, 3>(a, s);
+            if (a.epi == GLOWTTS_EPI_RESSKIP && a.taps == 1) return launch_dma<GLOWTTS_EPI_RESSKIP, 1>(a, s);
+            if (a.epi == GLOWTTS_EPI_DGATE && a.taps == 1) return launch_dma<GLOWTTS_EPI_DGATE, 1>(a, s);
+            if (a.epi == GLOWTTS_EPI_LINEAR && a.taps == 1) return launch_dma<GLOWTTS_EPI_LINEAR, 1>(a, s);
         }
         if (a.io_flags & GLOWTTS_IO_A_BF16) {      // bf16-stored A operand: the WaveNet state / gates / gate gradients
             if (a.epi == GLOWTTS_EPI_GATE && a.apro == N) return launch_taps<CT, GLOWTTS_EPI_GATE, GLOWTTS_APRO_NONE, true>(a, s);
             if (a.epi == GLOWTTS_EPI_LINEAR && a.apro == N) return launch_taps<CT, GLOWTTS_EPI_LINEAR, GLOWTTS_APRO_NONE, true>(a, s);
             if (a.epi == GLOWTTS_EPI_RESSKIP && a.apro == PM && a.taps == 1) return launch_tile<CT, GLOWTTS_EPI_RESSKIP, 1, GLOWTTS_APRO_PAIRMUL, true>(a, s);
+            if (a.epi == GLOWTTS_EPI_RESSKIP && a.apro == N && a.taps == 1) return launch_tile<CT, GLOWTTS_EPI_RESSKIP, 1, GLOWTTS_APRO_NONE, true>(a, s);
+            if (a.epi == GLOWTTS_EPI_DGATE && a.apro == N && a.taps == 1) return launch_tile<CT, GLOWTTS_EPI_DGATE, 1, GLOWTTS_APRO_NONE, true>(a, s);
             return GLOWTTS_E_ARG;
         }
     } else if (a.io_flags) return GLOWTTS_E_ARG;   // fp32 precision keeps every activation in fp32

@@ -40,7 +40,7 @@ class FlowParams(ctypes.Structure):
 class FlowActs(ctypes.Structure):
     _fields_ = [("xin", c_void_p), ("xmid", c_void_p), ("xout", c_void_p),
                 ("hs", c_void_p * MAXL), ("gates", c_void_p * MAXL), ("skip", c_void_p), ("outs", c_void_p),
-                ("rowmask", c_void_p)]
+                ("rowmask", c_void_p), ("acts", c_void_p * MAXL)]
 
 
 class FlowGrads(ctypes.Structure):
@@ -286,6 +286,7 @@ class _Buffers:
         self.xmid = torch.empty(F_, R, C, device=dev)
         self.hs = torch.empty(F_, L, R, H, device=dev, dtype=cfg.act_dtype)
         self.gates = torch.empty(F_, L, R, 2 * H, device=dev, dtype=cfg.act_dtype)
+        self.actp = torch.empty(F_, L, R, H, device=dev, dtype=torch.bfloat16) if cfg.act_bf16 else None     # tanh * sigmoid
         self.skip = torch.empty(F_, R, H, device=dev)
         self.outs = torch.empty(F_, R, prep.ldo, device=dev)
 
@@ -295,6 +296,8 @@ class _Buffers:
         for l in range(L):
             a.hs[l] = self.hs[f, l].data_ptr()
             a.gates[l] = self.gates[f, l].data_ptr()
+            if self.actp is not None:
+                a.acts[l] = self.actp[f, l].data_ptr()
         a.skip, a.outs, a.rowmask = self.skip[f].data_ptr(), self.outs[f].data_ptr(), rowmask.data_ptr()
         return a
 
@@ -332,6 +335,7 @@ def decoder_inverse(cfg, W, z, lengths, cond=None, fill=None):
     xmid = torch.empty_like(x)
     hs = torch.empty(2, R, cfg.H, device=dev, dtype=cfg.act_dtype)
     gates = torch.empty(R, 2 * cfg.H, device=dev, dtype=cfg.act_dtype)
+    actp = torch.empty(R, cfg.H, device=dev, dtype=torch.bfloat16) if cfg.act_bf16 else None
     skip = torch.empty(R, cfg.H, device=dev)
     dims = _dims(cfg, B, T)
     cur, nxt = x, other
@@ -340,6 +344,8 @@ def decoder_inverse(cfg, W, z, lengths, cond=None, fill=None):
         a.xout, a.xmid, a.xin = cur.data_ptr(), xmid.data_ptr(), nxt.data_ptr()
         a.hs[0], a.hs[1] = hs[0].data_ptr(), hs[1].data_ptr()
         a.gates[0], a.skip, a.rowmask = gates.data_ptr(), skip.data_ptr(), rowmask.data_ptr()
+        if actp is not None:
+            a.acts[0] = actp.data_ptr()
         a.outs = None
         _lib.check(L.glowtts_flow_inverse(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(a), _lib.stream()),
                    "glowtts_flow_inverse")
@@ -364,6 +370,7 @@ def actnorm_data_init(cfg, W, mels, lengths, cond=None, allreduce=None):
         xmid = torch.empty_like(x)
         hs = torch.empty(cfg.L, R, cfg.H, device=dev, dtype=cfg.act_dtype)
         gates = torch.empty(cfg.L, R, 2 * cfg.H, device=dev, dtype=cfg.act_dtype)
+        actp = torch.empty(cfg.L, R, cfg.H, device=dev, dtype=torch.bfloat16) if cfg.act_bf16 else None
         skip = torch.empty(R, cfg.H, device=dev)
         for f in range(cfg.F):
             _lib.check(L.glowtts_actnorm_stats(_lib.ptr(bufs[0]), _lib.ptr(rowmask), _lib.ptr(stats), _lib.ptr(scratch), R, cfg.C,
@@ -378,6 +385,8 @@ def actnorm_data_init(cfg, W, mels, lengths, cond=None, allreduce=None):
             a.xin, a.xmid, a.xout = bufs[0].data_ptr(), xmid.data_ptr(), bufs[1].data_ptr()
             for l in range(cfg.L):
                 a.hs[l], a.gates[l] = hs[l].data_ptr(), gates[l].data_ptr()
+                if actp is not None:
+                    a.acts[l] = actp[l].data_ptr()
             a.skip, a.outs, a.rowmask = skip.data_ptr(), outs.data_ptr(), rowmask.data_ptr()
             _lib.check(L.glowtts_flow_forward(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(a), _lib.stream()),
                        "glowtts_flow_forward(init)")
@@ -427,19 +436,20 @@ class DecoderFunction(torch.autograd.Function):
         bf = cfg.act_bf16
         gk = WgradGroup(R, cfg.k, cfg.precision, io_flags=(ops.WIO_DY_BF16 | ops.WIO_X_BF16) if bf else 0)     # In_l (k taps)
         g1 = WgradGroup(R, 1, cfg.precision)                            # Start / End (1x1)
-        gp = WgradGroup(R, 1, cfg.precision, ops.APRO_PAIRMUL, io_flags=ops.WIO_X_BF16 if bf else 0)          # Res_Skip_l (1x1 on tanh*sigmoid)
+        # Res_Skip_l (1x1 on tanh*sigmoid): the stored bf16 product, or the fp32 (tanh, sigmoid) pairs through the PAIRMUL prologue
+        gp = WgradGroup(R, 1, cfg.precision, ops.APRO_NONE if bf else ops.APRO_PAIRMUL, io_flags=ops.WIO_X_BF16 if bf else 0)
         C2 = C // 2
         order = list(range(F_ - 1, -1, -1))
         for f in order:       # weight-gradient problems of every flow (autograd of Modules.py:791,861,871,793): all pointers are known up front
             g1.add(douts[f].data_ptr(), prep.ldo, prep.ldo, buf.skip[f].data_ptr(), H, H, G["w_end"][f].data_ptr(), G["b_end"][f].data_ptr(),
                    perm=ops.PERM_PAIR, perm_h=C2)
             for l in range(Lw):
-                gates = buf.gates[f, l].data_ptr()
+                gates, ldg = (buf.actp[f, l].data_ptr(), H) if bf else (buf.gates[f, l].data_ptr(), 2 * H)
                 if l == Lw - 1:
-                    gp.add(dskip[f].data_ptr(), H, H, gates, 2 * H, H, G["w_rs_last"][f].data_ptr(), G["b_rs_last"][f].data_ptr())
+                    gp.add(dskip[f].data_ptr(), H, H, gates, ldg, H, G["w_rs_last"][f].data_ptr(), G["b_rs_last"][f].data_ptr())
                 else:
-                    gp.add(dh[f, l + 1].data_ptr(), H, H, gates, 2 * H, H, G["w_rs"][f, l].data_ptr(), G["b_rs"][f, l].data_ptr())
-                    gp.add(dskip[f].data_ptr(), H, H, gates, 2 * H, H, G["w_rs"][f, l].data_ptr() + 4 * H * H, G["b_rs"][f, l].data_ptr() + 4 * H)
+                    gp.add(dh[f, l + 1].data_ptr(), H, H, gates, ldg, H, G["w_rs"][f, l].data_ptr(), G["b_rs"][f, l].data_ptr())
+                    gp.add(dskip[f].data_ptr(), H, H, gates, ldg, H, G["w_rs"][f, l].data_ptr() + 4 * H * H, G["b_rs"][f, l].data_ptr() + 4 * H)
                 gk.add(dins[f, l].data_ptr(), prep.ldin, prep.ldin, buf.hs[f, l].data_ptr(), H, H, G["w_in"][f, l].data_ptr(), G["b_in"][f, l].data_ptr(),
                        perm=ops.PERM_PAIR, perm_h=H)
             g1.add(dh[f, 0].data_ptr(), H, H, buf.xmid[f].data_ptr(), C, C2, G["w_start"][f].data_ptr(), G["b_start"][f].data_ptr())

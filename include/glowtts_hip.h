@@ -216,7 +216,7 @@ typedef struct glowtts_wgrad_args {
     float *dw;                         /* [O][ca][taps] */
     float *dbias;                      /* [O] or NULL */
     int io_flags;                      /* GLOWTTS_WIO_*: dy / x hold bf16 elements (bf16 precision only; strides count elements).
-                                        * Supported: DY|X with no prologue, X alone with PAIRMUL. */
+                                        * Supported: DY|X with no prologue, X alone with or without PAIRMUL. */
 } glowtts_wgrad_args;
 #define GLOWTTS_WIO_DY_BF16 1
 #define GLOWTTS_WIO_X_BF16  2
@@ -283,6 +283,7 @@ typedef struct glowtts_flow_acts {        /* rows tensors, R = B*(T+2*PAD) rows 
     float *skip;                          /* [R][H]  sum of skip outputs * mask                  (kept) */
     float *outs;                          /* [R][ldo] PAIR-packed (m, logs), ldo = end.npad      (kept) */
     const float *rowmask;                 /* [R] */
+    float *acts[GLOWTTS_MAX_WN_LAYERS];   /* act_bf16 only (else NULL): [R][H] bf16 tanh * sigmoid of layer l                (kept) */
 } glowtts_flow_acts;
 
 typedef struct glowtts_flow_grads {       /* backward outputs; weight grads are ADDED (zero them first) */
