@@ -20,30 +20,40 @@ __global__ __launch_bounds__(256) void expand_fwd_kernel(const float* __restrict
     for (int y = blockIdx.x * 256 + threadIdx.x; y < Ty; y += gridDim.x * 256) { const int x = ib[y]; o[y] = x >= 0 ? s[x] : 0.f; }
 }
 // dsrc[b][c][x] = sum_{y : idx[b][y] == x} dout[b][c][y].  idx is non-decreasing over the valid frames, so the frames of token x are
-// the contiguous range [first[x], first[x+1]); one thread per (b, c, x), `first` from a per-utterance scan kept in LDS.
+// the contiguous range [first[x], next[x]); `first` / `next` come from a per-utterance scan kept in LDS.  One wavefront per (b, c) row:
+// the row is staged into LDS with coalesced loads, then every lane sums the segments of its tokens (fixed order: deterministic).
 __global__ __launch_bounds__(256) void expand_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ idx, float* __restrict__ dsrc,
                                                          int C, int Tx, int Ty)
 {
-    extern __shared__ int first[];                       // [Tx + 1]
-    const int b = blockIdx.y;
+    extern __shared__ int sm_i[];
+    int* first = sm_i;                                   // [Tx]  first frame of token x, -1 if it has none
+    int* cnt = sm_i + Tx;                                // [Tx]  number of frames of token x
+    float* rowbuf = reinterpret_cast<float*>(sm_i + 2 * Tx);      // [4 waves][Ty]
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t* ib = idx + (long)b * Ty;
-    for (int x = threadIdx.x; x <= Tx; x += 256) first[x] = -1;
+    for (int x = threadIdx.x; x < Tx; x += 256) { first[x] = -1; cnt[x] = 0; }
     __syncthreads();
     for (int y = threadIdx.x; y < Ty; y += 256) {
         const int x = ib[y];
         if (x >= 0 && (y == 0 || ib[y - 1] != x)) first[x] = y;
-        if (x >= 0 && (y == Ty - 1 || ib[y + 1] < 0)) first[Tx] = y + 1;      // one past the last valid frame (written once)
+        if (x >= 0 && (y == Ty - 1 || ib[y + 1] != x)) cnt[x] = y + 1;        // one past the last frame of x (turned into a count below)
     }
     __syncthreads();
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < C * Tx; i += gridDim.x * 256) {
-        const int c = i / Tx, x = i - c * Tx;
-        float acc = 0.f;
-        const int y0 = first[x];
-        if (y0 >= 0) {
-            const float* d = dout + ((long)b * C + c) * Ty;
-            for (int y = y0; y < Ty && ib[y] == x; ++y) acc += d[y];
+    for (int x = threadIdx.x; x < Tx; x += 256) cnt[x] = first[x] >= 0 ? cnt[x] - first[x] : 0;
+    __syncthreads();
+    float* rb = rowbuf + wave * Ty;
+    for (int c = blockIdx.x * 4 + wave; c < C; c += gridDim.x * 4) {
+        const float* d = dout + ((long)b * C + c) * Ty;
+        for (int y = lane; y < Ty; y += 64) rb[y] = d[y];
+        // (same wave reads below: LDS accesses of one wave complete in order)
+        __builtin_amdgcn_wave_barrier();
+        for (int x = lane; x < Tx; x += 64) {
+            float acc = 0.f;
+            const int y0 = first[x], n = cnt[x];
+            for (int k = 0; k < n; ++k) acc += rb[y0 + k];
+            dsrc[((long)b * C + c) * Tx + x] = acc;
         }
-        dsrc[((long)b * C + c) * Tx + x] = acc;
+        __builtin_amdgcn_wave_barrier();
     }
 }
 // target[b][x] = log(count_x + 1e-7) * (x < t_x[b])
@@ -117,8 +127,10 @@ extern "C" int glowtts_expand_fwd(const float* src, const int32_t* idx, float* o
 extern "C" int glowtts_expand_bwd(const float* dout, const int32_t* idx, float* dsrc, int B, int C, int Tx, int Ty, void* stream)
 {
     if (!dout || !idx || !dsrc || B < 1 || C < 1 || Tx < 1 || Ty < 1) return GLOWTTS_E_ARG;
-    const int gx = (C * Tx + 255) / 256 > 64 ? 64 : (C * Tx + 255) / 256;
-    hipLaunchKernelGGL(expand_bwd_kernel, dim3(gx, B), dim3(256), (Tx + 1) * sizeof(int), static_cast<hipStream_t>(stream), dout, idx, dsrc, C, Tx, Ty);
+    const int gx = (C + 15) / 16;                               // 4 rows per workgroup pass, ~4 passes
+    const size_t lds = (size_t)2 * Tx * sizeof(int) + (size_t)4 * Ty * sizeof(float);
+    if (lds > 64 * 1024) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(expand_bwd_kernel, dim3(gx, B), dim3(256), lds, static_cast<hipStream_t>(stream), dout, idx, dsrc, C, Tx, Ty);
     RET_LAUNCH();
 }
 extern "C" int glowtts_duration_targets(const int32_t* idx, const int64_t* token_lengths, float* out, int B, int Tx, int Ty, void* stream)

@@ -88,3 +88,25 @@ def test_rpr_attention_dropout_mask_consistency():
         delta = ((run(qkv + dv, 0.3) - o1) * dout).sum().item()
     pred = (qkv.grad * dv).sum().item()
     assert abs(delta - pred) <= 1e-3 * max(1.0, abs(pred)), (delta, pred)
+
+
+def test_expand_prior_forward_backward():
+    """ExpandPrior (Modules.py:120-121: mean @ attn with a one-hot monotonic attn) and its gradient (segment sums)."""
+    from glow_tts_amd.alignment import ExpandPrior
+    g = torch.Generator().manual_seed(4)
+    B, C, Tx, Ty = 3, 80, 37, 211
+    idx = torch.full((B, Ty), -1, dtype=torch.int32)
+    for b, (tx, ty) in enumerate([(37, 211), (20, 150), (5, 5)]):
+        cuts = torch.sort(torch.randperm(ty - 1, generator=g)[:tx - 1] + 1).values if tx > 1 else torch.zeros(0, dtype=torch.long)
+        bounds = torch.cat([torch.zeros(1, dtype=torch.long), cuts, torch.tensor([ty])])
+        for x in range(tx):
+            idx[b, bounds[x]:bounds[x + 1]] = x
+    src = torch.randn(B, C, Tx, generator=g).cuda().requires_grad_(True)
+    dout = torch.randn(B, C, Ty, generator=g).cuda()
+    out = ExpandPrior.apply(src, idx.cuda())
+    out.backward(dout)
+    onehot = (idx.unsqueeze(1) == torch.arange(Tx).view(1, Tx, 1)).float().cuda()           # [B, Tx, Ty]
+    want = src.detach() @ onehot
+    assert torch.equal(out.detach(), want)
+    want_g = dout.double() @ onehot.double().transpose(1, 2)
+    assert (src.grad.double() - want_g).abs().max() <= 1e-5 * want_g.abs().max()
