@@ -149,9 +149,8 @@ extern "C" int glowtts_flow_forward(const glowtts_flow_dims* d, const glowtts_fl
     if (d->act_bf16) for (int l = 0; l < d->L; ++l) if (!a->acts[l]) return GLOWTTS_E_ARG;
     const Ctx c = make_ctx(d, p, a, stream);
     // ActNorm + invertible 1x1                                                 Modules.py:693-694, 738-756
-    CHECK(glowtts_actnorm_inv1x1(a->xin, a->xmid, p->an_logs, p->an_bias, p->winfo, a->rowmask, c.R, d->C, 0, stream));
-    // x_a passes through                                                      Modules.py:808
-    CHECK(copy_half(a->xmid, a->xout, c.R, d->C, c.C2, stream));
+    // (x_a passes through, Modules.py:808: written to xout by the same kernel)
+    CHECK(glowtts_actnorm_inv1x1_pass(a->xin, a->xmid, a->xout, p->an_logs, p->an_bias, p->winfo, a->rowmask, c.R, d->C, stream));
     return coupling_net(c, a->xmid, a->xout, false, true);
 }
 
@@ -171,7 +170,7 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
                                      const glowtts_flow_grads* g, void* stream)
 {
     CHECK(check_dims(d));
-    if (!p || !a || !g || !g->dx || !g->dlogdet || !g->douts || !g->dskip || !g->dh[0] || !g->dins[0] || !g->scratch || !g->d_an) return GLOWTTS_E_ARG;
+    if (!p || !a || !g || !g->dx || !g->dlogdet || !g->douts || !g->dskip || !g->dh[0] || !g->dins[0] || !g->scratch) return GLOWTTS_E_ARG;
     const Ctx c = make_ctx(d, p, a, stream);
     const int H = c.H, L = d->L, C = d->C, C2 = c.C2, R = c.R;
     const int ldo = p->end.npad;          // PAIR-packed (m, logs) width

@@ -108,8 +108,10 @@ template <bool REVERSE>
 __global__ __launch_bounds__(256) void actnorm_inv_kernel(const float* __restrict__ xin, float* __restrict__ xout,
                                                           const float* __restrict__ logs, const float* __restrict__ bias,
                                                           const float* __restrict__ winfo, const float* __restrict__ rowmask,
-                                                          long rows, int C)
+                                                          long rows, int C, float* __restrict__ xpass)
 {
+    // xpass (forward only, may be null): the first C/2 output channels are also written there - the coupling layer passes x_a
+    // through unchanged (Modules.py:808), so the flow's output buffer gets its first half without a separate copy kernel
     const int G = C / 4, C2 = C / 2;
     const long total = rows * G;
     const float* Wm = winfo + (REVERSE ? 16 : 0);
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(256) void actnorm_inv_kernel(const float* __restric
         }
         *reinterpret_cast<float2*>(xout + r * C + 2 * g) = make_float2(o[0], o[1]);
         *reinterpret_cast<float2*>(xout + r * C + C2 + 2 * g) = make_float2(o[2], o[3]);
+        if (!REVERSE && xpass) *reinterpret_cast<float2*>(xpass + r * C + 2 * g) = make_float2(o[0], o[1]);
     }
 }
 
@@ -159,9 +162,11 @@ __global__ __launch_bounds__(256) void colstats_partial_kernel(const float* __re
     }
     if (threadIdx.x == 0) { float sm = 0.f; for (long r = r0; r < r1; ++r) sm += rowmask[r]; out[2 * C] = sm; }
 }
-__global__ __launch_bounds__(256) void colstats_final_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nblk, int n)
+__global__ __launch_bounds__(256) void colstats_final_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nblk, int n,
+                                                             long part_stride = 0, long out_stride = 0)
 {
-    // one wavefront per output: lanes stride over the partial rows, fixed-order shuffle tree (deterministic)
+    // one wavefront per output: lanes stride over the partial rows, fixed-order shuffle tree (deterministic); blockIdx.y = problem
+    partial += (long)blockIdx.y * part_stride; stats += (long)blockIdx.y * out_stride;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= n) return;
@@ -378,8 +383,17 @@ extern "C" int glowtts_actnorm_inv1x1(const float* xin, float* xout, const float
     if (!xin || !xout || !logs || !bias || !winfo || !rowmask || rows < 1 || C < 4 || (C & 3)) return GLOWTTS_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = grid_for(rows * (C / 4));
-    if (reverse) hipLaunchKernelGGL(actnorm_inv_kernel<true>, dim3(grid), dim3(256), 0, s, xin, xout, logs, bias, winfo, rowmask, (long)rows, C);
-    else         hipLaunchKernelGGL(actnorm_inv_kernel<false>, dim3(grid), dim3(256), 0, s, xin, xout, logs, bias, winfo, rowmask, (long)rows, C);
+    if (reverse) hipLaunchKernelGGL(actnorm_inv_kernel<true>, dim3(grid), dim3(256), 0, s, xin, xout, logs, bias, winfo, rowmask, (long)rows, C, (float*)nullptr);
+    else         hipLaunchKernelGGL(actnorm_inv_kernel<false>, dim3(grid), dim3(256), 0, s, xin, xout, logs, bias, winfo, rowmask, (long)rows, C, (float*)nullptr);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_actnorm_inv1x1_pass(const float* xin, float* xout, float* xpass, const float* logs, const float* bias, const float* winfo,
+                                           const float* rowmask, int64_t rows, int C, void* stream)
+{
+    if (!xin || !xout || !xpass || !logs || !bias || !winfo || !rowmask || rows < 1 || C < 4 || (C & 3)) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(actnorm_inv_kernel<false>, dim3(grid_for(rows * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       xin, xout, logs, bias, winfo, rowmask, (long)rows, C, xpass == xout ? (float*)nullptr : xpass);
     RET_LAUNCH();
 }
 
@@ -392,7 +406,7 @@ extern "C" int glowtts_actnorm_stats(const float* x, const float* rowmask, float
     const int nblk = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(colstats_partial_kernel, dim3(nblk), dim3(256), 0, s, x, rowmask, scratch, (long)rows, C, rpb);
     const int n = 2 * C + 1;
-    hipLaunchKernelGGL(colstats_final_kernel, dim3((n + 3) / 4), dim3(256), 0, s, scratch, stats, nblk, n);
+    hipLaunchKernelGGL(colstats_final_kernel, dim3((n + 3) / 4), dim3(256), 0, s, scratch, stats, nblk, n, 0L, 0L);
     RET_LAUNCH();
 }
 
@@ -426,14 +440,23 @@ extern "C" int glowtts_actnorm_inv1x1_bwd(const float* dz, float* dx, const floa
                                           const float* winfo, const float* rowmask, float* param_grads /* [2C+16]: dlogs, dbias, dW */,
                                           float* scratch, int64_t rows, int C, void* stream)
 {
-    if (!dz || !dx || !x || !logs || !bias || !winfo || !rowmask || !param_grads || !scratch || rows < 1 || C < 4 || (C & 3) || C / 4 > 256) return GLOWTTS_E_ARG;
+    if (!dz || !dx || !x || !logs || !bias || !winfo || !rowmask || !scratch || rows < 1 || C < 4 || (C & 3) || C / 4 > 256) return GLOWTTS_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int rpb = 64;
     const int nblk = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(actnorm_inv_bwd_kernel, dim3(nblk), dim3(256), 24 * 256 * sizeof(float), s, dz, dx, x, logs, bias, winfo, rowmask,
                        scratch, (long)rows, C, rpb);
     const int n = 2 * C + 16;
-    hipLaunchKernelGGL(colstats_final_kernel, dim3((n + 3) / 4), dim3(256), 0, s, scratch, param_grads, nblk, n);
+    // param_grads == NULL: the caller reduces the per-block partials of all its flows later with glowtts_colsum_batched
+    if (param_grads) hipLaunchKernelGGL(colstats_final_kernel, dim3((n + 3) / 4), dim3(256), 0, s, scratch, param_grads, nblk, n, 0L, 0L);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_colsum_batched(const float* partial, float* out, int nrows, int n, int batch, int64_t part_stride, int64_t out_stride, void* stream)
+{
+    if (!partial || !out || nrows < 1 || n < 1 || batch < 1) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(colstats_final_kernel, dim3((n + 3) / 4, batch), dim3(256), 0, static_cast<hipStream_t>(stream), partial, out, nrows, n,
+                       (long)part_stride, (long)out_stride);
     RET_LAUNCH();
 }
 

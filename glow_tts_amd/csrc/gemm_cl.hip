@@ -814,7 +814,7 @@ extern __shared__ __attribute__((aligned(1024))) unsigned char dma_smem[];
 constexpr int DMA1_CPS = 2;             // 1x1 convs: K chunks per pipeline stage
 
 template <int EPI, int TAPS>
-__global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args pin)
+__global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args pin, const int nst /* LDS stages: 2 or 3 */)
 {
     typedef __bf16 CT;
     constexpr int NI = 2, BN = 64, KC = 32;
@@ -950,20 +950,23 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
             default: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
         }
     };
+    // nst LDS stages: stage ss+1 .. ss+nst-1 are in flight while stage ss is multiplied (nst = 3: two ahead; nst = 2: one ahead, two
+    // thirds of the LDS, so that a second workgroup - of another kernel on another stream - can be co-resident on the CU)
+    const int ahead = nst - 1;
     StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 0, ssmap(0)); });
-    if (NSS > 1) StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 1, ssmap(1)); });
+    if (ahead > 1 && NSS > 1) StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 1, ssmap(1)); });
     TL(1);
-    int cur = 0;                                              // LDS stage of pipeline stage ss (ss % 3)
+    int cur = 0;                                              // LDS stage of pipeline stage ss (ss % nst)
     for (int ss = 0; ss < NSS; ++ss) {
-        // this wave's DMAs of stage ss have landed (those of stage ss+1 may still fly); after the barrier so have everyone's,
-        // and every wave is done reading the LDS stage of ss-1, which is refilled with stage ss+2 during the MFMAs below
-        wait_keep(ss + 1 < NSS ? nmine : 0);
+        // this wave's DMAs of stage ss have landed (those of later stages may still fly); after the barrier so have everyone's,
+        // and every wave is done reading the LDS stage of ss-1, which is refilled with stage ss+ahead during the MFMAs below
+        wait_keep((ahead > 1 && ss + 1 < NSS) ? nmine : 0);
         TL(3 + 3 * ss);
-        const bool more = ss + 2 < NSS;
-        const int nxt = cur == 0 ? 2 : cur - 1;               // (ss + 2) % 3
-        if (!(abl & 2)) compute(cur, more ? nxt : -1, more ? ssmap(ss + 2) : 0);
+        const bool more = ss + ahead < NSS;
+        const int nxt = cur == 0 ? nst - 1 : cur - 1;         // (ss + ahead) % nst
+        if (!(abl & 2)) compute(cur, more ? nxt : -1, more ? ssmap(ss + ahead) : 0);
         TL(5 + 3 * ss);
-        cur = cur == 2 ? 0 : cur + 1;
+        cur = cur == nst - 1 ? 0 : cur + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef GLOWTTS_TIMELINE
@@ -1009,7 +1012,8 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
     if (force >= 4 && force <= WMAX) best = force;
     const int BM = best * 32;
     const int nat = TAPS == 1 ? DMA1_CPS : 1, sub = TAPS == 1 ? DMA1_CPS : TAPS;
-    const int lds = 3 * ((nat * ((BM + TAPS - 1 + 15) >> 4) + sub * 4) * 1024);     // three stages: <= 159 KiB (16 waves x 5 taps, 10 waves 1x1)
+    static const int nst = [] { const char* e = getenv("GLOWTTS_DMA_STAGES"); const int v = e ? atoi(e) : 3; return v == 2 ? 2 : 3; }();
+    const int lds = nst * ((nat * ((BM + TAPS - 1 + 15) >> 4) + sub * 4) * 1024);     // three stages: <= 159 KiB (16 waves x 5 taps, 10 waves 1x1)
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<EPI, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -1017,7 +1021,7 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
         attr_done = true;
     }
     dim3 grid(((a.rows + BM - 1) / BM) * gy);
-    hipLaunchKernelGGL((conv_dma_kernel<EPI, TAPS>), grid, dim3(best * 64), lds, s, a);
+    hipLaunchKernelGGL((conv_dma_kernel<EPI, TAPS>), grid, dim3(best * 64), lds, s, a, nst);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 

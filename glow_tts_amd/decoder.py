@@ -74,6 +74,7 @@ def _L():
         L.glowtts_flow_backward.argtypes = [c_void_p] * 5
         L.glowtts_wgrad_grouped.argtypes = [c_void_p] + [c_int] * 9 + [c_void_p]
         L.glowtts_wgrad_grouped_io.argtypes = [c_void_p] + [c_int] * 10 + [c_void_p]
+        L.glowtts_colsum_batched.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_i64, c_i64, c_void_p]
         L.glowtts_weightnorm_fwd.argtypes = [c_void_p] * 4 + [c_i64, c_int, c_void_p]
         L.glowtts_weightnorm_bwd.argtypes = [c_void_p] * 6 + [c_i64, c_int, c_void_p]
         L.glowtts_decoder_logdet.argtypes = [c_void_p, c_i64] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]
@@ -431,7 +432,8 @@ class DecoderFunction(torch.autograd.Function):
         dins = (torch.empty if prep.ldin == 2 * H else torch.zeros)(F_, Lw, R, prep.ldin, device=dev, dtype=cfg.act_dtype)    # only pad columns need zeros
         dskip = torch.empty(F_, R, H, device=dev)
         dh = torch.empty(F_, Lw, R, H, device=dev)
-        scratch = torch.empty(L.glowtts_actnorm_stats_scratch_floats(R, C), device=dev)
+        nscr = L.glowtts_actnorm_stats_scratch_floats(R, C)
+        scratch = torch.empty(F_, nscr, device=dev)          # per-flow partials of the ActNorm / 1x1 parameter gradients, reduced once below
         dcond = torch.zeros_like(prep.cond) if prep.cond is not None else None
         bf = cfg.act_bf16
         gk = WgradGroup(R, cfg.k, cfg.precision, io_flags=(ops.WIO_DY_BF16 | ops.WIO_X_BF16) if bf else 0)     # In_l (k taps)
@@ -473,7 +475,7 @@ class DecoderFunction(torch.autograd.Function):
         for f in order:
             g = FlowGrads()
             g.dx, g.dlogdet, g.douts, g.dskip = dx.data_ptr(), dld.data_ptr(), douts[f].data_ptr(), dskip[f].data_ptr()
-            g.scratch, g.d_an, g.defer_wgrad = scratch.data_ptr(), d_an[f].data_ptr(), 1
+            g.scratch, g.d_an, g.defer_wgrad = scratch[f].data_ptr(), None, 1
             for l in range(Lw):
                 g.dh[l], g.dins[l] = dh[f, l].data_ptr(), dins[f, l].data_ptr()
             if dcond is not None:
@@ -499,6 +501,8 @@ class DecoderFunction(torch.autograd.Function):
         else:
             for grp in (gk, gp, g1):
                 grp.launch_segment(0)
+        _lib.check(L.glowtts_colsum_batched(scratch.data_ptr(), d_an.data_ptr(), (R + 63) // 64, 2 * C + 16, F_, nscr, 2 * C + 16, _lib.stream()),
+                   "glowtts_colsum_batched")
         # log-determinant terms of the parameters (Modules.py:694, 747): logdet_b += (sum logs + logdet(W) C/4) * len_b
         lens = rowmask.view(B, -1).sum(1)
         s = (dld * lens).sum()

@@ -173,6 +173,9 @@ int glowtts_inv1x1_prepare(const float *W, float *winfo, int F, void *stream);
  * reverse = 0: xout = W (bias + exp(logs) xin) ; reverse = 1: xout = (W^-1 xin - bias) exp(-logs).  In-place allowed. */
 int glowtts_actnorm_inv1x1(const float *xin, float *xout, const float *logs, const float *bias,
                            const float *winfo, const float *rowmask, int64_t rows, int C, int reverse, void *stream);
+/* forward form that also writes the first C/2 output channels to xpass (the coupling layer's pass-through half, Modules.py:808) */
+int glowtts_actnorm_inv1x1_pass(const float *xin, float *xout, float *xpass, const float *logs, const float *bias, const float *winfo,
+                                const float *rowmask, int64_t rows, int C, void *stream);
 /* ActNorm data-dependent init statistics (Modules.py:698-703): stats [2C+1] = { sum x*m [C], sum x^2*m [C], sum m }.
  * Deterministic two-stage reduction; scratch holds glowtts_actnorm_stats_scratch_floats(rows, C) floats.
  * Under data parallelism the caller all-reduces `stats` before glowtts_actnorm_from_stats. */
@@ -192,6 +195,9 @@ int glowtts_fill_zero(float *p, int64_t n, void *stream);
 int glowtts_actnorm_inv1x1_bwd(const float *dz, float *dx, const float *x, const float *logs, const float *bias,
                                const float *winfo, const float *rowmask, float *param_grads, float *scratch,
                                int64_t rows, int C, void *stream);
+/* out[b][i] = sum_r partial[b][r][i], i < n, r < nrows (deterministic): reduces the per-block partials of several
+ * glowtts_actnorm_inv1x1_bwd calls made with param_grads = NULL (their `scratch` buffers, part_stride floats apart) in one launch */
+int glowtts_colsum_batched(const float *partial, float *out, int nrows, int n, int batch, int64_t part_stride, int64_t out_stride, void *stream);
 /* Decoder log-determinant (Modules.py:309): logdet[b] = sum_f [ (sum logs_f + logdet W_f * C/4) * len_b + sum logs^coupling ].
  * outs_all: the F kept (m, logs) buffers, flow_stride floats apart; part [F*B] scratch. */
 int glowtts_decoder_logdet(const float *outs_all, int64_t flow_stride, const float *logs_all, const float *winfo_all,
@@ -297,7 +303,8 @@ typedef struct glowtts_flow_grads {       /* backward outputs; weight grads are 
                                              may all alias unless defer_wgrad */
     int defer_wgrad;                      /* 1: skip every weight-gradient launch (the caller runs glowtts_wgrad_grouped later) */
     float *scratch;                       /* glowtts_actnorm_stats_scratch_floats(R, C) floats */
-    float *d_an;                          /* [2C+16] = dlogs, dbias, dW(inv-1x1) data terms (overwritten) */
+    float *d_an;                          /* [2C+16] = dlogs, dbias, dW(inv-1x1) data terms (overwritten); NULL: left as per-block partials
+                                           * in `scratch` ([ceil(R/64)][2C+16]) for one glowtts_colsum_batched over all flows */
     float *dw_start, *db_start;           /* [H][C/2][1], [H] */
     float *dw_in[GLOWTTS_MAX_WN_LAYERS], *db_in[GLOWTTS_MAX_WN_LAYERS];   /* [2H][H][k], [2H] */
     float *dw_rs[GLOWTTS_MAX_WN_LAYERS], *db_rs[GLOWTTS_MAX_WN_LAYERS];   /* [2H|H][H][1], [2H|H] */
