@@ -182,6 +182,7 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
         return w;
     };
     const bool bf = d->act_bf16 != 0;         // gates / hs / dins stored as bf16
+    const bool bfg = bf;                      // ... and so are dskip and dh[l >= 1] (dh[0] stays fp32: it feeds the fp32 Start conv gradients)
 
     // 1. affine coupling backward                                               autograd of Modules.py:805-806
     CHECK(glowtts_coupling_bwd(g->dx, a->xmid, a->outs, g->douts, a->rowmask, g->dlogdet, R, C, ldo, c.Tp, stream));
@@ -189,7 +190,7 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
     {
         glowtts_conv_args q = base_args(c, p->end_t, 1);
         q.a = g->douts; q.lda = ldo; q.ca = ldo; q.n = H; q.epi = GLOWTTS_EPI_LINEAR; q.flags = GLOWTTS_F_MASK;
-        q.out0 = g->dskip; q.ld0 = H;
+        q.out0 = g->dskip; q.ld0 = H; q.io_flags = bfg ? GLOWTTS_IO_OUT0_BF16 : 0;
         CHECK(glowtts_conv_cl(&q, stream));
         if (!g->defer_wgrad) {
             glowtts_wgrad_args w = wargs(g->douts, ldo, ldo, a->skip, H, H, 1, g->dw_end, g->db_end);
@@ -210,23 +211,23 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
             else      { q.a = dnext; q.lda = H; q.ca1 = H; q.a2 = g->dskip; q.lda2 = H; q.ca = 2 * H; }
             q.n = H; q.epi = GLOWTTS_EPI_DGATE; q.in0 = a->gates[l]; q.ldi0 = 2 * H; q.out0 = dins; q.ld0 = ldin;
             q.drop_p = d->drop_p; q.seed = d->seed + (uint32_t)l; q.seed_ptr = d->seed_ptr;
-            q.io_flags = bf ? (GLOWTTS_IO_IN0_BF16 | GLOWTTS_IO_OUT0_BF16) : 0;
+            q.io_flags = bf ? (GLOWTTS_IO_IN0_BF16 | GLOWTTS_IO_OUT0_BF16 | (bfg ? GLOWTTS_IO_A_BF16 : 0)) : 0;
             CHECK(glowtts_conv_cl(&q, stream));
         }
         if (wg) {   // Res_Skip weight gradient: rows [0,H) <- d res, rows [H,2H) <- d skip (last layer: only H rows <- d skip)
             if (last) {
                 glowtts_wgrad_args w = bf ? wargs(g->dskip, H, H, a->acts[l], H, H, 1, g->dw_rs[l], g->db_rs[l])
                                           : wargs(g->dskip, H, H, a->gates[l], 2 * H, H, 1, g->dw_rs[l], g->db_rs[l]);
-                w.xpro = bf ? GLOWTTS_APRO_NONE : GLOWTTS_APRO_PAIRMUL; w.io_flags = bf ? GLOWTTS_WIO_X_BF16 : 0;
+                w.xpro = bf ? GLOWTTS_APRO_NONE : GLOWTTS_APRO_PAIRMUL; w.io_flags = bf ? (GLOWTTS_WIO_X_BF16 | (bfg ? GLOWTTS_WIO_DY_BF16 : 0)) : 0;
                 CHECK(glowtts_wgrad_cl(&w, stream));
             } else {
                 glowtts_wgrad_args w = bf ? wargs(dnext, H, H, a->acts[l], H, H, 1, g->dw_rs[l], g->db_rs[l])
                                           : wargs(dnext, H, H, a->gates[l], 2 * H, H, 1, g->dw_rs[l], g->db_rs[l]);
-                w.xpro = bf ? GLOWTTS_APRO_NONE : GLOWTTS_APRO_PAIRMUL; w.io_flags = bf ? GLOWTTS_WIO_X_BF16 : 0;
+                w.xpro = bf ? GLOWTTS_APRO_NONE : GLOWTTS_APRO_PAIRMUL; w.io_flags = bf ? (GLOWTTS_WIO_X_BF16 | (bfg ? GLOWTTS_WIO_DY_BF16 : 0)) : 0;
                 CHECK(glowtts_wgrad_cl(&w, stream));
                 glowtts_wgrad_args w2 = bf ? wargs(g->dskip, H, H, a->acts[l], H, H, 1, g->dw_rs[l] + (int64_t)H * H, g->db_rs[l] + H)
                                            : wargs(g->dskip, H, H, a->gates[l], 2 * H, H, 1, g->dw_rs[l] + (int64_t)H * H, g->db_rs[l] + H);
-                w2.xpro = bf ? GLOWTTS_APRO_NONE : GLOWTTS_APRO_PAIRMUL; w2.io_flags = bf ? GLOWTTS_WIO_X_BF16 : 0;
+                w2.xpro = bf ? GLOWTTS_APRO_NONE : GLOWTTS_APRO_PAIRMUL; w2.io_flags = bf ? (GLOWTTS_WIO_X_BF16 | (bfg ? GLOWTTS_WIO_DY_BF16 : 0)) : 0;
                 CHECK(glowtts_wgrad_cl(&w2, stream));
             }
         }
@@ -234,7 +235,8 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
             glowtts_conv_args q = base_args(c, p->in_t[l], d->ksize);
             q.a = dins; q.lda = ldin; q.ca = ldin; q.n = H; q.epi = GLOWTTS_EPI_LINEAR;
             q.flags = GLOWTTS_F_MASK | (last ? 0 : GLOWTTS_F_ADD_IN0);
-            q.in0 = last ? nullptr : dnext; q.ldi0 = H; q.out0 = dthis; q.ld0 = H; q.io_flags = bf ? GLOWTTS_IO_A_BF16 : 0;
+            q.in0 = last ? nullptr : dnext; q.ldi0 = H; q.out0 = dthis; q.ld0 = H;
+            q.io_flags = bf ? (GLOWTTS_IO_A_BF16 | (bfg && !last ? GLOWTTS_IO_IN0_BF16 : 0) | (bfg && l > 0 ? GLOWTTS_IO_OUT0_BF16 : 0)) : 0;
             CHECK(glowtts_conv_cl(&q, stream));
         }
         if (wg) {   // In_l weight gradient

@@ -184,7 +184,8 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
 
     if constexpr (EPI == GLOWTTS_EPI_LINEAR) {
         const uint32_t esz = out0_bf ? 2 : 4;
-        const Rsrc ro = mk(p.out0, (long)p.rows * p.ld0 * esz), ri = mk(p.in0, (long)p.rows * p.ldi0 * 4);
+        const uint32_t eiz = in0_bf ? 2 : 4;
+        const Rsrc ro = mk(p.out0, (long)p.rows * p.ld0 * esz), ri = mk(p.in0, (long)p.rows * p.ldi0 * eiz);
         const int ncv = (fl & GLOWTTS_F_COLMASK) ? p.ncols_valid[blockIdx.z] : 0x7FFFFFFF;
         uint32_t vo[NI], vi[NI], idn[NI]; float bs[NI]; bool cz[NI];
 #pragma unroll
@@ -192,7 +193,7 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
             const int n = n0 + (wn * NI + ni) * 32 + l31;
             const bool ok = n < p.n;
             vo[ni] = ok ? (uint32_t)(rb * (int)p.ld0 + n) * esz : OOB;
-            vi[ni] = ok ? (uint32_t)(rb * (int)p.ldi0 + n) * 4u : OOB;
+            vi[ni] = ok ? (uint32_t)(rb * (int)p.ldi0 + n) * eiz : OOB;
             bs[ni] = ((fl & GLOWTTS_F_BIAS) && ok) ? p.bias[n] : 0.f;
             cz[ni] = n >= ncv;
             idn[ni] = (uint32_t)rb * (uint32_t)p.n + (uint32_t)n;
@@ -217,10 +218,17 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
                     for (int q = 0; q < 8; ++q) mk8[q] = ldf(rmk, (uint32_t)rb * 4u, roff(mi, hb * 8 + q) * 4);
                 }
                 if (fl & GLOWTTS_F_ADD_IN0) {
+                    if (in0_bf) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q)
+                        for (int q = 0; q < 8; ++q)
 #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) xin[q][ni] = ldf(ri, vi[ni], roff(mi, hb * 8 + q) * (int)p.ldi0 * 4);
+                            for (int ni = 0; ni < NI; ++ni) xin[q][ni] = ldh(ri, vi[ni], roff(mi, hb * 8 + q) * (int)p.ldi0 * 2);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni) xin[q][ni] = ldf(ri, vi[ni], roff(mi, hb * 8 + q) * (int)p.ldi0 * 4);
+                    }
                 }
                 if (fl & GLOWTTS_F_ACCUM) {
 #pragma unroll

@@ -430,8 +430,10 @@ class DecoderFunction(torch.autograd.Function):
         # two grouped launches (k-tap problems, 1x1 problems) whose tiles fill the chip without split-K or atomics
         douts = torch.zeros(F_, R, prep.ldo, device=dev)
         dins = (torch.empty if prep.ldin == 2 * H else torch.zeros)(F_, Lw, R, prep.ldin, device=dev, dtype=cfg.act_dtype)    # only pad columns need zeros
-        dskip = torch.empty(F_, R, H, device=dev)
-        dh = torch.empty(F_, Lw, R, H, device=dev)
+        dskip = torch.empty(F_, R, H, device=dev, dtype=cfg.act_dtype)
+        dh0 = torch.empty(F_, R, H, device=dev)                                       # d h0: fp32 (feeds the fp32 Start conv gradients)
+        dhn = torch.empty(F_, max(Lw - 1, 1), R, H, device=dev, dtype=cfg.act_dtype)       # d x_l, l >= 1
+        dh_ptr = lambda f, l: dh0[f].data_ptr() if l == 0 else dhn[f, l - 1].data_ptr()
         nscr = L.glowtts_actnorm_stats_scratch_floats(R, C)
         scratch = torch.empty(F_, nscr, device=dev)          # per-flow partials of the ActNorm / 1x1 parameter gradients, reduced once below
         dcond = torch.zeros_like(prep.cond) if prep.cond is not None else None
@@ -439,7 +441,7 @@ class DecoderFunction(torch.autograd.Function):
         gk = WgradGroup(R, cfg.k, cfg.precision, io_flags=(ops.WIO_DY_BF16 | ops.WIO_X_BF16) if bf else 0)     # In_l (k taps)
         g1 = WgradGroup(R, 1, cfg.precision)                            # Start / End (1x1)
         # Res_Skip_l (1x1 on tanh*sigmoid): the stored bf16 product, or the fp32 (tanh, sigmoid) pairs through the PAIRMUL prologue
-        gp = WgradGroup(R, 1, cfg.precision, ops.APRO_NONE if bf else ops.APRO_PAIRMUL, io_flags=ops.WIO_X_BF16 if bf else 0)
+        gp = WgradGroup(R, 1, cfg.precision, ops.APRO_NONE if bf else ops.APRO_PAIRMUL, io_flags=(ops.WIO_DY_BF16 | ops.WIO_X_BF16) if bf else 0)
         C2 = C // 2
         order = list(range(F_ - 1, -1, -1))
         for f in order:       # weight-gradient problems of every flow (autograd of Modules.py:791,861,871,793): all pointers are known up front
@@ -450,11 +452,11 @@ class DecoderFunction(torch.autograd.Function):
                 if l == Lw - 1:
                     gp.add(dskip[f].data_ptr(), H, H, gates, ldg, H, G["w_rs_last"][f].data_ptr(), G["b_rs_last"][f].data_ptr())
                 else:
-                    gp.add(dh[f, l + 1].data_ptr(), H, H, gates, ldg, H, G["w_rs"][f, l].data_ptr(), G["b_rs"][f, l].data_ptr())
+                    gp.add(dh_ptr(f, l + 1), H, H, gates, ldg, H, G["w_rs"][f, l].data_ptr(), G["b_rs"][f, l].data_ptr())
                     gp.add(dskip[f].data_ptr(), H, H, gates, ldg, H, G["w_rs"][f, l].data_ptr() + 4 * H * H, G["b_rs"][f, l].data_ptr() + 4 * H)
                 gk.add(dins[f, l].data_ptr(), prep.ldin, prep.ldin, buf.hs[f, l].data_ptr(), H, H, G["w_in"][f, l].data_ptr(), G["b_in"][f, l].data_ptr(),
                        perm=ops.PERM_PAIR, perm_h=H)
-            g1.add(dh[f, 0].data_ptr(), H, H, buf.xmid[f].data_ptr(), C, C2, G["w_start"][f].data_ptr(), G["b_start"][f].data_ptr())
+            g1.add(dh0[f].data_ptr(), H, H, buf.xmid[f].data_ptr(), C, C2, G["w_start"][f].data_ptr(), G["b_start"][f].data_ptr())
             # GLOWTTS_WGRAD_SPLIT=n: weight gradients in n segments, each launched on a second stream as soon as its flows' chain is
             # done (default 1: one launch per class after the chain; see DESIGN.md for the measurements)
             nseg = int(os.environ.get("GLOWTTS_WGRAD_SPLIT", "1"))
@@ -477,7 +479,7 @@ class DecoderFunction(torch.autograd.Function):
             g.dx, g.dlogdet, g.douts, g.dskip = dx.data_ptr(), dld.data_ptr(), douts[f].data_ptr(), dskip[f].data_ptr()
             g.scratch, g.d_an, g.defer_wgrad = scratch[f].data_ptr(), None, 1
             for l in range(Lw):
-                g.dh[l], g.dins[l] = dh[f, l].data_ptr(), dins[f, l].data_ptr()
+                g.dh[l], g.dins[l] = dh_ptr(f, l), dins[f, l].data_ptr()
             if dcond is not None:
                 g.dcond = dcond.data_ptr() + 4 * f * Lw * 2 * H
             acts = buf.acts(f, Lw, rowmask)

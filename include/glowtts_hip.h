@@ -268,7 +268,8 @@ typedef struct glowtts_flow_dims {
     uint32_t seed;     /* dropout seed of this flow step (layer l uses seed + l); same value in forward and backward */
     const uint32_t *seed_ptr;  /* optional device word added to the seed (graph replay) */
     int act_bf16;      /* 1 (bf16 precision only): the GEMM-only activations - WaveNet states hs[], gates[], gate gradients dins[] -
-                        * are bf16 tensors (same shapes; halves their HBM traffic).  skip, outs, dh, dskip, the flow variable stay fp32. */
+                        * and, in the backward, dskip and dh[l >= 1] are bf16 tensors (same shapes; halves their HBM traffic and lets
+                        * the LDS-DMA conv kernel stage them).  skip, outs, dh[0], the flow variable stay fp32. */
 } glowtts_flow_dims;
 
 typedef struct glowtts_flow_params {

@@ -114,3 +114,30 @@ def test_actnorm_init_on_first_forward_matches_reference():
         assert f.layers[0].initialized
         assert (f.layers[0].logs.cpu() - sd[f"layer_Dict.Decoder.layer_Dict.Flows.{i}.layers.0.logs"]).abs().max() < 2e-4
         assert (f.layers[0].bias.cpu() - sd[f"layer_Dict.Decoder.layer_Dict.Flows.{i}.layers.0.bias"]).abs().max() < 2e-4
+
+
+def test_train_bf16_gradients_close_to_reference():
+    """bf16 mode (bf16 MFMA operands AND bf16-stored WaveNet state / gates / their gradients): every parameter gradient stays close
+    to the reference's fp32 gradient - direction (cosine) and size - so the reduced storage precision does not bias training."""
+    from glow_tts_amd.modules import MLE_Loss
+    sd, grads, r = load_case("tiny_vanilla.npz")
+    model = build("Vanilla", "bf16", sd)
+    t = lambda k: torch.from_numpy(r[k]).cuda()
+    z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, attn, _ = model(t("tokens"), t("token_lengths"), t("mels"), t("mel_lengths"), None, None, None)
+    mle = MLE_Loss(model.hp)(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=t("mel_lengths"))
+    length = torch.nn.functional.mse_loss(log_dur, log_dur_t)
+    model.zero_grad()
+    (mle + length).backward()
+    torch.cuda.synchronize()
+    worst_cos, n = 1.0, 0
+    for k, p in model.named_parameters():
+        want = grads.get(k)
+        if want is None or p.grad is None or want.abs().max() < 1e-6:
+            continue
+        got = p.grad.cpu().double().flatten(); want = want.double().flatten()
+        cos = (got @ want / (got.norm() * want.norm() + 1e-30)).item()
+        ratio = (got.norm() / (want.norm() + 1e-30)).item()
+        worst_cos = min(worst_cos, cos); n += 1
+        assert cos > 0.98 and 0.9 < ratio < 1.1, (k, cos, ratio)
+    assert n > 100
+    print("worst cosine", worst_cos)
