@@ -66,12 +66,53 @@ def _sp(t):
     return t.data_ptr() if t is not None else None
 
 
+class WgradTape:
+    """Weight-gradient problems of the convs of ONE forward pass.  ConvRows.backward only records (dz, x) and hands autograd an
+    unfilled dW / db; ParamGate.backward - which autograd runs after every consumer of the gated parameters - fills all of them with
+    one grouped launch per (taps, precision): no split-K atomics, no zero fills, 3 launches instead of ~30 for the text encoder."""
+
+    def __init__(self):
+        self.jobs = []
+
+    def add(self, dz, x, O, ca, taps, precision, dw, db):
+        self.jobs.append((dz, x, O, ca, taps, precision, dw, db))
+
+    def flush(self):
+        from .decoder import WgradGroup
+        groups = {}
+        for dz, x, O, ca, taps, precision, dw, db in self.jobs:
+            key = (dz.shape[0], taps, precision)
+            if key not in groups:
+                groups[key] = WgradGroup(dz.shape[0], taps, precision, tag="enc")
+            groups[key].add(dz.data_ptr(), dz.shape[1], O, x.data_ptr(), x.shape[1], ca, dw.data_ptr(), _sp(db))
+        for g in groups.values():
+            g.end_segment()
+            g.upload(self.jobs[0][0].device)
+            g.launch_segment(0)
+        self.jobs = []        # (dz / x stay referenced by the launched work's stream ordering: same stream, freed after)
+
+
+class ParamGate(torch.autograd.Function):
+    """Identity on the parameters that the taped convs consume; its backward launches the tape."""
+
+    @staticmethod
+    def forward(ctx, tape, *params):
+        ctx.tape = tape
+        return tuple(p.detach() for p in params)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.tape.flush()
+        return (None,) + grads
+
+
 class ConvRows(torch.autograd.Function):
     """y = dropout( relu?( conv1d_same(x, w) + b ) ) [+ residual] [* rowmask]   on rows tensors.
     Mirrors torch.nn.Conv1d(k, padding=(k-1)//2) + the elementwise tail the reference applies after it."""
 
     @staticmethod
-    def forward(ctx, x, w, b, rowmask, residual, relu, mask_out, precision, drop_p, seed, seed_t):
+    def forward(ctx, x, w, b, rowmask, residual, relu, mask_out, precision, drop_p, seed, seed_t, tape=None):
+        ctx.tape = tape
         x = x.contiguous()
         R, Cin = x.shape
         O, Ci2, k = w.shape
@@ -113,12 +154,17 @@ class ConvRows(torch.autograd.Function):
             ops.conv_cl(dz, pwt, O, R, lda=O, pad=(k - 1) // 2, epi=ops.EPI_LINEAR, flags=0, n=Ci2, out0=dx, ld0=Cin)
         dw = db = None
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
-            dw, db = wgrad(dz, x, O, Ci2, k, precision, want_bias=has_b, splits=min(4, max(1, R // 512)))
-        return dx, dw, db, None, dres, None, None, None, None, None, None
+            if ctx.tape is not None:                           # deferred: filled by ParamGate.backward (one grouped launch)
+                dw = torch.empty(O, Ci2, k, device=x.device)
+                db = torch.empty(O, device=x.device) if has_b else None
+                ctx.tape.add(dz, x, O, Ci2, k, precision, dw, db)
+            else:
+                dw, db = wgrad(dz, x, O, Ci2, k, precision, want_bias=has_b, splits=min(4, max(1, R // 512)))
+        return dx, dw, db, None, dres, None, None, None, None, None, None, None
 
 
-def conv_rows(x, w, b, rowmask, relu=False, mask_out=False, residual=None, precision=ops.BF16, drop_p=0.0, seed=0, seed_t=None):
-    return ConvRows.apply(x, w, b, rowmask, residual, relu, mask_out, precision, float(drop_p), seed, seed_t)
+def conv_rows(x, w, b, rowmask, relu=False, mask_out=False, residual=None, precision=ops.BF16, drop_p=0.0, seed=0, seed_t=None, tape=None):
+    return ConvRows.apply(x, w, b, rowmask, residual, relu, mask_out, precision, float(drop_p), seed, seed_t, tape)
 
 
 class LayerNormRows(torch.autograd.Function):

@@ -105,8 +105,8 @@ class WgradGroup:
     """Weight-gradient problems sharing (rows, taps, X prologue).  Problems are added in *segments* (one per flow); the whole
     job table is uploaded once and every segment is one glowtts_wgrad_grouped launch (tile indices restart per segment)."""
 
-    def __init__(self, rows, taps, precision, xpro=ops.APRO_NONE, io_flags=0):
-        self.rows, self.taps, self.precision, self.xpro, self.io_flags = rows, taps, precision, xpro, io_flags
+    def __init__(self, rows, taps, precision, xpro=ops.APRO_NONE, io_flags=0, tag="dec"):
+        self.rows, self.taps, self.precision, self.xpro, self.io_flags, self.tag = rows, taps, precision, xpro, io_flags, tag
         self.jobs, self.segments, self._tiles, self._start = [], [], 0, 0
         self.table = None
 
@@ -127,7 +127,7 @@ class WgradGroup:
             return
         arr = (WgradJob * len(self.jobs))(*self.jobs)
         raw = bytes(arr)
-        key = (self.taps, self.xpro, len(raw), str(device))
+        key = (self.tag, self.taps, self.xpro, self.io_flags, len(raw), str(device))
         pinned = _PINNED.get(key)
         if pinned is None:
             if torch.cuda.is_current_stream_capturing():

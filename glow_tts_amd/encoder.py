@@ -15,7 +15,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from .conv_fn import EmbeddingRows, RPRAttention, conv_rows, layernorm_rows
+from .conv_fn import EmbeddingRows, ParamGate, RPRAttention, WgradTape, conv_rows, layernorm_rows
 
 ROW_PAD = 2
 
@@ -41,10 +41,33 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
         counter[0] += 7919
         return counter[0]
 
+    # Conv parameters pass through one ParamGate: the convs' weight gradients are then deferred to a few grouped launches at the end
+    # of the encoder's backward (conv_fn.WgradTape).  QKV: one fused [3C, C, 1] weight per layer (views of a flat tensor with `cache`).
+    Pc = dict(P)
+    for i in range(e.Transformer.Stacks):
+        a = f"{prefix}.layer_Dict.Transformer.layer_Dict.ANCRDCN_{i}.layer_Dict.Attention"
+        names = [a + ".layer_Dict." + n for n in ("Query", "Key", "Value")]
+        if cache is not None:
+            if a not in cache:
+                from .decoder import LeafStack
+                cache[a] = (LeafStack([P[n + ".weight"] for n in names], (3,)), LeafStack([P[n + ".bias"] for n in names], (3,)))
+            Pc[a + ".QKV.weight"], Pc[a + ".QKV.bias"] = cache[a][0].tensor().view(3 * C, C, 1), cache[a][1].tensor().view(3 * C)
+        else:
+            Pc[a + ".QKV.weight"] = torch.cat([P[n + ".weight"] for n in names], 0)
+            Pc[a + ".QKV.bias"] = torch.cat([P[n + ".bias"] for n in names], 0)
+    tape = None
+    if torch.is_grad_enabled():
+        gated = [k for k, v in Pc.items() if k.startswith(prefix) and k.endswith(".weight") and v.dim() == 3 and v.requires_grad]
+        gated += [k[:-len(".weight")] + ".bias" for k in gated if (k[:-len(".weight")] + ".bias") in Pc]
+        if gated:
+            tape = WgradTape()
+            for k, v in zip(gated, ParamGate.apply(tape, *[Pc[k] for k in gated])):
+                Pc[k] = v
+
     def conv(xr, name, relu=False, mask_out=False, residual=None, drop=0.0):
         p_ = float(drop) if training else 0.0
-        return conv_rows(xr, P[name + ".weight"], P.get(name + ".bias"), rmf, relu=relu, mask_out=mask_out, residual=residual,
-                         precision=precision, drop_p=p_, seed=nseed(), seed_t=seed_t)
+        return conv_rows(xr, Pc[name + ".weight"], Pc.get(name + ".bias"), rmf, relu=relu, mask_out=mask_out, residual=residual,
+                         precision=precision, drop_p=p_, seed=nseed(), seed_t=seed_t, tape=tape)
 
     def ln(a, b, name, relu=False, drop=0.0):
         p_ = float(drop) if training else 0.0
@@ -64,17 +87,7 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
     for i in range(e.Transformer.Stacks):
         q = f"{prefix}.layer_Dict.Transformer.layer_Dict.ANCRDCN_{i}.layer_Dict"
         a = q + ".Attention"
-        # Query / Key / Value run as one 1x1 conv with 3C outputs.  With a `cache` (the model's) the three leaves are views of
-        # one flat tensor (decoder.LeafStack): no concatenation per step
-        names = [a + ".layer_Dict." + n for n in ("Query", "Key", "Value")]
-        if cache is not None:
-            if a not in cache:
-                from .decoder import LeafStack
-                cache[a] = (LeafStack([P[n + ".weight"] for n in names], (3,)), LeafStack([P[n + ".bias"] for n in names], (3,)))
-            wqkv, bqkv = cache[a][0].tensor().view(3 * C, C, 1), cache[a][1].tensor().view(3 * C)
-        else:
-            wqkv, bqkv = torch.cat([P[n + ".weight"] for n in names], 0), torch.cat([P[n + ".bias"] for n in names], 0)
-        qkv = conv_rows(x, wqkv, bqkv, rmf, precision=precision)                                             # RPR_MHA.py:82-84
+        qkv = conv(x, a + ".QKV")                                                                            # RPR_MHA.py:82-84 (one fused 1x1 conv)
         att = RPRAttention.apply(qkv, P[a + ".weight_K"], P[a + ".weight_V"], rmf, B, Tp, H, win,
                                  float(dr) if training else 0.0, nseed(), seed_t)                            # RPR_MHA.py:95-128
         att = conv(att, a + ".layer_Dict.Projection", drop=dr)                                               # :93 + Dropout :561
@@ -101,5 +114,5 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
         d = conv(d, q, relu=True, mask_out=True, drop=dp.Dropout_Rate)
     # Projection to one channel: N = 1 is not a GEMM; a masked dot product per frame
     wq = prefix + ".layer_Dict.Duration_Predictor.layer_Dict.Projection"
-    log_dur = (d @ P[wq + ".weight"][0, :, 0] + P[wq + ".bias"]).view(B, Tp)[:, ROW_PAD:-ROW_PAD].unsqueeze(1) * mask
+    log_dur = (d @ Pc[wq + ".weight"][0, :, 0] + Pc[wq + ".bias"]).view(B, Tp)[:, ROW_PAD:-ROW_PAD].unsqueeze(1) * mask
     return mean, log_std, log_dur
