@@ -29,7 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BMO = 128;      // o per block
 constexpr int BNC = 64;       // c per block
-constexpr int BK = 32;        // rows per step
+constexpr int BK = 64;        // rows per step
 
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
