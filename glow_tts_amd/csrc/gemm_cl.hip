@@ -137,6 +137,9 @@ template <> struct StaticFor<0> { template <class F> __device__ __forceinline__ 
 
 // tools/build_tl.sh builds with GLOWTTS_TIMELINE: thread 0 of every workgroup logs shader-clock stamps into `tlbuf`
 #ifdef GLOWTTS_TIMELINE
+#ifndef TL_STRIDE
+#define TL_STRIDE 32
+#endif
 #define TL(i) do { if (tid == 0) tlbuf[(i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define TL(i)
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
     // tools/build_tl.sh builds with GLOWTTS_TIMELINE: thread 0 of every workgroup logs shader-clock stamps into the
     // buffer passed through p.ncols_valid ([workgroups][32] int64) - never defined in the product build
 #ifdef GLOWTTS_TIMELINE
-    long long* tlbuf = reinterpret_cast<long long*>(const_cast<int*>(p.ncols_valid)) + (long)blockIdx.x * 32;
+    long long* tlbuf = reinterpret_cast<long long*>(const_cast<int*>(p.ncols_valid)) + (long)blockIdx.x * TL_STRIDE;
     if (tid == 0) { tlbuf[30] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); tlbuf[31] = (long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); }
 #endif
     TL(0);
@@ -822,7 +825,8 @@ extern __shared__ __attribute__((aligned(1024))) unsigned char dma_smem[];
 constexpr int DMA1_CPS = 2;             // 1x1 convs: K chunks per pipeline stage
 
 template <int EPI, int TAPS>
-__global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args pin, const int nst /* LDS stages: 2 or 3 */)
+__global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args pin, const int nst /* LDS stages: 2 or 3 */,
+                                                        const int nload /* loader waves (0: every wave stages its share) */)
 {
     typedef __bf16 CT;
     constexpr int NI = 2, BN = 64, KC = 32;
@@ -834,7 +838,7 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
     glowtts_conv_args p = pin;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // scalar: unit indices, LDS bases and branches below are wave-uniform
-    const int WMR = blockDim.x >> 6, BM = WMR * 32;
+    const int WMR = (blockDim.x >> 6) - nload, BM = WMR * 32; // compute waves (the last `nload` waves only issue DMAs)
     const int AU = (BM + TAPS - 1 + 15) >> 4;                 // 16-row (1 KiB) DMA units of one A tile
     constexpr int WU = SUB * 4;                               // 16-column units of the SUB weight tiles
     const int A_BYTES = NAT * AU * 1024, STAGE = A_BYTES + WU * 1024;
@@ -855,10 +859,52 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
     constexpr int pad = (TAPS - 1) / 2;
     const int l31 = lane & 31, lhi = lane >> 5;
 #ifdef GLOWTTS_TIMELINE
-    long long* tlbuf = reinterpret_cast<long long*>(const_cast<int*>(p.ncols_valid)) + (long)blockIdx.x * 32;
+    long long* tlbuf = reinterpret_cast<long long*>(const_cast<int*>(p.ncols_valid)) + (long)blockIdx.x * TL_STRIDE;
     if (tid == 0) { tlbuf[30] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); tlbuf[31] = (long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); }
 #endif
     TL(0);
+
+    // lane -> (row or column inside a 16-unit, logical 16-byte slot): LDS position `lane` of a unit holds slot q of row lane >> 2
+    const int lrow = lane >> 2, qa = (lane & 3) ^ ((lane >> 4) & 3);
+    const int nau = NAT * AU, nun = nau + WU;
+    const unsigned char* const abase = reinterpret_cast<const unsigned char*>(p.a);
+    const unsigned char* const a2base = reinterpret_cast<const unsigned char*>(p.a2);
+    const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(p.w);
+    const uint32_t wkstep = (uint32_t)p.npad * 64u * (T1 ? DMA1_CPS : 1);
+    constexpr uint32_t akstep = KC * 2 * (T1 ? DMA1_CPS : 1);
+    // stage-0 source offset of DMA unit u (32-bit byte offset from p.a (p.a2) / p.w, host-checked < 2^31)
+    auto unit_off = [&](int u) __attribute__((always_inline)) -> uint32_t {
+        if (u < nau) {
+            const int ja = T1 ? u / AU : 0, ur = u - ja * AU;
+            int g = m0 - pad + ur * 16 + lrow;
+            g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
+            return (uint32_t)g * (uint32_t)(p.lda * 2) + (uint32_t)(qa * 16 + ja * (KC * 2));
+        }
+        const int w = u - nau, t = w >> 2, cg = w & 3;        // t: tap (multi-tap) or chunk inside the stage (1x1)
+        return (uint32_t)((T1 ? t : t * KCH) * p.npad + n0 + cg * 16 + lrow) * 64u + (uint32_t)(qa * 16);
+    };
+    auto dma = [&](int u, uint32_t off, int buf, int st) __attribute__((always_inline)) {
+        const unsigned char* src;
+        if (u >= nau)       src = wbase + (off + (uint32_t)st * wkstep);
+        else if (st < NSS1) src = abase + (off + (uint32_t)st * akstep);
+        else                src = a2base + (off + (uint32_t)(st - NSS1) * akstep);
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                         (void __attribute__((address_space(3)))*)(dma_smem + buf * STAGE + u * 1024), 16, 0, 0);
+    };
+    if (wave >= WMR) {
+        // ---- loader wave (wave specialisation): an LDS-DMA instruction costs its issuing wave 100-200 clk in a phase that also reads
+        // LDS and feeds the matrix pipe; two waves that do nothing else stage every tile (two LDS stages: stage ss+1 streams in while
+        // the compute waves multiply stage ss).  They take part in every barrier and leave before the epilogue.
+        const int lw = wave - WMR;
+        for (int u = lw; u < nun; u += nload) dma(u, unit_off(u), 0, ssmap(0));
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int ss = 0; ss + 1 < NSS; ++ss) {
+            const int st = ssmap(ss + 1), buf = (ss + 1) & 1;
+            for (int u = lw; u < nun; u += nload) dma(u, unit_off(u), buf, st);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        return;
+    }
 
     f32x16 acc[1][NI];
 #pragma unroll
@@ -866,44 +912,18 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][ni][r] = 0.f;
 
-    // lane -> (row or column inside a 16-unit, logical 16-byte slot): LDS position `lane` of a unit holds slot q of row lane >> 2
-    const int lrow = lane >> 2, qa = (lane & 3) ^ ((lane >> 4) & 3);
-    // DMA units of this wave: u = wave + i * WMR.  Their stage-0 source offsets are computed once; a stage is a uniform byte step
-    // (SUB-or-1 x 64 B along an A row, SUB-or-1 [npad][64 B] slabs of the packed weights).
+    // DMA units of this wave when every wave stages its share: u = wave + i * WMR.  Their stage-0 source offsets are computed once; a
+    // stage is a uniform byte step (SUB-or-1 x 64 B along an A row, SUB-or-1 [npad][64 B] slabs of the packed weights).
     constexpr int MAXU = 8;                                   // >= ceil(units / WMR) for every WMR >= 4
-    const int nau = NAT * AU, nun = nau + WU;
-    uint32_t uoff[MAXU];                                      // 32-bit byte offsets from p.a (p.a2) / p.w (host-checked < 2^31)
+    uint32_t uoff[MAXU];
 #pragma unroll
-    for (int i = 0; i < MAXU; ++i) {
-        const int u = wave + i * WMR;                         // wave-uniform (wave comes from readfirstlane)
-        if (u < nau) {
-            const int ja = T1 ? u / AU : 0, ur = u - ja * AU;
-            int g = m0 - pad + ur * 16 + lrow;
-            g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
-            uoff[i] = (uint32_t)g * (uint32_t)(p.lda * 2) + (uint32_t)(qa * 16 + ja * (KC * 2));
-        } else {
-            const int w = u - nau, t = w >> 2, cg = w & 3;    // t: tap (multi-tap) or chunk inside the stage (1x1)
-            uoff[i] = (uint32_t)((T1 ? t : t * KCH) * p.npad + n0 + cg * 16 + lrow) * 64u + (uint32_t)(qa * 16);
-        }
-    }
-    const int nmine = (nun - wave + WMR - 1) / WMR;           // DMA instructions this wave issues per stage
-    const unsigned char* const abase = reinterpret_cast<const unsigned char*>(p.a);
-    const unsigned char* const a2base = reinterpret_cast<const unsigned char*>(p.a2);
-    const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(p.w);
-    const uint32_t wkstep = (uint32_t)p.npad * 64u * (T1 ? DMA1_CPS : 1);
-    constexpr uint32_t akstep = KC * 2 * (T1 ? DMA1_CPS : 1);
+    for (int i = 0; i < MAXU; ++i) uoff[i] = unit_off(wave + i * WMR);       // wave-uniform unit index (wave comes from readfirstlane)
+    const int nmine = nload ? 0 : (nun - wave + WMR - 1) / WMR;              // DMA instructions this wave issues per stage
     auto issue_unit = [&](auto I_, int buf, int st) __attribute__((always_inline)) {
         constexpr int i = decltype(I_)::value;
         if constexpr (i < MAXU) {
             const int u = wave + i * WMR;
-            if (u < nun) {
-                const unsigned char* src;
-                if (u >= nau)       src = wbase + (uoff[i] + (uint32_t)st * wkstep);
-                else if (st < NSS1) src = abase + (uoff[i] + (uint32_t)st * akstep);
-                else                src = a2base + (uoff[i] + (uint32_t)(st - NSS1) * akstep);
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                                 (void __attribute__((address_space(3)))*)(dma_smem + buf * STAGE + u * 1024), 16, 0, 0);
-            }
+            if (u < nun) dma(u, uoff[i], buf, st);
         }
     };
     // MFMAs of stage `buf`; when `nbuf >= 0` the DMAs of a later stage are issued between the sub-steps, so that their issue cost
@@ -960,9 +980,9 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
     };
     // nst LDS stages: stage ss+1 .. ss+nst-1 are in flight while stage ss is multiplied (nst = 3: two ahead; nst = 2: one ahead, two
     // thirds of the LDS, so that a second workgroup - of another kernel on another stream - can be co-resident on the CU)
-    const int ahead = nst - 1;
-    StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 0, ssmap(0)); });
-    if (ahead > 1 && NSS > 1) StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 1, ssmap(1)); });
+    const int ahead = nst - 1;                                // (loader waves: the host passes nst = 2)
+    if (!nload) StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 0, ssmap(0)); });
+    if (!nload && ahead > 1 && NSS > 1) StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 1, ssmap(1)); });
     TL(1);
     int cur = 0;                                              // LDS stage of pipeline stage ss (ss % nst)
     for (int ss = 0; ss < NSS; ++ss) {
@@ -970,9 +990,16 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
         // and every wave is done reading the LDS stage of ss-1, which is refilled with stage ss+ahead during the MFMAs below
         wait_keep((ahead > 1 && ss + 1 < NSS) ? nmine : 0);
         TL(3 + 3 * ss);
-        const bool more = ss + ahead < NSS;
+        const bool more = !nload && ss + ahead < NSS;
         const int nxt = cur == 0 ? nst - 1 : cur - 1;         // (ss + ahead) % nst
+#ifdef GLOWTTS_TIMELINE
+        if (ss == 3 && lane == 0) tlbuf[64 + wave * 3 + 0] = (long long)__builtin_readcyclecounter();      // per-wave: barrier passed
+#endif
         if (!(abl & 2)) compute(cur, more ? nxt : -1, more ? ssmap(ss + ahead) : 0);
+#ifdef GLOWTTS_TIMELINE
+        if (ss == 3 && lane == 0) tlbuf[64 + wave * 3 + 1] = (long long)__builtin_readcyclecounter();      // per-wave: compute done
+        if (ss == 3 && lane == 0) tlbuf[64 + wave * 3 + 2] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+#endif
         TL(5 + 3 * ss);
         cur = cur == nst - 1 ? 0 : cur + 1;
     }
@@ -1009,12 +1036,14 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
 {
     // waves per workgroup: all tiles resident at once (one workgroup per CU) if possible, else the fewest rounds
     static const int force = [] { const char* e = getenv("GLOWTTS_DMA_WAVES"); return e ? atoi(e) : 0; }();
+    // GLOWTTS_DMA_LOADERS = 1 | 2: that many extra waves per workgroup do all the LDS-DMA staging (wave specialisation)
+    static const int nload = [] { const char* e = getenv("GLOWTTS_DMA_LOADERS"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 4) ? v : 0; }();
     // GLOWTTS_DMA_CUS: CUs the chain kernels plan for (default: all).  Leaving a few CUs to the concurrently running encoder stream
     // can pay: these kernels are latency-bound, a fatter workgroup on fewer CUs costs them little.
     static const int cu_budget = [] { const char* e = getenv("GLOWTTS_DMA_CUS"); return e ? atoi(e) : 0; }();
     const int gy = a.npad / 64, ncu = (cu_budget >= 32 && cu_budget <= num_cus()) ? cu_budget : num_cus(), frags = (a.rows + 31) / 32;
     int best = 4; long best_cost = -1;
-    constexpr int WMAX = TAPS == 1 ? 10 : 16;             // three LDS stages must fit 160 KiB
+    const int WMAX = (TAPS == 1 ? 10 : 16) - nload;       // three LDS stages must fit 160 KiB; at most 16 waves
     for (int w = 4; w <= WMAX; ++w) {
         const long tiles = (long)((frags + w - 1) / w) * gy;
         const long cost = ((tiles + ncu - 1) / ncu) * (w + 4);      // rounds x (strip work + fixed prologue / epilogue share)
@@ -1026,7 +1055,7 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
     // LDS stages: 2 by default.  Alone, the kernel is as fast with 2 as with 3 (17.7 us either way); in the training step the smaller
     // footprint (83 instead of 124 KiB at 10 waves) lets encoder-stream workgroups share the CU: 7.1 vs 7.35 ms/step.
     static const int nst = [] { const char* e = getenv("GLOWTTS_DMA_STAGES"); const int v = e ? atoi(e) : 2; return v == 3 ? 3 : 2; }();
-    const int lds = nst * ((nat * ((BM + TAPS - 1 + 15) >> 4) + sub * 4) * 1024);     // three stages: <= 159 KiB (16 waves x 5 taps, 10 waves 1x1)
+    const int lds = (nload ? 2 : nst) * ((nat * ((BM + TAPS - 1 + 15) >> 4) + sub * 4) * 1024);     // three stages: <= 159 KiB (16 waves x 5 taps, 10 waves 1x1)
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<EPI, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -1034,7 +1063,7 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
         attr_done = true;
     }
     dim3 grid(((a.rows + BM - 1) / BM) * gy);
-    hipLaunchKernelGGL((conv_dma_kernel<EPI, TAPS>), grid, dim3(best * 64), lds, s, a, nst);
+    hipLaunchKernelGGL((conv_dma_kernel<EPI, TAPS>), grid, dim3((best + nload) * 64), lds, s, a, nload ? 2 : nst, nload);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 

@@ -18,7 +18,8 @@ pw = ops.pack_weight(w, perm=ops.PERM_PAIR, perm_h=H, precision=ops.BF16)
 bias = torch.zeros(2 * H, device="cuda")
 G = torch.empty(R, 2 * H, device="cuda", dtype=torch.bfloat16 if bf else torch.float32)
 NWG = 4096
-tl = torch.zeros(NWG, 32, dtype=torch.int64, device="cuda")
+TLS = int(os.environ.get("TL_STRIDE", "32"))
+tl = torch.zeros(NWG, TLS, dtype=torch.int64, device="cuda")
 args = ops.ConvArgs()
 args.a, args.lda, args.ca, args.rows = a.data_ptr(), H, H, R
 args.w, args.n, args.npad, args.kchunks, args.taps, args.pad, args.precision = pw.data.data_ptr(), 2 * H, pw.npad, pw.kchunks, 5, 2, ops.BF16
@@ -75,3 +76,14 @@ cu = (hw >> 8) & 0xF; se = (hw >> 13) & 0x7
 key = xcc * 1000 + se * 16 + cu
 u, c = np.unique(key, return_counts=True)
 print(f"distinct (xcc,se,cu): {len(u)}; workgroups per CU: " + ", ".join(f"{v}x{(c == v).sum()}" for v in sorted(set(c))))
+
+if TLS >= 128:
+    print("per-wave stamps at chunk 3 (clk after the workgroup's start; SIMD id from HW_ID bits 4-5):")
+    for w in range(16):
+        col = 64 + 3 * w
+        ok = t[:, col] != 0
+        if not ok.any():
+            continue
+        a = np.median(t[ok, col] - t[ok, 0]); b = np.median(t[ok, col + 1] - t[ok, 0])
+        simd = np.bincount(((t[ok, col + 2] >> 4) & 3).astype(int), minlength=4)
+        print(f"  wave {w:2d}: barrier passed +{a:7.0f}  compute done +{b:7.0f}  (compute {b - a:6.0f})  simd histogram {simd.tolist()}")
