@@ -824,12 +824,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
 extern __shared__ __attribute__((aligned(1024))) unsigned char dma_smem[];
 constexpr int DMA1_CPS = 2;             // 1x1 convs: K chunks per pipeline stage
 
-template <int EPI, int TAPS>
+template <int EPI, int TAPS, int NI = 2>
 __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args pin, const int nst /* LDS stages: 2 or 3 */,
                                                         const int nload /* loader waves (0: every wave stages its share) */)
 {
     typedef __bf16 CT;
-    constexpr int NI = 2, BN = 64, KC = 32;
+    constexpr int BN = NI * 32, KC = 32;                      // NI = 2: 64-column strips; NI = 3: 96 (when that balances the SIMDs better)
+    constexpr int WTB = BN * 64, WUT = BN / 16;               // bytes / DMA units of one weight tile
     // A stage holds SUB sub-steps.  Multi-tap: one K chunk = one A tile (with its TAPS - 1 halo rows) shared by the TAPS weight
     // tiles.  1x1 (TAPS == 1): DMA1_CPS consecutive K chunks, each with its own A tile and weight tile.
     constexpr bool T1 = (TAPS == 1);
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // scalar: unit indices, LDS bases and branches below are wave-uniform
     const int WMR = (blockDim.x >> 6) - nload, BM = WMR * 32; // compute waves (the last `nload` waves only issue DMAs)
     const int AU = (BM + TAPS - 1 + 15) >> 4;                 // 16-row (1 KiB) DMA units of one A tile
-    constexpr int WU = SUB * 4;                               // 16-column units of the SUB weight tiles
+    constexpr int WU = SUB * WUT;                             // 16-column units of the SUB weight tiles
     const int A_BYTES = NAT * AU * 1024, STAGE = A_BYTES + WU * 1024;
     int m_tile, n_tile;
     {   // XCD-aware tile order (see conv_cl_kernel)
@@ -880,7 +881,7 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
             g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
             return (uint32_t)g * (uint32_t)(p.lda * 2) + (uint32_t)(qa * 16 + ja * (KC * 2));
         }
-        const int w = u - nau, t = w >> 2, cg = w & 3;        // t: tap (multi-tap) or chunk inside the stage (1x1)
+        const int w = u - nau, t = w / WUT, cg = w - t * WUT; // t: tap (multi-tap) or chunk inside the stage (1x1)
         return (uint32_t)((T1 ? t : t * KCH) * p.npad + n0 + cg * 16 + lrow) * 64u + (uint32_t)(qa * 16);
     };
     auto dma = [&](int u, uint32_t off, int buf, int st) __attribute__((always_inline)) {
@@ -914,7 +915,7 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
 
     // DMA units of this wave when every wave stages its share: u = wave + i * WMR.  Their stage-0 source offsets are computed once; a
     // stage is a uniform byte step (SUB-or-1 x 64 B along an A row, SUB-or-1 [npad][64 B] slabs of the packed weights).
-    constexpr int MAXU = 8;                                   // >= ceil(units / WMR) for every WMR >= 4
+    constexpr int MAXU = NI == 2 ? 8 : 10;                    // >= ceil(units / WMR) for every WMR >= 4
     uint32_t uoff[MAXU];
 #pragma unroll
     for (int i = 0; i < MAXU; ++i) uoff[i] = unit_off(wave + i * WMR);       // wave-uniform unit index (wave comes from readfirstlane)
@@ -942,7 +943,7 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
                 const int q = 2 * s2 + lhi;
                 fa[set][s2] = *reinterpret_cast<const Chunk16*>(At + swz(wave * 32 + l31 + (T1 ? 0 : t), q));
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) fb[set][s2][ni] = *reinterpret_cast<const Chunk16*>(Wb + t * 4096 + swz(ni * 32 + l31, q));
+                for (int ni = 0; ni < NI; ++ni) fb[set][s2][ni] = *reinterpret_cast<const Chunk16*>(Wb + t * WTB + swz(ni * 32 + l31, q));
             }
         };
         load_frags(IC<0>{});
@@ -1031,7 +1032,16 @@ bool dma_ok(const glowtts_conv_args& a)
     return !a.a2 || ((a.ca1 % (32 * DMA1_CPS)) == 0 && a.lda2 == a.lda);
 }
 
-template <int EPI, int TAPS>
+// 96-column strips (NI = 3) balance the SIMDs better on paper for the WaveNet In data gradient (12928 rows x 192 columns: 4 waves x 202
+// workgroups, one wave per SIMD, instead of 5 x 243 with two waves on one SIMD), but one wave per SIMD hides no latency: measured
+// 7.13 vs 7.00 ms/step.  Kept behind GLOWTTS_DMA_NI=3 for other shapes.
+inline bool dma_prefers_96(const glowtts_conv_args& a)
+{
+    static const int force = [] { const char* e = getenv("GLOWTTS_DMA_NI"); return e ? atoi(e) : 0; }();
+    return force == 3 && (a.npad % 96) == 0;
+}
+
+template <int EPI, int TAPS, int NI = 2>
 int launch_dma(const glowtts_conv_args& a, hipStream_t s)
 {
     // waves per workgroup: all tiles resident at once (one workgroup per CU) if possible, else the fewest rounds
@@ -1041,7 +1051,7 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
     // GLOWTTS_DMA_CUS: CUs the chain kernels plan for (default: all).  Leaving a few CUs to the concurrently running encoder stream
     // can pay: these kernels are latency-bound, a fatter workgroup on fewer CUs costs them little.
     static const int cu_budget = [] { const char* e = getenv("GLOWTTS_DMA_CUS"); return e ? atoi(e) : 0; }();
-    const int gy = a.npad / 64, ncu = (cu_budget >= 32 && cu_budget <= num_cus()) ? cu_budget : num_cus(), frags = (a.rows + 31) / 32;
+    const int gy = a.npad / (NI * 32), ncu = (cu_budget >= 32 && cu_budget <= num_cus()) ? cu_budget : num_cus(), frags = (a.rows + 31) / 32;
     int best = 4; long best_cost = -1;
     const int WMAX = (TAPS == 1 ? 10 : 16) - nload;       // three LDS stages must fit 160 KiB; at most 16 waves
     for (int w = 4; w <= WMAX; ++w) {
@@ -1055,15 +1065,15 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
     // LDS stages: 2 by default.  Alone, the kernel is as fast with 2 as with 3 (17.7 us either way); in the training step the smaller
     // footprint (83 instead of 124 KiB at 10 waves) lets encoder-stream workgroups share the CU: 7.1 vs 7.35 ms/step.
     static const int nst = [] { const char* e = getenv("GLOWTTS_DMA_STAGES"); const int v = e ? atoi(e) : 2; return v == 3 ? 3 : 2; }();
-    const int lds = (nload ? 2 : nst) * ((nat * ((BM + TAPS - 1 + 15) >> 4) + sub * 4) * 1024);     // three stages: <= 159 KiB (16 waves x 5 taps, 10 waves 1x1)
+    const int lds = (nload ? 2 : nst) * ((nat * ((BM + TAPS - 1 + 15) >> 4) + sub * (NI * 2)) * 1024);     // three stages: <= 159 KiB (16 waves x 5 taps, 10 waves 1x1)
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<EPI, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<EPI, TAPS, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return GLOWTTS_E_LAUNCH;
         attr_done = true;
     }
     dim3 grid(((a.rows + BM - 1) / BM) * gy);
-    hipLaunchKernelGGL((conv_dma_kernel<EPI, TAPS>), grid, dim3((best + nload) * 64), lds, s, a, nload ? 2 : nst, nload);
+    hipLaunchKernelGGL((conv_dma_kernel<EPI, TAPS, NI>), grid, dim3((best + nload) * 64), lds, s, a, nload ? 2 : nst, nload);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
@@ -1123,7 +1133,7 @@ int launch_prec(const glowtts_conv_args& a, hipStream_t s)
     if constexpr (sizeof(CT) == 2) {
         if (dma_ok(a)) {
             if (a.epi == GLOWTTS_EPI_GATE && a.taps == 5) return launch_dma<GLOWTTS_EPI_GATE, 5>(a, s);
-            if (a.epi == GLOWTTS_EPI_LINEAR && a.taps == 5) return launch_dma<GLOWTTS_EPI_LINEAR, 5>(a, s);
+            if (a.epi == GLOWTTS_EPI_LINEAR && a.taps == 5) return dma_prefers_96(a) ? launch_dma<GLOWTTS_EPI_LINEAR, 5, 3>(a, s) : launch_dma<GLOWTTS_EPI_LINEAR, 5>(a, s);
             if (a.epi == GLOWTTS_EPI_GATE && a.taps == 3) return launch_dma<GLOWTTS_EPI_GATE, 3>(a, s);
             if (a.epi == GLOWTTS_EPI_LINEAR && a.taps == 3) return launch_dma<GLOWTTS_EPI_LINEAR, 3>(a, s);
             if (a.epi == GLOWTTS_EPI_RESSKIP && a.taps == 1) return launch_dma<GLOWTTS_EPI_RESSKIP, 1>(a, s);
