@@ -200,13 +200,16 @@ __global__ __launch_bounds__(256) void coupling_bwd_kernel(float* __restrict__ d
                                                            const float* __restrict__ rowmask, const float* __restrict__ dld,
                                                            long rows, int C, int ldo, int rows_per_utt)
 {
-    const int C2 = C / 2;
-    const long total = rows * C2;
+    // one thread per (row, pair slot): slots past C/2 are the pad columns of the PAIR packing; they are written as zeros here so that the
+    // caller needs no memset of douts (the End conv's data / weight gradients read them)
+    const int C2 = C / 2, P2 = ldo / 2;
+    const long total = rows * P2;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long r = i / C2;
-        const int j = (int)(i - r * C2);
-        const float m = rowmask[r];
+        const long r = i / P2;
+        const int j = (int)(i - r * P2);
         const int pc = (j >> 5) * 64 + (j & 31);
+        if (j >= C2) { douts[r * ldo + pc] = 0.f; douts[r * ldo + pc + 32] = 0.f; continue; }
+        const float m = rowmask[r];
         const float logs = outs[r * ldo + pc + 32];
         const float e = expf(logs);
         const float d = dz[r * C + C2 + j];
@@ -423,7 +426,8 @@ extern "C" int glowtts_coupling_bwd(float* dz, const float* xmid, const float* o
                                     const float* dlogdet, int64_t rows, int C, int ldo, int rows_per_utt, void* stream)
 {
     if (!dz || !xmid || !outs || !douts || !rowmask || !dlogdet || rows < 1 || C < 2) return GLOWTTS_E_ARG;
-    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(grid_for(rows * (C / 2))), dim3(256), 0, static_cast<hipStream_t>(stream),
+    if ((ldo & 63) || ldo < C) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(grid_for(rows * (ldo / 2))), dim3(256), 0, static_cast<hipStream_t>(stream),
                        dz, xmid, outs, douts, rowmask, dlogdet, (long)rows, C, ldo, rows_per_utt);
     RET_LAUNCH();
 }

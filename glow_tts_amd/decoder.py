@@ -428,7 +428,7 @@ class DecoderFunction(torch.autograd.Function):
         d_an = torch.empty(F_, 2 * C + 16, device=dev)
         # every flow / layer keeps its own gradient buffers: the weight gradients of ALL flows are computed afterwards by
         # two grouped launches (k-tap problems, 1x1 problems) whose tiles fill the chip without split-K or atomics
-        douts = torch.zeros(F_, R, prep.ldo, device=dev)
+        douts = torch.empty(F_, R, prep.ldo, device=dev)           # (pad columns are zeroed by the coupling backward kernel)
         dins = (torch.empty if prep.ldin == 2 * H else torch.zeros)(F_, Lw, R, prep.ldin, device=dev, dtype=cfg.act_dtype)    # only pad columns need zeros
         dskip = torch.empty(F_, R, H, device=dev, dtype=cfg.act_dtype)
         dh0 = torch.empty(F_, R, H, device=dev)                                       # d h0: fp32 (feeds the fp32 Start conv gradients)
