@@ -1,0 +1,64 @@
+"""Replay of a fixed-shape training step as ONE hipGraph.
+
+The flow decoder is a chain of ~600 short dependent kernels per step: launched eagerly from Python the step is bound by host launch
+work (14 ms at B = 32 on an MI355X against 7 ms of GPU time).  `GraphedTrainStep` captures forward + loss + backward once per input
+shape and replays it; parameters, gradients and the returned loss live at fixed addresses, new batches are copied into static input
+buffers.  What the capture needs from the model is already in place: dropout seeds are re-drawn on the device, weight-gradient job
+tables come from pinned memory, the flat parameter storage is built during the eager warm-up steps.
+
+    step = GraphedTrainStep(model, lambda m, tokens, tl, mels, ml: total_loss(m, tokens, tl, mels, ml))
+    loss = step(tokens, token_lengths, mels, mel_lengths)      # gradients are in p.grad, as after loss.backward()
+    optimizer.step()
+
+Use one padded shape (or a few length buckets): every new shape costs `warmup` eager steps plus a capture.
+Capture the model BEFORE any eager `backward()` of it ran on another stream in this process (or after every tensor of those earlier
+steps - losses, outputs - has been released): autograd keeps a parameter's AccumulateGrad node on the stream of its first use while
+an old graph is alive, and a captured backward that has to hop to that stream crashes hipStreamEndCapture on ROCm 7.2.
+"""
+import torch
+
+
+class GraphedTrainStep:
+    def __init__(self, model, loss_fn, warmup=3):
+        """loss_fn(model, *inputs) -> scalar loss tensor (forward + losses).  warmup >= 2: eager steps before the capture (the first
+        one also runs the ActNorm data-dependent init and builds the flat parameter storage)."""
+        self.model, self.loss_fn, self.warmup = model, loss_fn, max(2, int(warmup))
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.stream = torch.cuda.Stream()
+        self.graphs = {}
+
+    def _fwd_bwd(self, inputs):
+        loss = self.loss_fn(self.model, *inputs)
+        self.model.zero_grad(set_to_none=True)
+        loss.backward()
+        return loss
+
+    def _capture(self, inputs):
+        static_in = [t.clone() if torch.is_tensor(t) else t for t in inputs]
+        cur = torch.cuda.current_stream()
+        # every eager step that precedes the capture runs on the capture-side stream as well: a backward that first ran on another
+        # stream makes the captured AccumulateGrad nodes hop streams, which hipStreamEndCapture does not survive on ROCm 7.2
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            for _ in range(self.warmup):
+                self._fwd_bwd(static_in)
+        cur.wait_stream(self.stream)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = self._fwd_bwd(static_in)
+        grads = [p.grad for p in self.params]
+        return g, static_in, loss, grads
+
+    def __call__(self, *inputs):
+        key = tuple((tuple(t.shape), t.dtype) if torch.is_tensor(t) else t for t in inputs)
+        if key not in self.graphs:
+            self.graphs[key] = self._capture(inputs)
+        g, static_in, loss, grads = self.graphs[key]
+        for s, t in zip(static_in, inputs):
+            if torch.is_tensor(t) and s.data_ptr() != t.data_ptr():
+                s.copy_(t, non_blocking=True)
+        g.replay()
+        for p, gr in zip(self.params, grads):              # several cached shapes: point .grad at this graph's buffers
+            p.grad = gr
+        return loss

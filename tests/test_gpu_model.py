@@ -141,3 +141,13 @@ def test_train_bf16_gradients_close_to_reference():
         assert cos > 0.98 and 0.9 < ratio < 1.1, (k, cos, ratio)
     assert n > 100
     print("worst cosine", worst_cos)
+
+
+def test_graphed_train_step_matches_eager():
+    """glow_tts_amd.graph_step.GraphedTrainStep: the replayed hipGraph gives the eager step's loss and gradients (f32), also for a
+    second batch copied into the static buffers.  Runs in a child process: a failed stream capture takes the process down on
+    ROCm 7.2 instead of raising, and must not take the rest of the suite with it."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "graph_step_check.py")], capture_output=True, text=True, timeout=600, cwd=os.path.dirname(here))
+    assert out.returncode == 0 and "GRAPH STEP OK" in out.stdout, (out.returncode, out.stdout[-2000:], out.stderr[-2000:])
