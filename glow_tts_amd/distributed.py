@@ -30,40 +30,59 @@ def global_frame_weight(local_frames):
 
 
 class FlatGradReducer:
-    """All-reduces the gradients of `params` through a few large flat buckets (xGMI is point-to-point: few, large
-    collectives beat many small ones).  Buckets are filled in reverse parameter order, i.e. in the order the
-    backward pass produces them (decoder flows last-to-first, then the encoder)."""
+    """All-reduces the gradients of `params` with few, large collectives (xGMI is point-to-point: few large messages beat many small
+    ones) and IN PLACE: `p.grad` keeps its address, which a replayed hipGraph of the step relies on.
+      * gradients that already tile one contiguous storage - the decoder's stacked weight classes, whose leaf gradients are views of
+        one stacked tensor (decoder.LeafStack) - are reduced directly on that storage: no copy at all (>= 95 % of the bytes);
+      * the remaining small tensors are concatenated into flat buckets, reduced, and copied back.
+    Buckets follow reverse parameter order, i.e. the order the backward pass produces them."""
 
-    def __init__(self, params, bucket_bytes=64 << 20):
+    def __init__(self, params, bucket_bytes=64 << 20, direct_bytes=1 << 20):
         self.params = [p for p in params if p.requires_grad]
-        self.buckets = []
-        cur, size = [], 0
+        self.bucket_bytes, self.direct_bytes = bucket_bytes, direct_bytes
+
+    def _plan(self):
+        """-> (direct: list of flat tensors aliasing gradient storages, buckets: list of lists of gradient tensors)."""
+        groups = {}
         for p in reversed(self.params):
-            cur.append(p)
-            size += p.numel() * 4
-            if size >= bucket_bytes:
-                self.buckets.append(cur)
+            g = p.grad
+            if g is None:
+                g = p.grad = torch.zeros_like(p)
+            groups.setdefault(g.untyped_storage().data_ptr(), []).append(g)
+        direct, small = [], []
+        for gs in groups.values():
+            gs = sorted(gs, key=lambda t: t.storage_offset())
+            covered = all(t.is_contiguous() for t in gs) and all(a.storage_offset() + a.numel() == b.storage_offset() for a, b in zip(gs, gs[1:]))
+            total = sum(t.numel() for t in gs)
+            if covered and len({t.dtype for t in gs}) == 1 and total * gs[0].element_size() >= self.direct_bytes:
+                direct.append(torch.empty(0, dtype=gs[0].dtype, device=gs[0].device).set_(gs[0].untyped_storage(), gs[0].storage_offset(), (total,)))
+            else:
+                small.extend(gs)
+        buckets, cur, size = [], [], 0
+        for g in small:
+            cur.append(g)
+            size += g.numel() * g.element_size()
+            if size >= self.bucket_bytes:
+                buckets.append(cur)
                 cur, size = [], 0
         if cur:
-            self.buckets.append(cur)
+            buckets.append(cur)
+        return direct, buckets
 
     def reduce(self, average=False):
-        """SUM (or mean) all-reduce of every parameter gradient.  Per bucket: one concatenation kernel, one asynchronous
-        all-reduce, and the parameters' .grad become VIEWS of the reduced flat buffer (no copy back)."""
+        """SUM (or mean) all-reduce of every parameter gradient, in place."""
         if not is_dist():
             return
         ws = dist.get_world_size()
-        flats, works = [], []
-        for b in self.buckets:
-            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b])
-            flats.append(flat)
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
-        for b, flat, w in zip(self.buckets, flats, works):
+        direct, buckets = self._plan()
+        works = [dist.all_reduce(f, op=dist.ReduceOp.SUM, async_op=True) for f in direct]
+        flats = [torch.cat([g.reshape(-1) for g in b]) for b in buckets]
+        works += [dist.all_reduce(f, op=dist.ReduceOp.SUM, async_op=True) for f in flats]
+        for w in works:
             w.wait()
-            if average:
-                flat.div_(ws)
-            off = 0
-            for p in b:
-                n = p.numel()
-                p.grad = flat[off:off + n].view_as(p)
-                off += n
+        if average:
+            for f in direct + flats:
+                f.div_(ws)
+        for b, flat in zip(buckets, flats):
+            torch._foreach_copy_(b, list(flat.split([g.numel() for g in b])) if all(g.dim() == 1 for g in b)
+                                 else [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in b]), b)])

@@ -43,9 +43,13 @@ def _worker(rank, world, port, out):
     # local mean-over-frames loss (what MLE_Loss computes, Modules.py:1026), turned into this rank's share of the global loss
     loss = _nll_sum(model, xs, ls) / local_frames * global_frame_weight(local_frames)
     loss.backward()
-    red = FlatGradReducer(list(model.parameters()), bucket_bytes=256)     # tiny buckets: exercises several
-    assert len(red.buckets) > 1
+    # tiny thresholds: several buckets for the small gradients AND the zero-copy path for the larger ones
+    red = FlatGradReducer(list(model.parameters()), bucket_bytes=16, direct_bytes=128)
+    direct, buckets = red._plan()
+    assert len(buckets) > 1 and len(direct) >= 1
+    ptrs = [p.grad.data_ptr() for p in model.parameters()]
     red.reduce(average=False)
+    assert ptrs == [p.grad.data_ptr() for p in model.parameters()], "the reduction must be in place (hipGraph replays rely on it)"
     stats = torch.tensor([float(rank + 1), 2.0, float(local_frames)])
     actnorm_stats_allreduce(stats)
     if rank == 0:
