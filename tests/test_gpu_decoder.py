@@ -127,11 +127,9 @@ def test_actnorm_data_init_matches_reference():
         assert (W["an_bias"][f].cpu() - want_b).abs().max() < 2e-4, f
 
 
-@pytest.mark.parametrize("precision,ztol", [(0, 2e-4), (1, 6e-2)])
-def test_full_width_forward(precision, ztol):
-    """Default Hyper_Parameters sizes (C=160, H=192, 4 layers, k=5), 3 flows, ragged lengths, seeded weights."""
-    cfg = O.Cfg(n_flows=3)
-    g = torch.Generator().manual_seed(99)
+def full_width_state(n_flows, g):
+    """Seeded decoder weights at the default Hyper_Parameters sizes (C=160, H=192, 4 layers, k=5)."""
+    cfg = O.Cfg(n_flows=n_flows)
     sd = {}
     for f in range(cfg.n_flows):
         q = f"layer_Dict.Decoder.layer_Dict.Flows.{f}.layers"
@@ -151,6 +149,14 @@ def test_full_width_forward(precision, ztol):
             wn(f"WaveNet.layer_Dict.Res_Skip_{l}", 384 if l < 3 else 192, 192, 1)
         sd[f"{q}.2.layer_Dict.End.weight"] = torch.randn(160, 192, 1, generator=g) * 0.02
         sd[f"{q}.2.layer_Dict.End.bias"] = torch.randn(160, generator=g) * 0.02
+    return cfg, sd
+
+
+@pytest.mark.parametrize("precision,ztol", [(0, 2e-4), (1, 6e-2)])
+def test_full_width_forward(precision, ztol):
+    """Default Hyper_Parameters sizes, 3 flows, ragged lengths, seeded weights, against the oracle."""
+    g = torch.Generator().manual_seed(99)
+    cfg, sd = full_width_state(3, g)
     B, Tm = 3, 300
     ml = torch.tensor([300, 262, 120])
     mels = (torch.randn(B, 80, Tm, generator=g) * 1.5).clamp(-4, 4)
@@ -210,3 +216,35 @@ def test_fused_weightnorm_matches_torch():
         w2.backward(dw)
         for a, b in zip(got, (w2.detach(), g.grad, v.grad)):
             assert (a - b).abs().max() <= 1e-5 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("precision,tol", [(0, 2e-3), (1, 0.25)])
+def test_full_size_roundtrip_and_invariants(precision, tol):
+    """BASELINE config 2 size (12 flows, B = 32, 800 frames, ragged): the oracle would need minutes here, so size-independent
+    properties instead.  (1) inverse(forward(x)) == x on the valid frames (the flow is a bijection, Modules.py:298-309 vs 664);
+    (2) padded frames of z are exactly zero; (3) permuting the utterances permutes z and the log-determinants (no cross-talk
+    between utterances that share row tiles); (4) an utterance's result does not depend on the batch it sits in."""
+    from glow_tts_amd import decoder as D
+    g = torch.Generator().manual_seed(7)
+    cfg, sd = full_width_state(12, g)
+    B, Tm = 32, 800
+    ml = (torch.randint(200, 401, (B,), generator=g) * 2)
+    ml[0], ml[5] = 800, 2                                           # the longest and a one-squeezed-frame utterance
+    mels = (torch.randn(B, 80, Tm, generator=g) * 1.5).clamp(-4, 4)
+    mask = O.mask_from_lengths(ml, Tm)
+    mels = mels * mask
+    z, logdet, P, dc = run_hip_decoder(sd, cfg, mels, ml, precision)
+    assert torch.isfinite(z).all() and torch.isfinite(logdet).all()
+    assert (z.cpu() * (1 - mask)).abs().max() == 0
+    W = dict(zip(D.WEIGHT_KEYS, [w.detach().contiguous() for w in D.stack_decoder_weights(P, dc)]))
+    back = D.decoder_inverse(dc, W, z.detach().contiguous(), ml.cuda(), fill=0.0)
+    assert ((back.cpu() - mels) * mask).abs().max() <= tol
+    perm = torch.randperm(B, generator=g)
+    z2, ld2, _, _ = run_hip_decoder(sd, cfg, mels[perm], ml[perm], precision)
+    # (not bit-exact: a row tile's K-chunk order depends on its position, so fp32 sums associate differently; cross-talk would be O(1))
+    ptol = 5e-4 if precision == 0 else 0.15
+    close = lambda a, b: (a - b).abs().max().item() <= ptol * max(1.0, b.abs().max().item())
+    assert close(z2.cpu(), z.cpu()[perm]) and close(ld2.cpu(), logdet.cpu()[perm])
+    z3, ld3, _, _ = run_hip_decoder(sd, cfg, mels[3:5], ml[3:5], precision)
+    Ts = int(ml[3:5].max())
+    assert close(z3.cpu()[:, :, :Ts], z.cpu()[3:5, :, :Ts]) and close(ld3.cpu(), logdet.cpu()[3:5])
