@@ -98,6 +98,7 @@ class ParamGate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tape, *params):
         ctx.tape = tape
+        ctx.set_materialize_grads(False)      # gradients of gated tensors nobody used stay None (no zero tensors to add downstream)
         return tuple(p.detach() for p in params)
 
     @staticmethod

@@ -75,13 +75,15 @@ int coupling_net(const Ctx& c, const float* xsrc, float* xdst, bool reverse, boo
             a.epi = GLOWTTS_EPI_RESSKIP; a.flags = (l == 0 ? GLOWTTS_F_FIRST : 0) | (last ? GLOWTTS_F_LAST : 0);
             a.bias = p->b_rs[l];
             a.in0 = hin; a.ldi0 = H; a.out0 = last ? A->skip : hout; a.ld0 = H; a.out1 = A->skip; a.ld1 = H;
-            a.io_flags = bf ? (GLOWTTS_IO_A_BF16 | GLOWTTS_IO_IN0_BF16 | GLOWTTS_IO_OUT0_BF16) : 0;     // (last layer: out0 is unused)
+            a.io_flags = bf ? (GLOWTTS_IO_A_BF16 | GLOWTTS_IO_IN0_BF16 | GLOWTTS_IO_OUT0_BF16) : 0;
+            if (bf && last && A->skip_bf) { a.out0 = A->skip_bf; a.ld0 = H; }     // last layer: out0 = bf16 copy of the final skip sum
             CHECK(glowtts_conv_cl(&a, c.s));
         }
     }
     {   // End + affine coupling                                                 Modules.py:793-806
         glowtts_conv_args a = base_args(c, p->end, 1);
-        a.a = A->skip; a.lda = H; a.ca = H; a.n = c.d->C; a.h = c.C2;
+        if (bf && A->skip_bf) { a.a = A->skip_bf; a.io_flags = GLOWTTS_IO_A_BF16; } else a.a = A->skip;
+        a.lda = H; a.ca = H; a.n = c.d->C; a.h = c.C2;
         a.epi = GLOWTTS_EPI_COUPLE; a.flags = reverse ? GLOWTTS_F_REVERSE : 0; a.bias = p->b_end;
         a.in0 = xsrc + c.C2; a.ldi0 = c.d->C;
         a.out0 = xdst + c.C2; a.ld0 = c.d->C;
@@ -193,8 +195,8 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
         q.out0 = g->dskip; q.ld0 = H; q.io_flags = bfg ? GLOWTTS_IO_OUT0_BF16 : 0;
         CHECK(glowtts_conv_cl(&q, stream));
         if (!g->defer_wgrad) {
-            glowtts_wgrad_args w = wargs(g->douts, ldo, ldo, a->skip, H, H, 1, g->dw_end, g->db_end);
-            w.perm = GLOWTTS_PERM_PAIR; w.perm_h = C2;
+            glowtts_wgrad_args w = wargs(g->douts, ldo, ldo, (bf && a->skip_bf) ? a->skip_bf : a->skip, H, H, 1, g->dw_end, g->db_end);
+            w.perm = GLOWTTS_PERM_PAIR; w.perm_h = C2; w.io_flags = (bf && a->skip_bf) ? GLOWTTS_WIO_X_BF16 : 0;
             CHECK(glowtts_wgrad_cl(&w, stream));
         }
     }

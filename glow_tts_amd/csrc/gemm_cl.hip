@@ -274,9 +274,10 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
         // Modules.py:871-883.  Columns [0, h): x = (x + res) * mask -> out0; columns [h, 2h): output += skip -> out1;
         // last layer (n = h): output = (output + res_skip) * mask -> out1.
         const bool last = (fl & GLOWTTS_F_LAST) != 0, first = (fl & GLOWTTS_F_FIRST) != 0;
+        const bool copy_bf = last && out0_bf && (const void*)p.out0 != (const void*)p.out1;     // last layer: out0 = optional bf16 copy of the sum
         const uint32_t e0 = out0_bf ? 2 : 4, ei = in0_bf ? 2 : 4;
         const Rsrc ro0 = mk(p.out0, (long)p.rows * p.ld0 * e0), rin = mk(p.in0, (long)p.rows * p.ldi0 * ei), ro1 = mk(p.out1, (long)p.rows * p.ld1 * 4);
-        uint32_t v0[NI], vin[NI], v1[NI]; float bs[NI]; bool anyres[NI], anyskip[NI];
+        uint32_t v0[NI], vin[NI], v1[NI], vl0[NI]; float bs[NI]; bool anyres[NI], anyskip[NI];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int nb = n0 + (wn * NI + ni) * 32, n = nb + l31;
@@ -285,6 +286,7 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
             v0[ni] = (ok && res) ? (uint32_t)(rb * (int)p.ld0 + n) * e0 : OOB;
             vin[ni] = (ok && res) ? (uint32_t)(rb * (int)p.ldi0 + n) * ei : OOB;
             v1[ni] = (ok && !res) ? (uint32_t)(rb * (int)p.ld1 + (last ? n : n - p.h)) * 4u : OOB;
+            vl0[ni] = (ok && last) ? (uint32_t)(rb * (int)p.ld0 + n) * 2u : OOB;
             anyres[ni] = !last && nb < p.h;                   // wave-uniform: does this fragment hold residual / skip columns at all
             anyskip[ni] = last || nb + 31 >= p.h;
         }
@@ -334,6 +336,8 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
                         for (int q = 0; q < 8; ++q) {
                             const float so = xold[q] + acc[mi][ni][hb * 8 + q] + bs[ni];
                             stf(last ? so * mk8[q] : so, ro1, v1[ni], roff(mi, hb * 8 + q) * (int)p.ld1 * 4);
+                            // last layer + bf16 storage: out0 (otherwise unused) gets a bf16 copy of the final sum - the End conv's A operand
+                            if (copy_bf) sth(so * mk8[q], ro0, vl0[ni], roff(mi, hb * 8 + q) * (int)p.ld0 * 2);
                         }
                     }
                 }
@@ -1139,6 +1143,7 @@ int launch_prec(const glowtts_conv_args& a, hipStream_t s)
             if (a.epi == GLOWTTS_EPI_RESSKIP && a.taps == 1) return launch_dma<GLOWTTS_EPI_RESSKIP, 1>(a, s);
             if (a.epi == GLOWTTS_EPI_DGATE && a.taps == 1) return launch_dma<GLOWTTS_EPI_DGATE, 1>(a, s);
             if (a.epi == GLOWTTS_EPI_LINEAR && a.taps == 1) return launch_dma<GLOWTTS_EPI_LINEAR, 1>(a, s);
+            if (a.epi == GLOWTTS_EPI_COUPLE && a.taps == 1) return launch_dma<GLOWTTS_EPI_COUPLE, 1>(a, s);
         }
         if (a.io_flags & GLOWTTS_IO_A_BF16) {      // bf16-stored A operand: the WaveNet state / gates / gate gradients
             if (a.epi == GLOWTTS_EPI_GATE && a.apro == N) return launch_taps<CT, GLOWTTS_EPI_GATE, GLOWTTS_APRO_NONE, true>(a, s);
@@ -1146,6 +1151,7 @@ int launch_prec(const glowtts_conv_args& a, hipStream_t s)
             if (a.epi == GLOWTTS_EPI_RESSKIP && a.apro == PM && a.taps == 1) return launch_tile<CT, GLOWTTS_EPI_RESSKIP, 1, GLOWTTS_APRO_PAIRMUL, true>(a, s);
             if (a.epi == GLOWTTS_EPI_RESSKIP && a.apro == N && a.taps == 1) return launch_tile<CT, GLOWTTS_EPI_RESSKIP, 1, GLOWTTS_APRO_NONE, true>(a, s);
             if (a.epi == GLOWTTS_EPI_DGATE && a.apro == N && a.taps == 1) return launch_tile<CT, GLOWTTS_EPI_DGATE, 1, GLOWTTS_APRO_NONE, true>(a, s);
+            if (a.epi == GLOWTTS_EPI_COUPLE && a.apro == N && a.taps == 1) return launch_tile<CT, GLOWTTS_EPI_COUPLE, 1, GLOWTTS_APRO_NONE, true>(a, s);
             return GLOWTTS_E_ARG;
         }
     } else if (a.io_flags) return GLOWTTS_E_ARG;   // fp32 precision keeps every activation in fp32

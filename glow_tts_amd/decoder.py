@@ -40,7 +40,7 @@ class FlowParams(ctypes.Structure):
 class FlowActs(ctypes.Structure):
     _fields_ = [("xin", c_void_p), ("xmid", c_void_p), ("xout", c_void_p),
                 ("hs", c_void_p * MAXL), ("gates", c_void_p * MAXL), ("skip", c_void_p), ("outs", c_void_p),
-                ("rowmask", c_void_p), ("acts", c_void_p * MAXL)]
+                ("rowmask", c_void_p), ("acts", c_void_p * MAXL), ("skip_bf", c_void_p)]
 
 
 class FlowGrads(ctypes.Structure):
@@ -288,6 +288,7 @@ class _Buffers:
         self.hs = torch.empty(F_, L, R, H, device=dev, dtype=cfg.act_dtype)
         self.gates = torch.empty(F_, L, R, 2 * H, device=dev, dtype=cfg.act_dtype)
         self.actp = torch.empty(F_, L, R, H, device=dev, dtype=torch.bfloat16) if cfg.act_bf16 else None     # tanh * sigmoid
+        self.skipb = torch.empty(F_, R, H, device=dev, dtype=torch.bfloat16) if cfg.act_bf16 else None      # bf16 copy of skip (End conv operand)
         self.skip = torch.empty(F_, R, H, device=dev)
         self.outs = torch.empty(F_, R, prep.ldo, device=dev)
 
@@ -299,6 +300,8 @@ class _Buffers:
             a.gates[l] = self.gates[f, l].data_ptr()
             if self.actp is not None:
                 a.acts[l] = self.actp[f, l].data_ptr()
+        if self.skipb is not None:
+            a.skip_bf = self.skipb[f].data_ptr()
         a.skip, a.outs, a.rowmask = self.skip[f].data_ptr(), self.outs[f].data_ptr(), rowmask.data_ptr()
         return a
 
@@ -337,6 +340,7 @@ def decoder_inverse(cfg, W, z, lengths, cond=None, fill=None):
     hs = torch.empty(2, R, cfg.H, device=dev, dtype=cfg.act_dtype)
     gates = torch.empty(R, 2 * cfg.H, device=dev, dtype=cfg.act_dtype)
     actp = torch.empty(R, cfg.H, device=dev, dtype=torch.bfloat16) if cfg.act_bf16 else None
+    skipb = torch.empty(R, cfg.H, device=dev, dtype=torch.bfloat16) if cfg.act_bf16 else None
     skip = torch.empty(R, cfg.H, device=dev)
     dims = _dims(cfg, B, T)
     cur, nxt = x, other
@@ -346,7 +350,7 @@ def decoder_inverse(cfg, W, z, lengths, cond=None, fill=None):
         a.hs[0], a.hs[1] = hs[0].data_ptr(), hs[1].data_ptr()
         a.gates[0], a.skip, a.rowmask = gates.data_ptr(), skip.data_ptr(), rowmask.data_ptr()
         if actp is not None:
-            a.acts[0] = actp.data_ptr()
+            a.acts[0], a.skip_bf = actp.data_ptr(), skipb.data_ptr()
         a.outs = None
         _lib.check(L.glowtts_flow_inverse(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(a), _lib.stream()),
                    "glowtts_flow_inverse")
@@ -446,7 +450,7 @@ class DecoderFunction(torch.autograd.Function):
         order = list(range(F_ - 1, -1, -1))
         for f in order:       # weight-gradient problems of every flow (autograd of Modules.py:791,861,871,793): all pointers are known up front
             g1.add(douts[f].data_ptr(), prep.ldo, prep.ldo, buf.skip[f].data_ptr(), H, H, G["w_end"][f].data_ptr(), G["b_end"][f].data_ptr(),
-                   perm=ops.PERM_PAIR, perm_h=C2)
+                   perm=ops.PERM_PAIR, perm_h=C2)                 # (X = the fp32 skip sum: shares the launch with the Start conv)
             for l in range(Lw):
                 gates, ldg = (buf.actp[f, l].data_ptr(), H) if bf else (buf.gates[f, l].data_ptr(), 2 * H)
                 if l == Lw - 1:

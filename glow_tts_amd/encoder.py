@@ -57,7 +57,9 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
             Pc[a + ".QKV.bias"] = torch.cat([P[n + ".bias"] for n in names], 0)
     tape = None
     if torch.is_grad_enabled():
-        gated = [k for k, v in Pc.items() if k.startswith(prefix) and k.endswith(".weight") and v.dim() == 3 and v.requires_grad]
+        fused = (".Query.weight", ".Key.weight", ".Value.weight")                # consumed through the fused QKV tensor only
+        gated = [k for k, v in Pc.items() if k.startswith(prefix) and k.endswith(".weight") and v.dim() == 3 and v.requires_grad
+                 and not k.endswith(fused)]
         gated += [k[:-len(".weight")] + ".bias" for k in gated if (k[:-len(".weight")] + ".bias") in Pc]
         if gated:
             tape = WgradTape()

@@ -291,6 +291,7 @@ typedef struct glowtts_flow_acts {        /* rows tensors, R = B*(T+2*PAD) rows 
     float *outs;                          /* [R][ldo] PAIR-packed (m, logs), ldo = end.npad      (kept) */
     const float *rowmask;                 /* [R] */
     float *acts[GLOWTTS_MAX_WN_LAYERS];   /* act_bf16 only (else NULL): [R][H] bf16 tanh * sigmoid of layer l                (kept) */
+    float *skip_bf;                       /* act_bf16 only (else NULL): [R][H] bf16 copy of `skip` (End conv / its weight gradient) (kept) */
 } glowtts_flow_acts;
 
 typedef struct glowtts_flow_grads {       /* backward outputs; weight grads are ADDED (zero them first) */
