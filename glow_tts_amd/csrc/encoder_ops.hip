@@ -535,11 +535,11 @@ __device__ __forceinline__ float half_sum(float v) {
 __device__ __forceinline__ int acc_row(int reg, int lhi) { return (reg & 3) + 8 * (reg >> 2) + 4 * lhi; }
 
 // rows [0, nrows) x D floats of a [*, ld]-strided global tile -> LDS [128 or 32][LD] (rows >= nrows zero), all 256 threads
-template <int D, int LD, int ROWS>
+template <int D, int LD, int ROWS, int NT = 256>
 __device__ __forceinline__ void stage_rows(float* dst, const float* src, long ld, int nrows, int tid)
 {
     constexpr int Q4 = D / 4;
-    for (int i = tid; i < ROWS * Q4; i += 256) {
+    for (int i = tid; i < ROWS * Q4; i += NT) {
         const int r = i / Q4, c = (i - r * Q4) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < nrows) v = *reinterpret_cast<const float4*>(src + (long)r * ld + c);
@@ -831,11 +831,377 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
     col_products(dbase + C, mypart);
 }
 
-static bool attn_mfma_ok(int Tp, int D, int win)
+// ------------------------------------------------------------------------------------------------
+// The same attention core for 128 < Tp <= 256 (the reference trains on texts of up to 200 tokens).  Scores of one query against 256
+// keys are 8 accumulator tiles per wave, and a [queries][257] probability tile per wave no longer fits LDS next to four waves and a
+// full K / V, so: a workgroup = 2 waves = 64 queries, K and V pass through the 128-row LDS buffer in two halves, and the backward
+// is two kernels - attn_bwd_long_q_kernel per query block (dS -> global, dQ, d relK, d relV: everything that reduces over keys) and
+// attn_bwd_long_kv_kernel per 64-key block (dK, dV: reductions over all queries, with Pd / dS column blocks staged from global).
+// ------------------------------------------------------------------------------------------------
+constexpr int ATL_LDP = 257;
+
+template <int ND>
+__global__ __launch_bounds__(128) void attn_fwd_long_kernel(const float* __restrict__ qkv, const float* __restrict__ relk, const float* __restrict__ relv,
+                                                            const float* __restrict__ rowmask, float* __restrict__ out, float* __restrict__ P,
+                                                            int B, int Tp, int H, int win, float drop_p, uint32_t seed, const uint32_t* __restrict__ seed_ptr)
+{
+    constexpr int D = ND * 32, LD = D + 1, KS = D / 2;
+    extern __shared__ float sm[];
+    float* KV = sm;                               // [128][LD]   one half of K, then of V
+    float* RL = KV + 128 * LD;                    // [32][LD]
+    float* PT = RL + 32 * LD;                     // [2][32][257]
+    float* RQ = PT + 2 * 32 * ATL_LDP;            // [2][32][33]
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int C = H * D, ld = 3 * C, nw = 2 * win + 1, q0 = qb * 64 + wave * 32;
+    const float* base = qkv + (long)b * Tp * ld + h * D;
+    if (seed_ptr && drop_p > 0.f) seed += *seed_ptr;
+    float* myP = PT + wave * 32 * ATL_LDP;
+    float* myR = RQ + wave * 32 * 33;
+    stage_rows<D, LD, 32, 128>(RL, relk, D, nw, tid);
+    {
+        constexpr int Q4 = D / 4;
+        for (int i = lane; i < 32 * Q4; i += 64) {
+            const int r = i / Q4, c = (i - r * Q4) * 4, qi = q0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qi < Tp) v = *reinterpret_cast<const float4*>(base + (long)qi * ld + c);
+            float* o = myP + r * LD + c;
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        }
+    }
+    f32x16 S[8], R;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[t][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) R[r] = 0.f;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        __syncthreads();
+        stage_rows<D, LD, 128, 128>(KV, base + C + (long)hf * 128 * ld, ld, Tp - hf * 128, tid);
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = 2 * ks + lhi;
+            const float a = myP[l31 * LD + k];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) S[hf * 4 + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[(32 * nt + l31) * LD + k], S[hf * 4 + nt], 0, 0, 0);
+            if (hf == 0) R = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RL[l31 * LD + k], R, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) myR[acc_row(reg, lhi) * 33 + l31] = R[reg];
+    __syncthreads();
+    const float isd = rsqrtf((float)D);
+    const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const float* rm = rowmask + (long)b * Tp;
+    float mj[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { const int j = 32 * t + l31; mj[t] = j < Tp ? rm[j] : 0.f; }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = acc_row(reg, lhi), i = q0 + row;
+        const float mi = i < Tp ? rm[i] : 0.f;
+        float sc[8], mx = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int j = 32 * t + l31, dd = j - i + win;
+            float v = S[t][reg];
+            if (dd >= 0 && dd < nw) v += myR[row * 33 + dd];
+            v *= isd;
+            if (mi * mj[t] == 0.f) v = -1e4f;
+            if (j >= Tp) v = -3.0e38f;
+            sc[t] = v; mx = fmaxf(mx, v);
+        }
+        mx = half_max(mx);
+        float den = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { sc[t] = (32 * t + l31 < Tp) ? __expf(sc[t] - mx) : 0.f; den += sc[t]; }
+        den = 1.f / half_sum(den);
+        float* Pg = P + (((long)b * H + h) * Tp + i) * Tp;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int j = 32 * t + l31;
+            float p = sc[t] * den;
+            if (i < Tp && j < Tp) Pg[j] = p;
+            if (drop_p > 0.f) p *= drop_scale(seed, (uint32_t)((((long)b * H + h) * Tp + i) * Tp + j), drop_p, ik);
+            myP[row * ATL_LDP + j] = p;
+        }
+    }
+    f32x16 O[ND];
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[nd][r] = 0.f;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        __syncthreads();
+        stage_rows<D, LD, 128, 128>(KV, base + 2 * C + (long)hf * 128 * ld, ld, Tp - hf * 128, tid);
+        if (hf == 0) stage_rows<D, LD, 32, 128>(RL, relv, D, nw, tid);
+        __syncthreads();
+#pragma unroll 4
+        for (int ks = 0; ks < 64; ++ks) {
+            const int k = 2 * ks + lhi;
+            const float a = myP[l31 * ATL_LDP + hf * 128 + k];
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) O[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[k * LD + 32 * nd + l31], O[nd], 0, 0, 0);
+        }
+    }
+    {
+        const int i = q0 + l31;
+        for (int ks = 0; ks < (nw + 1) / 2; ++ks) {
+            const int dd = 2 * ks + lhi, j = i + dd - win;
+            const float a = (dd < nw && j >= 0 && j < Tp) ? myP[l31 * ATL_LDP + j] : 0.f;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) O[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RL[dd * LD + 32 * nd + l31], O[nd], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int i = q0 + acc_row(reg, lhi);
+        if (i >= Tp) continue;
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd) out[((long)b * Tp + i) * C + h * D + 32 * nd + l31] = O[nd][reg];
+    }
+}
+
+template <int ND>
+__global__ __launch_bounds__(128) void attn_bwd_long_q_kernel(const float* __restrict__ qkv, const float* __restrict__ relk, const float* __restrict__ relv,
+                                                              const float* __restrict__ rowmask, const float* __restrict__ P, const float* __restrict__ dout,
+                                                              float* __restrict__ dSg, float* __restrict__ dqkv, float* __restrict__ part,
+                                                              int B, int Tp, int H, int win, float drop_p, uint32_t seed, const uint32_t* __restrict__ seed_ptr)
+{
+    constexpr int D = ND * 32, LD = D + 1, KS = D / 2;
+    extern __shared__ float sm[];
+    float* KV = sm;
+    float* RL = KV + 128 * LD;
+    float* PT = RL + 32 * LD;
+    float* RQ = PT + 2 * 32 * ATL_LDP;
+    const int qb = blockIdx.x, nqb = gridDim.x, h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int C = H * D, ld = 3 * C, nw = 2 * win + 1, q0 = qb * 64 + wave * 32;
+    const float* base = qkv + (long)b * Tp * ld + h * D;
+    const float* dob = dout + (long)b * Tp * C + h * D;
+    float* dbase = dqkv + (long)b * Tp * ld + h * D;
+    if (seed_ptr && drop_p > 0.f) seed += *seed_ptr;
+    float* myP = PT + wave * 32 * ATL_LDP;
+    float* myR = RQ + wave * 32 * 33;
+    float* mypart = part + ((((long)b * H + h) * nqb + qb) * 2 + wave) * 2 * nw * D;
+    // ---- phase 1: dPd, D_i, dS (registers + global), Pd (LDS) ----
+    stage_rows<D, LD, 32, 128>(RL, relv, D, nw, tid);
+    {
+        constexpr int Q4 = D / 4;
+        for (int i = lane; i < 32 * Q4; i += 64) {
+            const int r = i / Q4, c = (i - r * Q4) * 4, qi = q0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qi < Tp) v = *reinterpret_cast<const float4*>(dob + (long)qi * C + c);
+            float* o = myP + r * LD + c;
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        }
+    }
+    f32x16 S[8], R;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[t][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) R[r] = 0.f;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        __syncthreads();
+        stage_rows<D, LD, 128, 128>(KV, base + 2 * C + (long)hf * 128 * ld, ld, Tp - hf * 128, tid);
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = 2 * ks + lhi;
+            const float a = myP[l31 * LD + k];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) S[hf * 4 + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[(32 * nt + l31) * LD + k], S[hf * 4 + nt], 0, 0, 0);
+            if (hf == 0) R = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RL[l31 * LD + k], R, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) myR[acc_row(reg, lhi) * 33 + l31] = R[reg];
+    __syncthreads();
+    const float isd = rsqrtf((float)D);
+    const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = acc_row(reg, lhi), i = q0 + row;
+        const float* Pg = P + (((long)b * H + h) * Tp + i) * Tp;
+        float* dSr = dSg + (((long)b * H + h) * Tp + i) * Tp;
+        float p0[8], kd[8], dsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int j = 32 * t + l31, dd = j - i + win;
+            float dpd = S[t][reg];
+            if (dd >= 0 && dd < nw) dpd += myR[row * 33 + dd];
+            p0[t] = (i < Tp && j < Tp) ? Pg[j] : 0.f;
+            float keep = 1.f;
+            if (drop_p > 0.f) keep = drop_scale(seed, (uint32_t)((((long)b * H + h) * Tp + i) * Tp + j), drop_p, ik);
+            kd[t] = keep * dpd;
+            dsum += p0[t] * kd[t];
+            myP[row * ATL_LDP + j] = p0[t] * keep;
+        }
+        dsum = half_sum(dsum);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int j = 32 * t + l31;
+            const float ds = p0[t] * (kd[t] - dsum) * isd;
+            S[t][reg] = ds;
+            if (i < Tp && j < Tp) dSr[j] = ds;
+        }
+    }
+    // rel[dd][d] = sum over the wave's 32 queries i of PT[i][i + dd - w] * X[i][d]   (X = dO or Q rows of this workgroup, staged in KV)
+    auto rel_partial = [&](const float* xrows, long xld, float* dst) __attribute__((always_inline)) {
+        __syncthreads();
+        stage_rows<D, LD, 64, 128>(KV, xrows + (long)qb * 64 * xld, xld, Tp - qb * 64, tid);
+        __syncthreads();
+        f32x16 RV[ND];
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) RV[nd][r] = 0.f;
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+            const int il = 2 * ks + lhi, j = q0 + il + l31 - win;
+            const float a = (l31 < nw && j >= 0 && j < Tp) ? myP[il * ATL_LDP + j] : 0.f;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) RV[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[(wave * 32 + il) * LD + 32 * nd + l31], RV[nd], 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = acc_row(reg, lhi);
+            if (row >= nw) continue;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) dst[row * D + 32 * nd + l31] = RV[nd][reg];
+        }
+    };
+    rel_partial(dob, C, mypart + nw * D);                 // d relV (PT holds Pd)
+    __syncthreads();
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = acc_row(reg, lhi);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) myP[row * ATL_LDP + 32 * t + l31] = S[t][reg];
+    }
+    // ---- dQ = dS K + dS_band relK ----
+    f32x16 O[ND];
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[nd][r] = 0.f;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        __syncthreads();
+        stage_rows<D, LD, 128, 128>(KV, base + C + (long)hf * 128 * ld, ld, Tp - hf * 128, tid);
+        if (hf == 0) stage_rows<D, LD, 32, 128>(RL, relk, D, nw, tid);
+        __syncthreads();
+#pragma unroll 4
+        for (int ks = 0; ks < 64; ++ks) {
+            const int k = 2 * ks + lhi;
+            const float a = myP[l31 * ATL_LDP + hf * 128 + k];
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) O[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[k * LD + 32 * nd + l31], O[nd], 0, 0, 0);
+        }
+    }
+    {
+        const int i = q0 + l31;
+        for (int ks = 0; ks < (nw + 1) / 2; ++ks) {
+            const int dd = 2 * ks + lhi, j = i + dd - win;
+            const float a = (dd < nw && j >= 0 && j < Tp) ? myP[l31 * ATL_LDP + j] : 0.f;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) O[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RL[dd * LD + 32 * nd + l31], O[nd], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int qi = q0 + acc_row(reg, lhi);
+        if (qi >= Tp) continue;
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd) dbase[(long)qi * ld + 32 * nd + l31] = O[nd][reg];
+    }
+    rel_partial(base, ld, mypart);                        // d relK (PT holds dS)
+}
+
+// dK / dV of one 64-key block: out[j][d] = sum_i X[i][j] Y[i][d] with (X, Y) = (Pd, dO) and (dS, Q)
+template <int ND>
+__global__ __launch_bounds__(128) void attn_bwd_long_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ P, const float* __restrict__ dSg,
+                                                               const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                               int B, int Tp, int H, float drop_p, uint32_t seed, const uint32_t* __restrict__ seed_ptr)
+{
+    constexpr int D = ND * 32, LD = D + 1;
+    extern __shared__ float sm[];
+    float* XT = sm;                               // [256][65]  column block of Pd, then of dS
+    float* KV = XT + 256 * 65;                    // [128][LD]  half of dO, then of Q
+    const int jb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int C = H * D, ld = 3 * C, j0 = jb * 64;
+    const float* base = qkv + (long)b * Tp * ld + h * D;
+    const float* dob = dout + (long)b * Tp * C + h * D;
+    float* dbase = dqkv + (long)b * Tp * ld + h * D;
+    if (seed_ptr && drop_p > 0.f) seed += *seed_ptr;
+    const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const float* Pb = P + ((long)b * H + h) * Tp * Tp;
+    const float* Sb = dSg + ((long)b * H + h) * Tp * Tp;
+    auto product = [&](const float* yrows, long yld, float* dst) __attribute__((always_inline)) {
+        f32x16 O[ND];
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[nd][r] = 0.f;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            __syncthreads();
+            stage_rows<D, LD, 128, 128>(KV, yrows + (long)hf * 128 * yld, yld, Tp - hf * 128, tid);
+            __syncthreads();
+#pragma unroll 4
+            for (int ks = 0; ks < 64; ++ks) {
+                const int il = 2 * ks + lhi;
+                const float a = XT[(hf * 128 + il) * 65 + 32 * wave + l31];
+#pragma unroll
+                for (int nd = 0; nd < ND; ++nd) O[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[il * LD + 32 * nd + l31], O[nd], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int j = j0 + 32 * wave + acc_row(reg, lhi);
+            if (j >= Tp) continue;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) dst[(long)j * ld + 32 * nd + l31] = O[nd][reg];
+        }
+    };
+    for (int idx = tid; idx < 256 * 64; idx += 128) {       // Pd[:, block]
+        const int i = idx >> 6, jj = idx & 63, j = j0 + jj;
+        float v = 0.f;
+        if (i < Tp && j < Tp) {
+            v = Pb[(long)i * Tp + j];
+            if (drop_p > 0.f) v *= drop_scale(seed, (uint32_t)((((long)b * H + h) * Tp + i) * Tp + j), drop_p, ik);
+        }
+        XT[i * 65 + jj] = v;
+    }
+    product(dob, C, dbase + 2 * C);                         // dV
+    __syncthreads();
+    for (int idx = tid; idx < 256 * 64; idx += 128) {       // dS[:, block]
+        const int i = idx >> 6, jj = idx & 63, j = j0 + jj;
+        XT[i * 65 + jj] = (i < Tp && j < Tp) ? Sb[(long)i * Tp + j] : 0.f;
+    }
+    product(base, ld, dbase + C);                           // dK
+}
+
+static bool attn_mfma_ok(int Tp, int D, int win)          // 1: single-workgroup kernels (Tp <= 128); 2: long kernels (Tp <= 256); 0: general fp32 FMA kernels
 {
     static const bool enabled = [] { const char* e = getenv("GLOWTTS_ATTN_MFMA"); return !(e && e[0] == '0'); }();
     return enabled && Tp <= AT_TP && (D == 64 || D == 96) && 2 * win + 1 <= 32;
 }
+static bool attn_long_ok(int Tp, int D, int win)
+{
+    static const bool enabled = [] { const char* e = getenv("GLOWTTS_ATTN_MFMA"); return !(e && e[0] == '0'); }();
+    return enabled && Tp > AT_TP && Tp <= 256 && (D == 64 || D == 96) && 2 * win + 1 <= 32;
+}
+static size_t attn_long_lds(int D) { return ((size_t)(128 + 32) * (D + 1) + 2 * 32 * ATL_LDP + 2 * 32 * 33) * sizeof(float); }
+static size_t attn_long_kv_lds(int D) { return ((size_t)256 * 65 + (size_t)128 * (D + 1)) * sizeof(float); }
 static size_t attn_mfma_lds(int D) { return ((size_t)(AT_TP + 32) * (D + 1) + 4 * 32 * AT_LDP + 4 * 32 * 33) * sizeof(float); }
 
 static size_t attn_lds_bytes(int Tp, int D, int win, bool)
@@ -859,6 +1225,19 @@ extern "C" int glowtts_rpr_attention_fwd(const float* qkv, const float* relk, co
         }
         RET_LAUNCH();
     }
+    if (attn_long_ok(Tp, D, win)) {
+        const size_t l2 = attn_long_lds(D);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const dim3 grid((Tp + 63) / 64, H, B);
+        if (D == 96) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_long_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+            hipLaunchKernelGGL(attn_fwd_long_kernel<3>, grid, dim3(128), l2, st, qkv, relk, relv, rowmask, out, P, B, Tp, H, win, drop_p, seed, seed_ptr);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_long_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+            hipLaunchKernelGGL(attn_fwd_long_kernel<2>, grid, dim3(128), l2, st, qkv, relk, relv, rowmask, out, P, B, Tp, H, win, drop_p, seed, seed_ptr);
+        }
+        RET_LAUNCH();
+    }
     const size_t lds = attn_lds_bytes(Tp, D, win, false);
     if (lds > 160 * 1024) return GLOWTTS_E_ARG;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -867,7 +1246,7 @@ extern "C" int glowtts_rpr_attention_fwd(const float* qkv, const float* relk, co
     RET_LAUNCH();
 }
 
-extern "C" int64_t glowtts_rpr_attention_scratch_floats(int B, int Tp, int H, int D, int win) { return (int64_t)B * H * 4 * 2 * (2 * win + 1) * D; }
+extern "C" int64_t glowtts_rpr_attention_scratch_floats(int B, int Tp, int H, int D, int win) { return (int64_t)B * H * 8 * 2 * (2 * win + 1) * D; }
 
 extern "C" int glowtts_rpr_attention_bwd(const float* qkv, const float* relk, const float* relv, const float* rowmask, const float* P, const float* dout,
                                          float* dS /* [B][H][Tp][Tp] scratch */, float* dqkv, float* drelk, float* drelv, float* scratch,
@@ -889,6 +1268,22 @@ extern "C" int glowtts_rpr_attention_bwd(const float* qkv, const float* relk, co
             hipLaunchKernelGGL(attn_bwd_mfma_kernel<2>, dim3(H, B), dim3(256), l2, st, qkv, relk, relv, rowmask, P, dout, dqkv, scratch, B, Tp, H, win, drop_p, seed, seed_ptr);
         }
         prow = B * H * 4;
+    } else if (attn_long_ok(Tp, D, win)) {
+        const size_t l2 = attn_long_lds(D), l3 = attn_long_kv_lds(D);
+        const int nqb = (Tp + 63) / 64;
+        const dim3 grid(nqb, H, B);
+        if (D == 96) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_long_q_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_long_kv_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3);
+            hipLaunchKernelGGL(attn_bwd_long_q_kernel<3>, grid, dim3(128), l2, st, qkv, relk, relv, rowmask, P, dout, dS, dqkv, scratch, B, Tp, H, win, drop_p, seed, seed_ptr);
+            hipLaunchKernelGGL(attn_bwd_long_kv_kernel<3>, grid, dim3(128), l3, st, qkv, P, dS, dout, dqkv, B, Tp, H, drop_p, seed, seed_ptr);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_long_q_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_long_kv_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3);
+            hipLaunchKernelGGL(attn_bwd_long_q_kernel<2>, grid, dim3(128), l2, st, qkv, relk, relv, rowmask, P, dout, dS, dqkv, scratch, B, Tp, H, win, drop_p, seed, seed_ptr);
+            hipLaunchKernelGGL(attn_bwd_long_kv_kernel<2>, grid, dim3(128), l3, st, qkv, P, dS, dout, dqkv, B, Tp, H, drop_p, seed, seed_ptr);
+        }
+        prow = B * H * nqb * 2;
     } else {
         const size_t lds = attn_lds_bytes(Tp, D, win, true);
         if (lds > 160 * 1024) return GLOWTTS_E_ARG;

@@ -344,7 +344,8 @@ int glowtts_embedding_fwd(const int64_t *tokens, const float *table, const float
 int glowtts_embedding_bwd(const int64_t *tokens, const float *drows, const float *rowmask, float *dtable, int V, int B, int T, int C, float scale, void *stream);
 /* Relative-position multi-head self-attention core (RPR_MHA.py:95-128; window `win`, embeddings shared over heads).
  * qkv rows [B][Tp][3*H*D] (Q | K | V); out rows [B][Tp][H*D]; P [B][H][Tp][Tp] is kept for the backward (opaque to the caller:
- * the MFMA path - Tp <= 128, D in {64, 96}, win <= 15 - stores the probabilities before dropout, the general path after). Tp <= 256.
+ * the MFMA paths - D in {64, 96}, win <= 15; one workgroup per (utterance, head) for Tp <= 128, query / key blocks above - store the
+ * probabilities before dropout, the general path after). Tp <= 256.
  * The backward takes the forward's (seed, seed_ptr): it regenerates the dropout keep mask. */
 int glowtts_rpr_attention_fwd(const float *qkv, const float *relk, const float *relv, const float *rowmask, float *out, float *P,
                               int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t *seed_ptr, void *stream);
