@@ -202,6 +202,20 @@ class GlowTTS(torch.nn.Module):
         self.overlap_encoder = os.environ.get("GLOWTTS_ENCODER_OVERLAP", "1") == "1"
 
     # ---------------------------------------------------------------- helpers
+    def __getstate__(self):
+        # run-time caches (HIP stream, flat parameter storage views) are rebuilt on first use: keep them out of copies / pickles
+        st = self.__dict__.copy()
+        st["_enc_stream"], st["_dec_stacks"], st["_enc_cache"] = None, None, {}
+        return st
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     def _params(self):
         return dict(self.named_parameters())
 

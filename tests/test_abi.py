@@ -36,3 +36,21 @@ def test_product_path_has_no_oracle_import():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in re.sub(r"#.*", "", src).replace('"""', ""), f"{f} mentions oracle"
+
+
+def test_model_deepcopy_and_state_dict_roundtrip_cpu():
+    """The module stays an ordinary torch.nn.Module on the host: deepcopy (run-time caches dropped), state_dict round trip."""
+    import copy, os, sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import tiny_hp_dict
+    from glow_tts_amd.hparams import Recursive_Parse
+    from glow_tts_amd.modules import GlowTTS
+    m = GlowTTS(Recursive_Parse(tiny_hp_dict("Vanilla")))
+    m._enc_cache["x"] = object()
+    c = copy.deepcopy(m)
+    assert c._enc_cache == {} and c._dec_stacks is None
+    sd = m.state_dict()
+    assert set(sd) == set(c.state_dict()) and all(torch.equal(sd[k], c.state_dict()[k]) for k in sd)
+    assert all(a.data_ptr() != b.data_ptr() for a, b in zip(m.parameters(), c.parameters()))
+    c.load_state_dict(sd, strict=True)
