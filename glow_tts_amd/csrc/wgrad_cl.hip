@@ -30,6 +30,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BMO = 128;      // o per block
 constexpr int BNC = 64;       // c per block
 constexpr int BK = 64;        // rows per step
+#ifndef WGRAD_WAVES
+#define WGRAD_WAVES 8
+#endif
+constexpr int NT = WGRAD_WAVES * 64;          // threads per workgroup: 8 waves = 4 (o) x 2 (c) wave tiles of 32 x 32 (x taps)
+constexpr int MI = WGRAD_WAVES == 8 ? 1 : 2; // 32-row fragments of o per wave
 
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -67,7 +72,7 @@ __device__ __forceinline__ void ldgw(uint32_t* dst, const unsigned char* src) {
 // job of this workgroup: p (by value when there is a single problem, else looked up in the device table by tile index)
 // DYBF / XBF: DY / X are stored as bf16 in HBM (bf16 precision only; glowtts_wgrad_args.io_flags) - then staging is a raw copy.
 template <typename CT, int TAPS, int XPRO, bool DYBF, bool XBF>
-__global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job single, const glowtts_wgrad_job* __restrict__ table, const WCommon cm)
+__global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job single, const glowtts_wgrad_job* __restrict__ table, const WCommon cm)
 {
     glowtts_wgrad_job p = single;
     int tile = blockIdx.x;
@@ -85,10 +90,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
     constexpr int LDX = BNC * ES + 64;
     constexpr int DY_BYTES = BK * LDY, X_BYTES = XROWS * LDX;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (DY_BYTES + X_BYTES)];
-    __shared__ float bias_red[8][BMO];
+    __shared__ float bias_red[NT / (BMO / 4)][BMO];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;                 // wave tile: 64 (o) x 32 (c)
+    const int wm = wave >> 1, wn = wave & 1;                 // wave tile: MI * 32 (o) x 32 (c)
     const int o0 = tile_o * BMO, c0 = tile_c * BNC;
     const int l31 = lane & 31, lhi = lane >> 5;
 
@@ -99,9 +104,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
     if (rbeg >= rend) return;
     const int nsteps = (int)((rend - rbeg + BK - 1) / BK);
 
-    f32x16 acc[2][TAPS];
+    f32x16 acc[MI][TAPS];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -109,8 +114,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
 
     // ---- staging: raw unconditional loads (clamped addresses) two steps ahead; masks / prologue / bf16 conversion at the
     //      LDS store (same reasoning as conv_cl_kernel: a fixed number of loads per step keeps the vmcnt waits counted) ----
-    constexpr int DY_IT = (BK * BMO / 4) / 256;               // float4 per thread for the DY tile (= 4)
-    constexpr int X_IT = (XROWS * BNC / 4 + 255) / 256;       // 4-channel groups per thread for the X tile
+    constexpr int DY_IT = (BK * BMO / 4) / NT;                // 4-channel groups per thread for the DY tile
+    constexpr int X_IT = (XROWS * BNC / 4 + NT - 1) / NT;     // 4-channel groups per thread for the X tile
     constexpr int XL = (XPRO == GLOWTTS_APRO_PAIRMUL) ? 2 : 1;
     static_assert(!(DYBF || XBF) || ES == 2, "bf16 activation storage needs bf16 precision");
     // raw register image of one item = 4 (x XL) stored elements: 16 B (f32) / 8 B (bf16) per 4 elements
@@ -128,14 +133,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
     auto gload = [&](DYRegs& rdy, XRegs& rx, long r0) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < DY_IT; ++it) {
-            const int idx = tid + it * 256;
+            const int idx = tid + it * NT;
             const int row = idx / (BMO / 4), c4 = idx % (BMO / 4);
             const long r = min(r0 + row, (long)cm.rows - 1);
             ldgw<DYW>(rdy[it], reinterpret_cast<const unsigned char*>(p.dy) + (r * p.lddy + min(o0 + c4 * 4, lim_dy)) * (DYBF ? 2 : 4));
         }
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
-            const int idx = tid + it * 256;
+            const int idx = tid + it * NT;
             const int row = idx / (BNC / 4), c4 = idx % (BNC / 4);
             long r = r0 + row - cm.pad;
             r = r < 0 ? 0 : (r >= cm.rows ? cm.rows - 1 : r);
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
         unsigned char* xb = dyb + DY_BYTES;
 #pragma unroll
         for (int it = 0; it < DY_IT; ++it) {
-            const int idx = tid + it * 256;
+            const int idx = tid + it * NT;
             const int row = idx / (BMO / 4), c4 = idx % (BMO / 4);
             const bool ok = (r0 + row < rend) && (o0 + c4 * 4 < p.m);            // m is a multiple of 4 (checked on the host)
             if constexpr (DYBF) {
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
         }
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
-            const int idx = tid + it * 256;
+            const int idx = tid + it * NT;
             const int row = idx / (BNC / 4), c4 = idx % (BNC / 4);
             if (row >= XROWS) continue;
             const long r = r0 + row - cm.pad;
@@ -208,10 +213,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
 #pragma unroll
             for (int k16 = 0; k16 < BK / 16; ++k16) {
                 const int krow = k16 * 16 + 8 * lhi + (s >> 2);          // + 4 for the second read
-                bf16x8 af[2];
+                bf16x8 af[MI];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    const int col = (wm * 2 + mi) * 32 + gq * 16 + 4 * (s & 3);
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int col = (wm * MI + mi) * 32 + gq * 16 + 4 * (s & 3);
                     const unsigned char* a0 = dyb + krow * LDY + col * 2;
                     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
                     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 4 * LDY));
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
                     s16x4 tmp[2] = {lo, hi};
                     const bf16x8 bfr = *reinterpret_cast<bf16x8*>(tmp);
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < MI; ++mi)
                         acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr, acc[mi][t], 0, 0, 0);
                 }
             }
@@ -235,15 +240,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
 #pragma unroll 4
             for (int k2 = 0; k2 < BK / 2; ++k2) {
                 const int krow = k2 * 2 + lhi;
-                float af[2];
+                float af[MI];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-                    af[mi] = *reinterpret_cast<const float*>(dyb + krow * LDY + ((wm * 2 + mi) * 32 + l31) * 4);
+                for (int mi = 0; mi < MI; ++mi)
+                    af[mi] = *reinterpret_cast<const float*>(dyb + krow * LDY + ((wm * MI + mi) * 32 + l31) * 4);
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) {
                     const float bv = *reinterpret_cast<const float*>(xb + (krow + t) * LDX + (wn * 32 + l31) * 4);
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < MI; ++mi)
                         acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bv, acc[mi][t], 0, 0, 0);
                 }
             }
@@ -271,10 +276,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
     // ---- epilogue: dW[o][c][t] ----
     const bool atomic = gridDim.z > 1 || cm.accumulate;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const int pcol = o0 + (wm * 2 + mi) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhi;    // DY column (possibly PAIR-packed)
+            const int pcol = o0 + (wm * MI + mi) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhi;    // DY column (possibly PAIR-packed)
             if (pcol >= p.m) continue;
             int o = pcol;
             if (p.perm == GLOWTTS_PERM_PAIR) {
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const glowtts_wgrad_job sing
         if (tid < BMO) {
             float s = 0.f;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) s += bias_red[g][tid];
+            for (int g = 0; g < NT / (BMO / 4); ++g) s += bias_red[g][tid];
             const int pcol = o0 + tid;
             if (pcol < p.m) {
                 int o = pcol; bool ok = true;
@@ -320,9 +325,9 @@ template <typename CT, int XPRO, bool DYBF, bool XBF>
 int launch_x(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const WCommon& cm, int taps, dim3 grid, hipStream_t s)
 {
     switch (taps) {
-        case 1: hipLaunchKernelGGL((wgrad_kernel<CT, 1, XPRO, DYBF, XBF>), grid, dim3(256), 0, s, one, table, cm); break;
-        case 3: hipLaunchKernelGGL((wgrad_kernel<CT, 3, XPRO, DYBF, XBF>), grid, dim3(256), 0, s, one, table, cm); break;
-        case 5: hipLaunchKernelGGL((wgrad_kernel<CT, 5, XPRO, DYBF, XBF>), grid, dim3(256), 0, s, one, table, cm); break;
+        case 1: hipLaunchKernelGGL((wgrad_kernel<CT, 1, XPRO, DYBF, XBF>), grid, dim3(NT), 0, s, one, table, cm); break;
+        case 3: hipLaunchKernelGGL((wgrad_kernel<CT, 3, XPRO, DYBF, XBF>), grid, dim3(NT), 0, s, one, table, cm); break;
+        case 5: hipLaunchKernelGGL((wgrad_kernel<CT, 5, XPRO, DYBF, XBF>), grid, dim3(NT), 0, s, one, table, cm); break;
         default: return GLOWTTS_E_ARG;
     }
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
