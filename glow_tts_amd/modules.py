@@ -196,6 +196,7 @@ class GlowTTS(torch.nn.Module):
                                              hp.Decoder.Affine_Coupling.Calc_Channels, wn.Num_Layers, wn.Kernel_Size, prec)
         self.actnorm_allreduce = None     # set by the data-parallel wrapper (glow_tts_amd.distributed)
         self._enc_stream = None
+        self._pcache = None               # name -> Parameter (see _params)
         self._dec_stacks = None           # decoder.DecoderStacks: flat per-class parameter storage, built on first use
         self._enc_cache = {}              # encoder leaf stacks (fused Query/Key/Value weights)
         self._register_state_dict_hook(_unshare_state_dict)
@@ -205,7 +206,7 @@ class GlowTTS(torch.nn.Module):
     def __getstate__(self):
         # run-time caches (HIP stream, flat parameter storage views) are rebuilt on first use: keep them out of copies / pickles
         st = self.__dict__.copy()
-        st["_enc_stream"], st["_dec_stacks"], st["_enc_cache"] = None, None, {}
+        st["_enc_stream"], st["_dec_stacks"], st["_enc_cache"], st["_pcache"] = None, None, {}, None
         return st
 
     def __deepcopy__(self, memo):
@@ -217,7 +218,15 @@ class GlowTTS(torch.nn.Module):
         return new
 
     def _params(self):
-        return dict(self.named_parameters())
+        # name -> Parameter, cached: walking 515 parameters costs ~1 ms of host time per call (eager launches are host-bound)
+        if self._pcache is None:
+            self._pcache = dict(self.named_parameters())
+        return self._pcache
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)           # .to() / .cuda() / .float(): parameter objects may be replaced
+        self._pcache, self._dec_stacks, self._enc_cache = None, None, {}
+        return out
 
     def _stacks(self, P):
         if self._dec_stacks is None:
