@@ -57,5 +57,12 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream (as an integer for ctypes).  Called once per kernel launch: the raw accessor avoids
+    building a torch.cuda.Stream object each time (eager launches are host-bound)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
