@@ -97,3 +97,113 @@ extern "C" int glowtts_weightnorm_bwd(const float* dw, const float* v, const flo
                        (long)rows, cols);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Optimizer side of the step: Rectified Adam exactly as the reference's Radam.py:25-90 and the global gradient
+// norm / clipping of torch.nn.utils.clip_grad_norm_ (Train.py:228-231), as multi-tensor launches over a device job table:
+// the reference walks ~500 parameter tensors in a Python loop with ~10 small torch kernels each.
+// One job = one contiguous run of elements (a stacked weight class is ONE job); blocks of OPT_CHUNK elements.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int OPT_CHUNK = 4096;        // elements per workgroup
+
+__device__ __forceinline__ const glowtts_opt_job& find_job(const glowtts_opt_job* __restrict__ jobs, int njobs, long block, long& first)
+{
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].block0 <= block) lo = mid; else hi = mid - 1; }
+    first = (block - jobs[lo].block0) * OPT_CHUNK;
+    return jobs[lo];
+}
+
+// partial[b] = sum of g^2 over block b
+__global__ __launch_bounds__(256) void multi_sqnorm_kernel(const glowtts_opt_job* __restrict__ jobs, int njobs, float* __restrict__ partial)
+{
+    long first;
+    const glowtts_opt_job& j = find_job(jobs, njobs, blockIdx.x, first);
+    const long end = min(first + OPT_CHUNK, (long)j.n);
+    float s = 0.f;
+    for (long i = first + threadIdx.x; i < end; i += 256) { const float g = j.g[i]; s += g * g; }
+    s = wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// norm[0] = sqrt(sum partial), norm[1] = clip coefficient min(1, max_norm / (norm + 1e-6))   (one workgroup, fixed order)
+__global__ __launch_bounds__(256) void norm_final_kernel(const float* __restrict__ partial, int n, float max_norm, float* __restrict__ norm)
+{
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    s = wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        norm[0] = t;
+        const float c = max_norm / (t + 1e-6f);
+        norm[1] = c < 1.f ? c : 1.f;
+    }
+}
+__global__ __launch_bounds__(256) void multi_scale_kernel(const glowtts_opt_job* __restrict__ jobs, int njobs, const float* __restrict__ coef)
+{
+    long first;
+    const glowtts_opt_job& j = find_job(jobs, njobs, blockIdx.x, first);
+    const long end = min(first + OPT_CHUNK, (long)j.n);
+    const float c = coef[0];
+    if (c == 1.f) return;
+    float* g = const_cast<float*>(j.g);
+    for (long i = first + threadIdx.x; i < end; i += 256) g[i] *= c;
+}
+// hyper (device): [0] lr  [1] beta1  [2] beta2  [3] eps  [4] weight_decay  [5] step_size  [6] rectified (N_sma >= 5 ? 1 : 0)
+__global__ __launch_bounds__(256) void radam_kernel(const glowtts_opt_job* __restrict__ jobs, int njobs, const float* __restrict__ hyper,
+                                                    const float* __restrict__ gscale)
+{
+    long first;
+    const glowtts_opt_job& j = find_job(jobs, njobs, blockIdx.x, first);
+    const long end = min(first + OPT_CHUNK, (long)j.n);
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], step_size = hyper[5];
+    const bool rect = hyper[6] != 0.f;
+    const float gs = gscale ? gscale[0] : 1.f;
+    for (long i = first + threadIdx.x; i < end; i += 256) {
+        const float g = j.g[i] * gs;
+        float p = j.p[i];
+        const float v = j.v[i] * b2 + (1.f - b2) * g * g;              // Radam.py:59
+        const float m = j.m[i] * b1 + (1.f - b1) * g;                  // Radam.py:60
+        j.v[i] = v; j.m[i] = m;
+        if (wd != 0.f) p += -wd * lr * p;                              // Radam.py:81-82
+        if (rect) p += -step_size * lr * m / (sqrtf(v) + eps);         // Radam.py:85-87
+        else      p += -step_size * lr * m;                            // Radam.py:88-89
+        j.p[i] = p;
+    }
+}
+
+}  // namespace
+
+extern "C" int glowtts_multi_grad_norm(const glowtts_opt_job* dev_jobs, int njobs, int total_blocks, float max_norm, float* partial,
+                                       float* norm_and_coef, void* stream)
+{
+    if (!dev_jobs || njobs < 1 || total_blocks < 1 || !partial || !norm_and_coef) return GLOWTTS_E_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(multi_sqnorm_kernel, dim3(total_blocks), dim3(256), 0, s, dev_jobs, njobs, partial);
+    hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, s, partial, total_blocks, max_norm, norm_and_coef);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
+extern "C" int glowtts_multi_grad_scale(const glowtts_opt_job* dev_jobs, int njobs, int total_blocks, const float* coef, void* stream)
+{
+    if (!dev_jobs || njobs < 1 || total_blocks < 1 || !coef) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(multi_scale_kernel, dim3(total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dev_jobs, njobs, coef);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
+extern "C" int glowtts_radam_step(const glowtts_opt_job* dev_jobs, int njobs, int total_blocks, const float* hyper, const float* grad_scale,
+                                  void* stream)
+{
+    if (!dev_jobs || njobs < 1 || total_blocks < 1 || !hyper) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(radam_kernel, dim3(total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dev_jobs, njobs, hyper, grad_scale);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
+extern "C" int glowtts_opt_chunk(void) { return OPT_CHUNK; }

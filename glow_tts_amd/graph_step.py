@@ -19,10 +19,14 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, model, loss_fn, warmup=3):
+    def __init__(self, model, loss_fn, warmup=3, optimizer=None, scheduler=None, max_grad_norm=None):
         """loss_fn(model, *inputs) -> scalar loss tensor (forward + losses).  warmup >= 2: eager steps before the capture (the first
-        one also runs the ActNorm data-dependent init and builds the flat parameter storage)."""
+        one also runs the ActNorm data-dependent init and builds the flat parameter storage).
+        optimizer (glow_tts_amd.optim.RAdam) / scheduler / max_grad_norm: the rest of `Train.py:218-233` - clip_grad_norm_, optimizer.step(),
+        scheduler.step() - joins the graph: the clip coefficient stays on the device, the step's hyper-parameters are refreshed from the host
+        before every replay (`RAdam.advance_host`).  NOTE: the warm-up steps are real optimizer steps."""
         self.model, self.loss_fn, self.warmup = model, loss_fn, max(2, int(warmup))
+        self.optimizer, self.scheduler, self.max_grad_norm = optimizer, scheduler, max_grad_norm
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.stream = torch.cuda.Stream()
         self.graphs = {}
@@ -31,6 +35,12 @@ class GraphedTrainStep:
         loss = self.loss_fn(self.model, *inputs)
         self.model.zero_grad(set_to_none=True)
         loss.backward()
+        if self.optimizer is not None:
+            coef = None
+            if self.max_grad_norm is not None:
+                from .optim import grad_norm_and_coef
+                _, coef = grad_norm_and_coef(self.params, self.max_grad_norm)
+            self.optimizer.step(grad_scale=coef)
         return loss
 
     def _capture(self, inputs):
@@ -42,12 +52,18 @@ class GraphedTrainStep:
         with torch.cuda.stream(self.stream):
             for _ in range(self.warmup):
                 self._fwd_bwd(static_in)
+                if self.scheduler is not None:
+                    self.scheduler.step()
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            loss = self._fwd_bwd(static_in)
-        grads = [p.grad for p in self.params]
+            loss = self._fwd_bwd(static_in)                # (with an optimizer: this capture pass advanced the step counters once; the
+        grads = [p.grad for p in self.params]              #  captured kernels only run at the replays)
+        if self.optimizer is not None:
+            for st in self.optimizer.state.values():
+                if "step" in st:
+                    st["step"] -= 1
         return g, static_in, loss, grads
 
     def __call__(self, *inputs):
@@ -58,7 +74,11 @@ class GraphedTrainStep:
         for s, t in zip(static_in, inputs):
             if torch.is_tensor(t) and s.data_ptr() != t.data_ptr():
                 s.copy_(t, non_blocking=True)
-        g.replay()
         for p, gr in zip(self.params, grads):              # several cached shapes: point .grad at this graph's buffers
             p.grad = gr
+        if self.optimizer is not None:
+            self.optimizer.advance_host()
+        g.replay()
+        if self.scheduler is not None:
+            self.scheduler.step()
         return loss

@@ -381,6 +381,28 @@ int glowtts_weightnorm_fwd(const float *v, const float *g, float *w, float *inv_
 int glowtts_weightnorm_bwd(const float *dw, const float *v, const float *g, const float *inv_norm, float *dv, float *dg,
                            int64_t rows, int cols, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Optimizer side of the training step: multi-tensor launches over a DEVICE job table.
+ * A job = one contiguous run of fp32 elements (a stacked weight class is one job); block0 = running sum of ceil(n / glowtts_opt_chunk())
+ * over the preceding jobs, total_blocks = that sum over all jobs.
+ *   glowtts_multi_grad_norm : norm_and_coef[0] = ||all gradients||_2, [1] = min(1, max_norm / (norm + 1e-6))   (torch.nn.utils.clip_grad_norm_,
+ *                             Train.py:228-231); partial: total_blocks floats of scratch; deterministic two-stage reduction
+ *   glowtts_multi_grad_scale: g *= coef[0] in place (clip_grad_norm_'s second half)
+ *   glowtts_radam_step      : Rectified Adam exactly as Radam.py:45-90.  hyper (device, 8 floats): lr, beta1, beta2, eps, weight_decay,
+ *                             step_size, rectified (N_sma >= 5), unused - computed on the host per step like Radam.py:63-79 and uploaded, so a
+ *                             captured hipGraph of the step stays valid while the learning rate changes; grad_scale (device, optional): the
+ *                             clip coefficient applied on the fly instead of a separate scale pass. */
+typedef struct glowtts_opt_job {
+    float *p; const float *g; float *m; float *v;     /* parameter, gradient, exp_avg, exp_avg_sq */
+    int64_t n;
+    int64_t block0;
+} glowtts_opt_job;
+int glowtts_opt_chunk(void);
+int glowtts_multi_grad_norm(const glowtts_opt_job *dev_jobs, int njobs, int total_blocks, float max_norm, float *partial,
+                            float *norm_and_coef, void *stream);
+int glowtts_multi_grad_scale(const glowtts_opt_job *dev_jobs, int njobs, int total_blocks, const float *coef, void *stream);
+int glowtts_radam_step(const glowtts_opt_job *dev_jobs, int njobs, int total_blocks, const float *hyper, const float *grad_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,4 +39,27 @@ for b, (wl, wg) in zip((b1, b2), want):
     for k, p in gmodel.named_parameters():
         if k in wg:
             assert (p.grad - wg[k]).abs().max() <= 1e-5 * max(1.0, wg[k].abs().max().item()), k
+# ---- the whole Train_Step (Train.py:193-233) in the graph: clip + RAdam + scheduler, against the same sequence run eagerly ----
+from glow_tts_amd.optim import Modified_Noam_Scheduler, RAdam, clip_grad_norm_   # noqa: E402
+ma, mb = build("Vanilla", "f32", sd), build("Vanilla", "f32", sd)
+oa, ob = RAdam(ma.parameters(), lr=1e-3, eps=1e-6, weight_decay=1e-6), RAdam(mb.parameters(), lr=1e-3, eps=1e-6, weight_decay=1e-6)
+sa, sb = Modified_Noam_Scheduler(oa, base=4000), Modified_Noam_Scheduler(ob, base=4000)
+gstep = GraphedTrainStep(mb, loss_fn, warmup=2, optimizer=ob, scheduler=sb, max_grad_norm=5.0)
+seq = [b1, b1, b1, b2, b1, b2]                          # graphed side: 2 warm-up steps + 1 replay on b1, then b2, b1, b2
+la = []
+for b in seq:
+    ma.zero_grad(set_to_none=True)
+    l = loss_fn(ma, *b)
+    l.backward()
+    clip_grad_norm_(list(ma.parameters()), 5.0)
+    oa.step(); sa.step()
+    la.append(l.item())
+lb = [gstep(*b).item() for b in seq[2:]]
+torch.cuda.synchronize()
+for x, y in zip(la[2:], lb):
+    assert abs(x - y) <= 2e-5 * max(1.0, abs(x)), (la, lb)
+assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"]
+for (k, pa), pb_ in zip(ma.named_parameters(), mb.parameters()):
+    assert (pa - pb_).abs().max() <= 2e-5 * max(1.0, pa.abs().max().item()), k
+    assert oa.state[pa]["step"] == ob.state[pb_]["step"] == len(seq), (k, oa.state[pa]["step"], ob.state[pb_]["step"])
 print("GRAPH STEP OK")

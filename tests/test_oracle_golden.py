@@ -77,3 +77,26 @@ def test_actnorm_init_and_invertibility():
     z, _, _ = O.decoder(sd, mels, mask, cfg, reverse=False)
     back, _, _ = O.decoder(sd, z, mask, cfg, reverse=True)
     assert torch.allclose(back * mask, mels * mask, atol=2e-4)
+
+
+def test_optimizer_oracle_matches_reference_golden():
+    """oracle/radam_ref.py replays the golden run of the reference's Radam.py + clip_grad_norm_ + Modified_Noam_Scheduler
+    (tests/golden/make_optim_golden.py): 12 steps over 4 tensors, both branches of the rectification."""
+    import os
+    from oracle import radam_ref as R
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "radam_case.npz"))
+    LR, B1, B2, EPS, WD, BASE, CLIP, STEPS = d["hyper"]
+    n = 4
+    st = [(d["p0/%d" % i], np.zeros_like(d["p0/%d" % i]), np.zeros_like(d["p0/%d" % i])) for i in range(n)]
+    for step in range(1, int(STEPS) + 1):
+        grads = [d["g%d/%d" % (step, i)] for i in range(n)]
+        total, coef = R.clip_coef(grads, CLIP)
+        assert abs(total - float(d["norm%d" % step])) <= 1e-5 * max(1.0, total)
+        lr = R.modified_noam_lr(LR, BASE, step - 1)
+        assert abs(lr - d["lrs"][step - 1]) <= 1e-12
+        st = [R.radam_step(p, g * np.float32(coef), m, v, step, lr, B1, B2, EPS, WD) for (p, m, v), g in zip(st, grads)]
+        for i in range(n):
+            assert np.abs(st[i][0] - d["p%d/%d" % (step, i)]).max() <= 2e-6
+    for i in range(n):
+        assert np.abs(st[i][1] - d["m/%d" % i]).max() <= 1e-6 and np.abs(st[i][2] - d["v/%d" % i]).max() <= 1e-6
+    assert all(abs(R.noam_lr(LR, 50, i) - v) <= 1e-12 for i, v in enumerate(d["noam50"]))
