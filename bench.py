@@ -217,6 +217,7 @@ def main():
             dist.broadcast(p.data, 0)
         model.actnorm_allreduce = actnorm_stats_allreduce
         reducer = FlatGradReducer(list(model.parameters()))
+    torch.manual_seed(4321 + rank)                              # dropout streams differ per rank; the replicas' weights do not
     B, Tt, Tm = args.batch, 120, 800
     batch = synthetic_batch(B, Tt, Tm, 80, 1234 + rank, dev, ragged=args.ragged)
 
