@@ -54,3 +54,32 @@ def test_model_deepcopy_and_state_dict_roundtrip_cpu():
     assert set(sd) == set(c.state_dict()) and all(torch.equal(sd[k], c.state_dict()[k]) for k in sd)
     assert all(a.data_ptr() != b.data_ptr() for a, b in zip(m.parameters(), c.parameters()))
     c.load_state_dict(sd, strict=True)
+
+
+def test_collater_matches_reference_layout_and_buckets():
+    """glow_tts_amd.data.Collater against a direct restatement of Datasets.py:23-39,67-74,225-250 (pad with '<E>', -Max_Abs_Mel, 0;
+    truncate mels to a multiple of Num_Squeeze; mels transposed to [B, Mel, T]) and the bucketed / pinned variants."""
+    import numpy as np
+    import torch
+    from glow_tts_amd.data import Collater
+    rng = np.random.default_rng(0)
+    batch = []
+    for tt, tm in [(7, 41), (12, 33), (3, 58), (9, 2)]:
+        batch.append((rng.integers(1, 40, tt), rng.standard_normal((tm, 5)).astype(np.float32), int(rng.integers(0, 9)),
+                      rng.random(tm).astype(np.float32)))
+    tok, tl, mel, ml, spk, ge2e, pit = Collater(num_squeeze=2, end_token_id=99, max_abs_mel=4.0)(batch)
+    want_ml = [(len(m) // 2) * 2 for _, m, _, _ in batch]
+    assert tl.tolist() == [7, 12, 3, 9] and ml.tolist() == want_ml and ge2e is None and spk.tolist() == [b[2] for b in batch]
+    assert tok.shape == (4, 12) and mel.shape == (4, 5, max(want_ml)) and pit.shape == (4, max(want_ml))
+    for b, (t, m, _, p) in enumerate(batch):
+        assert tok[b, :len(t)].tolist() == t.tolist() and (tok[b, len(t):] == 99).all()
+        assert torch.equal(mel[b, :, :want_ml[b]], torch.from_numpy(m[:want_ml[b]].T.copy())) and (mel[b, :, want_ml[b]:] == -4.0).all()
+        n = min(len(p), pit.shape[1])
+        assert torch.equal(pit[b, :n], torch.from_numpy(p[:n])) and (pit[b, n:] == 0).all()
+    c2 = Collater(num_squeeze=2, end_token_id=99, token_buckets=[8, 16, 32], mel_buckets=[32, 64, 128], pin_memory=False)
+    tok2, _, mel2, ml2, _, _, _ = c2(batch)
+    assert tok2.shape == (4, 16) and mel2.shape == (4, 5, 64) and ml2.tolist() == want_ml
+    assert torch.equal(tok2[:, :12], tok) and (tok2[:, 12:] == 99).all() and torch.equal(mel2[:, :, :max(want_ml)], mel)
+    import pytest
+    with pytest.raises(ValueError):
+        Collater(token_buckets=[4])(batch)
