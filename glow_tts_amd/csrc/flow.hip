@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 #include "../../include/glowtts_hip.h"
 
 namespace {
@@ -66,9 +67,10 @@ int coupling_net(const Ctx& c, const float* xsrc, float* xdst, bool reverse, boo
             if (acts) { a.out1 = acts; a.ld1 = H; }              // bf16 tanh * sigmoid for the Res_Skip conv below
             CHECK(glowtts_conv_cl(&a, c.s));
         }
-        {   // Res_Skip_l on acts = tanh*sigmoid                                 Modules.py:871-881
-            const bool last = (l == L - 1);
-            glowtts_conv_args a = base_args(c, p->rs[l], 1);
+        const bool last = (l == L - 1);
+        glowtts_conv_args rs = base_args(c, p->rs[l], 1);      // Res_Skip_l on acts = tanh*sigmoid                   Modules.py:871-881
+        {
+            glowtts_conv_args& a = rs;
             if (acts) { a.a = acts; a.lda = H; a.ca = H; }                                          // plain bf16 operand: LDS-DMA kernel
             else      { a.a = g; a.lda = 2 * H; a.ca = H; a.apro = GLOWTTS_APRO_PAIRMUL; }
             a.n = last ? H : 2 * H; a.h = H;
@@ -77,10 +79,9 @@ int coupling_net(const Ctx& c, const float* xsrc, float* xdst, bool reverse, boo
             a.in0 = hin; a.ldi0 = H; a.out0 = last ? A->skip : hout; a.ld0 = H; a.out1 = A->skip; a.ld1 = H;
             a.io_flags = bf ? (GLOWTTS_IO_A_BF16 | GLOWTTS_IO_IN0_BF16 | GLOWTTS_IO_OUT0_BF16) : 0;
             if (bf && last && A->skip_bf) { a.out0 = A->skip_bf; a.ld0 = H; }     // last layer: out0 = bf16 copy of the final skip sum
-            CHECK(glowtts_conv_cl(&a, c.s));
         }
-    }
-    {   // End + affine coupling                                                 Modules.py:793-806
+        if (!last) { CHECK(glowtts_conv_cl(&rs, c.s)); continue; }
+        // last layer: Res_Skip, then End + affine coupling                       Modules.py:793-806
         glowtts_conv_args a = base_args(c, p->end, 1);
         if (bf && A->skip_bf) { a.a = A->skip_bf; a.io_flags = GLOWTTS_IO_A_BF16; } else a.a = A->skip;
         a.lda = H; a.ca = H; a.n = c.d->C; a.h = c.C2;
@@ -88,6 +89,10 @@ int coupling_net(const Ctx& c, const float* xsrc, float* xdst, bool reverse, boo
         a.in0 = xsrc + c.C2; a.ldi0 = c.d->C;
         a.out0 = xdst + c.C2; a.ld0 = c.d->C;
         a.out1 = keep ? A->outs : nullptr; a.ld1 = p->end.npad;
+        // both in ONE launch when the shapes allow (bf16 storage, 192 channels): the final skip sum reaches the End conv through LDS
+        static const bool chain = [] { const char* e = getenv("GLOWTTS_CHAIN"); return !(e && e[0] == '0'); }();
+        if (chain && bf && acts && A->skip_bf && glowtts_conv_chain(&rs, &a, c.s) == GLOWTTS_OK) continue;
+        CHECK(glowtts_conv_cl(&rs, c.s));
         CHECK(glowtts_conv_cl(&a, c.s));
     }
     return GLOWTTS_OK;

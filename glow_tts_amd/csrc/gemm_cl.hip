@@ -513,29 +513,44 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
         };
         if (drop) rows_loop(IC<1>{}); else rows_loop(IC<0>{});
     } else {
-        // affine coupling on (m, logs) = End conv output (Modules.py:795-806); PAIR-packed like GATE
+        // affine coupling on (m, logs) = End conv output (Modules.py:795-806); PAIR-packed like GATE: fragment 2*pi holds m, 2*pi+1 logs
         static_assert(EPI == GLOWTTS_EPI_COUPLE && NI % 2 == 0, "pair epilogues need NI even");
+        const float* xsrc = p.in0 ? p.in0 : p.out0;           // x_b is read from the kept coupling input when given
+        const long ldx = p.in0 ? p.ldi0 : p.ld0;
+        const Rsrc rx = mk(xsrc, (long)p.rows * ldx * 4), ro = mk(p.out0, (long)p.rows * p.ld0 * 4), rk = mk(p.out1, p.out1 ? (long)p.rows * p.ld1 * 4 : 0);
+        const bool rev = (fl & GLOWTTS_F_REVERSE) != 0;
+        uint32_t vx[NI / 2], vo[NI / 2], vk[NI / 2]; float bm[NI / 2], bl[NI / 2];
+#pragma unroll
+        for (int pi = 0; pi < NI / 2; ++pi) {
+            const int pcol = n0 + (wn * NI + 2 * pi) * 32, j = (pcol >> 6) * 32 + l31;      // packed column of m / channel inside a half
+            const bool ok = j < p.h;
+            vx[pi] = ok ? (uint32_t)(rb * (int)ldx + j) * 4u : OOB;
+            vo[pi] = ok ? (uint32_t)(rb * (int)p.ld0 + j) * 4u : OOB;
+            vk[pi] = ok ? (uint32_t)(rb * (int)p.ld1 + pcol + l31) * 4u : OOB;
+            bm[pi] = ok ? p.bias[j] : 0.f;
+            bl[pi] = ok ? p.bias[p.h + j] : 0.f;
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int r = rb + roff(mi, reg);
-                if (r >= p.rows) continue;
-                const float mask = p.rowmask ? p.rowmask[r] : 1.f;
+            for (int hb = 0; hb < 2; ++hb) {
+                float xb[8][NI / 2], mk8[8];
 #pragma unroll
-                for (int pi = 0; pi < NI / 2; ++pi) {
-                    const int pcol = n0 + (wn * NI + 2 * pi) * 32;               // packed column of the first half
-                    const int j = (pcol >> 6) * 32 + l31;                         // channel inside a half
-                    if (j >= p.h) continue;
-                    const float v0 = acc[mi][2 * pi][reg] + p.bias[j];            // m
-                    const float v1 = acc[mi][2 * pi + 1][reg] + p.bias[p.h + j];  // logs
-                    float* xb = p.out0 + (long)r * p.ld0 + j;
-                    const float x = p.in0 ? p.in0[(long)r * p.ldi0 + j] : *xb;     // x_b read from the kept coupling input when given
-                    if (fl & GLOWTTS_F_REVERSE) *xb = (x - v0) * exp_<EX>(-v1) * mask;
-                    else                        *xb = (v0 + exp_<EX>(v1) * x) * mask;
-                    if (p.out1) {
-                        p.out1[(long)r * p.ld1 + pcol + l31] = v0;
-                        p.out1[(long)r * p.ld1 + pcol + 32 + l31] = v1;
+                for (int q = 0; q < 8; ++q) {
+                    mk8[q] = p.rowmask ? ldf(rmk, (uint32_t)rb * 4u, roff(mi, hb * 8 + q) * 4) : 1.f;
+#pragma unroll
+                    for (int pi = 0; pi < NI / 2; ++pi) xb[q][pi] = ldf(rx, vx[pi], roff(mi, hb * 8 + q) * (int)ldx * 4);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int reg = hb * 8 + q, ro_ = roff(mi, reg);
+#pragma unroll
+                    for (int pi = 0; pi < NI / 2; ++pi) {
+                        const float v0 = acc[mi][2 * pi][reg] + bm[pi];             // m
+                        const float v1 = acc[mi][2 * pi + 1][reg] + bl[pi];         // logs
+                        const float z = rev ? (xb[q][pi] - v0) * exp_<EX>(-v1) * mk8[q] : (v0 + exp_<EX>(v1) * xb[q][pi]) * mk8[q];
+                        stf(z, ro, vo[pi], ro_ * (int)p.ld0 * 4);
+                        if (p.out1) { stf(v0, rk, vk[pi], ro_ * (int)p.ld1 * 4); stf(v1, rk, vk[pi] + 128u, ro_ * (int)p.ld1 * 4); }
                     }
                 }
             }
@@ -1017,6 +1032,164 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
     TL(29);
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_chain_kernel: TWO chained 1x1 convs over the same rows in one launch; the intermediate (N1 = 192 channels) never leaves the CU.
+// The decoder's dependent kernel chain has row-local pairs whose second GEMM consumes all channels of the first one's output:
+//   forward : last Res_Skip (acts -> final skip sum)  ->  End conv + affine coupling     (EPI1 = RESSKIP (LAST), EPI2 = COUPLE)
+//   backward: End data gradient (douts -> d skip)     ->  last layer's gate derivative   (EPI1 = LINEAR + mask,  EPI2 = DGATE)
+// Workgroup = 64 rows x all 192 intermediate channels = 2 x 3 waves (32 rows x 64 columns each), 202 workgroups at B = 32.  GEMM 1 is
+// the LDS-DMA pipeline of conv_dma_kernel's 1x1 mode (bf16 A rows + weight slabs, two stages of two K chunks); its epilogue applies the
+// first conv's tail, writes what later kernels need to global memory (bf16) and the same values as six swizzled K-chunk tiles into LDS;
+// GEMM 2 multiplies those tiles with the second weight (streamed through the same stage buffers) and ends in the second epilogue.
+// ------------------------------------------------------------------------------------------------
+constexpr int CH_WN = 3, CH_BN = CH_WN * 64, CH_BM = 64, CH_KC2 = CH_BN / 32;      // 192 intermediate channels = 6 K chunks of GEMM 2
+
+template <int EPI1, int EPI2>
+__global__ __launch_bounds__(CH_WN * 2 * 64) void conv_chain_kernel(const glowtts_conv_args pin1, const glowtts_conv_args pin2)
+{
+    typedef __bf16 CT;
+    constexpr int NI = 2, KC = 32, CPS = DMA1_CPS;
+    constexpr int AU = CH_BM / 16, WUT = CH_BN / 16;          // DMA units of one A chunk tile / one weight chunk tile
+    constexpr int A_BYTES = CPS * AU * 1024, STAGE = A_BYTES + CPS * WUT * 1024;
+    glowtts_conv_args p = pin1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / CH_WN, wn = wave - wm * CH_WN;
+    const int m0 = blockIdx.x * CH_BM;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int lrow = lane >> 2, qa = (lane & 3) ^ ((lane >> 4) & 3);
+    unsigned char* A2 = dma_smem + 2 * STAGE;                 // [6 chunks][64 rows][64 B], swizzled like a staged A tile
+    long long* tlbuf = nullptr; (void)tlbuf;
+
+    f32x16 acc[1][NI];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][ni][r] = 0.f;
+    };
+    // DMA of stage `st` of GEMM `which` (1: A chunks + weight slabs, 2: weight slabs only) into stage buffer `buf`
+    auto issue = [&](int which, const glowtts_conv_args& q, int buf, int st) __attribute__((always_inline)) {
+        const int nau = which == 1 ? CPS * AU : 0, nun = nau + CPS * WUT;
+        for (int u = wave; u < nun; u += CH_WN * 2) {
+            const unsigned char* src;
+            int dstu;
+            if (u < nau) {
+                const int ja = u / AU, ur = u - ja * AU;
+                int g = m0 + ur * 16 + lrow;
+                g = g >= q.rows ? q.rows - 1 : g;
+                src = reinterpret_cast<const unsigned char*>(q.a) + (uint32_t)g * (uint32_t)(q.lda * 2) + (uint32_t)(qa * 16 + (st * CPS + ja) * (KC * 2));
+                dstu = u;
+            } else {
+                const int w = u - nau, t = w / WUT, cg = w - t * WUT;
+                src = reinterpret_cast<const unsigned char*>(q.w) + (uint32_t)((st * CPS + t) * q.npad + cg * 16 + lrow) * 64u + (uint32_t)(qa * 16);
+                dstu = CPS * AU + w;
+            }
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                             (void __attribute__((address_space(3)))*)(dma_smem + buf * STAGE + dstu * 1024), 16, 0, 0);
+        }
+    };
+    // MFMAs of one stage: A tiles from `Abase` (stage buffer or the resident A2 tiles), weight tiles from the stage buffer
+    auto compute = [&](const unsigned char* Abase, int atile_bytes, const unsigned char* Wb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < CPS; ++t) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int q = 2 * s2 + lhi;
+                const Chunk16 af = *reinterpret_cast<const Chunk16*>(Abase + t * atile_bytes + swz(wm * 32 + l31, q));
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const Chunk16 bf = *reinterpret_cast<const Chunk16*>(Wb + t * (CH_BN * 64) + swz((wn * NI + ni) * 32 + l31, q));
+                    acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&af), *reinterpret_cast<const bf16x8*>(&bf),
+                                                                        acc[0][ni], 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto wait_all = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // ---------------- GEMM 1 ----------------
+    const int NSS1 = p.kchunks / CPS;
+    zero_acc();
+    issue(1, p, 0, 0);
+    for (int ss = 0; ss < NSS1; ++ss) {
+        wait_all();
+        if (ss + 1 < NSS1) issue(1, p, (ss + 1) & 1, ss + 1);
+        else               issue(2, pin2, (ss + 1) & 1, 0);   // first weight stage of GEMM 2 streams in under GEMM 1's last MFMAs + epilogue
+        const unsigned char* sb = dma_smem + (ss & 1) * STAGE;
+        compute(sb, AU * 1024, sb + A_BYTES);
+    }
+    // ---------------- epilogue 1: values -> global (what later kernels need) and -> LDS tiles (A operand of GEMM 2) ----------------
+    {
+        const int rb = m0 + wm * 32 + 4 * lhi;
+        typedef __amdgpu_buffer_rsrc_t Rs;
+        auto mkr = [](const void* ptr, long bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000); };
+        const Rs rmk = mkr(p.rowmask, (long)p.rows * 4);
+        const Rs rold = mkr(p.out1, p.out1 ? (long)p.rows * p.ld1 * 4 : 0);          // RESSKIP: the fp32 skip sum of the earlier layers
+        const Rs rout = mkr(p.out0, (long)p.rows * p.ld0 * 2);                        // bf16 result rows [rows][ld0]
+        float mk[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            mk[reg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmk, (uint32_t)rb * 4u, ((reg & 3) + 8 * (reg >> 2)) * 4, 0));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = (wn * NI + ni) * 32 + l31;                                  // intermediate channel, < 192
+            const float bias = (EPI1 == GLOWTTS_EPI_RESSKIP || (p.flags & GLOWTTS_F_BIAS)) ? p.bias[n] : 0.f;
+            const uint32_t vo = (uint32_t)(rb * (int)p.ld0 + n) * 2u, vs = (uint32_t)(rb * (int)p.ld1 + n) * 4u;
+            unsigned char* tile = A2 + (n >> 5) * (CH_BM * 64);
+            const int q = (n & 31) >> 3, e2 = (n & 7) * 2;
+            float old[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) old[reg] = 0.f;
+            if (EPI1 == GLOWTTS_EPI_RESSKIP && !(p.flags & GLOWTTS_F_FIRST)) {       // the loads of the 16 rows are in flight together
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    old[reg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rold, vs, ((reg & 3) + 8 * (reg >> 2)) * (int)p.ld1 * 4, 0));
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int rr = (reg & 3) + 8 * (reg >> 2);                            // row offset inside the wave's 32 rows (+ 4 lhi in rb)
+                const float v = (old[reg] + acc[0][ni][reg] + bias) * mk[reg];        // RESSKIP (last layer, Modules.py:880-883) / LINEAR + mask
+                if constexpr (EPI1 == GLOWTTS_EPI_RESSKIP)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rold, vs, rr * (int)p.ld1 * 4, 0);    // the fp32 sum stays complete too
+                const __bf16 hb = (__bf16)v;
+                const unsigned short bits = *reinterpret_cast<const unsigned short*>(&hb);
+                __builtin_amdgcn_raw_buffer_store_b16(bits, rout, vo, rr * (int)p.ld0 * 2, 0);
+                *reinterpret_cast<unsigned short*>(tile + swz(wm * 32 + 4 * lhi + rr, q) + e2) = bits;
+            }
+        }
+    }
+    // ---------------- GEMM 2 ----------------
+    const glowtts_conv_args& p2 = pin2;
+    constexpr int NSS2 = CH_KC2 / CPS;
+    zero_acc();
+    for (int ss = 0; ss < NSS2; ++ss) {
+        wait_all();                                            // weights of stage ss landed; (ss = 0) every wave's A2 tiles are written
+        const int buf = (NSS1 + ss) & 1;
+        if (ss + 1 < NSS2) issue(2, p2, buf ^ 1, ss + 1);
+        compute(A2 + ss * CPS * (CH_BM * 64), CH_BM * 64, dma_smem + buf * STAGE + A_BYTES);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        glowtts_conv_args pe = pin2;
+        conv_epilogue<CT, 1, NI, EPI2>(pe, acc, m0, 0, CH_BM, wm, wn, lane, tid, nullptr);
+    }
+}
+
+template <int EPI1, int EPI2>
+int launch_chain(const glowtts_conv_args& a1, const glowtts_conv_args& a2, hipStream_t s)
+{
+    constexpr int lds = 2 * ((DMA1_CPS * (CH_BM / 16) + DMA1_CPS * (CH_BN / 16)) * 1024) + CH_KC2 * CH_BM * 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_chain_kernel<EPI1, EPI2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return GLOWTTS_E_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_chain_kernel<EPI1, EPI2>), dim3((a1.rows + CH_BM - 1) / CH_BM), dim3(CH_WN * 2 * 64), lds, s, a1, a2);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
 int num_cus()
 {
     static const int n = [] { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
@@ -1234,5 +1407,22 @@ extern "C" int glowtts_conv_cl(const glowtts_conv_args* args, void* stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.precision == GLOWTTS_BF16) return launch_prec<__bf16>(a, s);
     if (a.precision == GLOWTTS_F32) return launch_prec<float>(a, s);
+    return GLOWTTS_E_ARG;
+}
+
+extern "C" int glowtts_conv_chain(const glowtts_conv_args* first, const glowtts_conv_args* second, void* stream)
+{
+    if (!first || !second || !first->a || !first->w || !first->out0 || !second->w || !second->out0) return GLOWTTS_E_ARG;
+    const glowtts_conv_args &a = *first, &b = *second;
+    // both 1x1, bf16 MFMA on bf16-stored rows; the intermediate has exactly 192 channels (Calc_Channels of the reference's model)
+    if (a.precision != GLOWTTS_BF16 || b.precision != GLOWTTS_BF16 || a.taps != 1 || b.taps != 1 || !(a.io_flags & GLOWTTS_IO_A_BF16) ||
+        a.apro != GLOWTTS_APRO_NONE || a.a2 || a.batch > 1 || b.batch > 1 || a.rows != b.rows || a.rows < 1) return GLOWTTS_E_ARG;
+    if (a.n != CH_BN || a.npad != CH_BN || a.kchunks * 32 != a.ca || (a.kchunks % DMA1_CPS) || (a.lda & 7) || b.kchunks != CH_KC2 || b.npad != CH_BN ||
+        b.ca != CH_BN) return GLOWTTS_E_ARG;
+    const int64_t ldmax = std::max(std::max(std::max(a.ld0, a.ld1), std::max(b.ld0, b.ld1)), std::max(b.ldi0, b.ldcond));
+    if ((int64_t)a.rows * ldmax * 4 >= (int64_t)1 << 31) return GLOWTTS_E_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a.epi == GLOWTTS_EPI_RESSKIP && (a.flags & GLOWTTS_F_LAST) && b.epi == GLOWTTS_EPI_COUPLE) return launch_chain<GLOWTTS_EPI_RESSKIP, GLOWTTS_EPI_COUPLE>(a, b, s);
+    if (a.epi == GLOWTTS_EPI_LINEAR && (a.flags & GLOWTTS_F_MASK) && b.epi == GLOWTTS_EPI_DGATE) return launch_chain<GLOWTTS_EPI_LINEAR, GLOWTTS_EPI_DGATE>(a, b, s);
     return GLOWTTS_E_ARG;
 }

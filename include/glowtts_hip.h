@@ -148,6 +148,11 @@ typedef struct glowtts_conv_args {
     int io_flags;
 } glowtts_conv_args;
 
+/* Two chained 1x1 convs over the same rows in ONE launch (bf16 precision, bf16-stored `first->a`, 192 intermediate channels): the first
+ * conv's output is handed to the second through LDS.  Supported pairs: (RESSKIP with F_LAST -> COUPLE): first->out1 = fp32 skip sum of the
+ * earlier layers (read), first->out0 = bf16 final skip rows (written; the A operand `second->a` is ignored); (LINEAR with F_MASK -> DGATE):
+ * first->out0 = bf16 d(skip) rows (written).  Everything else as in glowtts_conv_cl for the two epilogues. */
+int glowtts_conv_chain(const glowtts_conv_args *first, const glowtts_conv_args *second, void *stream);
 int glowtts_conv_cl(const glowtts_conv_args *args /* host pointer */, void *stream);
 
 /* ------------------------------------------------------------------------------------------
