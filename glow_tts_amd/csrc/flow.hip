@@ -188,22 +188,22 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
         w.precision = d->precision; w.splits = 0; w.accumulate = 1; w.dw = dw; w.dbias = db;
         return w;
     };
+
     const bool bf = d->act_bf16 != 0;         // gates / hs / dins stored as bf16
     const bool bfg = bf;                      // ... and so are dskip and dh[l >= 1] (dh[0] stays fp32: it feeds the fp32 Start conv gradients)
-
     // 1. affine coupling backward                                               autograd of Modules.py:805-806
-    CHECK(glowtts_coupling_bwd(g->dx, a->xmid, a->outs, g->douts, a->rowmask, g->dlogdet, R, C, ldo, c.Tp, stream));
+    const bool dbf = bfg && g->douts_bf != nullptr;        // a bf16 copy of douts feeds the End data gradient (DMA / chained kernel)
+    if (dbf) CHECK(glowtts_coupling_bwd_bf16(g->dx, a->xmid, a->outs, g->douts, g->douts_bf, a->rowmask, g->dlogdet, R, C, ldo, c.Tp, stream));
+    else     CHECK(glowtts_coupling_bwd(g->dx, a->xmid, a->outs, g->douts, a->rowmask, g->dlogdet, R, C, ldo, c.Tp, stream));
     // 2. End conv: data gradient -> d(skip) (masked), weight gradient
-    {
-        glowtts_conv_args q = base_args(c, p->end_t, 1);
-        q.a = g->douts; q.lda = ldo; q.ca = ldo; q.n = H; q.epi = GLOWTTS_EPI_LINEAR; q.flags = GLOWTTS_F_MASK;
-        q.out0 = g->dskip; q.ld0 = H; q.io_flags = bfg ? GLOWTTS_IO_OUT0_BF16 : 0;
-        CHECK(glowtts_conv_cl(&q, stream));
-        if (!g->defer_wgrad) {
-            glowtts_wgrad_args w = wargs(g->douts, ldo, ldo, (bf && a->skip_bf) ? a->skip_bf : a->skip, H, H, 1, g->dw_end, g->db_end);
-            w.perm = GLOWTTS_PERM_PAIR; w.perm_h = C2; w.io_flags = (bf && a->skip_bf) ? GLOWTTS_WIO_X_BF16 : 0;
-            CHECK(glowtts_wgrad_cl(&w, stream));
-        }
+    glowtts_conv_args endq = base_args(c, p->end_t, 1);
+    endq.a = dbf ? g->douts_bf : g->douts; endq.lda = ldo; endq.ca = ldo; endq.n = H; endq.epi = GLOWTTS_EPI_LINEAR; endq.flags = GLOWTTS_F_MASK;
+    endq.out0 = g->dskip; endq.ld0 = H; endq.io_flags = (dbf ? GLOWTTS_IO_A_BF16 : 0) | (bfg ? GLOWTTS_IO_OUT0_BF16 : 0);
+    bool end_done = false;           // (bf16 storage, 192 channels: it runs chained with the last layer's gate derivative below)
+    if (!g->defer_wgrad) {
+        glowtts_wgrad_args w = wargs(g->douts, ldo, ldo, a->skip, H, H, 1, g->dw_end, g->db_end);          // fp32 operands
+        w.perm = GLOWTTS_PERM_PAIR; w.perm_h = C2;
+        CHECK(glowtts_wgrad_cl(&w, stream));
     }
     // 3. WaveNet layers, last to first.  dh[l] holds d x_l * mask.
     const bool wg = !g->defer_wgrad;
@@ -219,7 +219,17 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
             q.n = H; q.epi = GLOWTTS_EPI_DGATE; q.in0 = a->gates[l]; q.ldi0 = 2 * H; q.out0 = dins; q.ld0 = ldin;
             q.drop_p = d->drop_p; q.seed = d->seed + (uint32_t)l; q.seed_ptr = d->seed_ptr;
             q.io_flags = bf ? (GLOWTTS_IO_IN0_BF16 | GLOWTTS_IO_OUT0_BF16 | (bfg ? GLOWTTS_IO_A_BF16 : 0)) : 0;
-            CHECK(glowtts_conv_cl(&q, stream));
+            if (last) {
+                static const bool chain = [] { const char* e = getenv("GLOWTTS_CHAIN"); const char* f = getenv("GLOWTTS_CHAIN_BWD");
+                                               return !(e && e[0] == '0') && !(f && f[0] == '0'); }();
+                if (!(chain && dbf && glowtts_conv_chain(&endq, &q, stream) == GLOWTTS_OK)) {
+                    CHECK(glowtts_conv_cl(&endq, stream));
+                    CHECK(glowtts_conv_cl(&q, stream));
+                }
+                end_done = true;
+            } else {
+                CHECK(glowtts_conv_cl(&q, stream));
+            }
         }
         if (wg) {   // Res_Skip weight gradient: rows [0,H) <- d res, rows [H,2H) <- d skip (last layer: only H rows <- d skip)
             if (last) {
@@ -254,6 +264,7 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
         if (g->dcond && p->cond)   // conditioning gradient: sum over the frames of each utterance   (autograd of Modules.py:863-866)
             CHECK(utt_colsum(dins, ldin, g->dcond + (int64_t)l * 2 * H, p->ldcond, d->B, c.Tp, 2 * H, GLOWTTS_PERM_PAIR, H, bf, stream));
     }
+    if (!end_done) return GLOWTTS_E_ARG;
     float* dh0 = g->dh[0];                    // d h0 * mask
     // 4. Start conv: data gradient accumulates into d x_a, weight gradient
     {

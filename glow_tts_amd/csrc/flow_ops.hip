@@ -195,8 +195,9 @@ __global__ void actnorm_from_stats_kernel(const float* __restrict__ stats, float
 //   d m = dz_b mask ; d logs = (dz_b exp(logs) x_b + dld[b]) mask ; d x_b = dz_b exp(logs) mask
 // outs / douts are PAIR-packed [R][npair*64] (m in the first 32 of each 64, logs in the second 32)
 // ------------------------------------------------------------------------------------------------
+// douts16 (optional): a second, bf16 copy of douts - the A operand of the End conv's data gradient on the LDS-DMA / chained path
 __global__ __launch_bounds__(256) void coupling_bwd_kernel(float* __restrict__ dz, const float* __restrict__ xmid,
-                                                           const float* __restrict__ outs, float* __restrict__ douts,
+                                                           const float* __restrict__ outs, float* __restrict__ douts, __bf16* __restrict__ douts16,
                                                            const float* __restrict__ rowmask, const float* __restrict__ dld,
                                                            long rows, int C, int ldo, int rows_per_utt)
 {
@@ -208,14 +209,20 @@ __global__ __launch_bounds__(256) void coupling_bwd_kernel(float* __restrict__ d
         const long r = i / P2;
         const int j = (int)(i - r * P2);
         const int pc = (j >> 5) * 64 + (j & 31);
-        if (j >= C2) { douts[r * ldo + pc] = 0.f; douts[r * ldo + pc + 32] = 0.f; continue; }
+        if (j >= C2) {
+            douts[r * ldo + pc] = 0.f; douts[r * ldo + pc + 32] = 0.f;
+            if (douts16) { douts16[r * ldo + pc] = (__bf16)0.f; douts16[r * ldo + pc + 32] = (__bf16)0.f; }
+            continue;
+        }
         const float m = rowmask[r];
         const float logs = outs[r * ldo + pc + 32];
         const float e = expf(logs);
         const float d = dz[r * C + C2 + j];
         const float xb = xmid[r * C + C2 + j];
-        douts[r * ldo + pc] = d * m;
-        douts[r * ldo + pc + 32] = (d * e * xb + dld[r / rows_per_utt]) * m;
+        const float dm = d * m, dl = (d * e * xb + dld[r / rows_per_utt]) * m;
+        douts[r * ldo + pc] = dm;
+        douts[r * ldo + pc + 32] = dl;
+        if (douts16) { douts16[r * ldo + pc] = (__bf16)dm; douts16[r * ldo + pc + 32] = (__bf16)dl; }
         dz[r * C + C2 + j] = d * e * m;
     }
 }
@@ -428,7 +435,17 @@ extern "C" int glowtts_coupling_bwd(float* dz, const float* xmid, const float* o
     if (!dz || !xmid || !outs || !douts || !rowmask || !dlogdet || rows < 1 || C < 2) return GLOWTTS_E_ARG;
     if ((ldo & 63) || ldo < C) return GLOWTTS_E_ARG;
     hipLaunchKernelGGL(coupling_bwd_kernel, dim3(grid_for(rows * (ldo / 2))), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       dz, xmid, outs, douts, rowmask, dlogdet, (long)rows, C, ldo, rows_per_utt);
+                       dz, xmid, outs, douts, (__bf16*)nullptr, rowmask, dlogdet, (long)rows, C, ldo, rows_per_utt);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_coupling_bwd_bf16(float* dz, const float* xmid, const float* outs, float* douts, void* douts_bf16, const float* rowmask,
+                                         const float* dlogdet, int64_t rows, int C, int ldo, int rows_per_utt, void* stream)
+{
+    if (!dz || !xmid || !outs || !douts || !douts_bf16 || !rowmask || !dlogdet || rows < 1 || C < 2) return GLOWTTS_E_ARG;
+    if ((ldo & 63) || ldo < C) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(grid_for(rows * (ldo / 2))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       dz, xmid, outs, douts, static_cast<__bf16*>(douts_bf16), rowmask, dlogdet, (long)rows, C, ldo, rows_per_utt);
     RET_LAUNCH();
 }
 

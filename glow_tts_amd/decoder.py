@@ -50,7 +50,7 @@ class FlowGrads(ctypes.Structure):
                 ("dw_start", c_void_p), ("db_start", c_void_p),
                 ("dw_in", c_void_p * MAXL), ("db_in", c_void_p * MAXL),
                 ("dw_rs", c_void_p * MAXL), ("db_rs", c_void_p * MAXL),
-                ("dw_end", c_void_p), ("db_end", c_void_p), ("dcond", c_void_p)]
+                ("dw_end", c_void_p), ("db_end", c_void_p), ("dcond", c_void_p), ("douts_bf", c_void_p)]
 
 
 _declared = False
@@ -433,6 +433,7 @@ class DecoderFunction(torch.autograd.Function):
         # every flow / layer keeps its own gradient buffers: the weight gradients of ALL flows are computed afterwards by
         # two grouped launches (k-tap problems, 1x1 problems) whose tiles fill the chip without split-K or atomics
         douts = torch.empty(F_, R, prep.ldo, device=dev)           # (pad columns are zeroed by the coupling backward kernel)
+        douts_bf = torch.empty(R, prep.ldo, device=dev, dtype=torch.bfloat16) if cfg.act_bf16 else None      # bf16 copy, reused by every flow
         dins = (torch.empty if prep.ldin == 2 * H else torch.zeros)(F_, Lw, R, prep.ldin, device=dev, dtype=cfg.act_dtype)    # only pad columns need zeros
         dskip = torch.empty(F_, R, H, device=dev, dtype=cfg.act_dtype)
         dh0 = torch.empty(F_, R, H, device=dev)                                       # d h0: fp32 (feeds the fp32 Start conv gradients)
@@ -449,8 +450,10 @@ class DecoderFunction(torch.autograd.Function):
         C2 = C // 2
         order = list(range(F_ - 1, -1, -1))
         for f in order:       # weight-gradient problems of every flow (autograd of Modules.py:791,861,871,793): all pointers are known up front
+            # End conv: fp32 (m, logs) gradients x fp32 skip sum, in the Start conv's launch (a launch costs one tile time whatever its tile
+            # count up to the CU count: a separate launch for these 72 tiles was +0.15 ms, inside the Res_Skip launch +0.10 ms)
             g1.add(douts[f].data_ptr(), prep.ldo, prep.ldo, buf.skip[f].data_ptr(), H, H, G["w_end"][f].data_ptr(), G["b_end"][f].data_ptr(),
-                   perm=ops.PERM_PAIR, perm_h=C2)                 # (X = the fp32 skip sum: shares the launch with the Start conv)
+                   perm=ops.PERM_PAIR, perm_h=C2)
             for l in range(Lw):
                 gates, ldg = (buf.actp[f, l].data_ptr(), H) if bf else (buf.gates[f, l].data_ptr(), 2 * H)
                 if l == Lw - 1:
@@ -481,6 +484,7 @@ class DecoderFunction(torch.autograd.Function):
         for f in order:
             g = FlowGrads()
             g.dx, g.dlogdet, g.douts, g.dskip = dx.data_ptr(), dld.data_ptr(), douts[f].data_ptr(), dskip[f].data_ptr()
+            g.douts_bf = douts_bf.data_ptr() if douts_bf is not None else None
             g.scratch, g.d_an, g.defer_wgrad = scratch[f].data_ptr(), None, 1
             for l in range(Lw):
                 g.dh[l], g.dins[l] = dh_ptr(f, l), dins[f, l].data_ptr()

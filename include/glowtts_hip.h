@@ -193,6 +193,9 @@ int glowtts_actnorm_from_stats(const float *stats, float *logs, float *bias, int
  * d x_b), xmid = coupling input, outs/douts PAIR-packed (m, logs) [rows][ldo], dlogdet [B] = dL/dlogdet. */
 int glowtts_coupling_bwd(float *dz, const float *xmid, const float *outs, float *douts, const float *rowmask,
                          const float *dlogdet, int64_t rows, int C, int ldo, int rows_per_utt, void *stream);
+/* same, and a second bf16 copy of douts (act_bf16 mode: the A operand of the End conv's data gradient on the LDS-DMA / chained path) */
+int glowtts_coupling_bwd_bf16(float *dz, const float *xmid, const float *outs, float *douts, void *douts_bf16, const float *rowmask,
+                              const float *dlogdet, int64_t rows, int C, int ldo, int rows_per_utt, void *stream);
 int glowtts_fill_zero(float *p, int64_t n, void *stream);
 /* Backward of inv-1x1 + ActNorm (autograd of Modules.py:693,749-756).  dz -> dx (may alias), x = flow input.
  * param_grads [2C+16] = { dlogs[C], dbias[C], dW[16] } (data terms only; the log-det terms are added by the caller).
@@ -317,6 +320,7 @@ typedef struct glowtts_flow_grads {       /* backward outputs; weight grads are 
     float *dw_rs[GLOWTTS_MAX_WN_LAYERS], *db_rs[GLOWTTS_MAX_WN_LAYERS];   /* [2H|H][H][1], [2H|H] */
     float *dw_end, *db_end;               /* [C][H][1], [C] */
     float *dcond;                         /* [B][ldcond] or NULL: grad of the conditioning (overwritten per layer slice) */
+    float *douts_bf;                      /* act_bf16 only (else NULL): [R][ldo] bf16 copy of douts, scratch (End data gradient operand) */
 } glowtts_flow_grads;
 
 /* training forward: xin -> xout, fills every kept buffer of `acts` */
