@@ -193,7 +193,8 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
     const bool bfg = bf;                      // ... and so are dskip and dh[l >= 1] (dh[0] stays fp32: it feeds the fp32 Start conv gradients)
     // 1. affine coupling backward                                               autograd of Modules.py:805-806
     const bool dbf = bfg && g->douts_bf != nullptr;        // a bf16 copy of douts feeds the End data gradient (DMA / chained kernel)
-    if (dbf) CHECK(glowtts_coupling_bwd_bf16(g->dx, a->xmid, a->outs, g->douts, g->douts_bf, a->rowmask, g->dlogdet, R, C, ldo, c.Tp, stream));
+    if (g->coupling_done) { /* fused into the previous call's last kernel */ }
+    else if (dbf) CHECK(glowtts_coupling_bwd_bf16(g->dx, a->xmid, a->outs, g->douts, g->douts_bf, a->rowmask, g->dlogdet, R, C, ldo, c.Tp, stream));
     else     CHECK(glowtts_coupling_bwd(g->dx, a->xmid, a->outs, g->douts, a->rowmask, g->dlogdet, R, C, ldo, c.Tp, stream));
     // 2. End conv: data gradient -> d(skip) (masked), weight gradient
     glowtts_conv_args endq = base_args(c, p->end_t, 1);
@@ -277,6 +278,10 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
             CHECK(glowtts_wgrad_cl(&w, stream));
         }
     }
-    // 5. inv-1x1 + ActNorm backward (dx in place), parameter-gradient data terms -> d_an
+    // 5. inv-1x1 + ActNorm backward (dx in place), parameter-gradient data terms -> d_an; optionally the next flow's coupling backward
+    if (g->prev_outs && g->d_an) return GLOWTTS_E_ARG;      // the fused form leaves the parameter-gradient partials to the caller
+    if (g->prev_outs)
+        return glowtts_actnorm_inv1x1_bwd_coupling(g->dx, g->dx, a->xin, p->an_logs, p->an_bias, p->winfo, a->rowmask, g->scratch, R, C,
+                                                   g->prev_xmid, g->prev_outs, g->prev_douts, g->prev_douts_bf, g->dlogdet, ldo, c.Tp, stream);
     return glowtts_actnorm_inv1x1_bwd(g->dx, g->dx, a->xin, p->an_logs, p->an_bias, p->winfo, a->rowmask, g->d_an, g->scratch, R, C, stream);
 }

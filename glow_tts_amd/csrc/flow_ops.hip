@@ -4,6 +4,7 @@
 // [B][Tp][C] (channels contiguous, Tp = T + 2*GLOWTTS_ROW_PAD, zero pad rows around every utterance).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/glowtts_hip.h"
 
 namespace {
@@ -233,6 +234,10 @@ __global__ void zero_kernel(float* __restrict__ p, long n)
 }
 
 // ------------------------------------------------------------------------------------------------
+struct NextCoupling {            // the previous flow's coupling backward, fused into actnorm_inv_bwd_kernel (all null: not fused)
+    const float* xmid; const float* outs; float* douts; __bf16* douts16; const float* dld; int ldo; int rows_per_utt;
+};
+
 // inv-1x1 + ActNorm backward.  dz: grad wrt the inv-1x1 output (rows, C).  x: the flow input (ActNorm input).
 //   y = (bias + exp(logs) x) mask ; z = (W y) mask
 //   dy = W^T (dz mask) ; dx = dy exp(logs) mask ; dW += (dz mask) y^T ; dlogs += dy exp(logs) x mask ; dbias += dy mask
@@ -242,8 +247,10 @@ __global__ __launch_bounds__(256) void actnorm_inv_bwd_kernel(const float* __res
                                                               const float* __restrict__ x, const float* __restrict__ logs,
                                                               const float* __restrict__ bias, const float* __restrict__ winfo,
                                                               const float* __restrict__ rowmask, float* __restrict__ partial,
-                                                              long rows, int C, int rows_per_block)
+                                                              long rows, int C, int rows_per_block, const NextCoupling nc)
 {
+    // nc.outs != null: dx is the gradient of the PREVIOUS flow's output, and that flow's affine-coupling backward (coupling_bwd_kernel) is
+    // applied to it on the fly - the thread that produces d x_b[2g], d x_b[2g+1] has everything that elementwise step needs
     // thread owns group g = threadIdx.x % G for rows r0 + threadIdx.x / G, stepping by 256 / G ... simpler: loop
     const int G = C / 4, C2 = C / 2;
     extern __shared__ float red[];                 // [256][...] not used: accumulate per-thread then LDS reduce per channel
@@ -286,7 +293,28 @@ __global__ __launch_bounds__(256) void actnorm_inv_bwd_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < 4; ++k) { o[k] = dy[k] * el[k]; accL[k] += o[k] * xv[k]; accB[k] += dy[k]; }
             *reinterpret_cast<float2*>(dx + r * C + 2 * g) = make_float2(o[0], o[1]);
-            *reinterpret_cast<float2*>(dx + r * C + C2 + 2 * g) = make_float2(o[2], o[3]);
+            if (nc.outs) {
+                const float dl = nc.dld[r / nc.rows_per_utt];
+                const float2 xb = *reinterpret_cast<const float2*>(nc.xmid + r * C + C2 + 2 * g);
+                float ob[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int j = 2 * g + k, pc = (j >> 5) * 64 + (j & 31);
+                    const float d = o[2 + k], e = expf(nc.outs[r * nc.ldo + pc + 32]);
+                    const float dm = d * m, dlg = (d * e * (k ? xb.y : xb.x) + dl) * m;
+                    nc.douts[r * nc.ldo + pc] = dm; nc.douts[r * nc.ldo + pc + 32] = dlg;
+                    if (nc.douts16) { nc.douts16[r * nc.ldo + pc] = (__bf16)dm; nc.douts16[r * nc.ldo + pc + 32] = (__bf16)dlg; }
+                    ob[k] = d * e * m;
+                    for (int jp = C2 + j; jp < nc.ldo / 2; jp += C2) {       // pad slots of the PAIR packing: zero (see coupling_bwd_kernel)
+                        const int pp = (jp >> 5) * 64 + (jp & 31);
+                        nc.douts[r * nc.ldo + pp] = 0.f; nc.douts[r * nc.ldo + pp + 32] = 0.f;
+                        if (nc.douts16) { nc.douts16[r * nc.ldo + pp] = (__bf16)0.f; nc.douts16[r * nc.ldo + pp + 32] = (__bf16)0.f; }
+                    }
+                }
+                *reinterpret_cast<float2*>(dx + r * C + C2 + 2 * g) = make_float2(ob[0], ob[1]);
+            } else {
+                *reinterpret_cast<float2*>(dx + r * C + C2 + 2 * g) = make_float2(o[2], o[3]);
+            }
         }
     }
     // block reduction through LDS: red[24][256]
@@ -297,10 +325,14 @@ __global__ __launch_bounds__(256) void actnorm_inv_bwd_kernel(const float* __res
     }
     __syncthreads();
     // dW: sum over all threads; dlogs/dbias: sum over threads with the same g
-    if (threadIdx.x < 16) {
+    {   // 16 lanes per entry, 16 values each, then a 16-wide butterfly
+        const int q = threadIdx.x >> 4, part = threadIdx.x & 15;
         float s = 0.f;
-        for (int t = 0; t < 256; ++t) s += red[threadIdx.x * 256 + t];
-        out[2 * C + threadIdx.x] = s;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s += red[q * 256 + t * 16 + part];
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 16);
+        if (part == 0) out[2 * C + q] = s;
     }
     for (int i = threadIdx.x; i < 2 * 4 * G; i += 256) {          // (which in {L,B}) x k x g
         const int which = i / (4 * G), k = (i / G) % 4, gg = i % G;
@@ -420,7 +452,11 @@ extern "C" int glowtts_actnorm_stats(const float* x, const float* rowmask, float
     RET_LAUNCH();
 }
 
-extern "C" int64_t glowtts_actnorm_stats_scratch_floats(int64_t rows, int C) { return ((rows + 63) / 64) * (2 * (int64_t)C + 16); }
+// rows per block of actnorm_inv_bwd_kernel: small blocks (R / 16 = 800+ at the bench size) keep every CU busy; the per-block partials are
+// reduced later by colstats_final_kernel / glowtts_colsum_batched
+static int an_bwd_rpb() { static const int v = [] { const char* e = getenv("GLOWTTS_AN_RPB"); const int x = e ? atoi(e) : 16; return x < 16 ? 16 : x; }(); return v; }
+extern "C" int64_t glowtts_actnorm_bwd_blocks(int64_t rows) { return (rows + an_bwd_rpb() - 1) / an_bwd_rpb(); }
+extern "C" int64_t glowtts_actnorm_stats_scratch_floats(int64_t rows, int C) { return ((rows + 15) / 16) * (2 * (int64_t)C + 16); }
 
 extern "C" int glowtts_actnorm_from_stats(const float* stats, float* logs, float* bias, int C, void* stream)
 {
@@ -463,13 +499,28 @@ extern "C" int glowtts_actnorm_inv1x1_bwd(const float* dz, float* dx, const floa
 {
     if (!dz || !dx || !x || !logs || !bias || !winfo || !rowmask || !scratch || rows < 1 || C < 4 || (C & 3) || C / 4 > 256) return GLOWTTS_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int rpb = 64;
+    const int rpb = an_bwd_rpb();
     const int nblk = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(actnorm_inv_bwd_kernel, dim3(nblk), dim3(256), 24 * 256 * sizeof(float), s, dz, dx, x, logs, bias, winfo, rowmask,
-                       scratch, (long)rows, C, rpb);
+                       scratch, (long)rows, C, rpb, NextCoupling{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1});
     const int n = 2 * C + 16;
     // param_grads == NULL: the caller reduces the per-block partials of all its flows later with glowtts_colsum_batched
     if (param_grads) hipLaunchKernelGGL(colstats_final_kernel, dim3((n + 3) / 4), dim3(256), 0, s, scratch, param_grads, nblk, n, 0L, 0L);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_actnorm_inv1x1_bwd_coupling(const float* dz, float* dx, const float* x, const float* logs, const float* bias, const float* winfo,
+                                                   const float* rowmask, float* scratch, int64_t rows, int C,
+                                                   const float* prev_xmid, const float* prev_outs, float* prev_douts, void* prev_douts_bf16,
+                                                   const float* dlogdet, int ldo, int rows_per_utt, void* stream)
+{
+    if (!dz || !dx || !x || !logs || !bias || !winfo || !rowmask || !scratch || rows < 1 || C < 4 || (C & 3) || C / 4 > 256) return GLOWTTS_E_ARG;
+    if (!prev_xmid || !prev_outs || !prev_douts || !dlogdet || (ldo & 63) || ldo < C || rows_per_utt < 1) return GLOWTTS_E_ARG;
+    const int rpb = an_bwd_rpb();
+    const int nblk = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(actnorm_inv_bwd_kernel, dim3(nblk), dim3(256), 24 * 256 * sizeof(float), static_cast<hipStream_t>(stream), dz, dx, x, logs, bias, winfo,
+                       rowmask, scratch, (long)rows, C, rpb,
+                       NextCoupling{prev_xmid, prev_outs, prev_douts, static_cast<__bf16*>(prev_douts_bf16), dlogdet, ldo, rows_per_utt});
     RET_LAUNCH();
 }
 

@@ -50,7 +50,8 @@ class FlowGrads(ctypes.Structure):
                 ("dw_start", c_void_p), ("db_start", c_void_p),
                 ("dw_in", c_void_p * MAXL), ("db_in", c_void_p * MAXL),
                 ("dw_rs", c_void_p * MAXL), ("db_rs", c_void_p * MAXL),
-                ("dw_end", c_void_p), ("db_end", c_void_p), ("dcond", c_void_p), ("douts_bf", c_void_p)]
+                ("dw_end", c_void_p), ("db_end", c_void_p), ("dcond", c_void_p), ("douts_bf", c_void_p),
+                ("coupling_done", c_int), ("prev_xmid", c_void_p), ("prev_outs", c_void_p), ("prev_douts", c_void_p), ("prev_douts_bf", c_void_p)]
 
 
 _declared = False
@@ -67,6 +68,8 @@ def _L():
         L.glowtts_actnorm_stats.argtypes = [c_void_p] * 4 + [c_i64, c_int, c_void_p]
         L.glowtts_actnorm_stats_scratch_floats.argtypes = [c_i64, c_int]
         L.glowtts_actnorm_stats_scratch_floats.restype = c_i64
+        L.glowtts_actnorm_bwd_blocks.argtypes = [c_i64]
+        L.glowtts_actnorm_bwd_blocks.restype = c_i64
         L.glowtts_actnorm_from_stats.argtypes = [c_void_p] * 3 + [c_int, c_void_p]
         L.glowtts_actnorm_inv1x1.argtypes = [c_void_p] * 6 + [c_i64, c_int, c_int, c_void_p]
         L.glowtts_flow_forward.argtypes = [c_void_p] * 4
@@ -434,6 +437,7 @@ class DecoderFunction(torch.autograd.Function):
         # two grouped launches (k-tap problems, 1x1 problems) whose tiles fill the chip without split-K or atomics
         douts = torch.empty(F_, R, prep.ldo, device=dev)           # (pad columns are zeroed by the coupling backward kernel)
         douts_bf = torch.empty(R, prep.ldo, device=dev, dtype=torch.bfloat16) if cfg.act_bf16 else None      # bf16 copy, reused by every flow
+        fuse = os.environ.get("GLOWTTS_FUSE_COUPLING_BWD", "1") != "0"
         dins = (torch.empty if prep.ldin == 2 * H else torch.zeros)(F_, Lw, R, prep.ldin, device=dev, dtype=cfg.act_dtype)    # only pad columns need zeros
         dskip = torch.empty(F_, R, H, device=dev, dtype=cfg.act_dtype)
         dh0 = torch.empty(F_, R, H, device=dev)                                       # d h0: fp32 (feeds the fp32 Start conv gradients)
@@ -485,6 +489,11 @@ class DecoderFunction(torch.autograd.Function):
             g = FlowGrads()
             g.dx, g.dlogdet, g.douts, g.dskip = dx.data_ptr(), dld.data_ptr(), douts[f].data_ptr(), dskip[f].data_ptr()
             g.douts_bf = douts_bf.data_ptr() if douts_bf is not None else None
+            # the last kernel of this flow's backward also applies the coupling backward of the flow that runs next (f - 1)
+            g.coupling_done = int(fuse and f != order[0])
+            if fuse and f > 0:
+                g.prev_xmid, g.prev_outs, g.prev_douts = buf.xmid[f - 1].data_ptr(), buf.outs[f - 1].data_ptr(), douts[f - 1].data_ptr()
+                g.prev_douts_bf = douts_bf.data_ptr() if douts_bf is not None else None
             g.scratch, g.d_an, g.defer_wgrad = scratch[f].data_ptr(), None, 1
             for l in range(Lw):
                 g.dh[l], g.dins[l] = dh_ptr(f, l), dins[f, l].data_ptr()
@@ -511,7 +520,7 @@ class DecoderFunction(torch.autograd.Function):
         else:
             for grp in (gk, gp, g1):
                 grp.launch_segment(0)
-        _lib.check(L.glowtts_colsum_batched(scratch.data_ptr(), d_an.data_ptr(), (R + 63) // 64, 2 * C + 16, F_, nscr, 2 * C + 16, _lib.stream()),
+        _lib.check(L.glowtts_colsum_batched(scratch.data_ptr(), d_an.data_ptr(), L.glowtts_actnorm_bwd_blocks(R), 2 * C + 16, F_, nscr, 2 * C + 16, _lib.stream()),
                    "glowtts_colsum_batched")
         # log-determinant terms of the parameters (Modules.py:694, 747): logdet_b += (sum logs + logdet(W) C/4) * len_b
         lens = rowmask.view(B, -1).sum(1)

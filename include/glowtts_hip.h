@@ -203,6 +203,14 @@ int glowtts_fill_zero(float *p, int64_t n, void *stream);
 int glowtts_actnorm_inv1x1_bwd(const float *dz, float *dx, const float *x, const float *logs, const float *bias,
                                const float *winfo, const float *rowmask, float *param_grads, float *scratch,
                                int64_t rows, int C, void *stream);
+/* number of per-block partial rows glowtts_actnorm_inv1x1_bwd leaves in scratch (each 2C+16 floats) when param_grads == NULL */
+int64_t glowtts_actnorm_bwd_blocks(int64_t rows);
+/* glowtts_actnorm_inv1x1_bwd (param_grads = NULL form) of flow f FUSED with glowtts_coupling_bwd(_bf16) of flow f-1: dx leaves as the
+ * gradient of flow f-1's coupling input, prev_douts (+ optional bf16 copy) are filled.  One launch and one pass over the rows fewer per flow. */
+int glowtts_actnorm_inv1x1_bwd_coupling(const float *dz, float *dx, const float *x, const float *logs, const float *bias, const float *winfo,
+                                        const float *rowmask, float *scratch, int64_t rows, int C,
+                                        const float *prev_xmid, const float *prev_outs, float *prev_douts, void *prev_douts_bf16,
+                                        const float *dlogdet, int ldo, int rows_per_utt, void *stream);
 /* out[b][i] = sum_r partial[b][r][i], i < n, r < nrows (deterministic): reduces the per-block partials of several
  * glowtts_actnorm_inv1x1_bwd calls made with param_grads = NULL (their `scratch` buffers, part_stride floats apart) in one launch */
 int glowtts_colsum_batched(const float *partial, float *out, int nrows, int n, int batch, int64_t part_stride, int64_t out_stride, void *stream);
@@ -321,6 +329,10 @@ typedef struct glowtts_flow_grads {       /* backward outputs; weight grads are 
     float *dw_end, *db_end;               /* [C][H][1], [C] */
     float *dcond;                         /* [B][ldcond] or NULL: grad of the conditioning (overwritten per layer slice) */
     float *douts_bf;                      /* act_bf16 only (else NULL): [R][ldo] bf16 copy of douts, scratch (End data gradient operand) */
+    /* fusion across flows (backward runs flow F-1 .. 0): */
+    int coupling_done;                    /* 1: the previous call already applied THIS flow's coupling backward (dx, douts, douts_bf are ready) */
+    const float *prev_xmid, *prev_outs;   /* not NULL: after this flow's ActNorm / 1x1 backward, apply the coupling backward of the flow that */
+    float *prev_douts, *prev_douts_bf;    /*           runs next (f-1) in the same kernel; that call must then set coupling_done */
 } glowtts_flow_grads;
 
 /* training forward: xin -> xout, fills every kept buffer of `acts` */
