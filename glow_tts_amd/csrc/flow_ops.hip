@@ -348,33 +348,35 @@ __global__ __launch_bounds__(256) void actnorm_inv_bwd_kernel(const float* __res
 //   logdet[b] = sum_f [ (sum_c logs_f[c] + logdet(W_f) * C/4) * len'_b + sum_{valid rows of b} sum_j logs^{coupling}_f ]
 // stage 1: grid (F, B) -> part[f][b];  stage 2: fixed-order sum over f.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void logdet_partial_kernel(const float* __restrict__ outs_all, long flow_stride,
-                                                             const float* __restrict__ logs_all, const float* __restrict__ winfo_all,
-                                                             const float* __restrict__ rowmask, float* __restrict__ part,
-                                                             int B, int Tp, int C, int ldo)
+__global__ __launch_bounds__(1024) void logdet_partial_kernel(const float* __restrict__ outs_all, long flow_stride,
+                                                              const float* __restrict__ logs_all, const float* __restrict__ winfo_all,
+                                                              const float* __restrict__ rowmask, float* __restrict__ part,
+                                                              int B, int Tp, int C, int ldo)
 {
-    __shared__ float red[256];
+    // 16 wavefronts, one row per wavefront and pass: lane j reads the log-scale of pair slot j (PAIR packing: 32-wide runs at +32 of
+    // every 64 columns), so no index arithmetic beyond shifts and every load is a 128-byte run
+    __shared__ float red[3][16];
     const int f = blockIdx.x, b = blockIdx.y;
-    const int C2 = C / 2;
+    const int C2 = C / 2, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* outs = outs_all + (long)f * flow_stride + (long)b * Tp * ldo;
     const float* rm = rowmask + (long)b * Tp;
-    float s = 0.f, len = 0.f;
-    for (int i = threadIdx.x; i < Tp * C2; i += 256) {
-        const int t = i / C2, j = i - t * C2;
-        s += outs[(long)t * ldo + (j >> 5) * 64 + 32 + (j & 31)] * rm[t];
+    float s = 0.f, len = 0.f, ls = 0.f;
+    for (int t = wave; t < Tp; t += 16) {
+        const float m = rm[t];
+        len += m;                                                       // (every lane holds the same count)
+        if (m != 0.f)
+            for (int j = lane; j < C2; j += 64) s += outs[(long)t * ldo + (j >> 5) * 64 + 32 + (j & 31)];
     }
-    for (int t = threadIdx.x; t < Tp; t += 256) len += rm[t];
-    float ls = 0.f;
-    for (int c = threadIdx.x; c < C; c += 256) ls += logs_all[f * C + c];
-    red[threadIdx.x] = s; __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
-    const float S = red[0]; __syncthreads();
-    red[threadIdx.x] = len; __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
-    const float L = red[0]; __syncthreads();
-    red[threadIdx.x] = ls; __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
-    if (threadIdx.x == 0) part[f * B + b] = S + (red[0] + winfo_all[f * 36 + 32] * (float)(C / 4)) * L;
+    for (int c = threadIdx.x; c < C; c += 1024) ls += logs_all[f * C + c];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ls += __shfl_xor(ls, o); }
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = len; red[2][wave] = ls; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float S = 0.f, L = 0.f, A = 0.f;
+        for (int w = 0; w < 16; ++w) { S += red[0][w]; L += red[1][w]; A += red[2][w]; }
+        part[f * B + b] = S + (A + winfo_all[f * 36 + 32] * (float)(C / 4)) * L;
+    }
 }
 __global__ void logdet_final_kernel(const float* __restrict__ part, float* __restrict__ logdet, int F, int B)
 {
@@ -537,7 +539,7 @@ extern "C" int glowtts_decoder_logdet(const float* outs_all, int64_t flow_stride
 {
     if (!outs_all || !logs_all || !winfo_all || !rowmask || !part || !logdet || F < 1 || B < 1) return GLOWTTS_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(logdet_partial_kernel, dim3(F, B), dim3(256), 0, s, outs_all, (long)flow_stride, logs_all, winfo_all, rowmask, part, B, Tp, C, ldo);
+    hipLaunchKernelGGL(logdet_partial_kernel, dim3(F, B), dim3(1024), 0, s, outs_all, (long)flow_stride, logs_all, winfo_all, rowmask, part, B, Tp, C, ldo);
     hipLaunchKernelGGL(logdet_final_kernel, dim3((B + 255) / 256), dim3(256), 0, s, part, logdet, F, B);
     RET_LAUNCH();
 }

@@ -19,42 +19,36 @@ __global__ __launch_bounds__(256) void expand_fwd_kernel(const float* __restrict
     const int32_t* ib = idx + (long)b * Ty;
     for (int y = blockIdx.x * 256 + threadIdx.x; y < Ty; y += gridDim.x * 256) { const int x = ib[y]; o[y] = x >= 0 ? s[x] : 0.f; }
 }
-// dsrc[b][c][x] = sum_{y : idx[b][y] == x} dout[b][c][y].  idx is non-decreasing over the valid frames, so the frames of token x are
-// the contiguous range [first[x], next[x]); `first` / `next` come from a per-utterance scan kept in LDS.  One wavefront per (b, c) row:
-// the row is staged into LDS with coalesced loads, then every lane sums the segments of its tokens (fixed order: deterministic).
+// dsrc[b][c][x] = sum_{y : idx[b][y] == x} dout[b][c][y].  idx is non-decreasing over the valid frames, so the frames of a token are a
+// contiguous run.  One wavefront per (b, c) row: 64 frames at a time, a segmented (keyed by token) inclusive scan over the lanes, and
+// the lane at the end of each run adds the run's sum to its token's LDS slot.  Cost is independent of how skewed the durations are
+// (MAS on untrained weights gives runs of hundreds of frames), the order of the additions is fixed: deterministic.
 __global__ __launch_bounds__(256) void expand_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ idx, float* __restrict__ dsrc,
                                                          int C, int Tx, int Ty)
 {
-    extern __shared__ int sm_i[];
-    int* first = sm_i;                                   // [Tx]  first frame of token x, -1 if it has none
-    int* cnt = sm_i + Tx;                                // [Tx]  number of frames of token x
-    float* rowbuf = reinterpret_cast<float*>(sm_i + 2 * Tx);      // [4 waves][Ty]
+    extern __shared__ float sm_acc[];                    // [4 waves][Tx]
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= C) return;                                  // (no workgroup barrier below)
+    float* acc = sm_acc + wave * Tx;
+    for (int x = lane; x < Tx; x += 64) acc[x] = 0.f;
     const int32_t* ib = idx + (long)b * Ty;
-    for (int x = threadIdx.x; x < Tx; x += 256) { first[x] = -1; cnt[x] = 0; }
-    __syncthreads();
-    for (int y = threadIdx.x; y < Ty; y += 256) {
-        const int x = ib[y];
-        if (x >= 0 && (y == 0 || ib[y - 1] != x)) first[x] = y;
-        if (x >= 0 && (y == Ty - 1 || ib[y + 1] != x)) cnt[x] = y + 1;        // one past the last frame of x (turned into a count below)
-    }
-    __syncthreads();
-    for (int x = threadIdx.x; x < Tx; x += 256) cnt[x] = first[x] >= 0 ? cnt[x] - first[x] : 0;
-    __syncthreads();
-    float* rb = rowbuf + wave * Ty;
-    for (int c = blockIdx.x * 4 + wave; c < C; c += gridDim.x * 4) {
-        const float* d = dout + ((long)b * C + c) * Ty;
-        for (int y = lane; y < Ty; y += 64) rb[y] = d[y];
-        // (same wave reads below: LDS accesses of one wave complete in order)
-        __builtin_amdgcn_wave_barrier();
-        for (int x = lane; x < Tx; x += 64) {
-            float acc = 0.f;
-            const int y0 = first[x], n = cnt[x];
-            for (int k = 0; k < n; ++k) acc += rb[y0 + k];
-            dsrc[((long)b * C + c) * Tx + x] = acc;
+    const float* d = dout + ((long)b * C + c) * Ty;
+    for (int y0 = 0; y0 < Ty; y0 += 64) {
+        const int y = y0 + lane;
+        float v = y < Ty ? d[y] : 0.f;
+        const int x = y < Ty ? ib[y] : -1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float vv = __shfl_up(v, o);
+            const int xx = __shfl_up(x, o);
+            if (lane >= o && xx == x) v += vv;
         }
-        __builtin_amdgcn_wave_barrier();
+        const int xn = __shfl_down(x, 1);
+        if (x >= 0 && (lane == 63 || xn != x)) acc[x] += v;          // one lane per token and pass; LDS accesses of a wave complete in order
     }
+    __builtin_amdgcn_wave_barrier();
+    for (int x = lane; x < Tx; x += 64) dsrc[((long)b * C + c) * Tx + x] = acc[x];
 }
 // target[b][x] = log(count_x + 1e-7) * (x < t_x[b])
 __global__ __launch_bounds__(256) void dur_target_kernel(const int32_t* __restrict__ idx, const int64_t* __restrict__ t_x, float* __restrict__ out, int Tx, int Ty)
@@ -127,8 +121,8 @@ extern "C" int glowtts_expand_fwd(const float* src, const int32_t* idx, float* o
 extern "C" int glowtts_expand_bwd(const float* dout, const int32_t* idx, float* dsrc, int B, int C, int Tx, int Ty, void* stream)
 {
     if (!dout || !idx || !dsrc || B < 1 || C < 1 || Tx < 1 || Ty < 1) return GLOWTTS_E_ARG;
-    const int gx = (C + 15) / 16;                               // 4 rows per workgroup pass, ~4 passes
-    const size_t lds = (size_t)2 * Tx * sizeof(int) + (size_t)4 * Ty * sizeof(float);
+    const int gx = (C + 3) / 4;                                 // one (b, c) row per wavefront
+    const size_t lds = (size_t)4 * Tx * sizeof(float);
     if (lds > 64 * 1024) return GLOWTTS_E_ARG;
     hipLaunchKernelGGL(expand_bwd_kernel, dim3(gx, B), dim3(256), lds, static_cast<hipStream_t>(stream), dout, idx, dsrc, C, Tx, Ty);
     RET_LAUNCH();

@@ -114,7 +114,8 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
     for i in range(dp.Stacks):
         q = f"{prefix}.layer_Dict.Duration_Predictor.layer_Dict.CRND_{i}.layer_Dict.Conv"
         d = conv(d, q, relu=True, mask_out=True, drop=dp.Dropout_Rate)
-    # Projection to one channel: N = 1 is not a GEMM; a masked dot product per frame
+    # Projection to one channel: N = 1 is not a GEMM; a masked dot product per frame (multiply + row reduction: rocBLAS' gemv took
+    # 82 us for these 3.5k x 256 rows, 5x the two elementwise kernels)
     wq = prefix + ".layer_Dict.Duration_Predictor.layer_Dict.Projection"
-    log_dur = (d @ Pc[wq + ".weight"][0, :, 0] + Pc[wq + ".bias"]).view(B, Tp)[:, ROW_PAD:-ROW_PAD].unsqueeze(1) * mask
+    log_dur = ((d * Pc[wq + ".weight"][0, :, 0]).sum(-1) + Pc[wq + ".bias"]).view(B, Tp)[:, ROW_PAD:-ROW_PAD].unsqueeze(1) * mask
     return mean, log_std, log_dur
