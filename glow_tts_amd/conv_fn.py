@@ -112,13 +112,14 @@ class ConvRows(torch.autograd.Function):
     Mirrors torch.nn.Conv1d(k, padding=(k-1)//2) + the elementwise tail the reference applies after it."""
 
     @staticmethod
-    def forward(ctx, x, w, b, rowmask, residual, relu, mask_out, precision, drop_p, seed, seed_t, tape=None):
+    def forward(ctx, x, w, b, rowmask, residual, relu, mask_out, precision, drop_p, seed, seed_t, tape=None, packs=None):
         ctx.tape = tape
+        ctx.pwt = packs[1] if packs is not None else None         # packs: (forward, transposed) from an ops.PackSet already run this step
         x = x.contiguous()
         R, Cin = x.shape
         O, Ci2, k = w.shape
         assert Ci2 <= Cin and Cin % 4 == 0
-        pw = ops.pack_weight(w.detach(), precision=precision)
+        pw = packs[0] if packs is not None else ops.pack_weight(w.detach(), precision=precision)
         out = torch.empty(R, O, device=x.device)
         flags = (ops.F_BIAS if b is not None else 0) | (ops.F_RELU if relu else 0) | (ops.F_MASK if mask_out else 0) | \
                 (ops.F_ADD_IN0 if residual is not None else 0) | (ops.F_DROPOUT if drop_p > 0 else 0)
@@ -150,7 +151,7 @@ class ConvRows(torch.autograd.Function):
         dres = dz if (has_res and ctx.needs_input_grad[4]) else None
         dx = None
         if ctx.needs_input_grad[0]:
-            pwt = ops.pack_weight(w.detach(), transpose=True, precision=precision)
+            pwt = ctx.pwt if ctx.pwt is not None else ops.pack_weight(w.detach(), transpose=True, precision=precision)
             dx = torch.empty(R, Cin, device=x.device) if Cin == Ci2 else torch.zeros(R, Cin, device=x.device)
             ops.conv_cl(dz, pwt, O, R, lda=O, pad=(k - 1) // 2, epi=ops.EPI_LINEAR, flags=0, n=Ci2, out0=dx, ld0=Cin)
         dw = db = None
@@ -161,11 +162,12 @@ class ConvRows(torch.autograd.Function):
                 ctx.tape.add(dz, x, O, Ci2, k, precision, dw, db)
             else:
                 dw, db = wgrad(dz, x, O, Ci2, k, precision, want_bias=has_b, splits=min(4, max(1, R // 512)))
-        return dx, dw, db, None, dres, None, None, None, None, None, None, None
+        return dx, dw, db, None, dres, None, None, None, None, None, None, None, None
 
 
-def conv_rows(x, w, b, rowmask, relu=False, mask_out=False, residual=None, precision=ops.BF16, drop_p=0.0, seed=0, seed_t=None, tape=None):
-    return ConvRows.apply(x, w, b, rowmask, residual, relu, mask_out, precision, float(drop_p), seed, seed_t, tape)
+def conv_rows(x, w, b, rowmask, relu=False, mask_out=False, residual=None, precision=ops.BF16, drop_p=0.0, seed=0, seed_t=None, tape=None,
+              packs=None):
+    return ConvRows.apply(x, w, b, rowmask, residual, relu, mask_out, precision, float(drop_p), seed, seed_t, tape, packs)
 
 
 class LayerNormRows(torch.autograd.Function):

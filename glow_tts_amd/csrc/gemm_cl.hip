@@ -83,6 +83,32 @@ __device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t id, float p,
 // ------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------
+// one packed element: i = ((t * kchunks + kc) * npad + n) * KC + kk  ->  the fp32 weight it holds (0 in the padding)
+template <int KC>
+__device__ __forceinline__ float pack_element(const float* __restrict__ w, long i, int O, int I, int taps, int transpose, int perm, int perm_h,
+                                              int N, int K, int npad, int kchunks)
+{
+    const int kk = i % KC;
+    long r = i / KC;
+    const int n = r % npad; r /= npad;
+    const int kc = r % kchunks;
+    const int t = r / kchunks;
+    const int k = kc * KC + kk;
+    // map the packed (n, k) to original (o, c)
+    int o_idx = transpose ? k : n;      // index that runs over O (possibly permuted)
+    int c_idx = transpose ? n : k;
+    const int o_lim = transpose ? K : N;   // padded logical extent of the O-side index
+    bool ok = o_idx < o_lim;
+    int o = o_idx;
+    if (perm == GLOWTTS_PERM_PAIR) {
+        const int p = o_idx >> 6, hsel = (o_idx >> 5) & 1, j = (p << 5) + (o_idx & 31);
+        ok = ok && (j < perm_h);
+        o = hsel * perm_h + j;
+    }
+    ok = ok && (o < O) && (c_idx < I);
+    return ok ? w[((long)o * I + c_idx) * taps + (transpose ? (taps - 1 - t) : t)] : 0.f;
+}
+
 template <typename CT>
 __global__ void pack_weight_kernel(const float* __restrict__ w, CT* __restrict__ out, int O, int I, int taps,
                                    int transpose, int perm, int perm_h, int N, int K, int npad, int kchunks)
@@ -91,28 +117,27 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, CT* __restrict__
     const long total = (long)taps * kchunks * npad * KC;
     w += (long)blockIdx.y * O * I * taps;          // batch of independent weights
     out += (long)blockIdx.y * total;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int kk = i % KC;
-        long r = i / KC;
-        const int n = r % npad; r /= npad;
-        const int kc = r % kchunks;
-        const int t = r / kchunks;
-        const int k = kc * KC + kk;
-        float v = 0.f;
-        // map the packed (n, k) to original (o, c)
-        int o_idx = transpose ? k : n;      // index that runs over O (possibly permuted)
-        int c_idx = transpose ? n : k;
-        const int o_lim = transpose ? K : N;   // padded logical extent of the O-side index
-        bool ok = o_idx < o_lim;
-        int o = o_idx;
-        if (perm == GLOWTTS_PERM_PAIR) {
-            const int p = o_idx >> 6, hsel = (o_idx >> 5) & 1, j = (p << 5) + (o_idx & 31);
-            ok = ok && (j < perm_h);
-            o = hsel * perm_h + j;
-        }
-        ok = ok && (o < O) && (c_idx < I);
-        if (ok) v = w[((long)o * I + c_idx) * taps + (transpose ? (taps - 1 - t) : t)];
-        out[i] = (CT)v;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        out[i] = (CT)pack_element<KC>(w, i, O, I, taps, transpose, perm, perm_h, N, K, npad, kchunks);
+}
+
+// many weights of different shapes in one launch (the encoder's ~30 convs, forward and transposed): a device job table, PACK_CHUNK
+// packed elements per workgroup, the job found by bisection over the jobs' first workgroup
+constexpr int PACK_CHUNK = 2048;
+template <typename CT>
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const glowtts_pack_job* __restrict__ jobs, int njobs)
+{
+    constexpr int KC = 64 / sizeof(CT);
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const glowtts_pack_job j = jobs[lo];
+    const long total = (long)j.taps * j.kchunks * j.npad * KC;
+    const long base = (long)(blockIdx.x - j.block0) * PACK_CHUNK;
+    CT* out = static_cast<CT*>(j.packed);
+#pragma unroll
+    for (int e = 0; e < PACK_CHUNK / 256; ++e) {
+        const long i = base + e * 256 + threadIdx.x;
+        if (i < total) out[i] = (CT)pack_element<KC>(j.w, i, j.O, j.I, j.taps, j.transpose, j.perm, j.perm_h, j.N, j.K, j.npad, j.kchunks);
     }
 }
 
@@ -1370,6 +1395,33 @@ extern "C" int glowtts_pack_weight_batched(const float* w, int batch, int O, int
         hipLaunchKernelGGL(pack_weight_kernel<__bf16>, dim3(blocks, batch), dim3(256), 0, s, w, static_cast<__bf16*>(packed), O, I, taps, transpose, perm, perm_h, N, kchunks * KC, npad, kchunks);
     else
         hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks, batch), dim3(256), 0, s, w, static_cast<float*>(packed), O, I, taps, transpose, perm, perm_h, N, kchunks * KC, npad, kchunks);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
+extern "C" int glowtts_pack_job_init(glowtts_pack_job* job, const float* w, int O, int I, int taps, int transpose, int perm, int perm_h,
+                                     int precision, void* packed, int block0, int* blocks_out, int64_t* bytes_out)
+{
+    if (!job) return GLOWTTS_E_ARG;
+    int npad = 0, kchunks = 0;
+    const int rc = glowtts_pack_weight_batched(nullptr, 1, O, I, taps, transpose, perm, perm_h, precision, nullptr, &npad, &kchunks, nullptr);
+    if (rc != GLOWTTS_OK) return rc;
+    const int KC = precision == GLOWTTS_BF16 ? 32 : 16;
+    const int o_ext = (perm == GLOWTTS_PERM_PAIR) ? pad_to(perm_h, 32) * 2 : O;
+    *job = glowtts_pack_job{};
+    job->w = w; job->packed = packed; job->O = O; job->I = I; job->taps = taps; job->transpose = transpose; job->perm = perm; job->perm_h = perm_h;
+    job->N = transpose ? I : o_ext; job->K = kchunks * KC; job->npad = npad; job->kchunks = kchunks; job->block0 = block0;
+    const long total = (long)taps * kchunks * npad * KC;
+    if (blocks_out) *blocks_out = (int)((total + PACK_CHUNK - 1) / PACK_CHUNK);
+    if (bytes_out) *bytes_out = (int64_t)taps * kchunks * npad * 64;
+    return GLOWTTS_OK;
+}
+
+extern "C" int glowtts_pack_weight_multi(const glowtts_pack_job* dev_jobs, int njobs, int total_blocks, int precision, void* stream)
+{
+    if (!dev_jobs || njobs < 1 || total_blocks < 1 || (precision != GLOWTTS_F32 && precision != GLOWTTS_BF16)) return GLOWTTS_E_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (precision == GLOWTTS_BF16) hipLaunchKernelGGL(pack_weight_multi_kernel<__bf16>, dim3(total_blocks), dim3(256), 0, s, dev_jobs, njobs);
+    else hipLaunchKernelGGL(pack_weight_multi_kernel<float>, dim3(total_blocks), dim3(256), 0, s, dev_jobs, njobs);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 

@@ -15,6 +15,7 @@ import math
 import torch
 import torch.nn.functional as F
 
+from . import ops
 from .conv_fn import EmbeddingRows, ParamGate, RPRAttention, WgradTape, conv_rows, layernorm_rows
 
 ROW_PAD = 2
@@ -66,10 +67,24 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
             for k, v in zip(gated, ParamGate.apply(tape, *[Pc[k] for k in gated])):
                 Pc[k] = v
 
+    # every conv weight (and, when training, its transpose for the data gradient) is packed into MFMA tile order by one launch
+    packset = None
+    if cache is not None:
+        items = [(k[:-len(".weight")], v, tr) for k, v in Pc.items()
+                 if k.startswith(prefix) and k.endswith(".weight") and v.dim() == 3 and v.shape[0] > 1
+                 and not k.endswith((".Query.weight", ".Key.weight", ".Value.weight"))
+                 for tr in ((False, True) if torch.is_grad_enabled() else (False,))]
+        slot = ("packset", precision, torch.is_grad_enabled())
+        packset = cache.get(slot)
+        if packset is None or packset.sig != ops.PackSet.signature(items):
+            packset = cache[slot] = ops.PackSet(items, precision)
+        packset.run()
+
     def conv(xr, name, relu=False, mask_out=False, residual=None, drop=0.0):
         p_ = float(drop) if training else 0.0
         return conv_rows(xr, Pc[name + ".weight"], Pc.get(name + ".bias"), rmf, relu=relu, mask_out=mask_out, residual=residual,
-                         precision=precision, drop_p=p_, seed=nseed(), seed_t=seed_t, tape=tape)
+                         precision=precision, drop_p=p_, seed=nseed(), seed_t=seed_t, tape=tape,
+                         packs=packset.get(name) if packset is not None else None)
 
     def ln(a, b, name, relu=False, drop=0.0):
         p_ = float(drop) if training else 0.0

@@ -70,6 +70,61 @@ def pack_weight(w, transpose=False, perm=PERM_NONE, perm_h=0, precision=BF16):
     return PackedWeight(buf, npad.value, kch.value, taps, precision, n)
 
 
+class PackJob(ctypes.Structure):
+    """Mirror of `glowtts_pack_job` (include/glowtts_hip.h)."""
+    _fields_ = [("w", c_void_p), ("packed", c_void_p)] + [(n, c_int) for n in
+                ("O", "I", "taps", "transpose", "perm", "perm_h", "N", "K", "npad", "kchunks", "block0", "reserved")]
+
+
+class PackSet:
+    """Conv weights of different shapes packed by ONE launch (glowtts_pack_weight_multi) into one buffer.
+    items: [(key, fp32 weight [O, I, taps], transpose)].  The device job table is built once; `run()` re-packs the current values
+    (call it once per forward: the optimizer changes them in place).  `matches(items)` tells whether the pointers still hold."""
+
+    def __init__(self, items, precision=BF16):
+        L = _lib.lib()
+        L.glowtts_pack_job_init.argtypes = [ctypes.POINTER(PackJob), c_void_p] + [c_int] * 7 + [c_void_p, c_int,
+                                            ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_int64)]
+        L.glowtts_pack_weight_multi.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
+        assert items
+        dev = items[0][1].device
+        n = len(items)
+        jobs = (PackJob * n)()
+        blocks, nbytes = c_int(0), ctypes.c_int64(0)
+        offs, total = [], 0
+        for i, (_, w, tr) in enumerate(items):
+            assert w.dim() == 3 and w.is_contiguous() and w.dtype == torch.float32
+            O, I, k = w.shape
+            _lib.check(L.glowtts_pack_job_init(ctypes.byref(jobs[i]), None, O, I, k, int(tr), PERM_NONE, 0, precision, None, 0,
+                                               ctypes.byref(blocks), ctypes.byref(nbytes)), "glowtts_pack_job_init(size)")
+            offs.append(total)
+            total += (nbytes.value + 255) // 256 * 256
+        self.data = torch.empty(total, dtype=torch.uint8, device=dev)
+        self.packed, b0 = {}, 0
+        for i, (key, w, tr) in enumerate(items):
+            O, I, k = w.shape
+            _lib.check(L.glowtts_pack_job_init(ctypes.byref(jobs[i]), w.data_ptr(), O, I, k, int(tr), PERM_NONE, 0, precision,
+                                               self.data.data_ptr() + offs[i], b0, ctypes.byref(blocks), ctypes.byref(nbytes)), "glowtts_pack_job_init")
+            b0 += blocks.value
+            self.packed[(key, bool(tr))] = PackedWeight(self.data[offs[i]:offs[i] + nbytes.value], jobs[i].npad, jobs[i].kchunks, k, precision,
+                                                        I if tr else O)
+        self.table = torch.frombuffer(bytearray(jobs), dtype=torch.uint8).to(dev)
+        self.njobs, self.blocks, self.precision = n, b0, precision
+        self.sig = self.signature(items)
+
+    @staticmethod
+    def signature(items):
+        return tuple((k, w.data_ptr(), tuple(w.shape), bool(tr)) for k, w, tr in items)
+
+    def run(self):
+        _lib.check(_lib.lib().glowtts_pack_weight_multi(self.table.data_ptr(), self.njobs, self.blocks, self.precision, _lib.stream()),
+                   "glowtts_pack_weight_multi")
+
+    def get(self, key):
+        """(forward pack, transposed pack or None)"""
+        return self.packed[(key, False)], self.packed.get((key, True))
+
+
 def conv_cl(a, pw, ca, rows, *, lda=None, a2=None, lda2=0, ca1=0, apro=APRO_NONE, pad=0, epi=EPI_LINEAR, flags=0,
             n=None, h=0, rows_per_utt=1, bias=None, rowmask=None, cond=None, ldcond=0,
             out0=None, ld0=0, out1=None, ld1=0, in0=None, ldi0=0, out0_off=0, a_off=0, drop_p=0.0, seed=0, seed_t=None, io_flags=0):

@@ -87,6 +87,20 @@ int glowtts_mas_f32(const float *value, int32_t *path, const int32_t *t_xs, cons
 int glowtts_pack_weight(const float *w, int O, int I, int taps, int transpose, int perm, int perm_h,
                         int precision, void *packed, int *npad_out, int *kchunks_out, void *stream);
 
+/* Many weights of different shapes packed by ONE launch (the encoder's convs, forward and transposed: ~70 launches of
+ * glowtts_pack_weight per training step otherwise).  Jobs live in device memory; fill them on the host with glowtts_pack_job_init
+ * (same arguments as glowtts_pack_weight; block0 = running sum of the previous jobs' *blocks_out), copy the table to the device
+ * once - it stays valid while the weight and packed pointers do - and launch with total_blocks = the final running sum. */
+typedef struct glowtts_pack_job {
+    const float *w; void *packed;
+    int O, I, taps, transpose, perm, perm_h;
+    int N, K, npad, kchunks;               /* derived (glowtts_pack_job_init) */
+    int block0, reserved;
+} glowtts_pack_job;
+int glowtts_pack_job_init(glowtts_pack_job *job, const float *w, int O, int I, int taps, int transpose, int perm, int perm_h,
+                          int precision, void *packed, int block0, int *blocks_out, int64_t *bytes_out);
+int glowtts_pack_weight_multi(const glowtts_pack_job *dev_jobs, int njobs, int total_blocks, int precision, void *stream);
+
 /* `batch` independent weights of identical shape, w [batch][O][I][taps] -> packed [batch][taps*kchunks*npad*64 bytes] */
 int glowtts_pack_weight_batched(const float *w, int batch, int O, int I, int taps, int transpose, int perm, int perm_h,
                                 int precision, void *packed, int *npad_out, int *kchunks_out, void *stream);

@@ -203,3 +203,21 @@ def test_epilogue_stores_stay_inside_rows(prec):
     ops.conv_cl(a, pw3, 2 * H, R, a2=a, lda2=H, ca1=H, epi=ops.EPI_DGATE, n=H, h=H, in0=G, ldi0=2 * H, out0=d, ld0=pw.npad)
     assert torch.all(d[R:] == S) and not torch.any(d[:R, :2 * H] == S)
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [ops.F32, ops.BF16])
+def test_pack_set_equals_single_packs(precision):
+    """glowtts_pack_weight_multi (one launch, heterogeneous shapes, forward + transposed) writes the same bytes as glowtts_pack_weight."""
+    torch.manual_seed(3)
+    ws = {"a": torch.randn(768, 192, 3, device="cuda"), "b": torch.randn(192, 768, 3, device="cuda"), "c": torch.randn(576, 192, 1, device="cuda"),
+          "d": torch.randn(40, 20, 5, device="cuda")}
+    items = [(k, w, tr) for k, w in ws.items() for tr in (False, True)]
+    ps = ops.PackSet(items, precision)
+    ps.run()
+    for k, w in ws.items():
+        fwd, tr = ps.get(k)
+        for got, t in ((fwd, False), (tr, True)):
+            ref = ops.pack_weight(w, transpose=t, precision=precision)
+            assert (got.npad, got.kchunks, got.taps, got.n) == (ref.npad, ref.kchunks, ref.taps, ref.n)
+            assert torch.equal(got.data, ref.data)
