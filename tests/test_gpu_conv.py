@@ -206,9 +206,10 @@ def test_epilogue_stores_stay_inside_rows(prec):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", [ops.F32, ops.BF16])
+@pytest.mark.parametrize("precision", [0, 1])            # ops.F32, ops.BF16
 def test_pack_set_equals_single_packs(precision):
     """glowtts_pack_weight_multi (one launch, heterogeneous shapes, forward + transposed) writes the same bytes as glowtts_pack_weight."""
+    from glow_tts_amd import ops
     torch.manual_seed(3)
     ws = {"a": torch.randn(768, 192, 3, device="cuda"), "b": torch.randn(192, 768, 3, device="cuda"), "c": torch.randn(576, 192, 1, device="cuda"),
           "d": torch.randn(40, 20, 5, device="cuda")}
