@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 #include "../../include/glowtts_hip.h"
 
 namespace {
@@ -30,6 +31,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BMO = 128;      // o per block
 constexpr int BNC = 64;       // c per block
 constexpr int BK = 64;        // rows per step
+#ifndef WGRAD_SETS_MAXTAPS
+#define WGRAD_SETS_MAXTAPS 1
+#endif
+#ifndef WGRAD_SETS
+#define WGRAD_SETS 2
+#endif
 #ifndef WGRAD_WAVES
 #define WGRAD_WAVES 8
 #endif
@@ -42,7 +49,13 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
     return *reinterpret_cast<uint32_t*>(&v);
 }
 
-struct WCommon { int rows, pad, accumulate, njobs; };
+template <int V> struct WIC { static constexpr int value = V; };
+template <int N> struct WStaticFor {
+    template <class F> __device__ __forceinline__ static void run(F&& f) { WStaticFor<N - 1>::run(f); f(WIC<N - 1>{}); }
+};
+template <> struct WStaticFor<0> { template <class F> __device__ __forceinline__ static void run(F&&) {} };
+
+struct WCommon { int rows, pad, accumulate, njobs, xcd; };
 
 // pointers that come out of the device job table are "generic" to the compiler, which would emit flat_load (counted on
 // BOTH vmcnt and lgkmcnt, i.e. every LDS wait would also drain the prefetch).  They are global: say so.
@@ -76,6 +89,12 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job singl
 {
     glowtts_wgrad_job p = single;
     int tile = blockIdx.x;
+    if (cm.xcd) {
+        // Workgroup b runs on XCD b % 8, each with its own L2.  Hand every XCD a CONTIGUOUS range of tiles: the mt x nt tiles of one job
+        // (which all stream the same DY / X rows) then share one L2 instead of pulling 8 copies of both operands over the fabric.
+        const int G = gridDim.x, q = G >> 3, r = G & 7, x = tile & 7, k = tile >> 3;
+        tile = x * q + min(x, r) + k;
+    }
     if (table) {                                  // binary search for the last job with tile0 <= tile (wave-uniform)
         int lo = 0, hi = cm.njobs - 1;
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[mid].tile0 <= tile) lo = mid; else hi = mid - 1; }
@@ -123,8 +142,11 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job singl
     constexpr int XW = (XBF ? 2 : 4) * XL;                    // 32-bit words per X item
     typedef uint32_t DYRegs[DY_IT][DYW];
     typedef uint32_t XRegs[X_IT][XW];
-    DYRegs rdyA, rdyB;
-    XRegs rxA, rxB;
+    // NS register sets = loads of NS - 1 steps in flight.  A step of the 1x1 problems is 4 MFMAs per wave, far shorter than the HBM
+    // latency: with two sets every step waited a full round trip (1.45 us per 64 rows, measured)
+    constexpr int NS = (TAPS <= WGRAD_SETS_MAXTAPS && (DY_IT * DYW + X_IT * XW) <= 24) ? WGRAD_SETS : 2;
+    DYRegs rdy[NS];
+    XRegs rx[NS];
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     const bool want_bias = (p.dbias != nullptr) && (tile_c == 0);
     const int lim_dy = (int)p.lddy - 4;
@@ -255,22 +277,20 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job singl
         }
     };
 
-    // two steps per iteration so that the register sets are selected at compile time; every load is unconditional
+    // NS steps per iteration so that the register sets are selected at compile time; every load is unconditional
     // (rows past the end are clamped, their contribution is masked to zero when stored)
-    gload(rdyA, rxA, rbeg);
-    gload(rdyB, rxB, rbeg + BK);
-    sstore(rdyA, rxA, 0, rbeg);
+    WStaticFor<NS>::run([&](auto j) __attribute__((always_inline)) { gload(rdy[j.value], rx[j.value], rbeg + (long)j.value * BK); });
+    sstore(rdy[0], rx[0], 0, rbeg);
     __syncthreads();
-    for (int s = 0; s < nsteps; s += 2) {
+    for (int s = 0; s < nsteps; s += NS) {
         const long rs = rbeg + (long)s * BK;
-        gload(rdyA, rxA, rs + 2 * BK);
-        compute(0);
-        sstore(rdyB, rxB, 1, rs + BK);
-        __syncthreads();
-        gload(rdyB, rxB, rs + 3 * BK);
-        if (s + 1 < nsteps) compute(1);
-        sstore(rdyA, rxA, 0, rs + 2 * BK);
-        __syncthreads();
+        WStaticFor<NS>::run([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = jc.value, jn = (j + 1) % NS;
+            gload(rdy[j], rx[j], rs + (long)(j + NS) * BK);              // set j was stored for step s + j: refill it for step s + j + NS
+            if (s + j < nsteps) compute(j & 1);
+            sstore(rdy[jn], rx[jn], (j + 1) & 1, rs + (long)(j + 1) * BK);
+            __syncthreads();
+        });
     }
 
     // ---- epilogue: dW[o][c][t] ----
@@ -351,6 +371,8 @@ int launch_w(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const
 
 }  // namespace
 
+static int xcd_mode() { static const int v = [] { const char* e = getenv("GLOWTTS_WGRAD_XCD"); return e ? atoi(e) : 1; }(); return v; }
+
 extern "C" int glowtts_wgrad_cl(const glowtts_wgrad_args* args, void* stream)
 {
     if (!args || !args->dy || !args->x || !args->dw || args->rows < 1 || args->m < 1 || args->ca < 1) return GLOWTTS_E_ARG;
@@ -368,7 +390,7 @@ extern "C" int glowtts_wgrad_cl(const glowtts_wgrad_args* args, void* stream)
         if (splits > maxs) splits = maxs;
         if (splits < 1) splits = 1;
     }
-    WCommon cm{a.rows, a.pad, a.accumulate, 1};
+    WCommon cm{a.rows, a.pad, a.accumulate, 1, xcd_mode()};
     dim3 grid(tiles, 1, splits);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.xmask) return GLOWTTS_E_ARG;          // reserved: X row masks must be applied by the producer
@@ -392,7 +414,7 @@ extern "C" int glowtts_wgrad_grouped_io(const glowtts_wgrad_job* dev_jobs, int n
     glowtts_wgrad_job dummy;
     memset(&dummy, 0, sizeof(dummy));
     dummy.mt = 1; dummy.nt = 1;
-    WCommon cm{rows, pad, accumulate, njobs};
+    WCommon cm{rows, pad, accumulate, njobs, xcd_mode()};
     dim3 grid(total_tiles, 1, splits);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (precision == GLOWTTS_BF16) return launch_w<__bf16>(dummy, dev_jobs, cm, taps, xpro, io_flags, grid, s);
