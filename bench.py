@@ -231,7 +231,7 @@ def main():
     # device inside the graph), followed - when data parallel - by the flat-bucket gradient all-reduce.
     from glow_tts_amd.distributed import global_frame_weight
     mode = "eager"
-    graph = None
+    graph = tail_graph = early = tail = None
     side = torch.cuda.Stream() if args.graph else None
     if args.graph:
         # every eager step that precedes the capture runs on the side stream too: a backward that ran on the default stream
@@ -266,22 +266,44 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
-                static_loss = fwd_bwd()
+            if world > 1 and os.environ.get("GLOWTTS_DP_OVERLAP", "1") != "0":
+                # Data parallel: the step is two graphs.  The first ends with the k-tap weight gradients (71 of the 114 MB); their
+                # all-reduce - with the encoder's and the ActNorm / 1x1 gradients - then runs under the second graph, which holds the
+                # 1x1 weight-gradient groups and the weight-norm backward of their classes; the 15 MB those produce are reduced last.
+                from glow_tts_amd import decoder as D
+                with D.defer_tail_wgrads():
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                        static_loss = fwd_bwd()
+                tail_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(tail_graph, pool=graph.pool(), capture_error_mode="thread_local"):
+                    D.flush_tail_wgrads()
+                tail_ids = {id(p) for p in model._dec_stacks.tail_leaves()}
+                early = FlatGradReducer([p for p in model.parameters() if id(p) not in tail_ids])
+                tail = FlatGradReducer([p for p in model.parameters() if id(p) in tail_ids])
+            else:
+                with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
+                    static_loss = fwd_bwd()
             graph.replay()
+            if tail_graph is not None:
+                tail_graph.replay()
             torch.cuda.synchronize()
             mode = "hipgraph"
         except Exception as exc:                               # noqa: BLE001 - fall back to eager launches, say so
             import traceback
             traceback.print_exc()
             print(f"[bench] graph capture failed ({type(exc).__name__}); running eagerly", file=sys.stderr)
-            graph = None
+            graph = tail_graph = None
             torch.cuda.synchronize()
 
     def one_step():
         if graph is not None:
             graph.replay()
-            if reducer is not None:
+            if tail_graph is not None:
+                pending = early.begin()
+                tail_graph.replay()
+                tail.reduce(average=False)
+                early.finish(pending)
+            elif reducer is not None:
                 reducer.reduce(average=False)
             return static_loss
         return train_step(model, mle_loss, batch, reducer, world)
@@ -298,6 +320,16 @@ def main():
         t = torch.tensor([elapsed], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if world > 1:
+        # every gradient must have gone through the exchange: reduced gradients are identical on all ranks, unreduced ones are not
+        # (different utterances and dropout streams per rank)
+        import torch.distributed as dist
+        cs = torch.stack([p.grad.double().sum() for p in model.parameters() if p.grad is not None])
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit(f"[bench] rank {rank}: {int((lo != hi).sum())} gradient tensors differ between ranks after the all-reduce")
     frames = int(batch[3].sum().item())
     if world > 1:
         import torch.distributed as dist

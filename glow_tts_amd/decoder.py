@@ -97,6 +97,30 @@ _PINNED = {}
 _WSTREAM = {}
 
 
+# Data parallel overlap (bench.py, N > 1): the big k-tap weight gradients are launched first and their all-reduce starts while the
+# "tail" - the 1x1 weight-gradient groups and the weight-norm backward of their classes - is still running.  With TAIL["defer"] set the
+# backward queues the tail's launches here instead of issuing them; `flush_tail_wgrads()` issues them (bench.py captures that as a
+# second hipGraph).  The gradient tensors of the tail classes exist (autograd has already handed them to .grad) but hold no data until then.
+TAIL = {"defer": False, "pending": []}
+TAIL_STACKS = ("start_g", "start_v", "start_b", "rs_g", "rs_v", "rs_b", "rsl_g", "rsl_v", "rsl_b", "end_w", "end_b")
+
+
+class defer_tail_wgrads:
+    def __enter__(self):
+        TAIL["defer"], TAIL["pending"] = True, []
+        return self
+
+    def __exit__(self, *exc):
+        TAIL["defer"] = False
+        return False
+
+
+def flush_tail_wgrads():
+    """Issues, on the current stream, the launches queued by the last backward under `defer_tail_wgrads()` (kept for re-capture)."""
+    for fn in TAIL["pending"]:
+        fn()
+
+
 def _wgrad_stream(device):
     key = str(device)
     if key not in _WSTREAM:
@@ -517,6 +541,12 @@ class DecoderFunction(torch.autograd.Function):
                 for grp in (gk, gp, g1):
                     grp.launch_segment(halves - 1)
             main.wait_stream(side)
+        elif TAIL["defer"]:
+            gk.launch_segment(0)
+            # the queued launches read the kept activations and this backward's gradient buffers through raw pointers: the closure
+            # keeps them alive (also across replays when the flush is captured as its own hipGraph)
+            keep = (buf, dins, dskip, dh0, dhn, douts, G)
+            TAIL["pending"].append(lambda keep=keep: (gp.launch_segment(0), g1.launch_segment(0)))
         else:
             for grp in (gk, gp, g1):
                 grp.launch_segment(0)
@@ -620,7 +650,8 @@ class WeightNorm(torch.autograd.Function):
     """w = g * v / ||v||  (old-style torch weight_norm, norm over (in, k) per output channel) on stacked tensors [..., O, I, k]."""
 
     @staticmethod
-    def forward(ctx, g, v):
+    def forward(ctx, g, v, tail=False):
+        ctx.tail = tail                                  # its backward may be queued behind the deferred 1x1 weight gradients (TAIL)
         v, g = v.contiguous(), g.contiguous()
         rows, cols = v.numel() // (v.shape[-1] * v.shape[-2]), v.shape[-1] * v.shape[-2]
         w, inv = torch.empty_like(v), torch.empty(rows, device=v.device)
@@ -636,9 +667,13 @@ class WeightNorm(torch.autograd.Function):
         rows, cols = ctx.dims
         dw = dw.contiguous()
         dv, dg = torch.empty_like(v), torch.empty_like(g)
-        _lib.check(_L().glowtts_weightnorm_bwd(dw.data_ptr(), v.data_ptr(), g.data_ptr(), inv.data_ptr(), dv.data_ptr(), dg.data_ptr(), rows, cols,
-                                               _lib.stream()), "glowtts_weightnorm_bwd")
-        return dg, dv
+        run = lambda: _lib.check(_L().glowtts_weightnorm_bwd(dw.data_ptr(), v.data_ptr(), g.data_ptr(), inv.data_ptr(), dv.data_ptr(), dg.data_ptr(),
+                                                             rows, cols, _lib.stream()), "glowtts_weightnorm_bwd")
+        if ctx.tail and TAIL["defer"]:
+            TAIL["pending"].append(run)                  # dw is filled by the deferred weight-gradient launches queued before this one
+        else:
+            run()
+        return dg, dv, None
 
 
 class DecoderStacks:
@@ -668,12 +703,16 @@ class DecoderStacks:
                 wn3(kind, [f"{fl(f)}.2.layer_Dict.WaveNet.layer_Dict.{kind}_{l}" for f in range(F_) for l in range(L)], (F_ * L,))
         self.S = S
 
+    def tail_leaves(self):
+        """Parameters whose gradients are produced by the deferrable tail of the backward (see TAIL)."""
+        return [p for k in TAIL_STACKS if k in self.S for p in self.S[k].leaves]
+
     def weights(self):
         """The stacked effective weights in WEIGHT_KEYS order (differentiable w.r.t. the leaves)."""
         S, cfg = self.S, self.cfg
         F_, L = cfg.F, cfg.L
         t = lambda k: S[k].tensor()
-        wn = lambda tag: WeightNorm.apply(t(tag + "_g"), t(tag + "_v"))
+        wn = lambda tag: WeightNorm.apply(t(tag + "_g"), t(tag + "_v"), (tag + "_v") in TAIL_STACKS)
         if L > 1:
             w_rs, b_rs = wn("rs"), t("rs_b")
         else:

@@ -69,20 +69,31 @@ class FlatGradReducer:
             buckets.append(cur)
         return direct, buckets
 
-    def reduce(self, average=False):
-        """SUM (or mean) all-reduce of every parameter gradient, in place."""
+    def begin(self):
+        """Issues the SUM all-reduces (asynchronously, on the process group's stream) and returns the state `finish` needs.  Work that does
+        not touch these gradients may be launched in between: it overlaps the exchange."""
         if not is_dist():
-            return
-        ws = dist.get_world_size()
+            return None
         direct, buckets = self._plan()
         works = [dist.all_reduce(f, op=dist.ReduceOp.SUM, async_op=True) for f in direct]
         flats = [torch.cat([g.reshape(-1) for g in b]) for b in buckets]
         works += [dist.all_reduce(f, op=dist.ReduceOp.SUM, async_op=True) for f in flats]
+        return direct, buckets, flats, works
+
+    def finish(self, state, average=False):
+        if state is None:
+            return
+        direct, buckets, flats, works = state
         for w in works:
             w.wait()
         if average:
+            ws = dist.get_world_size()
             for f in direct + flats:
                 f.div_(ws)
         for b, flat in zip(buckets, flats):
             torch._foreach_copy_(b, list(flat.split([g.numel() for g in b])) if all(g.dim() == 1 for g in b)
                                  else [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in b]), b)])
+
+    def reduce(self, average=False):
+        """SUM (or mean) all-reduce of every parameter gradient, in place."""
+        self.finish(self.begin(), average)

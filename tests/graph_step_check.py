@@ -62,4 +62,42 @@ assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"]
 for (k, pa), pb_ in zip(ma.named_parameters(), mb.parameters()):
     assert (pa - pb_).abs().max() <= 2e-5 * max(1.0, pa.abs().max().item()), k
     assert oa.state[pa]["step"] == ob.state[pb_]["step"] == len(seq), (k, oa.state[pa]["step"], ob.state[pb_]["step"])
+# ---- the data-parallel form of bench.py: the step as two graphs (body with the k-tap weight gradients | deferred 1x1 tail) ----
+from glow_tts_amd import decoder as D   # noqa: E402
+mc = build("Vanilla", "f32", sd)
+side = torch.cuda.Stream()
+
+
+def fwd_bwd(b):
+    l = loss_fn(mc, *b)
+    mc.zero_grad(set_to_none=True)
+    l.backward()
+    return l.detach()
+
+
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for _ in range(2):
+        fwd_bwd(b1)
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+g_body, g_tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+with D.defer_tail_wgrads():
+    with torch.cuda.graph(g_body):
+        lc = fwd_bwd(b1)
+with torch.cuda.graph(g_tail, pool=g_body.pool()):
+    D.flush_tail_wgrads()
+junk = [torch.randn(1 << 20, device="cuda") for _ in range(8)]      # allocator traffic between capture and replay must not matter
+for _ in range(2):
+    for p in mc.parameters():
+        if p.grad is not None:
+            p.grad.fill_(7.0)
+    g_body.replay()
+    g_tail.replay()
+    torch.cuda.synchronize()
+    wl, wg = want[0]
+    assert abs(lc.item() - wl) <= 1e-5 * max(1.0, abs(wl)), (lc.item(), wl)
+    for k, p in mc.named_parameters():
+        if k in wg:
+            assert (p.grad - wg[k]).abs().max() <= 1e-5 * max(1.0, wg[k].abs().max().item()), k
 print("GRAPH STEP OK")

@@ -143,6 +143,40 @@ def test_train_bf16_gradients_close_to_reference():
     print("worst cosine", worst_cos)
 
 
+def test_deferred_tail_weight_gradients_equal_plain_backward():
+    """decoder.defer_tail_wgrads(): the 1x1 weight-gradient groups and the weight-norm backward behind them are queued during
+    backward() and issued by flush_tail_wgrads() (bench.py overlaps the gradient all-reduce with them).  Same gradients, bit for bit;
+    the tail set is exactly the parameters that change between "before flush" and "after flush"."""
+    from glow_tts_amd import decoder as D
+    from glow_tts_amd.modules import MLE_Loss
+    sd, _, r = load_case("tiny_vanilla.npz")
+    model = build("Vanilla", "f32", sd)
+    t = lambda k: torch.from_numpy(r[k]).cuda()
+
+    def step():
+        z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, _, _ = model(t("tokens"), t("token_lengths"), t("mels"), t("mel_lengths"), None, None, None)
+        loss = MLE_Loss(model.hp)(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=t("mel_lengths")) + \
+            torch.nn.functional.mse_loss(log_dur, log_dur_t)
+        model.zero_grad(set_to_none=True)
+        loss.backward()
+
+    step()
+    want = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    with D.defer_tail_wgrads():
+        step()
+        assert len(D.TAIL["pending"]) >= 2
+    tail_ids = {id(p) for p in model._dec_stacks.tail_leaves()}
+    assert tail_ids
+    for k, p in model.named_parameters():                      # everything outside the tail is final before the flush
+        if id(p) not in tail_ids and k in want:
+            assert torch.equal(p.grad, want[k]), k
+    D.flush_tail_wgrads()
+    torch.cuda.synchronize()
+    for k, p in model.named_parameters():
+        if k in want:
+            assert torch.equal(p.grad, want[k]), k
+
+
 def test_graphed_train_step_matches_eager():
     """glow_tts_amd.graph_step.GraphedTrainStep: the replayed hipGraph gives the eager step's loss and gradients (f32), also for a
     second batch copied into the static buffers.  Runs in a child process: a failed stream capture takes the process down on
