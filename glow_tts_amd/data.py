@@ -5,12 +5,170 @@ what keeping an MI355X fed needs:
   * shape buckets: the padded lengths are rounded up to the next bucket, so a training run sees a handful of static shapes and every step
     can be a replayed hipGraph (glow_tts_amd.graph_step.GraphedTrainStep) instead of ~600 eager launches;
   * pinned, reused staging buffers: the host-to-device copy of a batch (8.2 MB of mels at B = 32) is one asynchronous DMA per tensor.
-Pure host code (numpy / torch CPU tensors); the GE2E slice sampling (`Datasets.py:41-65`) is not part of this path: pass precomputed
-d-vectors or leave `mels_for_GE2E` None."""
+Pure host code (numpy / torch CPU tensors).
+
+On-disk formats of the reference, read here so that pattern directories written by its `Pattern_Generator.py` drop in unchanged:
+  * `Token.yaml` (`Pattern_Generator.py:401-411`): {'<S>': 0, '<E>': 1, letter: id, ...}  -> `load_token_dict`, `text_to_token`;
+  * pattern pickles (`Pattern_Generator.py:87-96`): {'Audio','Mel' [T, Mel],'Pitch' [T],'Speaker_ID','Speaker','Dataset','Text'};
+  * `METADATA.PICKLE` (`Pattern_Generator.py:344-396`): 'File_List', '*_Length_Dict', 'File_List_by_Speaker_Dict', ... -> `PatternDataset`,
+    `write_metadata` (the same keys, for pattern directories produced elsewhere);
+  * the inference prompt TSV (`Datasets.py:137-144`) -> `read_inference_prompts`.
+The audio front-end (wav -> mel / pitch, `Audio.py`, `yin.py`) stays out of scope: it needs librosa, which this image does not have."""
 import bisect
+import math
+import os
+import pickle
+import re
 
 import numpy as np
 import torch
+
+PATTERN_KEYS = ("Audio", "Mel", "Pitch", "Speaker_ID", "Speaker", "Dataset", "Text")
+_TEXT_OK = re.compile(r"[A-Z,.?!'\-\s]+")                      # Pattern_Generator.py:19
+
+
+def load_token_dict(path):
+    """Token.yaml -> {symbol: id}."""
+    import yaml
+    with open(path, encoding="utf-8") as f:
+        return yaml.load(f, Loader=yaml.Loader)
+
+
+def make_token_dict(texts):
+    """The dictionary `Token_Dict_Generate` writes (`Pattern_Generator.py:401-411`): '<S>', '<E>', then the sorted symbol set."""
+    symbols = set()
+    for t in texts:
+        symbols |= set(t)
+    return {tok: i for i, tok in enumerate(["<S>", "<E>"] + sorted(symbols))}
+
+
+def text_filtering(text):
+    """`Text_Filtering` (`Pattern_Generator.py:22-39`): upper-case, drop ()"[]:; , tidy spaces; None when the text holds anything
+    outside [A-Z,.?!'- and whitespace] or starts with an apostrophe."""
+    text = text.upper().strip()
+    for ch in ("(", ")", '"', "[", "]", ":", ";"):
+        text = text.replace(ch, "")
+    for a, b in (("  ", " "), (" ,", ","), ("' ", "'")):
+        text = text.replace(a, b)
+    text = text.strip()
+    found = _TEXT_OK.findall(text)
+    if len(found) != 1 or text.startswith("'"):
+        return None
+    return found[0]
+
+
+def text_to_token(text, token_dict):
+    """`Text_to_Token` (`Datasets.py:17-21`): <S> + letters + <E> as int32 ids (KeyError on a symbol the dictionary lacks)."""
+    return np.array([token_dict[c] for c in ["<S>"] + list(text) + ["<E>"]], dtype=np.int32)
+
+
+class PatternDataset(torch.utils.data.Dataset):
+    """`Datasets.Dataset` (`Datasets.py:78-131`): items are (token ids, mel [T, Mel], speaker id, pitch [T]) read from the pattern pickles
+    listed in the metadata pickle, filtered by mel / text length, optionally repeated `accumulated_dataset_epoch` times and cached."""
+
+    def __init__(self, pattern_path, metadata_file, token_dict, accumulated_dataset_epoch=1, mel_length_min=-math.inf, mel_length_max=math.inf,
+                 text_length_min=-math.inf, text_length_max=math.inf, use_cache=False):
+        self.pattern_path, self.token_dict, self.use_cache = pattern_path, token_dict, use_cache
+        with open(os.path.join(pattern_path, metadata_file).replace("\\", "/"), "rb") as f:
+            meta = pickle.load(f)
+        mel_len, text_len = meta["Mel_Length_Dict"], meta["Text_Length_Dict"]
+        self.files = [x for x in meta["File_List"]
+                      if mel_length_min <= mel_len[x] <= mel_length_max and text_length_min <= text_len[x] <= text_length_max]
+        self.base_length = len(self.files)
+        self.files = self.files * int(accumulated_dataset_epoch)
+        self.mel_lengths = [mel_len[x] for x in self.files]        # for length-bucketed samplers (not in the reference)
+        self._cache = {}
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, idx):
+        key = idx % self.base_length
+        if key in self._cache:
+            return self._cache[key]
+        with open(os.path.join(self.pattern_path, self.files[idx]).replace("\\", "/"), "rb") as f:
+            pat = pickle.load(f)
+        item = text_to_token(pat["Text"], self.token_dict), pat["Mel"], pat["Speaker_ID"], pat["Pitch"]
+        if self.use_cache:
+            self._cache[key] = item
+        return item
+
+
+def write_metadata(pattern_path, metadata_file, hp=None, use_text=True):
+    """Scans a pattern directory and writes the metadata pickle with the reference's keys (`Metadata_Generate`,
+    `Pattern_Generator.py:335-396`); files whose keys are not pattern keys are skipped.  Returns the dict."""
+    meta = {"File_List": [], "Audio_Length_Dict": {}, "Mel_Length_Dict": {}, "Pitch_Length_Dict": {}, "Speaker_ID_Dict": {},
+            "Speaker_Dict": {}, "Dataset_Dict": {}, "File_List_by_Speaker_Dict": {}}
+    if hp is not None:
+        s = hp.Sound
+        meta.update({"Spectrogram_Dim": s.Spectrogram_Dim, "Mel_Dim": s.Mel_Dim, "Frame_Shift": s.Frame_Shift, "Frame_Length": s.Frame_Length,
+                     "Sample_Rate": s.Sample_Rate, "Max_Abs_Mel": s.Max_Abs_Mel})
+    if use_text:
+        meta["Text_Length_Dict"] = {}
+    target = os.path.join(pattern_path, metadata_file.upper())
+    for root, _, files in sorted(os.walk(pattern_path)):
+        for name in sorted(files):
+            full = os.path.join(root, name)
+            if os.path.abspath(full) == os.path.abspath(target):
+                continue
+            try:
+                with open(full, "rb") as f:
+                    pat = pickle.load(f)
+                if not isinstance(pat, dict) or any(k not in PATTERN_KEYS for k in pat) or (use_text and "Text" not in pat):
+                    continue
+                rel = os.path.relpath(full, pattern_path).replace("\\", "/")
+                meta["Audio_Length_Dict"][rel] = pat["Audio"].shape[0]
+                meta["Mel_Length_Dict"][rel] = pat["Mel"].shape[0]
+                meta["Pitch_Length_Dict"][rel] = pat["Pitch"].shape[0]
+                meta["Speaker_ID_Dict"][rel] = pat["Speaker_ID"]
+                meta["Speaker_Dict"][rel] = pat["Speaker"]
+                meta["Dataset_Dict"][rel] = pat["Dataset"]
+                meta["File_List"].append(rel)
+                meta["File_List_by_Speaker_Dict"].setdefault(pat["Speaker"], []).append(rel)
+                if use_text:
+                    meta["Text_Length_Dict"][rel] = len(pat["Text"])
+            except Exception:                                  # noqa: BLE001 - the reference ignores unreadable files too (:390-391)
+                continue
+    with open(target, "wb") as f:
+        pickle.dump(meta, f, protocol=4)
+    return meta
+
+
+def mels_for_ge2e(mels, samples, slice_length, overlap_length, rng=np.random):
+    """`Mel_for_GE2E_Stack` (`Datasets.py:41-65`): per utterance a window of samples * (slice - overlap) + overlap frames (random offset, or
+    reflect-padded when the mel is shorter) cut into `samples` overlapping slices -> [B * samples, slice_length, Mel]."""
+    hop = slice_length - overlap_length
+    need = samples * hop + overlap_length
+    out = []
+    for mel in mels:
+        mel = np.asarray(mel)
+        if mel.shape[0] > need:
+            off = rng.randint(0, mel.shape[0] - need)
+            mel = mel[off:off + need]
+        else:
+            pad = (need - mel.shape[0]) / 2
+            mel = np.pad(mel, [[int(np.floor(pad)), int(np.ceil(pad))], [0, 0]], mode="reflect")
+        out.append(np.stack([mel[i:i + slice_length] for i in range(0, need - overlap_length, hop)]))
+    return np.vstack(out)
+
+
+def read_inference_prompts(path, token_dict=None):
+    """The inference TSV (`Datasets.py:137-144`): a header line, then
+    label, text, length scale, speaker id, wav for GE2E, wav for prosody, wav for pitch.  Text goes through `text_filtering`; with a token
+    dictionary every record also carries its token ids."""
+    out = []
+    with open(path, "r", encoding="utf-8") as f:
+        for line in f.readlines()[1:]:
+            if not line.strip():
+                continue
+            label, text, scale, speaker, w_ge2e, w_pro, w_pitch = [x.strip() for x in line.strip().split("\t")]
+            text = text_filtering(text)
+            rec = {"label": label, "text": text, "length_scale": float(scale), "speaker": int(speaker),
+                   "wav_for_ge2e": w_ge2e, "wav_for_prosody": w_pro, "wav_for_pitch": w_pitch}
+            if token_dict is not None and text is not None:
+                rec["token"] = text_to_token(text, token_dict)
+            out.append(rec)
+    return out
 
 
 def _bucket(n, buckets, multiple):
@@ -24,7 +182,7 @@ def _bucket(n, buckets, multiple):
 
 class Collater:
     def __init__(self, num_squeeze=2, end_token_id=0, max_abs_mel=4.0, token_buckets=None, mel_buckets=None, token_multiple=1,
-                 mel_multiple=None, pin_memory=False, ring=4):
+                 mel_multiple=None, pin_memory=False, ring=4, ge2e=None):
         """token_buckets / mel_buckets: ascending lists of padded lengths (None: pad to the batch maximum rounded up to
         token_multiple / mel_multiple, the reference's behaviour for multiples of 1 / num_squeeze).  ring: number of pinned buffer sets that
         are cycled, i.e. how many batches may be in flight between the loader and the GPU copy."""
@@ -35,6 +193,7 @@ class Collater:
         if self.mb and any(b % self.ns for b in self.mb):
             raise ValueError("mel buckets must be multiples of Decoder.Num_Squeeze")
         self.pin, self.ring, self._bufs, self._turn = bool(pin_memory), int(ring), {}, 0
+        self.ge2e = ge2e            # (samples, slice_length, overlap_length) of hp.Speaker_Embedding.GE2E.Inference, or None: no GE2E slices
 
     @classmethod
     def from_hp(cls, hp, token_dict, **kw):
@@ -55,6 +214,9 @@ class Collater:
         """batch: list of (token [Tt] int, mel [Tm, Mel] float, speaker int, pitch [Tm] float or None) like `Dataset.__getitem__`."""
         tokens, mels, speakers, pitches = zip(*batch)
         B = len(tokens)
+        ge2e = None
+        if self.ge2e is not None:                                                                  # on the UNtruncated mels, Datasets.py:229
+            ge2e = torch.from_numpy(np.ascontiguousarray(mels_for_ge2e(mels, *self.ge2e).astype(np.float32))).transpose(2, 1)
         mels = [np.asarray(m)[:(len(m) // self.ns) * self.ns] for m in mels]                      # Datasets.py:230-233
         tl = [len(t) for t in tokens]
         ml = [len(m) for m in mels]
@@ -72,7 +234,7 @@ class Collater:
                 out_pit[b, :n] = torch.as_tensor(np.asarray(pitches[b][:n]), dtype=torch.float32)
         self._turn += 1
         return (out_tok, torch.tensor(tl, dtype=torch.int64), out_mel, torch.tensor(ml, dtype=torch.int64),
-                torch.tensor(speakers, dtype=torch.int64), None, out_pit)
+                torch.tensor(speakers, dtype=torch.int64), ge2e, out_pit)
 
 
 def to_device(batch, device, non_blocking=True):
