@@ -1261,7 +1261,21 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
         const long cost = ((tiles + ncu - 1) / ncu) * (w + 4);      // rounds x (strip work + fixed prologue / epilogue share)
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = w; }
     }
+    // 1x1 convs (K <= 384: a short K loop between a load phase and a long epilogue): measured on the training step at B = 32
+    // (tools/ab.sh, two boxes), 4-wave workgroups that co-reside three to a CU (48 KiB LDS each) beat the single fat one - their
+    // pipelines drift apart, so one's epilogue (VALU / memory) runs under another's loads and MFMAs: 6.31 -> 6.25 and 6.42 -> 6.36
+    // ms/step.  Only while every workgroup is resident at once; otherwise the round-count model above decides.  The same idea for the
+    // k-tap convs (7 waves, two per CU) was box-dependent: -0.07 ms on one, +0.05 on the other; not adopted.
+    static const int coop = [] { const char* e = getenv("GLOWTTS_DMA_COOP"); return e ? atoi(e) : 1; }();
+    if (coop && !nload && TAPS == 1) {
+        const long tiles = (long)((frags + 3) / 4) * gy;
+        if (tiles > ncu && tiles <= 3L * ncu) best = 4;
+    }
+    static const int force_t1 = [] { const char* e = getenv("GLOWTTS_DMA_WAVES_T1"); return e ? atoi(e) : 0; }();
     if (force >= 4 && force <= WMAX) best = force;
+    static const int force_t5 = [] { const char* e = getenv("GLOWTTS_DMA_WAVES_T5"); return e ? atoi(e) : 0; }();
+    if (TAPS == 1 && force_t1 >= 4 && force_t1 <= WMAX) best = force_t1;
+    if (TAPS > 1 && force_t5 >= 4 && force_t5 <= WMAX) best = force_t5;
     const int BM = best * 32;
     const int nat = TAPS == 1 ? DMA1_CPS : 1, sub = TAPS == 1 ? DMA1_CPS : TAPS;
     // LDS stages: 2 by default.  Alone, the kernel is as fast with 2 as with 3 (17.7 us either way); in the training step the smaller
