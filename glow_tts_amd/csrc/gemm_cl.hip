@@ -1067,10 +1067,13 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
 // first conv's tail, writes what later kernels need to global memory (bf16) and the same values as six swizzled K-chunk tiles into LDS;
 // GEMM 2 multiplies those tiles with the second weight (streamed through the same stage buffers) and ends in the second epilogue.
 // ------------------------------------------------------------------------------------------------
-constexpr int CH_WN = 3, CH_BN = CH_WN * 64, CH_BM = 64, CH_KC2 = CH_BN / 32;      // 192 intermediate channels = 6 K chunks of GEMM 2
+#ifndef GLOWTTS_CH_BM
+#define GLOWTTS_CH_BM 64
+#endif
+constexpr int CH_WN = 3, CH_BN = CH_WN * 64, CH_BM = GLOWTTS_CH_BM, CH_WM = CH_BM / 32, CH_KC2 = CH_BN / 32;      // 192 intermediate channels = 6 K chunks of GEMM 2
 
 template <int EPI1, int EPI2>
-__global__ __launch_bounds__(CH_WN * 2 * 64) void conv_chain_kernel(const glowtts_conv_args pin1, const glowtts_conv_args pin2)
+__global__ __launch_bounds__(CH_WN * CH_WM * 64) void conv_chain_kernel(const glowtts_conv_args pin1, const glowtts_conv_args pin2)
 {
     typedef __bf16 CT;
     constexpr int NI = 2, KC = 32, CPS = DMA1_CPS;
@@ -1096,7 +1099,7 @@ __global__ __launch_bounds__(CH_WN * 2 * 64) void conv_chain_kernel(const glowtt
     // DMA of stage `st` of GEMM `which` (1: A chunks + weight slabs, 2: weight slabs only) into stage buffer `buf`
     auto issue = [&](int which, const glowtts_conv_args& q, int buf, int st) __attribute__((always_inline)) {
         const int nau = which == 1 ? CPS * AU : 0, nun = nau + CPS * WUT;
-        for (int u = wave; u < nun; u += CH_WN * 2) {
+        for (int u = wave; u < nun; u += CH_WN * CH_WM) {
             const unsigned char* src;
             int dstu;
             if (u < nau) {
@@ -1211,7 +1214,7 @@ int launch_chain(const glowtts_conv_args& a1, const glowtts_conv_args& a2, hipSt
             return GLOWTTS_E_LAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_chain_kernel<EPI1, EPI2>), dim3((a1.rows + CH_BM - 1) / CH_BM), dim3(CH_WN * 2 * 64), lds, s, a1, a2);
+    hipLaunchKernelGGL((conv_chain_kernel<EPI1, EPI2>), dim3((a1.rows + CH_BM - 1) / CH_BM), dim3(CH_WN * CH_WM * 64), lds, s, a1, a2);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
