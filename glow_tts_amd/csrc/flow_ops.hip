@@ -361,12 +361,25 @@ __global__ __launch_bounds__(1024) void logdet_partial_kernel(const float* __res
     const float* outs = outs_all + (long)f * flow_stride + (long)b * Tp * ldo;
     const float* rm = rowmask + (long)b * Tp;
     float s = 0.f, len = 0.f, ls = 0.f;
-    for (int t = wave; t < Tp; t += 16) {
-        const float m = rm[t];
-        len += m;                                                       // (every lane holds the same count)
-        if (m != 0.f)
-            for (int j = lane; j < C2; j += 64) s += outs[(long)t * ldo + (j >> 5) * 64 + 32 + (j & 31)];
+    // four rows per pass, all loads issued before the first use (the row mask multiplies: no branch between them)
+    for (int t0 = wave; t0 < Tp; t0 += 64) {
+        float m[4], v[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + 16 * u;
+            const bool in = t < Tp;
+            m[u] = in ? rm[t] : 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = lane + 64 * h;
+                v[u][h] = (in && j < C2) ? outs[(long)t * ldo + (j >> 5) * 64 + 32 + (j & 31)] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { len += m[u]; s += (v[u][0] + v[u][1]) * m[u]; }
     }
+    for (int j = lane + 128; j < C2; j += 64)                       // C/2 > 128 (not the reference's shapes): remaining pair slots
+        for (int t = wave; t < Tp; t += 16) s += outs[(long)t * ldo + (j >> 5) * 64 + 32 + (j & 31)] * rm[t];
     for (int c = threadIdx.x; c < C; c += 1024) ls += logs_all[f * C + c];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ls += __shfl_xor(ls, o); }
