@@ -343,6 +343,128 @@ __global__ __launch_bounds__(256) void actnorm_inv_bwd_kernel(const float* __res
     }
 }
 
+// The same pass for C % 8 == 0 with 16-byte accesses: a thread owns the two mixing groups {4q..4q+3} u {C/2+4q..C/2+4q+3} of a row, so
+// every load / store is a float4 (the 8-byte version above spent 19 us on 48 MB at the bench size).  Same per-block partial layout.
+__global__ __launch_bounds__(256) void actnorm_inv_bwd4_kernel(const float* __restrict__ dz, float* __restrict__ dx,
+                                                               const float* __restrict__ x, const float* __restrict__ logs,
+                                                               const float* __restrict__ bias, const float* __restrict__ winfo,
+                                                               const float* __restrict__ rowmask, float* __restrict__ partial,
+                                                               long rows, int C, int rows_per_block, const NextCoupling nc)
+{
+    const int Q = C / 8, C2 = C / 2;
+    extern __shared__ float red[];                 // [32][256]
+    float w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = winfo[i];
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    const int tpq = 256 / Q;                       // row lanes per pass
+    const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+    float accW[16], accL[8], accB[8];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accW[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { accL[i] = 0.f; accB[i] = 0.f; }
+    // slot s of the thread: 0..3 = channels 4q..4q+3, 4..7 = C/2+4q..; group e (0, 1) = slots {2e, 2e+1, 4+2e, 5+2e}
+    float el[8], bs[8];
+    {
+        const float4 la = *reinterpret_cast<const float4*>(logs + 4 * q), lb = *reinterpret_cast<const float4*>(logs + C2 + 4 * q);
+        const float4 ba = *reinterpret_cast<const float4*>(bias + 4 * q), bb = *reinterpret_cast<const float4*>(bias + C2 + 4 * q);
+        const float lv[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w}, bv[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { el[k] = expf(lv[k]); bs[k] = bv[k]; }
+    }
+    if (rl < tpq) {
+        for (long r = r0 + rl; r < r1; r += tpq) {
+            const float m = rowmask[r];
+            const float4 dlo = *reinterpret_cast<const float4*>(dz + r * C + 4 * q), dhi = *reinterpret_cast<const float4*>(dz + r * C + C2 + 4 * q);
+            const float4 xlo = *reinterpret_cast<const float4*>(x + r * C + 4 * q), xhi = *reinterpret_cast<const float4*>(x + r * C + C2 + 4 * q);
+            float4 lg = make_float4(0.f, 0.f, 0.f, 0.f), xb = lg;
+            float dl = 0.f;
+            const int j0 = 4 * q, pc = (j0 >> 5) * 64 + (j0 & 31);
+            if (nc.outs) {
+                lg = *reinterpret_cast<const float4*>(nc.outs + r * nc.ldo + pc + 32);
+                xb = *reinterpret_cast<const float4*>(nc.xmid + r * C + C2 + 4 * q);
+                dl = nc.dld[r / nc.rows_per_utt];
+            }
+            const float dv[8] = {dlo.x * m, dlo.y * m, dlo.z * m, dlo.w * m, dhi.x * m, dhi.y * m, dhi.z * m, dhi.w * m};
+            const float xv[8] = {xlo.x, xlo.y, xlo.z, xlo.w, xhi.x, xhi.y, xhi.z, xhi.w};
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int sl[4] = {2 * e, 2 * e + 1, 4 + 2 * e, 5 + 2 * e};
+                float y[4], dy[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = (bs[sl[k]] + el[sl[k]] * xv[sl[k]]) * m;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    dy[k] = (w[0 * 4 + k] * dv[sl[0]] + w[1 * 4 + k] * dv[sl[1]] + w[2 * 4 + k] * dv[sl[2]] + w[3 * 4 + k] * dv[sl[3]]) * m;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) accW[a * 4 + k] += dv[sl[a]] * y[k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { o[sl[k]] = dy[k] * el[sl[k]]; accL[sl[k]] += o[sl[k]] * xv[sl[k]]; accB[sl[k]] += dy[k]; }
+            }
+            *reinterpret_cast<float4*>(dx + r * C + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+            if (nc.outs) {
+                const float lgv[4] = {lg.x, lg.y, lg.z, lg.w}, xbv[4] = {xb.x, xb.y, xb.z, xb.w};
+                float dm[4], dg[4], ob[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d = o[4 + k], e = expf(lgv[k]);
+                    dm[k] = d * m; dg[k] = (d * e * xbv[k] + dl) * m; ob[k] = d * e * m;
+                }
+                float* dob = nc.douts + r * nc.ldo;
+                *reinterpret_cast<float4*>(dob + pc) = make_float4(dm[0], dm[1], dm[2], dm[3]);
+                *reinterpret_cast<float4*>(dob + pc + 32) = make_float4(dg[0], dg[1], dg[2], dg[3]);
+                typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+                if (nc.douts16) {
+                    bf4 a, b;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { a[k] = (__bf16)dm[k]; b[k] = (__bf16)dg[k]; }
+                    *reinterpret_cast<bf4*>(nc.douts16 + r * nc.ldo + pc) = a;
+                    *reinterpret_cast<bf4*>(nc.douts16 + r * nc.ldo + pc + 32) = b;
+                }
+                for (int jp = C2 + j0; jp < nc.ldo / 2; jp += C2) {      // pad slots of the PAIR packing: zero (see coupling_bwd_kernel)
+                    const int pp = (jp >> 5) * 64 + (jp & 31);
+                    *reinterpret_cast<float4*>(dob + pp) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(dob + pp + 32) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (nc.douts16) {
+                        *reinterpret_cast<uint2*>(nc.douts16 + r * nc.ldo + pp) = make_uint2(0u, 0u);
+                        *reinterpret_cast<uint2*>(nc.douts16 + r * nc.ldo + pp + 32) = make_uint2(0u, 0u);
+                    }
+                }
+                *reinterpret_cast<float4*>(dx + r * C + C2 + 4 * q) = make_float4(ob[0], ob[1], ob[2], ob[3]);
+            } else {
+                *reinterpret_cast<float4*>(dx + r * C + C2 + 4 * q) = make_float4(o[4], o[5], o[6], o[7]);
+            }
+        }
+    }
+    float* out = partial + (long)blockIdx.x * (2 * C + 16);
+    for (int i = 0; i < 32; ++i) {
+        const float v = (i < 16) ? accW[i] : (i < 24 ? accL[i - 16] : accB[i - 24]);
+        red[i * 256 + threadIdx.x] = (rl < tpq) ? v : 0.f;
+    }
+    __syncthreads();
+    {   // dW: 16 lanes per entry, 16 values each, then a 16-wide butterfly
+        const int e = threadIdx.x >> 4, part = threadIdx.x & 15;
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s += red[e * 256 + t * 16 + part];
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 16);
+        if (part == 0) out[2 * C + e] = s;
+    }
+    for (int i = threadIdx.x; i < 2 * 8 * Q; i += 256) {            // (which in {L, B}) x slot x q: sum over the row lanes
+        const int which = i / (8 * Q), sl = (i / Q) % 8, qq = i % Q;
+        float s = 0.f;
+        for (int t = qq; t < tpq * Q; t += Q) s += red[(16 + which * 8 + sl) * 256 + t];
+        const int c = (sl < 4) ? (4 * qq + sl) : (C2 + 4 * qq + (sl - 4));
+        out[which * C + c] = s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // log-determinant of the whole decoder (Modules.py:309 sum of the 3*F per-layer vectors):
 //   logdet[b] = sum_f [ (sum_c logs_f[c] + logdet(W_f) * C/4) * len'_b + sum_{valid rows of b} sum_j logs^{coupling}_f ]
@@ -467,6 +589,12 @@ extern "C" int glowtts_actnorm_stats(const float* x, const float* rowmask, float
     RET_LAUNCH();
 }
 
+// the float4 form needs C % 8 == 0, C / 8 <= 256 and 16-byte aligned rows (GLOWTTS_AN_WIDE=0 forces the 8-byte form)
+static bool an_bwd_wide(int C, const float* dz, const float* dx, const float* x, int ldo)
+{
+    static const int on = [] { const char* e = getenv("GLOWTTS_AN_WIDE"); return e ? atoi(e) : 1; }();
+    return on && (C % 8) == 0 && !((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(x)) & 15) && (ldo % 4) == 0;
+}
 // rows per block of actnorm_inv_bwd_kernel: small blocks (R / 16 = 800+ at the bench size) keep every CU busy; the per-block partials are
 // reduced later by colstats_final_kernel / glowtts_colsum_batched
 static int an_bwd_rpb() { static const int v = [] { const char* e = getenv("GLOWTTS_AN_RPB"); const int x = e ? atoi(e) : 16; return x < 16 ? 16 : x; }(); return v; }
@@ -516,8 +644,13 @@ extern "C" int glowtts_actnorm_inv1x1_bwd(const float* dz, float* dx, const floa
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int rpb = an_bwd_rpb();
     const int nblk = (int)((rows + rpb - 1) / rpb);
-    hipLaunchKernelGGL(actnorm_inv_bwd_kernel, dim3(nblk), dim3(256), 24 * 256 * sizeof(float), s, dz, dx, x, logs, bias, winfo, rowmask,
-                       scratch, (long)rows, C, rpb, NextCoupling{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1});
+    const NextCoupling none{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1};
+    if (an_bwd_wide(C, dz, dx, x, 0))
+        hipLaunchKernelGGL(actnorm_inv_bwd4_kernel, dim3(nblk), dim3(256), 32 * 256 * sizeof(float), s, dz, dx, x, logs, bias, winfo, rowmask,
+                           scratch, (long)rows, C, rpb, none);
+    else
+        hipLaunchKernelGGL(actnorm_inv_bwd_kernel, dim3(nblk), dim3(256), 24 * 256 * sizeof(float), s, dz, dx, x, logs, bias, winfo, rowmask,
+                           scratch, (long)rows, C, rpb, none);
     const int n = 2 * C + 16;
     // param_grads == NULL: the caller reduces the per-block partials of all its flows later with glowtts_colsum_batched
     if (param_grads) hipLaunchKernelGGL(colstats_final_kernel, dim3((n + 3) / 4), dim3(256), 0, s, scratch, param_grads, nblk, n, 0L, 0L);
@@ -533,9 +666,15 @@ extern "C" int glowtts_actnorm_inv1x1_bwd_coupling(const float* dz, float* dx, c
     if (!prev_xmid || !prev_outs || !prev_douts || !dlogdet || (ldo & 63) || ldo < C || rows_per_utt < 1) return GLOWTTS_E_ARG;
     const int rpb = an_bwd_rpb();
     const int nblk = (int)((rows + rpb - 1) / rpb);
-    hipLaunchKernelGGL(actnorm_inv_bwd_kernel, dim3(nblk), dim3(256), 24 * 256 * sizeof(float), static_cast<hipStream_t>(stream), dz, dx, x, logs, bias, winfo,
-                       rowmask, scratch, (long)rows, C, rpb,
-                       NextCoupling{prev_xmid, prev_outs, prev_douts, static_cast<__bf16*>(prev_douts_bf16), dlogdet, ldo, rows_per_utt});
+    const NextCoupling nc{prev_xmid, prev_outs, prev_douts, static_cast<__bf16*>(prev_douts_bf16), dlogdet, ldo, rows_per_utt};
+    const bool al = !((reinterpret_cast<uintptr_t>(prev_xmid) | reinterpret_cast<uintptr_t>(prev_outs) | reinterpret_cast<uintptr_t>(prev_douts)) & 15) &&
+                    !(reinterpret_cast<uintptr_t>(prev_douts_bf16) & 7);
+    if (al && an_bwd_wide(C, dz, dx, x, ldo))
+        hipLaunchKernelGGL(actnorm_inv_bwd4_kernel, dim3(nblk), dim3(256), 32 * 256 * sizeof(float), static_cast<hipStream_t>(stream), dz, dx, x, logs, bias,
+                           winfo, rowmask, scratch, (long)rows, C, rpb, nc);
+    else
+        hipLaunchKernelGGL(actnorm_inv_bwd_kernel, dim3(nblk), dim3(256), 24 * 256 * sizeof(float), static_cast<hipStream_t>(stream), dz, dx, x, logs, bias,
+                           winfo, rowmask, scratch, (long)rows, C, rpb, nc);
     RET_LAUNCH();
 }
 
