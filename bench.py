@@ -218,7 +218,7 @@ def main():
         model.actnorm_allreduce = actnorm_stats_allreduce
         reducer = FlatGradReducer(list(model.parameters()))
     torch.manual_seed(4321 + rank)                              # dropout streams differ per rank; the replicas' weights do not
-    B, Tt, Tm = args.batch, 120, 800
+    B, Tt, Tm = args.batch, int(os.environ.get("GLOWTTS_BENCH_TT", "120")), 800          # (the env override is for experiments only)
     batch = synthetic_batch(B, Tt, Tm, 80, 1234 + rank, dev, ragged=args.ragged)
 
     def barrier():
