@@ -246,7 +246,7 @@ class _Prepared:
                 self.pk["rs_t"] = PackedBatch(W["w_rs"].reshape(F_ * (Lw - 1), 2 * H, H, 1), True, ops.PERM_NONE, 0, P)
         self.ldo = self.pk["end"].npad
         self.ldin = self.pk["in"].npad
-        self.cond = cond
+        self.cond, self._H, self._Lw = cond, H, Lw
         self.params = []
         for f in range(F_):
             p = FlowParams()
@@ -272,10 +272,16 @@ class _Prepared:
                 for l in range(Lw):
                     p.in_t[l] = self.pk["in_t"].at(f * Lw + l)
                     p.rs_t[l] = self.pk["rs_t"].at(f * (Lw - 1) + l) if l < Lw - 1 else self.pk["rs_last_t"].at(f)
-            if cond is not None:            # cond [B, F, L, 2H]
-                p.cond = cond.data_ptr() + 4 * f * Lw * 2 * H
-                p.ldcond = F_ * Lw * 2 * H
             self.params.append(p)
+        self.set_cond(cond)
+
+    def set_cond(self, cond):
+        """Attach the per-call conditioning [B, F, L, 2H] (None: unconditioned) to the per-flow parameter structs."""
+        F_, H, Lw = len(self.params), self._H, self._Lw
+        self.cond = cond
+        for f, p in enumerate(self.params):
+            p.cond = (cond.data_ptr() + 4 * f * Lw * 2 * H) if cond is not None else None
+            p.ldcond = F_ * Lw * 2 * H if cond is not None else 0
 
 
 def _dims(cfg, B, T, drop_p=0.0, seed=None, flow=0):
@@ -354,10 +360,14 @@ def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None):
     return z, logdet, buf, rowmask, T
 
 
-def decoder_inverse(cfg, W, z, lengths, cond=None, fill=None):
-    """Decoder.forward(reverse=True) (Modules.py:298-309): z [B,Cm,Tm] -> mels [B,Cm,ns*(Tm//ns)]."""
+def decoder_inverse(cfg, W, z, lengths, cond=None, fill=None, prep=None):
+    """Decoder.forward(reverse=True) (Modules.py:298-309): z [B,Cm,Tm] -> mels [B,Cm,ns*(Tm//ns)].
+    prep: a _Prepared built earlier from the same weights (then W is not read; `cond`, which varies per call, is attached here)."""
     L = _L()
-    prep = _Prepared(cfg, W, need_bwd=False, cond=cond)
+    if prep is None:
+        prep = _Prepared(cfg, W, need_bwd=False, cond=cond)
+    elif cond is not None or prep.cond is not None:
+        prep.set_cond(cond)
     B, _, Tm = z.shape
     x, rowmask, T = squeeze_rows(cfg, z, lengths)
     R = x.shape[0]

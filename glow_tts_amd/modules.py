@@ -322,6 +322,14 @@ class GlowTTS(torch.nn.Module):
                   mels_for_ge2e=None, pitches=None, pitch_lengths=None, noise_scale=1.0, length_scale=1.0, noises=None):
         """Modules.py:128-204.  `noises` (optional, [B, Mel_Dim, >= max T_mel]) injects the Gaussian noise the reference
         draws with torch.randn_like (:187) so that results are reproducible."""
+        front = self.inference_front(tokens, token_lengths, mels_for_prosody, mel_lengths_for_prosody, speakers, mels_for_ge2e, length_scale)
+        return self.inference_back(front, None, noise_scale, noises)
+
+    @torch.no_grad()
+    def inference_front(self, tokens, token_lengths, mels_for_prosody=None, mel_lengths_for_prosody=None, speakers=None, mels_for_ge2e=None,
+                        length_scale=1.0):
+        """First half of `inference` (Modules.py:128-174): conditioning, encoder, durations -> (mean, log_std, dur, mel_lengths, token_mask,
+        spk, pro).  Everything stays on the device; nothing here depends on the mel length (glow_tts_amd.graph_infer replays it as a hipGraph)."""
         hp = self.hp
         P = self._params()
         spk, pro = self._conditioning(P, speakers, mels_for_ge2e, mels_for_prosody, mel_lengths_for_prosody)
@@ -332,7 +340,15 @@ class GlowTTS(torch.nn.Module):
         ls = length_scale.to(tokens.device).unsqueeze(-1).unsqueeze(-1)                                   # Modules.py:169
         dur = torch.ceil(torch.exp(log_dur) * token_mask * ls).squeeze(1)                                 # :173
         mel_lengths = torch.clamp_min(dur.sum(1), 1.0).long()                                             # :174
-        mel_mask = self.Mask_Generate(mel_lengths)
+        return mean, log_std, dur, mel_lengths, token_mask, spk, pro
+
+    @torch.no_grad()
+    def inference_back(self, front, max_mel_length=None, noise_scale=1.0, noises=None, prep=None):
+        """Second half (Modules.py:175-204): hard alignment, prior sample, inverse flow.  max_mel_length: padded frame count (None: the batch
+        maximum, read back from the device like the reference's torch.max); prep: a decoder._Prepared kept by the caller (static weights)."""
+        hp = self.hp
+        mean, log_std, dur, mel_lengths, token_mask, spk, pro = front
+        mel_mask = self.Mask_Generate(mel_lengths, max_mel_length)
         amask = (token_mask.unsqueeze(-1) * mel_mask.unsqueeze(2)).squeeze(1)
         attn = self.Path_Generate(dur, amask)                                                             # :181
         mel_mean = mean @ attn
@@ -340,11 +356,19 @@ class GlowTTS(torch.nn.Module):
         if noises is None:
             noises = torch.randn_like(mel_mean)
         z = (mel_mean + torch.exp(mel_log_std) * noises[:, :, :mel_mean.shape[2]] * noise_scale) * mel_mask   # :187-191
+        P = self._params()
         stacks = self._stacks(P)
         cond = stacks.conditioning(spk, pro)
-        W = dict(zip(decoder.WEIGHT_KEYS, [w.contiguous() for w in stacks.weights()]))
-        mels = decoder.decoder_inverse(self.dec_cfg, W, z.contiguous(), mel_lengths, cond=cond, fill=-float(hp.Sound.Max_Abs_Mel))   # :198-202
+        W = None if prep is not None else dict(zip(decoder.WEIGHT_KEYS, [w.contiguous() for w in stacks.weights()]))
+        mels = decoder.decoder_inverse(self.dec_cfg, W, z.contiguous(), mel_lengths, cond=cond, fill=-float(hp.Sound.Max_Abs_Mel), prep=prep)   # :198-202
         return mels, mel_lengths, attn
+
+    def prepared_decoder_weights(self):
+        """Packed weight images of the decoder for the CURRENT parameter values (inference with static weights: pack once, not per call)."""
+        with torch.no_grad():
+            P = self._params()
+            W = dict(zip(decoder.WEIGHT_KEYS, [w.contiguous() for w in self._stacks(P).weights()]))
+            return decoder._Prepared(self.dec_cfg, W, need_bwd=False, cond=None)
 
     def Path_Generate(self, durations, masks):
         """Modules.py:213-229."""

@@ -185,3 +185,12 @@ def test_graphed_train_step_matches_eager():
     here = os.path.dirname(os.path.abspath(__file__))
     out = subprocess.run([sys.executable, os.path.join(here, "graph_step_check.py")], capture_output=True, text=True, timeout=600, cwd=os.path.dirname(here))
     assert out.returncode == 0 and "GRAPH STEP OK" in out.stdout, (out.returncode, out.stdout[-2000:], out.stderr[-2000:])
+
+
+def test_graphed_inference_matches_eager():
+    """glow_tts_amd.graph_infer.GraphedInference: encoder graph + one length read + bucketed inverse-flow graph reproduce
+    GlowTTS.inference (same injected noise) for several length scales, Vanilla and speaker-conditioned.  Child process, see above."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "graph_infer_check.py")], capture_output=True, text=True, timeout=600, cwd=os.path.dirname(here))
+    assert out.returncode == 0 and "GRAPH INFER OK" in out.stdout, (out.returncode, out.stdout[-2000:], out.stderr[-2000:])
