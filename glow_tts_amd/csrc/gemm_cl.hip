@@ -1274,11 +1274,20 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
         const long tiles = (long)((frags + 3) / 4) * gy;
         if (tiles > ncu && tiles <= 3L * ncu) best = 4;
     }
+    // k-tap convs with few columns (the WaveNet In data gradient: 192 columns = 3 strips): the round model picks 5 waves x 243 workgroups,
+    // i.e. 1.25 waves per SIMD; 7 waves x 174 workgroups hide more of the load latency and leave 80 CUs to the encoder stream's backward:
+    // 6.21 -> 6.15 and 6.27 -> 6.21 ms/step on two boxes (8 waves: -0.04, 10: +0.05).  Only while that still fills half the chip.
+    if (coop && !nload && TAPS > 1 && gy <= 3 && best < 7) {
+        const long tiles = (long)((frags + 6) / 7) * gy;
+        if (tiles <= ncu && 2 * tiles >= ncu) best = 7;
+    }
     static const int force_t1 = [] { const char* e = getenv("GLOWTTS_DMA_WAVES_T1"); return e ? atoi(e) : 0; }();
     if (force >= 4 && force <= WMAX) best = force;
     static const int force_t5 = [] { const char* e = getenv("GLOWTTS_DMA_WAVES_T5"); return e ? atoi(e) : 0; }();
     if (TAPS == 1 && force_t1 >= 4 && force_t1 <= WMAX) best = force_t1;
     if (TAPS > 1 && force_t5 >= 4 && force_t5 <= WMAX) best = force_t5;
+    static const int force_t5n = [] { const char* e = getenv("GLOWTTS_DMA_WAVES_T5_NARROW"); return e ? atoi(e) : 0; }();      // k-tap convs with <= 192 columns
+    if (TAPS > 1 && gy <= 3 && force_t5n >= 4 && force_t5n <= WMAX) best = force_t5n;
     const int BM = best * 32;
     const int nat = TAPS == 1 ? DMA1_CPS : 1, sub = TAPS == 1 ? DMA1_CPS : TAPS;
     // LDS stages: 2 by default.  Alone, the kernel is as fast with 2 as with 3 (17.7 us either way); in the training step the smaller
