@@ -17,6 +17,7 @@ def _lib2():
     global _decl
     L = _L()
     if not _decl:
+        L.glowtts_logprior_prep.argtypes = [ctypes.c_void_p] * 9 + [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_int)] * 2 + [ctypes.c_void_p]
         L.glowtts_mas_dp_f32_t.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_void_p]
         L.glowtts_expand_fwd.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
         L.glowtts_expand_bwd.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
@@ -33,20 +34,27 @@ def log_prior_t(mean, log_std, z, token_lengths, mel_lengths):
     mean/log_std [B, Cm, Tx], z [B, Cm, Ty] (channel-first like the reference).  Always fp32 (MAS ties)."""
     B, Cm, Tx = mean.shape
     Ty = z.shape[2]
-    r = torch.exp(-2.0 * log_std)                                            # [B,Cm,Tx]
-    wb = torch.cat([r, mean * r], dim=1).transpose(1, 2).contiguous()         # [B,Tx,2Cm]: (sigma^-2 | mu sigma^-2)
-    cb = (-0.5 * LOG_2PI - log_std - 0.5 * mean * mean * r).sum(1).contiguous()   # [B,Tx]
+    L = _lib2()
+    dev = z.device
+    mean, log_std = mean.contiguous(), log_std.contiguous()
+    npad, kch = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(L.glowtts_logprior_prep(None, None, None, None, None, None, None, None, None, B, Cm, Tx, Ty, ctypes.byref(npad), ctypes.byref(kch), None),
+               "glowtts_logprior_prep(size)")
+    stride = kch.value * npad.value * 64                                     # bytes per utterance of the packed (sigma^-2 | mu sigma^-2) image
+    packed = torch.empty(B * stride, dtype=torch.uint8, device=dev)
+    cb, fmask = torch.empty(B, Tx, device=dev), torch.empty(B, Ty, device=dev)
+    tx, ty = torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev)
+    _lib.check(L.glowtts_logprior_prep(_lib.ptr(mean), _lib.ptr(log_std), _lib.ptr(token_lengths.contiguous()), _lib.ptr(mel_lengths.contiguous()),
+                                       _lib.ptr(packed), _lib.ptr(cb), _lib.ptr(fmask), _lib.ptr(tx), _lib.ptr(ty), B, Cm, Tx, Ty, None, None,
+                                       _lib.stream()), "glowtts_logprior_prep")
     zt = z.transpose(1, 2).contiguous()                                       # [B,Ty,Cm] frames x channels
-    pw = PackedBatch(wb.unsqueeze(-1), False, ops.PERM_NONE, 0, ops.F32)      # per-utterance "weights" [B][Tx][2Cm]
-    out = torch.empty(B, Ty, Tx, device=z.device)
-    fmask = (torch.arange(Ty, device=z.device)[None, :] < mel_lengths[:, None]).to(torch.float32).contiguous()
-    tx = token_lengths.to(torch.int32).contiguous()
+    out = torch.empty(B, Ty, Tx, device=dev)
     a = ops.ConvArgs()
     a.a, a.lda, a.ca1, a.ca, a.apro, a.rows = zt.data_ptr(), Cm, Cm, 2 * Cm, ops.APRO_SQNEG, Ty
-    a.w, a.n, a.npad, a.kchunks, a.taps, a.pad, a.precision = pw.data.data_ptr(), Tx, pw.npad, pw.kchunks, 1, 0, ops.F32
+    a.w, a.n, a.npad, a.kchunks, a.taps, a.pad, a.precision = packed.data_ptr(), Tx, npad.value, kch.value, 1, 0, ops.F32
     a.epi, a.flags = ops.EPI_LINEAR, ops.F_BIAS | ops.F_MASK | ops.F_COLMASK
     a.bias, a.rowmask, a.out0, a.ld0 = cb.data_ptr(), fmask.data_ptr(), out.data_ptr(), Tx
-    a.batch, a.a_bstride, a.w_bstride, a.bias_bstride, a.out_bstride, a.mask_bstride = B, Ty * Cm, pw.stride, Tx, Ty * Tx, Ty
+    a.batch, a.a_bstride, a.w_bstride, a.bias_bstride, a.out_bstride, a.mask_bstride = B, Ty * Cm, stride, Tx, Ty * Tx, Ty
     a.ncols_valid = tx.data_ptr()
     a.rows_per_utt = Ty
     _lib.check(_lib.lib().glowtts_conv_cl(ctypes.byref(a), _lib.stream()), "glowtts_conv_cl(log_prior)")

@@ -112,6 +112,61 @@ __global__ __launch_bounds__(256) void mle_bwd_kernel(const float* __restrict__ 
 #define RET_LAUNCH() return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH
 }  // namespace
 
+// Operands of the log-prior GEMM (Modules.py:108-114) from the encoder's mean / log_std [B][Cm][Tx] in ONE launch (was 15 small
+// PyTorch kernels between the decoder and MAS, on the step's critical path):
+//   packed  [b][k chunk][n = token, padded to npad][16]  fp32 MFMA weight image of (sigma^-2 | mu sigma^-2)      (K = 2 Cm, taps = 1)
+//   cb      [b][token]   = sum_c (-0.5 log 2pi - log_std - 0.5 mu^2 sigma^-2)
+//   fmask   [b][frame]   = frame < mel_length ;  tx32 / ty32 = the lengths as int32 (MAS takes int32)
+__global__ __launch_bounds__(256) void logprior_prep_kernel(const float* __restrict__ mean, const float* __restrict__ ls, const int64_t* __restrict__ tlen,
+                                                            const int64_t* __restrict__ mlen, float* __restrict__ packed, float* __restrict__ cb,
+                                                            float* __restrict__ fmask, int32_t* __restrict__ tx32, int32_t* __restrict__ ty32,
+                                                            int B, int Cm, int Tx, int Ty, int npad, int kch)
+{
+    const long tid = blockIdx.x * 256L + threadIdx.x, nth = (long)gridDim.x * 256;
+    const long per = (long)kch * npad * 16;
+    for (long i = tid; i < B * per; i += nth) {
+        const int b = (int)(i / per);
+        const long r = i - b * per;
+        const int kk = (int)(r & 15), n = (int)((r >> 4) % npad), kc = (int)((r >> 4) / npad);
+        const int k = kc * 16 + kk;
+        float v = 0.f;
+        if (n < Tx && k < 2 * Cm) {
+            const int c = k < Cm ? k : k - Cm;
+            const long src = ((long)b * Cm + c) * Tx + n;
+            const float rr = expf(-2.f * ls[src]);
+            v = k < Cm ? rr : mean[src] * rr;
+        }
+        packed[i] = v;
+    }
+    for (long i = tid; i < (long)B * Tx; i += nth) {                    // consecutive threads = consecutive tokens: coalesced over x
+        const int b = (int)(i / Tx), x = (int)(i - (long)b * Tx);
+        float acc = 0.f;
+        for (int c = 0; c < Cm; ++c) {
+            const long src = ((long)b * Cm + c) * Tx + x;
+            const float l = ls[src], m = mean[src];
+            acc += -0.9189385332046727f - l - 0.5f * m * m * expf(-2.f * l);
+        }
+        cb[i] = acc;
+    }
+    for (long i = tid; i < (long)B * Ty; i += nth) { const int b = (int)(i / Ty); fmask[i] = (i - (long)b * Ty) < mlen[b] ? 1.f : 0.f; }
+    for (long i = tid; i < B; i += nth) { tx32[i] = (int32_t)tlen[i]; ty32[i] = (int32_t)mlen[i]; }
+}
+
+extern "C" int glowtts_logprior_prep(const float* mean, const float* log_std, const int64_t* token_lengths, const int64_t* mel_lengths, float* packed,
+                                     float* cb, float* fmask, int32_t* tx32, int32_t* ty32, int B, int Cm, int Tx, int Ty, int* npad_out,
+                                     int* kchunks_out, void* stream)
+{
+    if (B < 1 || Cm < 1 || Tx < 1 || Ty < 1) return GLOWTTS_E_ARG;
+    const int npad = (Tx + 63) / 64 * 64, kch = (2 * Cm + 15) / 16;
+    if (npad_out) *npad_out = npad;
+    if (kchunks_out) *kchunks_out = kch;
+    if (!packed) return GLOWTTS_OK;                                     // size query
+    if (!mean || !log_std || !token_lengths || !mel_lengths || !cb || !fmask || !tx32 || !ty32) return GLOWTTS_E_ARG;
+    const long work = (long)B * kch * npad * 16;
+    hipLaunchKernelGGL(logprior_prep_kernel, dim3((int)((work + 1023) / 1024 > 2048 ? 2048 : (work + 1023) / 1024)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       mean, log_std, token_lengths, mel_lengths, packed, cb, fmask, tx32, ty32, B, Cm, Tx, Ty, npad, kch);
+    RET_LAUNCH();
+}
 extern "C" int glowtts_expand_fwd(const float* src, const int32_t* idx, float* out, int B, int C, int Tx, int Ty, void* stream)
 {
     if (!src || !idx || !out || B < 1 || C < 1 || Tx < 1 || Ty < 1) return GLOWTTS_E_ARG;
