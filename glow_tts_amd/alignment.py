@@ -17,7 +17,7 @@ def _lib2():
     global _decl
     L = _L()
     if not _decl:
-        L.glowtts_logprior_prep.argtypes = [ctypes.c_void_p] * 9 + [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_int)] * 2 + [ctypes.c_void_p]
+        L.glowtts_logprior_prep.argtypes = [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)] * 2 + [ctypes.c_void_p]
         L.glowtts_mas_dp_f32_t.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_void_p]
         L.glowtts_expand_fwd.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
         L.glowtts_expand_bwd.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
@@ -29,23 +29,25 @@ def _lib2():
 
 
 @torch.no_grad()
-def log_prior_t(mean, log_std, z, token_lengths, mel_lengths):
+def log_prior_t(mean, log_std, z, token_lengths, mel_lengths, mel_multiple=1, return_lengths=False):
     """Modules.py:108-114, transposed: returns value_t [B, T_mel, T_tok] = log N(z_y; mean_x, std_x) * mask.
-    mean/log_std [B, Cm, Tx], z [B, Cm, Ty] (channel-first like the reference).  Always fp32 (MAS ties)."""
+    mean/log_std [B, Cm, Tx], z [B, Cm, Ty] (channel-first like the reference).  Always fp32 (MAS ties).
+    mel_multiple: mel lengths are rounded down to a multiple of it on the device (Decoder.Num_Squeeze); return_lengths: also return the
+    int32 (token, mel) lengths the kernels used, for maximum_path_t."""
     B, Cm, Tx = mean.shape
     Ty = z.shape[2]
     L = _lib2()
     dev = z.device
     mean, log_std = mean.contiguous(), log_std.contiguous()
     npad, kch = ctypes.c_int(0), ctypes.c_int(0)
-    _lib.check(L.glowtts_logprior_prep(None, None, None, None, None, None, None, None, None, B, Cm, Tx, Ty, ctypes.byref(npad), ctypes.byref(kch), None),
+    _lib.check(L.glowtts_logprior_prep(None, None, None, None, None, None, None, None, None, B, Cm, Tx, Ty, int(mel_multiple), ctypes.byref(npad), ctypes.byref(kch), None),
                "glowtts_logprior_prep(size)")
     stride = kch.value * npad.value * 64                                     # bytes per utterance of the packed (sigma^-2 | mu sigma^-2) image
     packed = torch.empty(B * stride, dtype=torch.uint8, device=dev)
     cb, fmask = torch.empty(B, Tx, device=dev), torch.empty(B, Ty, device=dev)
     tx, ty = torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev)
     _lib.check(L.glowtts_logprior_prep(_lib.ptr(mean), _lib.ptr(log_std), _lib.ptr(token_lengths.contiguous()), _lib.ptr(mel_lengths.contiguous()),
-                                       _lib.ptr(packed), _lib.ptr(cb), _lib.ptr(fmask), _lib.ptr(tx), _lib.ptr(ty), B, Cm, Tx, Ty, None, None,
+                                       _lib.ptr(packed), _lib.ptr(cb), _lib.ptr(fmask), _lib.ptr(tx), _lib.ptr(ty), B, Cm, Tx, Ty, int(mel_multiple), None, None,
                                        _lib.stream()), "glowtts_logprior_prep")
     zt = z.transpose(1, 2).contiguous()                                       # [B,Ty,Cm] frames x channels
     out = torch.empty(B, Ty, Tx, device=dev)
@@ -58,7 +60,7 @@ def log_prior_t(mean, log_std, z, token_lengths, mel_lengths):
     a.ncols_valid = tx.data_ptr()
     a.rows_per_utt = Ty
     _lib.check(_lib.lib().glowtts_conv_cl(ctypes.byref(a), _lib.stream()), "glowtts_conv_cl(log_prior)")
-    return out
+    return (out, tx, ty) if return_lengths else out
 
 
 @torch.no_grad()
@@ -66,8 +68,8 @@ def maximum_path_t(value_t, token_lengths, mel_lengths, max_neg_val=-1e9):
     """value_t [B,Ty,Tx] -> idx [B,Ty] i32 (token aligned to each frame, -1 past the utterance)."""
     B, Ty, Tx = value_t.shape
     idx = torch.empty(B, Ty, dtype=torch.int32, device=value_t.device)
-    tx = token_lengths.to(torch.int32).contiguous()
-    ty = mel_lengths.to(torch.int32).contiguous()
+    tx = token_lengths if token_lengths.dtype == torch.int32 else token_lengths.to(torch.int32).contiguous()
+    ty = mel_lengths if mel_lengths.dtype == torch.int32 else mel_lengths.to(torch.int32).contiguous()
     _lib.check(_lib2().glowtts_mas_dp_f32_t(_lib.ptr(value_t), _lib.ptr(tx), _lib.ptr(ty), _lib.ptr(idx), None, B, Tx, Ty,
                                             max_neg_val, _lib.stream()), "glowtts_mas_dp_f32_t")
     return idx
@@ -135,9 +137,9 @@ class MLELoss(torch.autograd.Function):
 
 
 @torch.no_grad()
-def align(mean, log_std, z, token_lengths, mel_lengths):
-    """-> (attentions [B,Tx,Ty] float 0/1, idx [B,Ty] i32, value_t)."""
+def align(mean, log_std, z, token_lengths, mel_lengths, mel_multiple=1):
+    """-> (attentions [B,Tx,Ty] float 0/1, idx [B,Ty] i32, value_t).  mel_lengths are rounded down to a multiple of mel_multiple."""
     from .monotonic_align import path_from_idx
-    value_t = log_prior_t(mean, log_std, z, token_lengths, mel_lengths)
-    idx = maximum_path_t(value_t, token_lengths, mel_lengths)
+    value_t, tx, ty = log_prior_t(mean, log_std, z, token_lengths, mel_lengths, mel_multiple, return_lengths=True)
+    idx = maximum_path_t(value_t, tx, ty)
     return path_from_idx(idx, mean.shape[2], torch.float32), idx, value_t

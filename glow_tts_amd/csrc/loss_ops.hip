@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void mle_bwd_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void logprior_prep_kernel(const float* __restrict__ mean, const float* __restrict__ ls, const int64_t* __restrict__ tlen,
                                                             const int64_t* __restrict__ mlen, float* __restrict__ packed, float* __restrict__ cb,
                                                             float* __restrict__ fmask, int32_t* __restrict__ tx32, int32_t* __restrict__ ty32,
-                                                            int B, int Cm, int Tx, int Ty, int npad, int kch)
+                                                            int B, int Cm, int Tx, int Ty, int npad, int kch, int ns)
 {
     const long tid = blockIdx.x * 256L + threadIdx.x, nth = (long)gridDim.x * 256;
     const long per = (long)kch * npad * 16;
@@ -148,15 +148,15 @@ __global__ __launch_bounds__(256) void logprior_prep_kernel(const float* __restr
         }
         cb[i] = acc;
     }
-    for (long i = tid; i < (long)B * Ty; i += nth) { const int b = (int)(i / Ty); fmask[i] = (i - (long)b * Ty) < mlen[b] ? 1.f : 0.f; }
-    for (long i = tid; i < B; i += nth) { tx32[i] = (int32_t)tlen[i]; ty32[i] = (int32_t)mlen[i]; }
+    for (long i = tid; i < (long)B * Ty; i += nth) { const int b = (int)(i / Ty); fmask[i] = (i - (long)b * Ty) < (mlen[b] / ns) * ns ? 1.f : 0.f; }
+    for (long i = tid; i < B; i += nth) { tx32[i] = (int32_t)tlen[i]; ty32[i] = (int32_t)((mlen[i] / ns) * ns); }
 }
 
 extern "C" int glowtts_logprior_prep(const float* mean, const float* log_std, const int64_t* token_lengths, const int64_t* mel_lengths, float* packed,
-                                     float* cb, float* fmask, int32_t* tx32, int32_t* ty32, int B, int Cm, int Tx, int Ty, int* npad_out,
-                                     int* kchunks_out, void* stream)
+                                     float* cb, float* fmask, int32_t* tx32, int32_t* ty32, int B, int Cm, int Tx, int Ty, int mel_multiple,
+                                     int* npad_out, int* kchunks_out, void* stream)
 {
-    if (B < 1 || Cm < 1 || Tx < 1 || Ty < 1) return GLOWTTS_E_ARG;
+    if (B < 1 || Cm < 1 || Tx < 1 || Ty < 1 || mel_multiple < 1) return GLOWTTS_E_ARG;
     const int npad = (Tx + 63) / 64 * 64, kch = (2 * Cm + 15) / 16;
     if (npad_out) *npad_out = npad;
     if (kchunks_out) *kchunks_out = kch;
@@ -164,7 +164,7 @@ extern "C" int glowtts_logprior_prep(const float* mean, const float* log_std, co
     if (!mean || !log_std || !token_lengths || !mel_lengths || !cb || !fmask || !tx32 || !ty32) return GLOWTTS_E_ARG;
     const long work = (long)B * kch * npad * 16;
     hipLaunchKernelGGL(logprior_prep_kernel, dim3((int)((work + 1023) / 1024 > 2048 ? 2048 : (work + 1023) / 1024)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       mean, log_std, token_lengths, mel_lengths, packed, cb, fmask, tx32, ty32, B, Cm, Tx, Ty, npad, kch);
+                       mean, log_std, token_lengths, mel_lengths, packed, cb, fmask, tx32, ty32, B, Cm, Tx, Ty, npad, kch, mel_multiple);
     RET_LAUNCH();
 }
 extern "C" int glowtts_expand_fwd(const float* src, const int32_t* idx, float* out, int B, int C, int Tx, int Ty, void* stream)

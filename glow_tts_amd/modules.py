@@ -303,9 +303,8 @@ class GlowTTS(torch.nn.Module):
             main.wait_stream(side)
             for t_ in (mean, log_std, log_dur):
                 t_.record_stream(main)
-        ns = hp.Decoder.Num_Squeeze
-        z_len = (mel_lengths // ns) * ns
-        attn, idx, _ = alignment.align(mean.detach(), log_std.detach(), z.detach(), token_lengths, z_len)   # Modules.py:107-116
+        attn, idx, _ = alignment.align(mean.detach(), log_std.detach(), z.detach(), token_lengths, mel_lengths,
+                                       mel_multiple=int(hp.Decoder.Num_Squeeze))                      # Modules.py:107-116 (lengths of the squeezed z)
         if z.shape[2] != attn.shape[2]:
             attn = attn[:, :, :z.shape[2]]
         if idx.shape[1] != z.shape[2]:

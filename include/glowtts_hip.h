@@ -397,10 +397,11 @@ int glowtts_rpr_attention_bwd(const float *qkv, const float *relk, const float *
 /* out[b][c][y] = idx[b][y] >= 0 ? src[b][c][idx[b][y]] : 0   ==  src @ attentions (Modules.py:120-121), attentions one-hot per frame */
 /* Operands of the log-prior GEMM (Modules.py:108-114) in one launch: the fp32 MFMA weight image of (sigma^-2 | mu sigma^-2)
  * [B][kchunks][npad][16] (what glowtts_pack_weight_batched(F32) would produce from [B][Tx][2 Cm]), the per-token constant cb [B][Tx], the
- * frame mask [B][Ty] and the lengths as int32.  packed == NULL: size query (npad_out, kchunks_out). */
+ * frame mask [B][Ty] and the lengths as int32; mel lengths are first rounded down to a multiple of `mel_multiple` (Decoder.Num_Squeeze,
+ * Modules.py:897-898).  packed == NULL: size query (npad_out, kchunks_out). */
 int glowtts_logprior_prep(const float *mean, const float *log_std, const int64_t *token_lengths, const int64_t *mel_lengths, float *packed,
-                          float *cb, float *fmask, int32_t *tx32, int32_t *ty32, int B, int Cm, int Tx, int Ty, int *npad_out,
-                          int *kchunks_out, void *stream);
+                          float *cb, float *fmask, int32_t *tx32, int32_t *ty32, int B, int Cm, int Tx, int Ty, int mel_multiple,
+                          int *npad_out, int *kchunks_out, void *stream);
 int glowtts_expand_fwd(const float *src, const int32_t *idx, float *out, int B, int C, int Tx, int Ty, void *stream);
 /* its gradient w.r.t. src: a segment sum over the (contiguous) frames of each token */
 int glowtts_expand_bwd(const float *dout, const int32_t *idx, float *dsrc, int B, int C, int Tx, int Ty, void *stream);
