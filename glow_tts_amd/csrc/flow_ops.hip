@@ -595,9 +595,10 @@ static bool an_bwd_wide(int C, const float* dz, const float* dx, const float* x,
     static const int on = [] { const char* e = getenv("GLOWTTS_AN_WIDE"); return e ? atoi(e) : 1; }();
     return on && (C % 8) == 0 && !((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(x)) & 15) && (ldo % 4) == 0;
 }
-// rows per block of actnorm_inv_bwd_kernel: small blocks (R / 16 = 800+ at the bench size) keep every CU busy; the per-block partials are
+// rows per block of actnorm_inv_bwd_kernel: small blocks (36 rows = three passes of the float4 kernel, 360 blocks at the bench size; 16..48
+// measure the same within noise, 64 was 4 % of a step slower) keep every CU busy; the per-block partials are
 // reduced later by colstats_final_kernel / glowtts_colsum_batched
-static int an_bwd_rpb() { static const int v = [] { const char* e = getenv("GLOWTTS_AN_RPB"); const int x = e ? atoi(e) : 16; return x < 16 ? 16 : x; }(); return v; }
+static int an_bwd_rpb() { static const int v = [] { const char* e = getenv("GLOWTTS_AN_RPB"); const int x = e ? atoi(e) : 36; return x < 16 ? 16 : x; }(); return v; }
 extern "C" int64_t glowtts_actnorm_bwd_blocks(int64_t rows) { return (rows + an_bwd_rpb() - 1) / an_bwd_rpb(); }
 extern "C" int64_t glowtts_actnorm_stats_scratch_floats(int64_t rows, int C) { return ((rows + 15) / 16) * (2 * (int64_t)C + 16); }
 
