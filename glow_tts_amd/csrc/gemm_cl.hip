@@ -1292,7 +1292,9 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
     const int nat = TAPS == 1 ? DMA1_CPS : 1, sub = TAPS == 1 ? DMA1_CPS : TAPS;
     // LDS stages: 2 by default.  Alone, the kernel is as fast with 2 as with 3 (17.7 us either way); in the training step the smaller
     // footprint (83 instead of 124 KiB at 10 waves) lets encoder-stream workgroups share the CU: 7.1 vs 7.35 ms/step.
-    static const int nst = [] { const char* e = getenv("GLOWTTS_DMA_STAGES"); const int v = e ? atoi(e) : 2; return v == 3 ? 3 : 2; }();
+    static const int nst0 = [] { const char* e = getenv("GLOWTTS_DMA_STAGES"); const int v = e ? atoi(e) : 2; return v == 3 ? 3 : 2; }();
+    static const int nst_narrow = [] { const char* e = getenv("GLOWTTS_DMA_STAGES_NARROW"); const int v = e ? atoi(e) : 0; return v; }();
+    const int nst = (TAPS > 1 && gy <= 3 && (nst_narrow == 2 || nst_narrow == 3)) ? nst_narrow : nst0;
     const int lds = (nload ? 2 : nst) * ((nat * ((BM + TAPS - 1 + 15) >> 4) + sub * (NI * 2)) * 1024);     // three stages: <= 159 KiB (16 waves x 5 taps, 10 waves 1x1)
     static bool attr_done = false;
     if (!attr_done) {
