@@ -303,15 +303,26 @@ class GlowTTS(torch.nn.Module):
             main.wait_stream(side)
             for t_ in (mean, log_std, log_dur):
                 t_.record_stream(main)
-        attn, idx, _ = alignment.align(mean.detach(), log_std.detach(), z.detach(), token_lengths, mel_lengths,
-                                       mel_multiple=int(hp.Decoder.Num_Squeeze))                      # Modules.py:107-116 (lengths of the squeezed z)
-        if z.shape[2] != attn.shape[2]:
-            attn = attn[:, :, :z.shape[2]]
+        ns = int(hp.Decoder.Num_Squeeze)
+        value_t, tx32, ty32 = alignment.log_prior_t(mean.detach(), log_std.detach(), z.detach(), token_lengths, mel_lengths, ns,
+                                                    return_lengths=True)                       # Modules.py:107-114 (lengths of the squeezed z)
+        idx = alignment.maximum_path_t(value_t, tx32, ty32)                                          # :115-116
         if idx.shape[1] != z.shape[2]:
             idx = idx[:, :z.shape[2]].contiguous()
+        # The dense 0/1 attentions are only RETURNED (the losses use the per-frame token index): written on the encoder's stream, next to
+        # the expansion and the losses, and joined at the end of this call
+        from .monotonic_align import path_from_idx
+        if side is not main:
+            side.wait_stream(main)
+            idx.record_stream(side)
+        with torch.cuda.stream(side):
+            attn = path_from_idx(idx, tokens.shape[1], torch.float32)
         mel_mean = alignment.ExpandPrior.apply(mean, idx)                                            # Modules.py:120 (gather by the MAS index)
         mel_log_std = alignment.ExpandPrior.apply(log_std, idx)                                      # Modules.py:121
         log_dur_targets = alignment.duration_targets(idx, token_lengths, tokens.shape[1])            # Modules.py:122
+        if side is not main:
+            main.wait_stream(side)
+            attn.record_stream(main)
         classified = None
         return z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_targets, attn, classified
 
