@@ -115,7 +115,7 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
     proj = conv(x, prefix + ".layer_Dict.Project", mask_out=True).view(B, Tp, -1)
     M = hp.Sound.Mel_Dim
     proj = from_rows(proj)
-    mean, log_std = proj[:, :M], proj[:, M:]
+    mean, log_std = proj[:, :M].contiguous(), proj[:, M:].contiguous()      # (here, on the encoder stream: the consumers need dense rows)
     # Duration predictor on detached features (:277-282, 602-618)
     d = x.detach()
     cond = None
