@@ -168,6 +168,30 @@ class WgradGroup:
             # eager: the host may run ahead of the stream, so the job table is copied synchronously from a private buffer
             self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
 
+    @staticmethod
+    def upload_all(groups, device):
+        """One host-to-device copy for the job tables of several groups (one memcpy node in a captured step instead of one per group)."""
+        groups = [g for g in groups if g.jobs]
+        if not groups:
+            return
+        raws = [bytes((WgradJob * len(g.jobs))(*g.jobs)) for g in groups]
+        raw = b"".join(raws)
+        key = ("all",) + tuple((g.tag, g.taps, g.xpro, g.io_flags) for g in groups) + (len(raw), str(device))
+        pinned = _PINNED.get(key)
+        if pinned is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.GlowTTSHipError("run at least one eager step before capturing a hipGraph (pinned job table not allocated yet)")
+            pinned = _PINNED[key] = torch.empty(len(raw), dtype=torch.uint8).pin_memory()
+        if torch.cuda.is_current_stream_capturing():
+            pinned.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            table = pinned.to(device, non_blocking=True)
+        else:
+            table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        off = 0
+        for g, r in zip(groups, raws):
+            g.table = table[off:off + len(r)]
+            off += len(r)
+
     def launch_segment(self, i):
         start, n, tiles = self.segments[i]
         if n == 0:
@@ -515,7 +539,7 @@ class DecoderFunction(torch.autograd.Function):
         # measured 3x slower in total, even on a second stream).
         for grp in (gk, g1, gp):
             grp.end_segment()
-            grp.upload(dev)
+        WgradGroup.upload_all((gk, g1, gp), dev)
         halves = len(gk.segments)
         main = torch.cuda.current_stream()
         side = _wgrad_stream(dev)
