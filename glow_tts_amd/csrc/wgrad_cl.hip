@@ -84,7 +84,9 @@ __device__ __forceinline__ void ldgw(uint32_t* dst, const unsigned char* src) {
 
 // job of this workgroup: p (by value when there is a single problem, else looked up in the device table by tile index)
 // DYBF / XBF: DY / X are stored as bf16 in HBM (bf16 precision only; glowtts_wgrad_args.io_flags) - then staging is a raw copy.
-template <typename CT, int TAPS, int XPRO, bool DYBF, bool XBF>
+// WIDE (both operands stored as bf16, no X prologue): 8 channels = 16 bytes per staged item instead of 4 - half the loads, LDS stores and
+// mask selects per MFMA (the 1x1 problems do 4 MFMAs per wave and 64-row step: staging instructions are what they spend their time on)
+template <typename CT, int TAPS, int XPRO, bool DYBF, bool XBF, bool WIDE = false>
 __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job single, const glowtts_wgrad_job* __restrict__ table, const WCommon cm)
 {
     glowtts_wgrad_job p = single;
@@ -109,7 +111,9 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job singl
     constexpr int LDX = BNC * ES + 64;
     constexpr int DY_BYTES = BK * LDY, X_BYTES = XROWS * LDX;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (DY_BYTES + X_BYTES)];
-    __shared__ float bias_red[NT / (BMO / 4)][BMO];
+    constexpr int GRP = WIDE ? 8 : 4;                         // channels per staged item
+    static_assert(!WIDE || (DYBF && XBF && XPRO == GLOWTTS_APRO_NONE), "16-byte items: raw bf16 copies only");
+    float (*bias_red)[BMO] = reinterpret_cast<float (*)[BMO]>(smem);      // [NT / (BMO / GRP)][BMO], used after the last step (<= 16 KiB)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;                 // wave tile: MI * 32 (o) x 32 (c)
@@ -133,13 +137,13 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job singl
 
     // ---- staging: raw unconditional loads (clamped addresses) two steps ahead; masks / prologue / bf16 conversion at the
     //      LDS store (same reasoning as conv_cl_kernel: a fixed number of loads per step keeps the vmcnt waits counted) ----
-    constexpr int DY_IT = (BK * BMO / 4) / NT;                // 4-channel groups per thread for the DY tile
-    constexpr int X_IT = (XROWS * BNC / 4 + NT - 1) / NT;     // 4-channel groups per thread for the X tile
+    constexpr int DY_IT = (BK * BMO / GRP) / NT;              // channel groups per thread for the DY tile
+    constexpr int X_IT = (XROWS * BNC / GRP + NT - 1) / NT;   // channel groups per thread for the X tile
     constexpr int XL = (XPRO == GLOWTTS_APRO_PAIRMUL) ? 2 : 1;
     static_assert(!(DYBF || XBF) || ES == 2, "bf16 activation storage needs bf16 precision");
     // raw register image of one item = 4 (x XL) stored elements: 16 B (f32) / 8 B (bf16) per 4 elements
-    constexpr int DYW = DYBF ? 2 : 4;                         // 32-bit words per DY item
-    constexpr int XW = (XBF ? 2 : 4) * XL;                    // 32-bit words per X item
+    constexpr int DYW = DYBF ? GRP / 2 : 4;                   // 32-bit words per DY item
+    constexpr int XW = (XBF ? GRP / 2 : 4) * XL;              // 32-bit words per X item
     typedef uint32_t DYRegs[DY_IT][DYW];
     typedef uint32_t XRegs[X_IT][XW];
     // NS register sets = loads of NS - 1 steps in flight.  A step of the 1x1 problems is 4 MFMAs per wave, far shorter than the HBM
@@ -147,26 +151,28 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job singl
     constexpr int NS = (TAPS <= WGRAD_SETS_MAXTAPS && (DY_IT * DYW + X_IT * XW) <= 24) ? WGRAD_SETS : 2;
     DYRegs rdy[NS];
     XRegs rx[NS];
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float bsum[GRP];
+#pragma unroll
+    for (int e = 0; e < GRP; ++e) bsum[e] = 0.f;
     const bool want_bias = (p.dbias != nullptr) && (tile_c == 0);
-    const int lim_dy = (int)p.lddy - 4;
-    const int lim_x = (int)p.ldx - 4 * XL;
+    const int lim_dy = (int)p.lddy - GRP;
+    const int lim_x = (int)p.ldx - GRP * XL;
 
     auto gload = [&](DYRegs& rdy, XRegs& rx, long r0) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < DY_IT; ++it) {
             const int idx = tid + it * NT;
-            const int row = idx / (BMO / 4), c4 = idx % (BMO / 4);
+            const int row = idx / (BMO / GRP), c4 = idx % (BMO / GRP);
             const long r = min(r0 + row, (long)cm.rows - 1);
-            ldgw<DYW>(rdy[it], reinterpret_cast<const unsigned char*>(p.dy) + (r * p.lddy + min(o0 + c4 * 4, lim_dy)) * (DYBF ? 2 : 4));
+            ldgw<DYW>(rdy[it], reinterpret_cast<const unsigned char*>(p.dy) + (r * p.lddy + min(o0 + c4 * GRP, lim_dy)) * (DYBF ? 2 : 4));
         }
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
             const int idx = tid + it * NT;
-            const int row = idx / (BNC / 4), c4 = idx % (BNC / 4);
+            const int row = idx / (BNC / GRP), c4 = idx % (BNC / GRP);
             long r = r0 + row - cm.pad;
             r = r < 0 ? 0 : (r >= cm.rows ? cm.rows - 1 : r);
-            ldgw<XW>(rx[it], reinterpret_cast<const unsigned char*>(p.x) + (r * p.ldx + min((c0 + c4 * 4) * XL, lim_x)) * (XBF ? 2 : 4));
+            ldgw<XW>(rx[it], reinterpret_cast<const unsigned char*>(p.x) + (r * p.ldx + min((c0 + c4 * GRP) * XL, lim_x)) * (XBF ? 2 : 4));
         }
     };
     auto bf_lo = [](uint32_t w) { return __uint_as_float(w << 16); };
@@ -177,9 +183,14 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job singl
 #pragma unroll
         for (int it = 0; it < DY_IT; ++it) {
             const int idx = tid + it * NT;
-            const int row = idx / (BMO / 4), c4 = idx % (BMO / 4);
-            const bool ok = (r0 + row < rend) && (o0 + c4 * 4 < p.m);            // m is a multiple of 4 (checked on the host)
-            if constexpr (DYBF) {
+            const int row = idx / (BMO / GRP), c4 = idx % (BMO / GRP);
+            const bool ok = (r0 + row < rend) && (o0 + c4 * GRP < p.m);          // m is a multiple of GRP (checked on the host / promised by WIO_WIDE)
+            if constexpr (WIDE) {
+                uint32_t w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { w[e] = ok ? rdy[it][e] : 0u; bsum[2 * e] += bf_lo(w[e]); bsum[2 * e + 1] += bf_hi(w[e]); }
+                *reinterpret_cast<uint4*>(dyb + row * LDY + c4 * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+            } else if constexpr (DYBF) {
                 const uint32_t w0 = ok ? rdy[it][0] : 0u, w1 = ok ? rdy[it][1] : 0u;
                 bsum[0] += bf_lo(w0); bsum[1] += bf_hi(w0); bsum[2] += bf_lo(w1); bsum[3] += bf_hi(w1);
                 *reinterpret_cast<uint2*>(dyb + row * LDY + c4 * 8) = make_uint2(w0, w1);
@@ -198,12 +209,14 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job singl
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
             const int idx = tid + it * NT;
-            const int row = idx / (BNC / 4), c4 = idx % (BNC / 4);
+            const int row = idx / (BNC / GRP), c4 = idx % (BNC / GRP);
             if (row >= XROWS) continue;
             const long r = r0 + row - cm.pad;
             // rows outside [0, rows) are zero; rows outside this split's range ARE used (halo of the split)
-            const bool ok = (r >= 0) && (r < cm.rows) && (c0 + c4 * 4 < p.ca);  // ca is a multiple of 4 (checked on the host)
-            if constexpr (XBF && XPRO == GLOWTTS_APRO_NONE) {
+            const bool ok = (r >= 0) && (r < cm.rows) && (c0 + c4 * GRP < p.ca);  // ca is a multiple of GRP (checked on the host / WIO_WIDE)
+            if constexpr (WIDE) {
+                *reinterpret_cast<uint4*>(xb + row * LDX + c4 * 16) = make_uint4(ok ? rx[it][0] : 0u, ok ? rx[it][1] : 0u, ok ? rx[it][2] : 0u, ok ? rx[it][3] : 0u);
+            } else if constexpr (XBF && XPRO == GLOWTTS_APRO_NONE) {
                 *reinterpret_cast<uint2*>(xb + row * LDX + c4 * 8) = make_uint2(ok ? rx[it][0] : 0u, ok ? rx[it][1] : 0u);
             } else {
                 float4 v;
@@ -319,14 +332,14 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job singl
     }
     // ---- dbias[o] = column sums of DY (first c-tile only) ----
     if (want_bias) {
-        const int c4 = tid % (BMO / 4), rgrp = tid / (BMO / 4);       // 8 row groups share each column quad
+        const int c4 = tid % (BMO / GRP), rgrp = tid / (BMO / GRP);   // NT / (BMO / GRP) row groups share each column group
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bias_red[rgrp][c4 * 4 + e] = bsum[e];
+        for (int e = 0; e < GRP; ++e) bias_red[rgrp][c4 * GRP + e] = bsum[e];
         __syncthreads();
         if (tid < BMO) {
             float s = 0.f;
 #pragma unroll
-            for (int g = 0; g < NT / (BMO / 4); ++g) s += bias_red[g][tid];
+            for (int g = 0; g < NT / (BMO / GRP); ++g) s += bias_red[g][tid];
             const int pcol = o0 + tid;
             if (pcol < p.m) {
                 int o = pcol; bool ok = true;
@@ -341,13 +354,13 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job singl
     }
 }
 
-template <typename CT, int XPRO, bool DYBF, bool XBF>
+template <typename CT, int XPRO, bool DYBF, bool XBF, bool WIDE = false>
 int launch_x(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const WCommon& cm, int taps, dim3 grid, hipStream_t s)
 {
     switch (taps) {
-        case 1: hipLaunchKernelGGL((wgrad_kernel<CT, 1, XPRO, DYBF, XBF>), grid, dim3(NT), 0, s, one, table, cm); break;
-        case 3: hipLaunchKernelGGL((wgrad_kernel<CT, 3, XPRO, DYBF, XBF>), grid, dim3(NT), 0, s, one, table, cm); break;
-        case 5: hipLaunchKernelGGL((wgrad_kernel<CT, 5, XPRO, DYBF, XBF>), grid, dim3(NT), 0, s, one, table, cm); break;
+        case 1: hipLaunchKernelGGL((wgrad_kernel<CT, 1, XPRO, DYBF, XBF, WIDE>), grid, dim3(NT), 0, s, one, table, cm); break;
+        case 3: hipLaunchKernelGGL((wgrad_kernel<CT, 3, XPRO, DYBF, XBF, WIDE>), grid, dim3(NT), 0, s, one, table, cm); break;
+        case 5: hipLaunchKernelGGL((wgrad_kernel<CT, 5, XPRO, DYBF, XBF, WIDE>), grid, dim3(NT), 0, s, one, table, cm); break;
         default: return GLOWTTS_E_ARG;
     }
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
@@ -359,6 +372,9 @@ template <typename CT>
 int launch_w(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const WCommon& cm, int taps, int xpro, int io, dim3 grid, hipStream_t s)
 {
     if constexpr (sizeof(CT) == 2) {
+        if (io == (GLOWTTS_WIO_DY_BF16 | GLOWTTS_WIO_X_BF16 | GLOWTTS_WIO_WIDE) && xpro == GLOWTTS_APRO_NONE)
+            return launch_x<CT, GLOWTTS_APRO_NONE, true, true, true>(one, table, cm, taps, grid, s);
+        if (io & GLOWTTS_WIO_WIDE) return GLOWTTS_E_ARG;
         if (io == (GLOWTTS_WIO_DY_BF16 | GLOWTTS_WIO_X_BF16) && xpro == GLOWTTS_APRO_NONE) return launch_x<CT, GLOWTTS_APRO_NONE, true, true>(one, table, cm, taps, grid, s);
         if (io == GLOWTTS_WIO_X_BF16 && xpro == GLOWTTS_APRO_PAIRMUL) return launch_x<CT, GLOWTTS_APRO_PAIRMUL, false, true>(one, table, cm, taps, grid, s);
         if (io == GLOWTTS_WIO_X_BF16 && xpro == GLOWTTS_APRO_NONE) return launch_x<CT, GLOWTTS_APRO_NONE, false, true>(one, table, cm, taps, grid, s);

@@ -136,12 +136,16 @@ class WgradGroup:
         self.rows, self.taps, self.precision, self.xpro, self.io_flags, self.tag = rows, taps, precision, xpro, io_flags, tag
         self.jobs, self.segments, self._tiles, self._start = [], [], 0, 0
         self.table = None
+        # 16-byte staging items (glowtts_wgrad WIO_WIDE): both operands bf16, no prologue, and every job 8-channel / 16-byte aligned
+        self._wide = io_flags == (ops.WIO_DY_BF16 | ops.WIO_X_BF16) and xpro == ops.APRO_NONE and os.environ.get("GLOWTTS_WGRAD_WIDE", "1") != "0"
 
     def add(self, dy, lddy, m, x, ldx, ca, dw, dbias, perm=ops.PERM_NONE, perm_h=0):
         j = WgradJob()
         j.dy, j.x, j.dw, j.dbias, j.lddy, j.ldx = dy, x, dw, dbias, lddy, ldx
         j.m, j.ca, j.xpro, j.perm, j.perm_h = m, ca, self.xpro, perm, perm_h
         j.mt, j.nt, j.tile0 = (m + 127) // 128, (ca + 63) // 64, self._tiles
+        if (m | ca | lddy | ldx) & 7 or (dy | x) & 15:
+            self._wide = False
         self._tiles += j.mt * j.nt
         self.jobs.append(j)
 
@@ -197,7 +201,7 @@ class WgradGroup:
         if n == 0:
             return
         _lib.check(_L().glowtts_wgrad_grouped_io(self.table.data_ptr() + start * ctypes.sizeof(WgradJob), n, tiles, self.rows, self.taps,
-                                                 (self.taps - 1) // 2, self.xpro, self.precision, 1, 0, self.io_flags, _lib.stream()),
+                                                 (self.taps - 1) // 2, self.xpro, self.precision, 1, 0, self.io_flags | (ops.WIO_WIDE if self._wide else 0), _lib.stream()),
                    "glowtts_wgrad_grouped_io")
 
 
