@@ -112,7 +112,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job singl
     constexpr int DY_BYTES = BK * LDY, X_BYTES = XROWS * LDX;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (DY_BYTES + X_BYTES)];
     constexpr int GRP = WIDE ? 8 : 4;                         // channels per staged item
-    static_assert(!WIDE || (DYBF && XBF && XPRO == GLOWTTS_APRO_NONE), "16-byte items: raw bf16 copies only");
+    static_assert(!WIDE || (DYBF == XBF && XPRO == GLOWTTS_APRO_NONE && sizeof(CT) == 2), "8-channel items: bf16 MFMA, no prologue, both operands stored alike");
     float (*bias_red)[BMO] = reinterpret_cast<float (*)[BMO]>(smem);      // [NT / (BMO / GRP)][BMO], used after the last step (<= 16 KiB)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job singl
     constexpr int XL = (XPRO == GLOWTTS_APRO_PAIRMUL) ? 2 : 1;
     static_assert(!(DYBF || XBF) || ES == 2, "bf16 activation storage needs bf16 precision");
     // raw register image of one item = 4 (x XL) stored elements: 16 B (f32) / 8 B (bf16) per 4 elements
-    constexpr int DYW = DYBF ? GRP / 2 : 4;                   // 32-bit words per DY item
-    constexpr int XW = (XBF ? GRP / 2 : 4) * XL;              // 32-bit words per X item
+    constexpr int DYW = DYBF ? GRP / 2 : GRP;                 // 32-bit words per DY item
+    constexpr int XW = (XBF ? GRP / 2 : GRP) * XL;            // 32-bit words per X item
     typedef uint32_t DYRegs[DY_IT][DYW];
     typedef uint32_t XRegs[X_IT][XW];
     // NS register sets = loads of NS - 1 steps in flight.  A step of the 1x1 problems is 4 MFMAs per wave, far shorter than the HBM
@@ -185,10 +185,19 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job singl
             const int idx = tid + it * NT;
             const int row = idx / (BMO / GRP), c4 = idx % (BMO / GRP);
             const bool ok = (r0 + row < rend) && (o0 + c4 * GRP < p.m);          // m is a multiple of GRP (checked on the host / promised by WIO_WIDE)
-            if constexpr (WIDE) {
+            if constexpr (WIDE && DYBF) {
                 uint32_t w[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { w[e] = ok ? rdy[it][e] : 0u; bsum[2 * e] += bf_lo(w[e]); bsum[2 * e + 1] += bf_hi(w[e]); }
+                *reinterpret_cast<uint4*>(dyb + row * LDY + c4 * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+            } else if constexpr (WIDE) {          // 8 fp32 values -> one 16-byte LDS store of 8 bf16
+                uint32_t w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = ok ? __uint_as_float(rdy[it][2 * e]) : 0.f, b = ok ? __uint_as_float(rdy[it][2 * e + 1]) : 0.f;
+                    bsum[2 * e] += a; bsum[2 * e + 1] += b;
+                    w[e] = pk_bf16(a, b);
+                }
                 *reinterpret_cast<uint4*>(dyb + row * LDY + c4 * 16) = make_uint4(w[0], w[1], w[2], w[3]);
             } else if constexpr (DYBF) {
                 const uint32_t w0 = ok ? rdy[it][0] : 0u, w1 = ok ? rdy[it][1] : 0u;
@@ -214,8 +223,14 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job singl
             const long r = r0 + row - cm.pad;
             // rows outside [0, rows) are zero; rows outside this split's range ARE used (halo of the split)
             const bool ok = (r >= 0) && (r < cm.rows) && (c0 + c4 * GRP < p.ca);  // ca is a multiple of GRP (checked on the host / WIO_WIDE)
-            if constexpr (WIDE) {
+            if constexpr (WIDE && XBF) {
                 *reinterpret_cast<uint4*>(xb + row * LDX + c4 * 16) = make_uint4(ok ? rx[it][0] : 0u, ok ? rx[it][1] : 0u, ok ? rx[it][2] : 0u, ok ? rx[it][3] : 0u);
+            } else if constexpr (WIDE) {
+                uint32_t w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    w[e] = ok ? pk_bf16(__uint_as_float(rx[it][2 * e]), __uint_as_float(rx[it][2 * e + 1])) : 0u;
+                *reinterpret_cast<uint4*>(xb + row * LDX + c4 * 16) = make_uint4(w[0], w[1], w[2], w[3]);
             } else if constexpr (XBF && XPRO == GLOWTTS_APRO_NONE) {
                 *reinterpret_cast<uint2*>(xb + row * LDX + c4 * 8) = make_uint2(ok ? rx[it][0] : 0u, ok ? rx[it][1] : 0u);
             } else {
@@ -374,6 +389,7 @@ int launch_w(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const
     if constexpr (sizeof(CT) == 2) {
         if (io == (GLOWTTS_WIO_DY_BF16 | GLOWTTS_WIO_X_BF16 | GLOWTTS_WIO_WIDE) && xpro == GLOWTTS_APRO_NONE)
             return launch_x<CT, GLOWTTS_APRO_NONE, true, true, true>(one, table, cm, taps, grid, s);
+        if (io == GLOWTTS_WIO_WIDE && xpro == GLOWTTS_APRO_NONE) return launch_x<CT, GLOWTTS_APRO_NONE, false, false, true>(one, table, cm, taps, grid, s);
         if (io & GLOWTTS_WIO_WIDE) return GLOWTTS_E_ARG;
         if (io == (GLOWTTS_WIO_DY_BF16 | GLOWTTS_WIO_X_BF16) && xpro == GLOWTTS_APRO_NONE) return launch_x<CT, GLOWTTS_APRO_NONE, true, true>(one, table, cm, taps, grid, s);
         if (io == GLOWTTS_WIO_X_BF16 && xpro == GLOWTTS_APRO_PAIRMUL) return launch_x<CT, GLOWTTS_APRO_PAIRMUL, false, true>(one, table, cm, taps, grid, s);

@@ -137,7 +137,8 @@ class WgradGroup:
         self.jobs, self.segments, self._tiles, self._start = [], [], 0, 0
         self.table = None
         # 16-byte staging items (glowtts_wgrad WIO_WIDE): both operands bf16, no prologue, and every job 8-channel / 16-byte aligned
-        self._wide = io_flags == (ops.WIO_DY_BF16 | ops.WIO_X_BF16) and xpro == ops.APRO_NONE and os.environ.get("GLOWTTS_WGRAD_WIDE", "1") != "0"
+        self._wide = io_flags in (0, ops.WIO_DY_BF16 | ops.WIO_X_BF16) and xpro == ops.APRO_NONE and precision == ops.BF16 and \
+            os.environ.get("GLOWTTS_WGRAD_WIDE", "1") not in ("0", "2" if io_flags == 0 else "0")
 
     def add(self, dy, lddy, m, x, ldx, ca, dw, dbias, perm=ops.PERM_NONE, perm_h=0):
         j = WgradJob()

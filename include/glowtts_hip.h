@@ -256,8 +256,8 @@ typedef struct glowtts_wgrad_args {
 } glowtts_wgrad_args;
 #define GLOWTTS_WIO_DY_BF16 1
 #define GLOWTTS_WIO_X_BF16  2
-#define GLOWTTS_WIO_WIDE    4   /* with DY_BF16 | X_BF16, no prologue: the caller promises m, ca, lddy, ldx multiples of 8 and 16-byte aligned dy / x
-                                  for EVERY job: operands are then staged in 16-byte items */
+#define GLOWTTS_WIO_WIDE    4   /* bf16 precision, no prologue, both operands stored alike (both bf16 or both fp32): the caller promises m, ca, lddy,
+                                  ldx multiples of 8 and 16-byte aligned dy / x for EVERY job: operands are then staged 8 channels per item */
 int glowtts_wgrad_cl(const glowtts_wgrad_args *args /* host pointer */, void *stream);
 
 /* Grouped form: many weight-gradient problems that share (rows, taps, pad, precision) in ONE launch, so that the
