@@ -15,17 +15,22 @@ namespace {
 // squeeze: mel [B][Cm][Tm] -> rows [B][Tp][ns*Cm];  rows[b][PADR+t][s*Cm+c] = mel[b][c][ns*t+s] * mask'[t]
 // mask'[t] = (ns*t + ns-1 < len[b])   (Modules.py:903: mask[:, :, ns-1::ns]).  Also writes rowmask.
 // ------------------------------------------------------------------------------------------------
+#ifndef GLOWTTS_SQ_TS
+#define GLOWTTS_SQ_TS 16
+#endif
+constexpr int SQ_TS = GLOWTTS_SQ_TS;            // squeezed frames per workgroup of squeeze_kernel
 template <bool TO_ROWS>
 __global__ __launch_bounds__(256) void squeeze_kernel(float* __restrict__ mel, float* __restrict__ rows,
                                                       float* __restrict__ rowmask, const int64_t* __restrict__ lengths,
                                                       int Cm, int Tm, int T, int ns, float fill, int use_fill)
 {
-    // block: one utterance, 32 squeezed frames (= 32*ns mel frames), all channels.  LDS tile [Cm][32*ns + 1]
+    // block: one utterance, SQ_TS squeezed frames (= SQ_TS*ns mel frames), all channels.  LDS tile [Cm][SQ_TS*ns + 1]
+    // (16 frames: 800+ workgroups of 10 KiB at the bench size; with 32 the 416 workgroups left the copy latency-bound at 0.9 TB/s)
     extern __shared__ float tile[];
     const int b = blockIdx.y;
-    const int t0 = blockIdx.x * 32;
+    const int t0 = blockIdx.x * SQ_TS;
     const int Tp = T + 2 * PADR;
-    const int W = 32 * ns;                 // mel frames per tile
+    const int W = SQ_TS * ns;                 // mel frames per tile
     const int ldt = W + 1;
     const int C = Cm * ns;
     const long len = lengths[b];
@@ -38,7 +43,7 @@ __global__ __launch_bounds__(256) void squeeze_kernel(float* __restrict__ mel, f
             tile[c * ldt + y] = (yy < T * ns) ? melb[(long)c * Tm + yy] : 0.f;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < 32 * C; i += 256) {
+        for (int i = threadIdx.x; i < SQ_TS * C; i += 256) {
             const int t = i / C, ch = i - t * C;
             if (t0 + t >= T) continue;
             const int s = ch / Cm, c = ch - s * Cm;
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(256) void squeeze_kernel(float* __restrict__ mel, f
         }
     } else {
         // rows -> mel (unsqueeze, Modules.py:914-924): mel[b][c][ns*t+s] = rows[b][t][s*Cm+c] * mask'[t]; optional pad fill
-        for (int i = threadIdx.x; i < 32 * C; i += 256) {
+        for (int i = threadIdx.x; i < SQ_TS * C; i += 256) {
             const int t = i / C, ch = i - t * C;
             const int s = ch / Cm, c = ch - s * Cm;
             float v = 0.f;
@@ -532,8 +537,8 @@ extern "C" int glowtts_squeeze_rows(const float* mel, float* rows, float* rowmas
 {
     if (!mel || !rows || !lengths || B < 1 || Cm < 1 || ns < 1 || Tm < ns) return GLOWTTS_E_ARG;
     const int T = Tm / ns;
-    const size_t lds = (size_t)Cm * (32 * ns + 1) * sizeof(float);
-    hipLaunchKernelGGL(squeeze_kernel<true>, dim3((T + 31) / 32, B), dim3(256), lds, static_cast<hipStream_t>(stream),
+    const size_t lds = (size_t)Cm * (SQ_TS * ns + 1) * sizeof(float);
+    hipLaunchKernelGGL(squeeze_kernel<true>, dim3((T + SQ_TS - 1) / SQ_TS, B), dim3(256), lds, static_cast<hipStream_t>(stream),
                        const_cast<float*>(mel), rows, rowmask, lengths, Cm, Tm, T, ns, 0.f, 0);
     RET_LAUNCH();
 }
@@ -543,8 +548,8 @@ extern "C" int glowtts_unsqueeze_rows(const float* rows, float* mel, const int64
 {
     if (!mel || !rows || !lengths || B < 1 || Cm < 1 || ns < 1 || Tm < ns) return GLOWTTS_E_ARG;
     const int T = Tm / ns;
-    const size_t lds = (size_t)Cm * (32 * ns + 1) * sizeof(float);
-    hipLaunchKernelGGL(squeeze_kernel<false>, dim3((T + 31) / 32, B), dim3(256), lds, static_cast<hipStream_t>(stream),
+    const size_t lds = (size_t)Cm * (SQ_TS * ns + 1) * sizeof(float);
+    hipLaunchKernelGGL(squeeze_kernel<false>, dim3((T + SQ_TS - 1) / SQ_TS, B), dim3(256), lds, static_cast<hipStream_t>(stream),
                        mel, const_cast<float*>(rows), (float*)nullptr, lengths, Cm, Tm, T, ns, fill, use_fill);
     RET_LAUNCH();
 }
