@@ -1286,6 +1286,8 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
     static const int force_t5 = [] { const char* e = getenv("GLOWTTS_DMA_WAVES_T5"); return e ? atoi(e) : 0; }();
     if (TAPS == 1 && force_t1 >= 4 && force_t1 <= WMAX) best = force_t1;
     if (TAPS > 1 && force_t5 >= 4 && force_t5 <= WMAX) best = force_t5;
+    static const int force_t1n = [] { const char* e = getenv("GLOWTTS_DMA_WAVES_T1_NARROW"); return e ? atoi(e) : 0; }();      // 1x1 convs with <= 192 columns
+    if (TAPS == 1 && gy <= 3 && force_t1n >= 4 && force_t1n <= WMAX) best = force_t1n;
     static const int force_t5n = [] { const char* e = getenv("GLOWTTS_DMA_WAVES_T5_NARROW"); return e ? atoi(e) : 0; }();      // k-tap convs with <= 192 columns
     if (TAPS > 1 && gy <= 3 && force_t5n >= 4 && force_t5n <= WMAX) best = force_t5n;
     const int BM = best * 32;
