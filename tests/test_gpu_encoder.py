@@ -112,3 +112,28 @@ def test_expand_prior_forward_backward():
     assert torch.equal(out.detach(), want)
     want_g = dout.double() @ onehot.double().transpose(1, 2)
     assert (src.grad.double() - want_g).abs().max() <= 1e-5 * want_g.abs().max()
+
+
+@pytest.mark.parametrize("Cm,Tx,Ty,ns", [(80, 120, 800, 2), (80, 37, 96, 2), (12, 9, 30, 2), (160, 70, 64, 1)])
+def test_log_prior_operands_and_values(Cm, Tx, Ty, ns):
+    """glowtts_logprior_prep (tiled kernel; Cm = 160 takes the plain one) + the SQNEG GEMM reproduce Modules.py:108-114 on ragged lengths:
+    log N(z_y; mu_x, sigma_x) for valid (token, frame) pairs, exactly 0 elsewhere; mel lengths rounded down to a multiple of `ns`."""
+    from glow_tts_amd import alignment
+    torch.manual_seed(11)
+    B = 5
+    mean, log_std = torch.randn(B, Cm, Tx, device="cuda"), 0.3 * torch.randn(B, Cm, Tx, device="cuda")
+    z = torch.randn(B, Cm, Ty, device="cuda")
+    tl = torch.tensor([Tx, max(1, Tx // 2), Tx - 1, 3, Tx], device="cuda")
+    ml = torch.tensor([Ty, Ty - 1, max(ns, Ty // 3), Ty - 3, ns], device="cuda")
+    got, tx32, ty32 = alignment.log_prior_t(mean, log_std, z, tl, ml, ns, return_lengths=True)
+    zl = (ml // ns) * ns
+    assert tx32.dtype == torch.int32 and torch.equal(tx32.long(), tl) and torch.equal(ty32.long(), zl)
+    m64, s64, z64 = mean.double(), log_std.double(), z.double()
+    r = torch.exp(-2 * s64)
+    want = (-0.5 * math.log(2 * math.pi) - s64).sum(1)[:, :, None] + torch.einsum("bcx,bcy->bxy", r, -0.5 * z64 ** 2) + \
+        torch.einsum("bcx,bcy->bxy", m64 * r, z64) + (-0.5 * m64 ** 2 * r).sum(1)[:, :, None]                   # [B, Tx, Ty]
+    mask = (torch.arange(Tx, device="cuda")[None, :, None] < tl[:, None, None]) & (torch.arange(Ty, device="cuda")[None, None, :] < zl[:, None, None])
+    want = (want * mask).transpose(1, 2)
+    assert got.shape == (B, Ty, Tx)
+    assert (got[~mask.transpose(1, 2)] == 0).all()
+    assert (got.double() - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item())
