@@ -222,3 +222,39 @@ def test_pack_set_equals_single_packs(precision):
             ref = ops.pack_weight(w, transpose=t, precision=precision)
             assert (got.npad, got.kchunks, got.taps, got.n) == (ref.npad, ref.kchunks, ref.taps, ref.n)
             assert torch.equal(got.data, ref.data)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bf_io,taps", [(True, 5), (True, 1), (False, 1), (False, 3)])
+def test_wgrad_wide_staging_is_bit_identical(bf_io, taps):
+    """GLOWTTS_WIO_WIDE (8 channels per staged item) changes how operands reach LDS, not the arithmetic: grouped weight gradients and
+    equal the 4-channel staging bit for bit (bias sums to rounding: other partial-sum grouping), for bf16- and fp32-stored operands,
+    ragged tile edges included."""
+    from glow_tts_amd import decoder as D, ops
+    D._L()
+    torch.manual_seed(9)
+    R = 1000
+    shapes = [(192, 192), (384, 192), (192, 80), (200, 72)]            # (m, ca): multiples of 8, not of the 128 x 64 tile
+    dt = torch.bfloat16 if bf_io else torch.float32
+    io = (ops.WIO_DY_BF16 | ops.WIO_X_BF16) if bf_io else 0
+    dys = [torch.randn(R, m, device="cuda").to(dt) for m, _ in shapes]
+    xs = [torch.randn(R, ca, device="cuda").to(dt) for _, ca in shapes]
+    outs = []
+    for wide in (False, True):
+        g = D.WgradGroup(R, taps, ops.BF16, io_flags=io, tag=f"t{int(wide)}")
+        dws = [torch.full((m, ca, taps), 7.0, device="cuda") for m, ca in shapes]
+        dbs = [torch.full((m,), 7.0, device="cuda") for m, _ in shapes]
+        for dy, x, dw, db, (m, ca) in zip(dys, xs, dws, dbs, shapes):
+            g.add(dy.data_ptr(), m, m, x.data_ptr(), ca, ca, dw.data_ptr(), db.data_ptr())
+        assert g._wide
+        g._wide = wide
+        g.end_segment(); g.upload(torch.device("cuda")); g.launch_segment(0)
+        torch.cuda.synchronize()
+        outs.append((dws, dbs))
+    for a, b in zip(outs[0][0], outs[1][0]):                         # MFMA operands and K order are the same: identical bits
+        assert torch.equal(a, b)
+    for a, b in zip(outs[0][1], outs[1][1]):                         # bias sums: the per-thread partial sums group the rows differently
+        assert (a - b).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item())
+    ref = torch.einsum("ro,rc->oc", dys[3].float(), xs[3].float()) if taps == 1 else None
+    if ref is not None:
+        assert (outs[1][0][3][:, :, 0] - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
