@@ -1,7 +1,10 @@
 // Library identification for libglowtts_hip.so (see include/glowtts_hip.h).
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <atomic>
+#include <stdio.h>
 #include "../../include/glowtts_hip.h"
+#include "launch_log.h"
 
 extern "C" int glowtts_abi_version(void) { return 1; }
 
@@ -12,5 +15,74 @@ extern "C" int glowtts_device_arch(char* buf, int buflen)
     if (hipGetDeviceProperties(&prop, 0) != hipSuccess) { buf[0] = 0; return GLOWTTS_E_LAUNCH; }
     strncpy(buf, prop.gcnArchName, buflen - 1);
     buf[buflen - 1] = 0;
+    return GLOWTTS_OK;
+}
+
+// ---- launch log (see launch_log.h) ----
+namespace {
+constexpr int LOG_SLOTS = 128;
+struct Slot { char name[96]; std::atomic<long long> n; };
+Slot g_slots[LOG_SLOTS];
+std::atomic<int> g_used{0};
+std::atomic_flag g_lock = ATOMIC_FLAG_INIT;
+
+Slot* find_slot(const char* cls, bool create)
+{
+    int used = g_used.load(std::memory_order_acquire);
+    for (int i = 0; i < used; ++i) if (!strcmp(g_slots[i].name, cls)) return &g_slots[i];
+    if (!create) return nullptr;
+    while (g_lock.test_and_set(std::memory_order_acquire)) {}
+    used = g_used.load(std::memory_order_acquire);
+    Slot* s = nullptr;
+    for (int i = 0; i < used; ++i) if (!strcmp(g_slots[i].name, cls)) { s = &g_slots[i]; break; }
+    if (!s && used < LOG_SLOTS) {
+        s = &g_slots[used];
+        strncpy(s->name, cls, sizeof(s->name) - 1); s->name[sizeof(s->name) - 1] = 0; s->n.store(0);
+        g_used.store(used + 1, std::memory_order_release);
+    }
+    g_lock.clear(std::memory_order_release);
+    return s;
+}
+}  // namespace
+
+std::atomic<long long>* glowtts_launch_slot(const char* cls)
+{
+    Slot* s = find_slot(cls, true);
+    return s ? &s->n : nullptr;
+}
+
+void glowtts_note_launch(const char* cls)
+{
+    if (Slot* s = find_slot(cls, true)) s->n.fetch_add(1, std::memory_order_relaxed);
+}
+
+extern "C" int64_t glowtts_launch_count(const char* kernel_class)
+{
+    if (!kernel_class) return -1;
+    // prefix match: "conv_dma<LINEAR,5" counts every NI / wave variant of that class
+    long long total = 0; const size_t len = strlen(kernel_class);
+    const int used = g_used.load(std::memory_order_acquire);
+    for (int i = 0; i < used; ++i) if (!strncmp(g_slots[i].name, kernel_class, len)) total += g_slots[i].n.load(std::memory_order_relaxed);
+    return total;
+}
+
+extern "C" void glowtts_launch_log_reset(void)
+{
+    const int used = g_used.load(std::memory_order_acquire);
+    for (int i = 0; i < used; ++i) g_slots[i].n.store(0, std::memory_order_relaxed);
+}
+
+extern "C" int glowtts_launch_log_dump(char* buf, int buflen)
+{
+    if (!buf || buflen < 2) return GLOWTTS_E_ARG;
+    int off = 0; buf[0] = 0;
+    const int used = g_used.load(std::memory_order_acquire);
+    for (int i = 0; i < used; ++i) {
+        const long long n = g_slots[i].n.load(std::memory_order_relaxed);
+        if (!n) continue;
+        const int w = snprintf(buf + off, buflen - off, "%s %lld\n", g_slots[i].name, n);
+        if (w < 0 || w >= buflen - off) break;
+        off += w;
+    }
     return GLOWTTS_OK;
 }

@@ -29,6 +29,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "../../include/glowtts_hip.h"
+#include "launch_log.h"
 
 namespace {
 
@@ -1204,6 +1205,12 @@ __global__ __launch_bounds__(CH_WN * CH_WM * 64) void conv_chain_kernel(const gl
     }
 }
 
+inline const char* epi_name(int e)
+{
+    switch (e) { case GLOWTTS_EPI_LINEAR: return "LINEAR"; case GLOWTTS_EPI_GATE: return "GATE"; case GLOWTTS_EPI_RESSKIP: return "RESSKIP";
+                 case GLOWTTS_EPI_COUPLE: return "COUPLE"; case GLOWTTS_EPI_DGATE: return "DGATE"; default: return "?"; }
+}
+
 template <int EPI1, int EPI2>
 int launch_chain(const glowtts_conv_args& a1, const glowtts_conv_args& a2, hipStream_t s)
 {
@@ -1214,6 +1221,7 @@ int launch_chain(const glowtts_conv_args& a1, const glowtts_conv_args& a2, hipSt
             return GLOWTTS_E_LAUNCH;
         attr_done = true;
     }
+    GLOWTTS_NOTE_STATIC("conv_chain<%s,%s>", epi_name(EPI1), epi_name(EPI2));
     hipLaunchKernelGGL((conv_chain_kernel<EPI1, EPI2>), dim3((a1.rows + CH_BM - 1) / CH_BM), dim3(CH_WN * CH_WM * 64), lds, s, a1, a2);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
@@ -1305,6 +1313,7 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
         attr_done = true;
     }
     dim3 grid(((a.rows + BM - 1) / BM) * gy);
+    GLOWTTS_NOTE_STATIC("conv_dma<%s,%d>", epi_name(EPI), TAPS);
     hipLaunchKernelGGL((conv_dma_kernel<EPI, TAPS, NI>), grid, dim3((best + nload) * 64), lds, s, a, nload ? 2 : nst, nload);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
@@ -1314,6 +1323,7 @@ int launch_k(const glowtts_conv_args& a, hipStream_t s)
 {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     dim3 grid(((a.rows + BM - 1) / BM) * ((a.npad + BN - 1) / BN), 1, a.batch > 1 ? a.batch : 1);
+    GLOWTTS_NOTE_STATIC("conv_cl<%s,%d,%s%s>", epi_name(EPI), TAPS, sizeof(CT) == 2 ? "bf16" : "f32", ABF ? ",abf" : "");
     hipLaunchKernelGGL((conv_cl_kernel<CT, MI, NI, WM, WN, EPI, TAPS, APRO, ABF>), grid, dim3(WM * WN * 64), 0, s, a);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }

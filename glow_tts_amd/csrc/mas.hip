@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/glowtts_hip.h"
+#include "launch_log.h"
 
 namespace {
 
@@ -219,17 +220,21 @@ int launch_dp(const float* value, const int32_t* t_xs, const int32_t* t_ys, int3
     if (lds > 160 * 1024) return GLOWTTS_E_ARG;
     const bool al = (reinterpret_cast<uintptr_t>(value) & 15) == 0;
     void (*k)(const float*, const int32_t*, const int32_t*, int32_t*, float*, int, int, float);
+    bool vec_used;
     if (transposed) {
         const bool vec = al && (R == 2 || R == 4) && (Tx % R == 0) && (((size_t)Tx * sizeof(float)) % (R * sizeof(float)) == 0) && Tx >= R;
+        vec_used = vec;
         if (q_out) k = vec ? mas_dp_kernel<R, true, true, true> : mas_dp_kernel<R, false, true, true>;
         else       k = vec ? mas_dp_kernel<R, true, false, true> : mas_dp_kernel<R, false, false, true>;
     } else {
         const bool vec = al && (Ty % 4 == 0);
+        vec_used = vec;
         if (q_out) k = vec ? mas_dp_kernel<R, true, true, false> : mas_dp_kernel<R, false, true, false>;
         else       k = vec ? mas_dp_kernel<R, true, false, false> : mas_dp_kernel<R, false, false, false>;
     }
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    GLOWTTS_NOTE("mas_dp<R%d,%s,%s,%s>", R, vec_used ? "vec" : "scalar", q_out ? "q" : "noq", transposed ? "t" : "n");
     hipLaunchKernelGGL(k, dim3(B), dim3(64), lds, s, value, t_xs, t_ys, idx_out, q_out, Tx, Ty, neg);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }

@@ -20,6 +20,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include "../../include/glowtts_hip.h"
+#include "launch_log.h"
 
 namespace {
 
@@ -372,6 +373,8 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job singl
 template <typename CT, int XPRO, bool DYBF, bool XBF, bool WIDE = false>
 int launch_x(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const WCommon& cm, int taps, dim3 grid, hipStream_t s)
 {
+    GLOWTTS_NOTE("wgrad<%d,%s,dy%s,x%s%s%s>%s", taps, sizeof(CT) == 2 ? "bf16" : "f32", DYBF ? "bf16" : "f32", XBF ? "bf16" : "f32",
+                 XPRO == GLOWTTS_APRO_PAIRMUL ? ",pairmul" : "", WIDE ? ",wide" : "", table ? "/grouped" : "");
     switch (taps) {
         case 1: hipLaunchKernelGGL((wgrad_kernel<CT, 1, XPRO, DYBF, XBF, WIDE>), grid, dim3(NT), 0, s, one, table, cm); break;
         case 3: hipLaunchKernelGGL((wgrad_kernel<CT, 3, XPRO, DYBF, XBF, WIDE>), grid, dim3(NT), 0, s, one, table, cm); break;

@@ -26,6 +26,14 @@ int glowtts_abi_version(void);
 /* Writes the gfx arch string of device 0 into buf (host pointer).  0 on success. */
 int glowtts_device_arch(char *buf, int buflen);
 
+/* Launch log (diagnostics; no reference counterpart).  The library counts, on the host, the launches it issues per kernel class
+ * ("conv_dma<GATE,5>", "conv_chain<LINEAR,DGATE>", "conv_cl<LINEAR,1,f32>", "wgrad<5,bf16,dybf16,xbf16,wide>/grouped", ...), so a
+ * parity test can assert which kernel served a call.  glowtts_launch_count sums every class whose name starts with `kernel_class`
+ * (host string); _dump writes "name count" lines into buf (host pointer). */
+int64_t glowtts_launch_count(const char *kernel_class);
+void glowtts_launch_log_reset(void);
+int glowtts_launch_log_dump(char *buf, int buflen);
+
 /* ------------------------------------------------------------------------------------------
  * Monotonic Alignment Search.
  * Replaces monotonic_align/core.pyx:40 `maximum_path_c(paths, values, t_xs, t_ys, max_neg_val)`

@@ -42,3 +42,50 @@ def tiny_hp_dict(mode):
     hp["Speaker_Embedding"]["Type"] = "LUT"
     hp["Prosody_Encoder"]["Size"] = 16
     return hp
+
+
+def full_width_state(n_flows, g, spk_dim=0):
+    """Seeded decoder weights at the default Hyper_Parameters sizes (C=160, H=192, 4 layers, k=5); spk_dim > 0 adds the SE-mode
+    Speaker_l conditioning convs (Modules.py:832-838)."""
+    from oracle import glowtts_ref as O
+    cfg = O.Cfg(n_flows=n_flows, mode="SE" if spk_dim else "Vanilla", spk_dim=spk_dim or 256)
+    sd = {}
+    for f in range(cfg.n_flows):
+        q = f"layer_Dict.Decoder.layer_Dict.Flows.{f}.layers"
+        sd[q + ".0.logs"] = torch.randn(1, 160, 1, generator=g) * 0.1
+        sd[q + ".0.bias"] = torch.randn(1, 160, 1, generator=g) * 0.1
+        w4 = torch.linalg.qr(torch.randn(4, 4, generator=g))[0] + 0.05 * torch.randn(4, 4, generator=g)
+        if torch.det(w4) < 0:                       # the reference keeps det > 0 (Modules.py:722-723)
+            w4[:, 0] = -w4[:, 0]
+        sd[q + ".1.weight"] = w4
+        def wn(name, o, i, k):
+            sd[f"{q}.2.layer_Dict.{name}.weight_v"] = torch.randn(o, i, k, generator=g) / (i * k) ** 0.5
+            sd[f"{q}.2.layer_Dict.{name}.weight_g"] = torch.rand(o, 1, 1, generator=g) + 0.5
+            sd[f"{q}.2.layer_Dict.{name}.bias"] = torch.randn(o, generator=g) * 0.05
+        wn("Start", 192, 80, 1)
+        for l in range(4):
+            wn(f"WaveNet.layer_Dict.In_{l}", 384, 192, 5)
+            wn(f"WaveNet.layer_Dict.Res_Skip_{l}", 384 if l < 3 else 192, 192, 1)
+            if spk_dim:
+                wn(f"WaveNet.layer_Dict.Speaker_{l}", 384, spk_dim, 1)
+        sd[f"{q}.2.layer_Dict.End.weight"] = torch.randn(160, 192, 1, generator=g) * 0.02
+        sd[f"{q}.2.layer_Dict.End.bias"] = torch.randn(160, generator=g) * 0.02
+    return cfg, sd
+
+
+def launch_counts():
+    """name -> launches since the last reset (glowtts_launch_log_dump)."""
+    import ctypes
+    from glow_tts_amd import _lib
+    buf = ctypes.create_string_buffer(16384)
+    _lib.lib().glowtts_launch_log_dump(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, n = line.rsplit(" ", 1)
+        out[name] = int(n)
+    return out
+
+
+def launch_reset():
+    from glow_tts_amd import _lib
+    _lib.lib().glowtts_launch_log_reset()

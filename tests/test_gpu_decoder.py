@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import glowtts_ref as O
-from helpers import load_case, tiny_cfg
+from helpers import full_width_state, load_case, tiny_cfg
 
 pytestmark = pytest.mark.gpu
 
@@ -125,31 +125,6 @@ def test_actnorm_data_init_matches_reference():
         want_b = sd[f"layer_Dict.Decoder.layer_Dict.Flows.{f}.layers.0.bias"].reshape(-1)
         assert (W["an_logs"][f].cpu() - want_l).abs().max() < 2e-4, f
         assert (W["an_bias"][f].cpu() - want_b).abs().max() < 2e-4, f
-
-
-def full_width_state(n_flows, g):
-    """Seeded decoder weights at the default Hyper_Parameters sizes (C=160, H=192, 4 layers, k=5)."""
-    cfg = O.Cfg(n_flows=n_flows)
-    sd = {}
-    for f in range(cfg.n_flows):
-        q = f"layer_Dict.Decoder.layer_Dict.Flows.{f}.layers"
-        sd[q + ".0.logs"] = torch.randn(1, 160, 1, generator=g) * 0.1
-        sd[q + ".0.bias"] = torch.randn(1, 160, 1, generator=g) * 0.1
-        w4 = torch.linalg.qr(torch.randn(4, 4, generator=g))[0] + 0.05 * torch.randn(4, 4, generator=g)
-        if torch.det(w4) < 0:                       # the reference keeps det > 0 (Modules.py:722-723)
-            w4[:, 0] = -w4[:, 0]
-        sd[q + ".1.weight"] = w4
-        def wn(name, o, i, k):
-            sd[f"{q}.2.layer_Dict.{name}.weight_v"] = torch.randn(o, i, k, generator=g) / (i * k) ** 0.5
-            sd[f"{q}.2.layer_Dict.{name}.weight_g"] = torch.rand(o, 1, 1, generator=g) + 0.5
-            sd[f"{q}.2.layer_Dict.{name}.bias"] = torch.randn(o, generator=g) * 0.05
-        wn("Start", 192, 80, 1)
-        for l in range(4):
-            wn(f"WaveNet.layer_Dict.In_{l}", 384, 192, 5)
-            wn(f"WaveNet.layer_Dict.Res_Skip_{l}", 384 if l < 3 else 192, 192, 1)
-        sd[f"{q}.2.layer_Dict.End.weight"] = torch.randn(160, 192, 1, generator=g) * 0.02
-        sd[f"{q}.2.layer_Dict.End.bias"] = torch.randn(160, generator=g) * 0.02
-    return cfg, sd
 
 
 @pytest.mark.parametrize("precision,ztol", [(0, 2e-4), (1, 6e-2)])

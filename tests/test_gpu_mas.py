@@ -91,3 +91,113 @@ def test_wrapper_matches_reference_signature():
     assert p.dtype == v.dtype and p.device == v.device and p.shape == v.shape
     want = mas_ref.maximum_path_c((v * mask).cpu().numpy(), np.array([9, 4], np.int32), np.array([30, 22], np.int32))
     assert np.array_equal(p.cpu().numpy().astype(np.int32), want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The PRODUCTION layout: GlowTTS.forward runs the search on the transposed score matrix value_t [B, T_mel, T_tok] written by the
+# log-prior GEMM (glowtts_mas_dp_f32_t -> mas_dp_kernel<R, VEC, WRITE_Q, transposed = true>).  Same bar as above - paths AND
+# cumulative scores bit-exact against core.pyx's golden vectors (core.pyx:9-45) and the oracle - on R = 1, 2, 3, 4, 6, 8 token rows
+# per lane and on both loader variants (float2 / float4 gathers when T_tok % R == 0, scalar otherwise).
+# ---------------------------------------------------------------------------------------------------------------------------------
+def hip_mas_t(v, tx, ty, want_q=True):
+    """v [B,Tx,Ty] (numpy) -> runs glowtts_mas_dp_f32_t on its transpose; returns path [B,Tx,Ty] i32, idx, q [B,Tx,Ty]."""
+    import ctypes
+    from glow_tts_amd import _lib, alignment, monotonic_align as ma
+    from helpers import launch_counts, launch_reset
+    L = alignment._lib2()
+    B, Tx, Ty = v.shape
+    vt = torch.from_numpy(np.ascontiguousarray(v.transpose(0, 2, 1))).cuda()
+    txd, tyd = torch.from_numpy(tx).cuda(), torch.from_numpy(ty).cuda()
+    idx = torch.empty(B, Ty, dtype=torch.int32, device="cuda")
+    qt = torch.empty_like(vt) if want_q else None
+    launch_reset()
+    _lib.check(L.glowtts_mas_dp_f32_t(_lib.ptr(vt), _lib.ptr(txd), _lib.ptr(tyd), _lib.ptr(idx), _lib.ptr(qt), B, Tx, Ty, -1e9, _lib.stream()), "mas_t")
+    path = ma.path_from_idx(idx, Tx, torch.int32)
+    torch.cuda.synchronize()
+    kinds = [k for k in launch_counts() if k.startswith("mas_dp<")]
+    q = np.ascontiguousarray(qt.cpu().numpy().transpose(0, 2, 1)) if want_q else None
+    return path.cpu().numpy(), idx.cpu().numpy(), q, kinds
+
+
+@pytest.mark.parametrize("name", MAS_CASES)
+def test_transposed_golden_vectors(name, golden_dir):
+    d = np.load(f"{golden_dir}/mas_cases.npz")
+    v, tx, ty = d[f"{name}/value"], d[f"{name}/t_x"], d[f"{name}/t_y"]
+    path, idx, q, kinds = hip_mas_t(v, tx, ty)
+    assert np.array_equal(path, d[f"{name}/path"].astype(np.int32))
+    assert np.bitwise_xor.reduce(q.view(np.uint32).ravel()) == d[f"{name}/q_xor"]
+    _, q_ref = mas_ref.maximum_path_c(v, tx, ty, return_q=True)
+    assert np.array_equal(q.view(np.uint32), q_ref.view(np.uint32))
+    assert kinds and all(k.endswith(",t>") for k in kinds), kinds
+
+
+# (Tx, Ty, B, kernel variant expected): R = ceil(Tx / 64) rounded to an instantiated value; vector loads iff R in {2, 4} and Tx % R == 0
+T_SHAPES = [(1, 9, 3, "R1,scalar"), (63, 200, 3, "R1,scalar"), (64, 300, 3, "R1,scalar"), (65, 301, 3, "R2,scalar"),
+            (120, 800, 8, "R2,vec"), (128, 640, 4, "R2,vec"), (129, 403, 3, "R3,scalar"), (192, 500, 3, "R3,scalar"),
+            (200, 1000, 4, "R4,vec"), (254, 700, 2, "R4,scalar"), (256, 1024, 2, "R4,vec"), (257, 999, 2, "R6,scalar"),
+            (384, 901, 2, "R6,scalar"), (400, 1201, 2, "R8,scalar"), (512, 1024, 2, "R8,scalar")]
+
+
+@pytest.mark.parametrize("Tx,Ty,B,variant", T_SHAPES)
+def test_transposed_random_vs_oracle(Tx, Ty, B, variant):
+    rng = np.random.default_rng(Tx * 1000 + Ty + 7)
+    v = rng.normal(-100, 30, (B, Tx, Ty)).astype(np.float32)
+    tx = rng.integers(1, Tx + 1, B).astype(np.int32)
+    ty = np.array([rng.integers(t, Ty + 1) for t in tx], dtype=np.int32)
+    tx[0], ty[0] = Tx, Ty
+    if B > 2:
+        tx[1], ty[1] = min(Tx, Ty), min(Tx, Ty)                   # t_x == t_y: the diagonal-only path
+    mask = (np.arange(Tx)[None, :, None] < tx[:, None, None]) & (np.arange(Ty)[None, None, :] < ty[:, None, None])
+    v = (v * mask).astype(np.float32)
+    want, q_ref = mas_ref.maximum_path_c(v, tx, ty, return_q=True)
+    path, idx, q, kinds = hip_mas_t(v, tx, ty)
+    assert kinds == [f"mas_dp<{variant},q,t>"], kinds
+    assert np.array_equal(path, want)
+    assert np.array_equal(q.view(np.uint32), q_ref.view(np.uint32))
+    for b in range(B):
+        assert (idx[b, ty[b]:] == -1).all() and (idx[b, :ty[b]] == want[b, :, :ty[b]].argmax(0)).all()
+    # and without q_out_t (the instantiation the training step uses)
+    path2, _, _, kinds2 = hip_mas_t(v, tx, ty, want_q=False)
+    assert kinds2 == [f"mas_dp<{variant},noq,t>"], kinds2
+    assert np.array_equal(path2, want)
+
+
+def test_transposed_ties_sentinel_scale_and_full_size():
+    rng = np.random.default_rng(6)
+    B, Tx, Ty = 6, 50, 170
+    v = (np.round(rng.normal(-3, 2, (B, Tx, Ty))) * 1e6).astype(np.float32)     # exact ties, |scores| beyond the Python twin's -1e7 sentinel
+    tx = np.full(B, Tx, np.int32); ty = np.full(B, Ty, np.int32)
+    want, q_ref = mas_ref.maximum_path_c(v, tx, ty, return_q=True)
+    path, _, q, _ = hip_mas_t(v, tx, ty)
+    assert np.array_equal(path, want) and np.array_equal(q.view(np.uint32), q_ref.view(np.uint32))
+    # BASELINE size, ragged (Set V of SURVEY 8d): B = 32, 120 x 800 and the reference's maximum 200 x 1000
+    for (B, Tx, Ty) in [(32, 120, 800), (32, 200, 1000)]:
+        v = rng.normal(-100, 30, (B, Tx, Ty)).astype(np.float32)
+        ty = (2 * rng.integers(Ty * 3 // 8, Ty // 2 + 1, B)).astype(np.int32); ty[0] = Ty
+        tx = np.maximum(1, np.round(Tx / Ty * ty)).astype(np.int32)
+        mask = (np.arange(Tx)[None, :, None] < tx[:, None, None]) & (np.arange(Ty)[None, None, :] < ty[:, None, None])
+        v = (v * mask).astype(np.float32)
+        want, q_ref = mas_ref.maximum_path_c(v, tx, ty, return_q=True)
+        path, idx, q, _ = hip_mas_t(v, tx, ty)
+        assert np.array_equal(path, want) and np.array_equal(q.view(np.uint32), q_ref.view(np.uint32))
+
+
+def test_strict_twin_of_maximum_path_c():
+    """glowtts_mas_f32: the direct replacement of core.pyx:40 maximum_path_c (value, pre-zeroed int32 path, t_xs, t_ys)."""
+    import ctypes
+    from glow_tts_amd import _lib
+    d_rng = np.random.default_rng(21)
+    for (B, Tx, Ty) in [(3, 37, 96), (4, 120, 801), (2, 200, 1000)]:
+        v = d_rng.normal(-100, 30, (B, Tx, Ty)).astype(np.float32)
+        tx = d_rng.integers(1, Tx + 1, B).astype(np.int32)
+        ty = np.array([d_rng.integers(t, Ty + 1) for t in tx], dtype=np.int32)
+        tx[0], ty[0] = Tx, Ty
+        mask = (np.arange(Tx)[None, :, None] < tx[:, None, None]) & (np.arange(Ty)[None, None, :] < ty[:, None, None])
+        v = (v * mask).astype(np.float32)
+        vd = torch.from_numpy(v).cuda()
+        path = torch.zeros(B, Tx, Ty, dtype=torch.int32, device="cuda")
+        scratch = torch.empty(B, Ty, dtype=torch.int32, device="cuda")
+        _lib.check(_lib.lib().glowtts_mas_f32(_lib.ptr(vd), _lib.ptr(path), _lib.ptr(torch.from_numpy(tx).cuda()), _lib.ptr(torch.from_numpy(ty).cuda()),
+                                              _lib.ptr(scratch), B, Tx, Ty, -1e9, _lib.stream()), "glowtts_mas_f32")
+        torch.cuda.synchronize()
+        assert np.array_equal(path.cpu().numpy(), mas_ref.maximum_path_c(v, tx, ty))
