@@ -104,8 +104,13 @@ def test_full_width_backward_bf16_takes_the_benchmarked_kernels(spk_dim):
     assert _count(counts, "wgrad<1,bf16,dyf32,xf32,wide>/grouped") == 1, counts          # Start / End
     assert _count(counts, "conv_cl<GATE") == 0 and _count(counts, "conv_cl<RESSKIP") == 0 and _count(counts, "conv_cl<DGATE") == 0, counts
     mask = O.mask_from_lengths(case[3], TM)
-    assert ((z - zo) * mask).abs().max() <= 6e-2
-    assert ((ld - ldo).abs() <= 2e-3 * ldo.abs().clamp_min(1.0)).all()
+    rms = lambda t: t.double().pow(2).mean().sqrt().item()
+    print("bf16 z: max abs error", ((z - zo) * mask).abs().max().item(), "relative rms", rms((z - zo) * mask) / rms(zo * mask))
+    assert ((z - zo) * mask).abs().max() <= 0.1 and rms((z - zo) * mask) <= 1e-2 * rms(zo * mask)
+    # log-determinant: a sum of len/2 * 80 coupling log-scales computed from bf16 operands -> relative part + random-walk part
+    n_el = (case[3] // 2 * 80).float()
+    print("bf16 log-determinants", ld.tolist(), "oracle", ldo.tolist())
+    assert ((ld - ldo).abs() <= 2e-3 * ldo.abs() + 2e-3 * n_el.sqrt()).all()
     report = []
     for k, want in go.items():
         a, b = g[k].flatten().double(), want.flatten().double()

@@ -109,7 +109,7 @@ def hip_mas_t(v, tx, ty, want_q=True):
     vt = torch.from_numpy(np.ascontiguousarray(v.transpose(0, 2, 1))).cuda()
     txd, tyd = torch.from_numpy(tx).cuda(), torch.from_numpy(ty).cuda()
     idx = torch.empty(B, Ty, dtype=torch.int32, device="cuda")
-    qt = torch.empty_like(vt) if want_q else None
+    qt = vt.clone() if want_q else None          # cells outside the band keep their input value, as core.pyx leaves `values`
     launch_reset()
     _lib.check(L.glowtts_mas_dp_f32_t(_lib.ptr(vt), _lib.ptr(txd), _lib.ptr(tyd), _lib.ptr(idx), _lib.ptr(qt), B, Tx, Ty, -1e9, _lib.stream()), "mas_t")
     path = ma.path_from_idx(idx, Tx, torch.int32)
@@ -197,7 +197,8 @@ def test_strict_twin_of_maximum_path_c():
         vd = torch.from_numpy(v).cuda()
         path = torch.zeros(B, Tx, Ty, dtype=torch.int32, device="cuda")
         scratch = torch.empty(B, Ty, dtype=torch.int32, device="cuda")
-        _lib.check(_lib.lib().glowtts_mas_f32(_lib.ptr(vd), _lib.ptr(path), _lib.ptr(torch.from_numpy(tx).cuda()), _lib.ptr(torch.from_numpy(ty).cuda()),
+        txd, tyd = torch.from_numpy(tx).cuda(), torch.from_numpy(ty).cuda()
+        _lib.check(_lib.lib().glowtts_mas_f32(_lib.ptr(vd), _lib.ptr(path), _lib.ptr(txd), _lib.ptr(tyd),
                                               _lib.ptr(scratch), B, Tx, Ty, -1e9, _lib.stream()), "glowtts_mas_f32")
         torch.cuda.synchronize()
         assert np.array_equal(path.cpu().numpy(), mas_ref.maximum_path_c(v, tx, ty))
