@@ -66,3 +66,78 @@ def stream():
     if _raw_stream is not None:
         return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Pinned host staging for small tables that the device reads (weight-gradient / optimizer job tables, hyper-parameter words).
+#
+# (1) Under hipGraph capture a host-to-device copy becomes a memcpy NODE that re-reads its pinned source at every replay, and the
+#     tables hold pointers into that graph's private buffers: every capture therefore needs a pinned buffer of its OWN (a buffer shared
+#     between captures would make an earlier graph replay with a later graph's pointers).  Pinned memory cannot be allocated while a
+#     stream is capturing, so the eager steps that precede every capture keep a few spare buffers per size (`staged_upload` in eager
+#     mode), and a capture takes ownership of one of them for good.
+# (2) Eager copies from a pinned buffer that the host rewrites every step go through a ring with one event per slot (`PinnedRing`),
+#     so that the host running ahead of the stream never overwrites words an in-flight copy has not read yet.
+# --------------------------------------------------------------------------------------------------------------------
+_SPARE = {}            # nbytes -> [pinned uint8 tensors not owned by any captured graph]
+_SPARE_CAP = 4         # same-size tables per step (e.g. the optimizer's and the gradient-norm table of one parameter list)
+_OWNED = []            # buffers handed to captures when no sink is active (live as long as the process)
+_SINKS = []
+
+
+class pinned_sink:
+    """`with pinned_sink(lst):` - pinned buffers taken by captures inside the block are appended to `lst` (keep it alive with the graph)."""
+
+    def __init__(self, keep):
+        self.keep = keep
+
+    def __enter__(self):
+        _SINKS.append(self.keep)
+        return self.keep
+
+    def __exit__(self, *exc):
+        _SINKS.pop()
+        return False
+
+
+def staged_upload(raw, device):
+    """bytes -> device uint8 tensor.  Eager: synchronous copy from a private buffer (the host may run ahead of the stream) and one more
+    spare pinned buffer of this size is put aside; capturing: the copy node reads a pinned buffer that from now on belongs to the graph."""
+    n = len(raw)
+    src = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    if torch.cuda.is_current_stream_capturing():
+        pool = _SPARE.get(n)
+        if not pool:
+            raise GlowTTSHipError("run at least one eager step of this shape before capturing a hipGraph (no spare pinned job table of "
+                                  f"{n} bytes; pinned memory cannot be allocated during capture)")
+        pinned = pool.pop()
+        pinned.copy_(src)
+        (_SINKS[-1] if _SINKS else _OWNED).append(pinned)
+        return pinned.to(device, non_blocking=True)
+    pool = _SPARE.setdefault(n, [])
+    if len(pool) < _SPARE_CAP:
+        pool.append(torch.empty(n, dtype=torch.uint8).pin_memory())
+    return src.to(device)
+
+
+class PinnedRing:
+    """`slots` pinned buffers of `numel` elements reused round-robin; a slot is rewritten only after the copy that last read it has
+    completed (one event per slot, which in steady state has long fired)."""
+
+    def __init__(self, numel, dtype=torch.float32, slots=8):
+        self.bufs = [torch.empty(numel, dtype=dtype).pin_memory() for _ in range(slots)]
+        self.events = [None] * slots
+        self.i = 0
+
+    def push(self, values, dst):
+        """dst.copy_(values) through the next slot, asynchronously on the current stream; `values`: a CPU tensor of the slot's shape."""
+        i = self.i
+        self.i = (i + 1) % len(self.bufs)
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        self.bufs[i].copy_(values)
+        dst.copy_(self.bufs[i], non_blocking=True)
+        if self.events[i] is None:
+            self.events[i] = torch.cuda.Event()
+        self.events[i].record()
+        return dst

@@ -93,7 +93,6 @@ class WgradJob(ctypes.Structure):
                 ("tile0", c_int), ("mt", c_int), ("nt", c_int), ("reserved", c_i64)]
 
 
-_PINNED = {}
 _WSTREAM = {}
 
 
@@ -157,21 +156,8 @@ class WgradGroup:
     def upload(self, device):
         if not self.jobs:
             return
-        arr = (WgradJob * len(self.jobs))(*self.jobs)
-        raw = bytes(arr)
-        key = (self.tag, self.taps, self.xpro, self.io_flags, len(raw), str(device))
-        pinned = _PINNED.get(key)
-        if pinned is None:
-            if torch.cuda.is_current_stream_capturing():
-                raise _lib.GlowTTSHipError("run at least one eager step before capturing a hipGraph (pinned job table not allocated yet)")
-            pinned = _PINNED[key] = torch.empty(len(raw), dtype=torch.uint8).pin_memory()
-        if torch.cuda.is_current_stream_capturing():
-            # the captured copy node re-reads `pinned` at every replay; its content (pointers into graph-private buffers) is static
-            pinned.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
-            self.table = pinned.to(device, non_blocking=True)
-        else:
-            # eager: the host may run ahead of the stream, so the job table is copied synchronously from a private buffer
-            self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        # (a captured step gets a pinned table of its own: _lib.staged_upload)
+        self.table = _lib.staged_upload(bytes((WgradJob * len(self.jobs))(*self.jobs)), device)
 
     @staticmethod
     def upload_all(groups, device):
@@ -180,18 +166,7 @@ class WgradGroup:
         if not groups:
             return
         raws = [bytes((WgradJob * len(g.jobs))(*g.jobs)) for g in groups]
-        raw = b"".join(raws)
-        key = ("all",) + tuple((g.tag, g.taps, g.xpro, g.io_flags) for g in groups) + (len(raw), str(device))
-        pinned = _PINNED.get(key)
-        if pinned is None:
-            if torch.cuda.is_current_stream_capturing():
-                raise _lib.GlowTTSHipError("run at least one eager step before capturing a hipGraph (pinned job table not allocated yet)")
-            pinned = _PINNED[key] = torch.empty(len(raw), dtype=torch.uint8).pin_memory()
-        if torch.cuda.is_current_stream_capturing():
-            pinned.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
-            table = pinned.to(device, non_blocking=True)
-        else:
-            table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        table = _lib.staged_upload(b"".join(raws), device)
         off = 0
         for g, r in zip(groups, raws):
             g.table = table[off:off + len(r)]

@@ -17,19 +17,24 @@ an old graph is alive, and a captured backward that has to hop to that stream cr
 """
 import torch
 
+from . import _lib
+
 
 class GraphedTrainStep:
     def __init__(self, model, loss_fn, warmup=3, optimizer=None, scheduler=None, max_grad_norm=None):
         """loss_fn(model, *inputs) -> scalar loss tensor (forward + losses).  warmup >= 2: eager steps before the capture (the first
         one also runs the ActNorm data-dependent init and builds the flat parameter storage).
         optimizer (glow_tts_amd.optim.RAdam) / scheduler / max_grad_norm: the rest of `Train.py:218-233` - clip_grad_norm_, optimizer.step(),
-        scheduler.step() - joins the graph: the clip coefficient stays on the device, the step's hyper-parameters are refreshed from the host
-        before every replay (`RAdam.advance_host`).  NOTE: the warm-up steps are real optimizer steps."""
+        scheduler.step() - joins the graph: the clip coefficient stays on the device, the step's hyper-parameters are sent from the host
+        before every replay (`RAdam.advance_host`).  NOTE: the warm-up steps of every new input shape are REAL optimizer / scheduler steps
+        on the triggering batch; `steps_taken` counts every optimizer step actually applied (warm-up + replays), so a trainer that keeps
+        its own step counter (Train.py:234 `self.steps += 1`) can stay in sync with the optimizer: `trainer.steps = step.steps_taken`."""
         self.model, self.loss_fn, self.warmup = model, loss_fn, max(2, int(warmup))
         self.optimizer, self.scheduler, self.max_grad_norm = optimizer, scheduler, max_grad_norm
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.stream = torch.cuda.Stream()
         self.graphs = {}
+        self.steps_taken = 0
 
     def _fwd_bwd(self, inputs):
         loss = self.loss_fn(self.model, *inputs)
@@ -52,32 +57,38 @@ class GraphedTrainStep:
         with torch.cuda.stream(self.stream):
             for _ in range(self.warmup):
                 self._fwd_bwd(static_in)
+                if self.optimizer is not None:
+                    self.steps_taken += 1
                 if self.scheduler is not None:
                     self.scheduler.step()
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            loss = self._fwd_bwd(static_in)                # (with an optimizer: this capture pass advanced the step counters once; the
+        keep = []                                          # pinned job tables this graph's copy nodes read: owned by the graph's entry
+        with _lib.pinned_sink(keep):
+            with torch.cuda.graph(g):
+                loss = self._fwd_bwd(static_in)            # (with an optimizer: this capture pass advanced the step counters once; the
         grads = [p.grad for p in self.params]              #  captured kernels only run at the replays)
         if self.optimizer is not None:
-            for st in self.optimizer.state.values():
-                if "step" in st:
+            for p in self.params:                          # exactly the parameters step() counted: those that have a gradient
+                st = self.optimizer.state.get(p)
+                if p.grad is not None and st is not None and "step" in st:
                     st["step"] -= 1
-        return g, static_in, loss, grads
+        return g, static_in, loss, grads, keep
 
     def __call__(self, *inputs):
         key = tuple((tuple(t.shape), t.dtype) if torch.is_tensor(t) else t for t in inputs)
         if key not in self.graphs:
             self.graphs[key] = self._capture(inputs)
-        g, static_in, loss, grads = self.graphs[key]
+        g, static_in, loss, grads, _ = self.graphs[key]
         for s, t in zip(static_in, inputs):
             if torch.is_tensor(t) and s.data_ptr() != t.data_ptr():
                 s.copy_(t, non_blocking=True)
         for p, gr in zip(self.params, grads):              # several cached shapes: point .grad at this graph's buffers
             p.grad = gr
         if self.optimizer is not None:
-            self.optimizer.advance_host()
+            self.optimizer.advance_host()                  # stream-ordered, before the replay on the same stream
+            self.steps_taken += 1
         g.replay()
         if self.scheduler is not None:
             self.scheduler.step()

@@ -39,14 +39,16 @@ def _L():
 
 class _JobTable:
     """Device table of coalesced jobs for a list of (p, g, m, v) tensor tuples (m / v may be None: gradient-only tables).
-    Rebuilt only when an address changes; under hipGraph capture the upload is a captured copy from pinned memory."""
+    Rebuilt only when an address changes - and always under hipGraph capture, where the upload becomes a copy node reading a pinned
+    table owned by that graph (_lib.staged_upload): tables are never shared between captured graphs."""
 
     def __init__(self):
-        self.sig, self.table, self.njobs, self.blocks, self.pinned = None, None, 0, 0, None
+        self.sig, self.table, self.njobs, self.blocks = None, None, 0, 0
 
     def update(self, items, device):
         sig = tuple((p.data_ptr(), g.data_ptr(), m.data_ptr() if m is not None else 0, p.numel()) for p, g, m, v in items)
-        if sig == self.sig:
+        capturing = torch.cuda.is_current_stream_capturing()
+        if sig == self.sig and not capturing:
             return
         chunk = _L().glowtts_opt_chunk()
         order = sorted(range(len(items)), key=lambda i: sig[i][0])
@@ -64,17 +66,8 @@ class _JobTable:
         for k, (pp, gp, mp, vp, n) in enumerate(jobs):
             arr[k].p, arr[k].g, arr[k].m, arr[k].v, arr[k].n, arr[k].block0 = pp, gp, mp or None, vp or None, n, b0
             b0 += (n + chunk - 1) // chunk
-        raw = bytes(arr)
-        if torch.cuda.is_current_stream_capturing():
-            if self.pinned is None or self.pinned.numel() != len(raw):
-                raise _lib.GlowTTSHipError("run one eager optimizer step before capturing a hipGraph (job table not allocated yet)")
-            self.pinned.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
-            self.table = self.pinned.to(device, non_blocking=True)
-        else:
-            if self.pinned is None or self.pinned.numel() != len(raw):
-                self.pinned = torch.empty(len(raw), dtype=torch.uint8).pin_memory()
-            self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
-        self.sig, self.njobs, self.blocks = sig, len(jobs), b0
+        self.table = _lib.staged_upload(bytes(arr), device)      # (a captured step gets a pinned table of its own)
+        self.sig, self.njobs, self.blocks = (None if capturing else sig), len(jobs), b0
 
 
 _CLIP_TABLES = {}
@@ -138,17 +131,24 @@ class RAdam(torch.optim.Optimizer):
             i = j
 
     def _write_hyper(self, key, group, step, dev):
+        """The step's hyper-parameter words -> the device buffer the update kernel reads.  Stream-ordered copy through a ring of pinned
+        slots (the host may run steps ahead of the stream); never part of a captured graph (see advance_host)."""
         beta1, beta2 = group["betas"]
         n_sma, size = radam_scalars(step, beta1, beta2)
         hp = self._hyper.get(key)
         if hp is None:
-            hp = self._hyper[key] = (torch.empty(8, dtype=torch.float32).pin_memory(), torch.empty(8, device=dev))
-        hp[0].copy_(torch.tensor([group["lr"], beta1, beta2, group["eps"], group["weight_decay"], size, 1.0 if n_sma >= 5 else 0.0, 0.0]))
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.GlowTTSHipError("run one eager optimizer step before capturing a hipGraph (hyper-parameter buffer not allocated yet)")
+            hp = self._hyper[key] = (_lib.PinnedRing(8), torch.empty(8, device=dev))
+        words = torch.tensor([group["lr"], beta1, beta2, group["eps"], group["weight_decay"], size, 1.0 if n_sma >= 5 else 0.0, 0.0])
+        hp[0].push(words, hp[1])
         return hp
 
     def advance_host(self):
-        """Host half of a step, for replaying a captured hipGraph that contains `step()`: advance every step counter and refresh the
-        pinned hyper-parameter words (learning rate of the scheduler, step size, rectification flag) that the graph's copy node reads."""
+        """Host half of a step, for replaying a captured hipGraph that contains `step()`: advance every step counter and send this step's
+        hyper-parameter words (learning rate of the scheduler, step size, rectification flag) to the device buffer the captured update
+        kernel reads - a stream-ordered copy issued BEFORE the replay on the replay's stream, not a node of the graph, so a host that
+        runs ahead can neither skip nor repeat a step's values.  Call it on the stream the graph is replayed on."""
         for gi, group in enumerate(self.param_groups):
             by_step = {}
             for p in group["params"]:
@@ -185,8 +185,8 @@ class RAdam(torch.optim.Optimizer):
                 tab = self._tables.setdefault(key, _JobTable())
                 dev = ps[0].device
                 tab.update([(p, p.grad, self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]) for p in ps], dev)
-                hp = self._write_hyper(key, group, step, dev)
-                hp[1].copy_(hp[0], non_blocking=True)
+                # captured: the words arrive by advance_host() before every replay; eager: sent now
+                hp = self._hyper[key] if (torch.cuda.is_current_stream_capturing() and key in self._hyper) else self._write_hyper(key, group, step, dev)
                 _lib.check(L.glowtts_radam_step(tab.table.data_ptr(), tab.njobs, tab.blocks, hp[1].data_ptr(),
                                                 grad_scale.data_ptr() if grad_scale is not None else None, _lib.stream()), "glowtts_radam_step")
         return loss
