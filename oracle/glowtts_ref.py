@@ -50,6 +50,11 @@ class Cfg:
     n_speakers: int = 109            # Speaker_Embedding.Num_Speakers (:56)
     spk_dim: int = 256               # Speaker_Embedding.Embedding_Size (:57)
     pro_dim: int = 256               # Prosody_Encoder.Size         (:70)
+    pe_strides: tuple = (2, 2, 2, 2, 2, 2)      # Prosody_Encoder.Reference_Encoder.Conv.Strides (:75)
+    pe_kernels: tuple = (3, 3, 3, 3, 3, 3)      # ...Conv.Kernel_Size        (:73)
+    pe_heads: int = 4                # Prosody_Encoder.Style_Token.Attention_Head (:82)
+    grl_weight: float = 0.0005       # Train.Adversarial_Speaker_Weight (:112)
+    gr_hidden: int = 1               # len(Speaker_Classifier_GR.Channels) (:84-85)
 
     @staticmethod
     def from_yaml_dict(d):
@@ -68,6 +73,10 @@ class Cfg:
             wn_kernel=dec["Affine_Coupling"]["WaveNet"]["Kernel_Size"],
             spk_type=d["Speaker_Embedding"]["Type"], n_speakers=d["Speaker_Embedding"]["Num_Speakers"],
             spk_dim=d["Speaker_Embedding"]["Embedding_Size"], pro_dim=d["Prosody_Encoder"]["Size"],
+            pe_strides=tuple(d["Prosody_Encoder"]["Reference_Encoder"]["Conv"]["Strides"]),
+            pe_kernels=tuple(d["Prosody_Encoder"]["Reference_Encoder"]["Conv"]["Kernel_Size"]),
+            pe_heads=d["Prosody_Encoder"]["Style_Token"]["Attention_Head"],
+            grl_weight=float(d["Train"]["Adversarial_Speaker_Weight"]), gr_hidden=len(d["Speaker_Classifier_GR"]["Channels"]),
         )
 
 
@@ -186,6 +195,72 @@ def encoder(sd, tokens, mask, cfg, speakers=None, prosodies=None, p="layer_Dict.
             cond = cond + prosodies.detach()
     log_dur = duration_predictor(sd, p + ".layer_Dict.Duration_Predictor", x.detach(), mask, cond, cfg)
     return mean, log_std, log_dur
+
+
+# --------------------------------------------------------------------------- conditioning encoders (PE / GR modes)
+def prosody_encoder(sd, mels, lengths, cfg, p="layer_Dict.Prosody_Encoder"):
+    """Modules.py:312-385 (GST): 6 x [Conv2d(stride 2, no bias) + ReLU] over (mel, time) -> GRU over the compressed time axis -> the
+    state at the last valid compressed step of each utterance (:373-374) -> multi-head attention (RPR_MHA.py:69-128 without relative
+    positions or masks) over tanh(gst_Tokens) -> [B, Prosody_Encoder.Size]."""
+    x = mels.unsqueeze(1)                                                        # [B, 1, Mel_d, T]
+    for i, (k, st) in enumerate(zip(cfg.pe_kernels, cfg.pe_strides)):
+        x = torch.relu(F.conv2d(x, sd[f"{p}.layer_Dict.Conv_{i}.Conv.weight"], None, stride=st, padding=(k - 1) // 2))
+    x = x.reshape(x.size(0), x.size(1) * x.size(2), x.size(3)).transpose(2, 1)   # [B, T', C*H']
+    g = f"{p}.layer_Dict.GRU"
+    w_ih, w_hh, b_ih, b_hh = sd[g + ".weight_ih_l0"], sd[g + ".weight_hh_l0"], sd[g + ".bias_ih_l0"], sd[g + ".bias_hh_l0"]
+    Hs = w_hh.shape[1]
+    h = x.new_zeros(x.size(0), Hs)
+    hs = []
+    for t in range(x.size(1)):                                                   # torch.nn.GRU, one layer, batch_first (gate order r, z, n)
+        gi, gh = x[:, t] @ w_ih.t() + b_ih, h @ w_hh.t() + b_hh
+        r = torch.sigmoid(gi[:, :Hs] + gh[:, :Hs])
+        zg = torch.sigmoid(gi[:, Hs:2 * Hs] + gh[:, Hs:2 * Hs])
+        n = torch.tanh(gi[:, 2 * Hs:] + r * gh[:, 2 * Hs:])
+        h = (1 - zg) * n + zg * h
+        hs.append(h)
+    hs = torch.stack(hs, 1)                                                      # [B, T', Hs]
+    idx = torch.ceil(lengths / float(np.prod(cfg.pe_strides, dtype=float))).to(lengths.dtype) - 1     # :373
+    q = hs[torch.arange(hs.size(0)), idx].unsqueeze(2)                           # [B, Hs, 1]
+    keys = torch.tanh(sd[p + ".gst_Tokens"]).unsqueeze(0).expand(q.size(0), -1, -1)
+    a = p + ".layer_Dict.Attention.layer_Dict"
+    Q, K, V = conv(sd, a + ".Query", q), conv(sd, a + ".Key", keys), conv(sd, a + ".Value", keys)
+    B, Cc, _ = Q.shape
+    Hh = cfg.pe_heads
+    D = Cc // Hh
+    Q, K, V = (t.view(B, Hh, D, -1).transpose(2, 3) for t in (Q, K, V))
+    o = torch.softmax(Q @ K.transpose(3, 2) / math.sqrt(D), dim=-1) @ V          # RPR_MHA.py:103,118,121
+    o = o.transpose(3, 2).contiguous().view(B, Cc, 1)
+    return conv(sd, a + ".Projection", o).squeeze(2)
+
+
+class _GRL(torch.autograd.Function):
+    """Gradient_Reversal_Layer.py:6-20: identity forward, -weight * grad backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.weight = weight
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return -ctx.weight * g, None
+
+
+def speaker_classifier_gr(sd, prosodies, cfg, p="layer_Dict.Speaker_Classifier_GR.layer"):
+    """Modules.py:407-435: GRL -> [Conv1x1 + ReLU] x len(Channels) -> Conv1x1 to Num_Speakers, on [B, Size, 1]."""
+    x = _GRL.apply(prosodies, cfg.grl_weight).unsqueeze(2)
+    for i in range(cfg.gr_hidden):
+        x = torch.relu(conv(sd, f"{p}.Hidden_{i}", x))
+    return conv(sd, f"{p}.Output_{cfg.gr_hidden - 1}", x).squeeze(2)             # (the reference names it after the LAST hidden index, :426)
+
+
+def pitch_interpolate(pitches, base_lengths, new_lengths):
+    """Modules.py:387-405: per-utterance linear interpolation (align_corners) of the first base_length values to new_length,
+    zero-padded to the longest."""
+    out = [F.interpolate(pt[:int(bl)].view(1, 1, -1), size=int(nl), mode="linear", align_corners=True).view(-1)
+           for pt, bl, nl in zip(pitches, base_lengths, new_lengths)]
+    T = int(max(int(n) for n in new_lengths))
+    return torch.stack([F.pad(o, [0, T - o.numel()]) for o in out])
 
 
 # --------------------------------------------------------------------------- flow decoder
@@ -320,15 +395,25 @@ def mas(value, mask, max_neg_val=-1e9):
     return torch.from_numpy(path).to(dtype=value.dtype)
 
 
-def forward_train(sd, cfg, tokens, token_lengths, mels, mel_lengths, speakers=None, prosodies=None):
-    """Modules.py:50-126 GlowTTS.forward (Vanilla / SE-LUT / pre-computed speaker or prosody vectors).
-    `speakers`: int64 ids (LUT) or float [B,256] vectors (GE2E d-vectors are an input)."""
+def forward_train(sd, cfg, tokens, token_lengths, mels, mel_lengths, speakers=None, prosodies=None, pitches=None):
+    """Modules.py:50-126 GlowTTS.forward, every Mode: Vanilla / SE (LUT ids or pre-computed d-vectors) / PE (GST prosody encoder on the
+    target mels, :81-82) / GR (LUT + prosody encoder + adversarial speaker classifier :84-87 + per-frame pitch conditioning :89-90, 300-301).
+    `speakers`: int64 ids (LUT) or float [B,256] vectors (GE2E d-vectors are an input); `prosodies`: pre-computed vectors
+    override the prosody encoder."""
+    mode = cfg.mode.upper()
     if speakers is not None and speakers.dtype == torch.long:
         speakers = F.embedding(speakers, sd["layer_Dict.LUT.weight"])           # :73-74
+    elif speakers is not None:
+        speakers = speakers.detach()                                             # :77 (GE2E output is detached)
+    if prosodies is None and mode in ("PE", "GR"):
+        prosodies = prosody_encoder(sd, mels, mel_lengths, cfg)                  # :81-82
+    classified = speaker_classifier_gr(sd, prosodies, cfg) if mode == "GR" else None     # :84-87
+    if mode != "GR":
+        pitches = None                                                           # :89-90
     tmask = mask_from_lengths(token_lengths, tokens.shape[1])
     mmask = mask_from_lengths(mel_lengths, mels.shape[2])
     mean, log_std, log_dur = encoder(sd, tokens, tmask, cfg, speakers, prosodies)
-    z, log_dets, mmask2 = decoder(sd, mels, mmask, cfg, False, speakers, prosodies)
+    z, log_dets, mmask2 = decoder(sd, mels, mmask, cfg, False, speakers, prosodies, pitches)
     amask = (tmask.unsqueeze(-1) * mmask2.unsqueeze(2)).squeeze(1)               # :102-103
     with torch.no_grad():
         logp = log_prior(mean, log_std, z)
@@ -337,7 +422,8 @@ def forward_train(sd, cfg, tokens, token_lengths, mels, mel_lengths, speakers=No
     mel_log_std = log_std @ attn                                                 # :121
     log_dur_t = torch.log(attn.unsqueeze(1).sum(-1) + 1e-7) * tmask              # :122
     return dict(z=z, mel_mean=mel_mean, mel_log_std=mel_log_std, log_dets=log_dets, log_dur=log_dur,
-                log_dur_target=log_dur_t, attn=attn, mean=mean, log_std=log_std, logp=logp)
+                log_dur_target=log_dur_t, attn=attn, mean=mean, log_std=log_std, logp=logp, classified=classified,
+                prosodies=prosodies)
 
 
 def mle_loss(z, mean, log_std, log_dets, mel_lengths, cfg):
@@ -347,10 +433,13 @@ def mle_loss(z, mean, log_std, log_dets, mel_lengths, cfg):
     return loss + 0.5 * LOG_2PI
 
 
-def train_losses(out, mel_lengths, cfg):
-    """Train.py:203-211: MLE + MSE(log_durations, targets) (mean over the padded [B,1,Tt])."""
+def train_losses(out, mel_lengths, cfg, speakers=None):
+    """Train.py:203-216: MLE + MSE(log_durations, targets) (mean over the padded [B,1,Tt]); GR mode with `speakers` ids: also the
+    adversarial speaker cross-entropy (returned as a third value)."""
     mle = mle_loss(out["z"], out["mel_mean"], out["mel_log_std"], out["log_dets"], mel_lengths, cfg)
     length = F.mse_loss(out["log_dur"], out["log_dur_target"])
+    if speakers is not None and out.get("classified") is not None:
+        return mle, length, F.cross_entropy(out["classified"], speakers)
     return mle, length
 
 
@@ -365,11 +454,14 @@ def path_from_durations(durations, amask):
 
 
 def inference(sd, cfg, tokens, token_lengths, noise, length_scale, noise_scale=1.0,
-              speakers=None, prosodies=None):
+              speakers=None, prosodies=None, mels_for_prosody=None, mel_lengths_for_prosody=None, pitches=None, pitch_lengths=None):
     """Modules.py:128-204 GlowTTS.inference with the noise tensor *injected*
     (the reference draws torch.randn_like at :187).  `noise` must be [B, mel, >=max T_mel]."""
+    mode = cfg.mode.upper()
     if speakers is not None and speakers.dtype == torch.long:
         speakers = F.embedding(speakers, sd["layer_Dict.LUT.weight"])
+    if prosodies is None and mode in ("PE", "GR"):
+        prosodies = prosody_encoder(sd, mels_for_prosody, mel_lengths_for_prosody, cfg)      # :159-160
     tmask = mask_from_lengths(token_lengths, tokens.shape[1])
     mean, log_std, log_dur = encoder(sd, tokens, tmask, cfg, speakers, prosodies)
     ls = length_scale.view(-1, 1, 1)
@@ -382,6 +474,7 @@ def inference(sd, cfg, tokens, token_lengths, noise, length_scale, noise_scale=1
     mel_log_std = log_std @ attn
     Tm = mel_mean.shape[2]
     z = (mel_mean + torch.exp(mel_log_std) * noise[:, :, :Tm] * noise_scale) * mmask   # :187-191
-    mels, _, mmask2 = decoder(sd, z, mmask, cfg, True, speakers, prosodies)
+    pit = pitch_interpolate(pitches, pitch_lengths, mel_lengths) if mode == "GR" else None     # :193-196
+    mels, _, mmask2 = decoder(sd, z, mmask, cfg, True, speakers, prosodies, pit)
     mels = mels.masked_fill(mmask2 == 0.0, -cfg.max_abs_mel)                     # :202
     return mels, mel_lengths, attn

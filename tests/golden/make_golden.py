@@ -35,13 +35,23 @@ TINY = {
     "Speaker_Embedding.Num_Speakers": 5,
     "Speaker_Embedding.Embedding_Size": 16,
     "Prosody_Encoder.Size": 16,
+    "Prosody_Encoder.Reference_Encoder.Conv.Kernel_Size": [3, 3, 3],
+    "Prosody_Encoder.Reference_Encoder.Conv.Channels": [4, 8, 8],
+    "Prosody_Encoder.Reference_Encoder.Conv.Strides": [2, 2, 2],
+    "Prosody_Encoder.Reference_Encoder.GRU.Size": 8,
+    "Prosody_Encoder.Style_Token.Num_Tokens": 6,
+    "Prosody_Encoder.Style_Token.Size": 16,
+    "Prosody_Encoder.Style_Token.Attention_Head": 4,
+    "Speaker_Classifier_GR.Channels": [12],
+    "Train.Adversarial_Speaker_Weight": 0.05,
     "Use_Cython_Alignment": True,
 }
 
 
 def tiny_cfg(mode):
     return O.Cfg(mode=mode, mel_dim=12, enc_channels=32, prenet_stacks=2, ffn_channels=48, enc_stacks=2,
-                 dp_channels=24, n_flows=3, wn_channels=32, wn_layers=2, n_speakers=5, spk_dim=16, pro_dim=16)
+                 dp_channels=24, n_flows=3, wn_channels=32, wn_layers=2, n_speakers=5, spk_dim=16, pro_dim=16,
+                 pe_strides=(2, 2, 2), pe_kernels=(3, 3, 3), pe_heads=4, grl_weight=0.05, gr_hidden=1)
 
 
 def np_sd(sd):
@@ -76,7 +86,12 @@ def make_model_case(mode, seed, fname):
     for b in range(B):
         tokens[b, token_lengths[b]:] = 1
         mels[b, :, mel_lengths[b]:] = -4.0
-    speakers = torch.randint(0, 5, (B,), generator=gen) if mode == "SE" else None
+    speakers = torch.randint(0, 5, (B,), generator=gen) if mode in ("SE", "GR") else None
+    pitches = None
+    if mode == "GR":                                  # Datasets.py:240-247: per-frame pitch, zero-padded, same length as the mel
+        pitches = torch.rand(B, Tm, generator=gen) * 2.0
+        for b in range(B):
+            pitches[b, mel_lengths[b]:] = 0.0
 
     # (1) ActNorm data-dependent init happens on the first (training) forward  Modules.py:685-687
     model.train()
@@ -85,30 +100,32 @@ def make_model_case(mode, seed, fname):
     for mod in model.modules():
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0
-    model(tokens, token_lengths, mels, mel_lengths, speakers, None, None)
+    model(tokens, token_lengths, mels, mel_lengths, speakers, None, pitches)
     model.eval()
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
 
     # (2) training-graph forward + losses + grads, eval() => dropout off
-    out = model(tokens, token_lengths, mels, mel_lengths, speakers, None, None)
-    z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, attn, _ = out
+    out = model(tokens, token_lengths, mels, mel_lengths, speakers, None, pitches)
+    z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, attn, classified = out
     mle = M.MLE_Loss()(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=mel_lengths)
     length = torch.nn.MSELoss()(log_dur, log_dur_t)
+    ce = torch.nn.CrossEntropyLoss()(classified, speakers) if classified is not None else None       # Train.py:213-216
     model.zero_grad()
-    (mle + length).backward()
+    (mle + length + (ce if ce is not None else 0.0)).backward()
     grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
 
     # (3) inference with injected noise: seed right before the call so randn_like is reproducible
     length_scale = torch.tensor([1.0, 1.2, 0.9])
     with torch.no_grad():
         torch.manual_seed(seed + 1)
-        inf_mels, inf_lengths, inf_attn = model.inference(tokens, token_lengths, None, None, speakers, None, None, None,
+        pm, pl = (mels, mel_lengths) if mode in ("PE", "GR") else (None, None)
+        inf_mels, inf_lengths, inf_attn = model.inference(tokens, token_lengths, pm, pl, speakers, None, pitches, mel_lengths if pitches is not None else None,
                                                           noise_scale=0.667, length_scale=length_scale)
     torch.manual_seed(seed + 1)
     noise = torch.randn(B, 12, inf_attn.shape[2])
 
     # ---- pin the oracle on the same state dict ----
-    o = O.forward_train(sd, cfg, tokens, token_lengths, mels, mel_lengths, speakers)
+    o = O.forward_train(sd, cfg, tokens, token_lengths, mels, mel_lengths, speakers, pitches=pitches)
     def chk(a, b, name, tol=2e-5):
         err = (a - b).abs().max().item()
         print(f"  oracle vs reference  {name:18s} max|diff| = {err:.3e}")
@@ -117,12 +134,13 @@ def make_model_case(mode, seed, fname):
     chk(o["mel_mean"], mel_mean, "mel_mean"); chk(o["mel_log_std"], mel_log_std, "mel_log_std")
     chk(o["log_dur"], log_dur, "log_dur"); chk(o["log_dur_target"], log_dur_t, "log_dur_target")
     assert torch.equal(o["attn"], attn), "MAS path differs"
-    omle, olen = O.train_losses(o, mel_lengths, cfg)
-    chk(omle, mle, "mle"); chk(olen, length, "length")
+    olosses = O.train_losses(o, mel_lengths, cfg, speakers if mode == "GR" else None)
+    chk(olosses[0], mle, "mle"); chk(olosses[1], length, "length")
+    if mode == "GR":
+        chk(o["classified"], classified, "classified speakers"); chk(olosses[2], ce, "speaker CE")
     sdg = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
-    o2 = O.forward_train(sdg, cfg, tokens, token_lengths, mels, mel_lengths, speakers)
-    l1, l2 = O.train_losses(o2, mel_lengths, cfg)
-    (l1 + l2).backward()
+    o2 = O.forward_train(sdg, cfg, tokens, token_lengths, mels, mel_lengths, speakers, pitches=pitches)
+    sum(O.train_losses(o2, mel_lengths, cfg, speakers if mode == "GR" else None)).backward()
     worst = 0.0
     for k, g in grads.items():
         og = sdg[k].grad
@@ -135,7 +153,8 @@ def make_model_case(mode, seed, fname):
         worst = max(worst, rel)
     print(f"  oracle vs reference  grads (all {len(grads)} params) worst rel = {worst:.3e}")
     assert worst < 2e-3
-    om, ol, oa = O.inference(sd, cfg, tokens, token_lengths, noise, length_scale, 0.667, speakers)
+    om, ol, oa = O.inference(sd, cfg, tokens, token_lengths, noise, length_scale, 0.667, speakers, None, pm, pl, pitches,
+                             mel_lengths if pitches is not None else None)
     chk(om, inf_mels, "inference mels", 5e-5); assert torch.equal(ol, inf_lengths); assert torch.equal(oa, inf_attn)
     # ActNorm init restated: flow 0 sees the squeezed mels
     x0, m0 = O.squeeze(mels, O.mask_from_lengths(mel_lengths, Tm), 2)
@@ -153,6 +172,10 @@ def make_model_case(mode, seed, fname):
                 inf_mels=inf_mels.numpy(), inf_lengths=inf_lengths.numpy(), inf_attn=inf_attn.numpy().astype(np.int8))
     if speakers is not None:
         data["speakers"] = speakers.numpy()
+    if pitches is not None:
+        data["pitches"] = pitches.numpy()
+    if classified is not None:
+        data.update(classified=classified.detach().numpy(), ce=ce.detach().numpy())
     data.update({"grad/" + k: v.numpy() for k, v in grads.items()})
     np.savez_compressed(os.path.join(HERE, fname), **data)
     print(f"wrote {fname}: {os.path.getsize(os.path.join(HERE, fname)) / 1024:.0f} KiB")
@@ -195,3 +218,5 @@ if __name__ == "__main__":
     make_mas_cases()
     make_model_case("Vanilla", 1234, "tiny_vanilla.npz")
     make_model_case("SE", 4321, "tiny_se.npz")
+    make_model_case("PE", 777, "tiny_pe.npz")
+    make_model_case("GR", 999, "tiny_gr.npz")

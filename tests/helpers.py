@@ -18,7 +18,8 @@ def load_case(name):
 def tiny_cfg(mode):
     from oracle import glowtts_ref as O
     return O.Cfg(mode=mode, mel_dim=12, enc_channels=32, prenet_stacks=2, ffn_channels=48, enc_stacks=2,
-                 dp_channels=24, n_flows=3, wn_channels=32, wn_layers=2, n_speakers=5, spk_dim=16, pro_dim=16)
+                 dp_channels=24, n_flows=3, wn_channels=32, wn_layers=2, n_speakers=5, spk_dim=16, pro_dim=16,
+                 pe_strides=(2, 2, 2), pe_kernels=(3, 3, 3), pe_heads=4, grl_weight=0.05, gr_hidden=1)
 
 
 def tiny_hp_dict(mode):
@@ -40,7 +41,13 @@ def tiny_hp_dict(mode):
     hp["Speaker_Embedding"]["Num_Speakers"] = 5
     hp["Speaker_Embedding"]["Embedding_Size"] = 16
     hp["Speaker_Embedding"]["Type"] = "LUT"
-    hp["Prosody_Encoder"]["Size"] = 16
+    pe = hp["Prosody_Encoder"]
+    pe["Size"] = 16
+    pe["Reference_Encoder"]["Conv"] = {"Kernel_Size": [3, 3, 3], "Channels": [4, 8, 8], "Strides": [2, 2, 2]}
+    pe["Reference_Encoder"]["GRU"]["Size"] = 8
+    pe["Style_Token"] = {"Num_Tokens": 6, "Size": 16, "Attention_Head": 4}
+    hp["Speaker_Classifier_GR"]["Channels"] = [12]
+    hp["Train"]["Adversarial_Speaker_Weight"] = 0.05
     return hp
 
 

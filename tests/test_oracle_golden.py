@@ -40,27 +40,33 @@ def test_mas_oracle_matches_reference_build_if_present():
     assert np.array_equal(p, p2)
 
 
-@pytest.mark.parametrize("mode,fname", [("Vanilla", "tiny_vanilla.npz"), ("SE", "tiny_se.npz")])
+@pytest.mark.parametrize("mode,fname", [("Vanilla", "tiny_vanilla.npz"), ("SE", "tiny_se.npz"), ("PE", "tiny_pe.npz"), ("GR", "tiny_gr.npz")])
 def test_model_oracle_matches_reference_vectors(mode, fname):
+    """Every Mode of Hyper_Parameters.yaml:17-18: PE adds the GST prosody encoder (Modules.py:312-385), GR the adversarial speaker
+    classifier behind the gradient-reversal layer (:407-435, Gradient_Reversal_Layer.py) and per-frame pitch conditioning (:867-869)."""
     sd, grads, r = load_case(fname)
     cfg = tiny_cfg(mode)
     t = lambda k: torch.from_numpy(r[k])
     spk = t("speakers") if "speakers" in r else None
+    pit = t("pitches") if "pitches" in r else None
     sdg = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
-    o = O.forward_train(sdg, cfg, t("tokens"), t("token_lengths"), t("mels"), t("mel_lengths"), spk)
+    o = O.forward_train(sdg, cfg, t("tokens"), t("token_lengths"), t("mels"), t("mel_lengths"), spk, pitches=pit)
     for k in ["z", "mel_mean", "mel_log_std", "log_dets", "log_dur", "log_dur_target"]:
         assert torch.allclose(o[k], t(k), atol=3e-5, rtol=1e-5), k
     assert np.array_equal(o["attn"].numpy().astype(np.int8), r["attn"])
-    mle, length = O.train_losses(o, t("mel_lengths"), cfg)
-    assert abs(mle.item() - float(r["mle"])) < 1e-5 and abs(length.item() - float(r["length"])) < 1e-5
-    (mle + length).backward()
+    losses = O.train_losses(o, t("mel_lengths"), cfg, spk if mode == "GR" else None)
+    assert abs(losses[0].item() - float(r["mle"])) < 1e-5 and abs(losses[1].item() - float(r["length"])) < 1e-5
+    if mode == "GR":
+        assert torch.allclose(o["classified"], t("classified"), atol=1e-5) and abs(losses[2].item() - float(r["ce"])) < 1e-5
+    sum(losses).backward()
     for k, g in grads.items():
         og = sdg[k].grad
         og = torch.zeros_like(g) if og is None else og
         assert (og - g).abs().max() <= 1e-3 * (g.abs().max() + 1e-5), k
     with torch.no_grad():
+        pm, pl = (t("mels"), t("mel_lengths")) if mode in ("PE", "GR") else (None, None)
         m, l, a = O.inference(sd, cfg, t("tokens"), t("token_lengths"), t("noise"), t("length_scale"),
-                              float(r["noise_scale"]), spk)
+                              float(r["noise_scale"]), spk, None, pm, pl, pit, t("mel_lengths") if pit is not None else None)
     assert torch.allclose(m, t("inf_mels"), atol=5e-5) and torch.equal(l, t("inf_lengths"))
     assert np.array_equal(a.numpy().astype(np.int8), r["inf_attn"])
 
