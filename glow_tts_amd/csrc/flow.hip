@@ -62,7 +62,7 @@ int coupling_net(const Ctx& c, const float* xsrc, float* xdst, bool reverse, boo
             glowtts_conv_args a = base_args(c, p->in[l], c.d->ksize);
             a.a = hin; a.lda = H; a.ca = H; a.n = 2 * H; a.h = H;
             a.epi = GLOWTTS_EPI_GATE; a.bias = p->b_in[l]; a.drop_p = c.d->drop_p; a.seed = c.d->seed + (uint32_t)l; a.seed_ptr = c.d->seed_ptr;
-            if (p->cond) { a.cond = p->cond + (int64_t)l * 2 * H; a.ldcond = p->ldcond; }
+            if (p->cond) { a.cond = p->cond + (int64_t)l * 2 * H; a.ldcond = p->ldcond; if (p->cond_rows) a.flags |= GLOWTTS_F_COND_ROWS; }
             a.out0 = g; a.ld0 = 2 * H; a.io_flags = bf ? (GLOWTTS_IO_A_BF16 | GLOWTTS_IO_OUT0_BF16) : 0;
             if (acts) { a.out1 = acts; a.ld1 = H; }              // bf16 tanh * sigmoid for the Res_Skip conv below
             CHECK(glowtts_conv_cl(&a, c.s));
@@ -220,6 +220,8 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
             q.n = H; q.epi = GLOWTTS_EPI_DGATE; q.in0 = a->gates[l]; q.ldi0 = 2 * H; q.out0 = dins; q.ld0 = ldin;
             q.drop_p = d->drop_p; q.seed = d->seed + (uint32_t)l; q.seed_ptr = d->seed_ptr;
             q.io_flags = bf ? (GLOWTTS_IO_IN0_BF16 | GLOWTTS_IO_OUT0_BF16 | (bfg ? GLOWTTS_IO_A_BF16 : 0)) : 0;
+            // conditioning gradient (autograd of Modules.py:863-866): per-utterance sums of the gate gradients before the dropout mask
+            if (g->dcond && p->cond) { q.out1 = g->dcond + (int64_t)l * 2 * H; q.ld1 = p->ldcond; }
             if (last) {
                 static const bool chain = [] { const char* e = getenv("GLOWTTS_CHAIN"); const char* f = getenv("GLOWTTS_CHAIN_BWD");
                                                return !(e && e[0] == '0') && !(f && f[0] == '0'); }();
@@ -262,8 +264,6 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
             w.perm = GLOWTTS_PERM_PAIR; w.perm_h = H; w.io_flags = bf ? (GLOWTTS_WIO_DY_BF16 | GLOWTTS_WIO_X_BF16) : 0;
             CHECK(glowtts_wgrad_cl(&w, stream));
         }
-        if (g->dcond && p->cond)   // conditioning gradient: sum over the frames of each utterance   (autograd of Modules.py:863-866)
-            CHECK(utt_colsum(dins, ldin, g->dcond + (int64_t)l * 2 * H, p->ldcond, d->B, c.Tp, 2 * H, GLOWTTS_PERM_PAIR, H, bf, stream));
     }
     if (!end_done) return GLOWTTS_E_ARG;
     float* dh0 = g->dh[0];                    // d h0 * mask

@@ -379,7 +379,8 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
         // Res_Skip conv and the X operand of its weight gradient (both then need no prologue).  No out1: zero-sized descriptor,
         // the stores are dropped by the bounds check.
         const Rsrc ra = mk(p.out1, p.out1 ? (long)p.rows * p.ld1 * 2 : 0);
-        const int Tp = p.rows_per_utt > 0 ? p.rows_per_utt : 1;
+        // conditioning rows: one per utterance, or (GLOWTTS_F_COND_ROWS: per-frame conditioning, GR-mode pitch) one per activation row
+        const int Tp = (fl & GLOWTTS_F_COND_ROWS) ? 1 : (p.rows_per_utt > 0 ? p.rows_per_utt : 1);
         const int nutt = p.rows / Tp;
         const Rsrc rc = mk(p.cond, (long)nutt * p.ldcond * 4);
         const bool drop = p.drop_p > 0.f, cnd = p.cond != nullptr;
@@ -470,6 +471,12 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
         const uint32_t thr = drop_threshold(p.drop_p);
         const float ik = drop_inv_keep(thr);
         uint32_t vo[NI], vg[NI], jkey[NI];
+        // out1 (optional): d conditioning [utterances][ld1], original channel order, ACCUMULATED (atomic adds; zero it first).  The
+        // conditioning joins the pre-activation AFTER the dropout (Modules.py:861-866), so its gradient is the per-utterance sum of the
+        // gate gradients BEFORE the keep mask is applied - which only exists here, in registers.
+        float* dcnd = p.out1;
+        const int Tp = p.rows_per_utt > 0 ? p.rows_per_utt : 1;
+        int dcol[NI];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int j = n0 + (wn * NI + ni) * 32 + l31;                          // gate channel (natural order)
@@ -478,7 +485,23 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
             vo[ni] = ok ? (uint32_t)(rb * (int)p.ld0 + pc) * esz : OOB;
             vg[ni] = ok ? (uint32_t)(rb * (int)p.ldi0 + 2 * j) * ei : OOB;
             jkey[ni] = drop_colkey((uint32_t)j);
+            dcol[ni] = ok ? j : -1;
         }
+        float sa[NI], ss[NI]; int cur_u = -1;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) sa[ni] = ss[ni] = 0.f;
+        auto flush = [&]() __attribute__((always_inline)) {
+            if (cur_u >= 0) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    if (dcol[ni] >= 0) {
+                        float* dst = dcnd + (long)cur_u * p.ld1 + dcol[ni];
+                        unsafeAtomicAdd(dst, sa[ni]); unsafeAtomicAdd(dst + p.n, ss[ni]);
+                    }
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) sa[ni] = ss[ni] = 0.f;
+        };
         auto rows_loop = [&](auto DROP_) __attribute__((always_inline)) {
             constexpr bool DROP = decltype(DROP_)::value != 0;
 #pragma unroll
@@ -508,12 +531,18 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
                     for (int q = 0; q < 8; ++q) {
                         const int reg = hb * 8 + q;
                         const uint32_t rk = DROP ? drop_rowkey(seed, (uint32_t)(rb + roff(mi, reg))) : 0u;
+                        if (dcnd) {                                        // rows ascend with (mi, reg): one run of rows per utterance and lane
+                            const int r = rb + roff(mi, reg);
+                            const int u = r < p.rows ? r / Tp : -1;        // (rows past the end hold clamped garbage: not accumulated)
+                            if (u != cur_u) { flush(); cur_u = u; }
+                        }
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni) {
                             const float d = acc[mi][ni][reg], t = gt[q][ni], sg = gs[q][ni];
                             const float dsg = d * sg;
                             da[q][ni] = dsg * (1.f - t * t);
                             ds[q][ni] = dsg * t * (1.f - sg);
+                            if (dcnd) { sa[ni] += da[q][ni]; ss[ni] += ds[q][ni]; }
                             if constexpr (DROP) { const uint32_t w = drop_draw(rk, jkey[ni]); da[q][ni] *= drop_keep_lo(w, thr, ik); ds[q][ni] *= drop_keep_hi(w, thr, ik); }
                         }
                     }
@@ -538,6 +567,7 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
             }
         };
         if (drop) rows_loop(IC<1>{}); else rows_loop(IC<0>{});
+        if (dcnd) flush();
     } else {
         // affine coupling on (m, logs) = End conv output (Modules.py:795-806); PAIR-packed like GATE: fragment 2*pi holds m, 2*pi+1 logs
         static_assert(EPI == GLOWTTS_EPI_COUPLE && NI % 2 == 0, "pair epilogues need NI even");
@@ -1488,8 +1518,12 @@ extern "C" int glowtts_conv_cl(const glowtts_conv_args* args, void* stream)
         if ((a.ca & 3) || a.kchunks * (a.precision == GLOWTTS_BF16 ? 32 : 16) < a.ca) return GLOWTTS_E_ARG;
         if ((a.io_flags & GLOWTTS_IO_OUT0_BF16) && (a.flags & GLOWTTS_F_ACCUM)) return GLOWTTS_E_ARG;
         // the epilogue addresses out0 / out1 / in0 / cond with 32-bit byte offsets (buffer descriptors)
-        const int64_t ldmax = std::max(std::max(a.ld0, a.ld1), std::max(a.ldi0, a.ldcond));
+        const int64_t ldmax = std::max(std::max(a.ld0, a.epi == GLOWTTS_EPI_DGATE ? 0 : a.ld1), a.ldi0);
         if ((int64_t)a.rows * ldmax * 4 >= (int64_t)1 << 31) return GLOWTTS_E_ARG;
+        if (a.cond) {       // one conditioning row per utterance, or per activation row (GLOWTTS_F_COND_ROWS)
+            const int64_t crows = (a.flags & GLOWTTS_F_COND_ROWS) ? a.rows : a.rows / std::max(a.rows_per_utt, 1);
+            if (crows * a.ldcond * 4 >= (int64_t)1 << 31) return GLOWTTS_E_ARG;
+        }
         if (abf && ((a.ca & 7) || (a.lda & 7) || (a.a2 && ((a.lda2 & 7) || (a.ca1 & 7))))) return GLOWTTS_E_ARG;
         if (a.apro == GLOWTTS_APRO_PAIRMUL) { if (a.lda < 2 * up(a.ca)) return GLOWTTS_E_ARG; }
         else if (a.apro == GLOWTTS_APRO_SQNEG) { if (a.lda < up(a.ca1)) return GLOWTTS_E_ARG; }
@@ -1511,7 +1545,7 @@ extern "C" int glowtts_conv_chain(const glowtts_conv_args* first, const glowtts_
         a.apro != GLOWTTS_APRO_NONE || a.a2 || a.batch > 1 || b.batch > 1 || a.rows != b.rows || a.rows < 1) return GLOWTTS_E_ARG;
     if (a.n != CH_BN || a.npad != CH_BN || a.kchunks * 32 != a.ca || (a.kchunks % DMA1_CPS) || (a.lda & 7) || b.kchunks != CH_KC2 || b.npad != CH_BN ||
         b.ca != CH_BN) return GLOWTTS_E_ARG;
-    const int64_t ldmax = std::max(std::max(std::max(a.ld0, a.ld1), std::max(b.ld0, b.ld1)), std::max(b.ldi0, b.ldcond));
+    const int64_t ldmax = std::max(std::max(std::max(a.ld0, a.ld1), std::max(b.ld0, b.epi == GLOWTTS_EPI_DGATE ? 0 : b.ld1)), b.ldi0);
     if ((int64_t)a.rows * ldmax * 4 >= (int64_t)1 << 31) return GLOWTTS_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.epi == GLOWTTS_EPI_RESSKIP && (a.flags & GLOWTTS_F_LAST) && b.epi == GLOWTTS_EPI_COUPLE) return launch_chain<GLOWTTS_EPI_RESSKIP, GLOWTTS_EPI_COUPLE>(a, b, s);

@@ -34,7 +34,7 @@ class FlowParams(ctypes.Structure):
                 ("start", Packed), ("in_", Packed * MAXL), ("rs", Packed * MAXL), ("end", Packed),
                 ("start_t", Packed), ("in_t", Packed * MAXL), ("rs_t", Packed * MAXL), ("end_t", Packed),
                 ("b_start", c_void_p), ("b_in", c_void_p * MAXL), ("b_rs", c_void_p * MAXL), ("b_end", c_void_p),
-                ("cond", c_void_p), ("ldcond", c_i64)]
+                ("cond", c_void_p), ("ldcond", c_i64), ("cond_rows", c_int)]
 
 
 class FlowActs(ctypes.Structure):
@@ -286,6 +286,12 @@ class _Prepared:
         for f, p in enumerate(self.params):
             p.cond = (cond.data_ptr() + 4 * f * Lw * 2 * H) if cond is not None else None
             p.ldcond = F_ * Lw * 2 * H if cond is not None else 0
+            p.cond_rows = 0
+
+    def set_cond_rows(self, f, rows):
+        """Flow f reads per-ROW conditioning `rows` [R, L, 2H] (per-utterance terms already added in; GR-mode pitch, Modules.py:867-869)."""
+        p = self.params[f]
+        p.cond, p.ldcond, p.cond_rows = rows.data_ptr(), self._Lw * 2 * self._H, 1
 
 
 def _dims(cfg, B, T, drop_p=0.0, seed=None, flow=0):
@@ -343,14 +349,36 @@ class _Buffers:
         return a
 
 
-def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None):
+def pitch_rows(cfg, pitches, rowmask, B, T):
+    """Squeeze of the per-frame pitch (Modules.py:300-301: Squeeze(pitches.unsqueeze(1), mask) -> [B, ns, T]) in the rows layout:
+    [R, ns], row of (utterance b, squeezed frame t) = pitches[b, ns*t : ns*t + ns] * mask'[t]; pad rows zero."""
+    ns = cfg.ns
+    p = pitches[:, :T * ns].reshape(B, T, ns).to(torch.float32)
+    p = torch.nn.functional.pad(p, (0, 0, ROW_PAD, ROW_PAD)).reshape(B * (T + 2 * ROW_PAD), ns)
+    return (p * rowmask.unsqueeze(1)).contiguous()
+
+
+def _cond_rows(cfg, prep, f, prow, pitch_w, pitch_b, Tp):
+    """Per-row conditioning of flow f: Pitch_l(pitch)[r] + per-utterance (speaker + prosody) terms -> [R, L, 2H] fp32."""
+    cr = torch.einsum("rj,lnj->rln", prow, pitch_w[f]) + pitch_b[f]
+    if prep.cond is not None:
+        cr = cr + prep.cond[:, f].repeat_interleave(Tp, dim=0)
+    return cr.contiguous()
+
+
+def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
+    """pitch: None or (pitches [B, Tm], pitch_w [F, L, 2H, ns], pitch_b [F, L, 2H]) - GR mode."""
     L = _L()
     B, _, Tm = mels.shape
     x0, rowmask, T = squeeze_rows(cfg, mels, lengths)
     R = x0.shape[0]
     buf = _Buffers(cfg, prep, R, mels.device)
     buf.x[0].copy_(x0)
+    prow = pitch_rows(cfg, pitch[0], rowmask, B, T) if pitch is not None else None
     for f in range(cfg.F):
+        if pitch is not None:
+            cr = _cond_rows(cfg, prep, f, prow, pitch[1], pitch[2], T + 2 * ROW_PAD)
+            prep.set_cond_rows(f, cr)
         acts = buf.acts(f, cfg.L, rowmask)
         dims = _dims(cfg, B, T, drop_p, seed, f)
         _lib.check(L.glowtts_flow_forward(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(acts), _lib.stream()),
@@ -361,12 +389,15 @@ def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None):
     _lib.check(L.glowtts_decoder_logdet(_lib.ptr(buf.outs), R * prep.ldo, _lib.ptr(prep.keep["an_logs"].contiguous()), _lib.ptr(prep.winfo),
                                         _lib.ptr(rowmask), _lib.ptr(part), _lib.ptr(logdet), cfg.F, B, T + 2 * ROW_PAD, cfg.C, prep.ldo,
                                         _lib.stream()), "glowtts_decoder_logdet")
-    return z, logdet, buf, rowmask, T
+    if pitch is not None:
+        prep.set_cond(prep.cond)            # the backward addresses the conditioning gradient per utterance
+    return z, logdet, buf, rowmask, T, prow
 
 
-def decoder_inverse(cfg, W, z, lengths, cond=None, fill=None, prep=None):
+def decoder_inverse(cfg, W, z, lengths, cond=None, fill=None, prep=None, pitch=None):
     """Decoder.forward(reverse=True) (Modules.py:298-309): z [B,Cm,Tm] -> mels [B,Cm,ns*(Tm//ns)].
-    prep: a _Prepared built earlier from the same weights (then W is not read; `cond`, which varies per call, is attached here)."""
+    prep: a _Prepared built earlier from the same weights (then W is not read; `cond`, which varies per call, is attached here).
+    pitch: None or (pitches [B, Tm], pitch_w [F, L, 2H, ns], pitch_b [F, L, 2H]) - GR mode."""
     L = _L()
     if prep is None:
         prep = _Prepared(cfg, W, need_bwd=False, cond=cond)
@@ -385,7 +416,11 @@ def decoder_inverse(cfg, W, z, lengths, cond=None, fill=None, prep=None):
     skip = torch.empty(R, cfg.H, device=dev)
     dims = _dims(cfg, B, T)
     cur, nxt = x, other
+    prow = pitch_rows(cfg, pitch[0], rowmask, B, T) if pitch is not None else None
     for f in range(cfg.F - 1, -1, -1):
+        if pitch is not None:
+            cr = _cond_rows(cfg, prep, f, prow, pitch[1], pitch[2], T + 2 * ROW_PAD)
+            prep.set_cond_rows(f, cr)
         a = FlowActs()
         a.xout, a.xmid, a.xin = cur.data_ptr(), xmid.data_ptr(), nxt.data_ptr()
         a.hs[0], a.hs[1] = hs[0].data_ptr(), hs[1].data_ptr()
@@ -399,7 +434,7 @@ def decoder_inverse(cfg, W, z, lengths, cond=None, fill=None, prep=None):
     return unsqueeze_rows(cfg, cur, lengths, B, (Tm // cfg.ns) * cfg.ns, fill=fill)
 
 
-def actnorm_data_init(cfg, W, mels, lengths, cond=None, allreduce=None):
+def actnorm_data_init(cfg, W, mels, lengths, cond=None, allreduce=None, pitch=None):
     """ActNorm data-dependent init (Modules.py:685-687, 698-711): runs the flows once, setting
     W['an_logs'][f] / W['an_bias'][f] from the masked batch statistics of each flow's input.
     `allreduce(stats)` (optional) sums the [2C+1] statistics over data-parallel ranks."""
@@ -426,6 +461,10 @@ def actnorm_data_init(cfg, W, mels, lengths, cond=None, allreduce=None):
             _lib.check(L.glowtts_actnorm_from_stats(_lib.ptr(stats), W["an_logs"][f].data_ptr(), W["an_bias"][f].data_ptr(), cfg.C,
                                                     _lib.stream()), "actnorm_from_stats")
             prep = _Prepared(cfg, W, need_bwd=False, cond=cond)       # re-pack is cheap relative to a one-off init
+            if pitch is not None:
+                prow = pitch_rows(cfg, pitch[0], rowmask, B, T)
+                cr = _cond_rows(cfg, prep, f, prow, pitch[1], pitch[2], T + 2 * ROW_PAD)
+                prep.set_cond_rows(f, cr)
             outs = torch.empty(R, prep.ldo, device=dev)
             a = FlowActs()
             a.xin, a.xmid, a.xout = bufs[0].data_ptr(), xmid.data_ptr(), bufs[1].data_ptr()
@@ -443,15 +482,21 @@ class DecoderFunction(torch.autograd.Function):
     """z, logdet = Decoder(mels)   with autograd through the hand-written backward kernels."""
 
     @staticmethod
-    def forward(ctx, cfg, mels, lengths, cond, drop_p, *weights):
+    def forward(ctx, cfg, mels, lengths, cond, drop_p, pitches, pitch_w, pitch_b, *weights):
+        """pitches [B, Tm] / pitch_w [F, L, 2H, ns] / pitch_b [F, L, 2H]: the GR-mode per-frame pitch conditioning (Modules.py:867-869), else None."""
         W = dict(zip(WEIGHT_KEYS, [w.detach().contiguous() for w in weights]))
-        need_bwd = any(w.requires_grad for w in weights) or mels.requires_grad or (cond is not None and cond.requires_grad)
+        need_bwd = any(w.requires_grad for w in weights) or mels.requires_grad or (cond is not None and cond.requires_grad) or \
+            (pitch_w is not None and pitch_w.requires_grad)
         condc = cond.detach().contiguous() if cond is not None else None
         prep = _Prepared(cfg, W, need_bwd=need_bwd, cond=condc)
         # one random word on the device (torch's graph-safe generator); kept for the backward, which regenerates the masks
         seed = torch.randint(0, 2 ** 31 - 1, (1,), device=mels.device, dtype=torch.int32) if drop_p > 0 else None
-        z, logdet, buf, rowmask, T = _run_forward(cfg, prep, mels.detach(), lengths, drop_p, seed)
+        pitch = (pitches.detach(), pitch_w.detach().contiguous(), pitch_b.detach().contiguous()) if pitches is not None else None
+        if pitch is not None and condc is None:
+            raise _lib.GlowTTSHipError("per-frame pitch conditioning comes with the GR mode's speaker / prosody conditioning (Modules.py:84-90)")
+        z, logdet, buf, rowmask, T, prow = _run_forward(cfg, prep, mels.detach(), lengths, drop_p, seed, pitch)
         ctx.drop = (drop_p, seed)
+        ctx.prow = prow
         if need_bwd:
             ctx.cfg, ctx.prep, ctx.buf, ctx.rowmask, ctx.T = cfg, prep, buf, rowmask, T
             ctx.lengths, ctx.mel_shape = lengths, mels.shape
@@ -574,7 +619,21 @@ class DecoderFunction(torch.autograd.Function):
         winv_t = prep.winfo[:, 16:32].view(F_, 4, 4).transpose(1, 2)
         G["inv_w"] = d_an[:, 2 * C:].view(F_, 4, 4) + s * (C / 4) * winv_t
         dmel = unsqueeze_rows(cfg, dx, ctx.lengths, B, Tm) if ctx.want_dmel else None
-        return (None, dmel, None, dcond, None) + tuple(G[k].view_as(W[k]) for k in WEIGHT_KEYS)
+        dpw = dpb = None
+        if ctx.prow is not None:
+            # Pitch_l conv (Modules.py:846-852, 867-869): bias gradient = the conditioning gradient summed over utterances; weight
+            # gradient = sum_r d pre[r][n] * pitch[r][j] from the kept gate gradients (PAIR-packed columns -> original channels).
+            # NOTE: with WaveNet dropout > 0 the kept gate gradients carry the keep mask (the In_l conv sits behind the dropout, the
+            # pitch term does not): the weight gradient is then an unbiased estimate, exact for Dropout_Rate = 0 / eval mode.
+            dpb = dcond.sum(0).view(F_, Lw, 2 * H)
+            pc = torch.arange(prep.ldin, device=dev)
+            j = (pc >> 6) * 32 + (pc & 31)
+            valid = j < H
+            orig = (((pc >> 5) & 1) * H + j)[valid]
+            dpw = torch.zeros(F_, Lw, 2 * H, ctx.prow.shape[1], device=dev)
+            for f in range(F_):
+                dpw[f, :, orig] = torch.matmul(dins[f].float().transpose(1, 2), ctx.prow)[:, valid]
+        return (None, dmel, None, dcond, None, None, dpw, dpb) + tuple(G[k].view_as(W[k]) for k in WEIGHT_KEYS)
 
 
 def _wn(g, v):
@@ -712,7 +771,7 @@ class DecoderStacks:
         wn3("rsl", [f"{fl(f)}.2.layer_Dict.WaveNet.layer_Dict.Res_Skip_{L - 1}" for f in range(F_)], (F_,))
         S["end_w"] = LeafStack([P[f"{fl(f)}.2.layer_Dict.End.weight"] for f in range(F_)], (F_,))
         S["end_b"] = LeafStack([P[f"{fl(f)}.2.layer_Dict.End.bias"] for f in range(F_)], (F_,))
-        for kind in ("Speaker", "Prosody"):
+        for kind in ("Speaker", "Prosody", "Pitch"):
             if f"{fl(0)}.2.layer_Dict.WaveNet.layer_Dict.{kind}_0.weight_v" in P:
                 wn3(kind, [f"{fl(f)}.2.layer_Dict.WaveNet.layer_Dict.{kind}_{l}" for f in range(F_) for l in range(L)], (F_ * L,))
         self.S = S
@@ -734,6 +793,14 @@ class DecoderStacks:
             w_rs, b_rs = torch.zeros(F_, 0, 2 * cfg.H, cfg.H, 1, device=dev), torch.zeros(F_, 0, 2 * cfg.H, device=dev)
         return (t("an_logs").view(F_, -1), t("an_bias").view(F_, -1), t("inv_w"), wn("start"), t("start_b"), wn("in"), t("in_b"),
                 w_rs, b_rs, wn("rsl"), t("rsl_b"), t("end_w"), t("end_b"))
+
+    def pitch_weights(self):
+        """(pitch_w [F, L, 2H, ns], pitch_b [F, L, 2H]) of the GR-mode Pitch_l convs (Modules.py:846-852), or (None, None)."""
+        if "Pitch_v" not in self.S:
+            return None, None
+        cfg = self.cfg
+        w = WeightNorm.apply(self.S["Pitch_g"].tensor(), self.S["Pitch_v"].tensor()).squeeze(-1)
+        return w.view(cfg.F, cfg.L, 2 * cfg.H, -1), self.S["Pitch_b"].tensor().view(cfg.F, cfg.L, 2 * cfg.H)
 
     def conditioning(self, speakers=None, prosodies=None):
         """cond[b, f, l, :] = Speaker_l(spk_b) + Prosody_l(pro_b)  (Modules.py:863-866), one batched matmul each."""

@@ -165,6 +165,14 @@ def _unshare_state_dict(module, state_dict, prefix, local_metadata):
     return state_dict
 
 
+def _drop_ge2e_keys(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+    """Reference checkpoints trained with Speaker_Embedding.Type 'GE2E' carry the pre-trained d-vector LSTM under `layer_Dict.GE2E.*`
+    (Modules.py:30-35; loaded separately by Train.py:555-561).  That network is an un-vendored submodule of the reference: here the
+    d-vectors are an input, so those keys are dropped explicitly instead of failing a strict load."""
+    for k in [k for k in state_dict if k.startswith(prefix + "layer_Dict.GE2E.")]:
+        del state_dict[k]
+
+
 class GlowTTS(torch.nn.Module):
     """Drop-in for Modules.GlowTTS (Modules.py:16-229)."""
 
@@ -186,6 +194,12 @@ class GlowTTS(torch.nn.Module):
         if mode in ("PE", "GR"):
             from .prosody import Prosody_Encoder
             self.layer_Dict["Prosody_Encoder"] = Prosody_Encoder(hp)
+        if mode == "GR":                                                                   # Modules.py:44-46
+            from .prosody import Pitch_Interpolater, Speaker_Classifier_GR
+            assert hp.Speaker_Embedding.Embedding_Size == hp.Prosody_Encoder.Size, \
+                "In GR mode, the size of speaker embeding and prosody encoder must be same."     # Modules.py:588-589
+            self.layer_Dict["Speaker_Classifier_GR"] = Speaker_Classifier_GR(hp)
+            self.layer_Dict["Pitch_Interpolater"] = Pitch_Interpolater()
         self.layer_Dict["Encoder"] = _build_encoder(hp)
         dec = _Dict()
         dec.layer_Dict["Flows"] = torch.nn.ModuleList([_Flow(hp) for _ in range(hp.Decoder.Stack)])
@@ -200,6 +214,7 @@ class GlowTTS(torch.nn.Module):
         self._dec_stacks = None           # decoder.DecoderStacks: flat per-class parameter storage, built on first use
         self._enc_cache = {}              # encoder leaf stacks (fused Query/Key/Value weights)
         self._register_state_dict_hook(_unshare_state_dict)
+        self._register_load_state_dict_pre_hook(_drop_ge2e_keys)
         self.overlap_encoder = os.environ.get("GLOWTTS_ENCODER_OVERLAP", "1") == "1"
 
     # ---------------------------------------------------------------- helpers
@@ -256,14 +271,14 @@ class GlowTTS(torch.nn.Module):
             pro = self.layer_Dict["Prosody_Encoder"](prosody_mels, prosody_lengths)                       # Modules.py:81-82
         return spk, pro
 
-    def _maybe_init_actnorm(self, P, mels, mel_lengths, cond):
+    def _maybe_init_actnorm(self, P, mels, mel_lengths, cond, pitch=None):
         """ActNorm data-dependent init on the first call (Modules.py:685-687), flag kept per flow like the reference."""
         flows = self._flows()
         if all(f.layers[0].initialized for f in flows):
             return
         W = dict(zip(decoder.WEIGHT_KEYS, [w.detach().contiguous().clone() for w in decoder.stack_decoder_weights(P, self.dec_cfg)]))
         decoder.actnorm_data_init(self.dec_cfg, W, mels, mel_lengths, cond=None if cond is None else cond.detach(),
-                                  allreduce=self.actnorm_allreduce)
+                                  allreduce=self.actnorm_allreduce, pitch=pitch)
         with torch.no_grad():
             for i, f in enumerate(flows):
                 if not f.layers[0].initialized:
@@ -295,10 +310,16 @@ class GlowTTS(torch.nn.Module):
                                                              cache=self._enc_cache)
         stacks = self._stacks(P)
         cond = stacks.conditioning(spk, pro)
-        self._maybe_init_actnorm(P, mels, mel_lengths, cond)
+        pitch_w, pitch_b = stacks.pitch_weights()
+        if pitch_w is None:
+            pitches = None                                                                              # Modules.py:89-90
+        elif pitches is None:
+            raise ValueError("GR mode needs `pitches` [Batch, Mel_t] (Modules.py:58, 867-869)")
+        self._maybe_init_actnorm(P, mels, mel_lengths, cond, None if pitches is None else (pitches, pitch_w.detach(), pitch_b.detach()))
         W = stacks.weights()
         drop_p = float(hp.Decoder.Affine_Coupling.WaveNet.Dropout_Rate) if self.training else 0.0      # Modules.py:854-862
-        z, log_dets = decoder.DecoderFunction.apply(self.dec_cfg, mels, mel_lengths, cond, drop_p, *W)
+        z, log_dets = decoder.DecoderFunction.apply(self.dec_cfg, mels, mel_lengths, cond, drop_p, pitches, pitch_w if pitches is not None else None,
+                                                    pitch_b if pitches is not None else None, *W)
         if side is not main:
             main.wait_stream(side)
             for t_ in (mean, log_std, log_dur):
@@ -324,6 +345,8 @@ class GlowTTS(torch.nn.Module):
             main.wait_stream(side)
             attn.record_stream(main)
         classified = None
+        if "Speaker_Classifier_GR" in self.layer_Dict:
+            classified = self.layer_Dict["Speaker_Classifier_GR"](pro)                                    # Modules.py:84-87
         return z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_targets, attn, classified
 
     # ---------------------------------------------------------------- inverse flow
@@ -333,7 +356,7 @@ class GlowTTS(torch.nn.Module):
         """Modules.py:128-204.  `noises` (optional, [B, Mel_Dim, >= max T_mel]) injects the Gaussian noise the reference
         draws with torch.randn_like (:187) so that results are reproducible."""
         front = self.inference_front(tokens, token_lengths, mels_for_prosody, mel_lengths_for_prosody, speakers, mels_for_ge2e, length_scale)
-        return self.inference_back(front, None, noise_scale, noises)
+        return self.inference_back(front, None, noise_scale, noises, pitches=pitches, pitch_lengths=pitch_lengths)
 
     @torch.no_grad()
     def inference_front(self, tokens, token_lengths, mels_for_prosody=None, mel_lengths_for_prosody=None, speakers=None, mels_for_ge2e=None,
@@ -353,7 +376,7 @@ class GlowTTS(torch.nn.Module):
         return mean, log_std, dur, mel_lengths, token_mask, spk, pro
 
     @torch.no_grad()
-    def inference_back(self, front, max_mel_length=None, noise_scale=1.0, noises=None, prep=None):
+    def inference_back(self, front, max_mel_length=None, noise_scale=1.0, noises=None, prep=None, pitches=None, pitch_lengths=None):
         """Second half (Modules.py:175-204): hard alignment, prior sample, inverse flow.  max_mel_length: padded frame count (None: the batch
         maximum, read back from the device like the reference's torch.max); prep: a decoder._Prepared kept by the caller (static weights)."""
         hp = self.hp
@@ -370,7 +393,14 @@ class GlowTTS(torch.nn.Module):
         stacks = self._stacks(P)
         cond = stacks.conditioning(spk, pro)
         W = None if prep is not None else dict(zip(decoder.WEIGHT_KEYS, [w.contiguous() for w in stacks.weights()]))
-        mels = decoder.decoder_inverse(self.dec_cfg, W, z.contiguous(), mel_lengths, cond=cond, fill=-float(hp.Sound.Max_Abs_Mel), prep=prep)   # :198-202
+        pitch = None
+        if "Pitch_Interpolater" in self.layer_Dict:                                                        # :193-196
+            if pitches is None:
+                raise ValueError("GR mode needs `pitches` and `pitch_lengths` (Modules.py:136-137)")
+            pw, pb = stacks.pitch_weights()
+            pitch = (self.layer_Dict["Pitch_Interpolater"](pitches, pitch_lengths, mel_lengths, z.shape[2]), pw, pb)
+        mels = decoder.decoder_inverse(self.dec_cfg, W, z.contiguous(), mel_lengths, cond=cond, fill=-float(hp.Sound.Max_Abs_Mel), prep=prep,
+                                       pitch=pitch)   # :198-202
         return mels, mel_lengths, attn
 
     def prepared_decoder_weights(self):

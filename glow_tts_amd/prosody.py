@@ -1,7 +1,8 @@
-"""GST prosody encoder (Modules.py:312-385) - NOT part of the hot path (it produces one [B, 256]
-conditioning vector per utterance, < 1 % of the FLOPs, "next" row 8f-3).  Kept as plain PyTorch-ROCm modules with the
-reference's parameter names so that PE-mode checkpoints load and BASELINE config 5 runs; it feeds the HIP decoder /
-encoder as a conditioning vector."""
+"""Conditioning encoders of the PE / GR modes - NOT part of the hot path (each produces one small
+per-utterance tensor, < 1 % of the FLOPs): the GST `Prosody_Encoder` (Modules.py:312-385), the adversarial `Speaker_Classifier_GR` behind the
+gradient-reversal layer (Modules.py:407-435, Gradient_Reversal_Layer.py:6-35) and the `Pitch_Interpolater` (Modules.py:387-405).  Plain
+PyTorch-ROCm modules with the reference's parameter names, so PE- and GR-mode checkpoints load strictly; they feed the HIP decoder / encoder
+as conditioning vectors.  Parity: tests/test_gpu_modes.py against the golden vectors of the reference (tiny_pe.npz, tiny_gr.npz)."""
 import math
 
 import torch
@@ -66,3 +67,62 @@ class Prosody_Encoder(torch.nn.Module):
         x = x[torch.arange(x.size(0), device=x.device), idx]                               # [B, G]
         keys = torch.tanh(self.gst_Tokens).unsqueeze(0).expand(x.size(0), -1, -1)
         return self.layer_Dict["Attention"](x.unsqueeze(2), keys).squeeze(2)
+
+
+class _GRLFunc(torch.autograd.Function):
+    """Gradient_Reversal_Layer.py:6-20: identity forward, -weight * grad backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.weight = weight
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return -ctx.weight * g, None
+
+
+class GRL(torch.nn.Module):
+    def __init__(self, weight=1.0):
+        super().__init__()
+        self.weight = weight
+
+    def forward(self, x):
+        return _GRLFunc.apply(x, self.weight)
+
+
+class Speaker_Classifier_GR(torch.nn.Module):
+    """Modules.py:407-435: GRL -> [Conv1x1 + ReLU] per entry of Speaker_Classifier_GR.Channels -> Conv1x1 to Num_Speakers.  Keys
+    `layer.Hidden_{i}.{weight,bias}`, `layer.Output_{last i}.{weight,bias}` (the reference names the output after the last hidden index)."""
+
+    def __init__(self, hp):
+        super().__init__()
+        self.layer = torch.nn.Sequential()
+        self.layer.add_module("GRL", GRL(float(hp.Train.Adversarial_Speaker_Weight)))
+        cin, index = hp.Prosody_Encoder.Size, 0
+        for index, ch in enumerate(hp.Speaker_Classifier_GR.Channels):
+            conv = torch.nn.Conv1d(cin, ch, 1)
+            torch.nn.init.kaiming_uniform_(conv.weight, nonlinearity="relu")            # Modules.py:983-1003, w_init_gain 'relu'
+            torch.nn.init.zeros_(conv.bias)
+            self.layer.add_module(f"Hidden_{index}", conv)
+            self.layer.add_module(f"ReLU_{index}", torch.nn.ReLU())
+            cin = ch
+        out = torch.nn.Conv1d(cin, hp.Speaker_Embedding.Num_Speakers, 1)
+        torch.nn.init.xavier_uniform_(out.weight, gain=torch.nn.init.calculate_gain("linear"))
+        torch.nn.init.zeros_(out.bias)
+        self.layer.add_module(f"Output_{index}", out)
+
+    def forward(self, x):
+        return self.layer(x.unsqueeze(2)).squeeze(2)
+
+
+class Pitch_Interpolater(torch.nn.Module):
+    """Modules.py:387-405: per utterance, the first base_length pitch values linearly interpolated (align_corners) to new_length, zero-padded
+    to `max_length` (default: the longest, read back from the device like the reference's torch.max)."""
+
+    def forward(self, pitches, base_lengths, new_lengths, max_length=None):
+        T = int(max_length) if max_length is not None else int(torch.max(new_lengths))
+        out = pitches.new_zeros(pitches.shape[0], T)
+        for b, (bl, nl) in enumerate(zip(base_lengths.tolist(), new_lengths.tolist())):
+            out[b, :nl] = torch.nn.functional.interpolate(pitches[b, :bl].view(1, 1, -1), size=nl, mode="linear", align_corners=True).view(-1)
+        return out

@@ -136,6 +136,8 @@ int glowtts_pack_weight_batched(const float *w, int batch, int O, int I, int tap
 #define GLOWTTS_IO_OUT0_BF16 4
 #define GLOWTTS_F_DROPOUT 512  /* LINEAR: dropout(p = drop_p, seed) after the optional ReLU, before residual / mask */
 #define GLOWTTS_F_COLMASK 256  /* LINEAR: zero columns n >= ncols_valid[batch]  (attention mask, Modules.py:102) */
+#define GLOWTTS_F_COND_ROWS 1024 /* GATE: `cond` holds one row per ACTIVATION row, [rows][ldcond] (per-frame conditioning: the GR-mode
+                                  * pitch term, Modules.py:867-869, summed with the per-utterance speaker / prosody terms by the caller) */
 
 typedef struct glowtts_conv_args {
     const float *a;  int64_t lda;      /* A rows (floats per row = lda) */
@@ -154,7 +156,8 @@ typedef struct glowtts_conv_args {
     const float *rowmask;              /* [rows] 1 = valid frame */
     const float *cond; int64_t ldcond; /* GATE: per-utterance conditioning [B][ldcond], original order */
     float *out0; int64_t ld0;
-    float *out1; int64_t ld1;
+    float *out1; int64_t ld1;          /* (DGATE: optional d conditioning [B][ld1], original order, accumulated with atomic adds BEFORE the
+                                        *  dropout mask is applied to the gate gradients - zero it first) */
     const float *in0; int64_t ldi0;
     /* batched problems (gridDim.z): `rows` rows per problem; element strides between problems (0 = shared) */
     int batch;
@@ -319,6 +322,7 @@ typedef struct glowtts_flow_params {
     glowtts_packed start_t, in_t[GLOWTTS_MAX_WN_LAYERS], rs_t[GLOWTTS_MAX_WN_LAYERS], end_t;  /* transposed (backward only) */
     const float *b_start, *b_in[GLOWTTS_MAX_WN_LAYERS], *b_rs[GLOWTTS_MAX_WN_LAYERS], *b_end; /* biases, original order */
     const float *cond; int64_t ldcond;    /* optional conditioning [B][ldcond]; layer l reads cond + l*2H   Modules.py:863-866 */
+    int cond_rows;                        /* 1: cond is per ROW, [R][ldcond] (forward / inverse only; GR-mode pitch, Modules.py:867-869) */
 } glowtts_flow_params;
 
 typedef struct glowtts_flow_acts {        /* rows tensors, R = B*(T+2*PAD) rows */
@@ -351,7 +355,7 @@ typedef struct glowtts_flow_grads {       /* backward outputs; weight grads are 
     float *dw_in[GLOWTTS_MAX_WN_LAYERS], *db_in[GLOWTTS_MAX_WN_LAYERS];   /* [2H][H][k], [2H] */
     float *dw_rs[GLOWTTS_MAX_WN_LAYERS], *db_rs[GLOWTTS_MAX_WN_LAYERS];   /* [2H|H][H][1], [2H|H] */
     float *dw_end, *db_end;               /* [C][H][1], [C] */
-    float *dcond;                         /* [B][ldcond] or NULL: grad of the conditioning (overwritten per layer slice) */
+    float *dcond;                         /* [B][ldcond] or NULL: grad of the conditioning, ACCUMULATED (zero it first) */
     float *douts_bf;                      /* act_bf16 only (else NULL): [R][ldo] bf16 copy of douts, scratch (End data gradient operand) */
     /* fusion across flows (backward runs flow F-1 .. 0): */
     int coupling_done;                    /* 1: the previous call already applied THIS flow's coupling backward (dx, douts, douts_bf are ready) */

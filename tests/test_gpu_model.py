@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import glowtts_ref as O
-from helpers import load_case, tiny_cfg, tiny_hp_dict
+from helpers import load_case, tiny_cfg, tiny_hp_dict  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -24,7 +24,10 @@ def build(mode, precision, sd):
     return model.cuda().eval()
 
 
-@pytest.mark.parametrize("mode,fname", [("Vanilla", "tiny_vanilla.npz"), ("SE", "tiny_se.npz")])
+ALL_MODES = [("Vanilla", "tiny_vanilla.npz"), ("SE", "tiny_se.npz"), ("PE", "tiny_pe.npz"), ("GR", "tiny_gr.npz")]
+
+
+@pytest.mark.parametrize("mode,fname", ALL_MODES)
 def test_state_dict_keys_match_reference(mode, fname):
     from glow_tts_amd.hparams import Recursive_Parse
     from glow_tts_amd.modules import GlowTTS
@@ -36,14 +39,19 @@ def test_state_dict_keys_match_reference(mode, fname):
         assert tuple(mine[k].shape) == tuple(sd[k].shape), k
 
 
-@pytest.mark.parametrize("mode,fname", [("Vanilla", "tiny_vanilla.npz"), ("SE", "tiny_se.npz")])
+@pytest.mark.parametrize("mode,fname", ALL_MODES)
 def test_train_forward_losses_grads_f32(mode, fname):
+    """Every Mode of Hyper_Parameters.yaml:17-18 against the golden vectors the reference produced in that mode: the 8 outputs of
+    GlowTTS.forward (Modules.py:50-126; GR: also classified_Speakers), MLE + duration (+ speaker CE, Train.py:213-216) losses and
+    every parameter gradient - PE through the GST prosody encoder, GR through the gradient-reversal classifier and the per-frame pitch
+    conditioning of the WaveNet (Modules.py:867-869)."""
     from glow_tts_amd.modules import MLE_Loss
     sd, grads, r = load_case(fname)
     model = build(mode, "f32", sd)
     t = lambda k: torch.from_numpy(r[k]).cuda()
     spk = t("speakers") if "speakers" in r else None
-    z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, attn, _ = model(t("tokens"), t("token_lengths"), t("mels"), t("mel_lengths"), spk, None, None)
+    pit = t("pitches") if "pitches" in r else None
+    z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, attn, classified = model(t("tokens"), t("token_lengths"), t("mels"), t("mel_lengths"), spk, None, pit)
     torch.cuda.synchronize()
     assert np.array_equal(attn.cpu().numpy().astype(np.int8), r["attn"]), "alignment differs from the reference"
     for got, key, tol in [(z, "z", 1e-4), (mel_mean, "mel_mean", 1e-4), (mel_log_std, "mel_log_std", 1e-4), (log_dur, "log_dur", 1e-4),
@@ -53,8 +61,16 @@ def test_train_forward_losses_grads_f32(mode, fname):
     mle = MLE_Loss(model.hp)(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=t("mel_lengths"))
     length = torch.nn.functional.mse_loss(log_dur, log_dur_t)
     assert abs(mle.item() - float(r["mle"])) <= 1e-4 and abs(length.item() - float(r["length"])) <= 1e-4      # NLL within 1e-3 (north_star)
+    total = mle + length
+    if mode == "GR":
+        assert classified is not None and (classified.detach().cpu() - torch.from_numpy(r["classified"])).abs().max() <= 1e-4
+        ce = torch.nn.functional.cross_entropy(classified, spk)                                                    # Train.py:213-216
+        assert abs(ce.item() - float(r["ce"])) <= 1e-4
+        total = total + ce
+    else:
+        assert classified is None
     model.zero_grad()
-    (mle + length).backward()
+    total.backward()
     torch.cuda.synchronize()
     worst = 0.0
     for k, p in model.named_parameters():
@@ -68,6 +84,53 @@ def test_train_forward_losses_grads_f32(mode, fname):
     print("worst relative grad error", worst)
 
 
+def test_ge2e_mode_takes_precomputed_dvectors():
+    """Speaker_Embedding.Type 'GE2E' (BASELINE config 4; Modules.py:30-35, 75-77): the GE2E LSTM is an un-vendored submodule of the
+    reference, so the L2-normalised d-vectors [B, Embedding_Size] arrive in `mels_for_ge2e`, detached.  Same weights as the SE golden model
+    without its LUT; checked against the oracle's float-`speakers` path; reference-style checkpoints that still carry `layer_Dict.GE2E.*`
+    keys load strictly (those keys are dropped, modules._drop_ge2e_keys)."""
+    from glow_tts_amd.hparams import Recursive_Parse
+    from glow_tts_amd.modules import GlowTTS, MLE_Loss
+    sd, _, r = load_case("tiny_se.npz")
+    sd = {k: v for k, v in sd.items() if k != "layer_Dict.LUT.weight"}
+    sd["layer_Dict.GE2E.layer_Dict.LSTM.weight_ih_l0"] = torch.zeros(4, 4)             # what a reference GE2E checkpoint also holds
+    hp = tiny_hp_dict("SE")
+    hp["Speaker_Embedding"]["Type"] = "GE2E"
+    hp["HIP_Precision"] = "f32"
+    model = GlowTTS(Recursive_Parse(hp))
+    missing, unexpected = model.load_state_dict(dict(sd), strict=True)
+    assert not missing and not unexpected
+    for f in model.layer_Dict["Decoder"].layer_Dict["Flows"]:
+        f.layers[0].initialized = True
+    model = model.cuda().eval()
+    t = lambda k: torch.from_numpy(r[k])
+    g = torch.Generator().manual_seed(5)
+    dvec = torch.randn(3, 16, generator=g)
+    dvec = (dvec / dvec.norm(dim=1, keepdim=True)).requires_grad_(True)
+    dv_gpu = dvec.detach().cuda().requires_grad_(True)
+    out = model(t("tokens").cuda(), t("token_lengths").cuda(), t("mels").cuda(), t("mel_lengths").cuda(), None, dv_gpu, None)
+    z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, attn, _ = out
+    loss = MLE_Loss(model.hp)(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=t("mel_lengths").cuda()) + \
+        torch.nn.functional.mse_loss(log_dur, log_dur_t)
+    loss.backward()
+    torch.cuda.synchronize()
+    cfg = tiny_cfg("SE")
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items() if "GE2E" not in k}
+    o = O.forward_train(sdg, cfg, t("tokens"), t("token_lengths"), t("mels"), t("mel_lengths"), dvec)
+    omle, olen = O.train_losses(o, t("mel_lengths"), cfg)
+    (omle + olen).backward()
+    assert torch.equal(attn.cpu(), o["attn"])
+    assert (z.detach().cpu() - o["z"].detach()).abs().max() <= 1e-4 and (log_dur.detach().cpu() - o["log_dur"].detach()).abs().max() <= 1e-4
+    assert abs(loss.item() - (omle + olen).item()) <= 1e-4
+    assert dv_gpu.grad is None and dvec.grad is None                                     # detached (Modules.py:77)
+    for k, p in model.named_parameters():
+        want = sdg[k].grad
+        if want is None:
+            continue
+        err = (p.grad.cpu() - want).abs().max().item() / (want.abs().max().item() + 1e-5)
+        assert err < 5e-3, (k, err)
+
+
 def test_train_forward_bf16_nll_within_1e3():
     from glow_tts_amd.modules import MLE_Loss
     sd, _, r = load_case("tiny_vanilla.npz")
@@ -79,13 +142,17 @@ def test_train_forward_bf16_nll_within_1e3():
     assert (z.detach().cpu() - torch.from_numpy(r["z"])).abs().max() <= 5e-2
 
 
-@pytest.mark.parametrize("mode,fname", [("Vanilla", "tiny_vanilla.npz"), ("SE", "tiny_se.npz")])
+@pytest.mark.parametrize("mode,fname", ALL_MODES)
 def test_inference_matches_reference(mode, fname):
+    """GlowTTS.inference (Modules.py:128-204) in every mode: PE / GR take the prosody reference mels, GR interpolates the pitch track to
+    the predicted length (Pitch_Interpolater, :193-196) and feeds it to the inverse flows."""
     sd, _, r = load_case(fname)
     model = build(mode, "f32", sd)
     t = lambda k: torch.from_numpy(r[k]).cuda()
     spk = t("speakers") if "speakers" in r else None
-    mels, lengths, attn = model.inference(t("tokens"), t("token_lengths"), None, None, spk, None, None, None,
+    pm, pl = (t("mels"), t("mel_lengths")) if mode in ("PE", "GR") else (None, None)
+    pit, pitl = (t("pitches"), t("mel_lengths")) if mode == "GR" else (None, None)
+    mels, lengths, attn = model.inference(t("tokens"), t("token_lengths"), pm, pl, spk, None, pit, pitl,
                                           noise_scale=float(r["noise_scale"]), length_scale=t("length_scale"), noises=t("noise"))
     torch.cuda.synchronize()
     assert torch.equal(lengths.cpu(), torch.from_numpy(r["inf_lengths"]))
