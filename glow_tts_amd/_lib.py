@@ -9,6 +9,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglowtts_hip.so")
+# tools/ab.sh (A/B measurements of launch heuristics) points this at the experiment build `make -C glow_tts_amd/csrc tools`, whose
+# GLOWTTS_* switches are live; the product library above has them compiled to their defaults and reads no environment variable.
+if os.environ.get("GLOWTTS_LIB_PATH"):
+    LIB_PATH = os.environ["GLOWTTS_LIB_PATH"]
 _lib = None
 
 c_int, c_float, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p

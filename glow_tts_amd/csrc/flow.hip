@@ -7,6 +7,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include "../../include/glowtts_hip.h"
+#include "tunable.h"
 
 namespace {
 
@@ -90,7 +91,7 @@ int coupling_net(const Ctx& c, const float* xsrc, float* xdst, bool reverse, boo
         a.out0 = xdst + c.C2; a.ld0 = c.d->C;
         a.out1 = keep ? A->outs : nullptr; a.ld1 = p->end.npad;
         // both in ONE launch when the shapes allow (bf16 storage, 192 channels): the final skip sum reaches the End conv through LDS
-        static const bool chain = [] { const char* e = getenv("GLOWTTS_CHAIN"); return !(e && e[0] == '0'); }();
+        const bool chain = GLOWTTS_TUNABLE("GLOWTTS_CHAIN", 1) != 0;
         if (chain && bf && acts && A->skip_bf && glowtts_conv_chain(&rs, &a, c.s) == GLOWTTS_OK) continue;
         CHECK(glowtts_conv_cl(&rs, c.s));
         CHECK(glowtts_conv_cl(&a, c.s));
@@ -223,8 +224,7 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
             // conditioning gradient (autograd of Modules.py:863-866): per-utterance sums of the gate gradients before the dropout mask
             if (g->dcond && p->cond) { q.out1 = g->dcond + (int64_t)l * 2 * H; q.ld1 = p->ldcond; }
             if (last) {
-                static const bool chain = [] { const char* e = getenv("GLOWTTS_CHAIN"); const char* f = getenv("GLOWTTS_CHAIN_BWD");
-                                               return !(e && e[0] == '0') && !(f && f[0] == '0'); }();
+                const bool chain = GLOWTTS_TUNABLE("GLOWTTS_CHAIN", 1) != 0 && GLOWTTS_TUNABLE("GLOWTTS_CHAIN_BWD", 1) != 0;
                 if (!(chain && dbf && glowtts_conv_chain(&endq, &q, stream) == GLOWTTS_OK)) {
                     CHECK(glowtts_conv_cl(&endq, stream));
                     CHECK(glowtts_conv_cl(&q, stream));

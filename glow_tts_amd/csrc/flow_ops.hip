@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "../../include/glowtts_hip.h"
+#include "tunable.h"
 
 namespace {
 
@@ -597,13 +598,13 @@ extern "C" int glowtts_actnorm_stats(const float* x, const float* rowmask, float
 // the float4 form needs C % 8 == 0, C / 8 <= 256 and 16-byte aligned rows (GLOWTTS_AN_WIDE=0 forces the 8-byte form)
 static bool an_bwd_wide(int C, const float* dz, const float* dx, const float* x, int ldo)
 {
-    static const int on = [] { const char* e = getenv("GLOWTTS_AN_WIDE"); return e ? atoi(e) : 1; }();
+    const int on = GLOWTTS_TUNABLE("GLOWTTS_AN_WIDE", 1);
     return on && (C % 8) == 0 && !((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(x)) & 15) && (ldo % 4) == 0;
 }
 // rows per block of actnorm_inv_bwd_kernel: small blocks (36 rows = three passes of the float4 kernel, 360 blocks at the bench size; 16..48
 // measure the same within noise, 64 was 4 % of a step slower) keep every CU busy; the per-block partials are
 // reduced later by colstats_final_kernel / glowtts_colsum_batched
-static int an_bwd_rpb() { static const int v = [] { const char* e = getenv("GLOWTTS_AN_RPB"); const int x = e ? atoi(e) : 36; return x < 16 ? 16 : x; }(); return v; }
+static int an_bwd_rpb() { const int x = GLOWTTS_TUNABLE("GLOWTTS_AN_RPB", 36); return x < 16 ? 16 : x; }
 extern "C" int64_t glowtts_actnorm_bwd_blocks(int64_t rows) { return (rows + an_bwd_rpb() - 1) / an_bwd_rpb(); }
 extern "C" int64_t glowtts_actnorm_stats_scratch_floats(int64_t rows, int C) { return ((rows + 15) / 16) * (2 * (int64_t)C + 16); }
 

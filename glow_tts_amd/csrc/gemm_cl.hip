@@ -29,6 +29,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "../../include/glowtts_hip.h"
+#include "tunable.h"
 #include "launch_log.h"
 
 namespace {
@@ -181,7 +182,11 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
 {
     constexpr bool EX = sizeof(CT) == 4;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int abl = p.flags >> 16;                            // debug ablation bits (tools/bench_conv.py)
+#ifdef GLOWTTS_TOOLS
+    const int abl = p.flags >> 16;                            // debug ablation bits (tools/bench_conv.py; tools builds only)
+#else
+    constexpr int abl = 0;
+#endif
     // dropout seed: the device word (graph replays) is read here, not at kernel start, where the scalar load would sit in front
     // of the first tile loads
     uint32_t seed = p.seed;
@@ -841,7 +846,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
         }
         if constexpr (!T1) sstore_a(ra[0], 0, ss);
     };
-    const int abl = p.flags >> 16;                            // debug ablation bits (tools/bench_conv.py)
+#ifdef GLOWTTS_TOOLS
+    const int abl = p.flags >> 16;                            // debug ablation bits (tools/bench_conv.py; tools builds only)
+#else
+    constexpr int abl = 0;
+#endif
     // tools/build_tl.sh builds with GLOWTTS_TIMELINE: thread 0 of every workgroup logs shader-clock stamps into the
     // buffer passed through p.ncols_valid ([workgroups][32] int64) - never defined in the product build
 #ifdef GLOWTTS_TIMELINE
@@ -1038,7 +1047,11 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
         });
     };
 
+#ifdef GLOWTTS_TOOLS
     const int abl = p.flags >> 16;
+#else
+    constexpr int abl = 0;
+#endif
     // Three LDS stages, stages ss+1 and ss+2 in flight while stage ss is multiplied.  s_waitcnt takes an immediate, the number of
     // DMAs a wave has outstanding per stage (nmine) is uniform but only known at run time: dispatch once per wait.
     auto wait_keep = [&](int keep) __attribute__((always_inline)) {        // wait until at most `keep` of this wave's DMAs are outstanding, then barrier
@@ -1266,7 +1279,7 @@ int num_cus()
 // is the LDS-DMA kernel applicable to this problem?
 bool dma_ok(const glowtts_conv_args& a)
 {
-    static const bool enabled = [] { const char* e = getenv("GLOWTTS_DMA"); return !(e && e[0] == '0'); }();
+    const bool enabled = GLOWTTS_TUNABLE("GLOWTTS_DMA", 1) != 0;
     if (!(enabled && a.precision == GLOWTTS_BF16 && (a.io_flags & GLOWTTS_IO_A_BF16) && a.apro == GLOWTTS_APRO_NONE &&
           a.batch <= 1 && a.kchunks * 32 == a.ca && (a.npad % 64) == 0 && a.rows >= 128)) return false;
     if (a.taps > 1) return !a.a2;
@@ -1280,7 +1293,7 @@ bool dma_ok(const glowtts_conv_args& a)
 // 7.13 vs 7.00 ms/step.  Kept behind GLOWTTS_DMA_NI=3 for other shapes.
 inline bool dma_prefers_96(const glowtts_conv_args& a)
 {
-    static const int force = [] { const char* e = getenv("GLOWTTS_DMA_NI"); return e ? atoi(e) : 0; }();
+    const int force = GLOWTTS_TUNABLE("GLOWTTS_DMA_NI", 0);
     return force == 3 && (a.npad % 96) == 0;
 }
 
@@ -1288,12 +1301,12 @@ template <int EPI, int TAPS, int NI = 2>
 int launch_dma(const glowtts_conv_args& a, hipStream_t s)
 {
     // waves per workgroup: all tiles resident at once (one workgroup per CU) if possible, else the fewest rounds
-    static const int force = [] { const char* e = getenv("GLOWTTS_DMA_WAVES"); return e ? atoi(e) : 0; }();
+    const int force = GLOWTTS_TUNABLE("GLOWTTS_DMA_WAVES", 0);
     // GLOWTTS_DMA_LOADERS = 1 | 2: that many extra waves per workgroup do all the LDS-DMA staging (wave specialisation)
-    static const int nload = [] { const char* e = getenv("GLOWTTS_DMA_LOADERS"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 4) ? v : 0; }();
+    const int nload_ = GLOWTTS_TUNABLE("GLOWTTS_DMA_LOADERS", 0), nload = (nload_ >= 0 && nload_ <= 4) ? nload_ : 0;
     // GLOWTTS_DMA_CUS: CUs the chain kernels plan for (default: all).  Leaving a few CUs to the concurrently running encoder stream
     // can pay: these kernels are latency-bound, a fatter workgroup on fewer CUs costs them little.
-    static const int cu_budget = [] { const char* e = getenv("GLOWTTS_DMA_CUS"); return e ? atoi(e) : 0; }();
+    const int cu_budget = GLOWTTS_TUNABLE("GLOWTTS_DMA_CUS", 0);
     const int gy = a.npad / (NI * 32), ncu = (cu_budget >= 32 && cu_budget <= num_cus()) ? cu_budget : num_cus(), frags = (a.rows + 31) / 32;
     int best = 4; long best_cost = -1;
     const int WMAX = (TAPS == 1 ? 10 : 16) - nload;       // three LDS stages must fit 160 KiB; at most 16 waves
@@ -1307,7 +1320,7 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
     // pipelines drift apart, so one's epilogue (VALU / memory) runs under another's loads and MFMAs: 6.31 -> 6.25 and 6.42 -> 6.36
     // ms/step.  Only while every workgroup is resident at once; otherwise the round-count model above decides.  The same idea for the
     // k-tap convs (7 waves, two per CU) was box-dependent: -0.07 ms on one, +0.05 on the other; not adopted.
-    static const int coop = [] { const char* e = getenv("GLOWTTS_DMA_COOP"); return e ? atoi(e) : 1; }();
+    const int coop = GLOWTTS_TUNABLE("GLOWTTS_DMA_COOP", 1);
     if (coop && !nload && TAPS == 1) {
         const long tiles = (long)((frags + 3) / 4) * gy;
         if (tiles > ncu && tiles <= 3L * ncu) best = 4;
@@ -1319,21 +1332,21 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
         const long tiles = (long)((frags + 6) / 7) * gy;
         if (tiles <= ncu && 2 * tiles >= ncu) best = 7;
     }
-    static const int force_t1 = [] { const char* e = getenv("GLOWTTS_DMA_WAVES_T1"); return e ? atoi(e) : 0; }();
+    const int force_t1 = GLOWTTS_TUNABLE("GLOWTTS_DMA_WAVES_T1", 0);
     if (force >= 4 && force <= WMAX) best = force;
-    static const int force_t5 = [] { const char* e = getenv("GLOWTTS_DMA_WAVES_T5"); return e ? atoi(e) : 0; }();
+    const int force_t5 = GLOWTTS_TUNABLE("GLOWTTS_DMA_WAVES_T5", 0);
     if (TAPS == 1 && force_t1 >= 4 && force_t1 <= WMAX) best = force_t1;
     if (TAPS > 1 && force_t5 >= 4 && force_t5 <= WMAX) best = force_t5;
-    static const int force_t1n = [] { const char* e = getenv("GLOWTTS_DMA_WAVES_T1_NARROW"); return e ? atoi(e) : 0; }();      // 1x1 convs with <= 192 columns
+    const int force_t1n = GLOWTTS_TUNABLE("GLOWTTS_DMA_WAVES_T1_NARROW", 0);      // 1x1 convs with <= 192 columns
     if (TAPS == 1 && gy <= 3 && force_t1n >= 4 && force_t1n <= WMAX) best = force_t1n;
-    static const int force_t5n = [] { const char* e = getenv("GLOWTTS_DMA_WAVES_T5_NARROW"); return e ? atoi(e) : 0; }();      // k-tap convs with <= 192 columns
+    const int force_t5n = GLOWTTS_TUNABLE("GLOWTTS_DMA_WAVES_T5_NARROW", 0);      // k-tap convs with <= 192 columns
     if (TAPS > 1 && gy <= 3 && force_t5n >= 4 && force_t5n <= WMAX) best = force_t5n;
     const int BM = best * 32;
     const int nat = TAPS == 1 ? DMA1_CPS : 1, sub = TAPS == 1 ? DMA1_CPS : TAPS;
     // LDS stages: 2 by default.  Alone, the kernel is as fast with 2 as with 3 (17.7 us either way); in the training step the smaller
     // footprint (83 instead of 124 KiB at 10 waves) lets encoder-stream workgroups share the CU: 7.1 vs 7.35 ms/step.
-    static const int nst0 = [] { const char* e = getenv("GLOWTTS_DMA_STAGES"); const int v = e ? atoi(e) : 2; return v == 3 ? 3 : 2; }();
-    static const int nst_narrow = [] { const char* e = getenv("GLOWTTS_DMA_STAGES_NARROW"); const int v = e ? atoi(e) : 0; return v; }();
+    const int nst0 = GLOWTTS_TUNABLE("GLOWTTS_DMA_STAGES", 2) == 3 ? 3 : 2;
+    const int nst_narrow = GLOWTTS_TUNABLE("GLOWTTS_DMA_STAGES_NARROW", 0);
     const int nst = (TAPS > 1 && gy <= 3 && (nst_narrow == 2 || nst_narrow == 3)) ? nst_narrow : nst0;
     const int lds = (nload ? 2 : nst) * ((nat * ((BM + TAPS - 1 + 15) >> 4) + sub * (NI * 2)) * 1024);     // three stages: <= 159 KiB (16 waves x 5 taps, 10 waves 1x1)
     static bool attr_done = false;
@@ -1364,8 +1377,8 @@ int launch_tile(const glowtts_conv_args& a, hipStream_t s)
     // Tile choice.  These GEMMs are short (K <= 1920) and their operands come from L2, so a workgroup spends most of its
     // life waiting for a load phase or in its epilogue: what matters is how many workgroups are co-resident per CU to
     // overlap that, not the tile's arithmetic intensity.  GLOWTTS_TILE = 0: 128x128, 1: 64x128, 2: 128x64, 3: 64x64.
-    static const int force = [] { const char* e = getenv("GLOWTTS_TILE"); return e ? atoi(e) : -1; }();
-    static const int force_t1 = [] { const char* e = getenv("GLOWTTS_TILE_T1"); return e ? atoi(e) : -1; }();
+    const int force = GLOWTTS_TUNABLE("GLOWTTS_TILE", -1);
+    const int force_t1 = GLOWTTS_TUNABLE("GLOWTTS_TILE_T1", -1);
     int cfg = (TAPS == 1 && force_t1 >= 0) ? force_t1 : force;
     if (cfg < 0) cfg = (TAPS == 1) ? 1 : 2;   // measured at B = 32: 128 x 64 for the k-tap convs (tools/bench_conv.py), 64 x 128 for the 1x1
                                               // convs whose wide fp32 A rows would otherwise be re-read by six N tiles (bench.py: 21.9 -> 20.3 ms)

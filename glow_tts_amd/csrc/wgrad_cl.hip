@@ -20,6 +20,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include "../../include/glowtts_hip.h"
+#include "tunable.h"
 #include "launch_log.h"
 
 namespace {
@@ -406,7 +407,7 @@ int launch_w(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const
 
 }  // namespace
 
-static int xcd_mode() { static const int v = [] { const char* e = getenv("GLOWTTS_WGRAD_XCD"); return e ? atoi(e) : 1; }(); return v; }
+static int xcd_mode() { return GLOWTTS_TUNABLE("GLOWTTS_WGRAD_XCD", 1); }
 
 extern "C" int glowtts_wgrad_cl(const glowtts_wgrad_args* args, void* stream)
 {

@@ -66,7 +66,7 @@ def case():
     mle, length = O.train_losses(out, ml, cfg)
     (mle + length).backward()
     grads = {k: v.grad for k, v in sdg.items() if v.grad is not None}
-    return dict(sd=sd, cfg=cfg, tokens=tokens, tl=tl, mels=mels, ml=ml, out={k: v.detach() for k, v in out.items()}, mle=mle.item(),
+    return dict(sd=sd, cfg=cfg, tokens=tokens, tl=tl, mels=mels, ml=ml, out={k: v.detach() for k, v in out.items() if v is not None}, mle=mle.item(),
                 length=length.item(), grads=grads)
 
 
