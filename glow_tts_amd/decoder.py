@@ -8,7 +8,6 @@ glowtts_decoder_logdet).  This file only marshals pointers: weights arrive as *s
 the kernels.  There is no CPU fallback.
 """
 import ctypes
-import os
 
 import torch
 
@@ -101,6 +100,11 @@ _WSTREAM = {}
 # backward queues the tail's launches here instead of issuing them; `flush_tail_wgrads()` issues them (bench.py captures that as a
 # second hipGraph).  The gradient tensors of the tail classes exist (autograd has already handed them to .grad) but hold no data until then.
 TAIL = {"defer": False, "pending": []}
+# Measured design choices that tools / tests may flip programmatically (never read from the environment: DESIGN.md section 5 has the numbers).
+#   wgrad_wide: 16-byte staging items in the weight-gradient kernel; fuse_coupling_bwd: the next flow's coupling backward rides in the
+#   ActNorm / 1x1 backward pass; wgrad_split: weight gradients in n segments on a second stream (1 = one grouped launch per class);
+#   act_bf16: WaveNet state / gates / gate gradients stored as bf16 in bf16 precision
+TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True}
 TAIL_STACKS = ("start_g", "start_v", "start_b", "rs_g", "rs_v", "rs_b", "rsl_g", "rsl_v", "rsl_b", "end_w", "end_b")
 
 
@@ -136,8 +140,7 @@ class WgradGroup:
         self.jobs, self.segments, self._tiles, self._start = [], [], 0, 0
         self.table = None
         # 16-byte staging items (glowtts_wgrad WIO_WIDE): both operands bf16, no prologue, and every job 8-channel / 16-byte aligned
-        self._wide = io_flags in (0, ops.WIO_DY_BF16 | ops.WIO_X_BF16) and xpro == ops.APRO_NONE and precision == ops.BF16 and \
-            os.environ.get("GLOWTTS_WGRAD_WIDE", "1") not in ("0", "2" if io_flags == 0 else "0")
+        self._wide = io_flags in (0, ops.WIO_DY_BF16 | ops.WIO_X_BF16) and xpro == ops.APRO_NONE and precision == ops.BF16 and TUNE["wgrad_wide"]
 
     def add(self, dy, lddy, m, x, ldx, ca, dw, dbias, perm=ops.PERM_NONE, perm_h=0):
         j = WgradJob()
@@ -210,8 +213,8 @@ class DecoderConfig:
         self.precision = precision
         assert n_layers <= MAXL and self.C % 4 == 0 and hidden % 4 == 0
         # bf16 precision: the GEMM-only activations (WaveNet state, gates, gate gradients) live in HBM as bf16
-        # (glowtts_flow_dims.act_bf16); GLOWTTS_ACT_BF16=0 keeps them fp32 (same MFMA inputs, twice the traffic)
-        self.act_bf16 = precision == ops.BF16 and hidden % 8 == 0 and os.environ.get("GLOWTTS_ACT_BF16", "1") != "0"
+        # (glowtts_flow_dims.act_bf16); TUNE["act_bf16"] = False keeps them fp32 (same MFMA inputs, twice the traffic)
+        self.act_bf16 = precision == ops.BF16 and hidden % 8 == 0 and TUNE["act_bf16"]
         self.act_dtype = torch.bfloat16 if self.act_bf16 else torch.float32
 
 
@@ -520,7 +523,7 @@ class DecoderFunction(torch.autograd.Function):
         # two grouped launches (k-tap problems, 1x1 problems) whose tiles fill the chip without split-K or atomics
         douts = torch.empty(F_, R, prep.ldo, device=dev)           # (pad columns are zeroed by the coupling backward kernel)
         douts_bf = torch.empty(R, prep.ldo, device=dev, dtype=torch.bfloat16) if cfg.act_bf16 else None      # bf16 copy, reused by every flow
-        fuse = os.environ.get("GLOWTTS_FUSE_COUPLING_BWD", "1") != "0"
+        fuse = TUNE["fuse_coupling_bwd"]
         dins = (torch.empty if prep.ldin == 2 * H else torch.zeros)(F_, Lw, R, prep.ldin, device=dev, dtype=cfg.act_dtype)    # only pad columns need zeros
         dskip = torch.empty(F_, R, H, device=dev, dtype=cfg.act_dtype)
         dh0 = torch.empty(F_, R, H, device=dev)                                       # d h0: fp32 (feeds the fp32 Start conv gradients)
@@ -551,9 +554,9 @@ class DecoderFunction(torch.autograd.Function):
                 gk.add(dins[f, l].data_ptr(), prep.ldin, prep.ldin, buf.hs[f, l].data_ptr(), H, H, G["w_in"][f, l].data_ptr(), G["b_in"][f, l].data_ptr(),
                        perm=ops.PERM_PAIR, perm_h=H)
             g1.add(dh0[f].data_ptr(), H, H, buf.xmid[f].data_ptr(), C, C2, G["w_start"][f].data_ptr(), G["b_start"][f].data_ptr())
-            # GLOWTTS_WGRAD_SPLIT=n: weight gradients in n segments, each launched on a second stream as soon as its flows' chain is
+            # TUNE["wgrad_split"] = n: weight gradients in n segments, each launched on a second stream as soon as its flows' chain is
             # done (default 1: one launch per class after the chain; see DESIGN.md for the measurements)
-            nseg = int(os.environ.get("GLOWTTS_WGRAD_SPLIT", "1"))
+            nseg = int(TUNE["wgrad_split"])
             if nseg > 1:
                 per = -(-len(order) // nseg)
                 pos = order.index(f) + 1

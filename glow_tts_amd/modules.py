@@ -5,7 +5,6 @@ parameters from ./Hyper_Parameters.yaml), call signatures, return tuples, attrib
 HIP library (glow_tts_amd/csrc) or, for the parts still marked interim in DESIGN.md, in PyTorch-ROCm device ops.
 """
 import math
-import os
 
 import torch
 
@@ -215,7 +214,7 @@ class GlowTTS(torch.nn.Module):
         self._enc_cache = {}              # encoder leaf stacks (fused Query/Key/Value weights)
         self._register_state_dict_hook(_unshare_state_dict)
         self._register_load_state_dict_pre_hook(_drop_ge2e_keys)
-        self.overlap_encoder = os.environ.get("GLOWTTS_ENCODER_OVERLAP", "1") == "1"
+        self.overlap_encoder = True       # the text encoder runs on its own HIP stream beside the flow decoder (set False to serialise them)
 
     # ---------------------------------------------------------------- helpers
     def __getstate__(self):

@@ -62,7 +62,13 @@ class Prosody_Encoder(torch.nn.Module):
         for i in range(self.n_conv):
             x = self.layer_Dict[f"Conv_{i}"](x)
         x = x.reshape(x.size(0), x.size(1) * x.size(2), x.size(3))
-        x = self.layer_Dict["GRU"](x.transpose(2, 1))[0]                                  # [B, T', G]
+        if not self.training and torch.is_grad_enabled() and x.requires_grad:
+            # MIOpen's fused RNN has no backward in eval mode ("miopen RNN backward can only be called in training mode"): gradients
+            # through an eval()-mode model take torch's native GRU cell instead (same arithmetic, Modules.py:371)
+            with torch.backends.cudnn.flags(enabled=False):
+                x = self.layer_Dict["GRU"](x.transpose(2, 1))[0]
+        else:
+            x = self.layer_Dict["GRU"](x.transpose(2, 1))[0]                              # [B, T', G]
         idx = (torch.ceil(lengths / float(math.prod(self.strides))).long() - 1).clamp_min(0)   # Modules.py:373
         x = x[torch.arange(x.size(0), device=x.device), idx]                               # [B, G]
         keys = torch.tanh(self.gst_Tokens).unsqueeze(0).expand(x.size(0), -1, -1)
