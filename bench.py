@@ -1,15 +1,21 @@
 #!/usr/bin/env python
 """Headline benchmark (BASELINE.json): mel-frames/sec of a Glow-TTS training step (forward incl. log-prior + MAS +
-losses, backward, gradient all-reduce when N > 1) on LJSpeech-shaped synthetic batches, B = 32 utterances per GPU,
-T_tokens = 120, T_mel = 800 (BASELINE config 2: Vanilla, 1xMI355X, bf16), plus MAS us/utterance.
+losses, backward, gradient all-reduce when N > 1) on LJSpeech-shaped synthetic batches, plus MAS us/utterance.
 
-    python bench.py --gpus N --steps K --warmup W
-For N > 1 the driver launches it through torch.distributed.run (one rank per GPU, RCCL).
-Prints ONE JSON line on rank 0.
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
+For N > 1 the driver launches it through torch.distributed.run (one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
+
+--config selects the BASELINE.json workload (default 2, the one the metric is quoted on):
+    2  Vanilla single-speaker, bf16, 32 utterances per GPU, 800 frames / 120 tokens
+    3  LUT speaker embedding (109 speakers, VCTK-shaped), 64 utterances over 2 GPUs  = 32 per GPU
+    4  GE2E speaker-embedding mode (pre-computed unit-norm d-vectors), 128 over 8 GPUs = 16 per GPU
+    5  PE / GST prosody-encoder mode, 256 over 8 GPUs = 32 per GPU, plus a long-form inverse-flow leg (`inverse_flow` in the JSON line:
+       GlowTTS.inference through glow_tts_amd.graph_infer.GraphedInference, 200 tokens -> ~2000 frames per utterance)
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -19,6 +25,14 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FLOP_PER_FRAME_FWD_BWD = 71.3e6      # SURVEY.md 8d / BASELINE.md: 57.05 GFLOP per 800-frame utterance (reference FlopCounterMode)
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+CONFIGS = {
+    2: dict(mode="Vanilla", spk_type="LUT", batch=32, name="BASELINE config 2: Vanilla single-speaker"),
+    3: dict(mode="SE", spk_type="LUT", batch=32, name="BASELINE config 3: LUT speaker embedding (109 speakers, VCTK-shaped; 64 utterances over 2 GPUs)"),
+    4: dict(mode="SE", spk_type="GE2E", batch=16, name="BASELINE config 4: GE2E speaker-embedding mode (pre-computed d-vectors; 128 utterances over 8 GPUs)"),
+    5: dict(mode="PE", spk_type="LUT", batch=32, name="BASELINE config 5: PE/GST prosody-encoder mode (256 utterances over 8 GPUs) + long-form inverse flow"),
+}
 
 
 def synthetic_batch(B, Tt, Tm, mel_dim, seed, device, ragged=False):
@@ -38,13 +52,25 @@ def synthetic_batch(B, Tt, Tm, mel_dim, seed, device, ragged=False):
     return tokens.to(device), tl.to(device), mels.to(device), ml.to(device)
 
 
-def build_model(precision, device):
+def conditioning_inputs(cfg, B, seed, device, hp):
+    """(speakers, mels_for_ge2e) of GlowTTS.forward for the config: LUT ids ~ U{0..108}; GE2E: unit-norm [B, 256] from N(0,1)."""
+    g = torch.Generator().manual_seed(seed + 77)
+    if cfg["mode"] != "SE":
+        return None, None
+    if cfg["spk_type"] == "LUT":
+        return torch.randint(0, int(hp.Speaker_Embedding.Num_Speakers), (B,), generator=g).to(device), None
+    v = torch.randn(B, int(hp.Speaker_Embedding.Embedding_Size), generator=g)
+    return None, (v / v.norm(dim=1, keepdim=True)).to(device)
+
+
+def build_model(precision, device, mode="Vanilla", spk_type="LUT"):
     import yaml
     from glow_tts_amd.hparams import Recursive_Parse
     from glow_tts_amd.modules import GlowTTS, MLE_Loss
     with open(os.path.join(REPO, "glow_tts_amd", "Hyper_Parameters.default.yaml")) as f:
         hp = yaml.safe_load(f)
-    hp["Mode"] = "Vanilla"
+    hp["Mode"] = mode
+    hp["Speaker_Embedding"]["Type"] = spk_type
     hp["HIP_Precision"] = precision
     hp = Recursive_Parse(hp)
     torch.manual_seed(0)
@@ -59,20 +85,22 @@ def build_model(precision, device):
     return model, MLE_Loss(hp), hp
 
 
-def train_step(model, mle_loss, batch, reducer=None, world=1):
+def forward_losses(model, mle_loss, batch, cond):
+    tokens, tl, mels, ml = batch
+    z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, _, _ = model(tokens, tl, mels, ml, cond[0], cond[1], None)
+    mle = mle_loss(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=ml)
+    length = torch.nn.functional.mse_loss(log_dur, log_dur_t)                            # Train.py:203-211
+    return mle, length
+
+
+def train_step(model, mle_loss, batch, cond, reducer=None, world=1):
     """Train.py:193-227 up to (and including) backward, plus the gradient all-reduce when data parallel.
     Data parallel: every rank scales its MLE loss (a mean over ITS frames, Modules.py:1026) by local/global frames and its
     duration MSE (a mean over its padded [B,1,Tt]) by 1/world, and gradients are SUMMED: the result is the gradient of the
     single-process loss on the global batch (tests/test_distributed_cpu.py)."""
     from glow_tts_amd.distributed import global_frame_weight
-    tokens, tl, mels, ml = batch
-    z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, _, _ = model(tokens, tl, mels, ml, None, None, None)
-    mle = mle_loss(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=ml)
-    length = torch.nn.functional.mse_loss(log_dur, log_dur_t)                            # Train.py:203-211
-    if reducer is not None:
-        loss = mle * global_frame_weight(ml.sum()) + length / world
-    else:
-        loss = mle + length
+    mle, length = forward_losses(model, mle_loss, batch, cond)
+    loss = mle * global_frame_weight(batch[3].sum()) + length / world if reducer is not None else mle + length
     model.zero_grad(set_to_none=True)
     loss.backward()
     if reducer is not None:
@@ -80,27 +108,52 @@ def train_step(model, mle_loss, batch, reducer=None, world=1):
     return mle + length
 
 
-TRAFFIC_BF16_B32 = 21.1e6    # FETCH_SIZE x 2 + WRITE_SIZE of conv_dma_kernel at B = 32 (profiles/r01_conv_pmc.txt)
-
-
-def dominant_kernel_roofline(precision, B, T, iters=30):
-    """The WaveNet In_i k=5 conv (Modules.py:861), the kernel that carries most of the FLOPs: timed alone with HIP events
-    on the launch stream.  Algorithmic FLOPs per launch = 2 * rows * 384 * 192 * 5."""
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The two hottest kernels of the step, alone: the WaveNet In_l k = 5 conv with the gate epilogue (Modules.py:861-870) and its data
+# gradient (the single largest kernel by time in profiles/*_kernel_stats.csv).  Used by the roofline leg below and by tools/pmc_conv.py.
+# ------------------------------------------------------------------------------------------------------------------------------------
+def hot_kernel_cases(precision, B, T):
+    """-> {name: dict(run, flops, alg_bytes, kernel)}; flops / bytes per launch count VALID rows only."""
     from glow_tts_amd import ops
     dev = "cuda"
     H, k = 192, 5
     R = B * (T + 4)
     prec = ops.BF16 if precision == "bf16" else ops.F32
-    bf = prec == ops.BF16                           # bf16 mode: state and gates are stored as bf16 (what the training step runs)
-    a = torch.randn(R, H, device=dev)
+    bf = prec == ops.BF16                           # bf16 mode: state, gates and gate gradients are stored as bf16 (what the step runs)
+    es = 2 if bf else 4
+    dt = torch.bfloat16 if bf else torch.float32
     w = torch.randn(2 * H, H, k, device=dev) / (H * k) ** 0.5
-    pw = ops.pack_weight(w, perm=ops.PERM_PAIR, perm_h=H, precision=prec)
     bias = torch.zeros(2 * H, device=dev)
-    if bf:
-        a = a.to(torch.bfloat16)
-    G = torch.empty(R, 2 * H, device=dev, dtype=a.dtype)
+    rowmask = torch.ones(R, device=dev)
+    flops = 2.0 * B * T * (2 * H) * H * k
+    wbytes = 2 * H * H * k * es
+    cases = {}
+    # forward: hs [R, H] -> gates [R, 2H] (+ bf16 tanh*sigmoid product [R, H])
+    a = torch.randn(R, H, device=dev).to(dt)
+    pw = ops.pack_weight(w, perm=ops.PERM_PAIR, perm_h=H, precision=prec)
+    G = torch.empty(R, 2 * H, device=dev, dtype=dt)
+    acts = torch.empty(R, H, device=dev, dtype=torch.bfloat16) if bf else None
     io = (ops.IO_A_BF16 | ops.IO_OUT0_BF16) if bf else 0
-    run = lambda: ops.conv_cl(a, pw, H, R, pad=2, epi=ops.EPI_GATE, h=H, n=2 * H, rows_per_utt=T + 4, bias=bias, out0=G, ld0=2 * H, io_flags=io)
+    cases["in_fwd"] = dict(
+        run=lambda: ops.conv_cl(a, pw, H, R, pad=2, epi=ops.EPI_GATE, h=H, n=2 * H, rows_per_utt=T + 4, bias=bias, out0=G, ld0=2 * H,
+                                out1=acts, ld1=H, io_flags=io),
+        flops=flops, alg_bytes=B * T * (H * es + 2 * H * es + (H * 2 if bf else 0)) + wbytes,
+        kernel=("conv_dma_kernel<EPI_GATE, 5>" if bf else "conv_cl_kernel<float, EPI_GATE, 5>") + " (WaveNet In_l k=5 + gate, 192->384)")
+    # data gradient: d ins [R, 2H] (PAIR-packed) -> d h [R, H] = (conv^T + d h_next) * mask
+    dins = torch.randn(R, 2 * H, device=dev).to(dt)
+    pwt = ops.pack_weight(w, transpose=True, perm=ops.PERM_PAIR, perm_h=H, precision=prec)
+    dnext = torch.randn(R, H, device=dev).to(dt)
+    dh = torch.empty(R, H, device=dev, dtype=dt)
+    io2 = (ops.IO_A_BF16 | ops.IO_IN0_BF16 | ops.IO_OUT0_BF16) if bf else 0
+    cases["in_dgrad"] = dict(
+        run=lambda: ops.conv_cl(dins, pwt, 2 * H, R, pad=2, epi=ops.EPI_LINEAR, flags=ops.F_MASK | ops.F_ADD_IN0, n=H, rows_per_utt=T + 4,
+                                rowmask=rowmask, in0=dnext, ldi0=H, out0=dh, ld0=H, io_flags=io2),
+        flops=flops, alg_bytes=B * T * (2 * H * es + H * es + H * es) + wbytes,
+        kernel=("conv_dma_kernel<EPI_LINEAR, 5>" if bf else "conv_cl_kernel<float, EPI_LINEAR, 5>") + " (WaveNet In_l data gradient, 384->192)")
+    return cases
+
+
+def time_kernel(run, iters=30):
     for _ in range(5):
         run()
     torch.cuda.synchronize()
@@ -110,16 +163,41 @@ def dominant_kernel_roofline(precision, B, T, iters=30):
         run()
     e1.record()
     torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) / 1e3 / iters
-    flops = 2.0 * B * T * (2 * H) * H * k              # valid rows only
-    peak = 2500.0 if precision == "bf16" else 157.3
-    ach = flops / sec / 1e12
-    name = "conv_dma_kernel<EPI_GATE, 5>" if bf else "conv_cl_kernel<float, EPI_GATE, 5>"
-    return {"bound": "mfma", "kernel": name + " (WaveNet In_i k=5, 192->384)", "achieved": round(ach, 1), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "us_per_launch": round(sec * 1e6, 2),
-            # HBM bytes per launch of this kernel at this shape from separate rocprofv3 --pmc passes (FETCH_SIZE x 2 per the gfx950
-            # correction + WRITE_SIZE; profiles/r01_conv_pmc.txt), not re-measured live; algorithmic bytes are 15.6e6
-            "traffic": TRAFFIC_BF16_B32 if (precision == "bf16" and B == 32 and T == 400) else None}
+    return e0.elapsed_time(e1) / 1e3 / iters
+
+
+def measured_traffic():
+    """HBM bytes per launch from the rocprofv3 --pmc passes of tools/pmc_conv.sh (FETCH_SIZE doubled per the gfx950 note of the guide,
+    WRITE_SIZE calibrated on a fill of known size in the same pass) - the newest profiles/r*_conv_pmc.json, or nothing."""
+    pdir = os.path.join(REPO, "profiles")
+    cands = sorted(f for f in os.listdir(pdir) if f.endswith("_conv_pmc.json")) if os.path.isdir(pdir) else []
+    if not cands:
+        return None, None
+    with open(os.path.join(pdir, cands[-1])) as f:
+        return json.load(f), "profiles/" + cands[-1]
+
+
+def roofline(precision, B, T, step_tflops):
+    """The dominant kernel by time (profiles/*_kernel_stats.csv): `achieved` = algorithmic FLOPs per launch (2 x valid rows x 384 x 192 x 5,
+    DESIGN.md section 4) / its launch duration, timed here with HIP events over back-to-back launches on the launch stream (the
+    rocprofv3 average inside the running step, where launches are not back to back, is a few percent longer: profiles/)."""
+    peak = PEAK_TFLOPS[precision]
+    cases = hot_kernel_cases(precision, B, T)
+    pmc, src = measured_traffic()
+    rows = {}
+    for name, c in cases.items():
+        sec = time_kernel(c["run"])
+        ach = c["flops"] / sec / 1e12
+        tr = pmc.get(name, {}).get("traffic") if (pmc and pmc.get("shape") == [B, T] and pmc.get("precision") == precision) else None
+        rows[name] = {"kernel": c["kernel"], "achieved": round(ach, 1), "frac": round(ach / peak, 4), "us_per_launch": round(sec * 1e6, 2),
+                      "algorithmic_bytes": int(c["alg_bytes"]), "traffic": tr}
+    top = max(rows.values(), key=lambda r: r["us_per_launch"])
+    out = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": top["frac"],
+           "us_per_launch": top["us_per_launch"], "traffic": top["traffic"], "algorithmic_bytes": top["algorithmic_bytes"],
+           "traffic_source": src if top["traffic"] is not None else None,
+           "timing": "HIP events on the launch stream, 30 back-to-back launches of the kernel alone",
+           "step_frac": round(step_tflops / peak, 4), "kernels": rows}
+    return out
 
 
 def mas_us_per_utt(B, Tx, Ty, iters=30):
@@ -141,20 +219,24 @@ def mas_us_per_utt(B, Tx, Ty, iters=30):
     return e0.elapsed_time(e1) * 1e3 / iters / B
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle (CPU restatement of the reference, oracle/glowtts_ref.py + oracle/mas_ref.c) timed on this host:
-    BASELINE config 1 = Vanilla, B = 8, T_tokens = 120, T_mel = 800, fp32, forward + losses + backward."""
+def cpu_baseline():
+    """The oracle (CPU restatement of the reference, oracle/glowtts_ref.py + oracle/mas_ref.c / mas_ref.maximum_path_python) timed on this
+    host: BASELINE config 1 = Vanilla, B = 8, T_tokens = 120, T_mel = 800, fp32, forward + losses + backward.  Bounded to ~30 s: the intra-op
+    thread count is swept on a 2-utterance sample, the full B = 8 step is then timed at the best count; MAS is timed separately in both
+    variants of the reference (compiled core.pyx semantics, Python loop of Modules.py:951-980)."""
+    import numpy as np
     from oracle import glowtts_ref as O
+    from oracle import mas_ref
     import yaml
     from glow_tts_amd.hparams import Recursive_Parse
     from glow_tts_amd.modules import GlowTTS
-    cores = os.cpu_count() or 1
+    logical = os.cpu_count() or 1
+    physical = logical
     try:
         import psutil
-        cores = psutil.cpu_count(logical=False) or cores
+        physical = psutil.cpu_count(logical=False) or logical
     except Exception:
         pass
-    torch.set_num_threads(cores)
     with open(os.path.join(REPO, "glow_tts_amd", "Hyper_Parameters.default.yaml")) as f:
         hpd = yaml.safe_load(f)
     hpd["Mode"] = "Vanilla"
@@ -162,21 +244,78 @@ def cpu_baseline(seconds_budget=25.0):
     model = GlowTTS(Recursive_Parse(hpd))
     sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
     cfg = O.Cfg()
-    B, Tt, Tm = 8, 120, 800
-    tokens, tl, mels, ml = synthetic_batch(B, Tt, Tm, 80, 1234, "cpu")
-    times = []
-    t_start = time.time()
-    while len(times) < 4 and (time.time() - t_start < seconds_budget or len(times) < 2):
+    Tt, Tm = 120, 800
+
+    def step(batch):
+        tokens, tl, mels, ml = batch
         t0 = time.time()
         out = O.forward_train(sd, cfg, tokens, tl, mels, ml)
         mle, length = O.train_losses(out, ml, cfg)
         for v in sd.values():
             v.grad = None
         (mle + length).backward()
-        times.append(time.time() - t0)
-    best = min(times[1:]) if len(times) > 1 else times[0]
-    return {"value": round(B * Tm / best, 1), "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch fp32 + C MAS), Vanilla B=8 T_mel=800 T_tok=120, fwd+losses+bwd, best of {len(times) - 1} steps after 1 warm-up, {best:.2f} s/step"}
+        return time.time() - t0, out
+
+    small = synthetic_batch(2, Tt, Tm, 80, 1234, "cpu")
+    full = synthetic_batch(8, Tt, Tm, 80, 1234, "cpu")
+    cands = sorted({n for n in (8, 16, 32, physical) if n <= physical} or {physical})
+    torch.set_num_threads(cands[0])
+    step(small)                                        # warm-up (allocator, oneDNN primitives)
+    sweep = {}
+    for n in cands:
+        torch.set_num_threads(n)
+        sweep[n] = min(step(small)[0], step(small)[0])
+    best_n = min(sweep, key=sweep.get)
+    torch.set_num_threads(best_n)
+    step(full)
+    times, out = [], None
+    for _ in range(2):
+        t, out = step(full)
+        times.append(t)
+    best = min(times)
+    # MAS alone on the same batch's log-prior matrix: C restatement of core.pyx (kernel only; with the wrapper's host copies), Python loop
+    logp = out["logp"].detach()
+    tmask, mmask = O.mask_from_lengths(full[1], Tt), O.mask_from_lengths(full[3], Tm)
+    amask = (tmask.unsqueeze(-1) * mmask.unsqueeze(2)).squeeze(1)
+    v = (logp * amask).numpy().astype(np.float32)
+    tx, ty = full[1].numpy().astype(np.int32), full[3].numpy().astype(np.int32)
+    t0 = time.time(); mas_ref.maximum_path_c(v, tx, ty); c_kernel = time.time() - t0
+    t0 = time.time(); O.mas(logp, amask); c_wrapped = time.time() - t0
+    t0 = time.time(); mas_ref.maximum_path_python(v[:2], tx[:2], ty[:2]); py_utt = (time.time() - t0) / 2
+    py_step = best - c_wrapped + 8 * py_utt          # the same step with the Python-loop MAS (config 1 as BASELINE.json states it)
+    return {"value": round(8 * Tm / best, 1), "unit": "mel-frames/s", "cores": best_n, "kind": "port",
+            "sample": f"oracle (torch fp32 + C MAS = core.pyx semantics), Vanilla B=8 T_mel=800 T_tok=120, fwd+losses+bwd, best of 2 steps after 1 "
+                      f"warm-up at {best_n} intra-op threads ({best:.2f} s/step); thread sweep on a B=2 sample, s/step: "
+                      + ", ".join(f"{n}: {t:.2f}" for n, t in sweep.items()) + f"; host has {physical} physical / {logical} logical cores",
+            "value_python_mas": round(8 * Tm / py_step, 1),
+            "mas_us_per_utt": {"c_kernel": round(c_kernel / 8 * 1e6, 1), "c_with_wrapper_copies": round(c_wrapped / 8 * 1e6, 1),
+                               "python_loop": round(py_utt * 1e6, 1)}}
+
+
+def inverse_flow_leg(model, hp, dev, B, seed):
+    """BASELINE config 5's long-form inference: GlowTTS.inference (Modules.py:128-204) on 200-token utterances stretched to ~2000 mel
+    frames each (length_scale), replayed through GraphedInference; PE mode takes the prosody reference mels."""
+    from glow_tts_amd.graph_infer import GraphedInference
+    model.eval()
+    Tt = 200
+    tokens, tl, ref_mels, ref_ml = synthetic_batch(B, Tt, 800, 80, seed, dev)
+    gi = GraphedInference(model, mel_buckets=(1024, 2048, 2560))
+    kw = dict(noise_scale=0.667, length_scale=10.0)
+    if "Prosody_Encoder" in model.layer_Dict:
+        kw.update(mels_for_prosody=ref_mels, mel_lengths_for_prosody=ref_ml)
+    for _ in range(3):
+        mels, lengths, _ = gi(tokens, tl, **kw)
+    torch.cuda.synchronize()
+    n = 10
+    t0 = time.time()
+    for _ in range(n):
+        mels, lengths, _ = gi(tokens, tl, **kw)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / n
+    frames = int(lengths.sum().item())
+    model.train()
+    return {"metric": "mel-frames/sec (inverse flow, GlowTTS.inference)", "value": round(frames / dt, 1), "ms_per_batch": round(dt * 1e3, 3),
+            "utterances": B, "tokens": Tt, "mel_frames_per_utterance": round(frames / B, 1), "launch_mode": "hipgraph (2 graphs per call)"}
 
 
 def main():
@@ -184,23 +323,29 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config (default 2: the one the metric is quoted on)")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default: the config's per-GPU share)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--ragged", action="store_true", help="Set V (ragged lengths) instead of Set F (fixed)")
+    ap.add_argument("--windows", type=int, default=10, help="extra timed windows of --steps steps after the reported one (median / spread keys)")
+    ap.add_argument("--tokens", type=int, default=120, help="padded token length (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-device", action="store_true", help="all ranks on device 0 (multi-rank smoke test on a single-GPU box)")
+    ap.add_argument("--no-overlap", action="store_true", help="data parallel: one graph + one gradient exchange instead of the two-graph overlap")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to smoke-test the "
-                    "multi-rank code path on a single-GPU box together with GLOWTTS_BENCH_ONE_DEVICE=1)")
+                    "multi-rank code path on a single-GPU box together with --one-device)")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel eagerly instead of replaying the "
-                    "captured hipGraph of the step (default: graph replay; at B = 32 the eager step is bound by ~17 ms of host launch work)")
+                    "captured hipGraph of the step (default: graph replay; at B = 32 the eager step is bound by host launch work)")
     ap.set_defaults(graph=True)
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    if os.environ.get("GLOWTTS_BENCH_ONE_DEVICE") == "1":
+    if args.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -208,8 +353,9 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    from glow_tts_amd import _lib
     from glow_tts_amd.distributed import FlatGradReducer, actnorm_stats_allreduce
-    model, mle_loss, hp = build_model(args.precision, dev)
+    model, mle_loss, hp = build_model(args.precision, dev, cfg["mode"], cfg["spk_type"])
     reducer = None
     if world > 1:
         import torch.distributed as dist
@@ -218,8 +364,9 @@ def main():
         model.actnorm_allreduce = actnorm_stats_allreduce
         reducer = FlatGradReducer(list(model.parameters()))
     torch.manual_seed(4321 + rank)                              # dropout streams differ per rank; the replicas' weights do not
-    B, Tt, Tm = args.batch, int(os.environ.get("GLOWTTS_BENCH_TT", "120")), 800          # (the env override is for experiments only)
+    B, Tt, Tm = args.batch or cfg["batch"], args.tokens, 800
     batch = synthetic_batch(B, Tt, Tm, 80, 1234 + rank, dev, ragged=args.ragged)
+    cond = conditioning_inputs(cfg, B, 1234 + rank, dev, hp)
 
     def barrier():
         if world > 1:
@@ -232,6 +379,7 @@ def main():
     from glow_tts_amd.distributed import global_frame_weight
     mode = "eager"
     graph = tail_graph = early = tail = None
+    keep = []                                                   # pinned job tables owned by the captured graphs
     side = torch.cuda.Stream() if args.graph else None
     if args.graph:
         # every eager step that precedes the capture runs on the side stream too: a backward that ran on the default stream
@@ -239,21 +387,18 @@ def main():
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, args.warmup - 1)):
-                loss = train_step(model, mle_loss, batch, reducer, world)
+                loss = train_step(model, mle_loss, batch, cond, reducer, world)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
     else:
         for _ in range(max(1, args.warmup - 1)):               # also runs the ActNorm data-dependent init
-            loss = train_step(model, mle_loss, batch, reducer, world)
+            loss = train_step(model, mle_loss, batch, cond, reducer, world)
     if args.graph:
         try:
             wfr = global_frame_weight(batch[3].sum()) if world > 1 else None      # constant for a fixed batch
 
             def fwd_bwd():
-                tokens, tl, mels, ml = batch
-                z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, _, _ = model(tokens, tl, mels, ml, None, None, None)
-                mle = mle_loss(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=ml)
-                length = torch.nn.functional.mse_loss(log_dur, log_dur_t)
+                mle, length = forward_losses(model, mle_loss, batch, cond)
                 total = mle * wfr + length / world if world > 1 else mle + length
                 model.zero_grad(set_to_none=True)
                 total.backward()
@@ -266,23 +411,24 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            if world > 1 and os.environ.get("GLOWTTS_DP_OVERLAP", "1") != "0":
-                # Data parallel: the step is two graphs.  The first ends with the k-tap weight gradients (71 of the 114 MB); their
-                # all-reduce - with the encoder's and the ActNorm / 1x1 gradients - then runs under the second graph, which holds the
-                # 1x1 weight-gradient groups and the weight-norm backward of their classes; the 15 MB those produce are reduced last.
-                from glow_tts_amd import decoder as D
-                with D.defer_tail_wgrads():
-                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            with _lib.pinned_sink(keep):
+                if world > 1 and not args.no_overlap:
+                    # Data parallel: the step is two graphs.  The first ends with the k-tap weight gradients (71 of the 114 MB); their
+                    # all-reduce - with the encoder's and the ActNorm / 1x1 gradients - then runs under the second graph, which holds the
+                    # 1x1 weight-gradient groups and the weight-norm backward of their classes; the 15 MB those produce are reduced last.
+                    from glow_tts_amd import decoder as D
+                    with D.defer_tail_wgrads():
+                        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                            static_loss = fwd_bwd()
+                    tail_graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(tail_graph, pool=graph.pool(), capture_error_mode="thread_local"):
+                        D.flush_tail_wgrads()
+                    tail_ids = {id(p) for p in model._dec_stacks.tail_leaves()}
+                    early = FlatGradReducer([p for p in model.parameters() if id(p) not in tail_ids])
+                    tail = FlatGradReducer([p for p in model.parameters() if id(p) in tail_ids])
+                else:
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
                         static_loss = fwd_bwd()
-                tail_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(tail_graph, pool=graph.pool(), capture_error_mode="thread_local"):
-                    D.flush_tail_wgrads()
-                tail_ids = {id(p) for p in model._dec_stacks.tail_leaves()}
-                early = FlatGradReducer([p for p in model.parameters() if id(p) not in tail_ids])
-                tail = FlatGradReducer([p for p in model.parameters() if id(p) in tail_ids])
-            else:
-                with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
-                    static_loss = fwd_bwd()
             graph.replay()
             if tail_graph is not None:
                 tail_graph.replay()
@@ -306,20 +452,25 @@ def main():
             elif reducer is not None:
                 reducer.reduce(average=False)
             return static_loss
-        return train_step(model, mle_loss, batch, reducer, world)
+        return train_step(model, mle_loss, batch, cond, reducer, world)
+
+    def timed_window():
+        barrier()
+        t0 = time.time()
+        for _ in range(args.steps):
+            out = one_step()
+        barrier()
+        el = time.time() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([el], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
 
     one_step()
-    barrier()
-    t0 = time.time()
-    for _ in range(args.steps):
-        loss = one_step()
-    barrier()
-    elapsed = time.time() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, loss = timed_window()                              # the reported window: exactly --steps steps
+    extra = [timed_window()[0] for _ in range(max(0, args.windows))]
     if world > 1:
         # every gradient must have gone through the exchange: reduced gradients are identical on all ranks, unreduced ones are not
         # (different utterances and dropout streams per rank)
@@ -336,21 +487,29 @@ def main():
         ft = torch.tensor([frames], device=dev, dtype=torch.float64)
         dist.all_reduce(ft)
         frames = int(ft.item())
+    inv = inverse_flow_leg(model, hp, dev, B, 99 + rank) if (args.config == 5 and rank == 0) else None
     if rank == 0:
         value = frames * args.steps / elapsed
+        ms = [1e3 * e / args.steps for e in [elapsed] + extra]
+        tflops = value * FLOP_PER_FRAME_FWD_BWD / 1e12
         out = {
             "metric": "mel-frames/sec (train fwd+bwd)", "value": round(value, 1), "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: Vanilla single-speaker, LJSpeech-shaped synthetic (80-mel, 800 frames, 120 tokens), "
+            "config": {"workload": f"{cfg['name']}, LJSpeech-shaped synthetic (80-mel, {Tm} frames, {Tt} tokens), "
                                    f"batch={B}/GPU, {'ragged Set V' if args.ragged else 'fixed Set F'}, forward+losses+backward"
                                    + (", RCCL grad all-reduce" if world > 1 else ""),
+                       "baseline_config": args.config, "mode": cfg["mode"] + ("/" + cfg["spk_type"] if cfg["mode"] == "SE" else ""),
                        "global_batch": B * world, "mel_frames": Tm, "tokens": Tt, "parallelism": f"dp{world}"},
             "loss": round(float(loss.item()), 4), "launch_mode": mode,
-            "model_tflops": round(value * FLOP_PER_FRAME_FWD_BWD / 1e12, 2),
+            "windows": {"n": len(ms), "steps_each": args.steps, "ms_per_step_median": round(statistics.median(ms), 3),
+                        "ms_per_step_min": round(min(ms), 3), "ms_per_step_max": round(max(ms), 3)},
+            "model_tflops": round(tflops, 2),
             "mas_us_per_utt": round(mas_us_per_utt(B, Tt, Tm), 3),
-            "roofline": dominant_kernel_roofline(args.precision, B, Tm // 2),
+            "roofline": roofline(args.precision, B, Tm // 2, tflops / world),
         }
+        if inv is not None:
+            out["inverse_flow"] = inv
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -7,8 +7,8 @@ size (host-bound).  Here a call is
     graph B  (per token shape x bucket)   alignment expansion, prior sample, 12 inverse flows, unsqueeze
 with the decoder's weight images packed once (`GlowTTS.prepared_decoder_weights`): serving weights are static.  Frames beyond an
 utterance's length are masked exactly as the reference masks the batch padding, so the valid part of the result does not depend on the
-bucket.  Call `refresh()` after the parameters changed.  Vanilla / LUT / pre-computed d-vector conditioning (tensor inputs of fixed shape);
-the prosody encoder's inputs vary in length and stay on the eager path (`model.inference`)."""
+bucket.  Call `refresh()` after the parameters changed.  Vanilla / LUT / pre-computed d-vector conditioning are tensor inputs of fixed shape;
+PE mode: the GST prosody encoder, whose reference mels vary in length, runs eagerly before graph A and hands it the [B, Size] vector."""
 import bisect
 
 import torch
@@ -47,7 +47,8 @@ class GraphedInference:
         return g, out
 
     @torch.no_grad()
-    def __call__(self, tokens, token_lengths, speakers=None, mels_for_ge2e=None, noise_scale=1.0, length_scale=1.0, noises=None):
+    def __call__(self, tokens, token_lengths, speakers=None, mels_for_ge2e=None, noise_scale=1.0, length_scale=1.0, noises=None,
+                 mels_for_prosody=None, mel_lengths_for_prosody=None):
         """-> (mels [B, Mel, T], mel_lengths [B], attentions [B, T_token, T]) like `GlowTTS.inference`; T = the batch's longest utterance
         rounded down to a multiple of Num_Squeeze (as the reference).  `noises` [B, Mel, >= T] replaces the internal Gaussian draw."""
         m = self.model
@@ -55,17 +56,23 @@ class GraphedInference:
         if not torch.is_tensor(length_scale):
             length_scale = torch.tensor([float(length_scale)], device=dev)
         cond_in = speakers if speakers is not None else mels_for_ge2e
-        key = (tuple(tokens.shape), tuple(length_scale.shape), None if cond_in is None else (tuple(cond_in.shape), cond_in.dtype))
+        pro = None
+        if "Prosody_Encoder" in m.layer_Dict:                            # Modules.py:159-160, outside the graphs (variable-length input)
+            pro = m.layer_Dict["Prosody_Encoder"](mels_for_prosody, mel_lengths_for_prosody)
+        key = (tuple(tokens.shape), tuple(length_scale.shape), None if cond_in is None else (tuple(cond_in.shape), cond_in.dtype), pro is not None)
         if key not in self.front:
-            st = [tokens.clone(), token_lengths.clone(), length_scale.to(dev).clone(), None if cond_in is None else cond_in.clone()]
+            st = [tokens.clone(), token_lengths.clone(), length_scale.to(dev).clone(), None if cond_in is None else cond_in.clone(),
+                  None if pro is None else pro.clone()]
             fn = lambda: m.inference_front(st[0], st[1], None, None, st[3] if speakers is not None else None,
-                                           st[3] if speakers is None else None, st[2])
+                                           st[3] if speakers is None else None, st[2], prosodies=st[4])
             g, out = self._graph(fn)
             self.front[key] = (g, st, out)
         g, st, front = self.front[key]
         st[0].copy_(tokens, non_blocking=True); st[1].copy_(token_lengths, non_blocking=True); st[2].copy_(length_scale.to(dev), non_blocking=True)
         if cond_in is not None:
             st[3].copy_(cond_in, non_blocking=True)
+        if pro is not None:
+            st[4].copy_(pro, non_blocking=True)
         g.replay()
         mel_lengths = front[3]
         tmax = int(mel_lengths.max())                                  # the one device -> host read of the call

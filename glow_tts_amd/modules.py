@@ -258,7 +258,8 @@ class GlowTTS(torch.nn.Module):
         T = int(max_lengths) if max_lengths is not None else int(torch.max(lengths))
         return (torch.arange(T, device=lengths.device)[None, :] < lengths[:, None]).unsqueeze(1).to(dtype)
 
-    def _conditioning(self, P, speakers, mels_for_ge2e, prosody_mels, prosody_lengths):
+    def _conditioning(self, P, speakers, mels_for_ge2e, prosody_mels, prosody_lengths, prosodies=None):
+        """prosodies: a pre-computed prosody vector [B, Size] (GraphedInference runs the variable-length prosody encoder outside its graphs)."""
         mode = self.hp.Mode.upper()
         spk = pro = None
         if "LUT" in self.layer_Dict:
@@ -267,7 +268,7 @@ class GlowTTS(torch.nn.Module):
             # GE2E mode: the pre-computed, L2-normalised d-vectors arrive in `mels_for_ge2e` ([B, Embedding_Size])
             spk = mels_for_ge2e.detach()                                                                  # Modules.py:75-77
         if "Prosody_Encoder" in self.layer_Dict:
-            pro = self.layer_Dict["Prosody_Encoder"](prosody_mels, prosody_lengths)                       # Modules.py:81-82
+            pro = prosodies if prosodies is not None else self.layer_Dict["Prosody_Encoder"](prosody_mels, prosody_lengths)   # Modules.py:81-82
         return spk, pro
 
     def _maybe_init_actnorm(self, P, mels, mel_lengths, cond, pitch=None):
@@ -359,12 +360,12 @@ class GlowTTS(torch.nn.Module):
 
     @torch.no_grad()
     def inference_front(self, tokens, token_lengths, mels_for_prosody=None, mel_lengths_for_prosody=None, speakers=None, mels_for_ge2e=None,
-                        length_scale=1.0):
+                        length_scale=1.0, prosodies=None):
         """First half of `inference` (Modules.py:128-174): conditioning, encoder, durations -> (mean, log_std, dur, mel_lengths, token_mask,
         spk, pro).  Everything stays on the device; nothing here depends on the mel length (glow_tts_amd.graph_infer replays it as a hipGraph)."""
         hp = self.hp
         P = self._params()
-        spk, pro = self._conditioning(P, speakers, mels_for_ge2e, mels_for_prosody, mel_lengths_for_prosody)
+        spk, pro = self._conditioning(P, speakers, mels_for_ge2e, mels_for_prosody, mel_lengths_for_prosody, prosodies)
         token_mask = self.Mask_Generate(token_lengths, tokens.shape[1])
         mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, False, precision=self.dec_cfg.precision, cache=self._enc_cache)
         if not torch.is_tensor(length_scale):

@@ -50,3 +50,30 @@ def reference_core():
     mod = importlib.util.module_from_spec(spec)
     loader.exec_module(mod)
     return mod
+
+
+def maximum_path_python(values, t_xs, t_ys):
+    """The reference's pure-Python twin, Modules.py:951-980 `Maximum_Path_Generater.calc_path` (what BASELINE config 1 runs when
+    Use_Cython_Alignment is false): same recurrence with the sentinel -1e7 instead of core.pyx's -1e9, plain Python loops over numpy
+    scalars.  values float32 [B,Tx,Ty] pre-multiplied by the mask.  Identical to maximum_path_c unless a cumulative score falls between
+    -1e9 and -1e7.  Slow by construction (~60-100 ms per 120 x 800 utterance): bench.py's cpu_baseline times it."""
+    values = np.ascontiguousarray(values, dtype=np.float32).copy()
+    paths = []
+    for x, token_length, mel_length in zip(values, t_xs, t_ys):
+        token_length, mel_length = int(token_length), int(mel_length)
+        path = np.zeros_like(x).astype(np.int32)
+        for mel_index in range(mel_length):                                                       # :958-972
+            for token_index in range(max(0, token_length + mel_index - mel_length), min(token_length, mel_index + 1)):
+                current_q = -1e+7 if mel_index == token_index else x[token_index, mel_index - 1]
+                if token_index == 0:
+                    prev_q = 0.0 if mel_index == 0 else -1e+7
+                else:
+                    prev_q = x[token_index - 1, mel_index - 1]
+                x[token_index, mel_index] = max(current_q, prev_q) + x[token_index, mel_index]
+        token_index = token_length - 1                                                            # :974-978
+        for mel_index in range(mel_length - 1, -1, -1):
+            path[token_index, mel_index] = 1
+            if token_index == mel_index or x[token_index, mel_index - 1] < x[token_index - 1, mel_index - 1]:
+                token_index = max(0, token_index - 1)
+        paths.append(path)
+    return np.stack(paths, axis=0)

@@ -25,6 +25,15 @@ def test_mas_oracle_matches_reference_vectors(name, golden_dir):
         assert idx[0] == 0 and idx[-1] == tx - 1 and (np.diff(idx) >= 0).all() and (np.diff(idx) <= 1).all()
 
 
+@pytest.mark.parametrize("name", ["ragged", "square", "one_token"])
+def test_python_mas_twin_matches_core_pyx_vectors(name, golden_dir):
+    """oracle.mas_ref.maximum_path_python (restating Modules.py:951-980, the Use_Cython_Alignment = false path that BASELINE config 1
+    names) gives core.pyx's paths at ordinary score magnitudes (the two only part when a cumulative score passes -1e7)."""
+    d = np.load(f"{golden_dir}/mas_cases.npz")
+    path = mas_ref.maximum_path_python(d[f"{name}/value"], d[f"{name}/t_x"], d[f"{name}/t_y"])
+    assert np.array_equal(path, d[f"{name}/path"].astype(np.int32))
+
+
 def test_mas_oracle_matches_reference_build_if_present():
     core = mas_ref.reference_core()
     if core is None:

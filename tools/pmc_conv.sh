@@ -1,14 +1,52 @@
+#!/bin/bash
+# HBM traffic of the two hottest kernels from rocprofv3 PMC counters, collected as /opt/skills/guides/MI355X_MICROARCH.md prescribes:
+# FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (no tracing options), FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 B),
+# WRITE_SIZE calibrated against a fill of known size measured in the same pass.  Writes $OUT (default gpurun_out/conv_pmc.json), which
+# is copied to profiles/rNN_conv_pmc.json; bench.py reports its `traffic` figures and names the file.
+#   usage (GPU box): tools/pmc_conv.sh [out.json]
 cd /tmp && export TMPDIR=/tmp
-for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_MFMA GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
-  n=$(echo $c | cut -d' ' -f1)
-  ITERS=5 timeout 120 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$n -o run -- python /root/repo/tools/bench_conv.py > /tmp/pmc_$n.log 2>&1
-  python - <<PY
-import csv,collections
-rows=list(csv.DictReader(open("/tmp/pmc_$n/run_counter_collection.csv")))
-acc=collections.defaultdict(list)
-for r in rows:
-    if "conv_dma" in r["Kernel_Name"] or "conv_cl_kernel" in r["Kernel_Name"]:
-        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k,v in acc.items(): print(k, "per launch (mean of last launches):", sum(v[-4:])/len(v[-4:]), "n", len(v))
-PY
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=${1:-$REPO/gpurun_out/conv_pmc.json}
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  ITERS=6 timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o run -- python $REPO/tools/pmc_conv.py > /tmp/pmc_$c.log 2>&1 || { echo "rocprofv3 $c failed"; tail -5 /tmp/pmc_$c.log; }
 done
+python - "$OUT" <<'PY'
+import collections, csv, glob, json, sys
+def load(counter):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(f"/tmp/pmc_{counter}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v[-4:]) / len(v[-4:]) for k, v in acc.items()}        # mean of the last launches (warm caches, like the step)
+fetch, write = load("FETCH_SIZE"), load("WRITE_SIZE")
+def pick(d, *subs):
+    for k, v in d.items():
+        if all(s in k for s in subs):
+            return v
+    return None
+MiB256 = 256.0 * 1024 * 1024
+# the counters report KiB
+fill_w = pick(write, "FillFunctor")
+copy_r = pick(fetch, "copy") or pick(fetch, "Copy")
+copy_w = pick(write, "copy") or pick(write, "Copy")
+wcal = MiB256 / (fill_w * 1024) if fill_w else None
+rcal = MiB256 / (copy_r * 1024) if copy_r else None
+out = {"shape": [32, 400], "precision": "bf16", "units": "bytes per launch",
+       "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/pmc_conv.sh); FETCH_SIZE x 1024 x 2 (gfx950: 128-byte "
+                 "requests tallied at 64 B, MI355X_MICROARCH.md); WRITE_SIZE x 1024 x the factor that makes a 256 MiB fill read 256 MiB",
+       "calibration": {"fill_256MiB_WRITE_SIZE_KiB": fill_w, "write_factor": wcal, "copy_256MiB_FETCH_SIZE_KiB": copy_r,
+                       "fetch_factor_measured_on_copy": rcal, "copy_256MiB_WRITE_SIZE_KiB": copy_w}}
+for name, subs in (("in_fwd", ("conv_dma_kernel", "Li1ELi5E")), ("in_dgrad", ("conv_dma_kernel", "Li0ELi5E"))):
+    f, w = pick(fetch, *subs), pick(write, *subs)
+    if f is None:      # demangled names
+        subs2 = ("conv_dma_kernel<1, 5", ) if name == "in_fwd" else ("conv_dma_kernel<0, 5", )
+        f, w = pick(fetch, *subs2), pick(write, *subs2)
+    if f is not None and w is not None:
+        fb, wb = f * 1024 * 2, w * 1024 * (wcal or 1.0)
+        out[name] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "fetch_bytes": fb, "write_bytes": wb, "traffic": fb + wb}
+out["kernels_seen"] = sorted(set(list(fetch) + list(write)))[:40]
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != "kernels_seen"}, indent=1))
+PY
