@@ -4,9 +4,10 @@
 # WRITE_SIZE calibrated against a fill of known size measured in the same pass.  Writes $OUT (default gpurun_out/conv_pmc.json), which
 # is copied to profiles/rNN_conv_pmc.json; bench.py reports its `traffic` figures and names the file.
 #   usage (GPU box): tools/pmc_conv.sh [out.json]
-cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=${1:-$REPO/gpurun_out/conv_pmc.json}
+case "$OUT" in /*) ;; *) OUT="$PWD/$OUT";; esac
+cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   ITERS=6 timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o run -- python $REPO/tools/pmc_conv.py > /tmp/pmc_$c.log 2>&1 || { echo "rocprofv3 $c failed"; tail -5 /tmp/pmc_$c.log; }
