@@ -181,11 +181,16 @@ def _bucket(n, buckets, multiple):
 
 
 class Collater:
-    def __init__(self, num_squeeze=2, end_token_id=0, max_abs_mel=4.0, token_buckets=None, mel_buckets=None, token_multiple=1,
+    def __init__(self, num_squeeze=2, end_token_id=1, max_abs_mel=4.0, token_buckets=None, mel_buckets=None, token_multiple=1,
                  mel_multiple=None, pin_memory=False, ring=4, ge2e=None):
-        """token_buckets / mel_buckets: ascending lists of padded lengths (None: pad to the batch maximum rounded up to
+        """end_token_id: the id of '<E>' in Token.yaml (1 in every dictionary `Token_Dict_Generate` writes: '<S>' is 0; `from_hp` reads it
+        from the dictionary).  token_buckets / mel_buckets: ascending lists of padded lengths (None: pad to the batch maximum rounded up to
         token_multiple / mel_multiple, the reference's behaviour for multiples of 1 / num_squeeze).  ring: number of pinned buffer sets that
-        are cycled, i.e. how many batches may be in flight between the loader and the GPU copy."""
+        are cycled, i.e. how many batches may be in flight between the loader and the GPU copy; copy batches with `self.to_device`, which
+        records an event per set so that a set is not refilled while its copy is still in flight.
+        Pitches: without mel buckets they are padded like the reference's `Pitch_Stack` (to the longest UNtruncated track, so one frame
+        longer than the mels when that utterance has an odd length; `Squeeze` drops the odd frame, Modules.py:897-898); with mel buckets to
+        the mel bucket."""
         self.ns, self.end, self.pad_mel = int(num_squeeze), int(end_token_id), -float(max_abs_mel)
         self.tb = sorted(token_buckets) if token_buckets else None
         self.mb = sorted(mel_buckets) if mel_buckets else None
@@ -193,6 +198,7 @@ class Collater:
         if self.mb and any(b % self.ns for b in self.mb):
             raise ValueError("mel buckets must be multiples of Decoder.Num_Squeeze")
         self.pin, self.ring, self._bufs, self._turn = bool(pin_memory), int(ring), {}, 0
+        self._events = {}           # ring slot -> event recorded after the last host-to-device copy out of that slot
         self.ge2e = ge2e            # (samples, slice_length, overlap_length) of hp.Speaker_Embedding.GE2E.Inference, or None: no GE2E slices
 
     @classmethod
@@ -203,12 +209,25 @@ class Collater:
     def _buffer(self, name, shape, dtype, fill):
         if not self.pin:
             return torch.full(shape, fill, dtype=dtype)
-        key = (name, tuple(shape), self._turn % self.ring)
+        slot = self._turn % self.ring
+        ev = self._events.get(slot)
+        if ev is not None:
+            ev.synchronize()                                   # the copy that last read this buffer set has finished
+        key = (name, tuple(shape), slot)
         buf = self._bufs.get(key)
         if buf is None:
             buf = self._bufs[key] = torch.empty(shape, dtype=dtype).pin_memory()
         buf.fill_(fill)
         return buf
+
+    def to_device(self, batch, device, non_blocking=True):
+        """Host-to-device copy of the batch this collater produced LAST; with pinned buffers it records the event that guards the set."""
+        out = to_device(batch, device, non_blocking)
+        if self.pin and torch.cuda.is_available():
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events[(self._turn - 1) % self.ring] = ev
+        return out
 
     def __call__(self, batch):
         """batch: list of (token [Tt] int, mel [Tm, Mel] float, speaker int, pitch [Tm] float or None) like `Dataset.__getitem__`."""
@@ -225,12 +244,13 @@ class Collater:
         out_tok = self._buffer("tok", (B, Tt), torch.int64, self.end)                              # Token_Stack, Datasets.py:23-30
         out_mel = self._buffer("mel", (B, mel_dim, Tm), torch.float32, self.pad_mel)               # Mel_Stack + transpose, :32-39, :244
         has_pitch = pitches[0] is not None
-        out_pit = self._buffer("pit", (B, Tm), torch.float32, 0.0) if has_pitch else None          # Pitch_Stack, :67-74
+        Tp = Tm if (self.mb or not has_pitch) else max(Tm, max(len(p) for p in pitches))             # Pitch_Stack pads to the longest track
+        out_pit = self._buffer("pit", (B, Tp), torch.float32, 0.0) if has_pitch else None          # Pitch_Stack, :67-74
         for b in range(B):
             out_tok[b, :tl[b]] = torch.as_tensor(np.asarray(tokens[b]), dtype=torch.int64)
             out_mel[b, :, :ml[b]] = torch.as_tensor(np.ascontiguousarray(mels[b].T), dtype=torch.float32)
             if has_pitch:
-                n = min(len(pitches[b]), Tm)
+                n = min(len(pitches[b]), Tp)
                 out_pit[b, :n] = torch.as_tensor(np.asarray(pitches[b][:n]), dtype=torch.float32)
         self._turn += 1
         return (out_tok, torch.tensor(tl, dtype=torch.int64), out_mel, torch.tensor(ml, dtype=torch.int64),

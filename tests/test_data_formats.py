@@ -147,3 +147,37 @@ def test_checkpoint_files_roundtrip(tmp_path):
     m3 = GlowTTS(hp)
     assert C.load_checkpoint(root, m3, steps=10) == (10, 1)        # an explicit step: exactly S_10.pt
     assert all(torch.equal(a, b) for a, b in zip(raw["Model"].values(), m3.state_dict().values()))
+
+
+def test_collater_matches_the_reference_collater_bit_for_bit():
+    """tests/golden/collater_case.npz: a ragged batch (odd mel lengths, one-letter text) through the UNMODIFIED reference
+    `Datasets.Collater` (Datasets.py:225-250; generated by tests/golden/make_data_golden.py) - all seven tensors, dtypes included:
+    '<E>' padding, -Max_Abs_Mel padding, truncation to a multiple of Num_Squeeze, the GE2E slice stack (same numpy RNG stream), pitch
+    padding to the longest untruncated track."""
+    import os
+    import numpy as np
+    import torch
+    from glow_tts_amd import data
+    from glow_tts_amd.hparams import DEFAULT_YAML, Recursive_Parse, load_yaml
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "collater_case.npz"))
+    token_dict = {str(k): int(v) for k, v in zip(d["in/token_symbols"], d["in/token_ids"])}
+    texts = [str(t) for t in d["in/texts"]]
+    def split(cat, lens):
+        out, o = [], 0
+        for n in lens:
+            out.append(cat[o:o + n]); o += n
+        return out
+    tokens = split(d["in/token_cat"], d["in/token_lens"])
+    for t, text in zip(tokens, texts):
+        assert np.array_equal(t, data.text_to_token(text, token_dict))                       # Text_to_Token, Datasets.py:17-21
+    mels, pitches = split(d["in/mel_cat"], d["in/mel_lens"]), split(d["in/pitch_cat"], d["in/mel_lens"])
+    hp = Recursive_Parse(load_yaml(DEFAULT_YAML))
+    col = data.Collater.from_hp(hp, token_dict, ge2e=tuple(int(x) for x in d["in/ge2e"]))
+    np.random.seed(int(d["in/seed"]))
+    out = col(list(zip(tokens, mels, [int(s) for s in d["in/speakers"]], pitches)))
+    names = ["tokens", "token_lengths", "mels", "mel_lengths", "speakers", "mels_for_ge2e", "pitches"]
+    for name, got in zip(names, out):
+        want = torch.from_numpy(d["out/" + name])
+        assert got.dtype == want.dtype and got.shape == want.shape, (name, got.dtype, want.dtype, got.shape, want.shape)
+        assert torch.equal(got, want), name
+    assert data.Collater().end == 1                                                          # '<E>' (Token.yaml: '<S>' 0, '<E>' 1)
