@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the two hottest kernels from rocprofv3 PMC counters, collected as /opt/skills/guides/MI355X_MICROARCH.md prescribes:
 # FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (no tracing options), FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 B),
-# WRITE_SIZE calibrated against a fill of known size measured in the same pass.  Writes $OUT (default gpurun_out/conv_pmc.json), which
+# WRITE_SIZE calibrated against a 1 GiB fill measured in the same pass (and the x2 of FETCH_SIZE checked on a 1 GiB streaming read).  Writes $OUT (default gpurun_out/conv_pmc.json), which
 # is copied to profiles/rNN_conv_pmc.json; bench.py reports its `traffic` figures and names the file.
 #   usage (GPU box): tools/pmc_conv.sh [out.json]
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
@@ -27,18 +27,16 @@ def pick(d, *subs):
         if all(s in k for s in subs):
             return v
     return None
-MiB256 = 256.0 * 1024 * 1024
+GiB = 1024.0 ** 3
 # the counters report KiB
 fill_w = pick(write, "FillFunctor")
-copy_r = pick(fetch, "copy") or pick(fetch, "Copy")
-copy_w = pick(write, "copy") or pick(write, "Copy")
-wcal = MiB256 / (fill_w * 1024) if fill_w else None
-rcal = MiB256 / (copy_r * 1024) if copy_r else None
+mul_r, mul_w = pick(fetch, "MulFunctor"), pick(write, "MulFunctor")
+wcal = GiB / (fill_w * 1024) if fill_w else None
 out = {"shape": [32, 400], "precision": "bf16", "units": "bytes per launch",
        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/pmc_conv.sh); FETCH_SIZE x 1024 x 2 (gfx950: 128-byte "
-                 "requests tallied at 64 B, MI355X_MICROARCH.md); WRITE_SIZE x 1024 x the factor that makes a 256 MiB fill read 256 MiB",
-       "calibration": {"fill_256MiB_WRITE_SIZE_KiB": fill_w, "write_factor": wcal, "copy_256MiB_FETCH_SIZE_KiB": copy_r,
-                       "fetch_factor_measured_on_copy": rcal, "copy_256MiB_WRITE_SIZE_KiB": copy_w}}
+                 "requests tallied at 64 B, MI355X_MICROARCH.md); WRITE_SIZE x 1024 x the factor that makes a 1 GiB fill read 1 GiB",
+       "calibration": {"fill_1GiB_WRITE_SIZE_KiB": fill_w, "write_factor": wcal, "mul_1GiB_FETCH_SIZE_KiB": mul_r,
+                       "mul_fetch_bytes_after_x2_over_1GiB": (mul_r * 2048 / GiB) if mul_r else None, "mul_1GiB_WRITE_SIZE_KiB": mul_w}}
 for name, subs in (("in_fwd", ("conv_dma_kernel", "Li1ELi5E")), ("in_dgrad", ("conv_dma_kernel", "Li0ELi5E"))):
     f, w = pick(fetch, *subs), pick(write, *subs)
     if f is None:      # demangled names
