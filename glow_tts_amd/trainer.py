@@ -1,0 +1,231 @@
+"""The reference's training entry point (`Train.py:49-598`: `Trainer(steps).Train()`), thin, over this package's pieces: `data.PatternDataset` +
+`data.Collater` (shape buckets, pinned staging) -> `GlowTTS.forward` + `MLE_Loss` (+ duration MSE, + speaker CE in GR mode; Train.py:193-216)
+-> backward -> clip_grad_norm_ -> RAdam -> Modified_Noam_Scheduler, the whole `Train_Step` replayed as one hipGraph per batch shape
+(`graph_step.GraphedTrainStep`), checkpoints in the reference's `S_{steps}.pt` layout (`checkpoint.py`).  Same class / method names and the same
+`python Train.py -s <steps>` command line; no TensorBoard writer, no plots (Logger.py is out of scope): scalars go to
+`logging`.  Launched under torchrun (WORLD_SIZE > 1) it trains data parallel: utterances sharded per rank, gradients summed over RCCL
+(`distributed.FlatGradReducer`), ActNorm initialised from the global batch, losses weighted by global frame counts."""
+import logging
+import math
+import os
+from collections import defaultdict
+
+import torch
+
+from . import checkpoint, data
+from .hparams import get_hp
+from .modules import GlowTTS, MLE_Loss
+from .optim import Modified_Noam_Scheduler, RAdam, clip_grad_norm_
+
+
+def default_buckets(max_len, step):
+    return list(range(step, int(math.ceil(max_len / step)) * step + 1, step))
+
+
+class Trainer:
+    def __init__(self, steps=0, hp=None, speaker_encoder=None, use_graph=True):
+        """speaker_encoder: GE2E mode only - a callable mapping the collater's slice stack [B * Samples, Mel, Slice] to L2-normalised d-vectors
+        [B, Embedding_Size] (the reference's pre-trained GE2E network is an un-vendored submodule: DESIGN.md)."""
+        self.hp = hp if hp is not None else get_hp()
+        self.steps, self.epochs = steps, 0
+        self.speaker_encoder, self.use_graph = speaker_encoder, use_graph
+        self.rank, self.world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(self.device)
+        if self.world > 1 and not torch.distributed.is_initialized():
+            torch.distributed.init_process_group("nccl")                       # RCCL
+        self.Datset_Generate()
+        self.Model_Generate()
+        self.scalar_Dict = {"Train": defaultdict(float), "Evaluation": defaultdict(float)}
+        self.Load_Checkpoint()
+
+    # ------------------------------------------------------------------ Train.py:69-139
+    def Datset_Generate(self):
+        hp = self.hp
+        self.token_Dict = data.load_token_dict(hp.Token_Path)
+        mk = lambda p, acc: data.PatternDataset(
+            pattern_path=p.Path, metadata_file=p.Metadata_File, token_dict=self.token_Dict, accumulated_dataset_epoch=acc,
+            mel_length_min=p.Mel_Length.Min, mel_length_max=p.Mel_Length.Max, text_length_min=p.Text_Length.Min, text_length_max=p.Text_Length.Max,
+            use_cache=hp.Train.Use_Pattern_Cache)
+        train = mk(hp.Train.Train_Pattern, hp.Train.Train_Pattern.Accumulated_Dataset_Epoch)
+        dev = mk(hp.Train.Eval_Pattern, 1)
+        logging.info("The number of train patterns = {}.".format(len(train) // hp.Train.Train_Pattern.Accumulated_Dataset_Epoch))
+        logging.info("The number of development patterns = {}.".format(len(dev)))
+        ge = hp.Speaker_Embedding.GE2E.Inference
+        ge2e = (ge.Samples, ge.Slice_Length, ge.Overlap_Length) if (hp.Mode.upper() in ("SE", "GR") and hp.Speaker_Embedding.Type.upper() == "GE2E") else None
+        buckets = getattr(hp, "HIP_Buckets", None)          # optional extra yaml key: {Mel: [...], Token: [...]} padded shapes (one hipGraph each)
+        mel_b = list(buckets.Mel) if buckets is not None else default_buckets(hp.Train.Train_Pattern.Mel_Length.Max, 128)
+        tok_b = list(buckets.Token) if buckets is not None else default_buckets(hp.Train.Train_Pattern.Text_Length.Max + 2, 32)
+        self.collater = data.Collater.from_hp(hp, self.token_Dict, token_buckets=tok_b, mel_buckets=mel_b, pin_memory=True, ge2e=ge2e)
+        self.sampler = torch.utils.data.distributed.DistributedSampler(train, self.world, self.rank, shuffle=True, drop_last=True) if self.world > 1 else None
+        bs = hp.Train.Batch_Size                              # per process (= per GPU)
+        self.dataLoader_Dict = {
+            # the collater owns reused pinned buffers: it runs in THIS process (num_workers = 0); the pattern pickles are cached
+            "Train": torch.utils.data.DataLoader(train, batch_size=bs, shuffle=self.sampler is None, sampler=self.sampler, collate_fn=self.collater,
+                                                 num_workers=0, drop_last=True),
+            "Dev": torch.utils.data.DataLoader(dev, batch_size=bs, shuffle=False, collate_fn=self.collater, num_workers=0),
+        }
+
+    # ------------------------------------------------------------------ Train.py:143-180
+    def Model_Generate(self):
+        hp = self.hp
+        model = GlowTTS(hp).to(self.device)
+        self.model_Dict = {"GlowTTS": model}
+        self.criterion_Dict = {"MSE": torch.nn.MSELoss(), "MLE": MLE_Loss(hp), "CE": torch.nn.CrossEntropyLoss()}
+        self.optimizer = RAdam(model.parameters(), lr=hp.Train.Learning_Rate.Initial, betas=(hp.Train.ADAM.Beta1, hp.Train.ADAM.Beta2),
+                               eps=hp.Train.ADAM.Epsilon, weight_decay=hp.Train.Weight_Decay)
+        self.scheduler = Modified_Noam_Scheduler(self.optimizer, base=hp.Train.Learning_Rate.Base)
+        self.reducer = None
+        if self.world > 1:
+            from .distributed import FlatGradReducer, actnorm_stats_allreduce
+            for p in model.parameters():
+                torch.distributed.broadcast(p.data, 0)
+            model.actnorm_allreduce = actnorm_stats_allreduce
+            self.reducer = FlatGradReducer(list(model.parameters()))
+        self._comp = torch.zeros(4, device=self.device)      # MLE, Length, Total, Speaker of the last step (written inside the graph)
+        self._graphed = None
+
+    def _losses(self, model, tokens, token_lengths, mels, mel_lengths, speakers, mels_for_ge2e, pitches):
+        """Train.py:193-216 -> (loss to differentiate, [MLE, Length, Total, Speaker])."""
+        z, mel_Mean, mel_Log_Std, log_Dets, log_Durations, log_Duration_Targets, _, classified = model(
+            tokens, token_lengths, mels, mel_lengths, speakers, mels_for_ge2e, pitches)
+        mle = self.criterion_Dict["MLE"](z=z, mean=mel_Mean, std=mel_Log_Std, log_dets=log_Dets, lengths=mel_lengths)
+        length = self.criterion_Dict["MSE"](log_Durations, log_Duration_Targets)
+        total = mle + length
+        ce = self.criterion_Dict["CE"](classified, speakers) if classified is not None else None
+        if self.world > 1:
+            from .distributed import global_frame_weight
+            loss = mle * global_frame_weight(mel_lengths.sum()) + (length + (ce if ce is not None else 0.0)) / self.world
+        else:
+            loss = total + (ce if ce is not None else 0.0)
+        comp = torch.stack([mle.detach(), length.detach(), total.detach(), ce.detach() if ce is not None else torch.zeros((), device=mle.device)])
+        return loss, comp
+
+    def _batch_to_device(self, batch):
+        tokens, token_lengths, mels, mel_lengths, speakers, ge2e, pitches = self.collater.to_device(batch, self.device)
+        mode = self.hp.Mode.upper()
+        if mode in ("SE", "GR") and self.hp.Speaker_Embedding.Type.upper() == "GE2E":
+            if self.speaker_encoder is None:
+                raise RuntimeError("GE2E mode: pass Trainer(speaker_encoder=...) producing d-vectors (the GE2E network is not part of this package)")
+            ge2e = self.speaker_encoder(ge2e).detach()
+        else:
+            ge2e = None
+        if mode not in ("SE", "GR") or "LUT" not in self.model_Dict["GlowTTS"].layer_Dict:
+            speakers = speakers if mode == "GR" else None
+        return tokens, token_lengths, mels, mel_lengths, speakers, ge2e, (pitches if mode == "GR" else None)
+
+    # ------------------------------------------------------------------ Train.py:182-238
+    def Train_Step(self, *batch):
+        hp, model = self.hp, self.model_Dict["GlowTTS"]
+        inputs = self._batch_to_device(batch)
+
+        def loss_fn(m, *inp):
+            loss, comp = self._losses(m, *inp)
+            self._comp.copy_(comp)
+            return loss
+        if self.use_graph and self.world == 1:
+            if self._graphed is None:
+                from .graph_step import GraphedTrainStep
+                self._graphed = GraphedTrainStep(model, loss_fn, warmup=2, optimizer=self.optimizer, scheduler=self.scheduler,
+                                                 max_grad_norm=hp.Train.Gradient_Norm)
+                self._graphed.steps_taken = 0
+            before = self._graphed.steps_taken
+            self._graphed(*inputs)
+            self.steps += self._graphed.steps_taken - before       # a new batch shape costs warm-up steps, which are real optimizer steps
+        else:
+            loss = loss_fn(model, *inputs)
+            self.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            if self.reducer is not None:
+                self.reducer.reduce(average=False)
+            clip_grad_norm_(list(model.parameters()), hp.Train.Gradient_Norm)
+            self.optimizer.step()
+            self.scheduler.step()
+            self.steps += 1
+        for tag, v in zip(("MLE", "Length", "Total", "Speaker"), self._comp.unbind(0)):
+            self.scalar_Dict["Train"]["Loss/" + tag] += v          # device scalars: no host sync per step
+
+    # ------------------------------------------------------------------ Train.py:240-264
+    def Train_Epoch(self):
+        hp = self.hp
+        if self.sampler is not None:
+            self.sampler.set_epoch(self.epochs)
+        for batch in self.dataLoader_Dict["Train"]:
+            last = self.steps
+            self.Train_Step(*batch)
+            crossed = lambda n: self.steps // n != last // n
+            if crossed(hp.Train.Checkpoint_Save_Interval):
+                self.Save_Checkpoint()
+            if crossed(hp.Train.Logging_Interval):
+                msg = {tag: float(v) / hp.Train.Logging_Interval for tag, v in self.scalar_Dict["Train"].items()}
+                msg["Learning_Rate"] = self.scheduler.get_last_lr()[0]
+                if self.rank == 0:
+                    logging.info("(Steps: {}) {}".format(self.steps, msg))
+                self.scalar_Dict["Train"] = defaultdict(float)
+            if crossed(hp.Train.Evaluation_Interval):
+                self.Evaluation_Epoch()
+            if self.steps >= hp.Train.Max_Step:
+                return
+        self.epochs += hp.Train.Train_Pattern.Accumulated_Dataset_Epoch
+
+    # ------------------------------------------------------------------ Train.py:266-355 (losses only: the image / histogram logging is out of scope)
+    @torch.no_grad()
+    def Evaluation_Step(self, *batch):
+        inputs = self._batch_to_device(batch)
+        _, comp = self._losses(self.model_Dict["GlowTTS"], *inputs)
+        for tag, v in zip(("MLE", "Length", "Total", "Speaker"), comp.unbind(0)):
+            self.scalar_Dict["Evaluation"]["Loss/" + tag] += v
+
+    def Evaluation_Epoch(self):
+        logging.info("(Steps: {}) Start evaluation.".format(self.steps))
+        model = self.model_Dict["GlowTTS"]
+        model.eval()
+        n = 0
+        for n, batch in enumerate(self.dataLoader_Dict["Dev"], 1):
+            self.Evaluation_Step(*batch)
+        if n and self.rank == 0:
+            logging.info("(Steps: {}) Evaluation {}".format(self.steps, {t: float(v) / n for t, v in self.scalar_Dict["Evaluation"].items()}))
+        self.scalar_Dict["Evaluation"] = defaultdict(float)
+        model.train()
+
+    # ------------------------------------------------------------------ Train.py:498-553
+    def Load_Checkpoint(self):
+        got = checkpoint.load_checkpoint(self.hp.Checkpoint_Path, self.model_Dict["GlowTTS"], self.optimizer, self.scheduler, self.steps) \
+            if (self.steps != 0 or os.path.isdir(self.hp.Checkpoint_Path)) else None
+        if got is None:
+            return                                              # initial training
+        self.steps, self.epochs = got
+        logging.info("Checkpoint loaded at {} steps.".format(self.steps))
+
+    def Save_Checkpoint(self):
+        if self.rank != 0:
+            return
+        path = checkpoint.save_checkpoint(self.hp.Checkpoint_Path, self.model_Dict["GlowTTS"], self.optimizer, self.scheduler, self.steps, self.epochs)
+        logging.info("Checkpoint saved at {} steps: {}".format(self.steps, path))
+
+    # ------------------------------------------------------------------ Train.py:563-590
+    def Train(self):
+        hp = self.hp
+        hp_Path = os.path.join(hp.Checkpoint_Path, "Hyper_Parameters.yaml").replace("\\", "/")
+        if self.rank == 0 and not os.path.exists(hp_Path) and os.path.exists("Hyper_Parameters.yaml"):
+            from shutil import copyfile
+            os.makedirs(hp.Checkpoint_Path, exist_ok=True)
+            copyfile("Hyper_Parameters.yaml", hp_Path)
+        if self.steps == 0:
+            self.Evaluation_Epoch()
+        while self.steps < hp.Train.Max_Step:
+            try:
+                self.Train_Epoch()
+            except KeyboardInterrupt:
+                self.Save_Checkpoint()
+                raise SystemExit(1)
+        logging.info("Finished training.")
+
+
+def main(argv=None):
+    import argparse
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s")
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-s", "--steps", default=0, type=int)
+    args = ap.parse_args(argv)
+    Trainer(steps=args.steps).Train()
