@@ -29,6 +29,16 @@ def global_frame_weight(local_frames):
     return local_frames.to(torch.float32) / tot
 
 
+def global_batch_weight(local_utterances, device=None):
+    """local / global utterance count: the factor for losses that are means over the padded batch (the duration MSE, Train.py:211) when
+    ranks hold different numbers of utterances (equal shards: 1 / world)."""
+    if not is_dist():
+        return 1.0
+    t = torch.tensor([float(local_utterances)], device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(local_utterances) / float(t.item())
+
+
 class FlatGradReducer:
     """All-reduces the gradients of `params` with few, large collectives (xGMI is point-to-point: few large messages beat many small
     ones) and IN PLACE: `p.grad` keeps its address, which a replayed hipGraph of the step relies on.

@@ -261,3 +261,32 @@ def test_graphed_inference_matches_eager():
     here = os.path.dirname(os.path.abspath(__file__))
     out = subprocess.run([sys.executable, os.path.join(here, "graph_infer_check.py")], capture_output=True, text=True, timeout=600, cwd=os.path.dirname(here))
     assert out.returncode == 0 and "GRAPH INFER OK" in out.stdout, (out.returncode, out.stdout[-2000:], out.stderr[-2000:])
+
+
+def test_two_ranks_on_one_gpu(tmp_path):
+    """Data parallel with the real model on hardware: two ranks share the one GPU of the test box - RCCL if it
+    accepts that (probed in a child with a time-out: it usually refuses a duplicate device), else gloo over the same FlatGradReducer /
+    ActNorm / loss-weighting code.  tests/dp_gpu_check.py does the checks; its log is kept in gpurun_out/ (copied to profiles/)."""
+    import os, socket, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    repo = os.path.dirname(here)
+
+    def port():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+    os.makedirs(os.path.join(repo, "gpurun_out"), exist_ok=True)
+    log = os.path.join(repo, "gpurun_out", "dp_2rank_one_gpu.log")
+    open(log, "w").close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    backend, why = "gloo", ""
+    try:
+        pr = subprocess.run([sys.executable, os.path.join(here, "dp_gpu_check.py"), "probe", str(port()), log], capture_output=True, text=True, timeout=180, cwd=repo, env=env)
+        if pr.returncode == 0 and "NCCL PROBE OK" in pr.stdout:
+            backend = "nccl"
+        else:
+            why = (pr.stderr.strip().splitlines() or ["?"])[-1][:300]
+    except subprocess.TimeoutExpired:
+        why = "probe timed out"
+    with open(log, "a") as f:
+        f.write(f"[dp] backend {backend}" + (f" (RCCL refused two ranks on one device: {why})" if backend == "gloo" else " (RCCL, two ranks on one device)") + "\n")
+    out = subprocess.run([sys.executable, os.path.join(here, "dp_gpu_check.py"), backend, str(port()), log], capture_output=True, text=True, timeout=900, cwd=repo, env=env)
+    assert out.returncode == 0 and "DP GPU CHECK OK" in out.stdout, (out.returncode, out.stdout[-3000:], out.stderr[-3000:])
