@@ -62,6 +62,11 @@ int glowtts_mas_path_from_idx(const int32_t *idx, void *path, int B, int Tx, int
 /* Both steps: the direct replacement of maximum_path_c.  `scratch_idx` [B][Ty] i32. */
 int glowtts_mas_f32(const float *value, int32_t *path, const int32_t *t_xs, const int32_t *t_ys,
                     int32_t *scratch_idx, int B, int Tx, int Ty, float max_neg_val, void *stream);
+/* HOST twin (no stream, every pointer is a HOST pointer): exactly `maximum_path_c` of core.pyx:40 - `value` [B][Tx][Ty] is clobbered into
+ * the cumulative scores, `path` must arrive zeroed, utterances with t_x > t_y are left untouched.  num_threads <= 0: one thread per
+ * hardware thread (core.pyx:44 `prange`).  An explicit entry point for host-resident score matrices, never a fallback of the GPU path. */
+int glowtts_mas_f32_host(float *value, int32_t *path, const int32_t *t_xs, const int32_t *t_ys,
+                         int B, int Tx, int Ty, float max_neg_val, int num_threads);
 
 
 /* ------------------------------------------------------------------------------------------

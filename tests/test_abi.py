@@ -29,13 +29,54 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_product_path_has_no_oracle_import():
-    """The product package must never import the oracle (or any CPU fallback)."""
+    """The product package must never import, dlopen or execute the oracle (or any CPU fallback of the GPU path): no mention of it in
+    any Python or HIP / C++ source of the package, exactly one place that opens a shared library (`_lib.py`, the in-tree
+    libglowtts_hip.so), no dlopen / system / popen in the native sources, no subprocess use in the package."""
     pkg = os.path.join(REPO, "glow_tts_amd")
+    cdll_sites = []
     for root, _, files in os.walk(pkg):
         for f in files:
+            path = os.path.join(root, f)
             if f.endswith(".py"):
-                src = open(os.path.join(root, f)).read()
+                src = open(path).read()
                 assert "oracle" not in re.sub(r"#.*", "", src).replace('"""', ""), f"{f} mentions oracle"
+                assert not re.search(r"\bsubprocess\b|os\.system|os\.popen", src), f"{f} spawns processes"
+                if re.search(r"ctypes\.(CDLL|cdll|PyDLL)|LoadLibrary", src):
+                    cdll_sites.append(os.path.relpath(path, pkg))
+            elif f.endswith((".hip", ".h", ".cpp", ".c")):
+                src = open(path).read()
+                assert "oracle" not in src.lower(), f"{f} mentions oracle"
+                assert not re.search(r"\bdlopen\b|\bsystem\s*\(|\bpopen\b|\bexecv", src), f"{f} loads or executes external code"
+    assert cdll_sites == ["_lib.py"], cdll_sites
+    lib_src = open(os.path.join(pkg, "_lib.py")).read()
+    assert 'LIB_PATH = os.path.join(_HERE, "libglowtts_hip.so")' in lib_src
+
+
+def test_host_mas_twin_matches_core_pyx_vectors(golden_dir):
+    """glowtts_mas_f32_host (the C-ABI twin of core.pyx:40 `maximum_path_c` for host-resident score matrices) on the golden
+    vectors the reference's compiled core.pyx produced: paths and cumulative scores bit-exact; and the Python wrapper's signature."""
+    import numpy as np
+    import torch
+    L = ctypes.CDLL(os.path.join(REPO, "glow_tts_amd", "libglowtts_hip.so"))
+    L.glowtts_mas_f32_host.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_int]
+    d = np.load(os.path.join(golden_dir, "mas_cases.npz"))
+    for name in ["ragged", "ties", "square", "one_token", "x1000", "wide"]:
+        for threads in (1, 3):
+            v = d[f"{name}/value"].copy()
+            tx, ty = np.ascontiguousarray(d[f"{name}/t_x"], np.int32), np.ascontiguousarray(d[f"{name}/t_y"], np.int32)
+            path = np.zeros(v.shape, np.int32)
+            assert L.glowtts_mas_f32_host(v.ctypes.data, path.ctypes.data, tx.ctypes.data, ty.ctypes.data, *v.shape, -1e9, threads) == 0
+            assert np.array_equal(path, d[f"{name}/path"].astype(np.int32)), name
+            assert np.bitwise_xor.reduce(v.view(np.uint32).ravel()) == d[f"{name}/q_xor"], name
+    from glow_tts_amd.monotonic_align import maximum_path_host
+    v = torch.from_numpy(d["ragged/value"]).double()
+    tx, ty = d["ragged/t_x"], d["ragged/t_y"]
+    mask = torch.from_numpy(((np.arange(v.shape[1])[None, :, None] < tx[:, None, None]) & (np.arange(v.shape[2])[None, None, :] < ty[:, None, None])).astype(np.float64))
+    p = maximum_path_host(v, mask)
+    assert p.dtype == v.dtype and np.array_equal(p.numpy().astype(np.int32), d["ragged/path"].astype(np.int32))
+    bad = np.array([v.shape[1] + 1] * v.shape[0], np.int32)
+    vv = d["ragged/value"].copy(); pp = np.zeros(vv.shape, np.int32)
+    assert L.glowtts_mas_f32_host(vv.ctypes.data, pp.ctypes.data, bad.ctypes.data, ty.ctypes.data, *vv.shape, -1e9, 1) == -1      # GLOWTTS_E_ARG
 
 
 def test_model_deepcopy_and_state_dict_roundtrip_cpu():
