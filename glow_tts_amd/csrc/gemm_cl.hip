@@ -908,7 +908,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
 extern __shared__ __attribute__((aligned(1024))) unsigned char dma_smem[];
 constexpr int DMA1_CPS = 2;             // 1x1 convs: K chunks per pipeline stage
 
-template <int EPI, int TAPS, int NI = 2>
+// KS (round 2): the K loop is bound by LDS fragment reads - a 32-row x 64-column strip per wave reads 1 A + 2 B fragments (3 KiB) for
+// two MFMAs per 16-wide k-step, 1.5 KiB per MFMA against the 1 KiB per MFMA the LDS can feed at full matrix rate.  With KS the waves
+// work in PAIRS: wave (g, kh) multiplies a 64-row x 64-column tile over only ONE half (kh) of every 32-wide K chunk: 2 A + 2 B fragments for
+// four MFMAs = 1 KiB per MFMA, same MFMA count per wave, same LDS image, same staging.  After the loop the partners swap halves of their
+// partial sums through LDS (each keeps the 32-row fragment kh of the pair's 64 rows), which leaves every wave with exactly the
+// accumulators of the plain kernel: the epilogue is unchanged.
+template <int EPI, int TAPS, int NI = 2, bool KS = false>
 __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args pin, const int nst /* LDS stages: 2 or 3 */,
                                                         const int nload /* loader waves (0: every wave stages its share) */)
 {
@@ -991,11 +997,15 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
         return;
     }
 
-    f32x16 acc[1][NI];
+    constexpr int MIK = KS ? 2 : 1;
+    f32x16 acc[MIK][NI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+    for (int mi = 0; mi < MIK; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][ni][r] = 0.f;
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int kgrp = wave >> 1, kh = wave & 1;                // KS: pair index and K half of this wave
 
     // DMA units of this wave when every wave stages its share: u = wave + i * WMR.  Their stage-0 source offsets are computed once; a
     // stage is a uniform byte step (SUB-or-1 x 64 B along an A row, SUB-or-1 [npad][64 B] slabs of the packed weights).
@@ -1022,24 +1032,41 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
         auto load_frags = [&](auto T_) __attribute__((always_inline)) {
             constexpr int t = decltype(T_)::value, set = t & 1;
             const unsigned char* At = T1 ? Ab + t * (AU * 1024) : Ab;
+            if constexpr (KS) {                               // fa[set][mi]: the pair's two row fragments, fb[set][0][ni]; K half kh only
+                const int q = 2 * kh + lhi;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int q = 2 * s2 + lhi;
-                fa[set][s2] = *reinterpret_cast<const Chunk16*>(At + swz(wave * 32 + l31 + (T1 ? 0 : t), q));
+                for (int mi = 0; mi < 2; ++mi) fa[set][mi] = *reinterpret_cast<const Chunk16*>(At + swz(kgrp * 64 + mi * 32 + l31 + (T1 ? 0 : t), q));
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) fb[set][s2][ni] = *reinterpret_cast<const Chunk16*>(Wb + t * WTB + swz(ni * 32 + l31, q));
+                for (int ni = 0; ni < NI; ++ni) fb[set][0][ni] = *reinterpret_cast<const Chunk16*>(Wb + t * WTB + swz(ni * 32 + l31, q));
+            } else {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int q = 2 * s2 + lhi;
+                    fa[set][s2] = *reinterpret_cast<const Chunk16*>(At + swz(wave * 32 + l31 + (T1 ? 0 : t), q));
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) fb[set][s2][ni] = *reinterpret_cast<const Chunk16*>(Wb + t * WTB + swz(ni * 32 + l31, q));
+                }
             }
         };
         load_frags(IC<0>{});
         StaticFor<SUB>::run([&](auto T_) __attribute__((always_inline)) {
             constexpr int t = decltype(T_)::value, set = t & 1;
             if constexpr (t + 1 < SUB) load_frags(IC<t + 1>{});
+            if constexpr (KS) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
+                for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&fa[set][s2]),
-                                                                        *reinterpret_cast<const bf16x8*>(&fb[set][s2][ni]), acc[0][ni], 0, 0, 0);
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&fa[set][mi]),
+                                                                             *reinterpret_cast<const bf16x8*>(&fb[set][0][ni]), acc[mi][ni], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&fa[set][s2]),
+                                                                            *reinterpret_cast<const bf16x8*>(&fb[set][s2][ni]), acc[0][ni], 0, 0, 0);
+            }
             if (nbuf >= 0) {
                 constexpr int PER = (MAXU + SUB - 1) / SUB;
                 StaticFor<PER>::run([&](auto J_) __attribute__((always_inline)) { issue_unit(IC<t * PER + decltype(J_)::value>{}, nbuf, nst); });
@@ -1093,10 +1120,42 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
         cur = cur == nst - 1 ? 0 : cur + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (KS) {
+        // partners swap halves of their partial sums: wave (g, kh) hands over row fragment 1 - kh and keeps fragment kh, i.e. rows
+        // [32 * wave, 32 * wave + 32) of the tile - the plain kernel's assignment.  The stage buffers are free now (every DMA has landed,
+        // the barrier below orders the last fragment reads before the overwrite).
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float* xmine = reinterpret_cast<float*>(dma_smem) + wave * (NI * 16 * 64) + lane;
+        const float* xpart = reinterpret_cast<const float*>(dma_smem) + (wave ^ 1) * (NI * 16 * 64) + lane;
+        if (kh) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xmine[(ni * 16 + r) * 64] = acc[0][ni][r];
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xmine[(ni * 16 + r) * 64] = acc[1][ni][r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kh) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][ni][r] = acc[1][ni][r] + xpart[(ni * 16 + r) * 64];
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][ni][r] += xpart[(ni * 16 + r) * 64];
+        }
+    }
+    f32x16 (&accf)[1][NI] = reinterpret_cast<f32x16 (&)[1][NI]>(acc);         // row fragment of this wave: acc[0][*]
 #ifdef GLOWTTS_TIMELINE
-    conv_epilogue<CT, 1, NI, EPI>(p, acc, m0, n0, BM, wave, 0, lane, tid, tlbuf);
+    conv_epilogue<CT, 1, NI, EPI>(p, accf, m0, n0, BM, wave, 0, lane, tid, tlbuf);
 #else
-    conv_epilogue<CT, 1, NI, EPI>(p, acc, m0, n0, BM, wave, 0, lane, tid, nullptr);
+    conv_epilogue<CT, 1, NI, EPI>(p, accf, m0, n0, BM, wave, 0, lane, tid, nullptr);
 #endif
     TL(29);
 }
@@ -1300,6 +1359,7 @@ inline bool dma_prefers_96(const glowtts_conv_args& a)
 template <int EPI, int TAPS, int NI = 2>
 int launch_dma(const glowtts_conv_args& a, hipStream_t s)
 {
+    const int ksplit = GLOWTTS_TUNABLE("GLOWTTS_DMA_KSPLIT", 1);           // wave pairs over the two K halves (see conv_dma_kernel)
     // waves per workgroup: all tiles resident at once (one workgroup per CU) if possible, else the fewest rounds
     const int force = GLOWTTS_TUNABLE("GLOWTTS_DMA_WAVES", 0);
     // GLOWTTS_DMA_LOADERS = 1 | 2: that many extra waves per workgroup do all the LDS-DMA staging (wave specialisation)
@@ -1341,6 +1401,8 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
     if (TAPS == 1 && gy <= 3 && force_t1n >= 4 && force_t1n <= WMAX) best = force_t1n;
     const int force_t5n = GLOWTTS_TUNABLE("GLOWTTS_DMA_WAVES_T5_NARROW", 0);      // k-tap convs with <= 192 columns
     if (TAPS > 1 && gy <= 3 && force_t5n >= 4 && force_t5n <= WMAX) best = force_t5n;
+    const bool ks = ksplit && !nload && NI == 2;
+    if (ks && (best & 1)) best += (best < WMAX) ? 1 : -1;                 // wave pairs
     const int BM = best * 32;
     const int nat = TAPS == 1 ? DMA1_CPS : 1, sub = TAPS == 1 ? DMA1_CPS : TAPS;
     // LDS stages: 2 by default.  Alone, the kernel is as fast with 2 as with 3 (17.7 us either way); in the training step the smaller
@@ -1348,16 +1410,19 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
     const int nst0 = GLOWTTS_TUNABLE("GLOWTTS_DMA_STAGES", 2) == 3 ? 3 : 2;
     const int nst_narrow = GLOWTTS_TUNABLE("GLOWTTS_DMA_STAGES_NARROW", 0);
     const int nst = (TAPS > 1 && gy <= 3 && (nst_narrow == 2 || nst_narrow == 3)) ? nst_narrow : nst0;
-    const int lds = (nload ? 2 : nst) * ((nat * ((BM + TAPS - 1 + 15) >> 4) + sub * (NI * 2)) * 1024);     // three stages: <= 159 KiB (16 waves x 5 taps, 10 waves 1x1)
+    int lds = (nload ? 2 : nst) * ((nat * ((BM + TAPS - 1 + 15) >> 4) + sub * (NI * 2)) * 1024);     // three stages: <= 159 KiB (16 waves x 5 taps, 10 waves 1x1)
+    if (ks) lds = std::max(lds, best * NI * 16 * 64 * 4);                 // the partial-sum exchange reuses the stage buffers
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<EPI, TAPS, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<EPI, TAPS, NI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<EPI, TAPS, NI, NI == 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return GLOWTTS_E_LAUNCH;
         attr_done = true;
     }
     dim3 grid(((a.rows + BM - 1) / BM) * gy);
     GLOWTTS_NOTE_STATIC("conv_dma<%s,%d>", epi_name(EPI), TAPS);
-    hipLaunchKernelGGL((conv_dma_kernel<EPI, TAPS, NI>), grid, dim3((best + nload) * 64), lds, s, a, nload ? 2 : nst, nload);
+    if (ks) hipLaunchKernelGGL((conv_dma_kernel<EPI, TAPS, NI, NI == 2>), grid, dim3(best * 64), lds, s, a, nst, 0);
+    else    hipLaunchKernelGGL((conv_dma_kernel<EPI, TAPS, NI, false>), grid, dim3((best + nload) * 64), lds, s, a, nload ? 2 : nst, nload);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
