@@ -1359,7 +1359,14 @@ inline bool dma_prefers_96(const glowtts_conv_args& a)
 template <int EPI, int TAPS, int NI = 2>
 int launch_dma(const glowtts_conv_args& a, hipStream_t s)
 {
-    const int ksplit = GLOWTTS_TUNABLE("GLOWTTS_DMA_KSPLIT", 1);           // wave pairs over the two K halves (see conv_dma_kernel)
+    // wave pairs over the two K halves (see conv_dma_kernel): measured on MI355X at B = 32 (tools/ab_conv.sh), a third less LDS fragment
+    // traffic bought nothing - In_l forward 18.3 vs 17.0 us, data gradient 19.9 vs 19.6, 1x1 convs 13.0 vs 12.6: the K loop is not bound
+    // by LDS read bandwidth but by its barrier / DMA-issue / latency structure.  Instantiated in tools builds only.
+#ifdef GLOWTTS_TOOLS
+    const int ksplit = GLOWTTS_TUNABLE("GLOWTTS_DMA_KSPLIT", 0);
+#else
+    constexpr int ksplit = 0;
+#endif
     // waves per workgroup: all tiles resident at once (one workgroup per CU) if possible, else the fewest rounds
     const int force = GLOWTTS_TUNABLE("GLOWTTS_DMA_WAVES", 0);
     // GLOWTTS_DMA_LOADERS = 1 | 2: that many extra waves per workgroup do all the LDS-DMA staging (wave specialisation)
@@ -1414,15 +1421,20 @@ int launch_dma(const glowtts_conv_args& a, hipStream_t s)
     if (ks) lds = std::max(lds, best * NI * 16 * 64 * 4);                 // the partial-sum exchange reuses the stage buffers
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<EPI, TAPS, NI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<EPI, TAPS, NI, NI == 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<EPI, TAPS, NI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return GLOWTTS_E_LAUNCH;
+#ifdef GLOWTTS_TOOLS
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<EPI, TAPS, NI, NI == 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return GLOWTTS_E_LAUNCH;
+#endif
         attr_done = true;
     }
     dim3 grid(((a.rows + BM - 1) / BM) * gy);
     GLOWTTS_NOTE_STATIC("conv_dma<%s,%d>", epi_name(EPI), TAPS);
-    if (ks) hipLaunchKernelGGL((conv_dma_kernel<EPI, TAPS, NI, NI == 2>), grid, dim3(best * 64), lds, s, a, nst, 0);
-    else    hipLaunchKernelGGL((conv_dma_kernel<EPI, TAPS, NI, false>), grid, dim3((best + nload) * 64), lds, s, a, nload ? 2 : nst, nload);
+#ifdef GLOWTTS_TOOLS
+    if (ks) { hipLaunchKernelGGL((conv_dma_kernel<EPI, TAPS, NI, NI == 2>), grid, dim3(best * 64), lds, s, a, nst, 0); return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH; }
+#endif
+    hipLaunchKernelGGL((conv_dma_kernel<EPI, TAPS, NI, false>), grid, dim3((best + nload) * 64), lds, s, a, nload ? 2 : nst, nload);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
