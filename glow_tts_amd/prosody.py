@@ -8,6 +8,42 @@ import math
 import torch
 
 
+class _GRUFunction(torch.autograd.Function):
+    """torch.nn.GRU (one layer, batch_first, h0 = 0) on the GPU: the input projection and the weight-gradient GEMMs are torch matmuls, the
+    recurrence is one launch per direction of glowtts_gru_fwd / glowtts_gru_bwd (MIOpen issues ~30 small launches per time step)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        import ctypes
+        from . import _lib
+        L = _lib.lib()
+        L.glowtts_gru_fwd.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+        B, T, _ = x.shape
+        H = w_hh.shape[1]
+        gi = torch.addmm(b_ih, x.reshape(B * T, -1), w_ih.t()).contiguous()
+        hs, keep = torch.empty(B, T, H, device=x.device), torch.empty(B, T, 4 * H, device=x.device)
+        w_hh_c, b_hh_c = w_hh.contiguous(), b_hh.contiguous()
+        _lib.check(L.glowtts_gru_fwd(_lib.ptr(gi), _lib.ptr(w_hh_c), _lib.ptr(b_hh_c), _lib.ptr(hs), _lib.ptr(keep), B, T, H, _lib.stream()), "glowtts_gru_fwd")
+        ctx.save_for_backward(x, w_ih, w_hh_c, hs, keep)
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        import ctypes
+        from . import _lib
+        x, w_ih, w_hh, hs, keep = ctx.saved_tensors
+        L = _lib.lib()
+        L.glowtts_gru_bwd.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+        B, T, H = hs.shape
+        dgi, dgh = torch.empty(B, T, 3 * H, device=x.device), torch.empty(B, T, 3 * H, device=x.device)
+        _lib.check(L.glowtts_gru_bwd(_lib.ptr(dhs.contiguous()), _lib.ptr(hs), _lib.ptr(keep), _lib.ptr(w_hh), _lib.ptr(dgi), _lib.ptr(dgh), B, T, H,
+                                     _lib.stream()), "glowtts_gru_bwd")
+        dgi2, dgh2 = dgi.view(B * T, 3 * H), dgh.view(B * T, 3 * H)
+        hprev = torch.cat([hs.new_zeros(B, 1, H), hs[:, :-1]], dim=1).reshape(B * T, H)
+        dx = (dgi2 @ w_ih).view_as(x) if ctx.needs_input_grad[0] else None
+        return dx, dgi2.t() @ x.reshape(B * T, -1), dgh2.t() @ hprev, dgi2.sum(0), dgh2.sum(0)
+
+
 class _ConvBlock(torch.nn.Sequential):
     def __init__(self, cin, cout, k, stride):
         super().__init__()
@@ -62,7 +98,10 @@ class Prosody_Encoder(torch.nn.Module):
         for i in range(self.n_conv):
             x = self.layer_Dict[f"Conv_{i}"](x)
         x = x.reshape(x.size(0), x.size(1) * x.size(2), x.size(3))
-        if not self.training and torch.is_grad_enabled() and x.requires_grad:
+        gru = self.layer_Dict["GRU"]
+        if x.is_cuda and gru.num_layers == 1 and 3 * gru.hidden_size <= 1024 and x.dtype == torch.float32:
+            x = _GRUFunction.apply(x.transpose(2, 1).contiguous(), gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
+        elif not self.training and torch.is_grad_enabled() and x.requires_grad:
             # MIOpen's fused RNN has no backward in eval mode ("miopen RNN backward can only be called in training mode"): gradients
             # through an eval()-mode model take torch's native GRU cell instead (same arithmetic, Modules.py:371)
             with torch.backends.cudnn.flags(enabled=False):

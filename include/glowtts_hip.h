@@ -380,6 +380,17 @@ int glowtts_utt_colsum(const float *x, int64_t ldx, float *out, int64_t ldout, i
                        int perm, int perm_h, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * GRU recurrence of the GST prosody encoder (Modules.py:338-343, 371: torch.nn.GRU, one layer, batch_first, h0 = 0), one launch per
+ * direction instead of MIOpen's ~30 launches per time step.  The caller does the GEMMs around it: gi = x W_ih^T + b_ih before,
+ * dx = dgi W_ih, dW_ih = dgi^T x, dW_hh = dgh^T h_prev, db = column sums after.   3H <= 1024.
+ *   gi [B][T][3H] (r | z | n pre-activations of the input side), w_hh [3H][H], b_hh [3H]
+ *   hs [B][T][H] every step's state; keep [B][T][4H] = (r, z, n, W_hn h + b_hn) for the backward
+ *   dhs [B][T][H] gradient w.r.t. every step's output -> dgi, dgh [B][T][3H] (gradients of the input- / hidden-side pre-activations) */
+int glowtts_gru_fwd(const float *gi, const float *w_hh, const float *b_hh, float *hs, float *keep, int B, int T, int H, void *stream);
+int glowtts_gru_bwd(const float *dhs, const float *hs, const float *keep, const float *w_hh, float *dgi, float *dgh,
+                    int B, int T, int H, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Text-encoder kernels that are not convolutions (rows layout).
  */
 /* y = rowmask * dropout( relu?( LayerNorm_C(a + b) * gamma + beta ) )   (Modules.py:485-487, 561-562, 569-571; eps 1e-4).

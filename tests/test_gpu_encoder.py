@@ -137,3 +137,30 @@ def test_log_prior_operands_and_values(Cm, Tx, Ty, ns):
     assert got.shape == (B, Ty, Tx)
     assert (got[~mask.transpose(1, 2)] == 0).all()
     assert (got.double() - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("B,T,D,H", [(5, 13, 256, 128), (3, 5, 8, 8), (2, 1, 12, 20), (4, 40, 64, 341)])
+def test_gru_recurrence_matches_torch_gru(B, T, D, H):
+    """glowtts_gru_fwd / _bwd (the prosody encoder's GRU, Modules.py:338-343, 371) against torch.nn.GRU's own arithmetic in fp64 on the
+    CPU: every step's state and the gradients of the input and of all four parameter tensors, for a loss that touches every step."""
+    from glow_tts_amd.prosody import _GRUFunction
+    g = torch.Generator().manual_seed(B * 100 + H)
+    ref = torch.nn.GRU(D, H, 1, batch_first=True).double()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(torch.randn(p.shape, generator=g, dtype=torch.float64) * 0.3)
+    x = torch.randn(B, T, D, generator=g, dtype=torch.float64)
+    w = torch.randn(B, T, H, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    (ref(xr)[0] * w).sum().backward()
+    want = ref(x)[0].detach()
+    params = [getattr(ref, n).detach().float().cuda().requires_grad_(True) for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
+    xg = x.float().cuda().requires_grad_(True)
+    hs = _GRUFunction.apply(xg, *params)
+    (hs * w.float().cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert (hs.detach().cpu().double() - want).abs().max() <= 2e-5
+    close = lambda got, ref_: (got.cpu().double() - ref_).abs().max().item() <= 2e-4 * max(1.0, ref_.abs().max().item())
+    assert close(xg.grad, xr.grad)
+    for p, n in zip(params, ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")):
+        assert close(p.grad, getattr(ref, n).grad), n
