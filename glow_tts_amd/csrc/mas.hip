@@ -44,7 +44,8 @@ __device__ __forceinline__ void push_lt_bit(unsigned int& bits, float a, float b
 // ((v_prev > v_cur) ? v_prev : v_cur): 3 VALU instructions instead of 5 per cell, on a loop that is bound by single-wave VALU issue.
 __device__ __forceinline__ float push_lt_bit_and_max(unsigned int& bits, float q_cur, float v_prev) {
     float m;
-    asm volatile("v_cmp_lt_f32 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\tv_cndmask_b32 %1, %2, %3, vcc"
+    // (the select first: v_addc_co overwrites VCC with its carry-out)
+    asm volatile("v_cmp_lt_f32 vcc, %2, %3\n\tv_cndmask_b32 %1, %2, %3, vcc\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
                  : "+v"(bits), "=&v"(m) : "v"(q_cur), "v"(v_prev) : "vcc");
     return m;
 }
