@@ -1194,12 +1194,12 @@ __global__ __launch_bounds__(128) void attn_bwd_long_kv_kernel(const float* __re
 static bool attn_mfma_ok(int Tp, int D, int win)          // 1: single-workgroup kernels (Tp <= 128); 2: long kernels (Tp <= 256); 0: general fp32 FMA kernels
 {
     const bool enabled = GLOWTTS_TUNABLE("GLOWTTS_ATTN_MFMA", 1) != 0;
-    return enabled && Tp <= AT_TP && (D == 64 || D == 96) && 2 * win + 1 <= 32;
+    return enabled && Tp <= AT_TP && Tp < GLOWTTS_TUNABLE("GLOWTTS_ATTN_LONG_MIN", AT_TP + 1) && (D == 64 || D == 96) && 2 * win + 1 <= 32;
 }
 static bool attn_long_ok(int Tp, int D, int win)
 {
     const bool enabled = GLOWTTS_TUNABLE("GLOWTTS_ATTN_MFMA", 1) != 0;
-    return enabled && Tp > AT_TP && Tp <= 256 && (D == 64 || D == 96) && 2 * win + 1 <= 32;
+    return enabled && Tp >= GLOWTTS_TUNABLE("GLOWTTS_ATTN_LONG_MIN", AT_TP + 1) && Tp <= 256 && (D == 64 || D == 96) && 2 * win + 1 <= 32;
 }
 static size_t attn_long_lds(int D) { return ((size_t)(128 + 32) * (D + 1) + 2 * 32 * ATL_LDP + 2 * 32 * 33) * sizeof(float); }
 static size_t attn_long_kv_lds(int D) { return ((size_t)256 * 65 + (size_t)128 * (D + 1)) * sizeof(float); }
