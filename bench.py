@@ -498,7 +498,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"{cfg['name']}, LJSpeech-shaped synthetic (80-mel, {Tm} frames, {Tt} tokens), "
                                    f"batch={B}/GPU, {'ragged Set V' if args.ragged else 'fixed Set F'}, forward+losses+backward"
-                                   + (", RCCL grad all-reduce" if world > 1 else ""),
+                                   + (f", {'RCCL' if args.backend == 'nccl' else args.backend} grad all-reduce" if world > 1 else ""),
                        "baseline_config": args.config, "mode": cfg["mode"] + ("/" + cfg["spk_type"] if cfg["mode"] == "SE" else ""),
                        "global_batch": B * world, "mel_frames": Tm, "tokens": Tt, "parallelism": f"dp{world}"},
             "loss": round(float(loss.item()), 4), "launch_mode": mode,
