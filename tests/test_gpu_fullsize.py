@@ -152,7 +152,6 @@ def test_reference_maximum_sizes_f32(case):
     encoder outputs 1e-4, every gradient 5e-3."""
     from glow_tts_amd.hparams import Recursive_Parse
     from glow_tts_amd.modules import GlowTTS, MLE_Loss
-    from helpers import launch_counts, launch_reset
     g = torch.Generator().manual_seed(31)
     Bm, Tt, Tm = 2, 202, 1000
     tl, ml = torch.tensor([202, 137]), torch.tensor([1000, 612])
