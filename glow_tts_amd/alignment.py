@@ -49,17 +49,27 @@ def log_prior_t(mean, log_std, z, token_lengths, mel_lengths, mel_multiple=1, re
     _lib.check(L.glowtts_logprior_prep(_lib.ptr(mean), _lib.ptr(log_std), _lib.ptr(token_lengths.contiguous()), _lib.ptr(mel_lengths.contiguous()),
                                        _lib.ptr(packed), _lib.ptr(cb), _lib.ptr(fmask), _lib.ptr(tx), _lib.ptr(ty), B, Cm, Tx, Ty, int(mel_multiple), None, None,
                                        _lib.stream()), "glowtts_logprior_prep")
-    zt = z.transpose(1, 2).contiguous()                                       # [B,Ty,Cm] frames x channels
+    # frames x channels operand: the decoder's own output rows when z is the tensor it just produced (a squeezed row holds ns consecutive
+    # frames x Cm channels; ROW_PAD pad rows in front of every utterance), else a transposed copy of z
+    from . import decoder as _D
+    rows, ns = _D.LAST_Z_ROWS["rows"], int(mel_multiple)
+    if _D.LAST_Z_ROWS["z"] is not None and _D.LAST_Z_ROWS["z"].data_ptr() == z.data_ptr() and rows is not None and Ty % ns == 0 and \
+            rows.shape == (B * (Ty // ns + 2 * _D.ROW_PAD), ns * Cm):
+        zt_ptr, zt_bstride, keep = rows.data_ptr() + 4 * _D.ROW_PAD * ns * Cm, (Ty // ns + 2 * _D.ROW_PAD) * ns * Cm, rows
+    else:
+        keep = z.transpose(1, 2).contiguous()                                  # [B,Ty,Cm]
+        zt_ptr, zt_bstride = keep.data_ptr(), Ty * Cm
     out = torch.empty(B, Ty, Tx, device=dev)
     a = ops.ConvArgs()
-    a.a, a.lda, a.ca1, a.ca, a.apro, a.rows = zt.data_ptr(), Cm, Cm, 2 * Cm, ops.APRO_SQNEG, Ty
+    a.a, a.lda, a.ca1, a.ca, a.apro, a.rows = zt_ptr, Cm, Cm, 2 * Cm, ops.APRO_SQNEG, Ty
     a.w, a.n, a.npad, a.kchunks, a.taps, a.pad, a.precision = packed.data_ptr(), Tx, npad.value, kch.value, 1, 0, ops.F32
     a.epi, a.flags = ops.EPI_LINEAR, ops.F_BIAS | ops.F_MASK | ops.F_COLMASK
     a.bias, a.rowmask, a.out0, a.ld0 = cb.data_ptr(), fmask.data_ptr(), out.data_ptr(), Tx
-    a.batch, a.a_bstride, a.w_bstride, a.bias_bstride, a.out_bstride, a.mask_bstride = B, Ty * Cm, stride, Tx, Ty * Tx, Ty
+    a.batch, a.a_bstride, a.w_bstride, a.bias_bstride, a.out_bstride, a.mask_bstride = B, zt_bstride, stride, Tx, Ty * Tx, Ty
     a.ncols_valid = tx.data_ptr()
     a.rows_per_utt = Ty
     _lib.check(_lib.lib().glowtts_conv_cl(ctypes.byref(a), _lib.stream()), "glowtts_conv_cl(log_prior)")
+    _D.LAST_Z_ROWS["rows"] = _D.LAST_Z_ROWS["z"] = None                        # (the launch is stream-ordered behind the producer; drop the references)
     return (out, tx, ty) if return_lengths else out
 
 

@@ -100,6 +100,9 @@ _WSTREAM = {}
 # backward queues the tail's launches here instead of issuing them; `flush_tail_wgrads()` issues them (bench.py captures that as a
 # second hipGraph).  The gradient tensors of the tail classes exist (autograd has already handed them to .grad) but hold no data until then.
 TAIL = {"defer": False, "pending": []}
+# The decoder's output in the rows layout [B*(T+4), C] next to the tensor z it was unsqueezed into: one squeezed row is ns consecutive
+# frames x Cm channels, i.e. already "frames x channels" for the log-prior GEMM (alignment.log_prior_t reads it instead of transposing z).
+LAST_Z_ROWS = {"rows": None, "z": None}
 # Measured design choices that tools / tests may flip programmatically (never read from the environment: DESIGN.md section 5 has the numbers).
 #   wgrad_wide: 16-byte staging items in the weight-gradient kernel; fuse_coupling_bwd: the next flow's coupling backward rides in the
 #   ActNorm / 1x1 backward pass; wgrad_split: weight gradients in n segments on a second stream (1 = one grouped launch per class);
@@ -303,12 +306,12 @@ def _dims(cfg, B, T, drop_p=0.0, seed=None, flow=0):
                     seed.data_ptr() if seed is not None else None, int(cfg.act_bf16))
 
 
-def squeeze_rows(cfg, mels, lengths, want_mask=True):
-    """[B,Cm,Tm] -> rows [B*(T+4), C] (+ rowmask [B*(T+4)])."""
+def squeeze_rows(cfg, mels, lengths, want_mask=True, out=None):
+    """[B,Cm,Tm] -> rows [B*(T+4), C] (+ rowmask [B*(T+4)]).  out: write the rows there (a kept buffer) instead of a fresh tensor."""
     B, Cm, Tm = mels.shape
     T = Tm // cfg.ns
     R = B * (T + 2 * ROW_PAD)
-    rows = torch.empty(R, cfg.C, device=mels.device)
+    rows = out if out is not None else torch.empty(R, cfg.C, device=mels.device)
     mask = torch.empty(R, device=mels.device) if want_mask else None
     _lib.check(_L().glowtts_squeeze_rows(_lib.ptr(mels.contiguous()), _lib.ptr(rows), _lib.ptr(mask), _lib.ptr(lengths),
                                          B, Cm, Tm, cfg.ns, _lib.stream()), "squeeze_rows")
@@ -373,10 +376,9 @@ def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
     """pitch: None or (pitches [B, Tm], pitch_w [F, L, 2H, ns], pitch_b [F, L, 2H]) - GR mode."""
     L = _L()
     B, _, Tm = mels.shape
-    x0, rowmask, T = squeeze_rows(cfg, mels, lengths)
-    R = x0.shape[0]
+    R = B * (Tm // cfg.ns + 2 * ROW_PAD)
     buf = _Buffers(cfg, prep, R, mels.device)
-    buf.x[0].copy_(x0)
+    _, rowmask, T = squeeze_rows(cfg, mels, lengths, out=buf.x[0])
     prow = pitch_rows(cfg, pitch[0], rowmask, B, T) if pitch is not None else None
     for f in range(cfg.F):
         if pitch is not None:
@@ -394,6 +396,7 @@ def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
                                         _lib.stream()), "glowtts_decoder_logdet")
     if pitch is not None:
         prep.set_cond(prep.cond)            # the backward addresses the conditioning gradient per utterance
+    LAST_Z_ROWS["rows"], LAST_Z_ROWS["z"] = buf.x[cfg.F], z
     return z, logdet, buf, rowmask, T, prow
 
 
