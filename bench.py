@@ -330,6 +330,7 @@ def main():
     ap.add_argument("--windows", type=int, default=10, help="extra timed windows of --steps steps after the reported one (median / spread keys)")
     ap.add_argument("--tokens", type=int, default=120, help="padded token length (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], help="A/B measurements: key=value entries of glow_tts_amd.decoder.TUNE (e.g. z_rows=0)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on device 0 (multi-rank smoke test on a single-GPU box)")
     ap.add_argument("--no-overlap", action="store_true", help="data parallel: one graph + one gradient exchange instead of the two-graph overlap")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to smoke-test the "
@@ -353,7 +354,10 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    from glow_tts_amd import _lib
+    from glow_tts_amd import _lib, decoder as _dec
+    for kv in args.tune:
+        k, v = kv.split("=")
+        _dec.TUNE[k] = type(_dec.TUNE[k])(int(v))
     from glow_tts_amd.distributed import FlatGradReducer, actnorm_stats_allreduce
     model, mle_loss, hp = build_model(args.precision, dev, cfg["mode"], cfg["spk_type"])
     reducer = None

@@ -107,7 +107,8 @@ LAST_Z_ROWS = {"rows": None, "z": None}
 #   wgrad_wide: 16-byte staging items in the weight-gradient kernel; fuse_coupling_bwd: the next flow's coupling backward rides in the
 #   ActNorm / 1x1 backward pass; wgrad_split: weight gradients in n segments on a second stream (1 = one grouped launch per class);
 #   act_bf16: WaveNet state / gates / gate gradients stored as bf16 in bf16 precision
-TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True}
+#   z_rows: the log-prior GEMM reads the decoder's output rows directly (no transposed copy of z)
+TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "z_rows": True}
 TAIL_STACKS = ("start_g", "start_v", "start_b", "rs_g", "rs_v", "rs_b", "rsl_g", "rsl_v", "rsl_b", "end_w", "end_b")
 
 
@@ -396,7 +397,8 @@ def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
                                         _lib.stream()), "glowtts_decoder_logdet")
     if pitch is not None:
         prep.set_cond(prep.cond)            # the backward addresses the conditioning gradient per utterance
-    LAST_Z_ROWS["rows"], LAST_Z_ROWS["z"] = buf.x[cfg.F], z
+    if TUNE["z_rows"]:
+        LAST_Z_ROWS["rows"], LAST_Z_ROWS["z"] = buf.x[cfg.F], z
     return z, logdet, buf, rowmask, T, prow
 
 
