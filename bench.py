@@ -333,6 +333,8 @@ def main():
     ap.add_argument("--tune", action="append", default=[], help="A/B measurements: key=value entries of glow_tts_amd.decoder.TUNE (e.g. z_rows=0)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on device 0 (multi-rank smoke test on a single-GPU box)")
     ap.add_argument("--no-overlap", action="store_true", help="data parallel: one graph + one gradient exchange instead of the two-graph overlap")
+    ap.add_argument("--force-dist", action="store_true", help="run the data-parallel code path (process group, two-graph overlap, all-reduces) "
+                    "even with one rank: exercises RCCL on a single-GPU box")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to smoke-test the "
                     "multi-rank code path on a single-GPU box together with --one-device)")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel eagerly instead of replaying the "
@@ -350,8 +352,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dp = world > 1 or args.force_dist
+    if dp:
         import torch.distributed as dist
+        from glow_tts_amd import distributed as _gd
+        _gd.SINGLE_RANK_IS_DIST = args.force_dist
+        if args.force_dist and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from glow_tts_amd import _lib, decoder as _dec
@@ -361,7 +368,7 @@ def main():
     from glow_tts_amd.distributed import FlatGradReducer, actnorm_stats_allreduce
     model, mle_loss, hp = build_model(args.precision, dev, cfg["mode"], cfg["spk_type"])
     reducer = None
-    if world > 1:
+    if dp:
         import torch.distributed as dist
         for p in model.parameters():                       # identical replicas
             dist.broadcast(p.data, 0)
@@ -373,7 +380,7 @@ def main():
     cond = conditioning_inputs(cfg, B, 1234 + rank, dev, hp)
 
     def barrier():
-        if world > 1:
+        if dp:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -399,11 +406,11 @@ def main():
             loss = train_step(model, mle_loss, batch, cond, reducer, world)
     if args.graph:
         try:
-            wfr = global_frame_weight(batch[3].sum()) if world > 1 else None      # constant for a fixed batch
+            wfr = global_frame_weight(batch[3].sum()) if dp else None      # constant for a fixed batch
 
             def fwd_bwd():
                 mle, length = forward_losses(model, mle_loss, batch, cond)
-                total = mle * wfr + length / world if world > 1 else mle + length
+                total = mle * wfr + length / world if dp else mle + length
                 model.zero_grad(set_to_none=True)
                 total.backward()
                 return (mle + length).detach()
@@ -416,7 +423,7 @@ def main():
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with _lib.pinned_sink(keep):
-                if world > 1 and not args.no_overlap:
+                if dp and not args.no_overlap:
                     # Data parallel: the step is two graphs.  The first ends with the k-tap weight gradients (71 of the 114 MB); their
                     # all-reduce - with the encoder's and the ActNorm / 1x1 gradients - then runs under the second graph, which holds the
                     # 1x1 weight-gradient groups and the weight-norm backward of their classes; the 15 MB those produce are reduced last.
@@ -431,7 +438,7 @@ def main():
                     early = FlatGradReducer([p for p in model.parameters() if id(p) not in tail_ids])
                     tail = FlatGradReducer([p for p in model.parameters() if id(p) in tail_ids])
                 else:
-                    with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local" if dp else "global"):
                         static_loss = fwd_bwd()
             graph.replay()
             if tail_graph is not None:
@@ -465,7 +472,7 @@ def main():
             out = one_step()
         barrier()
         el = time.time() - t0
-        if world > 1:
+        if dp:
             import torch.distributed as dist
             t = torch.tensor([el], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -475,7 +482,7 @@ def main():
     one_step()
     elapsed, loss = timed_window()                              # the reported window: exactly --steps steps
     extra = [timed_window()[0] for _ in range(max(0, args.windows))]
-    if world > 1:
+    if dp:
         # every gradient must have gone through the exchange: reduced gradients are identical on all ranks, unreduced ones are not
         # (different utterances and dropout streams per rank)
         import torch.distributed as dist
@@ -486,7 +493,7 @@ def main():
         if not torch.equal(lo, hi):
             raise SystemExit(f"[bench] rank {rank}: {int((lo != hi).sum())} gradient tensors differ between ranks after the all-reduce")
     frames = int(batch[3].sum().item())
-    if world > 1:
+    if dp:
         import torch.distributed as dist
         ft = torch.tensor([frames], device=dev, dtype=torch.float64)
         dist.all_reduce(ft)
@@ -502,7 +509,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"{cfg['name']}, LJSpeech-shaped synthetic (80-mel, {Tm} frames, {Tt} tokens), "
                                    f"batch={B}/GPU, {'ragged Set V' if args.ragged else 'fixed Set F'}, forward+losses+backward"
-                                   + (f", {'RCCL' if args.backend == 'nccl' else args.backend} grad all-reduce" if world > 1 else ""),
+                                   + (f", {'RCCL' if args.backend == 'nccl' else args.backend} grad all-reduce" if dp else ""),
                        "baseline_config": args.config, "mode": cfg["mode"] + ("/" + cfg["spk_type"] if cfg["mode"] == "SE" else ""),
                        "global_batch": B * world, "mel_frames": Tm, "tokens": Tt, "parallelism": f"dp{world}"},
             "loss": round(float(loss.item()), 4), "launch_mode": mode,
@@ -517,7 +524,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if dp:
         import torch.distributed as dist
         dist.destroy_process_group()
 

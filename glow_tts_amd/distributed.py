@@ -10,8 +10,11 @@ import torch
 import torch.distributed as dist
 
 
+SINGLE_RANK_IS_DIST = False      # bench.py --force-dist: run the collective code path with a 1-rank group (exercises RCCL on a single-GPU box)
+
+
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or SINGLE_RANK_IS_DIST)
 
 
 def actnorm_stats_allreduce(stats):
