@@ -370,8 +370,8 @@ def main():
     reducer = None
     if dp:
         import torch.distributed as dist
-        for p in model.parameters():                       # identical replicas
-            dist.broadcast(p.data, 0)
+        from glow_tts_amd.distributed import broadcast_parameters
+        broadcast_parameters(model)                          # identical replicas
         model.actnorm_allreduce = actnorm_stats_allreduce
         reducer = FlatGradReducer(list(model.parameters()))
     torch.manual_seed(4321 + rank)                              # dropout streams differ per rank; the replicas' weights do not

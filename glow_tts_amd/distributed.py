@@ -17,6 +17,18 @@ def is_dist():
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or SINGLE_RANK_IS_DIST)
 
 
+def broadcast_parameters(model, src=0):
+    """Identical replicas at start: rank `src`'s parameters and buffers to every rank (tensors made contiguous first: RCCL rejects
+    strided ones, e.g. a loaded checkpoint's column-major 4x4 flow weights)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            if not t.data.is_contiguous():
+                t.data = t.data.contiguous()
+            dist.broadcast(t.data, src)
+
+
 def actnorm_stats_allreduce(stats):
     if is_dist():
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)

@@ -86,6 +86,7 @@ class _Flow(torch.nn.Module):
         w = torch.linalg.qr(torch.randn(ns, ns))[0]                     # Modules.py:718-725
         if torch.det(w) < 0:
             w[:, 0] = -w[:, 0]
+        w = w.contiguous()                                              # (qr returns a column-major Q; collectives need contiguous tensors)
         coupling = _Dict()
         coupling.layer_Dict["Start"] = _conv_params(H, C // 2, 1, "linear", weight_norm=True)
         wavenet = _Dict()

@@ -77,9 +77,8 @@ class Trainer:
         self.scheduler = Modified_Noam_Scheduler(self.optimizer, base=hp.Train.Learning_Rate.Base)
         self.reducer = None
         if self.world > 1:
-            from .distributed import FlatGradReducer, actnorm_stats_allreduce
-            for p in model.parameters():
-                torch.distributed.broadcast(p.data, 0)
+            from .distributed import FlatGradReducer, actnorm_stats_allreduce, broadcast_parameters
+            broadcast_parameters(model)
             model.actnorm_allreduce = actnorm_stats_allreduce
             self.reducer = FlatGradReducer(list(model.parameters()))
         self._comp = torch.zeros(4, device=self.device)      # MLE, Length, Total, Speaker of the last step (written inside the graph)
