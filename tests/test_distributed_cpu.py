@@ -56,6 +56,18 @@ def _worker(rank, world, port, out):
     assert ptrs == [p.grad.data_ptr() for p in model.parameters()], "the reduction must be in place (hipGraph replays rely on it)"
     stats = torch.tensor([float(rank + 1), 2.0, float(local_frames)])
     actnorm_stats_allreduce(stats)
+    # identical replicas at start, also for strided parameters (the 4x4 flow weights come column-major out of torch.linalg.qr; RCCL rejects those)
+    from glow_tts_amd.distributed import broadcast_parameters
+    torch.manual_seed(100 + rank)
+    m2 = torch.nn.Linear(4, 4)
+    m2.weight.data = torch.randn(4, 4).t()                        # non-contiguous
+    m2.register_buffer("buf", torch.full((3,), float(rank)))
+    assert not m2.weight.data.is_contiguous()
+    broadcast_parameters(m2)
+    torch.manual_seed(100)
+    ref = torch.nn.Linear(4, 4)
+    ref_w = torch.randn(4, 4).t()
+    assert m2.weight.data.is_contiguous() and torch.equal(m2.weight.data, ref_w) and torch.equal(m2.bias.data, ref.bias.data) and float(m2.buf[0]) == 0.0
     if rank == 0:
         torch.save({"grads": [p.grad.clone() for p in model.parameters()], "stats": stats}, out)
     dist.barrier()
