@@ -20,8 +20,8 @@ def load(counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return {k: sum(v[-4:]) / len(v[-4:]) for k, v in acc.items()}        # mean of the last launches (warm caches, like the step)
-fetch, write = load("FETCH_SIZE"), load("WRITE_SIZE")
+    return {k: sum(v[-4:]) / len(v[-4:]) for k, v in acc.items()}, {k: max(v) for k, v in acc.items()}     # mean of the last launches (warm caches, like the step); max
+(fetch, fetch_max), (write, write_max) = load("FETCH_SIZE"), load("WRITE_SIZE")
 def pick(d, *subs):
     for k, v in d.items():
         if all(s in k for s in subs):
@@ -32,8 +32,8 @@ GiB = 1024.0 ** 3
 def pick_max(d, sub):                                    # the 1 GiB calibration launches are the largest of their kernel class
     v = [x for k, x in d.items() if sub in k]
     return max(v) if v else None
-fill_w = pick_max(write, "FillFunctor")
-mul_r, mul_w = pick_max(fetch, "MulFunctor"), pick_max(write, "MulFunctor")
+fill_w = pick_max(write_max, "FillFunctor")
+mul_r, mul_w = pick_max(fetch_max, "MulFunctor"), pick_max(write_max, "MulFunctor")
 wcal = GiB / (fill_w * 1024) if fill_w else None
 out = {"shape": [32, 400], "precision": "bf16", "units": "bytes per launch",
        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/pmc_conv.sh); FETCH_SIZE x 1024 x 2 (gfx950: 128-byte "
