@@ -46,7 +46,7 @@ def _oracle_grads(cfg, sd, mels, ml, spk, wz, wl):
     return zo.detach(), ldo.detach(), {k: v.grad for k, v in sdg.items()}, x.grad, (s.grad if s is not None else None)
 
 
-def _hip_grads(cfg, sd, mels, ml, spk, wz, wl, precision):
+def _hip_grads(cfg, sd, mels, ml, spk, wz, wl, precision, drop_p=0.0):
     from glow_tts_amd import decoder as D
     dc = D.DecoderConfig(cfg.mel_dim, cfg.n_flows, cfg.n_squeeze, cfg.n_split, cfg.wn_channels, cfg.wn_layers, cfg.wn_kernel, precision)
     P = {k: v.cuda().requires_grad_(True) for k, v in sd.items()}
@@ -55,7 +55,7 @@ def _hip_grads(cfg, sd, mels, ml, spk, wz, wl, precision):
     W = D.stack_decoder_weights(P, dc)
     cond = D.conditioning(P, dc, speakers=s) if s is not None else None
     launch_reset()
-    z, logdet = D.DecoderFunction.apply(dc, x, ml.cuda(), cond, 0.0, None, None, None, *W)
+    z, logdet = D.DecoderFunction.apply(dc, x, ml.cuda(), cond, drop_p, None, None, None, *W)
     ((z * wz.cuda()).sum() + (logdet * wl.cuda()).sum()).backward()
     torch.cuda.synchronize()
     return z.detach().cpu(), logdet.detach().cpu(), {k: p.grad.cpu() for k, p in P.items()}, x.grad.cpu(), (s.grad.cpu() if s is not None else None), launch_counts()
@@ -125,4 +125,37 @@ def test_full_width_backward_bf16_takes_the_benchmarked_kernels(spk_dim):
     assert (a @ b / (a.norm() * b.norm())).item() >= 0.98 and 0.9 <= (a.norm() / b.norm()).item() <= 1.1
     if dso is not None:
         a, b = ds.flatten().double(), dso.flatten().double()
+        assert (a @ b / (a.norm() * b.norm())).item() >= 0.98
+
+
+@pytest.mark.parametrize("spk_dim", [0, 256])
+def test_full_width_dropout_masks_agree_between_forward_backward_and_precisions(spk_dim):
+    """Training-mode WaveNet dropout (Modules.py:861-862, p = 0.3 here) at the benchmarked width.  The keep mask is a counter hash of (seed, row,
+    channel), regenerated by the backward; the bf16 path draws it in `conv_dma_kernel<GATE>` / `conv_dma_kernel<DGATE>` / `conv_chain<LINEAR,DGATE>`,
+    the f32 path in the register-staged kernels.  Same seed => the two precisions see the SAME masks, so (1) z agrees to bf16 accuracy,
+    (2) every gradient of the bf16 path has cosine >= 0.98 with the f32 path's - a forward / backward mask mismatch in any of the DMA kernels
+    would decorrelate them (p = 0.3 rescales 30 % of the gate gradients to zero), (3) the conditioning gradient, taken BEFORE the mask, agrees
+    too, (4) the same seed reproduces z bit for bit, another seed does not."""
+    case = _case(spk_dim, 777 + spk_dim)
+    torch.manual_seed(5)
+    z32, ld32, g32, dx32, ds32, _ = _hip_grads(*case, precision=0, drop_p=0.3)
+    torch.manual_seed(5)
+    z16, ld16, g16, dx16, ds16, counts = _hip_grads(*case, precision=1, drop_p=0.3)
+    torch.manual_seed(5)
+    z16b = _hip_grads(*case, precision=1, drop_p=0.3)[0]
+    torch.manual_seed(6)
+    z16c = _hip_grads(*case, precision=1, drop_p=0.3)[0]
+    assert torch.equal(z16, z16b) and (z16 - z16c).abs().max() > 1e-2
+    assert _count(counts, "conv_dma<GATE,5>") == N_FLOWS * 4 and _count(counts, "conv_chain<LINEAR,DGATE>") == N_FLOWS
+    mask = O.mask_from_lengths(case[3], TM)
+    assert ((z16 - z32) * mask).abs().max() <= 0.15
+    worst = (2.0, "")
+    for k, want in g32.items():
+        a, b = g16[k].flatten().double(), want.flatten().double()
+        cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+        worst = min(worst, (cos, k))
+        assert cos >= 0.98 and 0.9 <= (a.norm() / (b.norm() + 1e-30)).item() <= 1.1, (k, cos)
+    print("dropout, bf16 vs f32 path, worst gradient cosine:", worst)
+    if ds32 is not None:
+        a, b = ds16.flatten().double(), ds32.flatten().double()
         assert (a @ b / (a.norm() * b.norm())).item() >= 0.98
