@@ -25,6 +25,8 @@
 #include <type_traits>
 #include "../../include/glowtts_hip.h"
 #include "launch_log.h"
+#include "tunable.h"
+#include <algorithm>
 
 namespace {
 
@@ -205,21 +207,24 @@ __global__ __launch_bounds__(64) void mas_dp_kernel(const float* __restrict__ va
 
 template <typename T>
 __global__ __launch_bounds__(256) void mas_path_kernel(const int32_t* __restrict__ idx, T* __restrict__ path,
-                                                       int Tx, int Ty, int vec_ok)
+                                                       int Tx, int Ty, int vec_ok, int rows_per_block)
 {
-    // grid: (ceil(Tx/8), B); a block writes 8 token rows x all frames; each thread 4 consecutive frames
+    // grid: (ceil(Tx / rows_per_block), B); a block writes rows_per_block token rows x all frames; each thread 4 consecutive frames
     const int b = blockIdx.y;
-    const int x0 = blockIdx.x * 8;
+    const int x0 = blockIdx.x * rows_per_block;
+    const int x1 = min(Tx, x0 + rows_per_block);
     const int32_t* ib = idx + (size_t)b * Ty;
     for (int y0 = threadIdx.x * 4; y0 < Ty; y0 += 1024) {
         int id[4];
+        if (vec_ok && y0 + 3 < Ty) {
+            const int4 v = *reinterpret_cast<const int4*>(ib + y0);
+            id[0] = v.x; id[1] = v.y; id[2] = v.z; id[3] = v.w;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) id[e] = (y0 + e < Ty) ? ib[y0 + e] : -1;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int x = x0 + r;
-            if (x >= Tx) break;
-            T* out = path + ((size_t)b * Tx + x) * Ty + y0;
+            for (int e = 0; e < 4; ++e) id[e] = (y0 + e < Ty) ? ib[y0 + e] : -1;
+        }
+        T* out = path + ((size_t)b * Tx + x0) * Ty + y0;
+        for (int x = x0; x < x1; ++x, out += Ty) {
             T v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (id[e] == x) ? (T)1 : (T)0;
@@ -298,10 +303,11 @@ extern "C" int glowtts_mas_path_from_idx(const int32_t* idx, void* path, int B, 
     if (!idx || !path || B < 0 || Tx < 1 || Ty < 1 || (out_dtype != 0 && out_dtype != 1)) return GLOWTTS_E_ARG;
     if (B == 0) return GLOWTTS_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    dim3 grid((Tx + 7) / 8, B);
-    const int vec_ok = (Ty % 4 == 0) && ((reinterpret_cast<uintptr_t>(path) & 15) == 0);
-    if (out_dtype == 0) hipLaunchKernelGGL(mas_path_kernel<int32_t>, grid, dim3(256), 0, s, idx, static_cast<int32_t*>(path), Tx, Ty, vec_ok);
-    else                hipLaunchKernelGGL(mas_path_kernel<float>, grid, dim3(256), 0, s, idx, static_cast<float*>(path), Tx, Ty, vec_ok);
+    const int rpb = std::max(1, GLOWTTS_TUNABLE("GLOWTTS_PATH_ROWS", 8));
+    dim3 grid((Tx + rpb - 1) / rpb, B);
+    const int vec_ok = (Ty % 4 == 0) && ((reinterpret_cast<uintptr_t>(path) & 15) == 0) && ((reinterpret_cast<uintptr_t>(idx) & 15) == 0);
+    if (out_dtype == 0) hipLaunchKernelGGL(mas_path_kernel<int32_t>, grid, dim3(256), 0, s, idx, static_cast<int32_t*>(path), Tx, Ty, vec_ok, rpb);
+    else                hipLaunchKernelGGL(mas_path_kernel<float>, grid, dim3(256), 0, s, idx, static_cast<float*>(path), Tx, Ty, vec_ok, rpb);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
