@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void mas_dp_kernel(const float* __restrict__ va
             float v[4][R];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float* col = vb + (size_t)min(chunk * 4 + e, Ty - 1) * Tx;
+                const float* col = vb + (uint32_t)min(chunk * 4 + e, Ty - 1) * (uint32_t)Tx;       // (Tx * Ty < 2^31 elements per utterance: host-checked)
                 if (VEC4 && R == 2) { const float2 t = *reinterpret_cast<const float2*>(col + xt); v[e][0] = t.x; v[e][R - 1] = t.y; }
                 else if (VEC4 && R == 4) { const float4 t = *reinterpret_cast<const float4*>(col + xt); v[e][0] = t.x; v[e][1 % R] = t.y; v[e][2 % R] = t.z; v[e][3 % R] = t.w; }
                 else {
@@ -123,13 +123,19 @@ __global__ __launch_bounds__(64) void mas_dp_kernel(const float* __restrict__ va
 #pragma unroll
     for (int j = 0; j < R; ++j) { q[j] = 0.f; bits[j] = 0u; }
 
+    float upkeep = neg;
     // DIAG: the chunk may hold cells on the diagonal x == y (columns < Tx); beyond it the cheaper fused compare is exact
     auto compute_chunk = [&](const float4 (&cur)[R], int chunk, auto DIAG_) {
         constexpr bool DIAG = decltype(DIAG_)::value;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int y = chunk * 4 + e;                                          // wave-uniform
-            const float up = wave_shr1(q[R - 1], (DIAG && y == 0) ? 0.f : neg);   // Q[x-1][y-1]; row -1: core.pyx:23-27
+            // Q[x-1][y-1] from the lane below; lane 0 (row -1, core.pyx:23-27) keeps `old`: 0 at y = 0, else neg.  Off the diagonal region `old`
+            // is the previous shift's result - its lane 0 still holds neg, the other lanes are overwritten - so the DPP move needs no
+            // re-initialised destination (one VALU less per column).
+            float up;
+            if constexpr (DIAG) up = wave_shr1(q[R - 1], y == 0 ? 0.f : neg);
+            else { up = wave_shr1(q[R - 1], upkeep); upkeep = up; }
             float qo[R];
 #pragma unroll
             for (int j = 0; j < R; ++j) qo[j] = q[j];
@@ -161,22 +167,26 @@ __global__ __launch_bounds__(64) void mas_dp_kernel(const float* __restrict__ va
 #pragma unroll
     for (int c = 0; c < D; ++c) load_chunk(ring[c], c);
     const int niter = (ty + 63) >> 6;
-    for (int it = 0; it < niter; ++it) {
+    // 64 columns per iteration; the first ceil(Tx / 64) iterations may touch the diagonal, the others take the cheaper cell update
+    auto iteration = [&](int it, auto DIAG_) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < D; ++c) {
             float4 cur[R];
 #pragma unroll
             for (int j = 0; j < R; ++j) cur[j] = ring[c][j];
             load_chunk(ring[c], (it + 1) * D + c);                               // refill this slot, 64 columns ahead
-            if ((it * D + c) * 4 < Tx) compute_chunk(cur, it * D + c, std::true_type{});          // wave-uniform
-            else                       compute_chunk(cur, it * D + c, std::false_type{});
+            compute_chunk(cur, it * D + c, DIAG_);
             if ((c & 7) == 7) {                                                  // 32 columns done: park the bit words
                 const int blk = it * 2 + (c >> 3);
 #pragma unroll
                 for (int j = 0; j < R; ++j) { dec[(blk * R + j) * 64 + lane] = bits[j]; bits[j] = 0u; }   // bit (31 - c) <-> column blk*32 + c
             }
         }
-    }
+    };
+    const int it_diag = min(niter, (Tx + 63) >> 6);
+    int it = 0;
+    for (; it < it_diag; ++it) iteration(it, std::true_type{});
+    for (; it < niter; ++it) iteration(it, std::false_type{});
     __syncthreads();
 
     // ---- backtrack (core.pyx:31-35): wave-uniform walk, one step per row change ----
@@ -284,7 +294,7 @@ int launch_dp(const float* value, const int32_t* t_xs, const int32_t* t_ys, int3
 int dispatch_dp(const float* value, const int32_t* t_xs, const int32_t* t_ys, int32_t* idx_out, float* q_out,
                 int B, int Tx, int Ty, float neg, bool tr, void* stream)
 {
-    if (!value || !t_xs || !t_ys || B < 0 || Tx < 1 || Ty < 1 || Tx > 512) return GLOWTTS_E_ARG;
+    if (!value || !t_xs || !t_ys || B < 0 || Tx < 1 || Ty < 1 || Tx > 512 || (int64_t)Tx * Ty >= ((int64_t)1 << 31)) return GLOWTTS_E_ARG;
     if (B == 0) return GLOWTTS_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int R = (Tx + 63) / 64;
