@@ -213,9 +213,32 @@ extern "C" int glowtts_logprior_prep(const float* mean, const float* log_std, co
                        mean, log_std, token_lengths, mel_lengths, packed, cb, fmask, tx32, ty32, B, Cm, Tx, Ty, npad, kch, mel_multiple);
     RET_LAUNCH();
 }
+// the same gather as a linear sweep over 16-byte groups of the output (four frames of one (utterance, channel) row per thread: one int4
+// of token indices, four gathers from the 480-byte source row, one 16-byte store)
+__global__ __launch_bounds__(256) void expand_fwd4_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, float* __restrict__ out,
+                                                          int C, int Tx, int Ty, unsigned int total4)
+{
+    const unsigned int q = (unsigned int)Ty >> 2;
+    for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < total4; i += gridDim.x * 256u) {
+        const unsigned int row = i / q, y4 = i - row * q;          // row = b * C + c
+        const unsigned int b = row / (unsigned int)C;
+        const int4 id = *reinterpret_cast<const int4*>(idx + (size_t)b * Ty + (size_t)y4 * 4);
+        const float* s = src + (size_t)row * Tx;
+        float4 v;
+        v.x = id.x >= 0 ? s[id.x] : 0.f; v.y = id.y >= 0 ? s[id.y] : 0.f; v.z = id.z >= 0 ? s[id.z] : 0.f; v.w = id.w >= 0 ? s[id.w] : 0.f;
+        *reinterpret_cast<float4*>(out + (size_t)i * 4) = v;
+    }
+}
+
 extern "C" int glowtts_expand_fwd(const float* src, const int32_t* idx, float* out, int B, int C, int Tx, int Ty, void* stream)
 {
     if (!src || !idx || !out || B < 1 || C < 1 || Tx < 1 || Ty < 1) return GLOWTTS_E_ARG;
+    const uint64_t total4 = (uint64_t)B * C * Ty / 4;
+    if ((Ty & 3) == 0 && ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && total4 < (1ull << 31)) {
+        const unsigned int blocks = (unsigned int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+        hipLaunchKernelGGL(expand_fwd4_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, idx, out, C, Tx, Ty, (unsigned int)total4);
+        RET_LAUNCH();
+    }
     hipLaunchKernelGGL(expand_fwd_kernel, dim3((Ty + 255) / 256, C, B), dim3(256), 0, static_cast<hipStream_t>(stream), src, idx, out, C, Tx, Ty);
     RET_LAUNCH();
 }
