@@ -23,7 +23,7 @@ def _lib2():
         L.glowtts_expand_bwd.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
         L.glowtts_duration_targets.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
         L.glowtts_mle_loss_fwd.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-        L.glowtts_mle_loss_bwd.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_void_p]
+        L.glowtts_mle_loss_bwd.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         _decl = True
     return L
 
@@ -140,9 +140,9 @@ class MLELoss(torch.autograd.Function):
         z, mean, log_std, inv = ctx.saved_tensors
         dz, dm, dl = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
         dl_ = dloss.contiguous().reshape(1)
+        dlogdet = torch.empty(ctx.B, device=z.device)
         _lib.check(_lib2().glowtts_mle_loss_bwd(_lib.ptr(z), _lib.ptr(mean), _lib.ptr(log_std), _lib.ptr(dl_), _lib.ptr(inv), _lib.ptr(dz),
-                                                _lib.ptr(dm), _lib.ptr(dl), z.numel(), _lib.stream()), "glowtts_mle_loss_bwd")
-        dlogdet = (-dl_ * inv).expand(ctx.B).contiguous()
+                                                _lib.ptr(dm), _lib.ptr(dl), z.numel(), _lib.ptr(dlogdet), ctx.B, _lib.stream()), "glowtts_mle_loss_bwd")
         return dz, dm, dl, dlogdet, None, None, None
 
 

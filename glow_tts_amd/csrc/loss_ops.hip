@@ -99,9 +99,11 @@ __global__ __launch_bounds__(256) void mle_final_kernel(const float* __restrict_
 // gradients: dz = g e (z - m), dmean = -dz, dls = g (1 - e (z - m)^2), with e = exp(-2 ls), g = dloss / denom
 __global__ __launch_bounds__(256) void mle_bwd_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ ls,
                                                       const float* __restrict__ dloss, const float* __restrict__ inv_denom,
-                                                      float* __restrict__ dz, float* __restrict__ dmean, float* __restrict__ dls, long n)
+                                                      float* __restrict__ dz, float* __restrict__ dmean, float* __restrict__ dls, long n,
+                                                      float* __restrict__ dlogdet, int B)
 {
     const float g = dloss[0] * inv_denom[0];
+    if (dlogdet && blockIdx.x == 0) for (int b = threadIdx.x; b < B; b += 256) dlogdet[b] = -g;          // d loss / d log_dets[b]  (Modules.py:1025-1027)
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float d = z[i] - mean[i], e = expf(-2.f * ls[i]);
         const float t = g * e * d;
@@ -268,10 +270,11 @@ extern "C" int glowtts_mle_loss_fwd(const float* z, const float* mean, const flo
     RET_LAUNCH();
 }
 extern "C" int glowtts_mle_loss_bwd(const float* z, const float* mean, const float* log_std, const float* dloss, const float* inv_denom,
-                                    float* dz, float* dmean, float* dlog_std, int64_t n, void* stream)
+                                    float* dz, float* dmean, float* dlog_std, int64_t n, float* dlogdet, int B, void* stream)
 {
-    if (!z || !mean || !log_std || !dloss || !inv_denom || !dz || !dmean || !dlog_std || n < 1) return GLOWTTS_E_ARG;
+    if (!z || !mean || !log_std || !dloss || !inv_denom || !dz || !dmean || !dlog_std || n < 1 || (dlogdet && B < 1)) return GLOWTTS_E_ARG;
     const long g = (n + 255) / 256;
-    hipLaunchKernelGGL(mle_bwd_kernel, dim3((int)(g > 2048 ? 2048 : g)), dim3(256), 0, static_cast<hipStream_t>(stream), z, mean, log_std, dloss, inv_denom, dz, dmean, dlog_std, (long)n);
+    hipLaunchKernelGGL(mle_bwd_kernel, dim3((int)(g > 2048 ? 2048 : g)), dim3(256), 0, static_cast<hipStream_t>(stream), z, mean, log_std, dloss, inv_denom, dz, dmean, dlog_std, (long)n,
+                       dlogdet, B);
     RET_LAUNCH();
 }

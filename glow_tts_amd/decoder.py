@@ -80,6 +80,7 @@ def _L():
         L.glowtts_weightnorm_fwd.argtypes = [c_void_p] * 4 + [c_i64, c_int, c_void_p]
         L.glowtts_weightnorm_bwd.argtypes = [c_void_p] * 6 + [c_i64, c_int, c_void_p]
         L.glowtts_decoder_logdet.argtypes = [c_void_p, c_i64] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]
+        L.glowtts_decoder_param_grads.argtypes = [c_void_p] * 7 + [c_int] * 4 + [c_void_p]
         _declared = True
     return L
 
@@ -619,13 +620,10 @@ class DecoderFunction(torch.autograd.Function):
                 grp.launch_segment(0)
         _lib.check(L.glowtts_colsum_batched(scratch.data_ptr(), d_an.data_ptr(), L.glowtts_actnorm_bwd_blocks(R), 2 * C + 16, F_, nscr, 2 * C + 16, _lib.stream()),
                    "glowtts_colsum_batched")
-        # log-determinant terms of the parameters (Modules.py:694, 747): logdet_b += (sum logs + logdet(W) C/4) * len_b
-        lens = rowmask.view(B, -1).sum(1)
-        s = (dld * lens).sum()
-        G["an_logs"] = d_an[:, :C] + s
-        G["an_bias"] = d_an[:, C:2 * C]
-        winv_t = prep.winfo[:, 16:32].view(F_, 4, 4).transpose(1, 2)
-        G["inv_w"] = d_an[:, 2 * C:].view(F_, 4, 4) + s * (C / 4) * winv_t
+        # + the log-determinant terms of the parameters (Modules.py:694, 747): logdet_b += (sum logs + logdet(W) C/4) * len_b
+        _lib.check(L.glowtts_decoder_param_grads(d_an.data_ptr(), dld.data_ptr(), rowmask.data_ptr(), prep.winfo.data_ptr(), G["an_logs"].data_ptr(),
+                                                 G["an_bias"].data_ptr(), G["inv_w"].data_ptr(), F_, B, T + 2 * ROW_PAD, C, _lib.stream()),
+                   "glowtts_decoder_param_grads")
         dmel = unsqueeze_rows(cfg, dx, ctx.lengths, B, Tm) if ctx.want_dmel else None
         dpw = dpb = None
         if ctx.prow is not None:

@@ -244,6 +244,10 @@ int glowtts_actnorm_inv1x1_bwd_coupling(const float *dz, float *dx, const float 
 /* out[b][i] = sum_r partial[b][r][i], i < n, r < nrows (deterministic): reduces the per-block partials of several
  * glowtts_actnorm_inv1x1_bwd calls made with param_grads = NULL (their `scratch` buffers, part_stride floats apart) in one launch */
 int glowtts_colsum_batched(const float *partial, float *out, int nrows, int n, int batch, int64_t part_stride, int64_t out_stride, void *stream);
+/* Parameter gradients of ActNorm / inv-1x1 of all F flows from the reduced data terms d_an [F][2C+16] (glowtts_colsum_batched) plus the
+ * log-determinant terms of Modules.py:694, 747: dlogs [F][C], dbias [F][C], dw [F][4][4]; rowmask [B][Tp], dlogdet [B], winfo [F][36]. */
+int glowtts_decoder_param_grads(const float *d_an, const float *dlogdet, const float *rowmask, const float *winfo,
+                                float *dlogs, float *dbias, float *dw, int F, int B, int Tp, int C, void *stream);
 /* Decoder log-determinant (Modules.py:309): logdet[b] = sum_f [ (sum logs_f + logdet W_f * C/4) * len_b + sum logs^coupling ].
  * outs_all: the F kept (m, logs) buffers, flow_stride floats apart; part [F*B] scratch. */
 int glowtts_decoder_logdet(const float *outs_all, int64_t flow_stride, const float *logs_all, const float *winfo_all,
@@ -440,8 +444,9 @@ int glowtts_duration_targets(const int32_t *idx, const int64_t *token_lengths, f
 /* MLE_Loss (Modules.py:1020-1029) over n = B*mel_dim*T_mel elements; loss and inv_denom are device scalars; scratch 1024 floats */
 int glowtts_mle_loss_fwd(const float *z, const float *mean, const float *log_std, const float *log_dets, const int64_t *lengths,
                          float *loss, float *inv_denom, float *scratch, int64_t n, int B, int n_squeeze, int mel_dim, void *stream);
+/* dlogdet (optional, [B]): also writes d loss / d log_dets[b] = -dloss * inv_denom */
 int glowtts_mle_loss_bwd(const float *z, const float *mean, const float *log_std, const float *dloss, const float *inv_denom,
-                         float *dz, float *dmean, float *dlog_std, int64_t n, void *stream);
+                         float *dz, float *dmean, float *dlog_std, int64_t n, float *dlogdet, int B, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Old-style weight normalisation of the WaveNet convolutions (Modules.py:766,818,825,838,845: torch.nn.utils.weight_norm,
