@@ -23,6 +23,8 @@ import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+if os.environ.get("GLOWTTS_PKG_ROOT"):          # A/B against another checkout of the package (tools only): its directory goes first on sys.path
+    sys.path.insert(0, os.environ["GLOWTTS_PKG_ROOT"])
 
 FLOP_PER_FRAME_FWD_BWD = 71.3e6      # SURVEY.md 8d / BASELINE.md: 57.05 GFLOP per 800-frame utterance (reference FlopCounterMode)
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
