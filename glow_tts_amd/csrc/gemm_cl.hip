@@ -1307,6 +1307,81 @@ __global__ __launch_bounds__(CH_WN * CH_WM * 64) void conv_chain_kernel(const gl
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_skinny_kernel: 1x1 convs with a SHORT K on fp32 rows (the coupling's Start conv 80 -> 192 and its data gradient 192 -> 80,
+// Modules.py:791; the encoder's 192-channel projections).  At B = 32 these problems are 404 row fragments of 32 rows: too few for any tile
+// to amortise staging, and the tiled kernel spends its 9-10 us in load -> LDS -> barrier -> MFMA -> epilogue phases that cannot overlap.
+// Here ONE WAVE owns one 32-row fragment and all (<= 192) output columns: every operand load - the A rows straight from global memory
+// as MFMA fragments (fp32 -> bf16 in registers), the whole packed weight image from L2 - is issued up front, no LDS, no barrier; waves
+// of different fragments drift apart, so loads, MFMAs and stores of neighbours overlap.  Registers: KS16 * 8 (A) + KS16 * NI * 4 (B) +
+// NI * 16 (accumulators) <= ~340 for K = 192, NI = 3: one wave per SIMD, which is all this problem size offers anyway.
+// ------------------------------------------------------------------------------------------------
+template <int KS16 /* 16-wide k steps = ca / 16 */, int NI /* 32-column fragments */>
+__global__ __launch_bounds__(64) void conv_skinny_kernel(const glowtts_conv_args pin)
+{
+    typedef __bf16 CT;
+    const glowtts_conv_args& p = pin;
+    const int lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
+    const int m0 = blockIdx.x * 32;
+    int row = m0 + l31;
+    row = row < p.rows ? row : p.rows - 1;                                   // clamped: rows past the end are dropped by the epilogue
+    const float* arow = p.a + (long)row * p.lda + lhi * 8;
+    f32x4 araw[KS16][2];
+#pragma unroll
+    for (int s = 0; s < KS16; ++s) {
+        araw[s][0] = *reinterpret_cast<const f32x4*>(arow + s * 16);
+        araw[s][1] = *reinterpret_cast<const f32x4*>(arow + s * 16 + 4);
+    }
+    Chunk16 bfr[KS16][NI];
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w);
+#pragma unroll
+    for (int s = 0; s < KS16; ++s)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)                                      // packed image [k chunk][n][64 B]: chunk s / 2, 16-byte slot 2 (s & 1) + lhi
+            bfr[s][ni] = *reinterpret_cast<const Chunk16*>(wb + ((size_t)((s >> 1) * p.npad + ni * 32 + l31) * 64 + (size_t)((2 * (s & 1) + lhi) * 16)));
+    f32x16 acc[1][NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][ni][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS16; ++s) {
+        Chunk16 af;
+        af[0] = pack_bf16x2(araw[s][0][0], araw[s][0][1]); af[1] = pack_bf16x2(araw[s][0][2], araw[s][0][3]);
+        af[2] = pack_bf16x2(araw[s][1][0], araw[s][1][1]); af[3] = pack_bf16x2(araw[s][1][2], araw[s][1][3]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&af), *reinterpret_cast<const bf16x8*>(&bfr[s][ni]), acc[0][ni], 0, 0, 0);
+    }
+    conv_epilogue<CT, 1, NI, GLOWTTS_EPI_LINEAR>(p, acc, m0, 0, 32, 0, 0, lane, lane, nullptr);
+}
+
+template <int KS16, int NI>
+int launch_skinny(const glowtts_conv_args& a, hipStream_t s)
+{
+    GLOWTTS_NOTE_STATIC("conv_skinny<%d,%d>", KS16 * 16, NI * 32);
+    hipLaunchKernelGGL((conv_skinny_kernel<KS16, NI>), dim3((a.rows + 31) / 32), dim3(64), 0, s, a);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
+// the short-K 1x1 problems of the path (LINEAR epilogue, fp32 A rows, bf16 MFMA, <= 192 columns): -1 = not one of them
+inline int try_skinny(const glowtts_conv_args& a, hipStream_t s)
+{
+    if (!(GLOWTTS_TUNABLE("GLOWTTS_SKINNY", 1) && a.precision == GLOWTTS_BF16 && a.taps == 1 && a.epi == GLOWTTS_EPI_LINEAR && a.apro == GLOWTTS_APRO_NONE &&
+          !(a.io_flags & (GLOWTTS_IO_A_BF16 | GLOWTTS_IO_IN0_BF16)) && !a.a2 && a.batch <= 1 && !(a.flags & (GLOWTTS_F_COLMASK | GLOWTTS_F_DROPOUT)) &&
+          (a.ca % 16) == 0 && a.lda >= a.ca && (a.lda & 3) == 0 && a.kchunks * 32 >= a.ca && a.rows >= 32)) return -1;
+    const int ni = (a.n + 31) / 32;
+    if (ni * 32 > a.npad) return -1;
+    switch (a.ca / 16) {
+        case 5:  if (ni == 6) return launch_skinny<5, 6>(a, s); break;           // Start conv: 80 -> 192
+        case 12: if (ni == 3) return launch_skinny<12, 3>(a, s);                 // Start data gradient: 192 -> 80
+                 if (ni == 6) return launch_skinny<12, 6>(a, s);                 // encoder 192 -> 192 projections
+                 if (ni == 5) return launch_skinny<12, 5>(a, s); break;          // encoder Project: 192 -> 160
+        default: break;
+    }
+    return -1;
+}
+
 inline const char* epi_name(int e)
 {
     switch (e) { case GLOWTTS_EPI_LINEAR: return "LINEAR"; case GLOWTTS_EPI_GATE: return "GATE"; case GLOWTTS_EPI_RESSKIP: return "RESSKIP";
@@ -1493,6 +1568,7 @@ int launch_prec(const glowtts_conv_args& a, hipStream_t s)
 #else
     const int N = GLOWTTS_APRO_NONE, PM = GLOWTTS_APRO_PAIRMUL;
     if constexpr (sizeof(CT) == 2) {
+        { const int rc = try_skinny(a, s); if (rc != -1) return rc; }
         if (dma_ok(a)) {
             if (a.epi == GLOWTTS_EPI_GATE && a.taps == 5) return launch_dma<GLOWTTS_EPI_GATE, 5>(a, s);
             if (a.epi == GLOWTTS_EPI_LINEAR && a.taps == 5) return dma_prefers_96(a) ? launch_dma<GLOWTTS_EPI_LINEAR, 5, 3>(a, s) : launch_dma<GLOWTTS_EPI_LINEAR, 5>(a, s);
