@@ -36,6 +36,19 @@ cases["dgate_1x1"] = dict(run=lambda: ops.conv_cl(dnext, pw_rst, 2 * H, R, a2=ds
                                                   in0=gates, ldi0=2 * H, out0=dins, ld0=2 * H,
                                                   io_flags=ops.IO_A_BF16 | ops.IO_IN0_BF16 | ops.IO_OUT0_BF16),
                           flops=2.0 * B * T * 2 * H * H)
+# Start conv (Modules.py:791): x_a = first 80 of 160 fp32 channels -> h0 bf16 [R, H]; and its data gradient accumulated into d x_a
+C = 160
+w_st = torch.randn(H, C // 2, 1, device=dev) / (C // 2) ** 0.5
+pw_st, pw_stt = ops.pack_weight(w_st, precision=ops.BF16), ops.pack_weight(w_st, transpose=True, precision=ops.BF16)
+xmid = torch.randn(R, C, device=dev)
+h0 = torch.empty(R, H, device=dev, dtype=bf)
+b_st = torch.zeros(H, device=dev)
+cases["start_fwd"] = dict(run=lambda: ops.conv_cl(xmid, pw_st, C // 2, R, lda=C, epi=ops.EPI_LINEAR, flags=ops.F_BIAS | ops.F_MASK, n=H, rows_per_utt=T + 4, bias=b_st,
+                                                  rowmask=rowmask, out0=h0, ld0=H, io_flags=ops.IO_OUT0_BF16), flops=2.0 * B * T * H * C // 2)
+dh0 = torch.randn(R, H, device=dev)
+dx = torch.zeros(R, C, device=dev)
+cases["start_dgrad"] = dict(run=lambda: ops.conv_cl(dh0, pw_stt, H, R, lda=H, epi=ops.EPI_LINEAR, flags=ops.F_ACCUM, n=C // 2, rows_per_utt=T + 4, out0=dx, ld0=C),
+                            flops=2.0 * B * T * H * C // 2)
 out = []
 for name, c in cases.items():
     sec = bench.time_kernel(c["run"], iters=int(os.environ.get("ITERS", "40")))
