@@ -383,10 +383,18 @@ class GlowTTS(torch.nn.Module):
         hp = self.hp
         mean, log_std, dur, mel_lengths, token_mask, spk, pro = front
         mel_mask = self.Mask_Generate(mel_lengths, max_mel_length)
-        amask = (token_mask.unsqueeze(-1) * mel_mask.unsqueeze(2)).squeeze(1)
-        attn = self.Path_Generate(dur, amask)                                                             # :181
-        mel_mean = mean @ attn
-        mel_log_std = log_std @ attn
+        # Path_Generate (:181, :213-229) makes the hard alignment dense - attentions[x, y] = 1 iff cum[x-1] <= y < cum[x] - and the reference
+        # expands mean / log_Std with two dense bmm (:183-184).  Here the per-frame token index comes from one search over the cumulative
+        # durations, the dense matrix (a returned output) from the MAS path kernel and the expansion is the training path's gather.
+        Tmax, Tx = mel_mask.shape[2], mean.shape[2]
+        cum = torch.cumsum(dur, dim=1).contiguous()                                                         # integer-valued floats
+        frames = torch.arange(Tmax, device=cum.device, dtype=cum.dtype)
+        idx = torch.searchsorted(cum, frames.unsqueeze(0).expand(cum.shape[0], -1).contiguous(), right=True)      # tokens whose span ended at or before y
+        idx = torch.where((frames.unsqueeze(0) < mel_lengths.unsqueeze(1)) & (idx < Tx), idx, torch.full_like(idx, -1)).to(torch.int32).contiguous()
+        from .monotonic_align import path_from_idx
+        attn = path_from_idx(idx, Tx, torch.float32)
+        mel_mean = alignment.ExpandPrior.apply(mean, idx)
+        mel_log_std = alignment.ExpandPrior.apply(log_std, idx)
         if noises is None:
             noises = torch.randn_like(mel_mean)
         z = (mel_mean + torch.exp(mel_log_std) * noises[:, :, :mel_mean.shape[2]] * noise_scale) * mel_mask   # :187-191
