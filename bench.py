@@ -332,7 +332,7 @@ def main():
     ap.add_argument("--windows", type=int, default=10, help="extra timed windows of --steps steps after the reported one (median / spread keys)")
     ap.add_argument("--tokens", type=int, default=120, help="padded token length (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tune", action="append", default=[], help="A/B measurements: key=value entries of glow_tts_amd.decoder.TUNE (e.g. z_rows=0)")
+    ap.add_argument("--tune", action="append", default=[], help="A/B measurements: key=value entries of glow_tts_amd.decoder.TUNE (e.g. wgrad_wide=0)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on device 0 (multi-rank smoke test on a single-GPU box)")
     ap.add_argument("--no-overlap", action="store_true", help="data parallel: one graph + one gradient exchange instead of the two-graph overlap")
     ap.add_argument("--force-dist", action="store_true", help="run the data-parallel code path (process group, two-graph overlap, all-reduces) "

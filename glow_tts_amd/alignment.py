@@ -29,7 +29,7 @@ def _lib2():
 
 
 @torch.no_grad()
-def log_prior_t(mean, log_std, z, token_lengths, mel_lengths, mel_multiple=1, return_lengths=False):
+def log_prior_t(mean, log_std, z, token_lengths, mel_lengths, mel_multiple=1, return_lengths=False, z_rows=None):
     """Modules.py:108-114, transposed: returns value_t [B, T_mel, T_tok] = log N(z_y; mean_x, std_x) * mask.
     mean/log_std [B, Cm, Tx], z [B, Cm, Ty] (channel-first like the reference).  Always fp32 (MAS ties).
     mel_multiple: mel lengths are rounded down to a multiple of it on the device (Decoder.Num_Squeeze); return_lengths: also return the
@@ -49,13 +49,12 @@ def log_prior_t(mean, log_std, z, token_lengths, mel_lengths, mel_multiple=1, re
     _lib.check(L.glowtts_logprior_prep(_lib.ptr(mean), _lib.ptr(log_std), _lib.ptr(token_lengths.contiguous()), _lib.ptr(mel_lengths.contiguous()),
                                        _lib.ptr(packed), _lib.ptr(cb), _lib.ptr(fmask), _lib.ptr(tx), _lib.ptr(ty), B, Cm, Tx, Ty, int(mel_multiple), None, None,
                                        _lib.stream()), "glowtts_logprior_prep")
-    # frames x channels operand: the decoder's own output rows when z is the tensor it just produced (a squeezed row holds ns consecutive
-    # frames x Cm channels; ROW_PAD pad rows in front of every utterance), else a transposed copy of z
+    # frames x channels operand: the decoder's own output rows when the caller has them (z_rows [B*(Ty/ns + 2*ROW_PAD), ns*Cm]: a squeezed
+    # row holds ns consecutive frames x Cm channels, ROW_PAD pad rows in front of every utterance), else a transposed copy of z
     from . import decoder as _D
-    rows, ns = _D.LAST_Z_ROWS["rows"], int(mel_multiple)
-    if _D.LAST_Z_ROWS["z"] is not None and _D.LAST_Z_ROWS["z"].data_ptr() == z.data_ptr() and rows is not None and Ty % ns == 0 and \
-            rows.shape == (B * (Ty // ns + 2 * _D.ROW_PAD), ns * Cm):
-        zt_ptr, zt_bstride, keep = rows.data_ptr() + 4 * _D.ROW_PAD * ns * Cm, (Ty // ns + 2 * _D.ROW_PAD) * ns * Cm, rows
+    ns = int(mel_multiple)
+    if z_rows is not None and Ty % ns == 0 and tuple(z_rows.shape) == (B * (Ty // ns + 2 * _D.ROW_PAD), ns * Cm) and z_rows.is_contiguous():
+        zt_ptr, zt_bstride, keep = z_rows.data_ptr() + 4 * _D.ROW_PAD * ns * Cm, (Ty // ns + 2 * _D.ROW_PAD) * ns * Cm, z_rows
     else:
         keep = z.transpose(1, 2).contiguous()                                  # [B,Ty,Cm]
         zt_ptr, zt_bstride = keep.data_ptr(), Ty * Cm
@@ -69,7 +68,6 @@ def log_prior_t(mean, log_std, z, token_lengths, mel_lengths, mel_multiple=1, re
     a.ncols_valid = tx.data_ptr()
     a.rows_per_utt = Ty
     _lib.check(_lib.lib().glowtts_conv_cl(ctypes.byref(a), _lib.stream()), "glowtts_conv_cl(log_prior)")
-    _D.LAST_Z_ROWS["rows"] = _D.LAST_Z_ROWS["z"] = None                        # (the launch is stream-ordered behind the producer; drop the references)
     return (out, tx, ty) if return_lengths else out
 
 

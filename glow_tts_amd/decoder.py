@@ -101,15 +101,11 @@ _WSTREAM = {}
 # backward queues the tail's launches here instead of issuing them; `flush_tail_wgrads()` issues them (bench.py captures that as a
 # second hipGraph).  The gradient tensors of the tail classes exist (autograd has already handed them to .grad) but hold no data until then.
 TAIL = {"defer": False, "pending": []}
-# The decoder's output in the rows layout [B*(T+4), C] next to the tensor z it was unsqueezed into: one squeezed row is ns consecutive
-# frames x Cm channels, i.e. already "frames x channels" for the log-prior GEMM (alignment.log_prior_t reads it instead of transposing z).
-LAST_Z_ROWS = {"rows": None, "z": None}
 # Measured design choices that tools / tests may flip programmatically (never read from the environment: DESIGN.md section 5 has the numbers).
 #   wgrad_wide: 16-byte staging items in the weight-gradient kernel; fuse_coupling_bwd: the next flow's coupling backward rides in the
 #   ActNorm / 1x1 backward pass; wgrad_split: weight gradients in n segments on a second stream (1 = one grouped launch per class);
 #   act_bf16: WaveNet state / gates / gate gradients stored as bf16 in bf16 precision
-#   z_rows: the log-prior GEMM reads the decoder's output rows directly (no transposed copy of z)
-TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "z_rows": True}
+TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True}
 TAIL_STACKS = ("start_g", "start_v", "start_b", "rs_g", "rs_v", "rs_b", "rsl_g", "rsl_v", "rsl_b", "end_w", "end_b")
 
 
@@ -398,8 +394,6 @@ def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
                                         _lib.stream()), "glowtts_decoder_logdet")
     if pitch is not None:
         prep.set_cond(prep.cond)            # the backward addresses the conditioning gradient per utterance
-    if TUNE["z_rows"]:
-        LAST_Z_ROWS["rows"], LAST_Z_ROWS["z"] = buf.x[cfg.F], z
     return z, logdet, buf, rowmask, T, prow
 
 
@@ -510,10 +504,14 @@ class DecoderFunction(torch.autograd.Function):
             ctx.cfg, ctx.prep, ctx.buf, ctx.rowmask, ctx.T = cfg, prep, buf, rowmask, T
             ctx.lengths, ctx.mel_shape = lengths, mels.shape
             ctx.want_dmel = mels.requires_grad
-        return z, logdet
+        # third output (not differentiable): z in the rows layout [B*(T+4), C] - one squeezed row is ns consecutive frames x Cm channels,
+        # i.e. already "frames x channels" for the log-prior GEMM (alignment.log_prior_t(z_rows=...) reads it instead of transposing z)
+        z_rows = buf.x[cfg.F]
+        ctx.mark_non_differentiable(z_rows)
+        return z, logdet, z_rows
 
     @staticmethod
-    def backward(ctx, dz, dlogdet):
+    def backward(ctx, dz, dlogdet, _dz_rows=None):
         L = _L()
         cfg, prep, buf, rowmask, T = ctx.cfg, ctx.prep, ctx.buf, ctx.rowmask, ctx.T
         W = prep.keep

@@ -319,15 +319,15 @@ class GlowTTS(torch.nn.Module):
         self._maybe_init_actnorm(P, mels, mel_lengths, cond, None if pitches is None else (pitches, pitch_w.detach(), pitch_b.detach()))
         W = stacks.weights()
         drop_p = float(hp.Decoder.Affine_Coupling.WaveNet.Dropout_Rate) if self.training else 0.0      # Modules.py:854-862
-        z, log_dets = decoder.DecoderFunction.apply(self.dec_cfg, mels, mel_lengths, cond, drop_p, pitches, pitch_w if pitches is not None else None,
-                                                    pitch_b if pitches is not None else None, *W)
+        z, log_dets, z_rows = decoder.DecoderFunction.apply(self.dec_cfg, mels, mel_lengths, cond, drop_p, pitches, pitch_w if pitches is not None else None,
+                                                            pitch_b if pitches is not None else None, *W)
         if side is not main:
             main.wait_stream(side)
             for t_ in (mean, log_std, log_dur):
                 t_.record_stream(main)
         ns = int(hp.Decoder.Num_Squeeze)
         value_t, tx32, ty32 = alignment.log_prior_t(mean.detach(), log_std.detach(), z.detach(), token_lengths, mel_lengths, ns,
-                                                    return_lengths=True)                       # Modules.py:107-114 (lengths of the squeezed z)
+                                                    return_lengths=True, z_rows=z_rows)        # Modules.py:107-114 (lengths of the squeezed z)
         idx = alignment.maximum_path_t(value_t, tx32, ty32)                                          # :115-116
         if idx.shape[1] != z.shape[2]:
             idx = idx[:, :z.shape[2]].contiguous()

@@ -25,7 +25,7 @@ def run_hip_decoder(sd, cfg, mels, lengths, precision, requires_grad=False, cond
     cond = None
     if cond_vectors is not None:
         cond = D.conditioning(P, dc, speakers=cond_vectors.cuda())
-    z, logdet = D.DecoderFunction.apply(dc, mels.cuda(), lengths.cuda(), cond, drop_p, None, None, None, *W)
+    z, logdet, _ = D.DecoderFunction.apply(dc, mels.cuda(), lengths.cuda(), cond, drop_p, None, None, None, *W)
     return z, logdet, P, dc
 
 

@@ -55,7 +55,7 @@ def _hip_grads(cfg, sd, mels, ml, spk, wz, wl, precision, drop_p=0.0):
     W = D.stack_decoder_weights(P, dc)
     cond = D.conditioning(P, dc, speakers=s) if s is not None else None
     launch_reset()
-    z, logdet = D.DecoderFunction.apply(dc, x, ml.cuda(), cond, drop_p, None, None, None, *W)
+    z, logdet, _ = D.DecoderFunction.apply(dc, x, ml.cuda(), cond, drop_p, None, None, None, *W)
     ((z * wz.cuda()).sum() + (logdet * wl.cuda()).sum()).backward()
     torch.cuda.synchronize()
     return z.detach().cpu(), logdet.detach().cpu(), {k: p.grad.cpu() for k, p in P.items()}, x.grad.cpu(), (s.grad.cpu() if s is not None else None), launch_counts()

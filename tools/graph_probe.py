@@ -68,7 +68,7 @@ def run_case(name):
             P = dict(model.named_parameters())
             if "decoder" in name:
                 W = D.stack_decoder_weights(P, model.dec_cfg)
-                z, ld = D.DecoderFunction.apply(model.dec_cfg, mels, ml, None, 0.05, None, None, None, *W); (z.sum() + ld.sum()).backward(); return z.detach()
+                z, ld, _ = D.DecoderFunction.apply(model.dec_cfg, mels, ml, None, 0.05, None, None, None, *W); (z.sum() + ld.sum()).backward(); return z.detach()
             if "encoder" in name:
                 tm = model.Mask_Generate(tl, tokens.shape[1])
                 mean, ls, dur = E.encoder_forward(P, model.hp, tokens, tm, None, None, True, precision=model.dec_cfg.precision)
@@ -94,9 +94,9 @@ def run_case(name):
             if name.startswith("decoder"):
                 P = dict(model.named_parameters()); W = D.stack_decoder_weights(P, model.dec_cfg)
                 if name == "decoder_fwd":
-                    with torch.no_grad(): z, ld = D.DecoderFunction.apply(model.dec_cfg, mels, ml, None, 0.05, None, None, None, *W)
+                    with torch.no_grad(): z, ld, _ = D.DecoderFunction.apply(model.dec_cfg, mels, ml, None, 0.05, None, None, None, *W)
                 else:
-                    z, ld = D.DecoderFunction.apply(model.dec_cfg, mels, ml, None, 0.05, None, None, None, *W); (z.sum() + ld.sum()).backward()
+                    z, ld, _ = D.DecoderFunction.apply(model.dec_cfg, mels, ml, None, 0.05, None, None, None, *W); (z.sum() + ld.sum()).backward()
                 return z.detach()
             if name == "encoder_fwdbwd":
                 P = dict(model.named_parameters()); tm = model.Mask_Generate(tl, tokens.shape[1])
