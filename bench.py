@@ -525,18 +525,23 @@ def main():
             out["inverse_flow"] = inv
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+    # The JSON line must be the LAST line of the job's stdout.  RCCL writes a banner ("Librccl path : ...") through C stdio, which a pipe
+    # buffers until exit, i.e. behind Python's own output: every rank flushes its C buffers, the ranks meet once more, then rank 0 prints.
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                        # noqa: BLE001
+        pass
+    sys.stdout.flush()
     if dp:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        # the JSON line must be the LAST line of stdout: RCCL writes a banner ("Librccl path : ...") through C stdio, which a pipe buffers
-        # until exit, i.e. behind Python's own output - flush the C buffers first
-        import ctypes
         try:
             ctypes.CDLL(None).fflush(None)
         except Exception:                                    # noqa: BLE001
             pass
-        sys.stdout.flush()
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
 
