@@ -105,10 +105,7 @@ TAIL = {"defer": False, "pending": []}
 #   wgrad_wide: 16-byte staging items in the weight-gradient kernel; fuse_coupling_bwd: the next flow's coupling backward rides in the
 #   ActNorm / 1x1 backward pass; wgrad_split: weight gradients in n segments on a second stream (1 = one grouped launch per class);
 #   act_bf16: WaveNet state / gates / gate gradients stored as bf16 in bf16 precision
-#   delay_encoder_bwd: the text encoder's backward (its own HIP stream) starts when the decoder's dependent data-gradient chain has ended,
-#   i.e. beside the large weight-gradient launches instead of beside the latency-bound chain (GateEncoderBackward below)
-TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "delay_encoder_bwd": False}
-CHAIN_DONE = {"event": None}      # recorded on the decoder's stream after the last flow's backward chain of the current backward pass
+TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True}
 TAIL_STACKS = ("start_g", "start_v", "start_b", "rs_g", "rs_v", "rs_b", "rsl_g", "rsl_v", "rsl_b", "end_w", "end_b")
 
 
@@ -604,10 +601,6 @@ class DecoderFunction(torch.autograd.Function):
                     with torch.cuda.stream(side):
                         for grp in (gk, gp, g1):
                             grp.launch_segment(pos // per - 1)
-        if TUNE["delay_encoder_bwd"]:
-            ev = torch.cuda.Event()
-            ev.record()
-            CHAIN_DONE["event"] = ev
         if halves > 1:
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -645,24 +638,6 @@ class DecoderFunction(torch.autograd.Function):
             for f in range(F_):
                 dpw[f, :, orig] = torch.matmul(dins[f].float().transpose(1, 2), ctx.prow)[:, valid]
         return (None, dmel, None, dcond, None, None, dpw, dpb) + tuple(G[k].view_as(W[k]) for k in WEIGHT_KEYS)
-
-
-class GateEncoderBackward(torch.autograd.Function):
-    """Identity on the encoder's outputs; in the backward the current (encoder) stream first waits for the event the decoder's backward
-    recorded after its data-gradient chain.  autograd runs the decoder's backward node before the encoder's (it was created later in the
-    forward), so the event of THIS pass exists when the wait is issued - also under hipGraph capture, where it becomes an edge of the graph."""
-
-    @staticmethod
-    def forward(ctx, *xs):
-        return tuple(x.view_as(x) for x in xs)
-
-    @staticmethod
-    def backward(ctx, *gs):
-        ev = CHAIN_DONE["event"]
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
-            CHAIN_DONE["event"] = None
-        return gs
 
 
 def _wn(g, v):

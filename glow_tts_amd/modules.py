@@ -309,8 +309,6 @@ class GlowTTS(torch.nn.Module):
         with torch.cuda.stream(side):
             mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, self.training, precision=self.dec_cfg.precision,
                                                              cache=self._enc_cache)
-            if decoder.TUNE["delay_encoder_bwd"] and side is not main and torch.is_grad_enabled():
-                mean, log_std, log_dur = decoder.GateEncoderBackward.apply(mean, log_std, log_dur)
         stacks = self._stacks(P)
         cond = stacks.conditioning(spk, pro)
         pitch_w, pitch_b = stacks.pitch_weights()
