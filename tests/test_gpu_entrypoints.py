@@ -126,7 +126,7 @@ def test_graphed_training_reduces_the_loss(precision):
     step2 = GraphedTrainStep(mg2, loss_fn_for(mle2), warmup=2, optimizer=og2, scheduler=sg2, max_grad_norm=5.0)
     curve = []
     for _ in range(steps - 2):
-        curve.append(float(step2(*batch)))
+        curve.append(float(step2(*batch).detach()))
     me, oe, se, mlee = make()
     lf = loss_fn_for(mlee)
     eager = []
