@@ -4,5 +4,5 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/_build
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DGLOWTTS_TOOLS_MIN -DGLOWTTS_TIMELINE "$@" \
-    glow_tts_amd/csrc/gemm_cl.hip -o tools/_build/libconv_tl.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DGLOWTTS_TOOLS -DGLOWTTS_TOOLS_MIN -DGLOWTTS_TIMELINE "$@" \
+    glow_tts_amd/csrc/gemm_cl.hip glow_tts_amd/csrc/common.hip -o tools/_build/libconv_tl.so
