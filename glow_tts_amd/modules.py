@@ -297,6 +297,12 @@ class GlowTTS(torch.nn.Module):
             raise RuntimeError("glow_tts_amd runs on the GPU only (no CPU fallback)")
         P = self._params()
         spk, pro = self._conditioning(P, speakers, mels_for_ge2e, mels, mel_lengths)
+        ns_ = int(hp.Decoder.Num_Squeeze)
+        if mels.shape[2] % ns_:                               # Squeeze cuts the frames that do not fill a group (Modules.py:897-898):
+            t_cut = (mels.shape[2] // ns_) * ns_              # z, the masks and the attentions all have the cut length
+            mels = mels[:, :, :t_cut].contiguous()
+            if pitches is not None:
+                pitches = pitches[:, :t_cut].contiguous()
         token_mask = self.Mask_Generate(token_lengths, tokens.shape[1])
         # Encoder and decoder are independent until the log-prior: the encoder runs on its own HIP stream, concurrently with the
         # flow decoder whose latency-bound kernels leave CUs idle.  autograd replays each backward on its forward stream, so the

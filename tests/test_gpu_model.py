@@ -290,3 +290,61 @@ def test_two_ranks_on_one_gpu(tmp_path):
         f.write(f"[dp] backend {backend}" + (f" (RCCL refused two ranks on one device: {why})" if backend == "gloo" else " (RCCL, two ranks on one device)") + "\n")
     out = subprocess.run([sys.executable, os.path.join(here, "dp_gpu_check.py"), backend, str(port()), log], capture_output=True, text=True, timeout=900, cwd=repo, env=env)
     assert out.returncode == 0 and "DP GPU CHECK OK" in out.stdout, (out.returncode, out.stdout[-3000:], out.stderr[-3000:])
+
+
+def _random_batch(seed, vocab):
+    """Ragged batches at the sizes a fixed fixture never hits: one utterance, one token, as many frames as tokens, odd lengths,
+    a padded frame axis that is not a multiple of the squeeze factor (the tail frame is cut)."""
+    g = torch.Generator().manual_seed(seed)
+    B = [1, 2, 3, 5, 4, 7][seed % 6]
+    tl = torch.randint(1, 12, (B,), generator=g)
+    extra = 2 * torch.randint(0, 20, (B,), generator=g)
+    ml = tl * 2 + extra * (torch.arange(B) % 3 != 0)          # every third utterance: exactly 2 frames per token (T_y/2 == T_x)
+    Tx, Ty = int(tl.max()), int(ml.max()) + (seed % 4 == 1)  # every fourth case: an odd padded frame axis (cut by the squeeze)
+    tokens = torch.randint(1, vocab, (B, Tx), generator=g)
+    mels = torch.randn(B, 12, Ty, generator=g) * 0.7
+    for b in range(B):
+        tokens[b, tl[b]:] = 0
+        mels[b, :, ml[b]:] = 0
+    return tokens, tl, mels, ml
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_ragged_shapes_match_oracle_f32(seed):
+    """Shape fuzz of the training graph against the oracle (Vanilla / SE alternating): outputs, bit-exact alignment, losses and every
+    parameter gradient at batch / length combinations the golden fixtures do not cover."""
+    from glow_tts_amd.modules import MLE_Loss
+    mode, fname = [("Vanilla", "tiny_vanilla.npz"), ("SE", "tiny_se.npz")][seed % 2]
+    sd, _, r = load_case(fname)
+    model = build(mode, "f32", sd)
+    vocab = sd["layer_Dict.Encoder.layer_Dict.Embedding.weight"].shape[0]
+    tokens, tl, mels, ml = _random_batch(seed, vocab)
+    spk = torch.randint(0, 5, (tokens.shape[0],), generator=torch.Generator().manual_seed(seed)) if mode == "SE" else None
+    if seed == 0:                                             # lengths that the squeeze cannot split are an error, as in Modules.py:71
+        with pytest.raises(AssertionError):
+            model(tokens.cuda(), tl.cuda(), mels.cuda(), (ml - 1).cuda(), None, None, None)
+    out = model(tokens.cuda(), tl.cuda(), mels.cuda(), ml.cuda(), spk.cuda() if spk is not None else None, None, None)
+    z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, attn, _ = out
+    loss = MLE_Loss(model.hp)(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=ml.cuda()) + \
+        torch.nn.functional.mse_loss(log_dur, log_dur_t)
+    model.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    cfg = tiny_cfg(mode)
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    o = O.forward_train(sdg, cfg, tokens, tl, mels, ml, spk)
+    omle, olen = O.train_losses(o, ml, cfg)
+    (omle + olen).backward()
+    assert attn.shape == o["attn"].shape and torch.equal(attn.cpu(), o["attn"]), "alignment differs from the oracle"
+    for got, key, tol in [(z, "z", 1e-4), (mel_mean, "mel_mean", 1e-4), (mel_log_std, "mel_log_std", 1e-4), (log_dur, "log_dur", 1e-4),
+                          (log_dur_t, "log_dur_target", 1e-5), (log_dets, "log_dets", 1e-3)]:
+        assert got.shape == o[key].shape, key
+        assert (got.detach().cpu() - o[key].detach()).abs().max() <= tol, key
+    assert abs(loss.item() - (omle + olen).item()) <= 1e-4 * max(1.0, abs((omle + olen).item()))
+    for k, p in model.named_parameters():
+        want = sdg[k].grad
+        if want is None:
+            continue
+        got = p.grad.cpu() if p.grad is not None else torch.zeros_like(want)
+        err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-5)
+        assert err < 5e-3, (k, err)
