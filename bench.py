@@ -179,6 +179,24 @@ def measured_traffic():
         return json.load(f), "profiles/" + cands[-1]
 
 
+def sustained_mfma_clock():
+    """GHz the chip holds under a dense bf16 MFMA loop (glowtts_mfma_clock_probe: 256 workgroups x 4 waves, ~0.4 ms), and the dense bf16
+    rate that clock allows: CUs x 4 SIMDs x 32768 FLOP per 32-clk MFMA."""
+    import ctypes
+    from glow_tts_amd import _lib
+    L = _lib.lib()
+    L.glowtts_mfma_clock_probe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    out = torch.zeros(ncu, 2, dtype=torch.int64, device="cuda")
+    khz = ctypes.c_int(0)
+    for _ in range(2):
+        _lib.check(L.glowtts_mfma_clock_probe(out.data_ptr(), ncu, 20000, ctypes.byref(khz), _lib.stream()), "mfma_clock_probe")
+    torch.cuda.synchronize()
+    o = out.double().sum(0)
+    ghz = float(o[0] / o[1]) * khz.value * 1e-6
+    return ghz, ncu * 4 * 32768 / 32 * ghz * 1e-3            # GHz, TFLOP/s
+
+
 def roofline(precision, B, T, step_tflops):
     """The dominant kernel by time (profiles/*_kernel_stats.csv): `achieved` = algorithmic FLOPs per launch (2 x valid rows x 384 x 192 x 5,
     DESIGN.md section 4) / its launch duration, timed here with HIP events over back-to-back launches on the launch stream (the
@@ -199,6 +217,12 @@ def roofline(precision, B, T, step_tflops):
            "traffic_source": src if top["traffic"] is not None else None,
            "timing": "HIP events on the launch stream, 30 back-to-back launches of the kernel alone",
            "step_frac": round(step_tflops / peak, 4), "kernels": rows}
+    if precision == "bf16":
+        # context, not the graded fraction: the clock (and with it the matrix rate) the chip actually sustains under MFMA load
+        ghz, sus = sustained_mfma_clock()
+        out["sustained_mfma_clock_ghz"] = round(ghz, 3)
+        out["peak_sustained"] = round(sus, 1)
+        out["frac_of_sustained"] = round(top["achieved"] / sus, 4)
     return out
 
 

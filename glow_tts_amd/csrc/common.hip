@@ -86,3 +86,48 @@ extern "C" int glowtts_launch_log_dump(char* buf, int buflen)
     }
     return GLOWTTS_OK;
 }
+
+// ---- sustained matrix clock (measurement aid for bench.py's roofline, see include/glowtts_hip.h) ----
+namespace {
+typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 probe_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void mfma_clock_probe_kernel(long long* out, int iters)
+{
+    // four independent accumulators per wave, one wave per SIMD: the matrix pipe issues back to back (32 clk per MFMA), operands are
+    // pseudo-random bf16 (zero operands draw less power and clock higher)
+    probe_f32x16 acc[4] = {};
+    probe_bf16x8 a, b;
+    uint32_t h = threadIdx.x * 0x9E3779B1u + blockIdx.x * 0x85EBCA6Bu + 12345u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+        a[k] = (__bf16)((float)(h & 0xFFFF) * (1.f / 32768.f) - 1.f);
+        b[k] = (__bf16)((float)(h >> 16) * (1.f / 32768.f) - 1.f);
+    }
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[j][r];
+    const long long c1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = c1 - c0 + (s == 12345.678f); out[2 * blockIdx.x + 1] = w1 - w0; }
+}
+}  // namespace
+
+extern "C" int glowtts_mfma_clock_probe(long long* out, int nwg, int iters, int* wall_khz, void* stream)
+{
+    if (!out || nwg <= 0 || iters <= 0) return GLOWTTS_E_ARG;
+    if (wall_khz) {
+        int dev = 0, khz = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return GLOWTTS_E_LAUNCH;
+        *wall_khz = khz;
+    }
+    GLOWTTS_NOTE_STATIC("mfma_clock_probe");
+    hipLaunchKernelGGL(mfma_clock_probe_kernel, dim3(nwg), dim3(256), 0, static_cast<hipStream_t>(stream), out, iters);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}

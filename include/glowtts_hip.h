@@ -34,6 +34,13 @@ int64_t glowtts_launch_count(const char *kernel_class);
 void glowtts_launch_log_reset(void);
 int glowtts_launch_log_dump(char *buf, int buflen);
 
+/* Sustained matrix clock (measurement aid for bench.py's roofline; no reference counterpart).  Launches `nwg` workgroups of four waves
+ * (one per SIMD), each issuing 4 * iters back-to-back v_mfma_f32_32x32x16_bf16 on pseudo-random operands; workgroup i writes the shader
+ * cycles (s_memtime) and the constant-rate wall ticks its loop took to out[2i], out[2i+1] (device pointer, 2 * nwg int64).  *wall_khz
+ * (host pointer, optional) receives the wall counter's rate.  cycles / ticks * rate = the clock the chip holds under a dense bf16 MFMA
+ * load, which on MI355X is well below the 2.4 GHz the 2.5 PFLOP/s datasheet peak assumes. */
+int glowtts_mfma_clock_probe(long long *out, int nwg, int iters, int *wall_khz, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Monotonic Alignment Search.
  * Replaces monotonic_align/core.pyx:40 `maximum_path_c(paths, values, t_xs, t_ys, max_neg_val)`
