@@ -222,7 +222,13 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
             q.drop_p = d->drop_p; q.seed = d->seed + (uint32_t)l; q.seed_ptr = d->seed_ptr;
             q.io_flags = bf ? (GLOWTTS_IO_IN0_BF16 | GLOWTTS_IO_OUT0_BF16 | (bfg ? GLOWTTS_IO_A_BF16 : 0)) : 0;
             // conditioning gradient (autograd of Modules.py:863-866): per-utterance sums of the gate gradients before the dropout mask
-            if (g->dcond && p->cond) { q.out1 = g->dcond + (int64_t)l * 2 * H; q.ld1 = p->ldcond; }
+            if (g->dcond && p->cond) {
+                q.out1 = g->dcond + (int64_t)l * 2 * H; q.ld1 = p->ldcond;
+                if (g->pitch_rows) {       // + the Pitch_l weight gradient, into the rows behind the utterances' (see glowtts_flow_grads)
+                    if (g->pitch_ns < 1 || g->pitch_ns > 2) return GLOWTTS_E_ARG;
+                    q.cond = g->pitch_rows; q.ldcond = g->pitch_ns; q.flags |= GLOWTTS_F_COND_ROWS;
+                }
+            }
             if (last) {
                 const bool chain = GLOWTTS_TUNABLE("GLOWTTS_CHAIN", 1) != 0 && GLOWTTS_TUNABLE("GLOWTTS_CHAIN_BWD", 1) != 0;
                 if (!(chain && dbf && glowtts_conv_chain(&endq, &q, stream) == GLOWTTS_OK)) {

@@ -495,6 +495,16 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
         float sa[NI], ss[NI]; int cur_u = -1;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) sa[ni] = ss[ni] = 0.f;
+        // GLOWTTS_F_COND_ROWS (GR-mode pitch): `cond` = the squeezed pitch rows [rows][ldcond <= 2]; rows nutt + j of out1 accumulate
+        // sum_r (da, ds)[r][n] * pitch[r][j] - the Pitch_l conv's weight gradient, also taken before the keep mask
+        const bool pit = dcnd && p.cond && (fl & GLOWTTS_F_COND_ROWS);
+        const int pns = pit ? (int)p.ldcond : 0;
+        const Rsrc rp = mk(p.cond, pit ? (long)p.rows * pns * 4 : 0);
+        float pa[2][NI], ps[2][NI];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) pa[j][ni] = ps[j][ni] = 0.f;
         auto flush = [&]() __attribute__((always_inline)) {
             if (cur_u >= 0) {
 #pragma unroll
@@ -507,13 +517,21 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) sa[ni] = ss[ni] = 0.f;
         };
-        auto rows_loop = [&](auto DROP_) __attribute__((always_inline)) {
-            constexpr bool DROP = decltype(DROP_)::value != 0;
+        auto rows_loop = [&](auto DROP_, auto PIT_) __attribute__((always_inline)) {
+            constexpr bool DROP = decltype(DROP_)::value != 0, PIT = decltype(PIT_)::value != 0;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
-                    float gt[8][NI], gs[8][NI];
+                    float gt[8][NI], gs[8][NI], pv[8][2];
+                    if constexpr (PIT) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {         // (rows past the end read 0 through the descriptor's bounds check)
+                            const uint32_t so = (uint32_t)(roff(mi, hb * 8 + q) * pns * 4);
+                            pv[q][0] = ldf(rp, (uint32_t)(rb * pns) * 4u, so);
+                            pv[q][1] = pns > 1 ? ldf(rp, (uint32_t)(rb * pns) * 4u + 4u, so) : 0.f;
+                        }
+                    }
                     if (in0_bf) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q)
@@ -548,6 +566,10 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
                             da[q][ni] = dsg * (1.f - t * t);
                             ds[q][ni] = dsg * t * (1.f - sg);
                             if (dcnd) { sa[ni] += da[q][ni]; ss[ni] += ds[q][ni]; }
+                            if constexpr (PIT) {
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) { pa[j][ni] += da[q][ni] * pv[q][j]; ps[j][ni] += ds[q][ni] * pv[q][j]; }
+                            }
                             if constexpr (DROP) { const uint32_t w = drop_draw(rk, jkey[ni]); da[q][ni] *= drop_keep_lo(w, thr, ik); ds[q][ni] *= drop_keep_hi(w, thr, ik); }
                         }
                     }
@@ -571,8 +593,19 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
                 }
             }
         };
-        if (drop) rows_loop(IC<1>{}); else rows_loop(IC<0>{});
+        if (pit) { if (drop) rows_loop(IC<1>{}, IC<1>{}); else rows_loop(IC<0>{}, IC<1>{}); }
+        else     { if (drop) rows_loop(IC<1>{}, IC<0>{}); else rows_loop(IC<0>{}, IC<0>{}); }
         if (dcnd) flush();
+        if (pit) {
+            const int nutt = p.rows / Tp;
+            for (int j = 0; j < pns; ++j)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    if (dcol[ni] >= 0) {
+                        float* dst = dcnd + (long)(nutt + j) * p.ld1 + dcol[ni];
+                        unsafeAtomicAdd(dst, pa[j][ni]); unsafeAtomicAdd(dst + p.n, ps[j][ni]);
+                    }
+        }
     } else {
         // affine coupling on (m, logs) = End conv output (Modules.py:795-806); PAIR-packed like GATE: fragment 2*pi holds m, 2*pi+1 logs
         static_assert(EPI == GLOWTTS_EPI_COUPLE && NI % 2 == 0, "pair epilogues need NI even");

@@ -50,7 +50,8 @@ class FlowGrads(ctypes.Structure):
                 ("dw_in", c_void_p * MAXL), ("db_in", c_void_p * MAXL),
                 ("dw_rs", c_void_p * MAXL), ("db_rs", c_void_p * MAXL),
                 ("dw_end", c_void_p), ("db_end", c_void_p), ("dcond", c_void_p), ("douts_bf", c_void_p),
-                ("coupling_done", c_int), ("prev_xmid", c_void_p), ("prev_outs", c_void_p), ("prev_douts", c_void_p), ("prev_douts_bf", c_void_p)]
+                ("coupling_done", c_int), ("prev_xmid", c_void_p), ("prev_outs", c_void_p), ("prev_douts", c_void_p), ("prev_douts_bf", c_void_p),
+                ("pitch_rows", c_void_p), ("pitch_ns", c_int)]
 
 
 _declared = False
@@ -535,7 +536,9 @@ class DecoderFunction(torch.autograd.Function):
         dh_ptr = lambda f, l: dh0[f].data_ptr() if l == 0 else dhn[f, l - 1].data_ptr()
         nscr = L.glowtts_actnorm_stats_scratch_floats(R, C)
         scratch = torch.empty(F_, nscr, device=dev)          # per-flow partials of the ActNorm / 1x1 parameter gradients, reduced once below
-        dcond = torch.zeros_like(prep.cond) if prep.cond is not None else None
+        # conditioning gradient [B, F*L*2H], accumulated by the gate-derivative epilogues; GR mode: + ns rows that collect the Pitch_l weight gradients
+        npit = ctx.prow.shape[1] if ctx.prow is not None else 0
+        dcond = torch.zeros((B + npit,) + tuple(prep.cond.shape[1:]), device=dev) if prep.cond is not None else None
         bf = cfg.act_bf16
         gk = WgradGroup(R, cfg.k, cfg.precision, io_flags=(ops.WIO_DY_BF16 | ops.WIO_X_BF16) if bf else 0)     # In_l (k taps)
         g1 = WgradGroup(R, 1, cfg.precision)                            # Start / End (1x1)
@@ -589,6 +592,8 @@ class DecoderFunction(torch.autograd.Function):
                 g.dh[l], g.dins[l] = dh_ptr(f, l), dins[f, l].data_ptr()
             if dcond is not None:
                 g.dcond = dcond.data_ptr() + 4 * f * Lw * 2 * H
+                if npit:
+                    g.pitch_rows, g.pitch_ns = ctx.prow.data_ptr(), npit
             acts = buf.acts(f, Lw, rowmask)
             dims = _dims(cfg, B, T, ctx.drop[0], ctx.drop[1], f)
             _lib.check(L.glowtts_flow_backward(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(acts), ctypes.byref(g),
@@ -625,18 +630,12 @@ class DecoderFunction(torch.autograd.Function):
         dmel = unsqueeze_rows(cfg, dx, ctx.lengths, B, Tm) if ctx.want_dmel else None
         dpw = dpb = None
         if ctx.prow is not None:
-            # Pitch_l conv (Modules.py:846-852, 867-869): bias gradient = the conditioning gradient summed over utterances; weight
-            # gradient = sum_r d pre[r][n] * pitch[r][j] from the kept gate gradients (PAIR-packed columns -> original channels).
-            # NOTE: with WaveNet dropout > 0 the kept gate gradients carry the keep mask (the In_l conv sits behind the dropout, the
-            # pitch term does not): the weight gradient is then an unbiased estimate, exact for Dropout_Rate = 0 / eval mode.
-            dpb = dcond.sum(0).view(F_, Lw, 2 * H)
-            pc = torch.arange(prep.ldin, device=dev)
-            j = (pc >> 6) * 32 + (pc & 31)
-            valid = j < H
-            orig = (((pc >> 5) & 1) * H + j)[valid]
-            dpw = torch.zeros(F_, Lw, 2 * H, ctx.prow.shape[1], device=dev)
-            for f in range(F_):
-                dpw[f, :, orig] = torch.matmul(dins[f].float().transpose(1, 2), ctx.prow)[:, valid]
+            # Pitch_l conv (Modules.py:846-852, 867-869): bias gradient = the conditioning gradient summed over utterances; weight gradient =
+            # sum_r d pre[r][n] * pitch[r][j] with d pre taken BEFORE the WaveNet dropout's keep mask (the pitch term joins behind the
+            # dropout, Modules.py:861-869), accumulated by the gate-derivative epilogues into the rows behind the utterances'
+            dpb = dcond[:B].sum(0).view(F_, Lw, 2 * H)
+            dpw = dcond[B:].view(npit, F_, Lw, 2 * H).permute(1, 2, 3, 0).contiguous()
+            dcond = dcond[:B]
         return (None, dmel, None, dcond, None, None, dpw, dpb) + tuple(G[k].view_as(W[k]) for k in WEIGHT_KEYS)
 
 

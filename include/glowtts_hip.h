@@ -377,6 +377,11 @@ typedef struct glowtts_flow_grads {       /* backward outputs; weight grads are 
     int coupling_done;                    /* 1: the previous call already applied THIS flow's coupling backward (dx, douts, douts_bf are ready) */
     const float *prev_xmid, *prev_outs;   /* not NULL: after this flow's ActNorm / 1x1 backward, apply the coupling backward of the flow that */
     float *prev_douts, *prev_douts_bf;    /*           runs next (f-1) in the same kernel; that call must then set coupling_done */
+    /* GR-mode per-frame pitch conditioning (Modules.py:846-852, 867-869): the Pitch_l conv's weight gradient is
+     * sum_r dpre[r][n] * pitch[r][j] over the gate-pre-activation gradients BEFORE the dropout mask, which only exist in the gate-derivative
+     * epilogue.  pitch_rows [R][pitch_ns] (the squeezed pitch in the rows layout, pitch_ns <= 2) or NULL; when given, `dcond` has
+     * B + pitch_ns rows and row B + j accumulates that sum for tap j (columns as in the rows above). */
+    const float *pitch_rows; int pitch_ns;
 } glowtts_flow_grads;
 
 /* training forward: xin -> xout, fills every kept buffer of `acts` */

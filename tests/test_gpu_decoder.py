@@ -223,3 +223,47 @@ def test_full_size_roundtrip_and_invariants(precision, tol):
     z3, ld3, _, _ = run_hip_decoder(sd, cfg, mels[3:5], ml[3:5], precision)
     Ts = int(ml[3:5].max())
     assert close(z3.cpu()[:, :, :Ts], z.cpu()[3:5, :, :Ts]) and close(ld3.cpu(), logdet.cpu()[3:5])
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_gr_pitch_weight_gradient_is_exact_under_dropout(precision):
+    """GR mode (Modules.py:846-852, 867-869): the per-frame pitch term joins the gate pre-activation BEHIND the WaveNet dropout, so the
+    Pitch_l weight / bias gradients are sums of the gate gradients before the keep mask (accumulated by the gate-derivative epilogue).
+    With p = 0.3 and a fixed seed the forward is a deterministic function of the pitch weights: central differences along random
+    directions must match the analytic gradient (they would not if the masked gradients were used), in both arithmetic modes."""
+    from glow_tts_amd import decoder as D
+    sd, _, r = load_case("tiny_gr.npz")
+    cfg = tiny_cfg("GR")
+    dc = dec_cfg(cfg, precision)
+    P = {k: v.cuda() for k, v in sd.items() if "Decoder" in k}
+    W = D.stack_decoder_weights(P, dc)
+    g = torch.Generator().manual_seed(3)
+    B = r["mels"].shape[0]
+    spk, pro = torch.randn(B, cfg.spk_dim, generator=g).cuda(), torch.randn(B, cfg.pro_dim, generator=g).cuda()
+    cond = D.conditioning(P, dc, speakers=spk, prosodies=pro)
+    mels, ml, pitches = torch.from_numpy(r["mels"]).cuda(), torch.from_numpy(r["mel_lengths"]).cuda(), torch.from_numpy(r["pitches"]).cuda()
+    F_, L, H, ns = dc.F, dc.L, dc.H, cfg.n_squeeze
+    pw = (torch.randn(F_, L, 2 * H, ns, generator=g) * 0.3).cuda()
+    pb = (torch.randn(F_, L, 2 * H, generator=g) * 0.1).cuda()
+    wz = torch.randn(mels.shape, generator=g).cuda()
+
+    def run(pw_, pb_, grad=False):
+        torch.manual_seed(21)                                  # the dropout seed is drawn from torch's generator
+        a, b = pw_.clone().requires_grad_(grad), pb_.clone().requires_grad_(grad)
+        z, _, _ = D.DecoderFunction.apply(dc, mels, ml, cond, 0.3, pitches, a, b, *W)
+        val = (z.double() * wz.double()).sum()
+        if grad:
+            val.backward()
+            return val.item(), a.grad, b.grad
+        return val.item()
+    _, gw, gb = run(pw, pb, grad=True)
+    assert gw is not None and gb is not None and torch.isfinite(gw).all() and gw.abs().max() > 0
+    for trial in range(3):
+        dw = torch.randn(pw.shape, generator=g).cuda()
+        db = torch.randn(pb.shape, generator=g).cuda()
+        analytic = (gw * dw).sum().item() + (gb * db).sum().item()
+        def central(eps):
+            return (run(pw + eps * dw, pb + eps * db) - run(pw - eps * dw, pb - eps * db)) / (2 * eps)
+        numeric = (4 * central(2e-3) - central(4e-3)) / 3 if precision == 0 else central(2e-2)
+        tol = (2e-2 if precision == 0 else 0.15) * max(1.0, abs(analytic))
+        assert abs(numeric - analytic) <= tol, (trial, numeric, analytic)
