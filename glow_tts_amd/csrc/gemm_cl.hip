@@ -176,7 +176,10 @@ template <> struct StaticFor<0> { template <class F> __device__ __forceinline__ 
 // the fused epilogues (shared by conv_cl_kernel and conv_dma_kernel).  acc[mi][ni] = 32x32 fragments of the wave's
 // (MI*32) x (NI*32) tile whose first row / column is (m0 + wm*MI*32, n0 + wn*NI*32); BM = rows of the workgroup tile.
 // ------------------------------------------------------------------------------------------------
-template <typename CT, int MI, int NI, int EPI>
+// PITCH: the DGATE epilogue also accumulates the GR-mode Pitch_l weight gradient when asked to (GLOWTTS_F_COND_ROWS).  Only the register-staged
+// kernel instantiates that variant: inside the 1024-thread LDS-DMA / chain kernels its extra live values cost the plain path 38 VGPRs and
+// spills (measured +0.12 ms/step), so those kernels decline such calls on the host side.
+template <typename CT, int MI, int NI, int EPI, bool PITCH = true>
 __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16 (&acc)[MI][NI], const int m0, const int n0, const int BM,
                                               const int wm, const int wn, const int lane, const int tid, long long* tlbuf)
 {
@@ -497,7 +500,7 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
         for (int ni = 0; ni < NI; ++ni) sa[ni] = ss[ni] = 0.f;
         // GLOWTTS_F_COND_ROWS (GR-mode pitch): `cond` = the squeezed pitch rows [rows][ldcond <= 2]; rows nutt + j of out1 accumulate
         // sum_r (da, ds)[r][n] * pitch[r][j] - the Pitch_l conv's weight gradient, also taken before the keep mask
-        const bool pit = dcnd && p.cond && (fl & GLOWTTS_F_COND_ROWS);
+        const bool pit = PITCH && dcnd && p.cond && (fl & GLOWTTS_F_COND_ROWS);
         const int pns = pit ? (int)p.ldcond : 0;
         const Rsrc rp = mk(p.cond, pit ? (long)p.rows * pns * 4 : 0);
         float pa[2][NI], ps[2][NI];
@@ -593,8 +596,12 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
                 }
             }
         };
-        if (pit) { if (drop) rows_loop(IC<1>{}, IC<1>{}); else rows_loop(IC<0>{}, IC<1>{}); }
-        else     { if (drop) rows_loop(IC<1>{}, IC<0>{}); else rows_loop(IC<0>{}, IC<0>{}); }
+        if constexpr (PITCH) {
+            if (pit) { if (drop) rows_loop(IC<1>{}, IC<1>{}); else rows_loop(IC<0>{}, IC<1>{}); }
+            else     { if (drop) rows_loop(IC<1>{}, IC<0>{}); else rows_loop(IC<0>{}, IC<0>{}); }
+        } else {
+            if (drop) rows_loop(IC<1>{}, IC<0>{}); else rows_loop(IC<0>{}, IC<0>{});
+        }
         if (dcnd) flush();
         if (pit) {
             const int nutt = p.rows / Tp;
@@ -1186,9 +1193,9 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
     }
     f32x16 (&accf)[1][NI] = reinterpret_cast<f32x16 (&)[1][NI]>(acc);         // row fragment of this wave: acc[0][*]
 #ifdef GLOWTTS_TIMELINE
-    conv_epilogue<CT, 1, NI, EPI>(p, accf, m0, n0, BM, wave, 0, lane, tid, tlbuf);
+    conv_epilogue<CT, 1, NI, EPI, false>(p, accf, m0, n0, BM, wave, 0, lane, tid, tlbuf);
 #else
-    conv_epilogue<CT, 1, NI, EPI>(p, accf, m0, n0, BM, wave, 0, lane, tid, nullptr);
+    conv_epilogue<CT, 1, NI, EPI, false>(p, accf, m0, n0, BM, wave, 0, lane, tid, nullptr);
 #endif
     TL(29);
 }
@@ -1336,7 +1343,7 @@ __global__ __launch_bounds__(CH_WN * CH_WM * 64) void conv_chain_kernel(const gl
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {
         glowtts_conv_args pe = pin2;
-        conv_epilogue<CT, 1, NI, EPI2>(pe, acc, m0, 0, CH_BM, wm, wn, lane, tid, nullptr);
+        conv_epilogue<CT, 1, NI, EPI2, false>(pe, acc, m0, 0, CH_BM, wm, wn, lane, tid, nullptr);
     }
 }
 
@@ -1386,7 +1393,7 @@ __global__ __launch_bounds__(64) void conv_skinny_kernel(const glowtts_conv_args
         for (int ni = 0; ni < NI; ++ni)
             acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&af), *reinterpret_cast<const bf16x8*>(&bfr[s][ni]), acc[0][ni], 0, 0, 0);
     }
-    conv_epilogue<CT, 1, NI, GLOWTTS_EPI_LINEAR>(p, acc, m0, 0, 32, 0, 0, lane, lane, nullptr);
+    conv_epilogue<CT, 1, NI, GLOWTTS_EPI_LINEAR, false>(p, acc, m0, 0, 32, 0, 0, lane, lane, nullptr);
 }
 
 template <int KS16, int NI>
@@ -1449,6 +1456,7 @@ bool dma_ok(const glowtts_conv_args& a)
     const bool enabled = GLOWTTS_TUNABLE("GLOWTTS_DMA", 1) != 0;
     if (!(enabled && a.precision == GLOWTTS_BF16 && (a.io_flags & GLOWTTS_IO_A_BF16) && a.apro == GLOWTTS_APRO_NONE &&
           a.batch <= 1 && a.kchunks * 32 == a.ca && (a.npad % 64) == 0 && a.rows >= 128)) return false;
+    if (a.epi == GLOWTTS_EPI_DGATE && (a.flags & GLOWTTS_F_COND_ROWS)) return false;       // the pitch-gradient variant lives in conv_cl_kernel only
     if (a.taps > 1) return !a.a2;
     // 1x1: whole stages of DMA1_CPS chunks; a second source must start on a stage boundary and share the row stride
     if (a.kchunks % DMA1_CPS) return false;
@@ -1739,6 +1747,7 @@ extern "C" int glowtts_conv_chain(const glowtts_conv_args* first, const glowtts_
 {
     if (!first || !second || !first->a || !first->w || !first->out0 || !second->w || !second->out0) return GLOWTTS_E_ARG;
     const glowtts_conv_args &a = *first, &b = *second;
+    if (b.epi == GLOWTTS_EPI_DGATE && (b.flags & GLOWTTS_F_COND_ROWS)) return GLOWTTS_E_ARG;   // (see conv_epilogue's PITCH)
     // both 1x1, bf16 MFMA on bf16-stored rows; the intermediate has exactly 192 channels (Calc_Channels of the reference's model)
     if (a.precision != GLOWTTS_BF16 || b.precision != GLOWTTS_BF16 || a.taps != 1 || b.taps != 1 || !(a.io_flags & GLOWTTS_IO_A_BF16) ||
         a.apro != GLOWTTS_APRO_NONE || a.a2 || a.batch > 1 || b.batch > 1 || a.rows != b.rows || a.rows < 1) return GLOWTTS_E_ARG;

@@ -124,3 +124,37 @@ def test_collater_matches_reference_layout_and_buckets():
     import pytest
     with pytest.raises(ValueError):
         Collater(token_buckets=[4])(batch)
+
+
+def test_hot_kernels_use_no_scratch_memory(tmp_path):
+    """Register-allocation guard: none of the kernels on the benchmarked path may spill (a DGATE epilogue variant once pushed the
+    1024-thread LDS-DMA kernel from 90 to 128 VGPRs + 348 bytes of scratch and cost 2 % of the step).  Reads the code objects' metadata
+    notes out of the built library (llvm-objdump --offloading + llvm-readelf --notes; nothing is executed)."""
+    import re
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(f"{llvm}/llvm-objdump") and os.path.exists(f"{llvm}/llvm-readelf")):
+        pytest.skip("ROCm LLVM tools not found")
+    so = os.path.join(REPO, "glow_tts_amd", "libglowtts_hip.so")
+    shutil.copy(so, tmp_path / "lib.so")
+    subprocess.run([f"{llvm}/llvm-objdump", "--offloading", "lib.so"], cwd=tmp_path, check=True, capture_output=True)
+    objs = [f for f in os.listdir(tmp_path) if f.endswith("gfx950")]
+    assert objs, "no gfx950 code objects in the library"
+    kernels = {}
+    for f in objs:
+        notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        for name, scratch, vgpr in re.findall(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)", notes, re.S):
+            kernels[name] = (int(scratch), int(vgpr))
+    assert len(kernels) > 100
+    hot = [r"conv_dma_kernelILi\dELi\dELi2ELb0E", r"conv_chain_kernel", r"conv_skinny_kernel", r"wgrad_kernel", r"attn_(fwd|bwd)_mfma_kernel",
+           r"mas_dp_kernelILi[12]E", r"ln_(fwd|bwd)_kernel", r"actnorm_inv", r"gate_bwd_kernel", r"mas_path_linear_kernel", r"expand_fwd4_kernel",
+           r"squeeze_kernel", r"optim|radam|adam"]
+    seen = {h: 0 for h in hot}
+    for name, (scratch, vgpr) in kernels.items():
+        for h in hot:
+            if re.search(h, name):
+                seen[h] += 1
+                assert scratch == 0, f"{name} spills: {scratch} bytes of scratch per lane at {vgpr} VGPRs"
+    for h, n in seen.items():
+        assert n > 0 or h == r"optim|radam|adam", f"pattern {h} matched no kernel"
