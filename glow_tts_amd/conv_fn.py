@@ -38,10 +38,10 @@ def _L():
         L.glowtts_gate_bwd.argtypes = [c_p] * 4 + [c_i64, c_int, c_f, c_p]
         L.glowtts_embedding_fwd.argtypes = [c_p] * 4 + [c_int] * 3 + [c_f, c_p]
         L.glowtts_embedding_bwd.argtypes = [c_p] * 4 + [c_int] * 4 + [c_f, c_p]
-        L.glowtts_rpr_attention_fwd.argtypes = [c_p] * 6 + [c_int] * 5 + [c_f, c_u32, c_p, c_p]
+        L.glowtts_rpr_attention_fwd_prec.argtypes = [c_p] * 6 + [c_int] * 5 + [c_f, c_u32, c_p, c_int, c_p]
         L.glowtts_rpr_attention_scratch_floats.argtypes = [c_int] * 5
         L.glowtts_rpr_attention_scratch_floats.restype = c_i64
-        L.glowtts_rpr_attention_bwd.argtypes = [c_p] * 11 + [c_int] * 5 + [c_f, c_u32, c_p, c_p]
+        L.glowtts_rpr_attention_bwd_prec.argtypes = [c_p] * 11 + [c_int] * 5 + [c_f, c_u32, c_p, c_int, c_p]
         _decl = True
     return L
 
@@ -234,26 +234,27 @@ class EmbeddingRows(torch.autograd.Function):
 
 
 class RPRAttention(torch.autograd.Function):
-    """Attention core of RPR_MHA.py:95-128 on fused QKV rows [B*Tp, 3*H*D] -> [B*Tp, H*D]."""
+    """Attention core of RPR_MHA.py:95-128 on fused QKV rows [B*Tp, 3*H*D] -> [B*Tp, H*D].  precision: ops.F32 / ops.BF16 (bf16 MFMA
+    contractions for Tp <= 128, fp32 softmax; see glowtts_rpr_attention_fwd_prec)."""
 
     @staticmethod
-    def forward(ctx, qkv, relk, relv, rowmask, B, Tp, H, win, drop_p, seed, seed_t):
+    def forward(ctx, qkv, relk, relv, rowmask, B, Tp, H, win, drop_p, seed, seed_t, precision=0):
         qkv = qkv.contiguous()
         D = qkv.shape[1] // (3 * H)
         out = torch.empty(B * Tp, H * D, device=qkv.device)
         P = torch.empty(B, H, Tp, Tp, device=qkv.device)
         rk, rv = relk.detach().contiguous(), relv.detach().contiguous()
-        _lib.check(_L().glowtts_rpr_attention_fwd(qkv.data_ptr(), rk.data_ptr(), rv.data_ptr(), rowmask.data_ptr(), out.data_ptr(), P.data_ptr(),
-                                                  B, Tp, H, D, win, float(drop_p), int(seed) & 0xFFFFFFFF, _sp(seed_t), _lib.stream()),
-                   "glowtts_rpr_attention_fwd")
+        _lib.check(_L().glowtts_rpr_attention_fwd_prec(qkv.data_ptr(), rk.data_ptr(), rv.data_ptr(), rowmask.data_ptr(), out.data_ptr(), P.data_ptr(),
+                                                       B, Tp, H, D, win, float(drop_p), int(seed) & 0xFFFFFFFF, _sp(seed_t), int(precision), _lib.stream()),
+                   "glowtts_rpr_attention_fwd_prec")
         ctx.save_for_backward(qkv, rk, rv, rowmask, P, seed_t)
-        ctx.cfg = (B, Tp, H, D, win, float(drop_p), int(seed) & 0xFFFFFFFF)
+        ctx.cfg = (B, Tp, H, D, win, float(drop_p), int(seed) & 0xFFFFFFFF, int(precision))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, rk, rv, rowmask, P, seed_t = ctx.saved_tensors
-        B, Tp, H, D, win, drop_p, seed = ctx.cfg
+        B, Tp, H, D, win, drop_p, seed, precision = ctx.cfg
         L = _L()
         dev = qkv.device
         nw = 2 * win + 1
@@ -262,7 +263,8 @@ class RPRAttention(torch.autograd.Function):
         drel = torch.empty(2, nw, D, device=dev)
         drk, drv = drel[0], drel[1]
         scratch = torch.empty(L.glowtts_rpr_attention_scratch_floats(B, Tp, H, D, win) + 2 * nw * D, device=dev)
-        _lib.check(L.glowtts_rpr_attention_bwd(qkv.data_ptr(), rk.data_ptr(), rv.data_ptr(), rowmask.data_ptr(), P.data_ptr(),
-                                               dout.contiguous().data_ptr(), dS.data_ptr(), dqkv.data_ptr(), drk.data_ptr(), drv.data_ptr(),
-                                               scratch.data_ptr(), B, Tp, H, D, win, drop_p, seed, _sp(seed_t), _lib.stream()), "glowtts_rpr_attention_bwd")
-        return dqkv, drk.view(1, nw, D), drv.view(1, nw, D), None, None, None, None, None, None, None, None
+        _lib.check(L.glowtts_rpr_attention_bwd_prec(qkv.data_ptr(), rk.data_ptr(), rv.data_ptr(), rowmask.data_ptr(), P.data_ptr(),
+                                                    dout.contiguous().data_ptr(), dS.data_ptr(), dqkv.data_ptr(), drk.data_ptr(), drv.data_ptr(),
+                                                    scratch.data_ptr(), B, Tp, H, D, win, drop_p, seed, _sp(seed_t), precision, _lib.stream()),
+                   "glowtts_rpr_attention_bwd_prec")
+        return dqkv, drk.view(1, nw, D), drv.view(1, nw, D), None, None, None, None, None, None, None, None, None

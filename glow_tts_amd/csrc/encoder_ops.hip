@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include "../../include/glowtts_hip.h"
 #include "tunable.h"
+#include "launch_log.h"
 
 namespace {
 
@@ -521,7 +522,33 @@ extern "C" int glowtts_embedding_bwd(const int64_t* tokens, const float* drows, 
 // P stores the probabilities BEFORE dropout (the backward regenerates the keep mask from the same hash).
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 at_bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int AT_TP = 128, AT_LDP = AT_TP + 1;
+
+// BF (bf16 precision only): the same contractions on v_mfma_f32_32x32x16_bf16.  The LDS tiles stay fp32; a lane gathers the 8 consecutive
+// k-values of its fragment (k = 16 step + 8 lhi + e) with the same addressing as the one fp32 value of the 32x32x2 form and rounds them to
+// bf16 in registers, fp32 accumulate, softmax and all element-wise arithmetic unchanged.  One bf16 MFMA does the work of 8 fp32 ones in
+// half the matrix-pipe time: the fp32 form spends 64 clk per 4096 FLOP and made these kernels matrix-pipe bound.
+template <bool BF> struct AtOp { typedef float T; static constexpr int KSTEP = 2, UNR = 4; };
+template <> struct AtOp<true> { typedef at_bf16x8 T; static constexpr int KSTEP = 16, UNR = 2; };
+template <bool BF, class F>
+__device__ __forceinline__ typename AtOp<BF>::T at_frag(F&& f)
+{
+    if constexpr (BF) {
+        at_bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)f(e);
+        return v;
+    } else {
+        return f(0);
+    }
+}
+template <bool BF>
+__device__ __forceinline__ f32x16 at_mma(typename AtOp<BF>::T a, typename AtOp<BF>::T b, f32x16 c)
+{
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
 
 __device__ __forceinline__ float half_max(float v) {          // over the 32 lanes that share lane >> 5
 #pragma unroll
@@ -549,12 +576,13 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* src, long ld
     }
 }
 
-template <int ND>
+template <int ND, bool BF = false>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ relk, const float* __restrict__ relv,
                                                             const float* __restrict__ rowmask, float* __restrict__ out, float* __restrict__ P,
                                                             int B, int Tp, int H, int win, float drop_p, uint32_t seed, const uint32_t* __restrict__ seed_ptr)
 {
-    constexpr int D = ND * 32, LD = D + 1, KS = D / 2;
+    constexpr int D = ND * 32, LD = D + 1;
+    constexpr int KSTEP = AtOp<BF>::KSTEP, UNR = AtOp<BF>::UNR;
     extern __shared__ float sm[];
     float* KV = sm;                               // [128][LD]   K, then V
     float* RL = KV + AT_TP * LD;                  // [32][LD]    relK, then relV (rows >= 2 win + 1 are zero)
@@ -585,13 +613,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
     f32x16 S[4], R;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { S[0][r] = 0.f; S[1][r] = 0.f; S[2][r] = 0.f; S[3][r] = 0.f; R[r] = 0.f; }
-#pragma unroll 4
-    for (int ks = 0; ks < KS; ++ks) {
-        const int k = 2 * ks + lhi;
-        const float a = myP[l31 * LD + k];                     // Q fragment (staged with row stride LD)
+    const int koff = BF ? 8 * lhi : lhi;          // first k of this lane's fragment inside a step
+#pragma unroll UNR
+    for (int kb = 0; kb < D; kb += KSTEP) {
+        const int k = kb + koff;
+        const auto a = at_frag<BF>([&](int e) { return myP[l31 * LD + k + e]; });          // Q fragment (staged with row stride LD)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) S[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[(32 * nt + l31) * LD + k], S[nt], 0, 0, 0);
-        R = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RL[l31 * LD + k], R, 0, 0, 0);
+        for (int nt = 0; nt < 4; ++nt) S[nt] = at_mma<BF>(a, at_frag<BF>([&](int e) { return KV[(32 * nt + l31) * LD + k + e]; }), S[nt]);
+        R = at_mma<BF>(a, at_frag<BF>([&](int e) { return RL[l31 * LD + k + e]; }), R);
     }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) myR[acc_row(reg, lhi) * 33 + l31] = R[reg];
@@ -642,20 +671,20 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
     for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[nd][r] = 0.f;
-#pragma unroll 4
-    for (int ks = 0; ks < AT_TP / 2; ++ks) {
-        const int k = 2 * ks + lhi;
-        const float a = myP[l31 * AT_LDP + k];
+#pragma unroll UNR
+    for (int kb = 0; kb < AT_TP; kb += KSTEP) {
+        const int k = kb + koff;
+        const auto a = at_frag<BF>([&](int e) { return myP[l31 * AT_LDP + k + e]; });
 #pragma unroll
-        for (int nd = 0; nd < ND; ++nd) O[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[k * LD + 32 * nd + l31], O[nd], 0, 0, 0);
+        for (int nd = 0; nd < ND; ++nd) O[nd] = at_mma<BF>(a, at_frag<BF>([&](int e) { return KV[(k + e) * LD + 32 * nd + l31]; }), O[nd]);
     }
     {
         const int i = 32 * wave + l31;
-        for (int ks = 0; ks < (nw + 1) / 2; ++ks) {
-            const int dd = 2 * ks + lhi, j = i + dd - win;
-            const float a = (dd < nw && j >= 0 && j < Tp) ? myP[l31 * AT_LDP + j] : 0.f;
+        for (int db = 0; db < nw; db += KSTEP) {          // (RL has 32 rows, those >= nw are zero)
+            const int dd0 = db + koff;
+            const auto a = at_frag<BF>([&](int e) { const int dd = dd0 + e, j = i + dd - win; return (dd < nw && j >= 0 && j < Tp) ? myP[l31 * AT_LDP + j] : 0.f; });
 #pragma unroll
-            for (int nd = 0; nd < ND; ++nd) O[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RL[dd * LD + 32 * nd + l31], O[nd], 0, 0, 0);
+            for (int nd = 0; nd < ND; ++nd) O[nd] = at_mma<BF>(a, at_frag<BF>([&](int e) { return RL[(dd0 + e) * LD + 32 * nd + l31]; }), O[nd]);
         }
     }
 #pragma unroll
@@ -673,13 +702,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
 // The 128 x 128 matrices Pd and dS pass through LDS (PT) so that they can be read both row-wise (A operand of dQ) and
 // column-wise (A operand of dV / dK); the 128 x D operands are staged one after the other into the same LDS buffer.
 // drelK / drelV: per-wave partial sums -> part[(bh * 4 + wave)][2][nw][D] (summed by colsum_final_kernel; deterministic).
-template <int ND>
+template <int ND, bool BF = false>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ relk, const float* __restrict__ relv,
                                                             const float* __restrict__ rowmask, const float* __restrict__ P, const float* __restrict__ dout,
                                                             float* __restrict__ dqkv, float* __restrict__ part,
                                                             int B, int Tp, int H, int win, float drop_p, uint32_t seed, const uint32_t* __restrict__ seed_ptr)
 {
-    constexpr int D = ND * 32, LD = D + 1, KS = D / 2;
+    constexpr int D = ND * 32, LD = D + 1;
+    constexpr int KSTEP = AtOp<BF>::KSTEP, UNR = AtOp<BF>::UNR;
     extern __shared__ float sm[];
     float* KV = sm;                               // [128][LD]   V, dO, K, Q in turn
     float* RL = KV + AT_TP * LD;                  // [32][LD]    relV, then relK
@@ -713,13 +743,14 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
     f32x16 S[4], R;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { S[0][r] = 0.f; S[1][r] = 0.f; S[2][r] = 0.f; S[3][r] = 0.f; R[r] = 0.f; }
-#pragma unroll 4
-    for (int ks = 0; ks < KS; ++ks) {
-        const int k = 2 * ks + lhi;
-        const float a = myP[l31 * LD + k];
+    const int koff = BF ? 8 * lhi : lhi;
+#pragma unroll UNR
+    for (int kb = 0; kb < D; kb += KSTEP) {
+        const int k = kb + koff;
+        const auto a = at_frag<BF>([&](int e) { return myP[l31 * LD + k + e]; });
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) S[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[(32 * nt + l31) * LD + k], S[nt], 0, 0, 0);
-        R = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RL[l31 * LD + k], R, 0, 0, 0);
+        for (int nt = 0; nt < 4; ++nt) S[nt] = at_mma<BF>(a, at_frag<BF>([&](int e) { return KV[(32 * nt + l31) * LD + k + e]; }), S[nt]);
+        R = at_mma<BF>(a, at_frag<BF>([&](int e) { return RL[l31 * LD + k + e]; }), R);
     }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) myR[acc_row(reg, lhi) * 33 + l31] = R[reg];
@@ -757,19 +788,19 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
         for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { O[nd][r] = 0.f; RV[nd][r] = 0.f; }
-#pragma unroll 4
-        for (int ks = 0; ks < AT_TP / 2; ++ks) {
-            const int i = 2 * ks + lhi;
-            const float a = PT[i * AT_LDP + 32 * wave + l31];
+#pragma unroll UNR
+        for (int kb = 0; kb < AT_TP; kb += KSTEP) {
+            const int i = kb + koff;
+            const auto a = at_frag<BF>([&](int e) { return PT[(i + e) * AT_LDP + 32 * wave + l31]; });
 #pragma unroll
-            for (int nd = 0; nd < ND; ++nd) O[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[i * LD + 32 * nd + l31], O[nd], 0, 0, 0);
+            for (int nd = 0; nd < ND; ++nd) O[nd] = at_mma<BF>(a, at_frag<BF>([&](int e) { return KV[(i + e) * LD + 32 * nd + l31]; }), O[nd]);
         }
-#pragma unroll 4
-        for (int ks = 0; ks < 16; ++ks) {
-            const int i = 32 * wave + 2 * ks + lhi, j = i + l31 - win;
-            const float a = (l31 < nw && j >= 0 && j < Tp) ? PT[i * AT_LDP + j] : 0.f;
+#pragma unroll UNR
+        for (int kb = 0; kb < 32; kb += KSTEP) {
+            const int i0 = 32 * wave + kb + koff;
+            const auto a = at_frag<BF>([&](int e) { const int i = i0 + e, j = i + l31 - win; return (l31 < nw && j >= 0 && j < Tp) ? PT[i * AT_LDP + j] : 0.f; });
 #pragma unroll
-            for (int nd = 0; nd < ND; ++nd) RV[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[i * LD + 32 * nd + l31], RV[nd], 0, 0, 0);
+            for (int nd = 0; nd < ND; ++nd) RV[nd] = at_mma<BF>(a, at_frag<BF>([&](int e) { return KV[(i0 + e) * LD + 32 * nd + l31]; }), RV[nd]);
         }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -803,19 +834,19 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
         for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[nd][r] = 0.f;
-#pragma unroll 4
-        for (int ks = 0; ks < AT_TP / 2; ++ks) {
-            const int k = 2 * ks + lhi;
-            const float a = myP[l31 * AT_LDP + k];
+#pragma unroll UNR
+        for (int kb = 0; kb < AT_TP; kb += KSTEP) {
+            const int k = kb + koff;
+            const auto a = at_frag<BF>([&](int e) { return myP[l31 * AT_LDP + k + e]; });
 #pragma unroll
-            for (int nd = 0; nd < ND; ++nd) O[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[k * LD + 32 * nd + l31], O[nd], 0, 0, 0);
+            for (int nd = 0; nd < ND; ++nd) O[nd] = at_mma<BF>(a, at_frag<BF>([&](int e) { return KV[(k + e) * LD + 32 * nd + l31]; }), O[nd]);
         }
         const int i = 32 * wave + l31;
-        for (int ks = 0; ks < (nw + 1) / 2; ++ks) {
-            const int dd = 2 * ks + lhi, j = i + dd - win;
-            const float a = (dd < nw && j >= 0 && j < Tp) ? myP[l31 * AT_LDP + j] : 0.f;
+        for (int db = 0; db < nw; db += KSTEP) {
+            const int dd0 = db + koff;
+            const auto a = at_frag<BF>([&](int e) { const int dd = dd0 + e, j = i + dd - win; return (dd < nw && j >= 0 && j < Tp) ? myP[l31 * AT_LDP + j] : 0.f; });
 #pragma unroll
-            for (int nd = 0; nd < ND; ++nd) O[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RL[dd * LD + 32 * nd + l31], O[nd], 0, 0, 0);
+            for (int nd = 0; nd < ND; ++nd) O[nd] = at_mma<BF>(a, at_frag<BF>([&](int e) { return RL[(dd0 + e) * LD + 32 * nd + l31]; }), O[nd]);
         }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -1210,19 +1241,38 @@ static size_t attn_lds_bytes(int Tp, int D, int win, bool)
     return ((size_t)Tp * (D + 1) + (size_t)(2 * win + 1) * D + 4 * (size_t)D + (size_t)ATT_QT * Tp) * sizeof(float);
 }
 
-extern "C" int glowtts_rpr_attention_fwd(const float* qkv, const float* relk, const float* relv, const float* rowmask, float* out, float* P,
-                                         int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t* seed_ptr, void* stream)
+template <int ND, bool BF>
+static void launch_attn_fwd_mfma(size_t lds, hipStream_t st, const float* qkv, const float* relk, const float* relv, const float* rowmask, float* out, float* P,
+                                 int B, int Tp, int H, int win, float drop_p, uint32_t seed, const uint32_t* seed_ptr)
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<ND, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    GLOWTTS_NOTE_STATIC("attn_fwd_mfma<%d,%s>", ND * 32, BF ? "bf16" : "f32");
+    hipLaunchKernelGGL((attn_fwd_mfma_kernel<ND, BF>), dim3(H, B), dim3(256), lds, st, qkv, relk, relv, rowmask, out, P, B, Tp, H, win, drop_p, seed, seed_ptr);
+}
+template <int ND, bool BF>
+static void launch_attn_bwd_mfma(size_t lds, hipStream_t st, const float* qkv, const float* relk, const float* relv, const float* rowmask, const float* P,
+                                 const float* dout, float* dqkv, float* scratch, int B, int Tp, int H, int win, float drop_p, uint32_t seed, const uint32_t* seed_ptr)
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel<ND, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    GLOWTTS_NOTE_STATIC("attn_bwd_mfma<%d,%s>", ND * 32, BF ? "bf16" : "f32");
+    hipLaunchKernelGGL((attn_bwd_mfma_kernel<ND, BF>), dim3(H, B), dim3(256), lds, st, qkv, relk, relv, rowmask, P, dout, dqkv, scratch, B, Tp, H, win, drop_p, seed, seed_ptr);
+}
+
+extern "C" int glowtts_rpr_attention_fwd_prec(const float* qkv, const float* relk, const float* relv, const float* rowmask, float* out, float* P,
+                                              int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t* seed_ptr, int precision, void* stream)
 {
     if (!qkv || !relk || !relv || !rowmask || !out || !P || B < 1 || Tp < 1 || Tp > 256 || H < 1 || D < 1 || win < 0) return GLOWTTS_E_ARG;
+    if (precision != GLOWTTS_F32 && precision != GLOWTTS_BF16) return GLOWTTS_E_ARG;
+    const bool bf = precision == GLOWTTS_BF16;
     if (attn_mfma_ok(Tp, D, win)) {
         const size_t l2 = attn_mfma_lds(D);
         hipStream_t st = static_cast<hipStream_t>(stream);
         if (D == 96) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-            hipLaunchKernelGGL(attn_fwd_mfma_kernel<3>, dim3(H, B), dim3(256), l2, st, qkv, relk, relv, rowmask, out, P, B, Tp, H, win, drop_p, seed, seed_ptr);
+            if (bf) launch_attn_fwd_mfma<3, true>(l2, st, qkv, relk, relv, rowmask, out, P, B, Tp, H, win, drop_p, seed, seed_ptr);
+            else    launch_attn_fwd_mfma<3, false>(l2, st, qkv, relk, relv, rowmask, out, P, B, Tp, H, win, drop_p, seed, seed_ptr);
         } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-            hipLaunchKernelGGL(attn_fwd_mfma_kernel<2>, dim3(H, B), dim3(256), l2, st, qkv, relk, relv, rowmask, out, P, B, Tp, H, win, drop_p, seed, seed_ptr);
+            if (bf) launch_attn_fwd_mfma<2, true>(l2, st, qkv, relk, relv, rowmask, out, P, B, Tp, H, win, drop_p, seed, seed_ptr);
+            else    launch_attn_fwd_mfma<2, false>(l2, st, qkv, relk, relv, rowmask, out, P, B, Tp, H, win, drop_p, seed, seed_ptr);
         }
         RET_LAUNCH();
     }
@@ -1247,13 +1297,21 @@ extern "C" int glowtts_rpr_attention_fwd(const float* qkv, const float* relk, co
     RET_LAUNCH();
 }
 
-extern "C" int64_t glowtts_rpr_attention_scratch_floats(int B, int Tp, int H, int D, int win) { return (int64_t)B * H * 8 * 2 * (2 * win + 1) * D; }
-
-extern "C" int glowtts_rpr_attention_bwd(const float* qkv, const float* relk, const float* relv, const float* rowmask, const float* P, const float* dout,
-                                         float* dS /* [B][H][Tp][Tp] scratch */, float* dqkv, float* drelk, float* drelv, float* scratch,
+extern "C" int glowtts_rpr_attention_fwd(const float* qkv, const float* relk, const float* relv, const float* rowmask, float* out, float* P,
                                          int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t* seed_ptr, void* stream)
 {
+    return glowtts_rpr_attention_fwd_prec(qkv, relk, relv, rowmask, out, P, B, Tp, H, D, win, drop_p, seed, seed_ptr, GLOWTTS_F32, stream);
+}
+
+extern "C" int64_t glowtts_rpr_attention_scratch_floats(int B, int Tp, int H, int D, int win) { return (int64_t)B * H * 8 * 2 * (2 * win + 1) * D; }
+
+extern "C" int glowtts_rpr_attention_bwd_prec(const float* qkv, const float* relk, const float* relv, const float* rowmask, const float* P, const float* dout,
+                                              float* dS /* [B][H][Tp][Tp] scratch */, float* dqkv, float* drelk, float* drelv, float* scratch,
+                                              int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t* seed_ptr, int precision, void* stream)
+{
     if (!qkv || !relk || !relv || !rowmask || !P || !dout || !dS || !dqkv || !drelk || !drelv || !scratch || Tp > 256) return GLOWTTS_E_ARG;
+    if (precision != GLOWTTS_F32 && precision != GLOWTTS_BF16) return GLOWTTS_E_ARG;
+    const bool bf = precision == GLOWTTS_BF16;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nw = 2 * win + 1;
     // per-(utterance, head[, wave]) partials of drelK | drelV, summed into `both`; when the caller's drelk / drelv are adjacent
@@ -1262,11 +1320,11 @@ extern "C" int glowtts_rpr_attention_bwd(const float* qkv, const float* relk, co
     if (attn_mfma_ok(Tp, D, win)) {
         const size_t l2 = attn_mfma_lds(D);
         if (D == 96) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-            hipLaunchKernelGGL(attn_bwd_mfma_kernel<3>, dim3(H, B), dim3(256), l2, st, qkv, relk, relv, rowmask, P, dout, dqkv, scratch, B, Tp, H, win, drop_p, seed, seed_ptr);
+            if (bf) launch_attn_bwd_mfma<3, true>(l2, st, qkv, relk, relv, rowmask, P, dout, dqkv, scratch, B, Tp, H, win, drop_p, seed, seed_ptr);
+            else    launch_attn_bwd_mfma<3, false>(l2, st, qkv, relk, relv, rowmask, P, dout, dqkv, scratch, B, Tp, H, win, drop_p, seed, seed_ptr);
         } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-            hipLaunchKernelGGL(attn_bwd_mfma_kernel<2>, dim3(H, B), dim3(256), l2, st, qkv, relk, relv, rowmask, P, dout, dqkv, scratch, B, Tp, H, win, drop_p, seed, seed_ptr);
+            if (bf) launch_attn_bwd_mfma<2, true>(l2, st, qkv, relk, relv, rowmask, P, dout, dqkv, scratch, B, Tp, H, win, drop_p, seed, seed_ptr);
+            else    launch_attn_bwd_mfma<2, false>(l2, st, qkv, relk, relv, rowmask, P, dout, dqkv, scratch, B, Tp, H, win, drop_p, seed, seed_ptr);
         }
         prow = B * H * 4;
     } else if (attn_long_ok(Tp, D, win)) {
@@ -1302,4 +1360,12 @@ extern "C" int glowtts_rpr_attention_bwd(const float* qkv, const float* relk, co
         if (hipMemcpyAsync(drelv, both + nw * D, (size_t)nw * D * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return GLOWTTS_E_LAUNCH;
     }
     RET_LAUNCH();
+}
+
+extern "C" int glowtts_rpr_attention_bwd(const float* qkv, const float* relk, const float* relv, const float* rowmask, const float* P, const float* dout,
+                                         float* dS, float* dqkv, float* drelk, float* drelv, float* scratch,
+                                         int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t* seed_ptr, void* stream)
+{
+    return glowtts_rpr_attention_bwd_prec(qkv, relk, relv, rowmask, P, dout, dS, dqkv, drelk, drelv, scratch, B, Tp, H, D, win, drop_p, seed, seed_ptr,
+                                          GLOWTTS_F32, stream);
 }

@@ -106,7 +106,7 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
         a = q + ".Attention"
         qkv = conv(x, a + ".QKV")                                                                            # RPR_MHA.py:82-84 (one fused 1x1 conv)
         att = RPRAttention.apply(qkv, P[a + ".weight_K"], P[a + ".weight_V"], rmf, B, Tp, H, win,
-                                 float(dr) if training else 0.0, nseed(), seed_t)                            # RPR_MHA.py:95-128
+                                 float(dr) if training else 0.0, nseed(), seed_t, precision)                 # RPR_MHA.py:95-128
         att = conv(att, a + ".layer_Dict.Projection", drop=dr)                                               # :93 + Dropout :561
         x = ln(att, x, q + ".LayerNorm_0")                                                                   # :562
         h = conv(x, q + ".Conv_0", relu=True, mask_out=True, drop=dr)                                        # :565-567

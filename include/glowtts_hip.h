@@ -436,6 +436,13 @@ int64_t glowtts_rpr_attention_scratch_floats(int B, int Tp, int H, int D, int wi
 int glowtts_rpr_attention_bwd(const float *qkv, const float *relk, const float *relv, const float *rowmask, const float *P, const float *dout,
                               float *dS, float *dqkv, float *drelk, float *drelv, float *scratch,
                               int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t *seed_ptr, void *stream);
+/* The same with an arithmetic mode (GLOWTTS_F32 = the two functions above; GLOWTTS_BF16: for Tp <= 128 the five contractions of the core run on
+ * bf16 MFMAs - operands rounded to bf16 in registers, fp32 accumulate, fp32 softmax - the other paths are fp32 in either mode). */
+int glowtts_rpr_attention_fwd_prec(const float *qkv, const float *relk, const float *relv, const float *rowmask, float *out, float *P,
+                                   int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t *seed_ptr, int precision, void *stream);
+int glowtts_rpr_attention_bwd_prec(const float *qkv, const float *relk, const float *relv, const float *rowmask, const float *P, const float *dout,
+                                   float *dS, float *dqkv, float *drelk, float *drelv, float *scratch,
+                                   int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t *seed_ptr, int precision, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Alignment expansion and likelihood loss.

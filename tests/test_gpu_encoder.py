@@ -67,6 +67,46 @@ def test_rpr_attention_core_forward_backward(T, D):
         assert err < 2e-5, (name, err)
 
 
+@pytest.mark.parametrize("T,D", [(120, 96), (57, 96), (100, 64), (124, 96)])
+def test_rpr_attention_core_bf16_mode(T, D):
+    """bf16 arithmetic mode of the single-workgroup attention core (the benchmarked configuration: 120 tokens, D = 96): the five contractions
+    run on bf16 MFMAs (launch class asserted), softmax in fp32.  Against the fp64 reference: bf16-level agreement of the output and of all
+    four gradients (relative to each tensor's largest entry) and a cosine >= 0.999."""
+    from glow_tts_amd.conv_fn import RPRAttention
+    from glow_tts_amd import ops
+    from helpers import launch_counts, launch_reset
+    B, H, win = 3, 2, 4
+    Tp = T + 4
+    g = torch.Generator().manual_seed(T + D)
+    lens = torch.tensor([T, T - 9, max(5, T // 3)])
+    rowmask = torch.zeros(B, Tp)
+    for b in range(B):
+        rowmask[b, 2:2 + lens[b]] = 1.0
+    rowmask = rowmask.reshape(-1).cuda()
+    qkv = (torch.randn(B * Tp, 3 * H * D, generator=g) * 0.5).cuda().requires_grad_(True)
+    relk = (torch.randn(1, 2 * win + 1, D, generator=g) * D ** -0.5).cuda().requires_grad_(True)
+    relv = (torch.randn(1, 2 * win + 1, D, generator=g) * D ** -0.5).cuda().requires_grad_(True)
+    dout = torch.randn(B * Tp, H * D, generator=g).cuda() * rowmask[:, None]
+    launch_reset()
+    out = RPRAttention.apply(qkv, relk, relv, rowmask, B, Tp, H, win, 0.0, 0, None, ops.BF16)
+    out.backward(dout)
+    counts = launch_counts()
+    assert counts.get(f"attn_fwd_mfma<{D},bf16>", 0) == 1 and counts.get(f"attn_bwd_mfma<{D},bf16>", 0) == 1, counts
+    got = [out.detach(), qkv.grad.clone(), relk.grad.clone(), relv.grad.clone()]
+    qkv.grad = relk.grad = relv.grad = None
+    ref = attention_core_ref(qkv.double(), relk[0].double(), relv[0].double(), rowmask.double(), B, Tp, H, win)
+    ref.backward(dout.double())
+    want = [ref.detach(), qkv.grad, relk.grad, relv.grad]
+    valid = rowmask[:, None] > 0
+    for name, a, b_ in zip(("out", "dqkv", "drelK", "drelV"), got, want):
+        a, b_ = a.double(), b_.double()
+        if name in ("out", "dqkv"):
+            a, b_ = a * valid, b_ * valid
+        err = (a - b_).abs().max().item() / max(1.0, b_.abs().max().item())
+        cos = (a.flatten() @ b_.flatten() / (a.norm() * b_.norm())).item()
+        assert err < 2e-2 and cos > 0.999, (name, err, cos)
+
+
 @pytest.mark.parametrize("T", [120, 200])
 def test_rpr_attention_dropout_mask_consistency(T):
     """p > 0: output changes, same seed reproduces it, and the backward uses the forward's keep mask (linear in V: exact check)."""

@@ -136,7 +136,7 @@ def test_graphed_training_reduces_the_loss(precision):
         l.backward()
         clip_grad_norm_(list(me.parameters()), 5.0)
         oe.step(); se.step()
-        eager.append(float(l))
+        eager.append(float(l.detach()))
     assert all(np.isfinite(curve)) and all(np.isfinite(eager))
     assert curve[-1] < curve[0] - 0.5, (curve[0], curve[-1])             # it learns
     assert step2.steps_taken == steps
