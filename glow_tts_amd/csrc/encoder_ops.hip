@@ -550,15 +550,27 @@ __device__ __forceinline__ f32x16 at_mma(typename AtOp<BF>::T a, typename AtOp<B
     else return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float half_max(float v) {          // over the 32 lanes that share lane >> 5
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+// Reductions over the 32 lanes that share lane >> 5.  Inside a row of 16 lanes they are DPP moves on the VALU (quad swaps, then the two
+// mirrors: after the quad steps every lane holds its quad's total, so mirroring 8 and then 16 lanes completes the row); only the step across
+// the two rows goes through the LDS crossbar.  (As five __shfl_xor = ds_bpermute_b32 each, the softmax of one 32 x 128 score tile issued 160
+// dependent LDS round trips per wave.)
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+constexpr int DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+__device__ __forceinline__ float half_max(float v) {
+    v = fmaxf(v, dpp_mov<DPP_QUAD_1032>(v));
+    v = fmaxf(v, dpp_mov<DPP_QUAD_2301>(v));
+    v = fmaxf(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    return fmaxf(v, __shfl_xor(v, 16, 64));
 }
 __device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<DPP_QUAD_1032>(v);
+    v += dpp_mov<DPP_QUAD_2301>(v);
+    v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_mov<DPP_ROW_MIRROR>(v);
+    return v + __shfl_xor(v, 16, 64);
 }
 __device__ __forceinline__ int acc_row(int reg, int lhi) { return (reg & 3) + 8 * (reg >> 2) + 4 * lhi; }
 
