@@ -95,8 +95,9 @@ def forward_losses(model, mle_loss, batch, cond):
     return mle, length
 
 
-def train_step(model, mle_loss, batch, cond, reducer=None, world=1):
-    """Train.py:193-227 up to (and including) backward, plus the gradient all-reduce when data parallel.
+def train_step(model, mle_loss, batch, cond, reducer=None, world=1, opt=None):
+    """Train.py:193-233 (Train_Step): forward, losses, backward, the gradient all-reduce when data parallel, then - opt = (optimizer,
+    scheduler, max_grad_norm) - clip_grad_norm_, RAdam and the Noam schedule.
     Data parallel: every rank scales its MLE loss (a mean over ITS frames, Modules.py:1026) by local/global frames and its
     duration MSE (a mean over its padded [B,1,Tt]) by 1/world, and gradients are SUMMED: the result is the gradient of the
     single-process loss on the global batch (tests/test_distributed_cpu.py)."""
@@ -107,6 +108,11 @@ def train_step(model, mle_loss, batch, cond, reducer=None, world=1):
     loss.backward()
     if reducer is not None:
         reducer.reduce(average=False)
+    if opt is not None:
+        from glow_tts_amd.optim import clip_grad_norm_
+        clip_grad_norm_(list(model.parameters()), opt[2])
+        opt[0].step()
+        opt[1].step()
     return mle + length
 
 
@@ -356,6 +362,8 @@ def main():
     ap.add_argument("--windows", type=int, default=10, help="extra timed windows of --steps steps after the reported one (median / spread keys)")
     ap.add_argument("--tokens", type=int, default=120, help="padded token length (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true", help="time forward + losses + backward only (round 1's definition of the step); "
+                    "default: the whole Train_Step of Train.py:193-233 including clip_grad_norm_, RAdam and the Noam schedule")
     ap.add_argument("--tune", action="append", default=[], help="A/B measurements: key=value entries of glow_tts_amd.decoder.TUNE (e.g. wgrad_wide=0)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on device 0 (multi-rank smoke test on a single-GPU box)")
     ap.add_argument("--no-overlap", action="store_true", help="data parallel: one graph + one gradient exchange instead of the two-graph overlap")
@@ -400,6 +408,12 @@ def main():
         broadcast_parameters(model)                          # identical replicas
         model.actnorm_allreduce = actnorm_stats_allreduce
         reducer = FlatGradReducer(list(model.parameters()))
+    opt = None
+    if not args.no_optimizer:                                   # Train.py:88-100 (Model_Generate): RAdam + Modified_Noam_Scheduler, hyper-parameters of the yaml
+        from glow_tts_amd.optim import Modified_Noam_Scheduler, RAdam
+        optimizer = RAdam(model.parameters(), lr=hp.Train.Learning_Rate.Initial, betas=(hp.Train.ADAM.Beta1, hp.Train.ADAM.Beta2),
+                          eps=hp.Train.ADAM.Epsilon, weight_decay=hp.Train.Weight_Decay)
+        opt = (optimizer, Modified_Noam_Scheduler(optimizer, base=hp.Train.Learning_Rate.Base), hp.Train.Gradient_Norm)
     torch.manual_seed(4321 + rank)                              # dropout streams differ per rank; the replicas' weights do not
     B, Tt, Tm = args.batch or cfg["batch"], args.tokens, 800
     batch = synthetic_batch(B, Tt, Tm, 80, 1234 + rank, dev, ragged=args.ragged)
@@ -415,7 +429,7 @@ def main():
     # device inside the graph), followed - when data parallel - by the flat-bucket gradient all-reduce.
     from glow_tts_amd.distributed import global_frame_weight
     mode = "eager"
-    graph = tail_graph = early = tail = None
+    graph = tail_graph = opt_graph = early = tail = None
     keep = []                                                   # pinned job tables owned by the captured graphs
     side = torch.cuda.Stream() if args.graph else None
     if args.graph:
@@ -424,27 +438,44 @@ def main():
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, args.warmup - 1)):
-                loss = train_step(model, mle_loss, batch, cond, reducer, world)
+                loss = train_step(model, mle_loss, batch, cond, reducer, world, opt)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
     else:
         for _ in range(max(1, args.warmup - 1)):               # also runs the ActNorm data-dependent init
-            loss = train_step(model, mle_loss, batch, cond, reducer, world)
+            loss = train_step(model, mle_loss, batch, cond, reducer, world, opt)
     if args.graph:
         try:
             wfr = global_frame_weight(batch[3].sum()) if dp else None      # constant for a fixed batch
+
+            params = [p for p in model.parameters() if p.requires_grad]
+
+            def clip_and_update():                              # Train.py:228-232; the clip coefficient stays on the device
+                from glow_tts_amd.optim import grad_norm_and_coef
+                _, coef = grad_norm_and_coef(params, opt[2])
+                opt[0].step(grad_scale=coef)
 
             def fwd_bwd():
                 mle, length = forward_losses(model, mle_loss, batch, cond)
                 total = mle * wfr + length / world if dp else mle + length
                 model.zero_grad(set_to_none=True)
                 total.backward()
+                if opt is not None and not dp:
+                    clip_and_update()
                 return (mle + length).detach()
+
+            def uncount_capture_pass():                         # a capture pass advances the optimizer's step counters without running a kernel
+                for p in params:
+                    st = opt[0].state.get(p)
+                    if p.grad is not None and st is not None and "step" in st:
+                        st["step"] -= 1
 
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
                     fwd_bwd()
+                    if opt is not None and not dp:
+                        opt[1].step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
@@ -466,7 +497,19 @@ def main():
                 else:
                     with torch.cuda.graph(graph, capture_error_mode="thread_local" if dp else "global"):
                         static_loss = fwd_bwd()
+                    if opt is not None and not dp:
+                        uncount_capture_pass()
+                if opt is not None and dp:
+                    # data parallel: the update reads the REDUCED gradients, so it is its own graph behind the exchange
+                    opt_graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(opt_graph, pool=graph.pool(), capture_error_mode="thread_local"):
+                        clip_and_update()
+                    uncount_capture_pass()
+            if opt is not None and not dp:
+                opt[0].advance_host()
             graph.replay()
+            if opt is not None and not dp:
+                opt[1].step()
             if tail_graph is not None:
                 tail_graph.replay()
             torch.cuda.synchronize()
@@ -475,11 +518,13 @@ def main():
             import traceback
             traceback.print_exc()
             print(f"[bench] graph capture failed ({type(exc).__name__}); running eagerly", file=sys.stderr)
-            graph = tail_graph = None
+            graph = tail_graph = opt_graph = None
             torch.cuda.synchronize()
 
     def one_step():
         if graph is not None:
+            if opt is not None and not dp:
+                opt[0].advance_host()                           # this step's hyper-parameter words, stream-ordered before the replay
             graph.replay()
             if tail_graph is not None:
                 pending = early.begin()
@@ -488,8 +533,13 @@ def main():
                 early.finish(pending)
             elif reducer is not None:
                 reducer.reduce(average=False)
+            if opt_graph is not None:
+                opt[0].advance_host()
+                opt_graph.replay()
+            if opt is not None:
+                opt[1].step()
             return static_loss
-        return train_step(model, mle_loss, batch, cond, reducer, world)
+        return train_step(model, mle_loss, batch, cond, reducer, world, opt)
 
     def timed_window():
         barrier()
@@ -518,6 +568,42 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         if not torch.equal(lo, hi):
             raise SystemExit(f"[bench] rank {rank}: {int((lo != hi).sum())} gradient tensors differ between ranks after the all-reduce")
+        if opt is not None:                                     # ... and the replicas must still hold the same weights after all those updates
+            ps = torch.stack([p.detach().double().sum() for p in model.parameters()])
+            lo, hi = ps.clone(), ps.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if not torch.equal(lo, hi):
+                raise SystemExit(f"[bench] rank {rank}: {int((lo != hi).sum())} parameter tensors differ between ranks after the optimizer steps")
+    fwd_bwd_only = None
+    if opt is not None and not dp and graph is not None:
+        # round 1's definition of the step (forward + losses + backward, no update), for continuity: a second graph of the same model
+        try:
+            def fwd_bwd_noopt():
+                mle, length = forward_losses(model, mle_loss, batch, cond)
+                model.zero_grad(set_to_none=True)
+                (mle + length).backward()
+                return (mle + length).detach()
+            g2, keep2 = torch.cuda.CUDAGraph(), []
+            with torch.cuda.stream(side):
+                fwd_bwd_noopt()
+            torch.cuda.synchronize()
+            with _lib.pinned_sink(keep2):
+                with torch.cuda.graph(g2):
+                    fwd_bwd_noopt()
+            keep.extend(keep2)
+            g2.replay()
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.time()
+                for _ in range(args.steps):
+                    g2.replay()
+                torch.cuda.synchronize()
+                ts.append((time.time() - t0) / args.steps)
+            fwd_bwd_only = statistics.median(ts)
+        except Exception as exc:                               # noqa: BLE001 - an extra, never fatal
+            print(f"[bench] forward+backward-only leg skipped ({type(exc).__name__}: {exc})", file=sys.stderr)
     frames = int(batch[3].sum().item())
     if dp:
         import torch.distributed as dist
@@ -534,17 +620,21 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"{cfg['name']}, LJSpeech-shaped synthetic (80-mel, {Tm} frames, {Tt} tokens), "
-                                   f"batch={B}/GPU, {'ragged Set V' if args.ragged else 'fixed Set F'}, forward+losses+backward"
+                                   f"batch={B}/GPU, {'ragged Set V' if args.ragged else 'fixed Set F'}, "
+                                   + ("forward+losses+backward" if opt is None else "Train_Step = forward+losses+backward+clip_grad_norm+RAdam+Noam schedule")
                                    + (f", {'RCCL' if args.backend == 'nccl' else args.backend} grad all-reduce" if dp else ""),
                        "baseline_config": args.config, "mode": cfg["mode"] + ("/" + cfg["spk_type"] if cfg["mode"] == "SE" else ""),
                        "global_batch": B * world, "mel_frames": Tm, "tokens": Tt, "parallelism": f"dp{world}"},
-            "loss": round(float(loss.item()), 4), "launch_mode": mode,
+            "loss": round(float(loss.item()), 4), "launch_mode": mode, "optimizer_in_step": opt is not None,
             "windows": {"n": len(ms), "steps_each": args.steps, "ms_per_step_median": round(statistics.median(ms), 3),
                         "ms_per_step_min": round(min(ms), 3), "ms_per_step_max": round(max(ms), 3)},
             "model_tflops": round(tflops, 2),
             "mas_us_per_utt": round(mas_us_per_utt(B, Tt, Tm), 3),
             "roofline": roofline(args.precision, B, Tm // 2, tflops / world),
         }
+        if fwd_bwd_only is not None:
+            out["fwd_bwd_only"] = {"ms_per_step": round(1e3 * fwd_bwd_only, 3), "value": round(frames / fwd_bwd_only, 1),
+                                   "note": "forward + losses + backward without the parameter update (the step round 1 reported)"}
         if inv is not None:
             out["inverse_flow"] = inv
         if world == 1 and not args.no_cpu_baseline:
