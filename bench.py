@@ -332,9 +332,12 @@ def inverse_flow_leg(model, hp, dev, B, seed):
     Tt = 200
     tokens, tl, ref_mels, ref_ml = synthetic_batch(B, Tt, 800, 80, seed, dev)
     gi = GraphedInference(model, mel_buckets=(1024, 2048, 2560))
-    kw = dict(noise_scale=0.667, length_scale=10.0)
-    if "Prosody_Encoder" in model.layer_Dict:
-        kw.update(mels_for_prosody=ref_mels, mel_lengths_for_prosody=ref_ml)
+    pe = dict(mels_for_prosody=ref_mels, mel_lengths_for_prosody=ref_ml) if "Prosody_Encoder" in model.layer_Dict else {}
+    # per-utterance length scales that stretch whatever the duration predictor says at this point of the (synthetic) training to ~2000
+    # frames: the leg measures the inverse flow at a fixed long-form size, not the state of the duration predictor
+    with torch.no_grad():
+        pred = model.inference_front(tokens, tl, pe.get("mels_for_prosody"), pe.get("mel_lengths_for_prosody"), None, None, 1.0)[3]
+    kw = dict(noise_scale=0.667, length_scale=(2000.0 / pred.clamp(min=1).float()).to(dev), **pe)
     for _ in range(3):
         mels, lengths, _ = gi(tokens, tl, **kw)
     torch.cuda.synchronize()
@@ -576,7 +579,7 @@ def main():
             if not torch.equal(lo, hi):
                 raise SystemExit(f"[bench] rank {rank}: {int((lo != hi).sum())} parameter tensors differ between ranks after the optimizer steps")
     fwd_bwd_only = None
-    if opt is not None and not dp and graph is not None:
+    if opt is not None and not dp and graph is not None and args.windows > 0:      # (--windows 0 = profiling runs: every traced step is a full Train_Step)
         # round 1's definition of the step (forward + losses + backward, no update), for continuity: a second graph of the same model
         try:
             def fwd_bwd_noopt():
