@@ -508,8 +508,18 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) pa[j][ni] = ps[j][ni] = 0.f;
-        auto flush = [&]() __attribute__((always_inline)) {
-            if (cur_u >= 0) {
+        // flush(need): called by ALL lanes of the wave (it shuffles); lanes with `need` add their run's sums to out1 and start a new run.
+        // Lanes l and l + 32 hold the same column (rows 4 apart): when both flush the same utterance run - the rule, a run is hundreds of
+        // rows - the upper half hands its sums to the lower one and only that issues the atomics (half the atomic traffic).
+        auto flush = [&](const bool need) __attribute__((always_inline)) {
+            const int other_u = __shfl_xor(need ? cur_u : -2, 32, 64);
+            const bool pair = need && other_u == cur_u;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const float oa = __shfl_xor(sa[ni], 32, 64), os = __shfl_xor(ss[ni], 32, 64);
+                if (pair) { sa[ni] += oa; ss[ni] += os; }
+            }
+            if (need && cur_u >= 0 && !(pair && lhi)) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
                     if (dcol[ni] >= 0) {
@@ -517,8 +527,10 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
                         unsafeAtomicAdd(dst, sa[ni]); unsafeAtomicAdd(dst + p.n, ss[ni]);
                     }
             }
+            if (need) {
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) sa[ni] = ss[ni] = 0.f;
+                for (int ni = 0; ni < NI; ++ni) sa[ni] = ss[ni] = 0.f;
+            }
         };
         auto rows_loop = [&](auto DROP_, auto PIT_) __attribute__((always_inline)) {
             constexpr bool DROP = decltype(DROP_)::value != 0, PIT = decltype(PIT_)::value != 0;
@@ -560,7 +572,8 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
                         if (dcnd) {                                        // rows ascend with (mi, reg): one run of rows per utterance and lane
                             const int r = rb + roff(mi, reg);
                             const int u = r < p.rows ? r / Tp : -1;        // (rows past the end hold clamped garbage: not accumulated)
-                            if (u != cur_u) { flush(); cur_u = u; }
+                            const bool need = u != cur_u;
+                            if (__builtin_amdgcn_ballot_w64(need)) { flush(need); if (need) cur_u = u; }      // (wave-uniform branch)
                         }
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni) {
@@ -602,7 +615,7 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
         } else {
             if (drop) rows_loop(IC<1>{}, IC<0>{}); else rows_loop(IC<0>{}, IC<0>{});
         }
-        if (dcnd) flush();
+        if (dcnd) flush(true);
         if (pit) {
             const int nutt = p.rows / Tp;
             for (int j = 0; j < pns; ++j)
