@@ -161,7 +161,9 @@ class ConvRows(torch.autograd.Function):
                 db = torch.empty(O, device=x.device) if has_b else None
                 ctx.tape.add(dz, x, O, Ci2, k, precision, dw, db)
             else:
-                dw, db = wgrad(dz, x, O, Ci2, k, precision, want_bias=has_b, splits=min(4, max(1, R // 512)))
+                # split-K slices: few for the text encoder's short row counts; 0 = the library's own choice (about two workgroups per CU) for
+                # the long ones (patch matrices of the prosody encoder's conv stack: up to 512 k rows against a handful of output tiles)
+                dw, db = wgrad(dz, x, O, Ci2, k, precision, want_bias=has_b, splits=0 if R > 65536 else min(4, max(1, R // 512)))
         return dx, dw, db, None, dres, None, None, None, None, None, None, None, None
 
 

@@ -208,6 +208,8 @@ class GlowTTS(torch.nn.Module):
         prec = {"bf16": ops.BF16, "f32": ops.F32}[str(getattr(hp, "HIP_Precision", "bf16")).lower()]
         self.dec_cfg = decoder.DecoderConfig(hp.Sound.Mel_Dim, hp.Decoder.Stack, hp.Decoder.Num_Squeeze, hp.Decoder.Num_Split,
                                              hp.Decoder.Affine_Coupling.Calc_Channels, wn.Num_Layers, wn.Kernel_Size, prec)
+        if "Prosody_Encoder" in self.layer_Dict:
+            self.layer_Dict["Prosody_Encoder"].hip_precision = prec
         self.actnorm_allreduce = None     # set by the data-parallel wrapper (glow_tts_amd.distributed)
         self._enc_stream = None
         self._pcache = None               # name -> Parameter (see _params)

@@ -44,6 +44,55 @@ class _GRUFunction(torch.autograd.Function):
         return dx, dgi2.t() @ x.reshape(B * T, -1), dgh2.t() @ hprev, dgi2.sum(0), dgh2.sum(0)
 
 
+class _Im2ColS2(torch.autograd.Function):
+    """Patch matrix of Conv2d(3x3, stride 2, padding 1) over channels-last activations [B, H, W, C] -> [B*Ho*Wo, ldc] (glowtts_im2col3x3s2);
+    the backward is the gather-sum adjoint (glowtts_col2im3x3s2)."""
+
+    @staticmethod
+    def forward(ctx, x, ldc):
+        import ctypes
+        from . import _lib
+        L = _lib.lib()
+        L.glowtts_im2col3x3s2.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        col = torch.empty(B * ((H + 1) // 2) * ((W + 1) // 2), ldc, device=x.device)
+        _lib.check(L.glowtts_im2col3x3s2(_lib.ptr(x), _lib.ptr(col), B, H, W, C, ldc, _lib.stream()), "glowtts_im2col3x3s2")
+        ctx.cfg = (B, H, W, C, ldc)
+        return col
+
+    @staticmethod
+    def backward(ctx, dcol):
+        import ctypes
+        from . import _lib
+        L = _lib.lib()
+        L.glowtts_col2im3x3s2.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+        B, H, W, C, ldc = ctx.cfg
+        dcol = dcol.contiguous()
+        dx = torch.empty(B, H, W, C, device=dcol.device)
+        _lib.check(L.glowtts_col2im3x3s2(_lib.ptr(dcol), _lib.ptr(dx), B, H, W, C, ldc, _lib.stream()), "glowtts_col2im3x3s2")
+        return dx, None
+
+
+def conv_stack_hip(convs, mels, precision):
+    """The reference encoder's Conv2d(3x3, stride 2, padding 1, no bias) + ReLU stack (Modules.py:320-333, 366-368) on the HIP path: per layer a
+    patch-matrix gather and ONE MFMA GEMM with the ReLU in its epilogue (conv_fn.conv_rows -> glowtts_conv_cl; its backward: gate, data-gradient
+    GEMM, weight-gradient kernel), activations channels-last.  mels [B, Mel, T] -> [B, T', C * Mel'] (the GRU's input, feature = c * Mel' + h as
+    in the reference's reshape at :369)."""
+    from .conv_fn import conv_rows
+    x = mels.unsqueeze(-1)                                    # [B, H = Mel, W = T, C = 1]
+    for conv in convs:
+        w = conv.weight                                       # [Co, Ci, 3, 3]
+        B, H, W, C = x.shape
+        Co, K = w.shape[0], 9 * C
+        ldc = max(32, -(-K // 32) * 32)
+        col = _Im2ColS2.apply(x, ldc)
+        w2 = torch.nn.functional.pad(w.permute(0, 2, 3, 1).reshape(Co, K), (0, ldc - K)).unsqueeze(-1)      # [Co, (kh, kw, ci) + zero pad, 1]
+        x = conv_rows(col, w2, None, None, relu=True, precision=precision).view(B, (H + 1) // 2, (W + 1) // 2, Co)
+    B, H, W, C = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B, W, C * H)
+
+
 class _ConvBlock(torch.nn.Sequential):
     def __init__(self, cin, cout, k, stride):
         super().__init__()
@@ -51,6 +100,12 @@ class _ConvBlock(torch.nn.Sequential):
         torch.nn.init.kaiming_uniform_(conv.weight, nonlinearity="relu")           # Modules.py:1010-1014
         self.add_module("Conv", conv)
         self.add_module("ReLU", torch.nn.ReLU(inplace=True))
+
+
+def _conv1x1(conv, x):
+    """torch.nn.Conv1d(kernel_size = 1) on [B, C, T] as a matmul with the module's own parameters."""
+    y = torch.matmul(conv.weight.squeeze(-1), x)
+    return y if conv.bias is None else y + conv.bias.view(1, -1, 1)
 
 
 class _Attention(torch.nn.Module):
@@ -69,13 +124,15 @@ class _Attention(torch.nn.Module):
         B, _, Tq = queries.shape
         Tk = keys.shape[2]
         H = self.heads
-        q = self.layer_Dict["Query"](queries)
-        k = self.layer_Dict["Key"](keys)
-        v = self.layer_Dict["Value"](keys)
+        # the 1x1 Conv1d layers as batched matmuls (rocBLAS): MIOpen serves these shapes with its naive direct kernels (~0.5 ms a call, and
+        # which solver a captured hipGraph got depended on when it was captured)
+        q = _conv1x1(self.layer_Dict["Query"], queries)
+        k = _conv1x1(self.layer_Dict["Key"], keys)
+        v = _conv1x1(self.layer_Dict["Value"], keys)
         D = q.shape[1] // H
         q, k, v = (t.view(B, H, D, -1).transpose(2, 3) for t in (q, k, v))
         a = torch.softmax(q @ k.transpose(2, 3) / math.sqrt(D), dim=-1) @ v
-        return self.layer_Dict["Projection"](a.transpose(2, 3).reshape(B, H * D, Tq))
+        return _conv1x1(self.layer_Dict["Projection"], a.transpose(2, 3).reshape(B, H * D, Tq))
 
 
 class Prosody_Encoder(torch.nn.Module):
@@ -93,14 +150,27 @@ class Prosody_Encoder(torch.nn.Module):
         self.gst_Tokens = torch.nn.Parameter(torch.randn(pe.Style_Token.Size, pe.Style_Token.Num_Tokens) * 0.5)
         self.n_conv = len(self.strides)
 
+    hip_precision = 0                                         # ops.F32 / ops.BF16: arithmetic of the HIP conv stack (set by GlowTTS from HIP_Precision)
+    # The six stride-2 Conv2d layers through the library's own GEMM path (conv_stack_hip) instead of torch's Conv2d (MIOpen).  Off by
+    # default: measured on the MI355X at B = 32 (bench.py --config 5) the patch-matrix form is no faster than MIOpen's direct kernels
+    # (7.97 vs 7.82 ms forward + backward per step; 1.15 ms of kernels, a third of it writing and re-reading the patch matrices), see DESIGN.md.
+    use_hip_convs = False
+
     def forward(self, x, lengths):
-        x = x.unsqueeze(1)
-        for i in range(self.n_conv):
-            x = self.layer_Dict[f"Conv_{i}"](x)
-        x = x.reshape(x.size(0), x.size(1) * x.size(2), x.size(3))
+        convs = [self.layer_Dict[f"Conv_{i}"].Conv for i in range(self.n_conv)]
+        hip_convs = self.use_hip_convs and x.is_cuda and x.dtype == torch.float32 and all(
+            c.kernel_size == (3, 3) and c.stride == (2, 2) and c.padding == (1, 1) and c.bias is None and c.out_channels % 4 == 0 for c in convs)
+        if hip_convs:
+            xt = conv_stack_hip(convs, x, self.hip_precision)                              # [B, T', C * Mel']
+        else:                                                 # other kernel sizes / strides of the yaml: torch's Conv2d (on the same device)
+            x = x.unsqueeze(1)
+            for i in range(self.n_conv):
+                x = self.layer_Dict[f"Conv_{i}"](x)
+            xt = x.reshape(x.size(0), x.size(1) * x.size(2), x.size(3)).transpose(2, 1)
         gru = self.layer_Dict["GRU"]
+        x = xt.transpose(2, 1)
         if x.is_cuda and gru.num_layers == 1 and 3 * gru.hidden_size <= 1024 and x.dtype == torch.float32:
-            x = _GRUFunction.apply(x.transpose(2, 1).contiguous(), gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
+            x = _GRUFunction.apply(xt.contiguous(), gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
         elif not self.training and torch.is_grad_enabled() and x.requires_grad:
             # MIOpen's fused RNN has no backward in eval mode ("miopen RNN backward can only be called in training mode"): gradients
             # through an eval()-mode model take torch's native GRU cell instead (same arithmetic, Modules.py:371)
@@ -158,7 +228,10 @@ class Speaker_Classifier_GR(torch.nn.Module):
         self.layer.add_module(f"Output_{index}", out)
 
     def forward(self, x):
-        return self.layer(x.unsqueeze(2)).squeeze(2)
+        x = x.unsqueeze(2)
+        for m in self.layer:
+            x = _conv1x1(m, x) if isinstance(m, torch.nn.Conv1d) else m(x)
+        return x.squeeze(2)
 
 
 class Pitch_Interpolater(torch.nn.Module):

@@ -405,6 +405,12 @@ int glowtts_utt_colsum(const float *x, int64_t ldx, float *out, int64_t ldout, i
 int glowtts_gru_fwd(const float *gi, const float *w_hh, const float *b_hh, float *hs, float *keep, int B, int T, int H, void *stream);
 int glowtts_gru_bwd(const float *dhs, const float *hs, const float *keep, const float *w_hh, float *dgi, float *dgh,
                     int B, int T, int H, void *stream);
+/* Patch matrix of Conv2d(3x3, stride 2, padding 1) - the six layers of the GST reference encoder (Modules.py:320-333) - and its adjoint.
+ * x [B][H][W][C] channels-last fp32; col [B*Ho*Wo][ldc], Ho = ceil(H/2), Wo = ceil(W/2), column (kh*3 + kw)*C + c = x[b][2ho+kh-1][2wo+kw-1][c]
+ * (0 outside the image; columns 9C..ldc-1 are written as 0).  The conv is then glowtts_conv_cl (1x1, ReLU) on `col` with the weight viewed as
+ * [Cout][kh][kw][Cin]; col2im sums, per input pixel, the patch entries that read it (a gather: no atomics, dx is overwritten). */
+int glowtts_im2col3x3s2(const float *x, float *col, int B, int H, int W, int C, int ldc, void *stream);
+int glowtts_col2im3x3s2(const float *dcol, float *dx, int B, int H, int W, int C, int ldc, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Text-encoder kernels that are not convolutions (rows layout).

@@ -204,3 +204,45 @@ def test_gru_recurrence_matches_torch_gru(B, T, D, H):
     assert close(xg.grad, xr.grad)
     for p, n in zip(params, ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")):
         assert close(p.grad, getattr(ref, n).grad), n
+
+
+@pytest.mark.parametrize("B,M,T,chans,precision", [(3, 80, 201, [32, 32, 64, 64, 128, 128], 0), (2, 12, 40, [4, 8, 12], 0), (1, 80, 7, [32, 32], 0),
+                                                   (3, 80, 201, [32, 32, 64, 64, 128, 128], 1)])
+def test_prosody_conv_stack_matches_conv2d(B, M, T, chans, precision):
+    """Reference encoder of the GST prosody encoder (Modules.py:320-333, 366-369): six Conv2d(3x3, stride 2, padding 1, no bias) + ReLU.
+    HIP path = patch-matrix gather + MFMA GEMM per layer (prosody.conv_stack_hip) against torch's Conv2d in fp64: the GRU input
+    [B, T', C * Mel'] and the gradients of every conv weight and of the input (odd sizes: the last window hangs over the edge)."""
+    from glow_tts_amd.prosody import conv_stack_hip
+    from helpers import launch_counts, launch_reset
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    convs, cin = [], 1
+    for c in chans:
+        conv = torch.nn.Conv2d(cin, c, 3, stride=2, padding=1, bias=False)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (9 * cin)) ** 0.5)
+        convs.append(conv.cuda())
+        cin = c
+    mels = torch.randn(B, M, T, generator=g).cuda().requires_grad_(True)
+    launch_reset()
+    out = conv_stack_hip(convs, mels, precision)
+    dout = torch.randn(out.shape, generator=g).cuda()
+    out.backward(dout)
+    counts = launch_counts()
+    assert counts.get("im2col3x3s2", 0) == len(chans) and counts.get("col2im3x3s2", 0) == len(chans), counts
+    got = [out.detach().double().cpu(), mels.grad.double().cpu()] + [c.weight.grad.double().cpu() for c in convs]
+    x = mels.detach().double().cpu().requires_grad_(True)
+    ws = [c.weight.detach().double().cpu().requires_grad_(True) for c in convs]
+    y = x.unsqueeze(1)
+    for w in ws:
+        y = torch.relu(torch.nn.functional.conv2d(y, w, None, stride=2, padding=1))
+    ref = y.reshape(y.size(0), y.size(1) * y.size(2), y.size(3)).transpose(2, 1)             # Modules.py:369-370
+    assert ref.shape == out.shape
+    ref.backward(dout.double().cpu())
+    want = [ref.detach(), x.grad] + [w.grad for w in ws]
+    for name, a, b_ in zip(["out", "dmels"] + [f"dW{i}" for i in range(len(ws))], got, want):
+        err = (a - b_).abs().max().item() / max(1e-6, b_.abs().max().item())
+        cos = (a.flatten() @ b_.flatten() / (a.norm() * b_.norm() + 1e-30)).item()
+        if precision == 0:
+            assert err < 2e-5, (name, err)
+        else:     # bf16 operands through six layers: direction and scale of every gradient, not its worst element (a flipped ReLU moves one)
+            assert cos > (0.98 if name == "dmels" else 0.99) and 0.95 < (a.norm() / b_.norm()).item() < 1.05, (name, err, cos)
