@@ -17,5 +17,14 @@ for _ in range(iters):
         c["run"]()
     x.fill_(1.0)                                     # writes 1 GiB
     torch.mul(x, 1.5, out=y)                         # reads 1 GiB, writes 1 GiB
+if os.environ.get("PMC_PROBE"):                      # calibration of the MFMA-busy pass: a loop of back-to-back bf16 MFMAs, one wave per SIMD on every CU
+    import ctypes
+    from glow_tts_amd import _lib
+    L = _lib.lib()
+    L.glowtts_mfma_clock_probe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    out = torch.zeros(ncu, 2, dtype=torch.int64, device="cuda")
+    for _ in range(iters):
+        _lib.check(L.glowtts_mfma_clock_probe(out.data_ptr(), ncu, 20000, None, _lib.stream()), "probe")
 torch.cuda.synchronize()
 print("ran", list(cases), "x", iters)
