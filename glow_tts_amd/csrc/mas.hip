@@ -64,11 +64,27 @@ __global__ __launch_bounds__(64) void mas_dp_kernel(const float* __restrict__ va
     const int lane = threadIdx.x;
     const int tx = t_xs[b], ty = t_ys[b];
     int32_t* idx_b = idx_out ? idx_out + (size_t)b * Ty : nullptr;
-    if (tx < 1 || ty < tx || tx > Tx || ty > Ty) {            // undefined in the reference -> empty alignment
+    if (tx < 1 || ty < 0 || tx > Tx || ty > Ty) {             // lengths outside the tensors: empty alignment
         if (idx_b) for (int y = lane; y < Ty; y += 64) idx_b[y] = -1;
         return;
     }
     const float* vb = value + (size_t)b * Tx * Ty;
+    if (ty < tx) {
+        // More tokens than frames: no monotonic alignment exists.  core.pyx:15-17's loops are then empty for every column (lo >= hi), `value`
+        // stays as it was passed in, and the backtrack (:31-35) walks those RAW inputs from row t_x - 1; reproduced literally (a serial,
+        // wave-uniform walk: not a case a model produces; the test at y == 0 cannot change the path any more and is skipped).
+        int index = tx - 1;
+        for (int y = ty - 1; y >= 0; --y) {
+            if (idx_b && lane == 0) idx_b[y] = index;
+            if (y > 0 && index != 0) {
+                const float a = TR ? vb[(size_t)(y - 1) * Tx + index] : vb[(size_t)index * Ty + y - 1];
+                const float c = TR ? vb[(size_t)(y - 1) * Tx + index - 1] : vb[(size_t)(index - 1) * Ty + y - 1];
+                if (index == y || a < c) index -= 1;
+            }
+        }
+        if (idx_b) for (int y = max(ty, 0) + lane; y < Ty; y += 64) idx_b[y] = -1;
+        return;
+    }
     float* qb = WRITEQ ? q_out + (size_t)b * Tx * Ty : nullptr;
     const int nblk = (ty + 31) >> 5;
 

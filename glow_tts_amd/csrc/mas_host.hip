@@ -14,7 +14,9 @@ namespace {
 
 void mas_each(int32_t* path, float* value, int t_x, int t_y, int Ty, float neg)
 {
-    if (t_x < 1 || t_y < t_x) return;                       // undefined in the reference (core.pyx reads Q[index, -1]); left all-zero here
+    if (t_x < 1) return;
+    // (t_y < t_x - no monotonic alignment exists: the loops below are then empty for every column and the backtrack walks the raw inputs,
+    // exactly as core.pyx does; its last test, at y == 0, would read value[index][-1] but cannot change the path any more: skipped)
     for (int y = 0; y < t_y; ++y) {
         const int lo = std::max(0, t_x + y - t_y), hi = std::min(t_x, y + 1);
         for (int x = lo; x < hi; ++x) {
@@ -26,7 +28,7 @@ void mas_each(int32_t* path, float* value, int t_x, int t_y, int Ty, float neg)
     int index = t_x - 1;
     for (int y = t_y - 1; y >= 0; --y) {
         path[(size_t)index * Ty + y] = 1;
-        if (index != 0 && (index == y || value[(size_t)index * Ty + y - 1] < value[(size_t)(index - 1) * Ty + y - 1])) index -= 1;
+        if (y > 0 && index != 0 && (index == y || value[(size_t)index * Ty + y - 1] < value[(size_t)(index - 1) * Ty + y - 1])) index -= 1;
     }
 }
 

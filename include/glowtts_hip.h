@@ -48,8 +48,9 @@ int glowtts_mfma_clock_probe(long long *out, int nwg, int iters, int *wall_khz, 
  *
  *   value    [B][Tx][Ty] f32, already multiplied by the mask (monotonic_align/__init__.py:11).
  *            Read-only unless q_out == value (then clobbered into cumulative scores like core.pyx:30).
- *   t_xs,t_ys[B] i32      valid tokens / frames per utterance (1 <= t_x <= t_y required, as in the
- *            reference where t_x > t_y is undefined; such rows get an all-zero path and idx = -1).
+ *   t_xs,t_ys[B] i32      valid tokens / frames per utterance, 1 <= t_x <= Tx, 0 <= t_y <= Ty (else: all-zero path, idx = -1).
+ *            t_x > t_y (no monotonic alignment exists) is reproduced as core.pyx behaves: nothing is accumulated and the
+ *            backtrack walks the raw inputs from row t_x - 1.
  *   idx_out  [B][Ty] i32  token index aligned to each frame, -1 for y >= t_y.           (may be NULL)
  *   q_out    [B][Tx][Ty] f32 cumulative scores exactly as core.pyx leaves `values`      (may be NULL)
  *   Tx <= 512.

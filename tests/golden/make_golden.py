@@ -210,12 +210,29 @@ def make_mas_cases():
                       f"{name}/q_sum": np.float64(q.astype(np.float64).sum()),
                       f"{name}/q_xor": np.bitwise_xor.reduce(q.view(np.uint32).ravel())})
         print(f"  MAS case {name}: oracle C == reference core.pyx (path + cumulative values bit-exact)")
+    # more tokens than frames: no monotonic alignment exists; core.pyx then accumulates nothing and backtracks over the raw inputs
+    for name, B, Tx, Ty in (("more_tokens", 3, 40, 17),):
+        v = rng.normal(-100, 30, (B, Tx, Ty)).astype(np.float32)
+        tx, ty = np.array([Tx, Tx - 9, 5], dtype=np.int32), np.array([Ty, Ty - 8, 1], dtype=np.int32)
+        mask = (np.arange(Tx)[None, :, None] < tx[:, None, None]) & (np.arange(Ty)[None, None, :] < ty[:, None, None])
+        v = (v * mask).astype(np.float32)
+        q = v.copy()
+        path = np.zeros((B, Tx, Ty), dtype=np.int32)
+        core.maximum_path_c(path, q, tx, ty)
+        p2, q2 = mas_ref.maximum_path_c(v, tx, ty, return_q=True)
+        assert (p2 == path).all() and (q2.view(np.int32) == q.view(np.int32)).all() and (q == v).all(), name
+        cases.update({f"{name}/value": v, f"{name}/t_x": tx, f"{name}/t_y": ty, f"{name}/path": path.astype(np.int8),
+                      f"{name}/q_sum": np.float64(q.astype(np.float64).sum()),
+                      f"{name}/q_xor": np.bitwise_xor.reduce(q.view(np.uint32).ravel())})
+        print(f"  MAS case {name}: oracle C == reference core.pyx (t_x > t_y: raw-input backtrack)")
     np.savez_compressed(os.path.join(HERE, "mas_cases.npz"), **cases)
     print(f"wrote mas_cases.npz: {os.path.getsize(os.path.join(HERE, 'mas_cases.npz')) / 1024:.0f} KiB")
 
 
 if __name__ == "__main__":
     make_mas_cases()
+    if "--mas-only" in sys.argv:
+        sys.exit(0)
     make_model_case("Vanilla", 1234, "tiny_vanilla.npz")
     make_model_case("SE", 4321, "tiny_se.npz")
     make_model_case("PE", 777, "tiny_pe.npz")

@@ -60,7 +60,7 @@ def test_host_mas_twin_matches_core_pyx_vectors(golden_dir):
     L = ctypes.CDLL(os.path.join(REPO, "glow_tts_amd", "libglowtts_hip.so"))
     L.glowtts_mas_f32_host.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_int]
     d = np.load(os.path.join(golden_dir, "mas_cases.npz"))
-    for name in ["ragged", "ties", "square", "one_token", "x1000", "wide"]:
+    for name in ["ragged", "ties", "square", "one_token", "x1000", "wide", "more_tokens"]:
         for threads in (1, 3):
             v = d[f"{name}/value"].copy()
             tx, ty = np.ascontiguousarray(d[f"{name}/t_x"], np.int32), np.ascontiguousarray(d[f"{name}/t_y"], np.int32)
@@ -74,6 +74,17 @@ def test_host_mas_twin_matches_core_pyx_vectors(golden_dir):
     mask = torch.from_numpy(((np.arange(v.shape[1])[None, :, None] < tx[:, None, None]) & (np.arange(v.shape[2])[None, None, :] < ty[:, None, None])).astype(np.float64))
     p = maximum_path_host(v, mask)
     assert p.dtype == v.dtype and np.array_equal(p.numpy().astype(np.int32), d["ragged/path"].astype(np.int32))
+    # more tokens than frames (no monotonic alignment): as core.pyx behaves - nothing accumulated, backtrack over the raw inputs (oracle C,
+    # itself checked against the compiled core.pyx for such shapes, tests/golden/make_golden.py)
+    from oracle import mas_ref
+    rng = np.random.default_rng(3)
+    w = rng.normal(-100, 30, (2, 40, 17)).astype(np.float32)
+    txw, tyw = np.array([40, 31], np.int32), np.array([17, 9], np.int32)
+    w *= ((np.arange(40)[None, :, None] < txw[:, None, None]) & (np.arange(17)[None, None, :] < tyw[:, None, None]))
+    want, _ = mas_ref.maximum_path_c(w, txw, tyw, return_q=True)
+    w2, pw = w.copy(), np.zeros(w.shape, np.int32)
+    assert L.glowtts_mas_f32_host(w2.ctypes.data, pw.ctypes.data, txw.ctypes.data, tyw.ctypes.data, *w.shape, -1e9, 1) == 0
+    assert np.array_equal(pw, want) and np.array_equal(w2, w)
     bad = np.array([v.shape[1] + 1] * v.shape[0], np.int32)
     vv = d["ragged/value"].copy(); pp = np.zeros(vv.shape, np.int32)
     assert L.glowtts_mas_f32_host(vv.ctypes.data, pp.ctypes.data, bad.ctypes.data, ty.ctypes.data, *vv.shape, -1e9, 1) == -1      # GLOWTTS_E_ARG

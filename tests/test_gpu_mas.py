@@ -8,7 +8,7 @@ from oracle import mas_ref
 
 pytestmark = pytest.mark.gpu
 
-MAS_CASES = ["ragged", "ties", "square", "one_token", "x1000", "wide"]
+MAS_CASES = ["ragged", "ties", "square", "one_token", "x1000", "wide", "more_tokens"]
 
 
 def hip_mas(v, tx, ty, want_q=False):
@@ -51,6 +51,29 @@ def test_random_vs_oracle(Tx, Ty, B):
     assert np.array_equal(q.view(np.uint32), q_ref.view(np.uint32))
     for b in range(B):
         assert (idx[b, ty[b]:] == -1).all() and (idx[b, :ty[b]] == want[b, :, :ty[b]].argmax(0)).all()
+
+
+@pytest.mark.parametrize("Tx,Ty,B", [(5, 3, 2), (40, 17, 3), (130, 64, 2), (3, 1, 1), (200, 120, 2)])
+def test_more_tokens_than_frames_follows_the_reference(Tx, Ty, B):
+    """t_x > t_y: no monotonic alignment exists.  core.pyx then accumulates nothing (its column loops are empty) and backtracks over the raw
+    inputs; the oracle C restatement does the same and was checked against the compiled core.pyx for these shapes.  All three device entry
+    points and the host twin reproduce that path bit for bit; the scores stay the inputs."""
+    rng = np.random.default_rng(Tx * 77 + Ty)
+    v = rng.normal(-100, 30, (B, Tx, Ty)).astype(np.float32)
+    tx = np.full(B, Tx, np.int32); ty = np.full(B, Ty, np.int32)
+    if B > 1:
+        tx[1], ty[1] = Tx - 1, max(1, Ty - 1)                      # ragged, still more tokens than frames
+    mask = (np.arange(Tx)[None, :, None] < tx[:, None, None]) & (np.arange(Ty)[None, None, :] < ty[:, None, None])
+    v = (v * mask).astype(np.float32)
+    want, q_ref = mas_ref.maximum_path_c(v, tx, ty, return_q=True)
+    assert np.array_equal(q_ref, v)
+    path, idx, q = hip_mas(v, tx, ty, want_q=True)
+    assert np.array_equal(path, want) and np.array_equal(q, v)
+    path_t, _, _, _ = hip_mas_t(v, tx, ty)
+    assert np.array_equal(path_t, want)
+    from glow_tts_amd.monotonic_align import maximum_path_host
+    ph = maximum_path_host(v.copy(), mask.astype(np.float32))
+    assert np.array_equal(np.asarray(ph).astype(np.int32), want)
 
 
 def test_ties_and_sentinel_scale():

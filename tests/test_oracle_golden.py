@@ -8,7 +8,7 @@ from oracle import glowtts_ref as O
 from oracle import mas_ref
 from helpers import load_case, tiny_cfg
 
-MAS_CASES = ["ragged", "ties", "square", "one_token", "x1000", "wide"]
+MAS_CASES = ["ragged", "ties", "square", "one_token", "x1000", "wide", "more_tokens"]
 
 
 @pytest.mark.parametrize("name", MAS_CASES)
@@ -22,7 +22,8 @@ def test_mas_oracle_matches_reference_vectors(name, golden_dir):
         tx, ty = d[f"{name}/t_x"][b], d[f"{name}/t_y"][b]
         assert (path[b, :, :ty].sum(0) == 1).all() and path[b, :, ty:].sum() == 0 and path[b, tx:].sum() == 0
         idx = path[b, :, :ty].argmax(0)
-        assert idx[0] == 0 and idx[-1] == tx - 1 and (np.diff(idx) >= 0).all() and (np.diff(idx) <= 1).all()
+        assert idx[-1] == tx - 1 and (np.diff(idx) >= 0).all() and (np.diff(idx) <= 1).all()
+        assert idx[0] == 0 or tx > ty                         # (more tokens than frames: the walk cannot reach the first token)
 
 
 @pytest.mark.parametrize("name", ["ragged", "square", "one_token"])
