@@ -980,6 +980,9 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
     constexpr int SUB = T1 ? DMA1_CPS : TAPS;
     constexpr int NAT = T1 ? DMA1_CPS : 1;
     glowtts_conv_args p = pin;
+#ifdef GLOWTTS_ABL   // tools/conv_prologue.py: early exits that price the launch, the address set-up and the first fetch
+    if ((pin.flags >> 16) & 256) return;
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // scalar: unit indices, LDS bases and branches below are wave-uniform
     const int WMR = (blockDim.x >> 6) - nload, BM = WMR * 32; // compute waves (the last `nload` waves only issue DMAs)
@@ -1150,6 +1153,9 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
     // nst LDS stages: stage ss+1 .. ss+nst-1 are in flight while stage ss is multiplied (nst = 3: two ahead; nst = 2: one ahead, two
     // thirds of the LDS, so that a second workgroup - of another kernel on another stream - can be co-resident on the CU)
     const int ahead = nst - 1;                                // (loader waves: the host passes nst = 2)
+#ifdef GLOWTTS_ABL
+    if ((pin.flags >> 16) & 512) { if (uoff[0] == 0x7fffffffu && uoff[MAXU - 1] == 1u && nmine == 77) p.out0[0] = 1.f; return; }
+#endif
     if (!nload) StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 0, ssmap(0)); });
     if (!nload && ahead > 1 && NSS > 1) StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 1, ssmap(1)); });
     TL(1);
@@ -1158,6 +1164,9 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
         // this wave's DMAs of stage ss have landed (those of later stages may still fly); after the barrier so have everyone's,
         // and every wave is done reading the LDS stage of ss-1, which is refilled with stage ss+ahead during the MFMAs below
         wait_keep((ahead > 1 && ss + 1 < NSS) ? nmine : 0);
+#ifdef GLOWTTS_ABL
+        if ((pin.flags >> 16) & 1024) return;
+#endif
         TL(3 + 3 * ss);
         const bool more = !nload && ss + ahead < NSS;
         const int nxt = cur == 0 ? nst - 1 : cur - 1;         // (ss + ahead) % nst
