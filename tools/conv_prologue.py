@@ -7,7 +7,7 @@ import torch
 from glow_tts_amd import ops, _lib
 B, T, H, k = 32, 400, 192, 5
 R = B * (T + 4)
-lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libconv_abl.so"))
+lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", os.environ.get("ABL_LIB", "libconv_abl.so")))
 lib.glowtts_conv_cl.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 a = torch.randn(R, H, device="cuda").to(torch.bfloat16)
 w = torch.randn(2 * H, H, k, device="cuda") / (H * k) ** 0.5
