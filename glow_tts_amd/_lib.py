@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libglowtts_hip.so")
 if os.environ.get("GLOWTTS_LIB_PATH"):
     LIB_PATH = os.environ["GLOWTTS_LIB_PATH"]
 _lib = None
+ABI_VERSION = 2                          # GLOWTTS_ABI_VERSION of include/glowtts_hip.h
 
 c_int, c_float, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -30,8 +31,11 @@ def lib():
             raise GlowTTSHipError(
                 f"{LIB_PATH} not found: build it with `make -C glow_tts_amd/csrc` "
                 "(or __graft_entry__.build()); the HIP path has no CPU fallback")
-        _lib = ctypes.CDLL(LIB_PATH)
-        _declare(_lib)
+        L = ctypes.CDLL(LIB_PATH)
+        _declare(L)
+        if L.glowtts_abi_version() != ABI_VERSION:       # struct layouts in decoder.py mirror include/glowtts_hip.h of exactly this version
+            raise GlowTTSHipError(f"{LIB_PATH} has ABI version {L.glowtts_abi_version()}, this package binds version {ABI_VERSION}: rebuild it")
+        _lib = L
     return _lib
 
 

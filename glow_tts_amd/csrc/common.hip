@@ -6,7 +6,7 @@
 #include "../../include/glowtts_hip.h"
 #include "launch_log.h"
 
-extern "C" int glowtts_abi_version(void) { return 1; }
+extern "C" int glowtts_abi_version(void) { return GLOWTTS_ABI_VERSION; }
 
 extern "C" int glowtts_device_arch(char* buf, int buflen)
 {

@@ -46,6 +46,9 @@ int coupling_net(const Ctx& c, const float* xsrc, float* xdst, bool reverse, boo
     const glowtts_flow_params* p = c.p; const glowtts_flow_acts* A = c.a;
     const int H = c.H, L = c.d->L;
     const bool bf = c.d->act_bf16 != 0;          // hs / gates stored as bf16
+    // the whole network in ONE launch when the caller packed this flow's weight image (wavenet_fused.hip; the image's Res_Skip slabs are
+    // PAIR-packed, which the per-conv launches below do not read: no silent fallback from here)
+    if (p->wn_img) return glowtts_wavenet_fwd(c.d, p, A, xsrc, xdst, reverse ? 1 : 0, keep ? 1 : 0, c.s);
     // Start: h0 = (W x_a + b) * mask                                         Modules.py:791
     {
         glowtts_conv_args a = base_args(c, p->start, 1);
@@ -165,8 +168,11 @@ extern "C" int glowtts_flow_forward(const glowtts_flow_dims* d, const glowtts_fl
 extern "C" int glowtts_flow_inverse(const glowtts_flow_dims* d, const glowtts_flow_params* p, const glowtts_flow_acts* a, void* stream)
 {
     CHECK(check_dims(d));
-    if (!p || !a || !a->xin || !a->xmid || !a->xout || !a->rowmask || !a->skip || !a->hs[0] || !a->hs[1] || !a->gates[0]) return GLOWTTS_E_ARG;
-    if (d->act_bf16 && !a->acts[0]) return GLOWTTS_E_ARG;
+    if (!p || !a || !a->xin || !a->xmid || !a->xout || !a->rowmask) return GLOWTTS_E_ARG;
+    if (!p->wn_img) {                            // scratch of the per-conv launches (the fused kernel keeps all of it on chip)
+        if (!a->skip || !a->hs[0] || !a->hs[1] || !a->gates[0]) return GLOWTTS_E_ARG;
+        if (d->act_bf16 && !a->acts[0]) return GLOWTTS_E_ARG;
+    }
     const Ctx c = make_ctx(d, p, a, stream);
     // reversed layer order (Modules.py:664): coupling^-1, then inv-1x1^-1, then ActNorm^-1
     CHECK(copy_half(a->xout, a->xmid, c.R, d->C, c.C2, stream));

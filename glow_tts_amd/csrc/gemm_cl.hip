@@ -31,56 +31,9 @@
 #include "../../include/glowtts_hip.h"
 #include "tunable.h"
 #include "launch_log.h"
+#include "device_common.h"
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-typedef uint32_t Chunk16 __attribute__((ext_vector_type(4)));      // one 16-byte LDS slot (native vector: stays in VGPRs)
-
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    bf16x2 v;
-    v[0] = (__bf16)lo;
-    v[1] = (__bf16)hi;
-    return *reinterpret_cast<uint32_t*>(&v);
-}
-
-__device__ __forceinline__ int swz(int row, int q) { return row * 64 + ((q ^ ((row >> 2) & 3)) << 4); }
-
-// EXACT = f32 mode: libm-grade transcendental functions; bf16 mode: hardware exp (v_exp_f32)
-template <bool EXACT> __device__ __forceinline__ float exp_(float x) { return EXACT ? expf(x) : __expf(x); }
-template <bool EXACT> __device__ __forceinline__ float rcp_(float x) { return EXACT ? 1.f / x : __builtin_amdgcn_rcpf(x); }
-template <bool EXACT> __device__ __forceinline__ float sigmoid_(float x) { return rcp_<EXACT>(1.f + exp_<EXACT>(-x)); }
-template <bool EXACT> __device__ __forceinline__ float tanh_(float x) {
-    if (EXACT) return tanhf(x);
-    const float e = __expf(2.f * x);          // tanh(x) = 1 - 2 / (exp(2x) + 1)
-    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
-}
-
-typedef __amdgpu_buffer_rsrc_t Rsrc;
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-
-// Dropout of the WaveNet gate pre-activations (Modules.py:862).  The GATE (forward) and DGATE (backward) epilogues must draw the
-// same mask, and integer multiplies are quarter rate, so: one key per row (2 multiplies), one 32-bit draw per (row, channel
-// pair) (1 multiply) whose low / high 16 bits decide the tanh / the sigmoid channel.  keep <=> half >= thr, thr = round(p * 2^16);
-// kept values are scaled by 2^16 / (2^16 - thr), the exact inverse keep rate of that threshold.
-__device__ __forceinline__ uint32_t drop_threshold(float p) { return p > 0.f ? (uint32_t)(p * 65536.f + 0.5f) : 0u; }
-__device__ __forceinline__ float drop_inv_keep(uint32_t thr) { return 65536.f / (65536.f - (float)thr); }
-__device__ __forceinline__ uint32_t drop_rowkey(uint32_t seed, uint32_t r) { uint32_t x = r * 0x9E3779B1u + seed; x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; return x; }
-__device__ __forceinline__ uint32_t drop_colkey(uint32_t j) { return (j + 1u) * 0x27D4EB2Fu; }
-__device__ __forceinline__ uint32_t drop_draw(uint32_t rowkey, uint32_t colkey) { const uint32_t x = (rowkey ^ colkey) * 0xC2B2AE35u; return x ^ (x >> 16); }
-__device__ __forceinline__ float drop_keep_lo(uint32_t d, uint32_t thr, float ik) { return (d & 0xFFFFu) >= thr ? ik : 0.f; }
-__device__ __forceinline__ float drop_keep_hi(uint32_t d, uint32_t thr, float ik) { return (d >> 16) >= thr ? ik : 0.f; }
-
-// dropout keep decision of the LINEAR epilogue: counter hash (murmur3 finalizer) of (seed, element id) -> 24-bit uniform
-__device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t id, float p, float inv_keep) {
-    uint32_t h = id * 0x9E3779B1u + seed;
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    return ((h >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
-}
 
 // ------------------------------------------------------------------------------------------------
 // weight packing
@@ -113,12 +66,14 @@ __device__ __forceinline__ float pack_element(const float* __restrict__ w, long 
 
 template <typename CT>
 __global__ void pack_weight_kernel(const float* __restrict__ w, CT* __restrict__ out, int O, int I, int taps,
-                                   int transpose, int perm, int perm_h, int N, int K, int npad, int kchunks)
+                                   int transpose, int perm, int perm_h, int N, int K, int npad, int kchunks,
+                                   int inner, long outer_stride, long inner_stride /* bytes; inner = 0: images back to back */)
 {
     constexpr int KC = 64 / sizeof(CT);
     const long total = (long)taps * kchunks * npad * KC;
     w += (long)blockIdx.y * O * I * taps;          // batch of independent weights
-    out += (long)blockIdx.y * total;
+    if (inner > 0) out = reinterpret_cast<CT*>(reinterpret_cast<unsigned char*>(out) + (blockIdx.y / inner) * outer_stride + (blockIdx.y % inner) * inner_stride);
+    else out += (long)blockIdx.y * total;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
         out[i] = (CT)pack_element<KC>(w, i, O, I, taps, transpose, perm, perm_h, N, K, npad, kchunks);
 }
@@ -1671,8 +1626,27 @@ int launch_prec(const glowtts_conv_args& a, hipStream_t s)
 
 }  // namespace
 
+namespace {
+int pack_batched(const float* w, int batch, int O, int I, int taps, int transpose, int perm, int perm_h, int precision, void* packed,
+                 int* npad_out, int* kchunks_out, int inner, long outer_stride, long inner_stride, void* stream);
+}
+
 extern "C" int glowtts_pack_weight_batched(const float* w, int batch, int O, int I, int taps, int transpose, int perm, int perm_h,
                                            int precision, void* packed, int* npad_out, int* kchunks_out, void* stream)
+{
+    return pack_batched(w, batch, O, I, taps, transpose, perm, perm_h, precision, packed, npad_out, kchunks_out, 0, 0, 0, stream);
+}
+
+extern "C" int glowtts_pack_weight_strided(const float* w, int batch, int inner, int O, int I, int taps, int transpose, int perm, int perm_h,
+                                           int precision, void* packed, int64_t outer_stride, int64_t inner_stride, void* stream)
+{
+    if (inner < 1 || !packed || (outer_stride & 15) || (inner_stride & 15)) return GLOWTTS_E_ARG;
+    return pack_batched(w, batch, O, I, taps, transpose, perm, perm_h, precision, packed, nullptr, nullptr, inner, (long)outer_stride, (long)inner_stride, stream);
+}
+
+namespace {
+int pack_batched(const float* w, int batch, int O, int I, int taps, int transpose, int perm, int perm_h, int precision, void* packed,
+                 int* npad_out, int* kchunks_out, int inner, long outer_stride, long inner_stride, void* stream)
 {
     if (batch < 1 || O < 1 || I < 1 || taps < 1 || taps > MAX_TAPS || (precision != GLOWTTS_F32 && precision != GLOWTTS_BF16)) return GLOWTTS_E_ARG;
     if (perm == GLOWTTS_PERM_PAIR && (perm_h < 1 || 2 * perm_h != O)) return GLOWTTS_E_ARG;
@@ -1691,11 +1665,14 @@ extern "C" int glowtts_pack_weight_batched(const float* w, int batch, int O, int
     const long total = (long)taps * kchunks * npad * KC;
     const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
     if (precision == GLOWTTS_BF16)
-        hipLaunchKernelGGL(pack_weight_kernel<__bf16>, dim3(blocks, batch), dim3(256), 0, s, w, static_cast<__bf16*>(packed), O, I, taps, transpose, perm, perm_h, N, kchunks * KC, npad, kchunks);
+        hipLaunchKernelGGL(pack_weight_kernel<__bf16>, dim3(blocks, batch), dim3(256), 0, s, w, static_cast<__bf16*>(packed), O, I, taps, transpose, perm, perm_h, N, kchunks * KC, npad, kchunks,
+                           inner, outer_stride, inner_stride);
     else
-        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks, batch), dim3(256), 0, s, w, static_cast<float*>(packed), O, I, taps, transpose, perm, perm_h, N, kchunks * KC, npad, kchunks);
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks, batch), dim3(256), 0, s, w, static_cast<float*>(packed), O, I, taps, transpose, perm, perm_h, N, kchunks * KC, npad, kchunks,
+                           inner, outer_stride, inner_stride);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
+}  // namespace
 
 extern "C" int glowtts_pack_job_init(glowtts_pack_job* job, const float* w, int O, int I, int taps, int transpose, int perm, int perm_h,
                                      int precision, void* packed, int block0, int* blocks_out, int64_t* bytes_out)

@@ -33,7 +33,7 @@ class FlowParams(ctypes.Structure):
                 ("start", Packed), ("in_", Packed * MAXL), ("rs", Packed * MAXL), ("end", Packed),
                 ("start_t", Packed), ("in_t", Packed * MAXL), ("rs_t", Packed * MAXL), ("end_t", Packed),
                 ("b_start", c_void_p), ("b_in", c_void_p * MAXL), ("b_rs", c_void_p * MAXL), ("b_end", c_void_p),
-                ("cond", c_void_p), ("ldcond", c_i64), ("cond_rows", c_int)]
+                ("cond", c_void_p), ("ldcond", c_i64), ("cond_rows", c_int), ("wn_img", c_void_p), ("wn_img_t", c_void_p)]
 
 
 class FlowActs(ctypes.Structure):
@@ -82,6 +82,8 @@ def _L():
         L.glowtts_weightnorm_bwd.argtypes = [c_void_p] * 6 + [c_i64, c_int, c_void_p]
         L.glowtts_decoder_logdet.argtypes = [c_void_p, c_i64] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]
         L.glowtts_decoder_param_grads.argtypes = [c_void_p] * 7 + [c_int] * 4 + [c_void_p]
+        L.glowtts_wavenet_image_bytes.argtypes = [c_int, c_int, ctypes.POINTER(c_i64)]
+        L.glowtts_wavenet_pack_images.argtypes = [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 3
         _declared = True
     return L
 
@@ -106,7 +108,9 @@ TAIL = {"defer": False, "pending": []}
 #   wgrad_wide: 16-byte staging items in the weight-gradient kernel; fuse_coupling_bwd: the next flow's coupling backward rides in the
 #   ActNorm / 1x1 backward pass; wgrad_split: weight gradients in n segments on a second stream (1 = one grouped launch per class);
 #   act_bf16: WaveNet state / gates / gate gradients stored as bf16 in bf16 precision
-TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True}
+#   fused_wn: the coupling network of a flow (Start .. End + coupling) as ONE launch (csrc/wavenet_fused.hip) where its shape contract holds
+TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True}
+WN_SLAB = 24576                          # GLOWTTS_WN_SLAB_BYTES
 TAIL_STACKS = ("start_g", "start_v", "start_b", "rs_g", "rs_v", "rs_b", "rsl_g", "rsl_v", "rsl_b", "end_w", "end_b")
 
 
@@ -205,6 +209,22 @@ class PackedBatch:
         return Packed(self.data.data_ptr() + i * self.stride, self.npad, self.kchunks)
 
 
+class ImageSlices:
+    """The convs of one weight class inside the per-flow weight images of the fused coupling-network kernel (same interface as PackedBatch):
+    element i = (flow i // inner, layer i % inner) starts at flow * flow_stride + offset + layer * layer_stride."""
+
+    def __init__(self, img, flow_stride, offset, inner, layer_stride, npad, kchunks):
+        self.img, self.flow_stride, self.offset, self.inner, self.layer_stride, self.npad, self.kchunks = img, flow_stride, offset, inner, layer_stride, npad, kchunks
+
+    def at(self, i):
+        return Packed(self.img.data_ptr() + (i // self.inner) * self.flow_stride + self.offset + (i % self.inner) * self.layer_stride, self.npad, self.kchunks)
+
+
+def fused_wn_supported(cfg):
+    """Shape contract of glowtts_wavenet_fwd (include/glowtts_hip.h): the reference's default decoder."""
+    return bool(TUNE["fused_wn"] and cfg.act_bf16 and cfg.H == 192 and cfg.k == 5 and 1 <= cfg.L <= 4 and 64 < cfg.C // 2 <= 96 and cfg.C % 8 == 0)
+
+
 class DecoderConfig:
     """Shapes of the decoder, from Hyper_Parameters.yaml (Decoder.*, Sound.Mel_Dim)."""
 
@@ -236,14 +256,35 @@ class _Prepared:
         self.winfo = torch.empty(F_, 36, device=dev)
         _lib.check(L.glowtts_inv1x1_prepare(_lib.ptr(W["inv_w"].contiguous()), _lib.ptr(self.winfo), F_, _lib.stream()), "inv1x1_prepare")
         w_in = W["w_in"].reshape(F_ * Lw, 2 * H, H, cfg.k)
-        self.pk = {
-            "start": PackedBatch(W["w_start"], False, ops.PERM_NONE, 0, P),
-            "in": PackedBatch(w_in, False, ops.PERM_PAIR, H, P),
-            "rs_last": PackedBatch(W["w_rs_last"], False, ops.PERM_NONE, 0, P),
-            "end": PackedBatch(W["w_end"], False, ops.PERM_PAIR, C // 2, P),
-        }
-        if Lw > 1:
-            self.pk["rs"] = PackedBatch(W["w_rs"].reshape(F_ * (Lw - 1), 2 * H, H, 1), False, ops.PERM_NONE, 0, P)
+        self.wn_img = None
+        if fused_wn_supported(cfg):
+            # one image per flow holding every forward weight of its coupling network as 24-KiB slabs (glowtts_wavenet_pack_images)
+            nb = c_i64(0)
+            _lib.check(L.glowtts_wavenet_image_bytes(Lw, 0, ctypes.byref(nb)), "wavenet_image_bytes")
+            nb = nb.value
+            self.wn_img = torch.empty(F_, nb, dtype=torch.uint8, device=dev)
+            _lib.check(L.glowtts_wavenet_pack_images(_lib.ptr(W["w_start"].contiguous()), _lib.ptr(W["w_in"].contiguous()),
+                                                     _lib.ptr(W["w_rs"].contiguous()) if Lw > 1 else None, _lib.ptr(W["w_rs_last"].contiguous()),
+                                                     _lib.ptr(W["w_end"].contiguous()), F_, Lw, C // 2, _lib.ptr(self.wn_img), None, _lib.stream()),
+                       "wavenet_pack_images")
+            S = WN_SLAB
+            self.pk = {
+                "start": ImageSlices(self.wn_img, nb, 0, 1, 0, 192, 3),
+                "in": ImageSlices(self.wn_img, nb, 2 * S, Lw, 36 * S, 2 * H, H // 32),
+                "rs_last": ImageSlices(self.wn_img, nb, (36 * (Lw - 1) + 32) * S, 1, 0, H, H // 32),
+                "end": ImageSlices(self.wn_img, nb, (36 * (Lw - 1) + 35) * S, 1, 0, 192, H // 32),
+            }
+            if Lw > 1:
+                self.pk["rs"] = ImageSlices(self.wn_img, nb, 32 * S, Lw - 1, 36 * S, 2 * H, H // 32)       # (PAIR-packed: read by the fused kernel only)
+        else:
+            self.pk = {
+                "start": PackedBatch(W["w_start"], False, ops.PERM_NONE, 0, P),
+                "in": PackedBatch(w_in, False, ops.PERM_PAIR, H, P),
+                "rs_last": PackedBatch(W["w_rs_last"], False, ops.PERM_NONE, 0, P),
+                "end": PackedBatch(W["w_end"], False, ops.PERM_PAIR, C // 2, P),
+            }
+            if Lw > 1:
+                self.pk["rs"] = PackedBatch(W["w_rs"].reshape(F_ * (Lw - 1), 2 * H, H, 1), False, ops.PERM_NONE, 0, P)
         if need_bwd:
             self.pk.update({
                 "start_t": PackedBatch(W["w_start"], True, ops.PERM_NONE, 0, P),
@@ -266,6 +307,7 @@ class _Prepared:
             p.end = self.pk["end"].at(f)
             p.b_start = W["b_start"][f].data_ptr()
             p.b_end = W["b_end"][f].data_ptr()
+            p.wn_img = self.wn_img[f].data_ptr() if self.wn_img is not None else None
             for l in range(Lw):
                 p.in_[l] = self.pk["in"].at(f * Lw + l)
                 p.b_in[l] = W["b_in"][f, l].data_ptr()

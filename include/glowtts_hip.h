@@ -20,8 +20,10 @@ extern "C" {
 #define GLOWTTS_OK            0
 #define GLOWTTS_E_ARG        -1   /* bad argument / unsupported size */
 #define GLOWTTS_E_LAUNCH     -2   /* hip launch error */
+#define GLOWTTS_ABI_VERSION    2
 
-/* Library / device identification.  Returns the ABI version (currently 1). */
+/* Library / device identification.  Returns the ABI version (currently 2: glowtts_flow_params grew wn_img / wn_img_t; round 2's additions to
+ * glowtts_mle_loss_bwd, glowtts_flow_params.cond_rows and glowtts_flow_grads.pitch_rows belong to version 2 as well). */
 int glowtts_abi_version(void);
 /* Writes the gfx arch string of device 0 into buf (host pointer).  0 on success. */
 int glowtts_device_arch(char *buf, int buflen);
@@ -125,6 +127,11 @@ int glowtts_pack_weight_multi(const glowtts_pack_job *dev_jobs, int njobs, int t
 /* `batch` independent weights of identical shape, w [batch][O][I][taps] -> packed [batch][taps*kchunks*npad*64 bytes] */
 int glowtts_pack_weight_batched(const float *w, int batch, int O, int I, int taps, int transpose, int perm, int perm_h,
                                 int precision, void *packed, int *npad_out, int *kchunks_out, void *stream);
+
+/* The same with a two-level destination: weight b (0 <= b < batch) is written at packed + (b / inner) * outer_stride + (b % inner) *
+ * inner_stride (bytes) - how glowtts_wavenet_pack_images places every conv of a flow inside that flow's weight image. */
+int glowtts_pack_weight_strided(const float *w, int batch, int inner, int O, int I, int taps, int transpose, int perm, int perm_h,
+                                int precision, void *packed, int64_t outer_stride, int64_t inner_stride, void *stream);
 
 #define GLOWTTS_APRO_NONE    0
 #define GLOWTTS_APRO_PAIRMUL 1  /* a[r][c] = A[r][2c] * A[r][2c+1]   (tanh*sigmoid gates, Modules.py:885-887) */
@@ -340,6 +347,8 @@ typedef struct glowtts_flow_params {
     const float *b_start, *b_in[GLOWTTS_MAX_WN_LAYERS], *b_rs[GLOWTTS_MAX_WN_LAYERS], *b_end; /* biases, original order */
     const float *cond; int64_t ldcond;    /* optional conditioning [B][ldcond]; layer l reads cond + l*2H   Modules.py:863-866 */
     int cond_rows;                        /* 1: cond is per ROW, [R][ldcond] (forward / inverse only; GR-mode pitch, Modules.py:867-869) */
+    const void *wn_img, *wn_img_t;        /* optional (ABI 2): this flow's weight images for the fused coupling-network kernels
+                                           * (glowtts_wavenet_pack_images); NULL: the per-conv launches above are used */
 } glowtts_flow_params;
 
 typedef struct glowtts_flow_acts {        /* rows tensors, R = B*(T+2*PAD) rows */
@@ -392,6 +401,33 @@ int glowtts_flow_inverse(const glowtts_flow_dims *d, const glowtts_flow_params *
 /* backward of glowtts_flow_forward */
 int glowtts_flow_backward(const glowtts_flow_dims *d, const glowtts_flow_params *p, const glowtts_flow_acts *a,
                           const glowtts_flow_grads *g, void *stream);
+/* ------------------------------------------------------------------------------------------
+ * Fused coupling network (Modules.py:785-806 Affine_Coupling_Layer.forward with its WaveNet, :858-887): Start conv, L x [In_l k = 5 +
+ * dropout + conditioning + tanh * sigmoid, Res_Skip_l + residual / skip], End conv + affine coupling in ONE launch per flow - one
+ * persistent workgroup per 64-row window (64 - 4 (L - 1) valid rows, recomputed halo), the WaveNet state in LDS, every weight of the flow
+ * streamed as 24-KiB slabs through an LDS ring by LDS-DMA.  bf16 precision with act_bf16, H = 192, k = 5, L <= 4, 64 < C/2 <= 96 (the
+ * reference's default decoder); anything else returns GLOWTTS_E_ARG and the caller uses the per-conv launches.
+ * Weight image of one flow (forward): slabs of GLOWTTS_WN_SLAB_BYTES = [384 n][64 B]:
+ *   [Start: 2 slabs][layer l: In_l 30 slabs = (tap, K chunk), Res_Skip_l 6 slabs (PAIR-packed: residual | skip per 32 channels; last
+ *   layer: 3 slabs of two K chunks x 192 columns)][End: 3 slabs]  = 36 L + 2 slabs. */
+#define GLOWTTS_WN_SLAB_BYTES 24576
+#define GLOWTTS_WN_FUSED_MAX_LAYERS 4
+int glowtts_wavenet_image_bytes(int L, int transposed, int64_t *bytes_out /* host */);
+/* Packs the effective weights of F flows (stacked fp32, torch Conv1d layouts: w_start [F][H][C2][1], w_in [F][L][2H][H][5], w_rs
+ * [F][L-1][2H][H][1] (NULL when L = 1), w_rs_last [F][H][H][1], w_end [F][2 C2][H][1]) into F forward images (img_fwd) and, when
+ * img_bwd != NULL, F images of the transposed weights for the fused backward; image f starts at f * glowtts_wavenet_image_bytes(). */
+int glowtts_wavenet_pack_images(const float *w_start, const float *w_in, const float *w_rs, const float *w_rs_last, const float *w_end,
+                                int F, int L, int C2, void *img_fwd, void *img_bwd, void *stream);
+/* xsrc [R][C]: channels [0, C/2) = x_a (WaveNet input), [C/2, C) = x_b; writes x_b' = m + exp(logs) x_b (reverse: (x_b - m) exp(-logs)),
+ * masked, to xdst[r][C/2 ...].  keep != 0: fills a->hs / gates / acts / skip / outs (the activations glowtts_flow_backward reads).
+ * Needs p->wn_img. */
+int glowtts_wavenet_fwd(const glowtts_flow_dims *d, const glowtts_flow_params *p, const glowtts_flow_acts *a,
+                        const float *xsrc, float *xdst, int reverse, int keep, void *stream);
+
+/* Diagnostics (no reference counterpart): on != 0 makes the fused kernels wait conservatively (drain their own stores) at every slab instead
+ * of with exact operation counts; results must be bit-identical either way (tests/test_gpu_wavenet_fused.py). */
+void glowtts_wavenet_debug_safe_waits(int on);
+
 /* per-utterance column sums: out[b][n] = sum over the rows of utterance b of x[r][col(n)]  (conditioning grads) */
 int glowtts_utt_colsum(const float *x, int64_t ldx, float *out, int64_t ldout, int B, int rows_per_utt, int n,
                        int perm, int perm_h, void *stream);

@@ -1,0 +1,160 @@
+"""GPU parity of the FUSED coupling-network kernel (csrc/wavenet_fused.hip: Start conv .. End conv + affine coupling of a flow in one
+launch, Modules.py:785-806 / 858-887) against the per-conv launches it replaces, at the benchmarked width (C = 160, 192 channels, 4 layers,
+k = 5).  Both paths round the same tensors to bf16 (WaveNet state, gates, tanh * sigmoid) and differ only in fp32 accumulation order, so a
+kept bf16 tensor may differ by an occasional one-ulp flip and what follows from it; a halo / tile-seam bug would show as O(1) errors on the
+rows next to a multiple of the 52-row tile.  The oracle comparisons of the fused path itself are tests/test_gpu_decoder_fullwidth.py and
+tests/test_gpu_fullsize.py (which run it by default)."""
+import pytest
+import torch
+
+from helpers import full_width_state, launch_counts, launch_reset
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n_flows, lengths, tm, spk_dim=0, seed=0):
+    from glow_tts_amd import decoder as D
+    g = torch.Generator().manual_seed(seed)
+    cfg, sd = full_width_state(n_flows, g, spk_dim=spk_dim)
+    dc = D.DecoderConfig(cfg.mel_dim, cfg.n_flows, cfg.n_squeeze, cfg.n_split, cfg.wn_channels, cfg.wn_layers, cfg.wn_kernel, 1)
+    P = {k: v.cuda() for k, v in sd.items()}
+    B = len(lengths)
+    mels = (torch.randn(B, 80, tm, generator=g) * 1.5).clamp(-4, 4).cuda()
+    ml = torch.tensor(lengths).cuda()
+    spk = None
+    if spk_dim:
+        spk = torch.randn(B, spk_dim, generator=g)
+        spk = (spk / spk.norm(dim=1, keepdim=True)).cuda()
+    W = dict(zip(D.WEIGHT_KEYS, [w.contiguous() for w in D.stack_decoder_weights(P, dc)]))
+    cond = D.conditioning(P, dc, speakers=spk) if spk is not None else None
+    return D, dc, W, mels, ml, cond
+
+
+def _forward(D, dc, W, mels, ml, cond, fused, drop_p=0.0, seed=None):
+    D.TUNE["fused_wn"] = fused
+    try:
+        with torch.no_grad():
+            prep = D._Prepared(dc, W, need_bwd=False, cond=cond)
+            launch_reset()
+            z, logdet, buf, rowmask, T, _ = D._run_forward(dc, prep, mels, ml, drop_p, seed)
+            torch.cuda.synchronize()
+            return z, logdet, buf, rowmask, launch_counts()
+    finally:
+        D.TUNE["fused_wn"] = True
+
+
+def _outs_columns(c2=80):
+    """Columns of the kept (m, logs) buffer: packed column p * 64 + h * 32 + j holds half h (0 = m, 1 = logs) of channel p * 32 + j < c2."""
+    m = [p * 64 + j for p in range(3) for j in range(32) if p * 32 + j < c2]
+    return torch.tensor(m, device="cuda"), torch.tensor([c + 32 for c in m], device="cuda")
+
+
+def _close(a, b, what, rowmask=None, atol=0.0, frac=0.0, big=None):
+    """|a - b| <= atol everywhere except on at most `frac` of the elements (bf16 one-ulp flips), where it stays <= big."""
+    a, b = a.float(), b.float()
+    if rowmask is not None:
+        m = rowmask.view(-1, *([1] * (a.dim() - 1)))
+        a, b = a * m, b * m
+    d = (a - b).abs()
+    bad = (d > atol).float().mean().item()
+    assert bad <= frac, (what, "fraction above atol", bad, "max", d.max().item())
+    if big is not None:
+        assert d.max().item() <= big, (what, d.max().item())
+
+
+@pytest.mark.parametrize("lengths,tm", [([640, 522, 240, 2], 640), ([800] * 3, 800), ([104], 104), ([2], 2), ([422, 36, 36, 36, 36, 800], 800)])
+def test_fused_forward_matches_per_conv_launches(lengths, tm):
+    D, dc, W, mels, ml, _ = _setup(3, lengths, tm, seed=11)
+    zf, ldf, bf, rm, cf = _forward(D, dc, W, mels, ml, None, True)
+    zu, ldu, bu, _, cu = _forward(D, dc, W, mels, ml, None, False)
+    assert cf.get("wn_fwd<nodrop>", 0) == 3 and not any(k.startswith("conv_dma") or k.startswith("conv_chain") for k in cf), cf
+    assert any(k.startswith("conv_chain<RESSKIP,COUPLE>") for k in cu) and not any(k.startswith("wn_fwd") for k in cu), cu
+    # kept activations of flow 0 see identical inputs: only accumulation-order noise and its one-ulp consequences
+    _close(bf.hs[0, 0], bu.hs[0, 0], "h0", rm, atol=0.0, frac=2e-3, big=0.05)
+    for l in range(4):
+        _close(bf.gates[0, l], bu.gates[0, l], f"gates{l}", rm, atol=1e-6, frac=2e-2 * (l + 1), big=0.05)
+        _close(bf.actp[0, l], bu.actp[0, l], f"acts{l}", rm, atol=1e-6, frac=2e-2 * (l + 1), big=0.05)
+        _close(bf.hs[0, l], bu.hs[0, l], f"hs{l}", rm, atol=1e-6, frac=2e-2 * (l + 1), big=0.1)
+    _close(bf.skip[0], bu.skip[0], "skip", rm, atol=2e-2, frac=1e-3, big=0.2)
+    cm, cl = _outs_columns()                  # PAIR-packed (m | logs) per 32 channels; the pad columns are never written
+    _close(bf.outs[0][:, cm], bu.outs[0][:, cm], "m", rm, atol=5e-3, frac=2e-3, big=0.05)
+    _close(bf.outs[0][:, cl], bu.outs[0][:, cl], "logs", rm, atol=5e-3, frac=2e-3, big=0.05)
+    # pad rows / masked frames are exact zeros in both
+    assert (bf.x[1] * (1 - rm).unsqueeze(1)).abs().max() == 0
+    # end to end
+    valid = (torch.arange(tm, device="cuda")[None, :] < (ml // 2 * 2)[:, None]).unsqueeze(1)
+    # (after three flows the one-ulp flips of 36 bf16-stored tensors have spread: both paths sit equally far from the fp32 oracle, whose bar for
+    #  either is 0.1 in tests/test_gpu_decoder_fullwidth.py)
+    assert ((zf - zu) * valid).abs().max() <= 0.2, ((zf - zu) * valid).abs().max()
+    assert (((zf - zu) * valid) ** 2).mean().sqrt() <= 5e-3 * ((zu * valid) ** 2).mean().sqrt()
+    assert ((ldf - ldu).abs() <= 2e-3 * ldu.abs() + 0.05).all(), (ldf, ldu)
+    # tile seams: the error next to the 52-row tile boundaries is of the same size as elsewhere
+    R = bf.x.shape[1]
+    err = ((bf.x[1] - bu.x[1]).abs().max(dim=1).values * rm)
+    seam = torch.zeros(R, dtype=torch.bool, device="cuda")
+    for k in range(0, R, 52):
+        seam[max(k - 2, 0):k + 2] = True
+    if seam.any() and (~seam).any() and err[~seam].max() > 0:
+        assert err[seam].max() <= 4 * err[~seam].max() + 1e-3, (err[seam].max().item(), err[~seam].max().item())
+
+
+def test_fused_forward_with_speaker_conditioning_and_dropout():
+    D, dc, W, mels, ml, cond = _setup(2, [640, 300, 64, 10], 640, spk_dim=256, seed=5)
+    seed = torch.tensor([12345], device="cuda", dtype=torch.int32)
+    for drop in (0.0, 0.3):
+        zf, ldf, bf, rm, cf = _forward(D, dc, W, mels, ml, cond, True, drop, seed if drop else None)
+        zu, ldu, bu, _, _ = _forward(D, dc, W, mels, ml, cond, False, drop, seed if drop else None)
+        assert sum(n for k, n in cf.items() if k.startswith("wn_fwd<")) == 2, cf
+        for l in range(4):      # same dropout masks: a mismatch would zero ~30 % of the gates in one path only
+            _close(bf.gates[0, l], bu.gates[0, l], f"gates{l} drop={drop}", rm, atol=1e-6, frac=2e-2 * (l + 1), big=0.05)
+        valid = (torch.arange(640, device="cuda")[None, :] < (ml // 2 * 2)[:, None]).unsqueeze(1)
+        assert ((zf - zu) * valid).abs().max() <= 0.2
+
+
+@pytest.mark.parametrize("lengths,tm", [([400, 222, 8], 400), ([2074] * 2, 2074)])
+def test_fused_inverse_matches_per_conv_launches(lengths, tm):
+    D, dc, W, mels, ml, _ = _setup(3, lengths, tm, seed=3)
+    z = torch.randn(len(lengths), 80, tm, device="cuda") * 0.6
+    outs = []
+    for fused in (True, False):
+        D.TUNE["fused_wn"] = fused
+        try:
+            with torch.no_grad():
+                launch_reset()
+                outs.append(D.decoder_inverse(dc, W, z, ml))
+                torch.cuda.synchronize()
+                c = launch_counts()
+                assert (sum(n for k, n in c.items() if k.startswith("wn_fwd<")) == 3) == fused, c
+        finally:
+            D.TUNE["fused_wn"] = True
+    valid = (torch.arange(outs[0].shape[2], device="cuda")[None, :] < (ml // 2 * 2)[:, None]).unsqueeze(1)
+    d = ((outs[0] - outs[1]) * valid).abs()
+    assert d.max() <= 0.2 and (d ** 2).mean().sqrt() <= 5e-3 * ((outs[1] * valid) ** 2).mean().sqrt(), d.max()
+    # and the round trip through the fused forward returns the input
+    with torch.no_grad():
+        prep = D._Prepared(dc, W, need_bwd=False)
+        back = D._run_forward(dc, prep, outs[0], ml)[0]
+    assert ((back - z) * valid[:, :, :back.shape[2]]).abs().max() <= 0.1
+
+
+def test_exact_wait_counts_equal_conservative_waits():
+    """The fused kernel waits for its weight slabs with exact vmcnt counts that step over its own outstanding stores (wavenet_fused.hip
+    begin_step).  A count that is too large would read a slab before it has landed - a race that shows as a wrong value now and then.  With
+    conservative waits the kernel is slower but cannot race: both must agree BIT FOR BIT, on several shapes and repeated launches."""
+    from glow_tts_amd import _lib
+    L = _lib.lib()
+    for lengths, tm, drop in (([800] * 32, 800, 0.05), ([640, 522, 240, 2], 640, 0.0), ([800] * 8, 800, 0.3)):
+        D, dc, W, mels, ml, _ = _setup(2, lengths, tm, seed=21)
+        seed = torch.tensor([99], device="cuda", dtype=torch.int32)
+        try:
+            L.glowtts_wavenet_debug_safe_waits(1)
+            ref = _forward(D, dc, W, mels, ml, None, True, drop, seed if drop else None)
+        finally:
+            L.glowtts_wavenet_debug_safe_waits(0)
+        for _ in range(5):
+            got = _forward(D, dc, W, mels, ml, None, True, drop, seed if drop else None)
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+            for name in ("hs", "gates", "actp", "skip", "x", "xmid"):
+                assert torch.equal(getattr(got[2], name), getattr(ref[2], name)), name
+            cm, cl = _outs_columns()
+            assert torch.equal(got[2].outs[:, :, cm], ref[2].outs[:, :, cm]) and torch.equal(got[2].outs[:, :, cl], ref[2].outs[:, :, cl])

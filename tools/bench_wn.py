@@ -1,0 +1,67 @@
+"""Times ONE flow's coupling network alone at the bench shape (B = 32, 800 frames -> 12 928 rows): the fused kernel (wn_fwd) against the ten
+per-conv launches, forward with kept activations.  With GLOWTTS_LIB_PATH = tools build, GLOWTTS_WN_ABL selects a timing ablation of the fused
+kernel (1: no weight DMAs, 2: no MFMAs, 4: no kept stores; sums combine)."""
+import ctypes
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+from helpers import full_width_state
+from glow_tts_amd import decoder as D, _lib
+
+B, TM = int(os.environ.get("WN_B", "32")), int(os.environ.get("WN_TM", "800"))
+DROP = float(os.environ.get("WN_DROP", "0.05"))
+g = torch.Generator().manual_seed(0)
+cfg, sd = full_width_state(1, g)
+dc = D.DecoderConfig(cfg.mel_dim, 1, cfg.n_squeeze, cfg.n_split, cfg.wn_channels, cfg.wn_layers, cfg.wn_kernel, 1)
+P = {k: v.cuda() for k, v in sd.items()}
+W = dict(zip(D.WEIGHT_KEYS, [w.contiguous() for w in D.stack_decoder_weights(P, dc)]))
+mels = torch.randn(B, 80, TM, generator=g).cuda()
+ml = torch.full((B,), TM).cuda()
+seed = torch.tensor([7], device="cuda", dtype=torch.int32)
+L = D._L()
+res = {}
+for fused in (True, False):
+    D.TUNE["fused_wn"] = fused
+    with torch.no_grad():
+        prep = D._Prepared(dc, W, need_bwd=False)
+        R = B * (TM // 2 + 4)
+        buf = D._Buffers(dc, prep, R, "cuda")
+        _, rowmask, T = D.squeeze_rows(dc, mels, ml, out=buf.x[0])
+        acts = buf.acts(0, dc.L, rowmask)
+        tl = torch.zeros(512 * 32, dtype=torch.int64, device="cuda")
+        if os.environ.get("GLOWTTS_WN_ABL") == "16" and fused:
+            acts.skip_bf = tl.data_ptr()
+        dims = D._dims(dc, B, T, DROP, seed if DROP > 0 else None, 0)
+        run = lambda: _lib.check(L.glowtts_flow_forward(ctypes.byref(dims), ctypes.byref(prep.params[0]), ctypes.byref(acts), _lib.stream()), "flow_forward")
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        n = int(os.environ.get("ITERS", "30"))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        gr = torch.cuda.CUDAGraph()
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            with torch.cuda.graph(gr, stream=st):
+                for _ in range(n):
+                    run()
+            gr.replay()
+            e0.record(st)
+            gr.replay()
+            e1.record(st)
+        torch.cuda.synchronize()
+        if fused:
+            tl_fused = tl
+        res["fused" if fused else "per-conv"] = e0.elapsed_time(e1) * 1e3 / n
+if os.environ.get("GLOWTTS_WN_ABL") == "16":
+    tl = tl_fused
+    t = tl.view(512, 32)[: (R + 51) // 52].cpu()
+    n = int((t[0] != 0).sum())
+    d = (t[:, 1:n] - t[:, : n - 1]).float()
+    names = ["prologue", "start gemm", "start epi"] + sum([[f"in{l} gemm", f"gate{l} epi", f"rs{l} gemm", f"rs{l} epi"] for l in range(dc.L)], []) + ["end gemm", "end epi"]
+    print("phase: median clocks over workgroups (min .. max)")
+    for i in range(n - 1):
+        print(f"  {names[i] if i < len(names) else i:12s} {d[:, i].median().item():9.0f} ({d[:, i].min().item():.0f} .. {d[:, i].max().item():.0f})")
+    print(f"  total        {(t[:, n - 1] - t[:, 0]).float().median().item():9.0f}; first start .. last end {(t[:, n - 1].max() - t[:, 0].min()).item()}")
+print(f"B={B} Tm={TM} drop={DROP} abl={os.environ.get('GLOWTTS_WN_ABL', '0')}: " + " | ".join(f"{k} {v:7.1f} us/flow" for k, v in res.items()))
