@@ -118,6 +118,7 @@ __global__ __launch_bounds__(WN_NT) void wn_fwd_kernel(const wn_fwd_args p)
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + 1024), (void __attribute__((address_space(3)))*)(dst + 1024), 16, 0, 0);
     };
     int snext = 0;                                             // slab being multiplied
+    bool stamp_on = false; int stamp_base = (blockIdx.x * WN_NW + wave) * 32;      // (ABL & 32)
     int tli = 0;
     auto TLS = [&]() __attribute__((always_inline)) { if constexpr ((ABL & 16) != 0) { if (tid == 0) p.tl[blockIdx.x * 32 + tli] = (long long)__builtin_readcyclecounter(); ++tli; } };
     TLS();
@@ -133,6 +134,16 @@ __global__ __launch_bounds__(WN_NT) void wn_fwd_kernel(const wn_fwd_args p)
     // (tests) runs the conservative vmcnt(4) everywhere and must give bit-identical results.
     auto begin_step = [&](auto X_) __attribute__((always_inline)) -> const unsigned char* {
         constexpr int X = decltype(X_)::value;
+        if constexpr ((ABL & 32) != 0) {                       // per-wave step anatomy (tools/bench_wn.py): before wait / after wait / after barrier
+            const bool on = stamp_on;
+            if (on && lane == 0) p.tl[stamp_base + 0] = (long long)__builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            if (on && lane == 0) p.tl[stamp_base + 1] = (long long)__builtin_readcyclecounter();
+            asm volatile("s_barrier" ::: "memory");
+            if (on && lane == 0) p.tl[stamp_base + 2] = (long long)__builtin_readcyclecounter();
+            if (on) stamp_base += 3;
+            return wn_smem + OFF_RING + (snext & (WN_NS - 1)) * WN_SLAB;
+        }
         if (X == 0 || p.safe_waits) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(4 + X) : "memory");
         return wn_smem + OFF_RING + (snext & (WN_NS - 1)) * WN_SLAB;
@@ -311,6 +322,7 @@ __global__ __launch_bounds__(WN_NT) void wn_fwd_kernel(const wn_fwd_args p)
             };
 #pragma unroll 1
             for (int t = 0; t < WN_TAPS; ++t) {
+                if constexpr ((ABL & 32) != 0) stamp_on = (l == 1 && t == 2);
                 int ao[2];
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) ao[s2] = swz(rf * 32 + l31 + t, 2 * s2 + lhi);
@@ -327,9 +339,12 @@ __global__ __launch_bounds__(WN_NT) void wn_fwd_kernel(const wn_fwd_args p)
                         fb[st][s2][0] = lds16(slot + offP + bl[s2]);
                         fb[st][s2][1] = lds16(slot + offP + 2048 + bl[s2]);
                     }
+                    if constexpr ((ABL & 192) != 0) __builtin_amdgcn_sched_barrier(0);          // order experiments: reads first, pinned
+                    if constexpr ((ABL & 128) != 0) { end_step(); __builtin_amdgcn_sched_barrier(0); }   // ... then the DMAs, then the MFMAs
                     if (kc > 0) { if (st) mma(IC<0>{}); else mma(IC<1>{}); }
                     else if (t > 0) mma(IC<1>{});
-                    end_step();
+                    if constexpr ((ABL & 192) != 0) __builtin_amdgcn_sched_barrier(0);
+                    if constexpr ((ABL & 128) == 0) end_step();
                 }
             }
             mma(IC<1>{});                                      // slab 29
@@ -561,6 +576,11 @@ int launch_wn_fwd(const wn_fwd_args& k, dim3 grid, hipStream_t s)
             case 4: return launch_wn_fwd<DROP, COND, 4>(k, grid, s);
             case 7: return launch_wn_fwd<DROP, COND, 7>(k, grid, s);
             case 16: return launch_wn_fwd<DROP, COND, 16>(k, grid, s);
+            case 32: return launch_wn_fwd<DROP, COND, 32>(k, grid, s);
+            case 64: return launch_wn_fwd<DROP, COND, 64>(k, grid, s);
+            case 128: return launch_wn_fwd<DROP, COND, 128>(k, grid, s);
+            case 96: return launch_wn_fwd<DROP, COND, 96>(k, grid, s);
+            case 160: return launch_wn_fwd<DROP, COND, 160>(k, grid, s);
             default: break;
         }
     }
@@ -630,7 +650,7 @@ extern "C" int glowtts_wavenet_fwd(const glowtts_flow_dims* d, const glowtts_flo
     k.drop_p = d->drop_p; k.seed = d->seed; k.seed_ptr = d->seed_ptr;
     k.safe_waits = g_wn_safe_waits;
 #ifdef GLOWTTS_TOOLS
-    if (GLOWTTS_TUNABLE("GLOWTTS_WN_ABL", 0) == 16) k.tl = reinterpret_cast<long long*>(a->skip_bf);      // tools/bench_wn.py passes the stamp buffer here
+    if (GLOWTTS_TUNABLE("GLOWTTS_WN_ABL", 0) & 48) k.tl = reinterpret_cast<long long*>(a->skip_bf);      // tools/bench_wn.py passes the stamp buffer here
 #endif
     if (keep) {
         if (!a->skip || !a->outs) return GLOWTTS_E_ARG;

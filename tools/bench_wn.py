@@ -30,8 +30,8 @@ for fused in (True, False):
         buf = D._Buffers(dc, prep, R, "cuda")
         _, rowmask, T = D.squeeze_rows(dc, mels, ml, out=buf.x[0])
         acts = buf.acts(0, dc.L, rowmask)
-        tl = torch.zeros(512 * 32, dtype=torch.int64, device="cuda")
-        if os.environ.get("GLOWTTS_WN_ABL") == "16" and fused:
+        tl = torch.zeros(512 * 12 * 32, dtype=torch.int64, device="cuda")
+        if os.environ.get("GLOWTTS_WN_ABL") in ("16", "32", "96", "160") and fused:
             acts.skip_bf = tl.data_ptr()
         dims = D._dims(dc, B, T, DROP, seed if DROP > 0 else None, 0)
         run = lambda: _lib.check(L.glowtts_flow_forward(ctypes.byref(dims), ctypes.byref(prep.params[0]), ctypes.byref(acts), _lib.stream()), "flow_forward")
@@ -54,9 +54,21 @@ for fused in (True, False):
         if fused:
             tl_fused = tl
         res["fused" if fused else "per-conv"] = e0.elapsed_time(e1) * 1e3 / n
+if os.environ.get("GLOWTTS_WN_ABL") in ("32", "96", "160"):
+    t = tl_fused.view(512, 12, 32)[:200, :, :18].cpu()
+    t = (t - t[:, :1, :1]).double().view(200, 12, 6, 3)      # [wg][wave][step][before wait, after wait, after barrier]
+    print("In_1, tap 2, steps kc = 0..5; clocks, median over 200 workgroups")
+    for w in (0, 3, 6, 11):
+        iss = (t[:, w, 1:, 0] - t[:, w, :-1, 2]).median().item()
+        wait = (t[:, w, :, 1] - t[:, w, :, 0]).median().item()
+        bar = (t[:, w, :, 2] - t[:, w, :, 1]).median().item()
+        step = (t[:, w, 1:, 2] - t[:, w, :-1, 2]).median().item()
+        print(f"  wave {w:2d}: barrier -> before wait (issue) {iss:6.0f} | waitcnt {wait:6.0f} | barrier {bar:6.0f} | step {step:6.0f}")
+    arrive = t[:, :, :, 1]                                           # when each wave reaches the barrier
+    print("  barrier arrival spread over the 12 waves (max - min), median:", (arrive.max(dim=1).values - arrive.min(dim=1).values).median().item())
 if os.environ.get("GLOWTTS_WN_ABL") == "16":
     tl = tl_fused
-    t = tl.view(512, 32)[: (R + 51) // 52].cpu()
+    t = tl.view(512 * 12, 32)[:512][: (R + 51) // 52].cpu()
     n = int((t[0] != 0).sum())
     d = (t[:, 1:n] - t[:, : n - 1]).float()
     names = ["prologue", "start gemm", "start epi"] + sum([[f"in{l} gemm", f"gate{l} epi", f"rs{l} gemm", f"rs{l} epi"] for l in range(dc.L)], []) + ["end gemm", "end epi"]
