@@ -3,7 +3,8 @@
 losses, backward, gradient all-reduce when N > 1) on LJSpeech-shaped synthetic batches, plus MAS us/utterance.
 
     python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
-For N > 1 the driver launches it through torch.distributed.run (one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
+For N > 1 it runs one rank per GPU over RCCL: launched through torch.distributed.run (WORLD_SIZE set) it joins that job, launched plainly
+(`python bench.py --gpus N`) it spawns the N ranks itself and refuses when the node has fewer GPUs.  Prints ONE JSON line on rank 0.
 
 --config selects the BASELINE.json workload (default 2, the one the metric is quoted on):
     2  Vanilla single-speaker, bf16, 32 utterances per GPU, 800 frames / 120 tokens
@@ -380,11 +381,31 @@ def main():
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: become the launcher - one rank per GPU under torch.distributed.run (RCCL over xGMI),
+        # rendezvous on 127.0.0.1; rank 0's JSON line is this process's last line of output.  Refuses when the node has fewer devices.
+        import subprocess
+        if not args.one_device and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node has {torch.cuda.device_count()} visible GPU(s)")
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if world != args.gpus and not (args.gpus == 1 and world == 1):
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: the two must agree (n_gpus in the JSON line is the "
+                         "number of ranks the process group really has)")
+    if not args.one_device and world > torch.cuda.device_count():
+        raise SystemExit(f"WORLD_SIZE={world} but only {torch.cuda.device_count()} visible GPU(s) (use --one-device for a single-GPU smoke test)")
     if args.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -577,7 +598,9 @@ def main():
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             if not torch.equal(lo, hi):
-                raise SystemExit(f"[bench] rank {rank}: {int((lo != hi).sum())} parameter tensors differ between ranks after the optimizer steps")
+                names = [k for (k, _), bad in zip(model.named_parameters(), (lo != hi).tolist()) if bad]
+                raise SystemExit(f"[bench] rank {rank}: {len(names)} parameter tensors differ between ranks after the optimizer steps, e.g. {names[:4]} .. {names[-2:]}; "
+                                 f"largest relative difference of the sums {((hi - lo).abs() / (lo.abs() + 1e-9)).max().item():.2e}")
     fwd_bwd_only = None
     if opt is not None and not dp and graph is not None and args.windows > 0:      # (--windows 0 = profiling runs: every traced step is a full Train_Step)
         # round 1's definition of the step (forward + losses + backward, no update), for continuity: a second graph of the same model

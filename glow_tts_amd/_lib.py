@@ -128,6 +128,16 @@ def staged_upload(raw, device):
     return src.to(device)
 
 
+def refill_spares():
+    """Tops every spare pool up to its cap (call OUTSIDE a capture, right before one): a capture takes pinned buffers of the sizes the eager
+    steps have used for good, and a later capture of another input shape - whose warm-up passes skip the optimizer - needs them again."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    for n, pool in _SPARE.items():
+        while len(pool) < _SPARE_CAP:
+            pool.append(torch.empty(n, dtype=torch.uint8).pin_memory())
+
+
 class PinnedRing:
     """`slots` pinned buffers of `numel` elements reused round-robin; a slot is rewritten only after the copy that last read it has
     completed (one event per slot, which in steady state has long fired)."""

@@ -45,19 +45,22 @@ class _JobTable:
     def __init__(self):
         self.sig, self.table, self.njobs, self.blocks = None, None, 0, 0
 
-    def update(self, items, device):
-        sig = tuple((p.data_ptr(), g.data_ptr(), m.data_ptr() if m is not None else 0, p.numel()) for p, g, m, v in items)
+    def update(self, items, device, canonical=False):
+        """canonical: one job per tensor in the order given, no coalescing - for REDUCTIONS (the gradient norm), whose summation order must
+        not depend on where the allocator of this process happened to place the tensors: data-parallel replicas otherwise compute clip
+        coefficients that differ in the last bit and drift apart (found by bench.py's replica check).  Elementwise launches may coalesce."""
+        sig = (canonical,) + tuple((p.data_ptr(), g.data_ptr(), m.data_ptr() if m is not None else 0, p.numel()) for p, g, m, v in items)
         capturing = torch.cuda.is_current_stream_capturing()
         if sig == self.sig and not capturing:
             return
         chunk = _L().glowtts_opt_chunk()
-        order = sorted(range(len(items)), key=lambda i: sig[i][0])
+        order = range(len(items)) if canonical else sorted(range(len(items)), key=lambda i: sig[1 + i][0])
         jobs, cur = [], None
         for i in order:
             p, g, m, v = items[i]
             ptrs = [p.data_ptr(), g.data_ptr(), m.data_ptr() if m is not None else 0, v.data_ptr() if v is not None else 0]
             n = p.numel()
-            if cur is not None and all(a + 4 * cur[4] == b or (a == 0 and b == 0) for a, b in zip(cur[:4], ptrs)):
+            if not canonical and cur is not None and all(a + 4 * cur[4] == b or (a == 0 and b == 0) for a, b in zip(cur[:4], ptrs)):
                 cur[4] += n                                    # adjacent in all four tensors: extend the run
             else:
                 cur = ptrs + [n]
@@ -82,7 +85,7 @@ def clip_grad_norm_(parameters, max_norm, _table_key=None):
     dev = params[0].grad.device
     key = _table_key if _table_key is not None else (id(params[0]), len(params))
     tab = _CLIP_TABLES.setdefault(key, _JobTable())
-    tab.update([(p.grad, p.grad, None, None) for p in params], dev)
+    tab.update([(p.grad, p.grad, None, None) for p in params], dev, canonical=True)
     partial = torch.empty(tab.blocks, device=dev)
     out = torch.empty(2, device=dev)
     L = _L()
@@ -198,7 +201,7 @@ def grad_norm_and_coef(parameters, max_norm, _table_key="fused"):
     params = [p for p in parameters if p.grad is not None]
     dev = params[0].grad.device
     tab = _CLIP_TABLES.setdefault((_table_key, id(params[0]), len(params)), _JobTable())
-    tab.update([(p.grad, p.grad, None, None) for p in params], dev)
+    tab.update([(p.grad, p.grad, None, None) for p in params], dev, canonical=True)
     partial, out = torch.empty(tab.blocks, device=dev), torch.empty(2, device=dev)
     _lib.check(_L().glowtts_multi_grad_norm(tab.table.data_ptr(), tab.njobs, tab.blocks, float(max_norm), partial.data_ptr(), out.data_ptr(),
                                             _lib.stream()), "glowtts_multi_grad_norm")

@@ -18,6 +18,15 @@ from .modules import GlowTTS, MLE_Loss
 from .optim import Modified_Noam_Scheduler, RAdam, clip_grad_norm_
 
 
+def duration_loss(log_durations, log_duration_targets, token_lengths):
+    """The reference's `MSELoss()(log_Durations, log_Duration_Targets)` (Train.py:210): a mean over B x (longest text OF THE BATCH) elements -
+    its collater pads to the batch maximum (Datasets.py:225-250).  This package pads the token axis to a shape bucket, so the mean is taken
+    over the unpadded extent explicitly: padded positions are zero in both tensors and must not enlarge the denominator (a plain MSELoss would
+    scale the loss and its gradient by max_len / bucket_len, a batch-dependent factor down to ~0.75).  No host sync: the extent stays on the device."""
+    d = (log_durations - log_duration_targets).reshape(log_durations.shape[0], -1)
+    return (d * d).sum() / (d.shape[0] * token_lengths.max().to(d.dtype))
+
+
 def default_buckets(max_len, step):
     return list(range(step, int(math.ceil(max_len / step)) * step + 1, step))
 
@@ -71,7 +80,7 @@ class Trainer:
         hp = self.hp
         model = GlowTTS(hp).to(self.device)
         self.model_Dict = {"GlowTTS": model}
-        self.criterion_Dict = {"MSE": torch.nn.MSELoss(), "MLE": MLE_Loss(hp), "CE": torch.nn.CrossEntropyLoss()}
+        self.criterion_Dict = {"MSE": duration_loss, "MLE": MLE_Loss(hp), "CE": torch.nn.CrossEntropyLoss()}
         self.optimizer = RAdam(model.parameters(), lr=hp.Train.Learning_Rate.Initial, betas=(hp.Train.ADAM.Beta1, hp.Train.ADAM.Beta2),
                                eps=hp.Train.ADAM.Epsilon, weight_decay=hp.Train.Weight_Decay)
         self.scheduler = Modified_Noam_Scheduler(self.optimizer, base=hp.Train.Learning_Rate.Base)
@@ -84,17 +93,20 @@ class Trainer:
         self._comp = torch.zeros(4, device=self.device)      # MLE, Length, Total, Speaker of the last step (written inside the graph)
         self._graphed = None
 
-    def _losses(self, model, tokens, token_lengths, mels, mel_lengths, speakers, mels_for_ge2e, pitches):
-        """Train.py:193-216 -> (loss to differentiate, [MLE, Length, Total, Speaker])."""
+    def _losses(self, model, tokens, token_lengths, mels, mel_lengths, speakers, mels_for_ge2e, pitches, frame_weight=None):
+        """Train.py:193-216 -> (loss to differentiate, [MLE, Length, Total, Speaker]).  frame_weight (data parallel): this rank's share of the
+        global batch's mel frames, a 0-d device tensor computed outside the captured step (`distributed.global_frame_weight`)."""
         z, mel_Mean, mel_Log_Std, log_Dets, log_Durations, log_Duration_Targets, _, classified = model(
             tokens, token_lengths, mels, mel_lengths, speakers, mels_for_ge2e, pitches)
         mle = self.criterion_Dict["MLE"](z=z, mean=mel_Mean, std=mel_Log_Std, log_dets=log_Dets, lengths=mel_lengths)
-        length = self.criterion_Dict["MSE"](log_Durations, log_Duration_Targets)
+        length = duration_loss(log_Durations, log_Duration_Targets, token_lengths)
         total = mle + length
         ce = self.criterion_Dict["CE"](classified, speakers) if classified is not None else None
         if self.world > 1:
-            from .distributed import global_frame_weight
-            loss = mle * global_frame_weight(mel_lengths.sum()) + (length + (ce if ce is not None else 0.0)) / self.world
+            if frame_weight is None:
+                from .distributed import global_frame_weight
+                frame_weight = global_frame_weight(mel_lengths.sum())
+            loss = mle * frame_weight + (length + (ce if ce is not None else 0.0)) / self.world
         else:
             loss = total + (ce if ce is not None else 0.0)
         comp = torch.stack([mle.detach(), length.detach(), total.detach(), ce.detach() if ce is not None else torch.zeros((), device=mle.device)])
@@ -122,15 +134,18 @@ class Trainer:
             loss, comp = self._losses(m, *inp)
             self._comp.copy_(comp)
             return loss
-        if self.use_graph and self.world == 1:
+        if self.world > 1:                                     # one tiny all-reduce per step, outside the captured graphs
+            from .distributed import global_frame_weight
+            inputs = tuple(inputs) + (global_frame_weight(inputs[3].sum()),)
+        if self.use_graph:
+            # one process or data parallel: the same captured step (data parallel: three graphs around the gradient exchange, graph_step.py)
             if self._graphed is None:
                 from .graph_step import GraphedTrainStep
                 self._graphed = GraphedTrainStep(model, loss_fn, warmup=2, optimizer=self.optimizer, scheduler=self.scheduler,
                                                  max_grad_norm=hp.Train.Gradient_Norm)
-                self._graphed.steps_taken = 0
             before = self._graphed.steps_taken
             self._graphed(*inputs)
-            self.steps += self._graphed.steps_taken - before       # a new batch shape costs warm-up steps, which are real optimizer steps
+            self.steps += self._graphed.steps_taken - before       # (always 1: a new batch shape costs dry warm-up passes, not optimizer steps)
         else:
             loss = loss_fn(model, *inputs)
             self.optimizer.zero_grad(set_to_none=True)

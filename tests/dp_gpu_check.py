@@ -131,6 +131,49 @@ def worker(rank, world, port, backend, log):
         early.finish(pending)
         check(f"two-graph overlap step, replay {rep}")
 
+    # (2b) the product form: glow_tts_amd.graph_step.GraphedTrainStep in data-parallel mode (what Trainer.Train_Step runs under torchrun): three
+    # graphs around the exchange, clip + RAdam + Noam schedule on the reduced gradients.  Four steps on uneven shards must leave every rank
+    # with the parameters of a single-process eager run on the global batch.
+    from glow_tts_amd.graph_step import GraphedTrainStep
+    from glow_tts_amd.optim import Modified_Noam_Scheduler, RAdam, clip_grad_norm_
+    full = tuple(t(k) for k in ("tokens", "token_lengths", "mels", "mel_lengths"))
+
+    def fresh():
+        m = make(sd).eval()
+        for f in m.layer_Dict["Decoder"].layer_Dict["Flows"]:
+            f.layers[0].initialized = True
+        o = RAdam(m.parameters(), lr=1e-3, eps=1e-6, weight_decay=1e-6)
+        return m, o, Modified_Noam_Scheduler(o, base=4000)
+
+    def dp_loss(m, tokens, tl, mels, ml, wf_, wb_):
+        z, mm, ms, ld, dur, durt, _, _ = m(tokens, tl, mels, ml, None, None, None)
+        return mle_fn(z=z, mean=mm, std=ms, log_dets=ld, lengths=ml) * wf_ + torch.nn.functional.mse_loss(dur, durt) * wb_
+    mg, og, sg = fresh()
+    gstep = GraphedTrainStep(mg, dp_loss, warmup=2, optimizer=og, scheduler=sg, max_grad_norm=5.0)
+    wb_t = torch.tensor(wb, device="cuda")
+    for _ in range(4):
+        gstep(*shard, wf.clone(), wb_t)
+    torch.cuda.synchronize()
+    assert gstep.steps_taken == 4 and len(gstep.graphs) == 1 and gstep.graphs[next(iter(gstep.graphs))]["tail"] is not None
+    mr, orr, sr = fresh()
+    for _ in range(4):
+        mr.zero_grad(set_to_none=True)
+        dp_loss(mr, *full, 1.0, 1.0).backward()
+        clip_grad_norm_(list(mr.parameters()), 5.0)
+        orr.step(); sr.step()
+    torch.cuda.synchronize()
+    worst = ("", 0.0)
+    for (k, pa), pb in zip(mr.named_parameters(), mg.parameters()):
+        err = (pa - pb).abs().max().item() / max(1.0, pa.abs().max().item())
+        worst = max(worst, (k, err), key=lambda x: x[1])
+        assert err < 2e-4, (k, err)
+        assert orr.state[pa]["step"] == og.state[pb]["step"] == 4
+    flat = torch.cat([p_.detach().reshape(-1) for p_ in mg.parameters()])
+    lo, hi = flat.clone(), flat.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    assert torch.equal(lo, hi), "replicas diverged"
+    say(f"[dp] GraphedTrainStep (3 graphs around the exchange, clip + RAdam): 4 steps == single-process global-batch run (worst rel {worst[1]:.2e}), replicas identical")
+
     # (3) dropout streams differ per rank (same inputs, per-rank seeds)
     torch.manual_seed(4321 + rank)
     mt = make(sd).train()

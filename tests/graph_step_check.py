@@ -45,7 +45,7 @@ ma, mb = build("Vanilla", "f32", sd), build("Vanilla", "f32", sd)
 oa, ob = RAdam(ma.parameters(), lr=1e-3, eps=1e-6, weight_decay=1e-6), RAdam(mb.parameters(), lr=1e-3, eps=1e-6, weight_decay=1e-6)
 sa, sb = Modified_Noam_Scheduler(oa, base=4000), Modified_Noam_Scheduler(ob, base=4000)
 gstep = GraphedTrainStep(mb, loss_fn, warmup=2, optimizer=ob, scheduler=sb, max_grad_norm=5.0)
-seq = [b1, b1, b1, b2, b1, b2]                          # graphed side: 2 warm-up steps + 1 replay on b1, then b2, b1, b2
+seq = [b1, b2, b1, b2, b1, b1]                          # one optimizer step per call: a new shape costs dry warm-up passes, no extra update
 la = []
 for b in seq:
     ma.zero_grad(set_to_none=True)
@@ -54,9 +54,10 @@ for b in seq:
     clip_grad_norm_(list(ma.parameters()), 5.0)
     oa.step(); sa.step()
     la.append(l.item())
-lb = [gstep(*b).item() for b in seq[2:]]
+lb = [gstep(*b).item() for b in seq]
 torch.cuda.synchronize()
-for x, y in zip(la[2:], lb):
+assert gstep.steps_taken == len(seq)
+for x, y in zip(la, lb):
     assert abs(x - y) <= 2e-5 * max(1.0, abs(x)), (la, lb)
 assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"]
 for (k, pa), pb_ in zip(ma.named_parameters(), mb.parameters()):
@@ -83,8 +84,8 @@ me, mf = build("Vanilla", "f32", sd), build("Vanilla", "f32", sd)
 oe, of = RAdam(me.parameters(), lr=1e-3, eps=1e-6, weight_decay=1e-6), RAdam(mf.parameters(), lr=1e-3, eps=1e-6, weight_decay=1e-6)
 se, sf = Modified_Noam_Scheduler(oe, base=4000), Modified_Noam_Scheduler(of, base=4000)
 gstep2 = GraphedTrainStep(mf, loss_fn, warmup=2, optimizer=of, scheduler=sf, max_grad_norm=5.0)
-calls = [b1, b3, b1, b3, b1]                            # graphed: the first call of a shape = 2 warm-up steps + 1 replay on that batch
-eager_seq = [b1, b1, b1, b3, b3, b3, b1, b3, b1]
+calls = [b1, b3, b1, b3, b1]                            # graphed: exactly one training step per call, also on the first call of a shape
+eager_seq = list(calls)
 for b in eager_seq:
     me.zero_grad(set_to_none=True)
     l = loss_fn(me, *b)

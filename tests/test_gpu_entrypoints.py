@@ -65,7 +65,7 @@ def test_train_resume_and_inference(mode, tmp_path):
     state = torch.load(os.path.join(hp.Checkpoint_Path, f"S_{tr.steps}.pt"), map_location="cpu")
     assert set(state) >= {"Model", "Optimizer", "Scheduler", "Steps", "Epochs"} and state["Steps"] == tr.steps      # Train.py:538-544
     assert all(torch.isfinite(v).all() for v in state["Model"].values() if v.is_floating_point())
-    # optimizer and trainer step counters agree (warm-up steps of a new batch shape are real steps, GraphedTrainStep.steps_taken)
+    # optimizer and trainer step counters agree (a new batch shape costs dry warm-up passes, never extra optimizer steps)
     some = next(iter(tr.optimizer.state.values()))
     assert some["step"] == tr.steps
     # resume: -s <steps> (Train.py:499-533)
@@ -125,7 +125,7 @@ def test_graphed_training_reduces_the_loss(precision):
     mg2, og2, sg2, mle2 = make()
     step2 = GraphedTrainStep(mg2, loss_fn_for(mle2), warmup=2, optimizer=og2, scheduler=sg2, max_grad_norm=5.0)
     curve = []
-    for _ in range(steps - 2):
+    for _ in range(steps):
         curve.append(float(step2(*batch).detach()))
     me, oe, se, mlee = make()
     lf = loss_fn_for(mlee)
