@@ -73,7 +73,9 @@ int glowtts_mas_path_from_idx(const int32_t *idx, void *path, int B, int Tx, int
 int glowtts_mas_f32(const float *value, int32_t *path, const int32_t *t_xs, const int32_t *t_ys,
                     int32_t *scratch_idx, int B, int Tx, int Ty, float max_neg_val, void *stream);
 /* HOST twin (no stream, every pointer is a HOST pointer): exactly `maximum_path_c` of core.pyx:40 - `value` [B][Tx][Ty] is clobbered into
- * the cumulative scores, `path` must arrive zeroed, utterances with t_x > t_y are left untouched.  num_threads <= 0: one thread per
+ * the cumulative scores, `path` must arrive zeroed; an utterance with t_x > t_y (no monotonic alignment exists) is treated as core.pyx
+ * treats it: nothing is accumulated into `value`, the backtrack walks the RAW scores from row t_x - 1 and writes its ones into `path` (same
+ * as the device entry points above).  num_threads <= 0: one thread per
  * hardware thread (core.pyx:44 `prange`).  An explicit entry point for host-resident score matrices, never a fallback of the GPU path. */
 int glowtts_mas_f32_host(float *value, int32_t *path, const int32_t *t_xs, const int32_t *t_ys,
                          int B, int Tx, int Ty, float max_neg_val, int num_threads);
