@@ -203,6 +203,16 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
     if (g->coupling_done) { /* fused into the previous call's last kernel */ }
     else if (dbf) CHECK(glowtts_coupling_bwd_bf16(g->dx, a->xmid, a->outs, g->douts, g->douts_bf, a->rowmask, g->dlogdet, R, C, ldo, c.Tp, stream));
     else     CHECK(glowtts_coupling_bwd(g->dx, a->xmid, a->outs, g->douts, a->rowmask, g->dlogdet, R, C, ldo, c.Tp, stream));
+    // 2-4 in ONE launch when the caller packed the transposed weight image (wavenet_fused_bwd.hip; its per-conv transposed images are then
+    // not packed at all: no fallback from here)
+    if (p->wn_img_t) {
+        CHECK(glowtts_wavenet_bwd(d, p, a, g, stream));
+        if (g->prev_outs && g->d_an) return GLOWTTS_E_ARG;
+        if (g->prev_outs)
+            return glowtts_actnorm_inv1x1_bwd_coupling(g->dx, g->dx, a->xin, p->an_logs, p->an_bias, p->winfo, a->rowmask, g->scratch, R, C,
+                                                       g->prev_xmid, g->prev_outs, g->prev_douts, g->prev_douts_bf, g->dlogdet, ldo, c.Tp, stream);
+        return glowtts_actnorm_inv1x1_bwd(g->dx, g->dx, a->xin, p->an_logs, p->an_bias, p->winfo, a->rowmask, g->d_an, g->scratch, R, C, stream);
+    }
     // 2. End conv: data gradient -> d(skip) (masked), weight gradient
     glowtts_conv_args endq = base_args(c, p->end_t, 1);
     endq.a = dbf ? g->douts_bf : g->douts; endq.lda = ldo; endq.ca = ldo; endq.n = H; endq.epi = GLOWTTS_EPI_LINEAR; endq.flags = GLOWTTS_F_MASK;

@@ -67,11 +67,11 @@ __device__ __forceinline__ float pack_element(const float* __restrict__ w, long 
 template <typename CT>
 __global__ void pack_weight_kernel(const float* __restrict__ w, CT* __restrict__ out, int O, int I, int taps,
                                    int transpose, int perm, int perm_h, int N, int K, int npad, int kchunks,
-                                   int inner, long outer_stride, long inner_stride /* bytes; inner = 0: images back to back */)
+                                   int inner, long outer_stride, long inner_stride /* bytes; inner = 0: images back to back */, long w_stride /* elements */)
 {
     constexpr int KC = 64 / sizeof(CT);
     const long total = (long)taps * kchunks * npad * KC;
-    w += (long)blockIdx.y * O * I * taps;          // batch of independent weights
+    w += (long)blockIdx.y * w_stride;              // batch of independent weights
     if (inner > 0) out = reinterpret_cast<CT*>(reinterpret_cast<unsigned char*>(out) + (blockIdx.y / inner) * outer_stride + (blockIdx.y % inner) * inner_stride);
     else out += (long)blockIdx.y * total;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
@@ -1628,26 +1628,27 @@ int launch_prec(const glowtts_conv_args& a, hipStream_t s)
 
 namespace {
 int pack_batched(const float* w, int batch, int O, int I, int taps, int transpose, int perm, int perm_h, int precision, void* packed,
-                 int* npad_out, int* kchunks_out, int inner, long outer_stride, long inner_stride, void* stream);
+                 int* npad_out, int* kchunks_out, int inner, long outer_stride, long inner_stride, long w_stride, void* stream);
 }
 
 extern "C" int glowtts_pack_weight_batched(const float* w, int batch, int O, int I, int taps, int transpose, int perm, int perm_h,
                                            int precision, void* packed, int* npad_out, int* kchunks_out, void* stream)
 {
-    return pack_batched(w, batch, O, I, taps, transpose, perm, perm_h, precision, packed, npad_out, kchunks_out, 0, 0, 0, stream);
+    return pack_batched(w, batch, O, I, taps, transpose, perm, perm_h, precision, packed, npad_out, kchunks_out, 0, 0, 0, 0, stream);
 }
 
 extern "C" int glowtts_pack_weight_strided(const float* w, int batch, int inner, int O, int I, int taps, int transpose, int perm, int perm_h,
-                                           int precision, void* packed, int64_t outer_stride, int64_t inner_stride, void* stream)
+                                           int precision, void* packed, int64_t outer_stride, int64_t inner_stride, int64_t w_stride, void* stream)
 {
-    if (inner < 1 || !packed || (outer_stride & 15) || (inner_stride & 15)) return GLOWTTS_E_ARG;
-    return pack_batched(w, batch, O, I, taps, transpose, perm, perm_h, precision, packed, nullptr, nullptr, inner, (long)outer_stride, (long)inner_stride, stream);
+    if (inner < 1 || !packed || (outer_stride & 15) || (inner_stride & 15) || w_stride < 0) return GLOWTTS_E_ARG;
+    return pack_batched(w, batch, O, I, taps, transpose, perm, perm_h, precision, packed, nullptr, nullptr, inner, (long)outer_stride, (long)inner_stride, (long)w_stride, stream);
 }
 
 namespace {
 int pack_batched(const float* w, int batch, int O, int I, int taps, int transpose, int perm, int perm_h, int precision, void* packed,
-                 int* npad_out, int* kchunks_out, int inner, long outer_stride, long inner_stride, void* stream)
+                 int* npad_out, int* kchunks_out, int inner, long outer_stride, long inner_stride, long w_stride, void* stream)
 {
+    if (w_stride == 0) w_stride = (long)O * I * taps;
     if (batch < 1 || O < 1 || I < 1 || taps < 1 || taps > MAX_TAPS || (precision != GLOWTTS_F32 && precision != GLOWTTS_BF16)) return GLOWTTS_E_ARG;
     if (perm == GLOWTTS_PERM_PAIR && (perm_h < 1 || 2 * perm_h != O)) return GLOWTTS_E_ARG;
     const int KC = precision == GLOWTTS_BF16 ? 32 : 16;
@@ -1666,10 +1667,10 @@ int pack_batched(const float* w, int batch, int O, int I, int taps, int transpos
     const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
     if (precision == GLOWTTS_BF16)
         hipLaunchKernelGGL(pack_weight_kernel<__bf16>, dim3(blocks, batch), dim3(256), 0, s, w, static_cast<__bf16*>(packed), O, I, taps, transpose, perm, perm_h, N, kchunks * KC, npad, kchunks,
-                           inner, outer_stride, inner_stride);
+                           inner, outer_stride, inner_stride, w_stride);
     else
         hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks, batch), dim3(256), 0, s, w, static_cast<float*>(packed), O, I, taps, transpose, perm, perm_h, N, kchunks * KC, npad, kchunks,
-                           inner, outer_stride, inner_stride);
+                           inner, outer_stride, inner_stride, w_stride);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 }  // namespace

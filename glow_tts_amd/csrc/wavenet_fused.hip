@@ -24,21 +24,9 @@
 #include "../../include/glowtts_hip.h"
 #include "tunable.h"
 #include "launch_log.h"
-#include "device_common.h"
+#include "wavenet_common.h"
 
 namespace {
-
-constexpr int WN_H = 192;                         // Calc_Channels the kernel is written for
-constexpr int WN_KCH = WN_H / 32;                 // K chunks (64 B of bf16) per 192 channels
-constexpr int WN_TAPS = 5, WN_PAD = 2;
-constexpr int WN_WIN = 64;                        // rows of the compute window (two 32-row MFMA fragments)
-constexpr int WN_XR = WN_WIN + 2 * WN_PAD;        // rows of the state tile
-constexpr int WN_SLAB = GLOWTTS_WN_SLAB_BYTES;    // one weight slab
-constexpr int WN_NS = 4;                          // ring slots
-constexpr int WN_NW = 12;                         // waves per workgroup
-constexpr int WN_NT = WN_NW * 64;
-constexpr int WN_MAXL = GLOWTTS_WN_FUSED_MAX_LAYERS;
-constexpr int WN_SROWS = 96;                      // rows of the Start conv's operand tile (three fragments cover the 68 state rows)
 
 // LDS map (bytes)
 constexpr int OFF_XT = 0;                                       // x_l: [6][68][64]; after the last layer: bf16 skip sum [6][64][64]
@@ -68,21 +56,6 @@ struct wn_fwd_args {
     float* skip; float* outs; int64_t ldo;                              // kept (fp32)
     long long* tl;                                                      // tools builds (ABL & 16): per-workgroup phase stamps [grid][32]
 };
-
-typedef __amdgpu_buffer_rsrc_t Rsrc;
-template <int V> struct IC { static constexpr int value = V; };
-constexpr uint32_t OOB = 0x80000000u;
-
-__device__ __forceinline__ Rsrc mk_rsrc(const void* ptr, long bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000); }
-__device__ __forceinline__ int frag_row(int reg) { return (reg & 3) + 8 * (reg >> 2); }       // + 4 * (lane >> 5): row of accumulator element `reg`
-template <bool ON = true>
-__device__ __forceinline__ f32x16 mfma_bf16(const Chunk16& a, const Chunk16& b, const f32x16& c) {
-    if constexpr (!ON) { f32x16 r = c; r[0] += __uint_as_float(a[0] ^ b[0]); return r; }
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
-}
-__device__ __forceinline__ Chunk16 lds16(const unsigned char* p) { return *reinterpret_cast<const Chunk16*>(p); }
-template <class T> __device__ __forceinline__ T pick4(T const (&a)[4], int l) { return l == 0 ? a[0] : (l == 1 ? a[1] : (l == 2 ? a[2] : a[3])); }   // (no dynamic indexing of kernel arguments)
-__device__ __forceinline__ unsigned short bf16_bits(float v) { const __bf16 b = (__bf16)v; return *reinterpret_cast<const unsigned short*>(&b); }
 
 // DROP / COND: training-mode dropout / conditioning present (compile-time, so that the unrolled gate epilogue is straight-line code)
 // ABL (tools builds only, tools/bench_wn.py): timing ablations - 1: no weight DMAs after the prologue, 2: no MFMAs, 4: no kept-activation stores
@@ -597,6 +570,8 @@ int launch_wn_fwd(const wn_fwd_args& k, dim3 grid, hipStream_t s)
 
 }  // namespace
 
+int glowtts_wavenet_pack_bwd_images(const float* w_start, const float* w_in, const float* w_rs, const float* w_rs_last, const float* w_end,
+                                    int F, int L, int C2, void* img_bwd, void* stream);      // wavenet_fused_bwd.hip
 static int g_wn_safe_waits = 0;
 extern "C" void glowtts_wavenet_debug_safe_waits(int on) { g_wn_safe_waits = on ? 1 : 0; }
 
@@ -617,14 +592,14 @@ extern "C" int glowtts_wavenet_pack_images(const float* w_start, const float* w_
     if (img_fwd) {
         unsigned char* img = static_cast<unsigned char*>(img_fwd);
         // [Start: 2 slabs][layer l: In_l 30 slabs, Res_Skip_l 6 slabs (last layer: 3)][End: 3 slabs]
-        int rc = glowtts_pack_weight_strided(w_start, F, 1, H, C2, 1, 0, GLOWTTS_PERM_NONE, 0, GLOWTTS_BF16, img, stride, 0, stream);
-        if (rc == GLOWTTS_OK) rc = glowtts_pack_weight_strided(w_in, F * L, L, 2 * H, H, WN_TAPS, 0, GLOWTTS_PERM_PAIR, H, GLOWTTS_BF16, img + 2 * WN_SLAB, stride, 36 * (int64_t)WN_SLAB, stream);
-        if (rc == GLOWTTS_OK && L > 1) rc = glowtts_pack_weight_strided(w_rs, F * (L - 1), L - 1, 2 * H, H, 1, 0, GLOWTTS_PERM_PAIR, H, GLOWTTS_BF16, img + 32 * WN_SLAB, stride, 36 * (int64_t)WN_SLAB, stream);
-        if (rc == GLOWTTS_OK) rc = glowtts_pack_weight_strided(w_rs_last, F, 1, H, H, 1, 0, GLOWTTS_PERM_NONE, 0, GLOWTTS_BF16, img + (int64_t)(36 * (L - 1) + 32) * WN_SLAB, stride, 0, stream);
-        if (rc == GLOWTTS_OK) rc = glowtts_pack_weight_strided(w_end, F, 1, 2 * C2, H, 1, 0, GLOWTTS_PERM_PAIR, C2, GLOWTTS_BF16, img + (int64_t)(36 * (L - 1) + 35) * WN_SLAB, stride, 0, stream);
+        int rc = glowtts_pack_weight_strided(w_start, F, 1, H, C2, 1, 0, GLOWTTS_PERM_NONE, 0, GLOWTTS_BF16, img, stride, 0, 0, stream);
+        if (rc == GLOWTTS_OK) rc = glowtts_pack_weight_strided(w_in, F * L, L, 2 * H, H, WN_TAPS, 0, GLOWTTS_PERM_PAIR, H, GLOWTTS_BF16, img + 2 * WN_SLAB, stride, 36 * (int64_t)WN_SLAB, 0, stream);
+        if (rc == GLOWTTS_OK && L > 1) rc = glowtts_pack_weight_strided(w_rs, F * (L - 1), L - 1, 2 * H, H, 1, 0, GLOWTTS_PERM_PAIR, H, GLOWTTS_BF16, img + 32 * WN_SLAB, stride, 36 * (int64_t)WN_SLAB, 0, stream);
+        if (rc == GLOWTTS_OK) rc = glowtts_pack_weight_strided(w_rs_last, F, 1, H, H, 1, 0, GLOWTTS_PERM_NONE, 0, GLOWTTS_BF16, img + (int64_t)(36 * (L - 1) + 32) * WN_SLAB, stride, 0, 0, stream);
+        if (rc == GLOWTTS_OK) rc = glowtts_pack_weight_strided(w_end, F, 1, 2 * C2, H, 1, 0, GLOWTTS_PERM_PAIR, C2, GLOWTTS_BF16, img + (int64_t)(36 * (L - 1) + 35) * WN_SLAB, stride, 0, 0, stream);
         if (rc != GLOWTTS_OK) return rc;
     }
-    (void)img_bwd;
+    if (img_bwd) return glowtts_wavenet_pack_bwd_images(w_start, w_in, w_rs, w_rs_last, w_end, F, L, C2, img_bwd, stream);
     return GLOWTTS_OK;
 }
 

@@ -108,8 +108,9 @@ TAIL = {"defer": False, "pending": []}
 #   wgrad_wide: 16-byte staging items in the weight-gradient kernel; fuse_coupling_bwd: the next flow's coupling backward rides in the
 #   ActNorm / 1x1 backward pass; wgrad_split: weight gradients in n segments on a second stream (1 = one grouped launch per class);
 #   act_bf16: WaveNet state / gates / gate gradients stored as bf16 in bf16 precision
+#   fused_wn_bwd: its data gradients likewise (csrc/wavenet_fused_bwd.hip; unconditioned models)
 #   fused_wn: the coupling network of a flow (Start .. End + coupling) as ONE launch (csrc/wavenet_fused.hip) where its shape contract holds
-TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True}
+TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": True}
 WN_SLAB = 24576                          # GLOWTTS_WN_SLAB_BYTES
 TAIL_STACKS = ("start_g", "start_v", "start_b", "rs_g", "rs_v", "rs_b", "rsl_g", "rsl_v", "rsl_b", "end_w", "end_b")
 
@@ -285,7 +286,16 @@ class _Prepared:
             }
             if Lw > 1:
                 self.pk["rs"] = PackedBatch(W["w_rs"].reshape(F_ * (Lw - 1), 2 * H, H, 1), False, ops.PERM_NONE, 0, P)
-        if need_bwd:
+        # backward: the transposed image of the fused data-gradient kernel (glowtts_wavenet_bwd) where it applies - no conditioning gradient -
+        # else the per-conv transposed images
+        self.wn_img_t = None
+        if need_bwd and self.wn_img is not None and cond is None and TUNE["fused_wn_bwd"]:
+            self.wn_img_t = torch.empty_like(self.wn_img)
+            _lib.check(L.glowtts_wavenet_pack_images(_lib.ptr(W["w_start"].contiguous()), _lib.ptr(W["w_in"].contiguous()),
+                                                     _lib.ptr(W["w_rs"].contiguous()) if Lw > 1 else None, _lib.ptr(W["w_rs_last"].contiguous()),
+                                                     _lib.ptr(W["w_end"].contiguous()), F_, Lw, C // 2, None, _lib.ptr(self.wn_img_t), _lib.stream()),
+                       "wavenet_pack_images(bwd)")
+        if need_bwd and self.wn_img_t is None:
             self.pk.update({
                 "start_t": PackedBatch(W["w_start"], True, ops.PERM_NONE, 0, P),
                 "in_t": PackedBatch(w_in, True, ops.PERM_PAIR, H, P),
@@ -317,7 +327,8 @@ class _Prepared:
                 else:
                     p.rs[l] = self.pk["rs_last"].at(f)
                     p.b_rs[l] = W["b_rs_last"][f].data_ptr()
-            if need_bwd:
+            p.wn_img_t = self.wn_img_t[f].data_ptr() if self.wn_img_t is not None else None
+            if need_bwd and self.wn_img_t is None:
                 p.start_t = self.pk["start_t"].at(f)
                 p.end_t = self.pk["end_t"].at(f)
                 for l in range(Lw):

@@ -131,9 +131,10 @@ int glowtts_pack_weight_batched(const float *w, int batch, int O, int I, int tap
                                 int precision, void *packed, int *npad_out, int *kchunks_out, void *stream);
 
 /* The same with a two-level destination: weight b (0 <= b < batch) is written at packed + (b / inner) * outer_stride + (b % inner) *
- * inner_stride (bytes) - how glowtts_wavenet_pack_images places every conv of a flow inside that flow's weight image. */
+ * inner_stride (bytes, may be negative) - how glowtts_wavenet_pack_images places every conv of a flow inside that flow's weight image.
+ * w_stride: elements between consecutive source weights (0 = O * I * taps; larger: each weight is the leading [O] slice of a bigger tensor). */
 int glowtts_pack_weight_strided(const float *w, int batch, int inner, int O, int I, int taps, int transpose, int perm, int perm_h,
-                                int precision, void *packed, int64_t outer_stride, int64_t inner_stride, void *stream);
+                                int precision, void *packed, int64_t outer_stride, int64_t inner_stride, int64_t w_stride, void *stream);
 
 #define GLOWTTS_APRO_NONE    0
 #define GLOWTTS_APRO_PAIRMUL 1  /* a[r][c] = A[r][2c] * A[r][2c+1]   (tanh*sigmoid gates, Modules.py:885-887) */
@@ -425,6 +426,13 @@ int glowtts_wavenet_pack_images(const float *w_start, const float *w_in, const f
  * Needs p->wn_img. */
 int glowtts_wavenet_fwd(const glowtts_flow_dims *d, const glowtts_flow_params *p, const glowtts_flow_acts *a,
                         const float *xsrc, float *xdst, int reverse, int keep, void *stream);
+/* Its backward, data gradients only (steps 2-4 of glowtts_flow_backward: End^T, per layer Res_Skip^T + gate derivative + In^T, Start^T), in
+ * ONE launch: reads g->douts_bf (the coupling backward's bf16 d(m, logs)) and a->gates, writes g->dskip, g->dins[l] (PAIR-packed), g->dh[l]
+ * and accumulates d x_a into g->dx - the operands the grouped weight-gradient launches read.  Needs p->wn_img_t (the transposed image:
+ * [End^T 3 slabs][layer L-1 .. 0: Res_Skip^T 3 / 6, In^T tanh-side 15, In^T sigmoid-side 15][Start^T 2]), g->defer_wgrad and no conditioning
+ * gradient (GLOWTTS_E_ARG otherwise: the caller then packs the per-conv images instead). */
+int glowtts_wavenet_bwd(const glowtts_flow_dims *d, const glowtts_flow_params *p, const glowtts_flow_acts *a, const glowtts_flow_grads *g,
+                        void *stream);
 
 /* Diagnostics (no reference counterpart): on != 0 makes the fused kernels wait conservatively (drain their own stores) at every slab instead
  * of with exact operation counts; results must be bit-identical either way (tests/test_gpu_wavenet_fused.py). */
