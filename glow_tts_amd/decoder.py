@@ -108,9 +108,12 @@ TAIL = {"defer": False, "pending": []}
 #   wgrad_wide: 16-byte staging items in the weight-gradient kernel; fuse_coupling_bwd: the next flow's coupling backward rides in the
 #   ActNorm / 1x1 backward pass; wgrad_split: weight gradients in n segments on a second stream (1 = one grouped launch per class);
 #   act_bf16: WaveNet state / gates / gate gradients stored as bf16 in bf16 precision
-#   fused_wn_bwd: its data gradients likewise (csrc/wavenet_fused_bwd.hip; unconditioned models)
+#   fused_wn_bwd: its data gradients likewise (csrc/wavenet_fused_bwd.hip; unconditioned models).  OFF by default: alone it is faster than the
+#       ten launches it replaces (126 vs 155 us per flow, tools/bench_wn.py), inside the training step it is slower (6.33 vs 5.93 ms/step): a
+#       workgroup that owns a whole CU (150 KB of LDS, 3 x 168 VGPRs per SIMD) for 126 us leaves the encoder stream's backward no CU to share,
+#       and that stream stops being hidden
 #   fused_wn: the coupling network of a flow (Start .. End + coupling) as ONE launch (csrc/wavenet_fused.hip) where its shape contract holds
-TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": True}
+TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": False}
 WN_SLAB = 24576                          # GLOWTTS_WN_SLAB_BYTES
 TAIL_STACKS = ("start_g", "start_v", "start_b", "rs_g", "rs_v", "rs_b", "rsl_g", "rsl_v", "rsl_b", "end_w", "end_b")
 

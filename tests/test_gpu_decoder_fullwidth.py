@@ -95,12 +95,11 @@ def test_full_width_backward_bf16_takes_the_benchmarked_kernels(spk_dim):
     L = 4
     assert _count(counts, "wn_fwd<") == N_FLOWS, counts                                   # the fused coupling network: one launch per flow
     assert _count(counts, "conv_dma<GATE,5>") == 0 and _count(counts, "conv_dma<RESSKIP,1>") == 0 and _count(counts, "conv_chain<RESSKIP,COUPLE>") == 0, counts
-    if spk_dim == 0:                                                                      # the fused data-gradient kernel: one launch per flow
-        assert _count(counts, "wn_bwd<") == N_FLOWS and _count(counts, "conv_dma<LINEAR,5>") == 0 and _count(counts, "conv_chain") == 0, counts
-    else:                                                                                 # conditioning gradients: the per-conv backward
-        assert _count(counts, "conv_dma<LINEAR,5>") == N_FLOWS * L, counts                # In_l data gradient
-        assert _count(counts, "conv_dma<DGATE,1>") == N_FLOWS * (L - 1), counts
-        assert _count(counts, "conv_chain<LINEAR,DGATE>") == N_FLOWS, counts
+    # the backward the training step runs by default: per-conv launches (the fused data-gradient kernel, decoder.TUNE["fused_wn_bwd"], has its
+    # own parity tests in tests/test_gpu_wavenet_fused.py and is slower INSIDE the step: DESIGN.md section 5)
+    assert _count(counts, "conv_dma<LINEAR,5>") == N_FLOWS * L, counts                    # In_l data gradient
+    assert _count(counts, "conv_dma<DGATE,1>") == N_FLOWS * (L - 1), counts
+    assert _count(counts, "conv_chain<LINEAR,DGATE>") == N_FLOWS, counts
     assert _count(counts, "wgrad<5,bf16,dybf16,xbf16,wide>/grouped") == 1, counts        # all In_l weight gradients: one grouped launch
     assert _count(counts, "wgrad<1,bf16,dybf16,xbf16,wide>/grouped") == 1, counts        # Res_Skip_l
     assert _count(counts, "wgrad<1,bf16,dyf32,xf32,wide>/grouped") == 1, counts          # Start / End
@@ -148,7 +147,7 @@ def test_full_width_dropout_masks_agree_between_forward_backward_and_precisions(
     torch.manual_seed(6)
     z16c = _hip_grads(*case, precision=1, drop_p=0.3)[0]
     assert torch.equal(z16, z16b) and (z16 - z16c).abs().max() > 1e-2
-    assert _count(counts, "wn_fwd<drop") == N_FLOWS and (_count(counts, "conv_chain<LINEAR,DGATE>") == N_FLOWS if spk_dim else _count(counts, "wn_bwd<drop") == N_FLOWS)
+    assert _count(counts, "wn_fwd<drop") == N_FLOWS and _count(counts, "conv_chain<LINEAR,DGATE>") == N_FLOWS
     mask = O.mask_from_lengths(case[3], TM)
     assert ((z16 - z32) * mask).abs().max() <= 0.15
     worst = (2.0, "")

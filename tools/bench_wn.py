@@ -51,9 +51,40 @@ for fused in (True, False):
             gr.replay()
             e1.record(st)
         torch.cuda.synchronize()
+        fwd_us = e0.elapsed_time(e1) * 1e3 / n
         if fused:
             tl_fused = tl
-        res["fused" if fused else "per-conv"] = e0.elapsed_time(e1) * 1e3 / n
+        # ---- backward of the same flow (data gradients + ActNorm / 1x1 backward; weight gradients deferred as in the training step) ----
+        D.TUNE["fused_wn_bwd"] = fused
+        prepb = D._Prepared(dc, W, need_bwd=True)
+        ldo, ldin, H, C = prepb.ldo, prepb.ldin, dc.H, dc.C
+        dx = torch.randn(R, C, device="cuda") * 0.1
+        gb = D.FlowGrads()
+        douts = torch.zeros(R, ldo, device="cuda"); douts_bf = torch.zeros(R, ldo, device="cuda", dtype=torch.bfloat16)
+        dins = torch.zeros(dc.L, R, ldin, device="cuda", dtype=torch.bfloat16); dskip = torch.empty(R, H, device="cuda", dtype=torch.bfloat16)
+        dh0 = torch.empty(R, H, device="cuda"); dhn = torch.empty(dc.L, R, H, device="cuda", dtype=torch.bfloat16)
+        scratch = torch.empty(L.glowtts_actnorm_stats_scratch_floats(R, C), device="cuda"); dld = torch.zeros(B, device="cuda")
+        gb.dx, gb.dlogdet, gb.douts, gb.dskip, gb.douts_bf = dx.data_ptr(), dld.data_ptr(), douts.data_ptr(), dskip.data_ptr(), douts_bf.data_ptr()
+        gb.scratch, gb.defer_wgrad = scratch.data_ptr(), 1
+        for l in range(dc.L):
+            gb.dh[l] = dh0.data_ptr() if l == 0 else dhn[l].data_ptr()
+            gb.dins[l] = dins[l].data_ptr()
+        runb = lambda: _lib.check(L.glowtts_flow_backward(ctypes.byref(dims), ctypes.byref(prepb.params[0]), ctypes.byref(acts), ctypes.byref(gb), _lib.stream()), "flow_backward")
+        for _ in range(3):
+            runb()
+        torch.cuda.synchronize()
+        gr2 = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(st):
+            with torch.cuda.graph(gr2, stream=st):
+                for _ in range(n):
+                    runb()
+            gr2.replay()
+            e0.record(st)
+            gr2.replay()
+            e1.record(st)
+        torch.cuda.synchronize()
+        res[("fused" if fused else "per-conv") + " bwd"] = e0.elapsed_time(e1) * 1e3 / n
+        res["fused" if fused else "per-conv"] = fwd_us
 if os.environ.get("GLOWTTS_WN_ABL") in ("32", "96", "160"):
     t = tl_fused.view(512, 12, 32)[:200, :, :18].cpu()
     t = (t - t[:, :1, :1]).double().view(200, 12, 6, 3)      # [wg][wave][step][before wait, after wait, after barrier]
