@@ -83,12 +83,18 @@ __global__ __launch_bounds__(WN_NT) void wn_fwd_kernel(const wn_fwd_args p)
 
     // ---- weight stream: slab s -> ring slot s % 4; this wave's two 1-KiB units are rows [32 wave, 32 wave + 32) of the slab ----
     const int lrow = lane >> 2, qa = (lane & 3) ^ ((lane >> 4) & 3);
-    const unsigned char* const wsrc = p.wimg + (uint32_t)((wave * 32 + lrow) * 64 + qa * 16);
+    // LD6 (experiment, ABL & 256): only waves 0..5 - the older half, which the arbiter favours and which otherwise idles ~480 clocks at every
+    // slab barrier - issue DMAs (four units each); the younger half, last in line for the matrix pipe, is spared the ~300 clocks of DMA issue
+    constexpr bool LD6 = (ABL & 256) != 0;
+    constexpr int DPS = LD6 ? 4 : 2;                           // DMA instructions per slab of an issuing wave
+    const unsigned char* const wsrc = p.wimg + (uint32_t)((wave * (16 * DPS) + lrow) * 64 + qa * 16);
     auto issue = [&](int s) __attribute__((always_inline)) {
+        if (LD6 && wave >= 6) return;
         const unsigned char* src = wsrc + (size_t)s * WN_SLAB;
-        unsigned char* dst = wn_smem + OFF_RING + (s & (WN_NS - 1)) * WN_SLAB + wave * 2048;
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + 1024), (void __attribute__((address_space(3)))*)(dst + 1024), 16, 0, 0);
+        unsigned char* dst = wn_smem + OFF_RING + (s & (WN_NS - 1)) * WN_SLAB + wave * (1024 * DPS);
+#pragma unroll
+        for (int u = 0; u < DPS; ++u)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + u * 1024), (void __attribute__((address_space(3)))*)(dst + u * 1024), 16, 0, 0);
     };
     int snext = 0;                                             // slab being multiplied
     bool stamp_on = false; int stamp_base = (blockIdx.x * WN_NW + wave) * 32;      // (ABL & 32)
@@ -110,15 +116,15 @@ __global__ __launch_bounds__(WN_NT) void wn_fwd_kernel(const wn_fwd_args p)
         if constexpr ((ABL & 32) != 0) {                       // per-wave step anatomy (tools/bench_wn.py): before wait / after wait / after barrier
             const bool on = stamp_on;
             if (on && lane == 0) p.tl[stamp_base + 0] = (long long)__builtin_readcyclecounter();
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * DPS) : "memory");
             if (on && lane == 0) p.tl[stamp_base + 1] = (long long)__builtin_readcyclecounter();
             asm volatile("s_barrier" ::: "memory");
             if (on && lane == 0) p.tl[stamp_base + 2] = (long long)__builtin_readcyclecounter();
             if (on) stamp_base += 3;
             return wn_smem + OFF_RING + (snext & (WN_NS - 1)) * WN_SLAB;
         }
-        if (X == 0 || p.safe_waits) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(4 + X) : "memory");
+        if (X == 0 || p.safe_waits) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(2 * DPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(2 * DPS + X) : "memory");
         return wn_smem + OFF_RING + (snext & (WN_NS - 1)) * WN_SLAB;
     };
     constexpr int XG = 16;                                     // stores of a gate / last Res_Skip epilogue (one per accumulator register)
@@ -484,12 +490,12 @@ __global__ __launch_bounds__(WN_NT) void wn_fwd_kernel(const wn_fwd_args p)
     for (int j = 0; j < 3; ++j) {                              // the last three slabs: the ring drains
         // behind these slabs' DMAs: the XG skip stores of the last epilogue and the 16 x_b loads
         if (p.safe_waits) {
-            if (j == 0)      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else if (j == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (j == 0)      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(2 * DPS) : "memory");
+            else if (j == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(DPS) : "memory");
             else             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
-            if (j == 0)      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(4 + XG + 16) : "memory");
-            else if (j == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(2 + XG + 16) : "memory");
+            if (j == 0)      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(2 * DPS + XG + 16) : "memory");
+            else if (j == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(DPS + XG + 16) : "memory");
             else             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(XG + 16) : "memory");
         }
         const unsigned char* slot = wn_smem + OFF_RING + (snext & (WN_NS - 1)) * WN_SLAB;
@@ -554,6 +560,8 @@ int launch_wn_fwd(const wn_fwd_args& k, dim3 grid, hipStream_t s)
             case 128: return launch_wn_fwd<DROP, COND, 128>(k, grid, s);
             case 96: return launch_wn_fwd<DROP, COND, 96>(k, grid, s);
             case 160: return launch_wn_fwd<DROP, COND, 160>(k, grid, s);
+            case 256: return launch_wn_fwd<DROP, COND, 256>(k, grid, s);
+            case 288: return launch_wn_fwd<DROP, COND, 288>(k, grid, s);
             default: break;
         }
     }

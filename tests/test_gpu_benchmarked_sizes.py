@@ -1,0 +1,174 @@
+"""GPU parity AT THE BENCHMARKED SIZES: what bench.py times must also be what the oracle checks.
+
+(a) BASELINE config 2 exactly - the default Hyper_Parameters.yaml model, B = 32, 800 frames / 120 tokens, fixed lengths (Set F) and one
+    ragged batch (Set V) - through `GlowTTS.forward` + `MLE_Loss` + backward (Modules.py:50-126, 1020-1029; Train.py:193-216) against
+    `oracle.forward_train` on the same state dict.  At B = 32 the row tiles of every decoder kernel straddle utterances, the fused
+    coupling-network kernel runs its 249-workgroup shape and the LDS-DMA convs their 10-wave one.
+      f32 : alignment bit-exact, |NLL - oracle| <= 1e-3 (north_star), every parameter gradient within 1e-2 of the tensor's largest entry
+            (5e-3 at B = 4; at B = 32 the fp32 oracle's own summation noise reaches 7e-3, measured against a float64 run).
+      bf16: |NLL - oracle| <= 1e-3, <= 2 % of the frames aligned differently, decoder gradient cosines >= 0.995, norm ratios 0.97..1.03.
+(b) The full-size SE (LUT, 109 speakers) and PE (GST prosody encoder) models, B = 4 ragged, same bars (f32) - the conditioning path of
+    configs 3 and 5 at real width.
+(c) tests/longform_check.py (child process: it captures hipGraphs): long-form inverse flow at full width, 2 utterances x > 2000 frames,
+    `GlowTTS.inference` and `GraphedInference` against `oracle.inference` with injected noise (Modules.py:128-204)."""
+import copy
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oracle import glowtts_ref as O
+
+pytestmark = pytest.mark.gpu
+TT, TM = 120, 800
+
+
+def _hp(mode, precision):
+    from glow_tts_amd import hparams
+    d = copy.deepcopy(hparams.load_yaml(hparams.DEFAULT_YAML))
+    d["Mode"] = mode
+    d["HIP_Precision"] = precision
+    d["Speaker_Embedding"]["Type"] = "LUT"
+    return d
+
+
+def _build(mode, precision, sd=None):
+    from glow_tts_amd.hparams import Recursive_Parse
+    from glow_tts_amd.modules import GlowTTS
+    model = GlowTTS(Recursive_Parse(_hp(mode, precision)))
+    if sd is not None:
+        model.load_state_dict(sd, strict=True)
+        for f in model.layer_Dict["Decoder"].layer_Dict["Flows"]:
+            f.layers[0].initialized = True
+    return model
+
+
+def make_case(mode, tok_len, mel_len, seed):
+    """Seeded full-size model (End conv not zero, Modules.py:773-778 would hide the WaveNet), ActNorm initialised from the batch by the
+    f32 HIP path; oracle outputs, losses and gradients on the same state dict and batch."""
+    B = len(tok_len)
+    torch.manual_seed(seed)
+    model = _build(mode, "f32")
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for f in model.layer_Dict["Decoder"].layer_Dict["Flows"]:
+            end = f.layers[2].layer_Dict["End"]
+            end.weight.copy_(torch.randn(end.weight.shape, generator=g) * 0.02)
+            end.bias.copy_(torch.randn(end.bias.shape, generator=g) * 0.02)
+            f.layers[1].weight.add_(0.05 * torch.randn(4, 4, generator=g))
+    tokens = torch.randint(0, 35, (B, TT), generator=g)
+    mels = (torch.randn(B, 80, TM, generator=g) * 1.5).clamp(-4, 4)
+    tl, ml = torch.tensor(tok_len), torch.tensor(mel_len)
+    for b in range(B):                                   # the reference's padding (Datasets.py:225-250)
+        tokens[b, tok_len[b]:] = 1
+        mels[b, :, mel_len[b]:] = -4.0
+    spk = torch.randint(0, 109, (B,), generator=g) if mode == "SE" else None
+    model = model.cuda().eval()
+    with torch.no_grad():
+        model(tokens.cuda(), tl.cuda(), mels.cuda(), ml.cuda(), spk.cuda() if spk is not None else None, None, None)      # ActNorm data init
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    cfg = O.Cfg.from_yaml_dict(_hp(mode, "f32"))
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    out = O.forward_train(sdg, cfg, tokens, tl, mels, ml, spk)
+    mle, length = O.train_losses(out, ml, cfg)
+    (mle + length).backward()
+    return dict(mode=mode, sd=sd, tokens=tokens, tl=tl, mels=mels, ml=ml, spk=spk, out={k: v.detach() for k, v in out.items() if v is not None},
+                mle=mle.item(), length=length.item(), grads={k: v.grad for k, v in sdg.items() if v.grad is not None})
+
+
+def run_hip(case, precision):
+    from glow_tts_amd.modules import MLE_Loss
+    model = _build(case["mode"], precision, case["sd"]).cuda().eval()
+    c = lambda k: case[k].cuda()
+    z, mm, ms, ld, dur, durt, attn, _ = model(c("tokens"), c("tl"), c("mels"), c("ml"), c("spk") if case["spk"] is not None else None, None, None)
+    mle = MLE_Loss(model.hp)(z=z, mean=mm, std=ms, log_dets=ld, lengths=c("ml"))
+    length = torch.nn.functional.mse_loss(dur, durt)
+    (mle + length).backward()
+    torch.cuda.synchronize()
+    cpu = lambda t: t.detach().cpu()
+    return dict(z=cpu(z), log_dets=cpu(ld), attn=cpu(attn), mle=mle.item(), length=length.item(),
+                grads={k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None})
+
+
+def check_f32(case, r, grad_tol=5e-3):
+    o = case["out"]
+    mmask = O.mask_from_lengths(case["ml"], TM)
+    assert torch.equal(r["attn"], o["attn"]), f"{(r['attn'] != o['attn']).any(1).sum().item()} frames aligned differently"
+    assert ((r["z"] - o["z"]) * mmask).abs().max() <= 1e-3
+    assert abs(r["mle"] - case["mle"]) <= 1e-3 and abs(r["length"] - case["length"]) <= 1e-3, (r["mle"], case["mle"])
+    worst = ("", 0.0)
+    for k, want in case["grads"].items():
+        got = r["grads"].get(k)
+        got = got if got is not None else torch.zeros_like(want)
+        err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-6)
+        worst = max(worst, (k, err), key=lambda t: t[1])
+        assert err <= grad_tol, (k, err)
+    print(f"f32 {case['mode']} B={len(case['tl'])}: NLL {r['mle']:.6f} vs oracle {case['mle']:.6f}; worst gradient {worst}")
+
+
+def check_bf16(case, r):
+    o = case["out"]
+    mmask = O.mask_from_lengths(case["ml"], TM)
+    differ = ((r["attn"] != o["attn"]).any(1).float() * mmask[:, 0]).sum().item() / mmask.sum().item()
+    assert abs(r["mle"] - case["mle"]) <= 1e-3, (r["mle"], case["mle"])
+    assert differ <= 0.02, differ                     # (random-init scores are near-ties: 0.94 % at B = 32 Set F, 0 % at B = 4)
+    assert ((r["z"] - o["z"]) * mmask).abs().max() <= 0.1
+    rep = []
+    for k, want in case["grads"].items():
+        if "Decoder" not in k:
+            continue
+        a, b = r["grads"][k].flatten().double(), want.flatten().double()
+        rep.append(((a @ b / (a.norm() * b.norm() + 1e-30)).item(), (a.norm() / (b.norm() + 1e-30)).item(), k))
+    rep.sort()
+    print(f"bf16 {case['mode']} B={len(case['tl'])}: |dNLL| {abs(r['mle'] - case['mle']):.2e}, frames aligned differently {100 * differ:.3f} %, worst decoder gradients {rep[:2]}")
+    for cos, ratio, k in rep:
+        assert cos >= 0.995 and 0.97 <= ratio <= 1.03, (k, cos, ratio)
+
+
+def _set_v(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    ml = (torch.randint(200, 801, (B,), generator=g) // 2 * 2).tolist()
+    ml[0] = 800
+    tl = [max(8, min(120, int(m * 120 / 800 + torch.randint(-6, 7, (1,), generator=g).item()))) for m in ml]
+    tl[0] = 120
+    return tl, ml
+
+
+@pytest.fixture(scope="module", params=["set_f", "set_v"])
+def config2_case(request):
+    B = 32
+    tl, ml = ([120] * B, [800] * B) if request.param == "set_f" else _set_v(B, 5)
+    return make_case("Vanilla", tl, ml, 2025)
+
+
+def test_config2_batch32_f32(config2_case):
+    # gradient bar 1e-2 at B = 32: the fp32 ORACLE is the noisy side here - tools/grad_noise_check.py (oracle re-run in float64 on the Set V
+    # case): FFN Conv_0 weight gradient oracle-f32 vs f64 7.1e-3 of the largest entry, this path's f32 vs f64 6.1e-4 (B = 4 cases keep 5e-3)
+    check_f32(config2_case, run_hip(config2_case, "f32"), grad_tol=1e-2)
+
+
+def test_config2_batch32_bf16(config2_case):
+    from glow_tts_amd import _lib
+    from helpers import launch_counts, launch_reset
+    launch_reset()
+    r = run_hip(config2_case, "bf16")
+    counts = launch_counts()
+    assert sum(n for k, n in counts.items() if k.startswith("wn_fwd<")) == 12, counts      # the benchmarked forward kernel served it
+    check_bf16(config2_case, r)
+
+
+@pytest.mark.parametrize("mode", ["SE", "PE"])
+def test_full_size_conditioned_models(mode):
+    case = make_case(mode, [120, 104, 75, 31], [800, 702, 500, 210], 99)
+    check_f32(case, run_hip(case, "f32"))
+    check_bf16(case, run_hip(case, "bf16"))
+
+
+def test_long_form_inverse_at_full_width():
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "longform_check.py")], capture_output=True, text=True, timeout=1200, cwd=os.path.dirname(here))
+    assert out.returncode == 0 and "LONGFORM OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+    print(out.stdout[-600:])

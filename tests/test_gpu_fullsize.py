@@ -8,7 +8,7 @@ f32 mode (the reference's arithmetic; north_star bar "mel / NLL within 1e-3 fp32
    gradient of (MLE + duration loss) within 5e-3 of the oracle's (relative to the tensor's largest entry).
 bf16 mode (the benchmarked dtype: bf16 MFMA operands and bf16-stored WaveNet state / gates, fp32 everything else):
    |NLL - oracle| <= 1e-3, per-utterance log-determinant <= 1e-3 relative, fraction of frames whose alignment differs reported and
-   bounded, decoder gradients cosine >= 0.95.  A miss here is a finding to fix, not a tolerance to loosen."""
+   bounded, decoder gradients cosine >= 0.995, norm ratio 0.97..1.03.  A miss here is a finding to fix, not a tolerance to loosen."""
 import copy
 
 import numpy as np
@@ -142,7 +142,7 @@ def test_full_size_bf16_nll_within_1e3(case):
     report.sort()
     print("bf16 full size, worst decoder gradient tensors (cosine, norm ratio):", report[:3])
     for cos, ratio, k in report:
-        assert cos >= 0.95 and 0.85 <= ratio <= 1.15, (k, cos, ratio)
+        assert cos >= 0.995 and 0.97 <= ratio <= 1.03, (k, cos, ratio)      # (observed 0.9999 / 1.00: a regression to 0.99 is a finding)
 
 
 def test_reference_maximum_sizes_f32(case):

@@ -31,7 +31,7 @@ for fused in (True, False):
         _, rowmask, T = D.squeeze_rows(dc, mels, ml, out=buf.x[0])
         acts = buf.acts(0, dc.L, rowmask)
         tl = torch.zeros(512 * 12 * 32, dtype=torch.int64, device="cuda")
-        if os.environ.get("GLOWTTS_WN_ABL") in ("16", "32", "96", "160") and fused:
+        if os.environ.get("GLOWTTS_WN_ABL") in ("16", "32", "96", "160", "288") and fused:
             acts.skip_bf = tl.data_ptr()
         dims = D._dims(dc, B, T, DROP, seed if DROP > 0 else None, 0)
         run = lambda: _lib.check(L.glowtts_flow_forward(ctypes.byref(dims), ctypes.byref(prep.params[0]), ctypes.byref(acts), _lib.stream()), "flow_forward")
@@ -85,7 +85,7 @@ for fused in (True, False):
         torch.cuda.synchronize()
         res[("fused" if fused else "per-conv") + " bwd"] = e0.elapsed_time(e1) * 1e3 / n
         res["fused" if fused else "per-conv"] = fwd_us
-if os.environ.get("GLOWTTS_WN_ABL") in ("32", "96", "160"):
+if os.environ.get("GLOWTTS_WN_ABL") in ("32", "96", "160", "288"):
     t = tl_fused.view(512, 12, 32)[:200, :, :18].cpu()
     t = (t - t[:, :1, :1]).double().view(200, 12, 6, 3)      # [wg][wave][step][before wait, after wait, after barrier]
     print("In_1, tap 2, steps kc = 0..5; clocks, median over 200 workgroups")
