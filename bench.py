@@ -159,7 +159,54 @@ def hot_kernel_cases(precision, B, T):
                                 rowmask=rowmask, in0=dnext, ldi0=H, out0=dh, ld0=H, io_flags=io2),
         flops=flops, alg_bytes=B * T * (2 * H * es + H * es + H * es) + wbytes,
         kernel=("conv_dma_kernel<EPI_LINEAR, 5>" if bf else "conv_cl_kernel<float, EPI_LINEAR, 5>") + " (WaveNet In_l data gradient, 384->192)")
+    if bf:
+        cases["wn_fwd"] = fused_forward_case(B, T)
     return cases
+
+
+def fused_forward_case(B, T):
+    """The fused coupling-network forward (csrc/wavenet_fused.hip: Start .. End + affine coupling of ONE flow, kept activations written),
+    launched alone through the C ABI.  Algorithmic FLOPs per valid row: 2 x (80 x 192 + 4 x 192 x 384 x 5 + 3 x 192 x 384 + 192 x 192 +
+    192 x 160) = 3 557 376 (the halo rows the kernel recomputes are NOT counted); algorithmic bytes per valid row: 640 read (flow input)
+    + 320 (x_b') + 4 x (384 + 768 + 384) (kept x_l, gate pairs, tanh * sigmoid, bf16) + 768 (skip) + 640 (m, logs) written, + the 3.6 MB
+    weight image once."""
+    import ctypes
+    from glow_tts_amd import _lib, decoder as D, ops
+    dev = "cuda"
+    g = torch.Generator().manual_seed(5)
+    cfgd = D.DecoderConfig(80, 1, 2, 4, 192, 4, 5, ops.BF16)
+    H, C, Lw, k = 192, 160, 4, 5
+    rn = lambda *sh, s=1.0: (torch.randn(*sh, generator=g) * s).to(dev)
+    W = {"an_logs": rn(1, C, s=0.1), "an_bias": rn(1, C, s=0.1), "inv_w": torch.eye(4).unsqueeze(0).to(dev),
+         "w_start": rn(1, H, C // 2, 1, s=(C // 2) ** -0.5), "b_start": rn(1, H, s=0.05),
+         "w_in": rn(1, Lw, 2 * H, H, k, s=(H * k) ** -0.5), "b_in": rn(1, Lw, 2 * H, s=0.05),
+         "w_rs": rn(1, Lw - 1, 2 * H, H, 1, s=H ** -0.5), "b_rs": rn(1, Lw - 1, 2 * H, s=0.05),
+         "w_rs_last": rn(1, H, H, 1, s=H ** -0.5), "b_rs_last": rn(1, H, s=0.05), "w_end": rn(1, C, H, 1, s=0.02), "b_end": rn(1, C, s=0.02)}
+    prep = D._Prepared(cfgd, W, need_bwd=False)
+    if prep.wn_img is None:
+        raise RuntimeError("fused coupling-network kernel not selected (decoder.TUNE['fused_wn'] off?)")
+    R = B * (T + 4)
+    buf = D._Buffers(cfgd, prep, R, dev)
+    mels = rn(B, 80, 2 * T)
+    _, rowmask, _ = D.squeeze_rows(cfgd, mels, torch.full((B,), 2 * T, device=dev), out=buf.x[0])
+    buf.xmid[0].copy_(buf.x[0])
+    acts = buf.acts(0, Lw, rowmask)
+    seed = torch.tensor([7], device=dev, dtype=torch.int32)
+    dims = D._dims(cfgd, B, T, 0.05, seed, 0)
+    Lb = D._L()
+    Lb.glowtts_wavenet_fwd.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    keep = (prep, buf, rowmask, seed, W)
+
+    def run(keep=keep):
+        _lib.check(Lb.glowtts_wavenet_fwd(ctypes.byref(dims), ctypes.byref(prep.params[0]), ctypes.byref(acts), buf.xmid[0].data_ptr(),
+                                          buf.x[1].data_ptr(), 0, 1, _lib.stream()), "glowtts_wavenet_fwd")
+    per_row = 2.0 * (80 * H + Lw * H * 2 * H * k + (Lw - 1) * H * 2 * H + H * H + H * C)
+    return dict(run=run, flops=B * T * per_row, alg_bytes=B * T * (640 + 320 + Lw * (384 + 768 + 384) + 768 + 640) + (36 * Lw + 2) * 24576,
+                kernel="wn_fwd_kernel<drop> (fused coupling network of one flow: Start + 4 x [In_l k=5 + gate + Res_Skip_l] + End + coupling)")
+
+
+# launches per training step of config 2 (12 flows x 4 layers; the fused forward replaced the In_l forward launches)
+CALLS_PER_STEP = {"wn_fwd": 12, "in_dgrad": 48, "in_fwd": 0}
 
 
 def time_kernel(run, iters=30):
@@ -205,8 +252,8 @@ def sustained_mfma_clock():
 
 
 def roofline(precision, B, T, step_tflops):
-    """The dominant kernel by time (profiles/*_kernel_stats.csv): `achieved` = algorithmic FLOPs per launch (2 x valid rows x 384 x 192 x 5,
-    DESIGN.md section 4) / its launch duration, timed here with HIP events over back-to-back launches on the launch stream (the
+    """The dominant kernel by time in the step (launch duration x launches per step; profiles/*_kernel_stats.csv): `achieved` = algorithmic
+    FLOPs per launch (valid rows only: fused_forward_case / 2 x rows x 384 x 192 x 5 for the In_l data gradient) / its launch duration, timed here with HIP events over back-to-back launches on the launch stream (the
     rocprofv3 average inside the running step, where launches are not back to back, is a few percent longer: profiles/)."""
     peak = PEAK_TFLOPS[precision]
     cases = hot_kernel_cases(precision, B, T)
@@ -218,7 +265,10 @@ def roofline(precision, B, T, step_tflops):
         tr = pmc.get(name, {}).get("traffic") if (pmc and pmc.get("shape") == [B, T] and pmc.get("precision") == precision) else None
         rows[name] = {"kernel": c["kernel"], "achieved": round(ach, 1), "frac": round(ach / peak, 4), "us_per_launch": round(sec * 1e6, 2),
                       "algorithmic_bytes": int(c["alg_bytes"]), "traffic": tr}
-    top = max(rows.values(), key=lambda r: r["us_per_launch"])
+    for name, r in rows.items():
+        r["launches_per_step"] = CALLS_PER_STEP.get(name, 0)
+        r["us_per_step"] = round(r["us_per_launch"] * r["launches_per_step"], 1)
+    top = max(rows.values(), key=lambda r: r["us_per_step"])          # the dominant kernel BY TIME IN THE STEP
     out = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": top["frac"],
            "us_per_launch": top["us_per_launch"], "traffic": top["traffic"], "algorithmic_bytes": top["algorithmic_bytes"],
            "traffic_source": src if top["traffic"] is not None else None,
@@ -233,12 +283,19 @@ def roofline(precision, B, T, step_tflops):
     return out
 
 
-def mas_us_per_utt(B, Tx, Ty, iters=30):
+def mas_us_per_utt(B, Tx, Ty, iters=30, ragged=False):
+    """Transposed DP + dense path (what the training step runs), us per utterance.  ragged: Set V lengths (synthetic_batch's)."""
     from glow_tts_amd import alignment
     g = torch.Generator().manual_seed(1234)
     v = (torch.randn(B, Ty, Tx, generator=g) * 30 - 100).cuda()
-    tx = torch.full((B,), Tx, dtype=torch.long, device="cuda")
-    ty = torch.full((B,), Ty, dtype=torch.long, device="cuda")
+    if ragged:
+        ty = (2 * torch.randint(300, 501, (B,), generator=g).clamp(max=Ty // 2)).clamp(max=Ty)
+        tx = torch.round(0.15 * ty).long().clamp(min=1, max=Tx)
+        ty[0], tx[0] = Ty, Tx
+        tx, ty = tx.cuda(), ty.cuda()
+    else:
+        tx = torch.full((B,), Tx, dtype=torch.long, device="cuda")
+        ty = torch.full((B,), Ty, dtype=torch.long, device="cuda")
     from glow_tts_amd.monotonic_align import path_from_idx
     for _ in range(3):
         path_from_idx(alignment.maximum_path_t(v, tx, ty), Tx)
@@ -250,6 +307,15 @@ def mas_us_per_utt(B, Tx, Ty, iters=30):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / iters / B
+
+
+def mas_keys(B, Tx, Ty):
+    """MAS timings beside the headline `mas_us_per_utt` (fixed-length Set F at the bench batch): ragged Set V, the latency of a
+    single utterance, and the throughput at B = 256; 200 x 1000 is the reference's maximum text / mel size (Hyper_Parameters.yaml:94-99)."""
+    return {"set_v_us_per_utt": round(mas_us_per_utt(B, Tx, Ty, ragged=True), 3),
+            "latency_us_b1": round(mas_us_per_utt(1, Tx, Ty), 2),
+            "b256_us_per_utt": round(mas_us_per_utt(256, Tx, Ty, iters=10), 3),
+            "max_size_200x1000_us_per_utt": round(mas_us_per_utt(B, 200, 1000), 3)}
 
 
 def cpu_baseline():
@@ -299,13 +365,17 @@ def cpu_baseline():
         torch.set_num_threads(n)
         sweep[n] = min(step(small)[0], step(small)[0])
     best_n = min(sweep, key=sweep.get)
-    torch.set_num_threads(best_n)
-    step(full)
-    times, out = [], None
-    for _ in range(2):
-        t, out = step(full)
-        times.append(t)
-    best = min(times)
+
+    def timed(n_threads, reps=5):                      # >= 5 timed steps after a warm-up, median
+        torch.set_num_threads(n_threads)
+        step(full)
+        ts, out = [], None
+        for _ in range(reps):
+            t, out = step(full)
+            ts.append(t)
+        return statistics.median(ts), min(ts), max(ts), out
+    med, lo, hi, out = timed(best_n)
+    at8 = timed(8) if best_n != 8 and physical >= 8 else (med, lo, hi, out)
     # MAS alone on the same batch's log-prior matrix: C restatement of core.pyx (kernel only; with the wrapper's host copies), Python loop
     logp = out["logp"].detach()
     tmask, mmask = O.mask_from_lengths(full[1], Tt), O.mask_from_lengths(full[3], Tm)
@@ -315,14 +385,48 @@ def cpu_baseline():
     t0 = time.time(); mas_ref.maximum_path_c(v, tx, ty); c_kernel = time.time() - t0
     t0 = time.time(); O.mas(logp, amask); c_wrapped = time.time() - t0
     t0 = time.time(); mas_ref.maximum_path_python(v[:2], tx[:2], ty[:2]); py_utt = (time.time() - t0) / 2
-    py_step = best - c_wrapped + 8 * py_utt          # the same step with the Python-loop MAS (config 1 as BASELINE.json states it)
-    return {"value": round(8 * Tm / best, 1), "unit": "mel-frames/s", "cores": best_n, "kind": "port",
-            "sample": f"oracle (torch fp32 + C MAS = core.pyx semantics), Vanilla B=8 T_mel=800 T_tok=120, fwd+losses+bwd, best of 2 steps after 1 "
-                      f"warm-up at {best_n} intra-op threads ({best:.2f} s/step); thread sweep on a B=2 sample, s/step: "
+    # config 1 as BASELINE.json states it ("Python MAS"): the same step with the Python-loop search of Modules.py:951-980, TIMED (3 steps)
+    torch.set_num_threads(best_n)
+    c_mas = O.mas
+
+    def python_mas(value, mask, max_neg_val=-1e9):
+        vv = (value * mask).detach().numpy().astype(np.float32)
+        txs = mask.sum(1)[:, 0].numpy().astype(np.int32)
+        tys = mask.sum(2)[:, 0].numpy().astype(np.int32)
+        return torch.from_numpy(np.ascontiguousarray(mas_ref.maximum_path_python(vv, txs, tys))).to(value.dtype)
+    py_steps = []
+    try:
+        O.mas = python_mas
+        for _ in range(3):
+            py_steps.append(step(full)[0])
+    finally:
+        O.mas = c_mas
+    py_step = statistics.median(py_steps)
+    return {"value": round(8 * Tm / med, 1), "unit": "mel-frames/s", "cores": best_n, "kind": "port",
+            "sample": f"oracle (torch fp32 + C MAS = core.pyx semantics), Vanilla B=8 T_mel=800 T_tok=120, fwd+losses+bwd, MEDIAN of 5 steps after 1 "
+                      f"warm-up at {best_n} intra-op threads ({med:.3f} s/step, min {lo:.3f}, max {hi:.3f}); thread sweep on a B=2 sample, s/step: "
                       + ", ".join(f"{n}: {t:.2f}" for n, t in sweep.items()) + f"; host has {physical} physical / {logical} logical cores",
-            "value_python_mas": round(8 * Tm / py_step, 1),
+            "value_at_8_threads": round(8 * Tm / at8[0], 1), "s_per_step_at_8_threads": round(at8[0], 3),
+            "value_python_mas": round(8 * Tm / py_step, 1), "s_per_step_python_mas": round(py_step, 3),
+            "python_mas_sample": "the same step with Modules.py:951-980's Python-loop search, median of 3 timed steps",
             "mas_us_per_utt": {"c_kernel": round(c_kernel / 8 * 1e6, 1), "c_with_wrapper_copies": round(c_wrapped / 8 * 1e6, 1),
                                "python_loop": round(py_utt * 1e6, 1)}}
+
+
+def f32_key(args):
+    """north_star states its tolerance in fp32: the same step in `HIP_Precision: f32` (exact fp32 MFMA, v_mfma_f32_32x32x2_f32, the arithmetic the
+    1e-3 / 1e-4 parity tests run in), timed by a child process so that its model and graph do not share this one's memory."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--precision", "f32", "--steps", "5", "--warmup", "3", "--windows", "0", "--no-cpu-baseline",
+           "--no-f32-key", "--config", str(args.config)] + (["--batch", str(args.batch)] if args.batch else [])
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        return {"ms_per_step": d["ms_per_step"], "value": d["value"], "model_tflops": d["model_tflops"],
+                "step_frac": round(d["model_tflops"] / PEAK_TFLOPS["f32"], 4), "peak": PEAK_TFLOPS["f32"],
+                "note": "whole Train_Step in exact-fp32 MFMA arithmetic; frac against the 157.3 TFLOP/s fp32 matrix peak"}
+    except Exception as exc:                                    # noqa: BLE001
+        return {"error": f"{type(exc).__name__}: {exc}"}
 
 
 def inverse_flow_leg(model, hp, dev, B, seed):
@@ -366,6 +470,7 @@ def main():
     ap.add_argument("--windows", type=int, default=10, help="extra timed windows of --steps steps after the reported one (median / spread keys)")
     ap.add_argument("--tokens", type=int, default=120, help="padded token length (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-key", action="store_true", help="skip the extra `f32` key (the same step in HIP_Precision f32, timed in a child process)")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward + losses + backward only (round 1's definition of the step); "
                     "default: the whole Train_Step of Train.py:193-233 including clip_grad_norm_, RAdam and the Noam schedule")
     ap.add_argument("--tune", action="append", default=[], help="A/B measurements: key=value entries of glow_tts_amd.decoder.TUNE (e.g. wgrad_wide=0)")
@@ -656,6 +761,7 @@ def main():
                         "ms_per_step_min": round(min(ms), 3), "ms_per_step_max": round(max(ms), 3)},
             "model_tflops": round(tflops, 2),
             "mas_us_per_utt": round(mas_us_per_utt(B, Tt, Tm), 3),
+            "mas": mas_keys(B, Tt, Tm),
             "roofline": roofline(args.precision, B, Tm // 2, tflops / world),
         }
         if fwd_bwd_only is not None:
@@ -665,6 +771,8 @@ def main():
             out["inverse_flow"] = inv
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        if args.precision == "bf16" and not dp and not args.no_f32_key and args.config == 2 and opt is not None:
+            out["f32"] = f32_key(args)
     # The JSON line must be the LAST line of the job's stdout.  RCCL writes a banner ("Librccl path : ...") through C stdio, which a pipe
     # buffers until exit, i.e. behind Python's own output: every rank flushes its C buffers, the ranks meet once more, then rank 0 prints.
     import ctypes

@@ -40,9 +40,9 @@ out = {"shape": [32, 400], "precision": "bf16", "units": "bytes per launch",
                  "requests tallied at 64 B, MI355X_MICROARCH.md); WRITE_SIZE x 1024 x the factor that makes a 1 GiB fill read 1 GiB",
        "calibration": {"fill_1GiB_WRITE_SIZE_KiB": fill_w, "write_factor": wcal, "mul_1GiB_FETCH_SIZE_KiB": mul_r,
                        "mul_fetch_bytes_after_x2_over_1GiB": (mul_r * 2048 / GiB) if mul_r else None, "mul_1GiB_WRITE_SIZE_KiB": mul_w}}
-for name, subs in (("in_fwd", ("conv_dma_kernel", "Li1ELi5E")), ("in_dgrad", ("conv_dma_kernel", "Li0ELi5E"))):
+for name, subs in (("in_fwd", ("conv_dma_kernel", "Li1ELi5E")), ("in_dgrad", ("conv_dma_kernel", "Li0ELi5E")), ("wn_fwd", ("wn_fwd_kernel",))):
     f, w = pick(fetch, *subs), pick(write, *subs)
-    if f is None:      # demangled names
+    if f is None and name != "wn_fwd":      # demangled names
         subs2 = ("conv_dma_kernel<1, 5", ) if name == "in_fwd" else ("conv_dma_kernel<0, 5", )
         f, w = pick(fetch, *subs2), pick(write, *subs2)
     if f is not None and w is not None:

@@ -13,10 +13,10 @@ import csv, glob, sys, collections
 tag, repo = sys.argv[1], sys.argv[2]
 f = glob.glob(f"/tmp/prof_{tag}/**/*kernel_stats.csv", recursive=True)
 rows = list(csv.DictReader(open(f[0])))
-# steps traced: warm-up eager steps + capture passes + replays; normalise by the call count of a once-per-step kernel (the MAS search)
-mas = [r for r in rows if "mas_dp_kernel" in r["Name"]]
-steps = float(mas[0]["Calls"]) - 33.0 if mas else 1.0          # bench.py's MAS micro-benchmark adds 33 calls
-steps = max(steps, 1.0)
+# steps traced = launches of a kernel that runs exactly once per step and in none of bench.py's micro-benchmarks: the RAdam update
+# (eager warm-up steps and graph replays alike; the capture pass launches nothing)
+one = [r for r in rows if "radam_kernel" in r["Name"]]
+steps = max(float(one[0]["Calls"]) if one else 1.0, 1.0)
 out = [("Name", "CallsPerStep", "TotalDurationNsPerStep", "AverageNs", "Percentage")]
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
