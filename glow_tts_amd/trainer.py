@@ -182,13 +182,53 @@ class Trainer:
                 return
         self.epochs += hp.Train.Train_Pattern.Accumulated_Dataset_Epoch
 
-    # ------------------------------------------------------------------ Train.py:266-355 (losses only: the image / histogram logging is out of scope)
+    # ------------------------------------------------------------------ Train.py:266-316
     @torch.no_grad()
     def Evaluation_Step(self, *batch):
+        """Losses of `GlowTTS.forward` on a development batch AND `GlowTTS.inference` on the same batch (Train.py:279-316: the reference runs both
+        on every dev batch; its TensorBoard images of the last batch are out of scope - the tensors are returned and kept in `last_Evaluation`)."""
         inputs = self._batch_to_device(batch)
-        _, comp = self._losses(self.model_Dict["GlowTTS"], *inputs)
-        for tag, v in zip(("MLE", "Length", "Total", "Speaker"), comp.unbind(0)):
+        model = self.model_Dict["GlowTTS"]
+        tokens, token_lengths, mels, mel_lengths, speakers, ge2e, pitches = inputs
+        z, mel_Mean, mel_Log_Std, log_Dets, log_Durations, log_Duration_Targets, attentions_from_Train, classified = model(*inputs)
+        mle = self.criterion_Dict["MLE"](z=z, mean=mel_Mean, std=mel_Log_Std, log_dets=log_Dets, lengths=mel_lengths)
+        length = duration_loss(log_Durations, log_Duration_Targets, token_lengths)
+        comp = {"MLE": mle, "Length": length, "Total": mle + length}
+        if classified is not None:
+            comp["Speaker"] = self.criterion_Dict["CE"](classified, speakers)
+        for tag, v in comp.items():
             self.scalar_Dict["Evaluation"]["Loss/" + tag] += v
+        mel_Predictions, _, attentions_from_Inference = model.inference(
+            tokens, token_lengths, mels_for_prosody=mels, mel_lengths_for_prosody=mel_lengths, speakers=speakers, mels_for_ge2e=ge2e,
+            pitches=pitches, pitch_lengths=mel_lengths, length_scale=torch.tensor([1.0], device=tokens.device))
+        self.last_Evaluation = (mel_Predictions, attentions_from_Train, attentions_from_Inference, classified)
+        return self.last_Evaluation
+
+    # ------------------------------------------------------------------ Train.py:371-440 (the PNG plots are out of scope: mels are saved as .npy)
+    @torch.no_grad()
+    def Inference_Step(self, tokens, token_lengths, mels_for_prosody, mel_lengths_for_prosody, speakers, mels_for_ge2e, pitches, pitch_lengths,
+                       length_scales, labels, texts, start_index=0, tag_step=False, tag_index=False):
+        """Same arguments and file naming as the reference; writes `<Inference_Path>/Step-<steps>/NPY/<file>.npy` ([T_mel, Mel_Dim] per utterance,
+        trimmed to its length) and returns the file names."""
+        import numpy as np
+        dev = self.device
+        mv = lambda t: t.to(dev) if torch.is_tensor(t) else t
+        mode = self.hp.Mode.upper()
+        lut = "LUT" in self.model_Dict["GlowTTS"].layer_Dict
+        mels, mel_Lengths, attentions = self.model_Dict["GlowTTS"].inference(
+            mv(tokens), mv(token_lengths), mels_for_prosody=mv(mels_for_prosody) if mode in ("PE", "GR") else None,
+            mel_lengths_for_prosody=mv(mel_lengths_for_prosody) if mode in ("PE", "GR") else None,
+            speakers=mv(speakers) if (mode in ("SE", "GR") and lut) else None, mels_for_ge2e=mv(mels_for_ge2e) if (mode in ("SE", "GR") and not lut) else None,
+            pitches=mv(pitches) if mode == "GR" else None, pitch_lengths=mv(pitch_lengths) if mode == "GR" else None, length_scale=mv(length_scales))
+        files = []
+        for index, label in enumerate(labels):
+            tags = (["Step-{}".format(self.steps)] if tag_step else []) + [label] + (["IDX_{}".format(index + start_index)] if tag_index else [])
+            files.append(".".join(tags))
+        out_dir = os.path.join(self.hp.Inference_Path, "Step-{}".format(self.steps), "NPY").replace("\\", "/")
+        os.makedirs(out_dir, exist_ok=True)
+        for mel, n, file in zip(mels.cpu().numpy(), mel_Lengths.cpu().numpy(), files):
+            np.save(os.path.join(out_dir, file + ".npy"), mel[:, :int(n)].T.astype(np.float32), allow_pickle=False)
+        return files
 
     def Evaluation_Epoch(self):
         logging.info("(Steps: {}) Start evaluation.".format(self.steps))

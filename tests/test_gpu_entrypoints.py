@@ -45,6 +45,7 @@ def _make_dataset(root, mode):
     hp["Train"].update(Batch_Size=4, Max_Step=9, Checkpoint_Save_Interval=4, Logging_Interval=3, Evaluation_Interval=100, Use_Pattern_Cache=True)
     hp["Checkpoint_Path"] = os.path.join(root, "Checkpoint")
     hp["Inference_Batch_Size"] = 3
+    hp["Inference_Path"] = os.path.join(root, "Inference")
     hp["HIP_Buckets"] = {"Mel": [128, 256, 384], "Token": [32, 64]}
     return hp
 
@@ -59,6 +60,18 @@ def test_train_resume_and_inference(mode, tmp_path):
     tr = Trainer(steps=0, hp=hp)
     tr.Train()
     assert tr.steps >= hp.Train.Max_Step
+    # the evaluation epoch ran forward AND inference on the dev batches (Train.py:279-316); Inference_Step names its files like the reference
+    mp, a_train, a_inf, _ = tr.last_Evaluation
+    assert torch.isfinite(mp).all() and a_train.shape[:2] == a_inf.shape[:2] and mp.shape[1] == 12
+    batch = next(iter(tr.dataLoader_Dict["Dev"]))
+    tokens, tl, mels_b, ml_b, spk_b, ge2e_b, pit_b = batch
+    nb = tokens.shape[0]
+    files = tr.Inference_Step(tokens, tl, mels_b, ml_b, spk_b, ge2e_b, pit_b, ml_b, torch.ones(nb), [f"L{i}" for i in range(nb)], ["text"] * nb,
+                              start_index=3, tag_step=True, tag_index=True)
+    assert files[0] == f"Step-{tr.steps}.L0.IDX_3"
+    for f in files:
+        m = np.load(os.path.join(hp.Inference_Path, f"Step-{tr.steps}", "NPY", f + ".npy"))
+        assert m.ndim == 2 and m.shape[1] == 12 and np.isfinite(m).all()
     ckpts = sorted(os.listdir(hp.Checkpoint_Path))
     assert any(f.startswith("S_") and f.endswith(".pt") for f in ckpts), ckpts
     tr.Save_Checkpoint()
