@@ -32,12 +32,12 @@ def default_buckets(max_len, step):
 
 
 class Trainer:
-    def __init__(self, steps=0, hp=None, speaker_encoder=None, use_graph=True):
+    def __init__(self, steps=0, hp=None, speaker_encoder=None, use_graph=True, workers=None):
         """speaker_encoder: GE2E mode only - a callable mapping the collater's slice stack [B * Samples, Mel, Slice] to L2-normalised d-vectors
         [B, Embedding_Size] (the reference's pre-trained GE2E network is an un-vendored submodule: DESIGN.md)."""
         self.hp = hp if hp is not None else get_hp()
         self.steps, self.epochs = steps, 0
-        self.speaker_encoder, self.use_graph = speaker_encoder, use_graph
+        self.speaker_encoder, self.use_graph, self.workers = speaker_encoder, use_graph, workers       # workers: overrides hp.Train.Num_Workers
         self.rank, self.world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
         self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
         torch.cuda.set_device(self.device)
@@ -65,13 +65,21 @@ class Trainer:
         buckets = getattr(hp, "HIP_Buckets", None)          # optional extra yaml key: {Mel: [...], Token: [...]} padded shapes (one hipGraph each)
         mel_b = list(buckets.Mel) if buckets is not None else default_buckets(hp.Train.Train_Pattern.Mel_Length.Max, 128)
         tok_b = list(buckets.Token) if buckets is not None else default_buckets(hp.Train.Train_Pattern.Text_Length.Max + 2, 32)
-        self.collater = data.Collater.from_hp(hp, self.token_Dict, token_buckets=tok_b, mel_buckets=mel_b, pin_memory=True, ge2e=ge2e)
+        # Collation (unpickling, padding to the shape bucket): in worker processes like the reference's DataLoader(num_workers = hp.Train.Num_Workers,
+        # pin_memory = True) (Train.py:100-107) - at ~6 ms per B = 32 step one Python thread cannot unpickle and pad 5 300 utterances per second.
+        # Workers return plain CPU tensors, the loader's pin thread stages them in pinned memory, `_batch_to_device` issues the async copy.
+        # num_workers = 0 (tests, tiny corpora): the collater runs here and owns a ring of reused pinned buffers.
+        nw = max(0, int(getattr(hp.Train, "Num_Workers", 0))) if self.workers is None else int(self.workers)
+        self.num_workers = nw
+        self.collater = data.Collater.from_hp(hp, self.token_Dict, token_buckets=tok_b, mel_buckets=mel_b, pin_memory=(nw == 0), ge2e=ge2e)
         self.sampler = torch.utils.data.distributed.DistributedSampler(train, self.world, self.rank, shuffle=True, drop_last=True) if self.world > 1 else None
         bs = hp.Train.Batch_Size                              # per process (= per GPU)
+        kw = dict(num_workers=nw, pin_memory=nw > 0, persistent_workers=nw > 0)
+        if nw > 0:
+            kw["prefetch_factor"] = 4
         self.dataLoader_Dict = {
-            # the collater owns reused pinned buffers: it runs in THIS process (num_workers = 0); the pattern pickles are cached
             "Train": torch.utils.data.DataLoader(train, batch_size=bs, shuffle=self.sampler is None, sampler=self.sampler, collate_fn=self.collater,
-                                                 num_workers=0, drop_last=True),
+                                                 drop_last=True, **kw),
             "Dev": torch.utils.data.DataLoader(dev, batch_size=bs, shuffle=False, collate_fn=self.collater, num_workers=0),
         }
 
@@ -113,7 +121,9 @@ class Trainer:
         return loss, comp
 
     def _batch_to_device(self, batch):
-        tokens, token_lengths, mels, mel_lengths, speakers, ge2e, pitches = self.collater.to_device(batch, self.device)
+        # (worker-collated batches arrive in the loader's pinned memory; in-process ones in the collater's own pinned ring, whose slot the copy guards)
+        pinned_ring = self.collater.pin and batch[0].is_pinned()
+        tokens, token_lengths, mels, mel_lengths, speakers, ge2e, pitches = (self.collater.to_device if pinned_ring else data.to_device)(batch, self.device)
         mode = self.hp.Mode.upper()
         if mode in ("SE", "GR") and self.hp.Speaker_Embedding.Type.upper() == "GE2E":
             if self.speaker_encoder is None:
