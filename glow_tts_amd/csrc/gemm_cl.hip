@@ -117,15 +117,6 @@ template <int N> struct StaticFor {
 };
 template <> struct StaticFor<0> { template <class F> __device__ __forceinline__ static void run(F&&) {} };
 
-// tools/build_tl.sh builds with GLOWTTS_TIMELINE: thread 0 of every workgroup logs shader-clock stamps into `tlbuf`
-#ifdef GLOWTTS_TIMELINE
-#ifndef TL_STRIDE
-#define TL_STRIDE 32
-#endif
-#define TL(i) do { if (tid == 0) tlbuf[(i)] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
-#define TL(i)
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // the fused epilogues (shared by conv_cl_kernel and conv_dma_kernel).  acc[mi][ni] = 32x32 fragments of the wave's
@@ -140,11 +131,6 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
 {
     constexpr bool EX = sizeof(CT) == 4;
     const int l31 = lane & 31, lhi = lane >> 5;
-#ifdef GLOWTTS_TOOLS
-    const int abl = p.flags >> 16;                            // debug ablation bits (tools/bench_conv.py; tools builds only)
-#else
-    constexpr int abl = 0;
-#endif
     // dropout seed: the device word (graph replays) is read here, not at kernel start, where the scalar load would sit in front
     // of the first tile loads
     uint32_t seed = p.seed;
@@ -156,7 +142,6 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
     // tensors may alias for all the compiler knows, so it cannot hoist them over the stores itself).  The epilogue is VALU-issue
     // bound (tools/conv_timeline.py): instruction count per element is what matters here.
     const bool in0_bf = (p.io_flags & GLOWTTS_IO_IN0_BF16) != 0, out0_bf = (p.io_flags & GLOWTTS_IO_OUT0_BF16) != 0;
-    if (abl & 1) { if (acc[0][0][0] == 12345.678f) p.out0[0] = 1.f; return; }
     const int fl = p.flags;
     constexpr uint32_t OOB = 0x80000000u;
     const int rb = m0 + wm * MI * 32 + 4 * lhi;               // row of (mi = 0, reg = 0)
@@ -172,7 +157,6 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
         __builtin_amdgcn_raw_buffer_store_b16(*reinterpret_cast<const unsigned short*>(&b), r, vo, so, 0);
     };
     const Rsrc rmk = mk(p.rowmask, (long)p.rows * 4);
-    TL(22);
 
     if constexpr (EPI == GLOWTTS_EPI_LINEAR) {
         const uint32_t esz = out0_bf ? 2 : 4;
@@ -382,8 +366,6 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int ro_ = roff(mi, reg), r = rb + ro_;
-                    if (mi == 0 && reg == 4) TL(23);
-                    if (mi == 0 && reg == 8) TL(24);
                     const uint32_t rk = (MODE == 1 || (MODE == 2 && drop)) ? drop_rowkey(seed, (uint32_t)r) : 0u;
                     const bool sel = r >= rnext;
 #pragma unroll
@@ -406,10 +388,6 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
                             x1 += sel ? sb1[pi] : sa1[pi];
                         }
                         float2 g = make_float2(tanh_<EX>(x0), sigmoid_<EX>(x1));
-#ifdef GLOWTTS_TIMELINE
-                        if (abl & 8) g = make_float2(x0, x1);
-                        if (abl & 4) { if (g.x == 12345.678f) p.out0[0] = 1.f; continue; }
-#endif
                         if constexpr (OBF) { st32(pack_bf16x2(g.x, g.y), ro, vo[pi], ro_ * (int)p.ld0 * 2); sth(g.x * g.y, ra, va[pi], ro_ * (int)p.ld1 * 2); }
                         else {
                             u32x2 w; w[0] = __float_as_uint(g.x); w[1] = __float_as_uint(g.y);
@@ -854,49 +832,26 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cl_kernel(const glowtts_con
         }
         if constexpr (!T1) sstore_a(ra[0], 0, ss);
     };
-#ifdef GLOWTTS_TOOLS
-    const int abl = p.flags >> 16;                            // debug ablation bits (tools/bench_conv.py; tools builds only)
-#else
-    constexpr int abl = 0;
-#endif
-    // tools/build_tl.sh builds with GLOWTTS_TIMELINE: thread 0 of every workgroup logs shader-clock stamps into the
-    // buffer passed through p.ncols_valid ([workgroups][32] int64) - never defined in the product build
-#ifdef GLOWTTS_TIMELINE
-    long long* tlbuf = reinterpret_cast<long long*>(const_cast<int*>(p.ncols_valid)) + (long)blockIdx.x * TL_STRIDE;
-    if (tid == 0) { tlbuf[30] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); tlbuf[31] = (long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); }
-#endif
-    TL(0);
     gload_ss(ssmap(0));
-    TL(1);
     sstore_ss(ssmap(0));
-    TL(2);
     __syncthreads();
-    TL(3);
     for (int ss = 0; ss < NSS; ++ss) {
         const int cur = ssmap(ss), nxt = ssmap(ss + 1 < NSS ? ss + 1 : ss);
         gload_ss(nxt);                                        // next super-step, in flight during the MFMAs below
-        if (!(abl & 2)) {
+        {
 #pragma unroll
             for (int j = 0; j < NSUB; ++j) {
                 if constexpr (T1) { if (cur * NSUB + j < KCH) compute(j, 0, j); }
                 else              compute(0, j, j);
             }
         }
-        TL(4 + 3 * ss);
         __syncthreads();                                      // every wave is done reading the tiles
-        TL(5 + 3 * ss);
         sstore_ss(nxt);
         __syncthreads();
-        TL(6 + 3 * ss);
     }
 
     // ---- fused epilogue ----
-#ifdef GLOWTTS_TIMELINE
-    conv_epilogue<CT, MI, NI, EPI>(p, acc, m0, n0, BM, wm, wn, lane, tid, tlbuf);
-#else
     conv_epilogue<CT, MI, NI, EPI>(p, acc, m0, n0, BM, wm, wn, lane, tid, nullptr);
-#endif
-    TL(29);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -935,9 +890,6 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
     constexpr int SUB = T1 ? DMA1_CPS : TAPS;
     constexpr int NAT = T1 ? DMA1_CPS : 1;
     glowtts_conv_args p = pin;
-#ifdef GLOWTTS_ABL   // tools/conv_prologue.py: early exits that price the launch, the address set-up and the first fetch
-    if ((pin.flags >> 16) & 256) return;
-#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // scalar: unit indices, LDS bases and branches below are wave-uniform
     const int WMR = (blockDim.x >> 6) - nload, BM = WMR * 32; // compute waves (the last `nload` waves only issue DMAs)
@@ -960,11 +912,6 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
     auto ssmap = [&](int ss) __attribute__((always_inline)) { int v = ss + rot; return v >= NSS ? v - NSS : v; };
     constexpr int pad = (TAPS - 1) / 2;
     const int l31 = lane & 31, lhi = lane >> 5;
-#ifdef GLOWTTS_TIMELINE
-    long long* tlbuf = reinterpret_cast<long long*>(const_cast<int*>(p.ncols_valid)) + (long)blockIdx.x * TL_STRIDE;
-    if (tid == 0) { tlbuf[30] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); tlbuf[31] = (long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); }
-#endif
-    TL(0);
 
     // lane -> (row or column inside a 16-unit, logical 16-byte slot): LDS position `lane` of a unit holds slot q of row lane >> 2
     const int lrow = lane >> 2, qa = (lane & 3) ^ ((lane >> 4) & 3);
@@ -1085,11 +1032,6 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
         });
     };
 
-#ifdef GLOWTTS_TOOLS
-    const int abl = p.flags >> 16;
-#else
-    constexpr int abl = 0;
-#endif
     // Three LDS stages, stages ss+1 and ss+2 in flight while stage ss is multiplied.  s_waitcnt takes an immediate, the number of
     // DMAs a wave has outstanding per stage (nmine) is uniform but only known at run time: dispatch once per wait.
     auto wait_keep = [&](int keep) __attribute__((always_inline)) {        // wait until at most `keep` of this wave's DMAs are outstanding, then barrier
@@ -1108,32 +1050,16 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
     // nst LDS stages: stage ss+1 .. ss+nst-1 are in flight while stage ss is multiplied (nst = 3: two ahead; nst = 2: one ahead, two
     // thirds of the LDS, so that a second workgroup - of another kernel on another stream - can be co-resident on the CU)
     const int ahead = nst - 1;                                // (loader waves: the host passes nst = 2)
-#ifdef GLOWTTS_ABL
-    if ((pin.flags >> 16) & 512) { if (uoff[0] == 0x7fffffffu && uoff[MAXU - 1] == 1u && nmine == 77) p.out0[0] = 1.f; return; }
-#endif
     if (!nload) StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 0, ssmap(0)); });
     if (!nload && ahead > 1 && NSS > 1) StaticFor<MAXU>::run([&](auto I_) __attribute__((always_inline)) { issue_unit(I_, 1, ssmap(1)); });
-    TL(1);
     int cur = 0;                                              // LDS stage of pipeline stage ss (ss % nst)
     for (int ss = 0; ss < NSS; ++ss) {
         // this wave's DMAs of stage ss have landed (those of later stages may still fly); after the barrier so have everyone's,
         // and every wave is done reading the LDS stage of ss-1, which is refilled with stage ss+ahead during the MFMAs below
         wait_keep((ahead > 1 && ss + 1 < NSS) ? nmine : 0);
-#ifdef GLOWTTS_ABL
-        if ((pin.flags >> 16) & 1024) return;
-#endif
-        TL(3 + 3 * ss);
         const bool more = !nload && ss + ahead < NSS;
         const int nxt = cur == 0 ? nst - 1 : cur - 1;         // (ss + ahead) % nst
-#ifdef GLOWTTS_TIMELINE
-        if (ss == 3 && lane == 0) tlbuf[64 + wave * 3 + 0] = (long long)__builtin_readcyclecounter();      // per-wave: barrier passed
-#endif
-        if (!(abl & 2)) compute(cur, more ? nxt : -1, more ? ssmap(ss + ahead) : 0);
-#ifdef GLOWTTS_TIMELINE
-        if (ss == 3 && lane == 0) tlbuf[64 + wave * 3 + 1] = (long long)__builtin_readcyclecounter();      // per-wave: compute done
-        if (ss == 3 && lane == 0) tlbuf[64 + wave * 3 + 2] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
-#endif
-        TL(5 + 3 * ss);
+        compute(cur, more ? nxt : -1, more ? ssmap(ss + ahead) : 0);
         cur = cur == nst - 1 ? 0 : cur + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1169,12 +1095,7 @@ __global__ __launch_bounds__(1024) void conv_dma_kernel(const glowtts_conv_args 
         }
     }
     f32x16 (&accf)[1][NI] = reinterpret_cast<f32x16 (&)[1][NI]>(acc);         // row fragment of this wave: acc[0][*]
-#ifdef GLOWTTS_TIMELINE
-    conv_epilogue<CT, 1, NI, EPI, false>(p, accf, m0, n0, BM, wave, 0, lane, tid, tlbuf);
-#else
     conv_epilogue<CT, 1, NI, EPI, false>(p, accf, m0, n0, BM, wave, 0, lane, tid, nullptr);
-#endif
-    TL(29);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1575,15 +1496,6 @@ int launch_taps(const glowtts_conv_args& a, hipStream_t s)
 template <typename CT>
 int launch_prec(const glowtts_conv_args& a, hipStream_t s)
 {
-#ifdef GLOWTTS_TOOLS_MIN     // tools/build_tl.sh: only the dominant kernel, for fast experiment builds
-    if constexpr (sizeof(CT) == 2) {
-        if (dma_ok(a) && a.epi == GLOWTTS_EPI_GATE && a.taps == 5) return launch_dma<GLOWTTS_EPI_GATE, 5>(a, s);
-        if (a.epi == GLOWTTS_EPI_GATE && a.taps == 5)
-            return (a.io_flags & GLOWTTS_IO_A_BF16) ? launch_tile<CT, GLOWTTS_EPI_GATE, 5, GLOWTTS_APRO_NONE, true>(a, s)
-                                                    : launch_tile<CT, GLOWTTS_EPI_GATE, 5, GLOWTTS_APRO_NONE, false>(a, s);
-    }
-    return GLOWTTS_E_ARG;
-#else
     const int N = GLOWTTS_APRO_NONE, PM = GLOWTTS_APRO_PAIRMUL;
     if constexpr (sizeof(CT) == 2) {
         { const int rc = try_skinny(a, s); if (rc != -1) return rc; }
@@ -1621,7 +1533,6 @@ int launch_prec(const glowtts_conv_args& a, hipStream_t s)
         case GLOWTTS_EPI_DGATE:   return (a.apro == N && a.taps == 1) ? launch_tile<CT, GLOWTTS_EPI_DGATE, 1, GLOWTTS_APRO_NONE>(a, s) : GLOWTTS_E_ARG;
         default: return GLOWTTS_E_ARG;
     }
-#endif
 }
 
 }  // namespace
