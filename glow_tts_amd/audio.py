@@ -6,8 +6,12 @@ PARITY UNPINNED: the arithmetic of `Audio.py` lives in a third-party dependency 
 (librosa; the reference's requirements pin no version, its 2020 era is librosa 0.7 / 0.8).  What is restated here is librosa's published
 algorithm for exactly the calls `Audio.py` makes - `stft` (centered, reflect padding, periodic Hann window of `win_length` zero-padded to
 `n_fft`), `filters.mel` (Slaney scale, Slaney area normalisation), `effects.trim` (frame RMS against the peak, `top_db`), `util.normalize` (peak) -
-and checked by properties in tests/test_audio_frontend.py, not against librosa outputs.  `librosa.core.load`'s resampling is NOT restated: the
-wav must already be at hp.Sound.Sample_Rate.  The YIN pitch tracker (`yin.py`, GR mode only) is out of scope."""
+and checked in tests/test_audio_frontend.py against an INDEPENDENT computation of the same published definitions (scipy.signal.stft on the
+padded signal; a per-filter loop over the Slaney triangles; the two values librosa's own documentation prints for `filters.mel(22050, 2048)`),
+not against librosa outputs.  `librosa.core.load` resamples with resampy's `kaiser_best` filter, which is absent too: `resample` here is a
+polyphase Kaiser resampler (scipy.signal.resample_poly) - same purpose, different filter, parity unpinned.
+The YIN pitch tracker of GR mode (`yin.py`, `Pattern_Generator.py:41-52`) IS pinned: `yin.py` is plain numpy in the reference mount, and
+tests/golden/make_audio_golden.py wrote `yin_case.npz` by importing it unmodified."""
 import numpy as np
 from scipy import signal
 from scipy.io import wavfile
@@ -81,11 +85,20 @@ def trim(audio, top_db=60, frame_length=512, hop_length=256):
     return audio[keep[0] * hop_length:min(len(audio), (keep[-1] + 1) * hop_length)]
 
 
-def audio_prep(path, sample_rate, trim_top_db=60):
-    """Audio.py:6-11 `Audio_Prep` (no resampling: the file's rate must equal sample_rate)."""
+def resample(x, sr_in, sr_out):
+    """Stand-in for the resampling inside `librosa.core.load(path, sr=...)` (Audio.py:7): polyphase resampling with a Kaiser-windowed low-pass."""
+    if sr_in == sr_out:
+        return x
+    from math import gcd
+    g = gcd(int(sr_in), int(sr_out))
+    return signal.resample_poly(x, int(sr_out) // g, int(sr_in) // g, window=("kaiser", 12.0)).astype(np.float32)
+
+
+def audio_prep(path, sample_rate, trim_top_db=60, allow_resample=True):
+    """Audio.py:6-11 `Audio_Prep`: load (mono, float, resampled to sample_rate), trim, peak-normalise."""
     sr, x = wavfile.read(path)
-    if sr != sample_rate:
-        raise ValueError(f"{path}: {sr} Hz, expected {sample_rate} Hz (resampling is not part of this front-end)")
+    if sr != sample_rate and not allow_resample:
+        raise ValueError(f"{path}: {sr} Hz, expected {sample_rate} Hz")
     if x.dtype.kind == "i":
         x = x.astype(np.float32) / float(np.iinfo(x.dtype).max + 1)
     elif x.dtype.kind == "u":
@@ -93,14 +106,57 @@ def audio_prep(path, sample_rate, trim_top_db=60):
     x = x.astype(np.float32)
     if x.ndim > 1:
         x = x.mean(axis=1)
+    x = resample(x, sr, sample_rate)
     x = trim(x, trim_top_db)
     return x / max(np.abs(x).max(), 1e-10)                                      # librosa.util.normalize (peak)
 
 
-def pattern_from_wav(path, hp, top_db=30):
-    """`Pattern_Generate` (Pattern_Generator.py:63-79) without the pitch: -> (mel [T, Mel], None).  top_db = 30 as Inference.py:57 passes."""
+def yin_pitch(sig, sr, harmo_thresh, w_len=1024, w_step=256, f0_min=100, f0_max=500):
+    """`yin.compute_yin(...)[0]` (yin.py:99-150) for all frames at once: centred reflect padding, per frame the difference function (:40-63, via
+    FFT autocorrelation), its cumulative-mean normalisation (:66-80) and the first dip below `harmo_thresh` followed down to its local minimum
+    (:83-96); 0 where unvoiced.  Frame bookkeeping as the reference's: `range(0, len - w_len, w_step)`."""
+    sig = np.asarray(sig, dtype=np.float64)
+    sig = np.pad(sig, (w_step + w_len - sig.shape[0] % w_step) // 2, mode="reflect")
+    tau_min, tau_max = int(sr / f0_max), min(int(sr / f0_min), w_len)
+    starts = np.arange(0, len(sig) - w_len, w_step)
+    if starts.size == 0:
+        return np.zeros(0)
+    frames = sig[starts[:, None] + np.arange(w_len)[None, :]]                              # [F, w_len]
+    csum = np.concatenate([np.zeros((len(starts), 1)), np.cumsum(frames * frames, axis=1)], axis=1)
+    nfft = 1 << int(np.ceil(np.log2(w_len + tau_max)))
+    spec = np.fft.rfft(frames, nfft, axis=1)
+    acf = np.fft.irfft(spec * np.conj(spec), nfft, axis=1)[:, :tau_max]
+    taus = np.arange(tau_max)
+    df = csum[:, w_len - taus] + csum[:, w_len:w_len + 1] - csum[:, taus] - 2.0 * acf      # d(tau) = sum_j (x_j - x_{j+tau})^2
+    cm = np.ones_like(df)
+    cm[:, 1:] = df[:, 1:] * np.arange(1, tau_max)[None, :] / (np.cumsum(df[:, 1:], axis=1) + 1e-8)
+    pitches = np.zeros(len(starts))
+    for i, c in enumerate(cm):                                                               # first dip below the threshold, walked to its minimum
+        below = np.flatnonzero(c[tau_min:tau_max] < harmo_thresh)
+        if below.size:
+            tau = tau_min + int(below[0])
+            while tau + 1 < tau_max and c[tau + 1] < c[tau]:
+                tau += 1
+            pitches[i] = sr / tau
+    return pitches
+
+
+def pitch_generate(audio, hp):
+    """`Pattern_Generator.Pitch_Generate` (:41-52) -> [frames] in [0, 1].  NOTE the reference's `pitch_calc` (yin.py:159-183) ignores the window /
+    hop / f0 range it is handed and always analyses 1024-sample windows every 256 samples between 100 and 500 Hz; only the confidence threshold and
+    the smoothing sigma of Hyper_Parameters.yaml take effect.  Reproduced as is."""
+    s = hp.Sound
+    pitch = yin_pitch(audio, s.Sample_Rate, harmo_thresh=1.0 - float(s.Confidence_Threshold))
+    if float(s.Gaussian_Smoothing_Sigma) > 0.0:
+        from scipy.ndimage import gaussian_filter1d
+        pitch = gaussian_filter1d(pitch, sigma=float(s.Gaussian_Smoothing_Sigma))
+    return ((pitch - pitch.min()) / (pitch.max() - pitch.min() + 1e-7)).astype(np.float32)
+
+
+def pattern_from_wav(path, hp, top_db=30, with_pitch=False):
+    """`Pattern_Generate` (Pattern_Generator.py:54-70): -> (mel [T, Mel], pitch [T] or None).  top_db = 30 as Inference.py:57 passes."""
     s = hp.Sound
     audio = audio_prep(path, s.Sample_Rate, top_db)
     mel = mel_generate(audio, s.Sample_Rate, s.Mel_Dim, s.Spectrogram_Dim, s.Frame_Length, s.Frame_Shift, mel_fmin=s.Mel_F_Min, mel_fmax=s.Mel_F_Max,
                        max_abs_value=s.Max_Abs_Mel)
-    return mel, None
+    return mel, (pitch_generate(audio, hp) if with_pitch else None)

@@ -44,7 +44,7 @@ class Inferencer:
         if str(ref).lower().endswith(".npy"):
             return np.load(ref).astype(np.float32), None
         from . import audio
-        return audio.pattern_from_wav(ref, self.hp)
+        return audio.pattern_from_wav(ref, self.hp, with_pitch=self.hp.Mode.upper() == "GR")       # GR: the YIN pitch track (Inference.py:56-58, Pattern_Generator.py:41-52)
 
     @torch.no_grad()
     def Inference_Step(self, tokens, token_lengths, prosodies, prosody_lengths, speakers, ge2es, pitches, pitch_lengths, length_scales, labels, texts,

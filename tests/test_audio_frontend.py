@@ -51,7 +51,7 @@ def test_audio_prep_reads_trims_and_normalises(tmp_path):
     assert abs(np.abs(y).max() - 1.0) < 1e-6 and 11000 <= len(y) <= 13500
     import pytest
     with pytest.raises(ValueError):
-        audio.audio_prep(p, 22050)
+        audio.audio_prep(p, 22050, allow_resample=False)
 
 
 def test_entry_point_facade_exposes_the_reference_names():
@@ -86,3 +86,80 @@ def test_reference_schema_yaml_loads_from_cwd(tmp_path, monkeypatch):
     m = GlowTTS()                                           # no-argument constructor reading the global hp (Modules.py:17)
     assert len(m.layer_Dict["Decoder"].layer_Dict["Flows"]) == 7 and "LUT" in m.layer_Dict
     monkeypatch.setattr(hparams, "_hp", None)
+
+
+def test_stft_matches_an_independent_scipy_computation():
+    """`audio.stft_magnitude` restates librosa.stft (centred, reflect padding, periodic Hann of win_length zero-padded to n_fft).  Independent
+    check: scipy.signal.stft on the signal padded by hand, with its 1 / sum(window) scaling undone.  (parity with librosa itself: UNPINNED.)"""
+    from scipy import signal
+    from glow_tts_amd import audio
+    rng = np.random.default_rng(3)
+    y = rng.standard_normal(9000)
+    n_fft, hop, win = 2048, 256, 1024
+    got = audio.stft_magnitude(y, n_fft, hop, win)
+    w = np.zeros(n_fft)
+    w[(n_fft - win) // 2:(n_fft - win) // 2 + win] = signal.get_window("hann", win, fftbins=True)
+    yp = np.pad(y, n_fft // 2, mode="reflect")
+    _, _, Z = signal.stft(yp, window=w, nperseg=n_fft, noverlap=n_fft - hop, boundary=None, padded=False, return_onesided=True)
+    want = np.abs(Z) * w.sum()
+    assert got.shape == want.shape == (1025, 1 + len(y) // hop)
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
+
+
+def test_mel_filterbank_known_answers_and_independent_triangles():
+    """Two values librosa's documentation prints for `librosa.filters.mel(22050, 2048)` (128 filters, Slaney scale and normalisation): weight
+    [0, 1] = 0.016, and 0.02 with fmax = 8000; the Slaney scale's fixed points; and every filter rebuilt by an explicit per-filter loop."""
+    from glow_tts_amd import audio
+    assert round(float(audio.mel_filterbank(22050, 2048, 128, 0.0, 11025.0)[0, 1]), 3) == 0.016
+    assert round(float(audio.mel_filterbank(22050, 2048, 128, 0.0, 8000.0)[0, 1]), 2) == 0.02
+    assert np.allclose(audio._hz_to_mel([0.0, 200.0 / 3, 1000.0]), [0.0, 1.0, 15.0]) and np.isclose(audio._mel_to_hz(15.0 + 27.0), 6400.0)
+    sr, n_fft, n_mels, fmin, fmax = 24000, 2048, 80, 125.0, 7600.0
+    fb = audio.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    edges = audio._mel_to_hz(np.linspace(audio._hz_to_mel(fmin), audio._hz_to_mel(fmax), n_mels + 2))
+    freqs = np.arange(1 + n_fft // 2) * sr / n_fft
+    for m in range(n_mels):
+        lo, ce, hi = edges[m], edges[m + 1], edges[m + 2]
+        tri = np.where(freqs <= ce, (freqs - lo) / (ce - lo), (hi - freqs) / (hi - ce)).clip(min=0.0)
+        assert np.allclose(fb[m], tri * 2.0 / (hi - lo), atol=1e-7), m
+
+
+def test_yin_pitch_matches_the_reference_yin_py_vectors():
+    """GR-mode pitch track (Pattern_Generator.py:41-52 -> yin.py:159-183).  tests/golden/yin_case.npz was written by the reference's own yin.py
+    (tests/golden/make_audio_golden.py): `compute_yin(...)[0]` at two thresholds and `pitch_calc` - whose window / hop / f0 arguments the
+    reference ignores (always 1024 / 256, 100..500 Hz) - on a glide, a harmonic stack with silence, noise, a mixture and an odd-length signal."""
+    import os
+    from glow_tts_amd import audio
+    from glow_tts_amd.hparams import Recursive_Parse
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "yin_case.npz"))
+    sr = int(d["sr"])
+    voiced = 0
+    for name in ("glide", "vowel", "noise", "mix", "odd"):
+        sig = d[f"{name}/sig"]
+        for thr in (0.15, 0.4):
+            want = d[f"{name}/yin_{thr}"]
+            got = audio.yin_pitch(sig, sr, harmo_thresh=thr)
+            assert got.shape == want.shape and np.allclose(got, want, rtol=0, atol=1e-9), (name, thr, np.abs(got - want).max())
+            voiced += int((want > 0).sum())
+        for key, conf, sigma in (("calc_0.6_0", 0.6, 0.0), ("calc_0.85_1", 0.85, 1.0)):
+            hp = Recursive_Parse({"Sound": {"Sample_Rate": sr, "Confidence_Threshold": conf, "Gaussian_Smoothing_Sigma": sigma}})
+            want = d[f"{name}/{key}"]
+            norm = (want - want.min()) / (want.max() - want.min() + 1e-7)
+            assert np.allclose(audio.pitch_generate(sig, hp), norm, atol=1e-6), (name, key)
+    assert voiced > 200                                              # the vectors do exercise voiced frames
+
+
+def test_resample_keeps_pitch_and_duration(tmp_path):
+    """Stand-in for librosa.core.load's resampling (resampy is absent: parity UNPINNED): a 440 Hz tone at 22.05 kHz read through `audio_prep`
+    at 24 kHz keeps its frequency and its duration."""
+    from scipy.io import wavfile
+    from glow_tts_amd import audio
+    sr_in, sr_out = 22050, 24000
+    x = 0.5 * np.sin(2 * np.pi * 440.0 * np.arange(sr_in) / sr_in)
+    y = audio.resample(x, sr_in, sr_out)
+    assert abs(len(y) - sr_out) <= 1
+    spec = np.abs(np.fft.rfft(y * np.hanning(len(y))))
+    assert abs(np.argmax(spec) * sr_out / len(y) - 440.0) < 2.0
+    p = str(tmp_path / "t.wav")
+    wavfile.write(p, sr_in, (x * 32767).astype(np.int16))
+    z = audio.audio_prep(p, sr_out, trim_top_db=60)
+    assert abs(len(z) - sr_out) < 600 and abs(np.abs(z).max() - 1.0) < 1e-6
