@@ -31,11 +31,11 @@ def _L():
     L = _lib.lib()
     if not _decl:
         L.glowtts_wgrad_cl.argtypes = [c_p, c_p]
-        L.glowtts_layernorm_fwd.argtypes = [c_p] * 8 + [c_i64, c_int, c_f, c_int, c_f, c_u32, c_p, c_p]
+        L.glowtts_layernorm_fwd_io.argtypes = [c_p] * 8 + [c_i64, c_int, c_f, c_int, c_f, c_u32, c_p, c_p, c_p]
         L.glowtts_layernorm_scratch_floats.argtypes = [c_i64, c_int]
         L.glowtts_layernorm_scratch_floats.restype = c_i64
-        L.glowtts_layernorm_bwd.argtypes = [c_p] * 9 + [c_i64, c_int, c_int, c_f, c_p]
-        L.glowtts_gate_bwd.argtypes = [c_p] * 4 + [c_i64, c_int, c_f, c_p]
+        L.glowtts_layernorm_bwd_io.argtypes = [c_p] * 9 + [c_i64, c_int, c_int, c_f, c_p, c_p]
+        L.glowtts_gate_bwd_io.argtypes = [c_p] * 4 + [c_i64, c_int, c_f, c_int, c_p]
         L.glowtts_embedding_fwd.argtypes = [c_p] * 4 + [c_int] * 3 + [c_f, c_p]
         L.glowtts_embedding_bwd.argtypes = [c_p] * 4 + [c_int] * 4 + [c_f, c_p]
         L.glowtts_rpr_attention_fwd_prec.argtypes = [c_p] * 6 + [c_int] * 5 + [c_f, c_u32, c_p, c_int, c_p]
@@ -81,9 +81,10 @@ class WgradTape:
         from .decoder import WgradGroup
         groups = {}
         for dz, x, O, ca, taps, precision, dw, db in self.jobs:
-            key = (dz.shape[0], taps, precision)
+            io = (ops.WIO_DY_BF16 if dz.dtype == torch.bfloat16 else 0) | (ops.WIO_X_BF16 if x.dtype == torch.bfloat16 else 0)
+            key = (dz.shape[0], taps, precision, io)
             if key not in groups:
-                groups[key] = WgradGroup(dz.shape[0], taps, precision, tag="enc")
+                groups[key] = WgradGroup(dz.shape[0], taps, precision, io_flags=io, tag="enc")
             groups[key].add(dz.data_ptr(), dz.shape[1], O, x.data_ptr(), x.shape[1], ca, dw.data_ptr(), _sp(db))
         for g in groups.values():
             g.end_segment()
@@ -107,53 +108,76 @@ class ParamGate(torch.autograd.Function):
         return (None,) + grads
 
 
+def bf16_of(t):
+    """The bf16 copy a producer attached to its fp32 rows (`LayerNormRows` with want_bf16), or None."""
+    return getattr(t, "_bf16", None)
+
+
 class ConvRows(torch.autograd.Function):
     """y = dropout( relu?( conv1d_same(x, w) + b ) ) [+ residual] [* rowmask]   on rows tensors.
-    Mirrors torch.nn.Conv1d(k, padding=(k-1)//2) + the elementwise tail the reference applies after it."""
+    Mirrors torch.nn.Conv1d(k, padding=(k-1)//2) + the elementwise tail the reference applies after it.
+
+    bf16 mode, bf16-STORED operand (`xb`: a bf16 copy of x written by its producer, or x itself bf16): the conv is served by the LDS-DMA
+    kernel (`conv_dma_kernel`, raw 16-byte staging), its data gradient too (the gate of relu / dropout writes d(pre-activation) as bf16), and
+    the weight gradient stages both operands as raw bf16.  `out_bf16`: the output is only ever a conv operand - store it as bf16."""
 
     @staticmethod
-    def forward(ctx, x, w, b, rowmask, residual, relu, mask_out, precision, drop_p, seed, seed_t, tape=None, packs=None):
+    def forward(ctx, x, w, b, rowmask, residual, relu, mask_out, precision, drop_p, seed, seed_t, tape=None, packs=None, xb=None, out_bf16=False):
         ctx.tape = tape
         ctx.pwt = packs[1] if packs is not None else None         # packs: (forward, transposed) from an ops.PackSet already run this step
         x = x.contiguous()
         R, Cin = x.shape
         O, Ci2, k = w.shape
         assert Ci2 <= Cin and Cin % 4 == 0
+        if x.dtype == torch.bfloat16:
+            assert precision == ops.BF16, "bf16-stored rows exist in bf16 mode only"
+            a = x
+        else:
+            a = xb.contiguous() if (xb is not None and precision == ops.BF16 and Ci2 % 32 == 0 and Ci2 == Cin) else None
+            assert a is None or a.shape == x.shape
+        assert not out_bf16 or (a is not None and residual is None)
         pw = packs[0] if packs is not None else ops.pack_weight(w.detach(), precision=precision)
-        out = torch.empty(R, O, device=x.device)
+        out = torch.empty(R, O, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
         flags = (ops.F_BIAS if b is not None else 0) | (ops.F_RELU if relu else 0) | (ops.F_MASK if mask_out else 0) | \
                 (ops.F_ADD_IN0 if residual is not None else 0) | (ops.F_DROPOUT if drop_p > 0 else 0)
-        ops.conv_cl(x, pw, Ci2, R, lda=Cin, pad=(k - 1) // 2, epi=ops.EPI_LINEAR, flags=flags, n=O,
+        io = (ops.IO_A_BF16 if a is not None else 0) | (ops.IO_OUT0_BF16 if out_bf16 else 0)
+        ops.conv_cl(a if a is not None else x, pw, Ci2, R, lda=Cin, pad=(k - 1) // 2, epi=ops.EPI_LINEAR, flags=flags, n=O,
                     bias=b.detach().contiguous() if b is not None else None, rowmask=rowmask,
                     in0=residual.contiguous() if residual is not None else None, ldi0=O, out0=out, ld0=O,
-                    drop_p=drop_p, seed=seed, seed_t=seed_t)
+                    drop_p=drop_p, seed=seed, seed_t=seed_t, io_flags=io)
         gated = relu or drop_p > 0
         assert not (gated and residual is not None), "gate recovery from the output needs out = gated value"
-        ctx.save_for_backward(x, w, out if gated else None, rowmask)
-        ctx.cfg = (gated, mask_out, precision, b is not None, residual is not None, Ci2, drop_p)
+        # what the backward reads of x is the weight gradient's operand: the bf16 rows when there are any
+        ctx.save_for_backward(a if a is not None else x, w, out if gated else None, rowmask)
+        ctx.cfg = (gated, mask_out, precision, b is not None, residual is not None, Ci2, drop_p, x.dtype, a is not None)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         x, w, out, rowmask = ctx.saved_tensors
-        gated, mask_out, precision, has_b, has_res, Ci2, drop_p = ctx.cfg
+        gated, mask_out, precision, has_b, has_res, Ci2, drop_p, x_dtype, bfpath = ctx.cfg
         R, Cin = x.shape
         O, _, k = w.shape
         dy = dy.contiguous()
+        bf = torch.bfloat16
         if gated:                                              # d(pre-activation): relu / dropout cut exactly where out == 0
-            dz = torch.empty_like(dy)
-            _lib.check(_L().glowtts_gate_bwd(dy.data_ptr(), out.data_ptr(), _sp(rowmask) if mask_out else None, dz.data_ptr(), R, O,
-                                             1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0, _lib.stream()), "glowtts_gate_bwd")
+            dz = torch.empty(R, O, device=dy.device, dtype=bf if bfpath else torch.float32)
+            io = (1 if dy.dtype == bf else 0) | (2 if out.dtype == bf else 0) | (4 if bfpath else 0)
+            _lib.check(_L().glowtts_gate_bwd_io(dy.data_ptr(), out.data_ptr(), _sp(rowmask) if mask_out else None, dz.data_ptr(), R, O,
+                                                1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0, io, _lib.stream()), "glowtts_gate_bwd_io")
         elif mask_out:
             dz = dy * rowmask.unsqueeze(1)
         else:
             dz = dy
         dres = dz if (has_res and ctx.needs_input_grad[4]) else None
+        if bfpath and dz.dtype != bf:
+            dz = dz.to(bf)
         dx = None
         if ctx.needs_input_grad[0]:
             pwt = ctx.pwt if ctx.pwt is not None else ops.pack_weight(w.detach(), transpose=True, precision=precision)
-            dx = torch.empty(R, Cin, device=x.device) if Cin == Ci2 else torch.zeros(R, Cin, device=x.device)
-            ops.conv_cl(dz, pwt, O, R, lda=O, pad=(k - 1) // 2, epi=ops.EPI_LINEAR, flags=0, n=Ci2, out0=dx, ld0=Cin)
+            dx = torch.empty(R, Cin, device=x.device, dtype=x_dtype) if Cin == Ci2 else torch.zeros(R, Cin, device=x.device, dtype=x_dtype)
+            io = (ops.IO_A_BF16 if dz.dtype == bf else 0) | (ops.IO_OUT0_BF16 if x_dtype == bf else 0)
+            ops.conv_cl(dz, pwt, O, R, lda=O, pad=(k - 1) // 2, epi=ops.EPI_LINEAR, flags=0, n=Ci2, out0=dx, ld0=Cin, io_flags=io)
         dw = db = None
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             if ctx.tape is not None:                           # deferred: filled by ParamGate.backward (one grouped launch)
@@ -163,28 +187,30 @@ class ConvRows(torch.autograd.Function):
             else:
                 # split-K slices: few for the text encoder's short row counts; 0 = the library's own choice (about two workgroups per CU) for
                 # the long ones (patch matrices of the prosody encoder's conv stack: up to 512 k rows against a handful of output tiles)
-                dw, db = wgrad(dz, x, O, Ci2, k, precision, want_bias=has_b, splits=0 if R > 65536 else min(4, max(1, R // 512)))
-        return dx, dw, db, None, dres, None, None, None, None, None, None, None, None
+                wio = (ops.WIO_DY_BF16 if dz.dtype == bf else 0) | (ops.WIO_X_BF16 if x.dtype == bf else 0)
+                dw, db = wgrad(dz, x, O, Ci2, k, precision, want_bias=has_b, splits=0 if R > 65536 else min(4, max(1, R // 512)), io_flags=wio)
+        return dx, dw, db, None, dres, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_rows(x, w, b, rowmask, relu=False, mask_out=False, residual=None, precision=ops.BF16, drop_p=0.0, seed=0, seed_t=None, tape=None,
-              packs=None):
-    return ConvRows.apply(x, w, b, rowmask, residual, relu, mask_out, precision, float(drop_p), seed, seed_t, tape, packs)
+              packs=None, xb=None, out_bf16=False):
+    return ConvRows.apply(x, w, b, rowmask, residual, relu, mask_out, precision, float(drop_p), seed, seed_t, tape, packs, xb, out_bf16)
 
 
 class LayerNormRows(torch.autograd.Function):
     """y = rowmask * dropout( relu?( LayerNorm(a [+ b]) * gamma + beta ) ), eps = 1e-4 (Modules.py:472-475)."""
 
     @staticmethod
-    def forward(ctx, a, b, gamma, beta, rowmask, relu, drop_p, seed, seed_t):
+    def forward(ctx, a, b, gamma, beta, rowmask, relu, drop_p, seed, seed_t, yb=None):
         a = a.contiguous()
         R, C = a.shape
         y = torch.empty_like(a)
         stats = torch.empty(R, 2, device=a.device)
         s = torch.empty_like(a) if b is not None else a
-        _lib.check(_L().glowtts_layernorm_fwd(a.data_ptr(), _sp(b.contiguous() if b is not None else None), s.data_ptr() if b is not None else None,
-                                              gamma.data_ptr(), beta.data_ptr(), _sp(rowmask), y.data_ptr(), stats.data_ptr(), R, C, 1e-4,
-                                              int(relu), float(drop_p), int(seed) & 0xFFFFFFFF, _sp(seed_t), _lib.stream()), "glowtts_layernorm_fwd")
+        _lib.check(_L().glowtts_layernorm_fwd_io(a.data_ptr(), _sp(b.contiguous() if b is not None else None), s.data_ptr() if b is not None else None,
+                                                 gamma.data_ptr(), beta.data_ptr(), _sp(rowmask), y.data_ptr(), stats.data_ptr(), R, C, 1e-4,
+                                                 int(relu), float(drop_p), int(seed) & 0xFFFFFFFF, _sp(seed_t), _sp(yb), _lib.stream()),
+                   "glowtts_layernorm_fwd_io")
         gated = relu or drop_p > 0
         ctx.save_for_backward(s, stats, gamma, rowmask, y if gated else None)
         ctx.cfg = (gated, float(drop_p), b is not None)
@@ -200,13 +226,19 @@ class LayerNormRows(torch.autograd.Function):
         ds = torch.empty_like(s)
         gb = torch.empty(2 * C, device=s.device)
         scratch = torch.empty(L.glowtts_layernorm_scratch_floats(R, C), device=s.device)
-        _lib.check(L.glowtts_layernorm_bwd(dy.data_ptr(), _sp(y), s.data_ptr(), stats.data_ptr(), gamma.data_ptr(), _sp(rowmask), ds.data_ptr(),
-                                           gb.data_ptr(), scratch.data_ptr(), R, C, int(gated), drop_p, _lib.stream()), "glowtts_layernorm_bwd")
-        return ds, (ds if has_b else None), gb[:C], gb[C:], None, None, None, None, None
+        _lib.check(L.glowtts_layernorm_bwd_io(dy.data_ptr(), _sp(y), s.data_ptr(), stats.data_ptr(), gamma.data_ptr(), _sp(rowmask), ds.data_ptr(),
+                                              gb.data_ptr(), scratch.data_ptr(), R, C, int(gated), drop_p, None, _lib.stream()), "glowtts_layernorm_bwd_io")
+        return ds, (ds if has_b else None), gb[:C], gb[C:], None, None, None, None, None, None
 
 
-def layernorm_rows(a, b, gamma, beta, rowmask, relu=False, drop_p=0.0, seed=0, seed_t=None):
-    return LayerNormRows.apply(a, b, gamma, beta, rowmask, relu, float(drop_p), seed, seed_t)
+def layernorm_rows(a, b, gamma, beta, rowmask, relu=False, drop_p=0.0, seed=0, seed_t=None, want_bf16=False):
+    """want_bf16: the result also exists rounded to bf16 (`bf16_of(y)`), written by the same pass - the operand of the convs that read y."""
+    if not want_bf16:
+        return LayerNormRows.apply(a, b, gamma, beta, rowmask, relu, float(drop_p), seed, seed_t)
+    yb = torch.empty(a.shape, device=a.device, dtype=torch.bfloat16)
+    y = LayerNormRows.apply(a, b, gamma, beta, rowmask, relu, float(drop_p), seed, seed_t, yb)
+    y._bf16 = yb
+    return y
 
 
 class EmbeddingRows(torch.autograd.Function):

@@ -33,11 +33,14 @@ constexpr int LN_MAXK = 16;          // channels per lane: C <= 1024
 // y = rowmask * dropout( relu?( LayerNorm(a + b) * gamma + beta ) ),  one wavefront per row.
 // Keeps s = a + b (when b is given) and (mean, rstd) per row for the backward.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t f2bf(float v) { const __bf16 b = (__bf16)v; return *reinterpret_cast<const uint16_t*>(&b); }
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ s_out,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ rowmask, float* __restrict__ y, float* __restrict__ stats,
                                                      long rows, int C, float eps, int relu, float drop_p, uint32_t seed,
-                                                     const uint32_t* __restrict__ seed_ptr)
+                                                     const uint32_t* __restrict__ seed_ptr, uint16_t* __restrict__ yb)
 {
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -71,32 +74,40 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ a
         if (relu) o = fmaxf(o, 0.f);
         if (drop_p > 0.f) o *= drop_scale(seed, (uint32_t)(r * C + c), drop_p, ik);
         y[r * C + c] = o * m;
+        if (yb) yb[r * C + c] = f2bf(o * m);          // the same rows as an MFMA operand (LDS-DMA convs read raw bf16)
     }
 }
 
 // backward: dz = dy * mask * gate(y) ; ds = rstd (g dz - mean(g dz) - xhat mean(g dz xhat)) ; partial dgamma / dbeta per block
 // gate(y): relu and/or dropout -> (y != 0) * 1/(1-p)   (y is the forward output: zero exactly where relu / dropout / mask cut)
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ s,
+// KT: compile-time ceil(C / 64) (3 for the 192-channel encoder, 4 for the duration predictor; 0 = generic): the per-lane arrays then have exactly
+// KT entries.  ONE row per wavefront, 16 wavefronts = 16 rows per workgroup: every load of the pass is in flight at once (four waves walking
+// four rows each in dependent round trips to HBM took 22.6 us for 12 MB, 6 % of HBM bandwidth; now 9) and the second stage still sums only
+// rows / 16 partials per column.
+constexpr int LN_BWD_WAVES = 16;
+template <int KT>
+__global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ s,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* __restrict__ rowmask, float* __restrict__ ds, float* __restrict__ partial,
-                                                     long rows, int C, int gated, float drop_p, int rows_per_block)
+                                                     long rows, int C, int gated, float drop_p, int rows_per_block, uint16_t* __restrict__ dsb)
 {
-    extern __shared__ float red[];                 // [4 waves][2][C]
+    extern __shared__ float red[];                 // [LN_BWD_WAVES][2][C]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int K = (C + 63) / 64;
+    constexpr int KM = KT > 0 ? KT : LN_MAXK;
+    const int K = KT > 0 ? KT : (C + 63) / 64;
     const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    float accg[LN_MAXK], accb[LN_MAXK];
+    float accg[KM], accb[KM];
 #pragma unroll
-    for (int k = 0; k < LN_MAXK; ++k) { accg[k] = 0.f; accb[k] = 0.f; }
+    for (int k = 0; k < KM; ++k) { accg[k] = 0.f; accb[k] = 0.f; }
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min(rows, r0 + rows_per_block);
-    for (long r = r0 + wave; r < r1; r += 4) {
+    for (long r = r0 + wave; r < r1; r += LN_BWD_WAVES) {
         const float mean = stats[2 * r], rstd = stats[2 * r + 1];
         const float m = rowmask ? rowmask[r] : 1.f;
-        float dz[LN_MAXK], xh[LN_MAXK];
+        float dz[KM], xh[KM];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXK; ++k) {
+        for (int k = 0; k < KM; ++k) {
             if (k >= K) break;
             const int c = lane + 64 * k;
             float d = 0.f, x = 0.f;
@@ -111,23 +122,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         }
         s1 = wave_sum(s1) / C; s2 = wave_sum(s2) / C;
 #pragma unroll
-        for (int k = 0; k < LN_MAXK; ++k) {
+        for (int k = 0; k < KM; ++k) {
             if (k >= K) break;
             const int c = lane + 64 * k;
-            if (c < C) ds[r * C + c] = rstd * (dz[k] - s1 - xh[k] * s2);
+            if (c < C) {
+                const float g = rstd * (dz[k] - s1 - xh[k] * s2);
+                ds[r * C + c] = g;
+                if (dsb) dsb[r * C + c] = f2bf(g);
+            }
         }
     }
 #pragma unroll
-    for (int k = 0; k < LN_MAXK; ++k) {
+    for (int k = 0; k < KM; ++k) {
         if (k >= K) break;
         const int c = lane + 64 * k;
         if (c < C) { red[(wave * 2 + 0) * C + c] = accg[k]; red[(wave * 2 + 1) * C + c] = accb[k]; }
     }
     __syncthreads();
     float* out = partial + (long)blockIdx.x * 2 * C;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    for (int i = threadIdx.x; i < 2 * C; i += LN_BWD_WAVES * 64) {
         const int which = i / C, c = i - which * C;
-        out[i] = red[(0 * 2 + which) * C + c] + red[(1 * 2 + which) * C + c] + red[(2 * 2 + which) * C + c] + red[(3 * 2 + which) * C + c];
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < LN_BWD_WAVES; ++w) t += red[(w * 2 + which) * C + c];
+        out[i] = t;
     }
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int n)
@@ -142,16 +160,23 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 }
 
 // dz = dy * (out != 0 ? scale : 0) * rowmask      (backward gate of relu and/or dropout, see ln_bwd_kernel)
-__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out, const float* __restrict__ rowmask,
-                                                       float* __restrict__ dz, long rows, int C, float scale)
+template <bool DYB, bool OUTB, bool DZB>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const void* __restrict__ dy_, const void* __restrict__ out_, const float* __restrict__ rowmask,
+                                                       void* __restrict__ dz_, long rows, int C, float scale)
 {
+    // DYB / OUTB / DZB: that tensor is stored as bf16 (operands of the LDS-DMA convs and of the wide weight-gradient staging)
     const long total = rows * C / 4;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long r = (i * 4) / C;
         const float m = (rowmask ? rowmask[r] : 1.f) * scale;
-        const float4 d = reinterpret_cast<const float4*>(dy)[i];
-        const float4 o = reinterpret_cast<const float4*>(out)[i];
-        reinterpret_cast<float4*>(dz)[i] = make_float4(o.x != 0.f ? d.x * m : 0.f, o.y != 0.f ? d.y * m : 0.f, o.z != 0.f ? d.z * m : 0.f, o.w != 0.f ? d.w * m : 0.f);
+        float4 d, o;
+        if (DYB) { const ushort4 t = reinterpret_cast<const ushort4*>(dy_)[i]; d = make_float4(bf2f(t.x), bf2f(t.y), bf2f(t.z), bf2f(t.w)); }
+        else d = reinterpret_cast<const float4*>(dy_)[i];
+        if (OUTB) { const ushort4 t = reinterpret_cast<const ushort4*>(out_)[i]; o = make_float4(bf2f(t.x), bf2f(t.y), bf2f(t.z), bf2f(t.w)); }
+        else o = reinterpret_cast<const float4*>(out_)[i];
+        const float4 z = make_float4(o.x != 0.f ? d.x * m : 0.f, o.y != 0.f ? d.y * m : 0.f, o.z != 0.f ? d.z * m : 0.f, o.w != 0.f ? d.w * m : 0.f);
+        if (DZB) { ushort4 t; t.x = f2bf(z.x); t.y = f2bf(z.y); t.z = f2bf(z.z); t.w = f2bf(z.w); reinterpret_cast<ushort4*>(dz_)[i] = t; }
+        else reinterpret_cast<float4*>(dz_)[i] = z;
     }
 }
 
@@ -462,35 +487,66 @@ inline int grid_for(long total, int per = 256, int cap = 2048) { long g = (total
 
 }  // namespace
 
+extern "C" int glowtts_layernorm_fwd_io(const float* a, const float* b, float* s_out, const float* gamma, const float* beta, const float* rowmask,
+                                        float* y, float* stats, int64_t rows, int C, float eps, int relu, float drop_p, uint32_t seed,
+                                        const uint32_t* seed_ptr, uint16_t* y_bf16, void* stream)
+{
+    if (!a || !gamma || !beta || !y || !stats || rows < 1 || C < 1 || C > 64 * LN_MAXK || (b && !s_out)) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       a, b, s_out, gamma, beta, rowmask, y, stats, (long)rows, C, eps, relu, drop_p, seed, seed_ptr, y_bf16);
+    RET_LAUNCH();
+}
 extern "C" int glowtts_layernorm_fwd(const float* a, const float* b, float* s_out, const float* gamma, const float* beta, const float* rowmask,
                                      float* y, float* stats, int64_t rows, int C, float eps, int relu, float drop_p, uint32_t seed,
                                      const uint32_t* seed_ptr, void* stream)
 {
-    if (!a || !gamma || !beta || !y || !stats || rows < 1 || C < 1 || C > 64 * LN_MAXK || (b && !s_out)) return GLOWTTS_E_ARG;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       a, b, s_out, gamma, beta, rowmask, y, stats, (long)rows, C, eps, relu, drop_p, seed, seed_ptr);
-    RET_LAUNCH();
+    return glowtts_layernorm_fwd_io(a, b, s_out, gamma, beta, rowmask, y, stats, rows, C, eps, relu, drop_p, seed, seed_ptr, nullptr, stream);
 }
 
-extern "C" int64_t glowtts_layernorm_scratch_floats(int64_t rows, int C) { return ((rows + 15) / 16) * 2 * (int64_t)C; }
+constexpr int LN_BWD_RPB = LN_BWD_WAVES;  // rows per workgroup of ln_bwd_kernel (one per wavefront)
+extern "C" int64_t glowtts_layernorm_scratch_floats(int64_t rows, int C) { return ((rows + LN_BWD_RPB - 1) / LN_BWD_RPB) * 2 * (int64_t)C; }
 
-extern "C" int glowtts_layernorm_bwd(const float* dy, const float* y, const float* s, const float* stats, const float* gamma, const float* rowmask,
-                                     float* ds, float* dgamma_dbeta /* [2C] */, float* scratch, int64_t rows, int C, int gated, float drop_p, void* stream)
+extern "C" int glowtts_layernorm_bwd_io(const float* dy, const float* y, const float* s, const float* stats, const float* gamma, const float* rowmask,
+                                        float* ds, float* dgamma_dbeta /* [2C] */, float* scratch, int64_t rows, int C, int gated, float drop_p,
+                                        uint16_t* ds_bf16, void* stream)
 {
     if (!dy || !s || !stats || !gamma || !ds || !dgamma_dbeta || !scratch || rows < 1 || C < 1 || C > 64 * LN_MAXK || (gated && !y)) return GLOWTTS_E_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int rpb = 16;
+    const int rpb = LN_BWD_RPB;
     const int nblk = (int)((rows + rpb - 1) / rpb);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 8 * C * sizeof(float), st, dy, y, s, stats, gamma, rowmask, ds, scratch, (long)rows, C, gated, drop_p, rpb);
+    const int K = (C + 63) / 64;
+    if (K == 3)      hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(nblk), dim3(LN_BWD_WAVES * 64), 2 * LN_BWD_WAVES * C * sizeof(float), st, dy, y, s, stats, gamma, rowmask, ds, scratch, (long)rows, C, gated, drop_p, rpb, ds_bf16);
+    else if (K == 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nblk), dim3(LN_BWD_WAVES * 64), 2 * LN_BWD_WAVES * C * sizeof(float), st, dy, y, s, stats, gamma, rowmask, ds, scratch, (long)rows, C, gated, drop_p, rpb, ds_bf16);
+    else {
+        if (2 * LN_BWD_WAVES * C * sizeof(float) > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GLOWTTS_E_LAUNCH;
+        hipLaunchKernelGGL(ln_bwd_kernel<0>, dim3(nblk), dim3(LN_BWD_WAVES * 64), 2 * LN_BWD_WAVES * C * sizeof(float), st, dy, y, s, stats, gamma, rowmask, ds, scratch, (long)rows, C, gated, drop_p, rpb, ds_bf16);
+    }
     hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, st, scratch, dgamma_dbeta, nblk, 2 * C);
     RET_LAUNCH();
 }
+extern "C" int glowtts_layernorm_bwd(const float* dy, const float* y, const float* s, const float* stats, const float* gamma, const float* rowmask,
+                                     float* ds, float* dgamma_dbeta /* [2C] */, float* scratch, int64_t rows, int C, int gated, float drop_p, void* stream)
+{
+    return glowtts_layernorm_bwd_io(dy, y, s, stats, gamma, rowmask, ds, dgamma_dbeta, scratch, rows, C, gated, drop_p, nullptr, stream);
+}
 
+extern "C" int glowtts_gate_bwd_io(const void* dy, const void* out, const float* rowmask, void* dz, int64_t rows, int C, float scale, int io_flags, void* stream)
+{
+    if (!dy || !out || !dz || rows < 1 || C < 4 || (C & 3) || (io_flags & ~7)) return GLOWTTS_E_ARG;
+    const dim3 grid(grid_for(rows * C / 4));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define GATE_CASE(F, A, B, Z) case F: hipLaunchKernelGGL((gate_bwd_kernel<A, B, Z>), grid, dim3(256), 0, st, dy, out, rowmask, dz, (long)rows, C, scale); break;
+    switch (io_flags) {
+        GATE_CASE(0, false, false, false) GATE_CASE(1, true, false, false) GATE_CASE(2, false, true, false) GATE_CASE(3, true, true, false)
+        GATE_CASE(4, false, false, true)  GATE_CASE(5, true, false, true)  GATE_CASE(6, false, true, true)  GATE_CASE(7, true, true, true)
+    }
+#undef GATE_CASE
+    RET_LAUNCH();
+}
 extern "C" int glowtts_gate_bwd(const float* dy, const float* out, const float* rowmask, float* dz, int64_t rows, int C, float scale, void* stream)
 {
-    if (!dy || !out || !dz || rows < 1 || C < 4 || (C & 3)) return GLOWTTS_E_ARG;
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(rows * C / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, out, rowmask, dz, (long)rows, C, scale);
-    RET_LAUNCH();
+    return glowtts_gate_bwd_io(dy, out, rowmask, dz, rows, C, scale, 0, stream);
 }
 
 extern "C" int glowtts_embedding_fwd(const int64_t* tokens, const float* table, const float* rowmask, float* rows, int B, int T, int C, float scale, void* stream)

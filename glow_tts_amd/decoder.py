@@ -108,12 +108,14 @@ TAIL = {"defer": False, "pending": []}
 #   wgrad_wide: 16-byte staging items in the weight-gradient kernel; fuse_coupling_bwd: the next flow's coupling backward rides in the
 #   ActNorm / 1x1 backward pass; wgrad_split: weight gradients in n segments on a second stream (1 = one grouped launch per class);
 #   act_bf16: WaveNet state / gates / gate gradients stored as bf16 in bf16 precision
-#   fused_wn_bwd: its data gradients likewise (csrc/wavenet_fused_bwd.hip; unconditioned models).  OFF by default: alone it is faster than the
-#       ten launches it replaces (126 vs 155 us per flow, tools/bench_wn.py), inside the training step it is slower (6.33 vs 5.93 ms/step): a
-#       workgroup that owns a whole CU (150 KB of LDS, 3 x 168 VGPRs per SIMD) for 126 us leaves the encoder stream's backward no CU to share,
-#       and that stream stops being hidden
+#   fused_wn_bwd: its data gradients likewise (csrc/wavenet_fused_bwd.hip; unconditioned models), for flows 0 .. n-1 - the flows the backward
+#       reaches LAST.  n: a count, True = all flows, -1 (default) = half of them.  Alone the fused kernel is faster than the ten launches it
+#       replaces (126 vs 155 us per flow, 151 vs 178 with cold caches: tools/bench_wn.py), but a workgroup that owns a whole CU (150 KB of LDS,
+#       3 x 168 VGPRs per SIMD) for 126 us leaves the encoder stream's backward no CU to share, and while that stream is busy the step LOSES:
+#       all 12 flows 6.33 vs 5.90 ms/step, 9 flows 5.95.  The encoder's backward has drained by the time the decoder's backward is half way:
+#       the last 6 flows fused 5.70 vs 5.85 and 5.82 vs 5.92 ms/step on two boxes
 #   fused_wn: the coupling network of a flow (Start .. End + coupling) as ONE launch (csrc/wavenet_fused.hip) where its shape contract holds
-TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": False}
+TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_fwd_skip": 0}
 WN_SLAB = 24576                          # GLOWTTS_WN_SLAB_BYTES
 TAIL_STACKS = ("start_g", "start_v", "start_b", "rs_g", "rs_v", "rs_b", "rsl_g", "rsl_v", "rsl_b", "end_w", "end_b")
 
@@ -280,25 +282,33 @@ class _Prepared:
             }
             if Lw > 1:
                 self.pk["rs"] = ImageSlices(self.wn_img, nb, 32 * S, Lw - 1, 36 * S, 2 * H, H // 32)       # (PAIR-packed: read by the fused kernel only)
-        else:
-            self.pk = {
+        # training: the first flows of the forward can stay on the per-conv launches (TUNE["fused_wn_fwd_skip"]) - they run beside the
+        # text encoder's forward on the other stream, which a CU-filling fused workgroup starves
+        nskip = min(int(TUNE["fused_wn_fwd_skip"]), F_) if (need_bwd and self.wn_img is not None) else 0
+        pk_conv = None
+        if self.wn_img is None or nskip > 0:
+            pk_conv = {
                 "start": PackedBatch(W["w_start"], False, ops.PERM_NONE, 0, P),
                 "in": PackedBatch(w_in, False, ops.PERM_PAIR, H, P),
                 "rs_last": PackedBatch(W["w_rs_last"], False, ops.PERM_NONE, 0, P),
                 "end": PackedBatch(W["w_end"], False, ops.PERM_PAIR, C // 2, P),
             }
             if Lw > 1:
-                self.pk["rs"] = PackedBatch(W["w_rs"].reshape(F_ * (Lw - 1), 2 * H, H, 1), False, ops.PERM_NONE, 0, P)
+                pk_conv["rs"] = PackedBatch(W["w_rs"].reshape(F_ * (Lw - 1), 2 * H, H, 1), False, ops.PERM_NONE, 0, P)
+            if self.wn_img is None:
+                self.pk = pk_conv
         # backward: the transposed image of the fused data-gradient kernel (glowtts_wavenet_bwd) where it applies - no conditioning gradient -
         # else the per-conv transposed images
         self.wn_img_t = None
-        if need_bwd and self.wn_img is not None and cond is None and TUNE["fused_wn_bwd"]:
+        nfb = TUNE["fused_wn_bwd"]
+        nfb = F_ if nfb is True else (F_ // 2 if int(nfb) < 0 else min(int(nfb), F_))      # flows 0 .. nfb-1 take the fused kernel
+        if need_bwd and self.wn_img is not None and cond is None and nfb > 0:
             self.wn_img_t = torch.empty_like(self.wn_img)
             _lib.check(L.glowtts_wavenet_pack_images(_lib.ptr(W["w_start"].contiguous()), _lib.ptr(W["w_in"].contiguous()),
                                                      _lib.ptr(W["w_rs"].contiguous()) if Lw > 1 else None, _lib.ptr(W["w_rs_last"].contiguous()),
                                                      _lib.ptr(W["w_end"].contiguous()), F_, Lw, C // 2, None, _lib.ptr(self.wn_img_t), _lib.stream()),
                        "wavenet_pack_images(bwd)")
-        if need_bwd and self.wn_img_t is None:
+        if need_bwd and (self.wn_img_t is None or nfb < F_):
             self.pk.update({
                 "start_t": PackedBatch(W["w_start"], True, ops.PERM_NONE, 0, P),
                 "in_t": PackedBatch(w_in, True, ops.PERM_PAIR, H, P),
@@ -316,22 +326,24 @@ class _Prepared:
             p.an_logs = W["an_logs"][f].data_ptr()
             p.an_bias = W["an_bias"][f].data_ptr()
             p.winfo = self.winfo[f].data_ptr()
-            p.start = self.pk["start"].at(f)
-            p.end = self.pk["end"].at(f)
+            fused_f = self.wn_img is not None and f >= nskip
+            pkf = self.pk if fused_f or pk_conv is None else pk_conv
+            p.start = pkf["start"].at(f)
+            p.end = pkf["end"].at(f)
             p.b_start = W["b_start"][f].data_ptr()
             p.b_end = W["b_end"][f].data_ptr()
-            p.wn_img = self.wn_img[f].data_ptr() if self.wn_img is not None else None
+            p.wn_img = self.wn_img[f].data_ptr() if fused_f else None
             for l in range(Lw):
-                p.in_[l] = self.pk["in"].at(f * Lw + l)
+                p.in_[l] = pkf["in"].at(f * Lw + l)
                 p.b_in[l] = W["b_in"][f, l].data_ptr()
                 if l < Lw - 1:
-                    p.rs[l] = self.pk["rs"].at(f * (Lw - 1) + l)
+                    p.rs[l] = pkf["rs"].at(f * (Lw - 1) + l)
                     p.b_rs[l] = W["b_rs"][f, l].data_ptr()
                 else:
-                    p.rs[l] = self.pk["rs_last"].at(f)
+                    p.rs[l] = pkf["rs_last"].at(f)
                     p.b_rs[l] = W["b_rs_last"][f].data_ptr()
-            p.wn_img_t = self.wn_img_t[f].data_ptr() if self.wn_img_t is not None else None
-            if need_bwd and self.wn_img_t is None:
+            p.wn_img_t = self.wn_img_t[f].data_ptr() if (self.wn_img_t is not None and f < nfb) else None
+            if need_bwd and p.wn_img_t is None:
                 p.start_t = self.pk["start_t"].at(f)
                 p.end_t = self.pk["end_t"].at(f)
                 for l in range(Lw):

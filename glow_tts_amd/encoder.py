@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from .conv_fn import EmbeddingRows, ParamGate, RPRAttention, WgradTape, conv_rows, layernorm_rows
+from .conv_fn import EmbeddingRows, ParamGate, RPRAttention, WgradTape, bf16_of, conv_rows, layernorm_rows
 
 ROW_PAD = 2
 
@@ -80,15 +80,22 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
             packset = cache[slot] = ops.PackSet(items, precision)
         packset.run()
 
-    def conv(xr, name, relu=False, mask_out=False, residual=None, drop=0.0):
+    # bf16 mode: every LayerNorm also writes its rows as bf16 and the convs that read them (and chains of convs) run on bf16-stored
+    # operands - the LDS-DMA kernel instead of the register-staged one (fp32 -> bf16 in the loop); see conv_fn.ConvRows
+    bf_rows = precision == ops.BF16 and C % 32 == 0
+
+    def conv(xr, name, relu=False, mask_out=False, residual=None, drop=0.0, out_bf16=False, xb=None):
         p_ = float(drop) if training else 0.0
+        xb = (xb if xb is not None else bf16_of(xr)) if bf_rows else None
+        out_bf16 = out_bf16 and (xb is not None or xr.dtype == torch.bfloat16)
         return conv_rows(xr, Pc[name + ".weight"], Pc.get(name + ".bias"), rmf, relu=relu, mask_out=mask_out, residual=residual,
                          precision=precision, drop_p=p_, seed=nseed(), seed_t=seed_t, tape=tape,
-                         packs=packset.get(name) if packset is not None else None)
+                         packs=packset.get(name) if packset is not None else None, xb=xb, out_bf16=out_bf16)
 
     def ln(a, b, name, relu=False, drop=0.0):
         p_ = float(drop) if training else 0.0
-        return layernorm_rows(a, b, P[name + ".weight"], P[name + ".bias"], rmf, relu=relu, drop_p=p_, seed=nseed(), seed_t=seed_t)
+        return layernorm_rows(a, b, P[name + ".weight"], P[name + ".bias"], rmf, relu=relu, drop_p=p_, seed=nseed(), seed_t=seed_t,
+                              want_bf16=bf_rows)
 
     x = EmbeddingRows.apply(tokens, P[prefix + ".layer_Dict.Embedding.weight"], rmf, math.sqrt(C))          # :267
     # Prenet :438-489   Conv(x*mask) -> LayerNorm -> ReLU -> Dropout, x3; Conv1x1 + residual; *mask
@@ -109,7 +116,7 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
                                  float(dr) if training else 0.0, nseed(), seed_t, precision)                 # RPR_MHA.py:95-128
         att = conv(att, a + ".layer_Dict.Projection", drop=dr)                                               # :93 + Dropout :561
         x = ln(att, x, q + ".LayerNorm_0")                                                                   # :562
-        h = conv(x, q + ".Conv_0", relu=True, mask_out=True, drop=dr)                                        # :565-567
+        h = conv(x, q + ".Conv_0", relu=True, mask_out=True, drop=dr, out_bf16=True)                         # :565-567 (only Conv_1 reads it)
         h = conv(h, q + ".Conv_1", mask_out=True, drop=dr)                                                   # :568-569 (x*mask at :571)
         x = ln(h, x, q + ".LayerNorm_1")                                                                     # :571
     proj = conv(x, prefix + ".layer_Dict.Project", mask_out=True).view(B, Tp, -1)
@@ -117,7 +124,7 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
     proj = from_rows(proj)
     mean, log_std = proj[:, :M].contiguous(), proj[:, M:].contiguous()      # (here, on the encoder stream: the consumers need dense rows)
     # Duration predictor on detached features (:277-282, 602-618)
-    d = x.detach()
+    d, db = x.detach(), bf16_of(x)
     cond = None
     if speakers is not None:
         cond = speakers.detach()
@@ -125,10 +132,11 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
         cond = prosodies.detach() if cond is None else cond + prosodies.detach()
     if cond is not None:
         d = torch.cat([d.view(B, Tp, C), cond.unsqueeze(1).expand(-1, Tp, -1) * rmf.view(B, Tp, 1)], dim=2).reshape(B * Tp, -1).contiguous()
+        db = None
     dp = e.Duration_Predictor
     for i in range(dp.Stacks):
         q = f"{prefix}.layer_Dict.Duration_Predictor.layer_Dict.CRND_{i}.layer_Dict.Conv"
-        d = conv(d, q, relu=True, mask_out=True, drop=dp.Dropout_Rate)
+        d = conv(d, q, relu=True, mask_out=True, drop=dp.Dropout_Rate, xb=db if i == 0 else None, out_bf16=i + 1 < dp.Stacks)
     # Projection to one channel: N = 1 is not a GEMM; a masked dot product per frame (multiply + row reduction: rocBLAS' gemv took
     # 82 us for these 3.5k x 256 rows, 5x the two elementwise kernels)
     wq = prefix + ".layer_Dict.Duration_Predictor.layer_Dict.Projection"

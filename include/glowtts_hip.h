@@ -467,12 +467,22 @@ int glowtts_col2im3x3s2(const float *dcol, float *dx, int B, int H, int W, int C
 int glowtts_layernorm_fwd(const float *a, const float *b, float *s_out, const float *gamma, const float *beta, const float *rowmask,
                           float *y, float *stats, int64_t rows, int C, float eps, int relu, float drop_p, uint32_t seed,
                           const uint32_t *seed_ptr, void *stream);
+/* same, and y_bf16 (may be NULL) additionally receives y rounded to bf16: the A operand of the LDS-DMA convs that consume y */
+int glowtts_layernorm_fwd_io(const float *a, const float *b, float *s_out, const float *gamma, const float *beta, const float *rowmask,
+                             float *y, float *stats, int64_t rows, int C, float eps, int relu, float drop_p, uint32_t seed,
+                             const uint32_t *seed_ptr, uint16_t *y_bf16, void *stream);
 int64_t glowtts_layernorm_scratch_floats(int64_t rows, int C);
 /* ds = dL/d(a + b); dgamma_dbeta [2C].  gated != 0: the forward applied relu and/or dropout, y is its output (zero where cut). */
 int glowtts_layernorm_bwd(const float *dy, const float *y, const float *s, const float *stats, const float *gamma, const float *rowmask,
                           float *ds, float *dgamma_dbeta, float *scratch, int64_t rows, int C, int gated, float drop_p, void *stream);
+/* same, and ds_bf16 (may be NULL) additionally receives ds rounded to bf16 */
+int glowtts_layernorm_bwd_io(const float *dy, const float *y, const float *s, const float *stats, const float *gamma, const float *rowmask,
+                             float *ds, float *dgamma_dbeta, float *scratch, int64_t rows, int C, int gated, float drop_p,
+                             uint16_t *ds_bf16, void *stream);
 /* dz = dy * (out != 0 ? scale : 0) * rowmask : backward gate of relu / dropout given the forward output */
 int glowtts_gate_bwd(const float *dy, const float *out, const float *rowmask, float *dz, int64_t rows, int C, float scale, void *stream);
+/* io_flags: 1 = dy, 2 = out, 4 = dz stored as bf16 instead of fp32 (C a multiple of 4) */
+int glowtts_gate_bwd_io(const void *dy, const void *out, const float *rowmask, void *dz, int64_t rows, int C, float scale, int io_flags, void *stream);
 /* rows[b][PAD+t][:] = table[tokens[b][t]][:] * scale * mask (Modules.py:267), and its gradient (deterministic) */
 int glowtts_embedding_fwd(const int64_t *tokens, const float *table, const float *rowmask, float *rows, int B, int T, int C, float scale, void *stream);
 int glowtts_embedding_bwd(const int64_t *tokens, const float *drows, const float *rowmask, float *dtable, int V, int B, int T, int C, float scale, void *stream);

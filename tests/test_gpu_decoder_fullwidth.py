@@ -95,11 +95,13 @@ def test_full_width_backward_bf16_takes_the_benchmarked_kernels(spk_dim):
     L = 4
     assert _count(counts, "wn_fwd<") == N_FLOWS, counts                                   # the fused coupling network: one launch per flow
     assert _count(counts, "conv_dma<GATE,5>") == 0 and _count(counts, "conv_dma<RESSKIP,1>") == 0 and _count(counts, "conv_chain<RESSKIP,COUPLE>") == 0, counts
-    # the backward the training step runs by default: per-conv launches (the fused data-gradient kernel, decoder.TUNE["fused_wn_bwd"], has its
-    # own parity tests in tests/test_gpu_wavenet_fused.py and is slower INSIDE the step: DESIGN.md section 5)
-    assert _count(counts, "conv_dma<LINEAR,5>") == N_FLOWS * L, counts                    # In_l data gradient
-    assert _count(counts, "conv_dma<DGATE,1>") == N_FLOWS * (L - 1), counts
-    assert _count(counts, "conv_chain<LINEAR,DGATE>") == N_FLOWS, counts
+    # the backward the training step runs by default: per-conv launches for the flows it reaches first, the fused data-gradient kernel for
+    # the last half (unconditioned models only; decoder.TUNE["fused_wn_bwd"], parity in tests/test_gpu_wavenet_fused.py)
+    nfb = N_FLOWS // 2 if spk_dim == 0 else 0
+    assert _count(counts, "wn_bwd<") == nfb, counts
+    assert _count(counts, "conv_dma<LINEAR,5>") == (N_FLOWS - nfb) * L, counts           # In_l data gradient
+    assert _count(counts, "conv_dma<DGATE,1>") == (N_FLOWS - nfb) * (L - 1), counts
+    assert _count(counts, "conv_chain<LINEAR,DGATE>") == N_FLOWS - nfb, counts
     assert _count(counts, "wgrad<5,bf16,dybf16,xbf16,wide>/grouped") == 1, counts        # all In_l weight gradients: one grouped launch
     assert _count(counts, "wgrad<1,bf16,dybf16,xbf16,wide>/grouped") == 1, counts        # Res_Skip_l
     assert _count(counts, "wgrad<1,bf16,dyf32,xf32,wide>/grouped") == 1, counts          # Start / End
@@ -132,7 +134,7 @@ def test_full_width_backward_bf16_takes_the_benchmarked_kernels(spk_dim):
 @pytest.mark.parametrize("spk_dim", [0, 256])
 def test_full_width_dropout_masks_agree_between_forward_backward_and_precisions(spk_dim):
     """Training-mode WaveNet dropout (Modules.py:861-862, p = 0.3 here) at the benchmarked width.  The keep mask is a counter hash of (seed, row,
-    channel), regenerated by the backward; the bf16 path draws it in the fused `wn_fwd_kernel` / `conv_dma_kernel<DGATE>` / `conv_chain<LINEAR,DGATE>`,
+    channel), regenerated by the backward; the bf16 path draws it in the fused `wn_fwd_kernel` / `wn_bwd_kernel` / `conv_dma_kernel<DGATE>` / `conv_chain<LINEAR,DGATE>`,
     the f32 path in the register-staged kernels.  Same seed => the two precisions see the SAME masks, so (1) z agrees to bf16 accuracy,
     (2) every gradient of the bf16 path has cosine >= 0.98 with the f32 path's - a forward / backward mask mismatch in any of the DMA kernels
     would decorrelate them (p = 0.3 rescales 30 % of the gate gradients to zero), (3) the conditioning gradient, taken BEFORE the mask, agrees
@@ -147,7 +149,9 @@ def test_full_width_dropout_masks_agree_between_forward_backward_and_precisions(
     torch.manual_seed(6)
     z16c = _hip_grads(*case, precision=1, drop_p=0.3)[0]
     assert torch.equal(z16, z16b) and (z16 - z16c).abs().max() > 1e-2
-    assert _count(counts, "wn_fwd<drop") == N_FLOWS and _count(counts, "conv_chain<LINEAR,DGATE>") == N_FLOWS
+    nfb = N_FLOWS // 2 if spk_dim == 0 else 0            # the unconditioned backward's last flows take the fused data-gradient kernel
+    assert _count(counts, "wn_fwd<drop") == N_FLOWS and _count(counts, "conv_chain<LINEAR,DGATE>") == N_FLOWS - nfb
+    assert _count(counts, "wn_bwd<drop") == nfb
     mask = O.mask_from_lengths(case[3], TM)
     assert ((z16 - z32) * mask).abs().max() <= 0.15
     worst = (2.0, "")

@@ -161,6 +161,7 @@ def test_exact_wait_counts_equal_conservative_waits():
 
 
 def _grads(D, dc, P, mels, ml, wz, wl, fused_bwd, drop_p=0.0):
+    default = D.TUNE["fused_wn_bwd"]
     D.TUNE["fused_wn_bwd"] = fused_bwd
     try:
         Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
@@ -172,7 +173,7 @@ def _grads(D, dc, P, mels, ml, wz, wl, fused_bwd, drop_p=0.0):
         torch.cuda.synchronize()
         return {k: p.grad for k, p in Pg.items()}, x.grad, launch_counts()
     finally:
-        D.TUNE["fused_wn_bwd"] = False
+        D.TUNE["fused_wn_bwd"] = default
 
 
 @pytest.mark.parametrize("lengths,tm,drop", [([640, 522, 240, 2], 640, 0.0), ([800] * 3, 800, 0.3), ([104], 104, 0.0), ([422, 36, 36, 800], 800, 0.05)])

@@ -55,7 +55,7 @@ for fused in (True, False):
         if fused:
             tl_fused = tl
         # ---- backward of the same flow (data gradients + ActNorm / 1x1 backward; weight gradients deferred as in the training step) ----
-        D.TUNE["fused_wn_bwd"] = fused
+        D.TUNE["fused_wn_bwd"] = bool(fused)
         prepb = D._Prepared(dc, W, need_bwd=True)
         ldo, ldin, H, C = prepb.ldo, prepb.ldin, dc.H, dc.C
         dx = torch.randn(R, C, device="cuda") * 0.1
@@ -84,6 +84,26 @@ for fused in (True, False):
             e1.record(st)
         torch.cuda.synchronize()
         res[("fused" if fused else "per-conv") + " bwd"] = e0.elapsed_time(e1) * 1e3 / n
+        if os.environ.get("COLD") == "1":
+            # the same with the caches flushed between launches (in the training step a flow's kept activations were written milliseconds
+            # and > 1 GB of traffic earlier: they come from HBM, not from the 256 MB MALL that a back-to-back loop over ONE flow enjoys)
+            flush = torch.empty(768 << 20, dtype=torch.uint8, device="cuda")
+            def timed(body):
+                gg = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(st):
+                    with torch.cuda.graph(gg, stream=st):
+                        for i in range(n):
+                            flush.fill_(i & 1)
+                            body()
+                    gg.replay()
+                    e0.record(st)
+                    gg.replay()
+                    e1.record(st)
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1e3 / n
+            base = timed(lambda: None)
+            res[("fused" if fused else "per-conv") + " bwd COLD"] = timed(runb) - base
+            res[("fused" if fused else "per-conv") + " fwd COLD"] = timed(run) - base
         res["fused" if fused else "per-conv"] = fwd_us
 if os.environ.get("GLOWTTS_WN_ABL") in ("32", "96", "160", "288"):
     t = tl_fused.view(512, 12, 32)[:200, :, :18].cpu()
