@@ -621,7 +621,7 @@ extern "C" int glowtts_wavenet_fwd(const glowtts_flow_dims* d, const glowtts_flo
     const int Tp = d->T + 2 * GLOWTTS_ROW_PAD;
     const int64_t R = (int64_t)d->B * Tp;
     if (R * 2 * WN_H * 2 >= ((int64_t)1 << 31) || R * d->C * 4 >= ((int64_t)1 << 31)) return GLOWTTS_E_ARG;
-    if (p->cond && (R * p->ldcond * 4 >= ((int64_t)1 << 31))) return GLOWTTS_E_ARG;
+    if (p->cond && ((p->cond_rows ? R : (int64_t)d->B) * p->ldcond * 4 >= ((int64_t)1 << 31))) return GLOWTTS_E_ARG;   // 32-bit buffer offsets (per-row / per-utterance table)
     wn_fwd_args k;
     memset(&k, 0, sizeof(k));
     k.rows = (int)R; k.rows_per_utt = Tp; k.L = d->L; k.C2 = C2; k.reverse = reverse; k.keep = keep;

@@ -303,20 +303,22 @@ class _Prepared:
         nfb = TUNE["fused_wn_bwd"]
         nfb = F_ if nfb is True else (F_ // 2 if int(nfb) < 0 else min(int(nfb), F_))      # flows 0 .. nfb-1 take the fused kernel
         if need_bwd and self.wn_img is not None and cond is None and nfb > 0:
-            self.wn_img_t = torch.empty_like(self.wn_img)
+            self.wn_img_t = torch.empty_like(self.wn_img[:nfb])                # (flows 0 .. nfb-1 only)
             _lib.check(L.glowtts_wavenet_pack_images(_lib.ptr(W["w_start"].contiguous()), _lib.ptr(W["w_in"].contiguous()),
                                                      _lib.ptr(W["w_rs"].contiguous()) if Lw > 1 else None, _lib.ptr(W["w_rs_last"].contiguous()),
-                                                     _lib.ptr(W["w_end"].contiguous()), F_, Lw, C // 2, None, _lib.ptr(self.wn_img_t), _lib.stream()),
+                                                     _lib.ptr(W["w_end"].contiguous()), nfb, Lw, C // 2, None, _lib.ptr(self.wn_img_t), _lib.stream()),
                        "wavenet_pack_images(bwd)")
-        if need_bwd and (self.wn_img_t is None or nfb < F_):
+        else:
+            nfb = 0
+        if need_bwd and nfb < F_:                                              # per-conv transposed images of flows nfb .. F-1 (element i = flow nfb + i)
             self.pk.update({
-                "start_t": PackedBatch(W["w_start"], True, ops.PERM_NONE, 0, P),
-                "in_t": PackedBatch(w_in, True, ops.PERM_PAIR, H, P),
-                "rs_last_t": PackedBatch(W["w_rs_last"], True, ops.PERM_NONE, 0, P),
-                "end_t": PackedBatch(W["w_end"], True, ops.PERM_PAIR, C // 2, P),
+                "start_t": PackedBatch(W["w_start"][nfb:], True, ops.PERM_NONE, 0, P),
+                "in_t": PackedBatch(w_in[nfb * Lw:], True, ops.PERM_PAIR, H, P),
+                "rs_last_t": PackedBatch(W["w_rs_last"][nfb:], True, ops.PERM_NONE, 0, P),
+                "end_t": PackedBatch(W["w_end"][nfb:], True, ops.PERM_PAIR, C // 2, P),
             })
             if Lw > 1:
-                self.pk["rs_t"] = PackedBatch(W["w_rs"].reshape(F_ * (Lw - 1), 2 * H, H, 1), True, ops.PERM_NONE, 0, P)
+                self.pk["rs_t"] = PackedBatch(W["w_rs"][nfb:].reshape((F_ - nfb) * (Lw - 1), 2 * H, H, 1), True, ops.PERM_NONE, 0, P)
         self.ldo = self.pk["end"].npad
         self.ldin = self.pk["in"].npad
         self.cond, self._H, self._Lw = cond, H, Lw
@@ -342,13 +344,14 @@ class _Prepared:
                 else:
                     p.rs[l] = pkf["rs_last"].at(f)
                     p.b_rs[l] = W["b_rs_last"][f].data_ptr()
-            p.wn_img_t = self.wn_img_t[f].data_ptr() if (self.wn_img_t is not None and f < nfb) else None
+            p.wn_img_t = self.wn_img_t[f].data_ptr() if f < nfb else None
             if need_bwd and p.wn_img_t is None:
-                p.start_t = self.pk["start_t"].at(f)
-                p.end_t = self.pk["end_t"].at(f)
+                fc = f - nfb
+                p.start_t = self.pk["start_t"].at(fc)
+                p.end_t = self.pk["end_t"].at(fc)
                 for l in range(Lw):
-                    p.in_t[l] = self.pk["in_t"].at(f * Lw + l)
-                    p.rs_t[l] = self.pk["rs_t"].at(f * (Lw - 1) + l) if l < Lw - 1 else self.pk["rs_last_t"].at(f)
+                    p.in_t[l] = self.pk["in_t"].at(fc * Lw + l)
+                    p.rs_t[l] = self.pk["rs_t"].at(fc * (Lw - 1) + l) if l < Lw - 1 else self.pk["rs_last_t"].at(fc)
             self.params.append(p)
         self.set_cond(cond)
 

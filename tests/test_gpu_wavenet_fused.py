@@ -137,6 +137,32 @@ def test_fused_inverse_matches_per_conv_launches(lengths, tm):
     assert ((back - z) * valid[:, :, :back.shape[2]]).abs().max() <= 0.1
 
 
+def test_fused_inverse_with_conditioning_at_long_form_size():
+    """Serving shape of the speaker-conditioned model: 12 flows, 32 utterances of 2074 frames.  rows x (F L 2H) x 4 bytes exceeds 2^31 - the
+    per-UTTERANCE conditioning table is indexed by utterance, so the 32-bit buffer offsets only have to span B x (F L 2H) (a bound on the row
+    count rejected this call with GLOWTTS_E_ARG until round 3).  Fused against per-conv launches on the same conditioning."""
+    Bn, tm = 32, 2074
+    D, dc, W, mels, ml, cond = _setup(12, [tm] * (Bn - 1) + [1500], tm, spk_dim=256, seed=11)
+    assert Bn * (tm // 2 + 4) * cond[0].numel() * 4 >= 2 ** 31
+    z = torch.randn(Bn, 80, tm, device="cuda") * 0.6
+    outs = []
+    for fused in (True, False):
+        D.TUNE["fused_wn"] = fused
+        try:
+            with torch.no_grad():
+                launch_reset()
+                outs.append(D.decoder_inverse(dc, W, z, ml, cond=cond))
+                torch.cuda.synchronize()
+                c = launch_counts()
+                assert (sum(n for k, n in c.items() if k.startswith("wn_fwd<nodrop,cond")) == 12) == fused, c
+        finally:
+            D.TUNE["fused_wn"] = True
+    valid = (torch.arange(outs[0].shape[2], device="cuda")[None, :] < (ml // 2 * 2)[:, None]).unsqueeze(1)
+    d = ((outs[0] - outs[1]) * valid).abs()
+    assert torch.isfinite(outs[0]).all()
+    assert (d ** 2).mean().sqrt() <= 2e-2 * ((outs[1] * valid) ** 2).mean().sqrt(), (d.max(), (d ** 2).mean().sqrt())
+
+
 def test_exact_wait_counts_equal_conservative_waits():
     """The fused kernel waits for its weight slabs with exact vmcnt counts that step over its own outstanding stores (wavenet_fused.hip
     begin_step).  A count that is too large would read a slab before it has landed - a race that shows as a wrong value now and then.  With
