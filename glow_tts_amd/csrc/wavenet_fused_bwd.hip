@@ -40,7 +40,8 @@ constexpr int BSZ_T = WN_KCH * WN_XR * 64;
 constexpr int BOFF_DT = BOFF_DS + BSZ_T;                        // da or ds of the layer: [6][68][64]; before that: d(m, logs) rows
 constexpr int BOFF_RING = BOFF_DT + BSZ_T;
 constexpr int BOFF_MK = BOFF_RING + BW_NS * WN_SLAB;
-constexpr int BW_LDS = BOFF_MK + WN_XR * 4;
+constexpr int BOFF_UT = BOFF_MK + WN_XR * 4;                    // utterance of the 68 tile rows (conditioned models)
+constexpr int BW_LDS = BOFF_UT + WN_XR * 4;
 static_assert(BW_LDS <= 160 * 1024, "LDS budget");
 static_assert(BSZ_T >= WN_NW * 8 * 256, "the partial-sum exchange (8 registers per wave and round) reuses the gate-gradient tile");
 
@@ -55,9 +56,13 @@ struct wn_bwd_args {
     void* dins[WN_MAXL]; int64_t ldin;            // out: bf16 [rows][ldin] PAIR-packed (da | ds per 32 channels)
     void* dh[WN_MAXL];                            // out: d x_l, l >= 1 bf16 [rows][H]; l = 0 fp32 [rows][H]
     float* dx; int64_t lddx;                      // in / out: [rows][lddx] fp32, channels [0, C2) += d x_a
+    float* dcond; int64_t ldcond;                 // COND: d conditioning [utterances][ldcond], layer l at + l * 2 H; ACCUMULATED (atomic adds)
 };
 
-template <bool DROP>
+// COND: the per-utterance conditioning joins the gate pre-activation AFTER the dropout (Modules.py:861-866): its gradient is the sum over an
+// utterance's rows of (da, ds) BEFORE the keep mask, which only exists here in registers.  Every workgroup adds the sums of its OWNED rows to
+// dcond with atomic adds, one run per utterance (as the per-conv DGATE epilogue does: order-dependent in the last bits).
+template <bool DROP, bool COND>
 __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char wb_smem[];
@@ -65,6 +70,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
     unsigned char* const DS = wb_smem + BOFF_DS;
     unsigned char* const DT = wb_smem + BOFF_DT;
     float* const MK = reinterpret_cast<float*>(wb_smem + BOFF_MK);
+    int* const UT = reinterpret_cast<int*>(wb_smem + BOFF_UT);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
             int g = xr0 + tid;
             g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
             MK[tid] = p.rowmask[g];
+            if (COND) UT[tid] = g / p.rows_per_utt;
         }
     }
     int bl[2];
@@ -264,10 +271,42 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
             const Rsrc rg = mk_rsrc(pick4(p.gates, l), (long)p.rows * (2 * WN_H * 2));
             const int g0 = xr0 + roff + rb;                     // global row of register 0
             const uint32_t rk0 = (uint32_t)g0 * 0x9E3779B1u + seed0 + (uint32_t)l;
+            // conditioning gradient: running sums of the current utterance's owned rows (this lane's column pair)
+            float sa = 0.f, ss = 0.f;
+            int cur_u = -1;
+            float* const dcl = COND ? p.dcond + (long)l * (2 * WN_H) + jch : nullptr;
+            // flush: called by ALL lanes (it shuffles).  Lanes l and l + 32 hold the same column, rows 4 apart: when both close a run of the
+            // same utterance the upper half hands its sums to the lower one, which alone issues the atomics.
+            auto flush = [&](const bool need) __attribute__((always_inline)) {
+                const int other_u = __shfl_xor(need ? cur_u : -2, 32, 64);
+                const bool pair = need && other_u == cur_u;
+                const float oa = __shfl_xor(sa, 32, 64), os = __shfl_xor(ss, 32, 64);
+                if (pair) { sa += oa; ss += os; }
+                if (need && cur_u >= 0 && !(pair && lhi)) {
+                    float* dst = dcl + (long)cur_u * p.ldcond;
+                    unsafeAtomicAdd(dst, sa); unsafeAtomicAdd(dst + WN_H, ss);
+                }
+                if (need) sa = ss = 0.f;
+            };
+            // (wave-uniform) all owned rows of this workgroup in one utterance - the rule, an utterance is hundreds of rows: no run logic
+            const int own_lo = halo + WN_PAD, own_hi = own_lo + lim;                     // owned TILE rows [own_lo, own_hi)
+            const bool one_utt = COND && lim > 0 && UT[halo + WN_PAD] == UT[halo + WN_PAD + lim - 1];
             auto gate = [&](float d, uint32_t w, int c) __attribute__((always_inline)) -> uint32_t {
                 const float t = __uint_as_float(w << 16), sg = __uint_as_float(w & 0xFFFF0000u);
                 const float dsg = d * sg;
                 float da = dsg * (1.f - t * t), ds = dsg * t * (1.f - sg);
+                if constexpr (COND) {
+                    const int tr = roff + rb + c;                                  // tile row of this accumulator row
+                    const bool own = tr >= own_lo && tr < own_hi;
+                    if (one_utt) { sa += own ? da : 0.f; ss += own ? ds : 0.f; }
+                    else {
+                        const int u = own ? UT[tr < WN_XR ? tr : WN_XR - 1] : cur_u;
+                        const bool need = own && u != cur_u;
+                        if (__any(need)) flush(need);
+                        if (need) cur_u = u;
+                        sa += own ? da : 0.f; ss += own ? ds : 0.f;
+                    }
+                }
                 if constexpr (DROP) {
                     uint32_t x = rk0 + (uint32_t)c * 0x9E3779B1u; x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13;
                     const uint32_t dd = drop_draw(x, jkey);
@@ -284,6 +323,11 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
             }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) pk[reg] = gate(acc0[reg], gw[reg], frag_row(reg));
+            if constexpr (COND) {
+                if (one_utt) cur_u = UT[halo + WN_PAD];
+                flush(true);
+                cur_u = -1;                                     // (the third row fragment below holds tile rows 64..67: never owned)
+            }
             if (last && w3) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
@@ -448,16 +492,16 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
 #undef WN_TOFF
 }
 
-template <bool DROP>
+template <bool DROP, bool COND>
 int launch_wn_bwd(const wn_bwd_args& k, dim3 grid, hipStream_t s)
 {
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wn_bwd_kernel<DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GLOWTTS_E_LAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wn_bwd_kernel<DROP, COND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GLOWTTS_E_LAUNCH;
         attr_done = true;
     }
-    GLOWTTS_NOTE_STATIC("wn_bwd<%s>", DROP ? "drop" : "nodrop");
-    hipLaunchKernelGGL((wn_bwd_kernel<DROP>), grid, dim3(WN_NT), BW_LDS, s, k);
+    GLOWTTS_NOTE_STATIC("wn_bwd<%s%s>", DROP ? "drop" : "nodrop", COND ? ",cond" : "");
+    hipLaunchKernelGGL((wn_bwd_kernel<DROP, COND>), grid, dim3(WN_NT), BW_LDS, s, k);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
@@ -490,7 +534,10 @@ extern "C" int glowtts_wavenet_bwd(const glowtts_flow_dims* d, const glowtts_flo
     const int C2 = d->C / 2;
     if (d->precision != GLOWTTS_BF16 || !d->act_bf16 || d->H != WN_H || d->ksize != WN_TAPS || d->L < 1 || d->L > WN_MAXL ||
         (d->C & 7) || C2 <= 64 || C2 > 96 || p->end.npad != 192 || p->in[0].npad != 2 * WN_H) return GLOWTTS_E_ARG;
-    if ((g->dcond && p->cond) || !g->defer_wgrad) return GLOWTTS_E_ARG;      // conditioning gradients / inline weight gradients: per-conv path
+    // inline weight gradients and the GR-mode per-row (pitch) conditioning gradient: per-conv path only
+    if (!g->defer_wgrad || g->pitch_rows || p->cond_rows) return GLOWTTS_E_ARG;
+    const bool cnd = g->dcond && p->cond;
+    if (cnd && (int64_t)d->B * p->ldcond * 4 >= ((int64_t)1 << 31)) return GLOWTTS_E_ARG;
     const int Tp = d->T + 2 * GLOWTTS_ROW_PAD;
     const int64_t R = (int64_t)d->B * Tp;
     if (R * 2 * WN_H * 2 >= ((int64_t)1 << 31) || R * d->C * 4 >= ((int64_t)1 << 31)) return GLOWTTS_E_ARG;
@@ -508,5 +555,7 @@ extern "C" int glowtts_wavenet_bwd(const glowtts_flow_dims* d, const glowtts_flo
     const int nvalid = WN_WIN - 2 * WN_PAD * (d->L - 1);
     const dim3 grid((unsigned)((R + nvalid - 1) / nvalid));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return d->drop_p > 0.f ? launch_wn_bwd<true>(k, grid, s) : launch_wn_bwd<false>(k, grid, s);
+    if (cnd) { k.dcond = g->dcond; k.ldcond = p->ldcond; }
+    if (d->drop_p > 0.f) return cnd ? launch_wn_bwd<true, true>(k, grid, s) : launch_wn_bwd<true, false>(k, grid, s);
+    return cnd ? launch_wn_bwd<false, true>(k, grid, s) : launch_wn_bwd<false, false>(k, grid, s);
 }

@@ -108,7 +108,7 @@ TAIL = {"defer": False, "pending": []}
 #   wgrad_wide: 16-byte staging items in the weight-gradient kernel; fuse_coupling_bwd: the next flow's coupling backward rides in the
 #   ActNorm / 1x1 backward pass; wgrad_split: weight gradients in n segments on a second stream (1 = one grouped launch per class);
 #   act_bf16: WaveNet state / gates / gate gradients stored as bf16 in bf16 precision
-#   fused_wn_bwd: its data gradients likewise (csrc/wavenet_fused_bwd.hip; unconditioned models), for flows 0 .. n-1 - the flows the backward
+#   fused_wn_bwd: its data gradients likewise (csrc/wavenet_fused_bwd.hip; every mode but GR's per-frame pitch), for flows 0 .. n-1 - the flows the backward
 #       reaches LAST.  n: a count, True = all flows, -1 (default) = half of them.  Alone the fused kernel is faster than the ten launches it
 #       replaces (126 vs 155 us per flow, 151 vs 178 with cold caches: tools/bench_wn.py), but a workgroup that owns a whole CU (150 KB of LDS,
 #       3 x 168 VGPRs per SIMD) for 126 us leaves the encoder stream's backward no CU to share, and while that stream is busy the step LOSES:
@@ -253,7 +253,9 @@ WEIGHT_KEYS = ("an_logs", "an_bias", "inv_w", "w_start", "b_start", "w_in", "b_i
 class _Prepared:
     """Packed weight images + per-flow parameter structs for one set of stacked weights."""
 
-    def __init__(self, cfg, W, need_bwd, cond=None):
+    def __init__(self, cfg, W, need_bwd, cond=None, fused_bwd_ok=True):
+        """fused_bwd_ok = False: the backward needs what only the per-conv kernels produce (GR mode: the per-row pitch conditioning and the
+        Pitch_l weight gradient)."""
         L = _L()
         F_, H, C, Lw = cfg.F, cfg.H, cfg.C, cfg.L
         P = cfg.precision
@@ -302,7 +304,7 @@ class _Prepared:
         self.wn_img_t = None
         nfb = TUNE["fused_wn_bwd"]
         nfb = F_ if nfb is True else (F_ // 2 if int(nfb) < 0 else min(int(nfb), F_))      # flows 0 .. nfb-1 take the fused kernel
-        if need_bwd and self.wn_img is not None and cond is None and nfb > 0:
+        if need_bwd and self.wn_img is not None and fused_bwd_ok and nfb > 0:
             self.wn_img_t = torch.empty_like(self.wn_img[:nfb])                # (flows 0 .. nfb-1 only)
             _lib.check(L.glowtts_wavenet_pack_images(_lib.ptr(W["w_start"].contiguous()), _lib.ptr(W["w_in"].contiguous()),
                                                      _lib.ptr(W["w_rs"].contiguous()) if Lw > 1 else None, _lib.ptr(W["w_rs_last"].contiguous()),
@@ -563,7 +565,7 @@ class DecoderFunction(torch.autograd.Function):
         need_bwd = any(w.requires_grad for w in weights) or mels.requires_grad or (cond is not None and cond.requires_grad) or \
             (pitch_w is not None and pitch_w.requires_grad)
         condc = cond.detach().contiguous() if cond is not None else None
-        prep = _Prepared(cfg, W, need_bwd=need_bwd, cond=condc)
+        prep = _Prepared(cfg, W, need_bwd=need_bwd, cond=condc, fused_bwd_ok=pitches is None)
         # one random word on the device (torch's graph-safe generator); kept for the backward, which regenerates the masks
         seed = torch.randint(0, 2 ** 31 - 1, (1,), device=mels.device, dtype=torch.int32) if drop_p > 0 else None
         pitch = (pitches.detach(), pitch_w.detach().contiguous(), pitch_b.detach().contiguous()) if pitches is not None else None

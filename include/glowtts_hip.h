@@ -429,8 +429,9 @@ int glowtts_wavenet_fwd(const glowtts_flow_dims *d, const glowtts_flow_params *p
 /* Its backward, data gradients only (steps 2-4 of glowtts_flow_backward: End^T, per layer Res_Skip^T + gate derivative + In^T, Start^T), in
  * ONE launch: reads g->douts_bf (the coupling backward's bf16 d(m, logs)) and a->gates, writes g->dskip, g->dins[l] (PAIR-packed), g->dh[l]
  * and accumulates d x_a into g->dx - the operands the grouped weight-gradient launches read.  Needs p->wn_img_t (the transposed image:
- * [End^T 3 slabs][layer L-1 .. 0: Res_Skip^T 3 / 6, In^T tanh-side 15, In^T sigmoid-side 15][Start^T 2]), g->defer_wgrad and no conditioning
- * gradient (GLOWTTS_E_ARG otherwise: the caller then packs the per-conv images instead). */
+ * [End^T 3 slabs][layer L-1 .. 0: Res_Skip^T 3 / 6, In^T tanh-side 15, In^T sigmoid-side 15][Start^T 2]) and g->defer_wgrad.  With g->dcond and
+ * p->cond set it also ACCUMULATES the per-utterance conditioning gradient (atomic adds, like the per-conv path).  Not served: the GR-mode
+ * per-row conditioning (p->cond_rows / g->pitch_rows) - GLOWTTS_E_ARG, the caller packs the per-conv images for those flows instead. */
 int glowtts_wavenet_bwd(const glowtts_flow_dims *d, const glowtts_flow_params *p, const glowtts_flow_acts *a, const glowtts_flow_grads *g,
                         void *stream);
 

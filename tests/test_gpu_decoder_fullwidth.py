@@ -96,8 +96,8 @@ def test_full_width_backward_bf16_takes_the_benchmarked_kernels(spk_dim):
     assert _count(counts, "wn_fwd<") == N_FLOWS, counts                                   # the fused coupling network: one launch per flow
     assert _count(counts, "conv_dma<GATE,5>") == 0 and _count(counts, "conv_dma<RESSKIP,1>") == 0 and _count(counts, "conv_chain<RESSKIP,COUPLE>") == 0, counts
     # the backward the training step runs by default: per-conv launches for the flows it reaches first, the fused data-gradient kernel for
-    # the last half (unconditioned models only; decoder.TUNE["fused_wn_bwd"], parity in tests/test_gpu_wavenet_fused.py)
-    nfb = N_FLOWS // 2 if spk_dim == 0 else 0
+    # the last half (decoder.TUNE["fused_wn_bwd"], parity in tests/test_gpu_wavenet_fused.py)
+    nfb = N_FLOWS // 2
     assert _count(counts, "wn_bwd<") == nfb, counts
     assert _count(counts, "conv_dma<LINEAR,5>") == (N_FLOWS - nfb) * L, counts           # In_l data gradient
     assert _count(counts, "conv_dma<DGATE,1>") == (N_FLOWS - nfb) * (L - 1), counts
@@ -149,7 +149,7 @@ def test_full_width_dropout_masks_agree_between_forward_backward_and_precisions(
     torch.manual_seed(6)
     z16c = _hip_grads(*case, precision=1, drop_p=0.3)[0]
     assert torch.equal(z16, z16b) and (z16 - z16c).abs().max() > 1e-2
-    nfb = N_FLOWS // 2 if spk_dim == 0 else 0            # the unconditioned backward's last flows take the fused data-gradient kernel
+    nfb = N_FLOWS // 2                                   # the backward's last flows take the fused data-gradient kernel
     assert _count(counts, "wn_fwd<drop") == N_FLOWS and _count(counts, "conv_chain<LINEAR,DGATE>") == N_FLOWS - nfb
     assert _count(counts, "wn_bwd<drop") == nfb
     mask = O.mask_from_lengths(case[3], TM)

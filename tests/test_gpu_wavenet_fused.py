@@ -186,18 +186,22 @@ def test_exact_wait_counts_equal_conservative_waits():
             assert torch.equal(got[2].outs[:, :, cm], ref[2].outs[:, :, cm]) and torch.equal(got[2].outs[:, :, cl], ref[2].outs[:, :, cl])
 
 
-def _grads(D, dc, P, mels, ml, wz, wl, fused_bwd, drop_p=0.0):
+def _grads(D, dc, P, mels, ml, wz, wl, fused_bwd, drop_p=0.0, cond=None):
     default = D.TUNE["fused_wn_bwd"]
     D.TUNE["fused_wn_bwd"] = fused_bwd
     try:
         Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
         x = mels.clone().requires_grad_(True)
         W = D.stack_decoder_weights(Pg, dc)
+        c = cond.clone().requires_grad_(True) if cond is not None else None
         launch_reset()
-        z, logdet, _ = D.DecoderFunction.apply(dc, x, ml, None, drop_p, None, None, None, *W)
+        z, logdet, _ = D.DecoderFunction.apply(dc, x, ml, c, drop_p, None, None, None, *W)
         ((z * wz).sum() + (logdet * wl).sum()).backward()
         torch.cuda.synchronize()
-        return {k: p.grad for k, p in Pg.items()}, x.grad, launch_counts()
+        g = {k: p.grad for k, p in Pg.items() if p.grad is not None}
+        if c is not None:
+            g["<conditioning>"] = c.grad
+        return g, x.grad, launch_counts()
     finally:
         D.TUNE["fused_wn_bwd"] = default
 
@@ -233,3 +237,41 @@ def test_fused_backward_matches_per_conv_backward(lengths, tm, drop):
     a, b = (dxf * valid).flatten().double(), (dxu * valid).flatten().double()
     assert (a @ b / (a.norm() * b.norm())).item() >= 0.9995 and 0.99 <= (a.norm() / b.norm()).item() <= 1.01
     print("fused vs per-conv backward: worst gradient cosine", worst)
+
+
+@pytest.mark.parametrize("lengths,tm,drop", [([640, 522, 240, 2], 640, 0.3), ([40, 36, 20, 8, 40, 40, 12], 40, 0.3), ([800] * 3, 800, 0.0)])
+def test_fused_backward_conditioning_gradient(lengths, tm, drop):
+    """Speaker / prosody conditioning (Modules.py:863-866) joins the gate pre-activation AFTER the dropout: its gradient is the per-utterance sum
+    of the gate gradients BEFORE the keep mask.  The fused backward accumulates it per workgroup over the rows it OWNS (halo rows are another
+    workgroup's), one run per utterance: windows inside one utterance (the fast path), straddling two (640 frames: 324 rows per utterance
+    against 52-row windows), and holding several whole utterances (40 frames: 24 rows each) must all agree with the per-conv backward - in
+    the conditioning gradient and, with it present, in every other gradient."""
+    from glow_tts_amd import decoder as D
+    g = torch.Generator().manual_seed(17)
+    cfg, sd = full_width_state(2, g, spk_dim=256)
+    dc = D.DecoderConfig(cfg.mel_dim, cfg.n_flows, cfg.n_squeeze, cfg.n_split, cfg.wn_channels, cfg.wn_layers, cfg.wn_kernel, 1)
+    P = {k: v.cuda() for k, v in sd.items()}
+    B = len(lengths)
+    mels = (torch.randn(B, 80, tm, generator=g) * 1.5).clamp(-4, 4).cuda()
+    ml = torch.tensor(lengths).cuda()
+    spk = torch.randn(B, 256, generator=g)
+    cond = D.conditioning(P, dc, speakers=(spk / spk.norm(dim=1, keepdim=True)).cuda()).detach()
+    wz, wl = torch.randn(B, 80, tm, generator=g).cuda(), (torch.randn(B, generator=g) * 0.05).cuda()
+    torch.manual_seed(3)
+    gf, dxf, cf = _grads(D, dc, P, mels, ml, wz, wl, True, drop, cond)
+    torch.manual_seed(3)
+    gu, dxu, cu = _grads(D, dc, P, mels, ml, wz, wl, False, drop, cond)
+    tag = "wn_bwd<drop,cond>" if drop else "wn_bwd<nodrop,cond>"
+    assert cf.get(tag, 0) == 2 and not any(k.startswith("conv_dma<LINEAR,5") for k in cf), cf
+    assert not any(k.startswith("wn_bwd") for k in cu), cu
+    assert gf["<conditioning>"].shape == cond.shape and gu["<conditioning>"].abs().max() > 0
+    for k, want in gu.items():
+        a, b = gf[k].flatten().double(), want.flatten().double()
+        cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+        ratio = (a.norm() / (b.norm() + 1e-30)).item()
+        assert cos >= 0.9995 and 0.99 <= ratio <= 1.01, (k, cos, ratio)
+    # per utterance as well (a run credited to the wrong utterance keeps the total)
+    for b_ in range(B):
+        a, b = gf["<conditioning>"][b_].flatten().double(), gu["<conditioning>"][b_].flatten().double()
+        if b.norm() > 0:
+            assert (a @ b / (a.norm() * b.norm() + 1e-30)).item() >= 0.999, (b_, (a @ b / (a.norm() * b.norm() + 1e-30)).item())
