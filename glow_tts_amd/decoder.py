@@ -109,7 +109,7 @@ TAIL = {"defer": False, "pending": []}
 #   ActNorm / 1x1 backward pass; wgrad_split: weight gradients in n segments on a second stream (1 = one grouped launch per class);
 #   act_bf16: WaveNet state / gates / gate gradients stored as bf16 in bf16 precision
 #   fused_wn_bwd: its data gradients likewise (csrc/wavenet_fused_bwd.hip; every mode but GR's per-frame pitch), for flows 0 .. n-1 - the flows the backward
-#       reaches LAST.  n: a count, True = all flows, -1 (default) = half of them.  Alone the fused kernel is faster than the ten launches it
+#       reaches LAST.  n: a count, True = all flows, -1 (default) = automatic: all flows when the batch leaves a quarter of the CUs free, else half.  Alone the fused kernel is faster than the ten launches it
 #       replaces (126 vs 155 us per flow, 151 vs 178 with cold caches: tools/bench_wn.py), but a workgroup that owns a whole CU (150 KB of LDS,
 #       3 x 168 VGPRs per SIMD) for 126 us leaves the encoder stream's backward no CU to share, and while that stream is busy the step LOSES:
 #       all 12 flows 6.33 vs 5.90 ms/step, 9 flows 5.95.  The encoder's backward has drained by the time the decoder's backward is half way:
@@ -253,9 +253,9 @@ WEIGHT_KEYS = ("an_logs", "an_bias", "inv_w", "w_start", "b_start", "w_in", "b_i
 class _Prepared:
     """Packed weight images + per-flow parameter structs for one set of stacked weights."""
 
-    def __init__(self, cfg, W, need_bwd, cond=None, fused_bwd_ok=True):
+    def __init__(self, cfg, W, need_bwd, cond=None, fused_bwd_ok=True, rows=None):
         """fused_bwd_ok = False: the backward needs what only the per-conv kernels produce (GR mode: the per-row pitch conditioning and the
-        Pitch_l weight gradient)."""
+        Pitch_l weight gradient).  rows: B * (T + 4) of the batch this is prepared for (sizes the automatic choice of TUNE["fused_wn_bwd"])."""
         L = _L()
         F_, H, C, Lw = cfg.F, cfg.H, cfg.C, cfg.L
         P = cfg.precision
@@ -303,7 +303,17 @@ class _Prepared:
         # else the per-conv transposed images
         self.wn_img_t = None
         nfb = TUNE["fused_wn_bwd"]
-        nfb = F_ if nfb is True else (F_ // 2 if int(nfb) < 0 else min(int(nfb), F_))      # flows 0 .. nfb-1 take the fused kernel
+        if nfb is True:
+            nfb = F_
+        elif int(nfb) < 0:
+            # automatic: a fused workgroup owns its CU.  A batch whose 52-row windows leave a quarter of the CUs free (B = 16 x 800 frames: 125
+            # workgroups) shares the chip with the encoder stream anyway - every flow takes the fused kernel (config 4: 4.28 vs 4.68 ms/step);
+            # a chip-filling one (B = 32: 249) only the half of the backward that runs after the encoder's backward has drained
+            nwg = -(-rows // (64 - 4 * (Lw - 1))) if rows else None
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
+            nfb = F_ if (nwg is not None and 4 * nwg <= 3 * cus) else F_ // 2
+        else:
+            nfb = min(int(nfb), F_)                             # flows 0 .. nfb-1 take the fused kernel
         if need_bwd and self.wn_img is not None and fused_bwd_ok and nfb > 0:
             self.wn_img_t = torch.empty_like(self.wn_img[:nfb])                # (flows 0 .. nfb-1 only)
             _lib.check(L.glowtts_wavenet_pack_images(_lib.ptr(W["w_start"].contiguous()), _lib.ptr(W["w_in"].contiguous()),
@@ -565,7 +575,8 @@ class DecoderFunction(torch.autograd.Function):
         need_bwd = any(w.requires_grad for w in weights) or mels.requires_grad or (cond is not None and cond.requires_grad) or \
             (pitch_w is not None and pitch_w.requires_grad)
         condc = cond.detach().contiguous() if cond is not None else None
-        prep = _Prepared(cfg, W, need_bwd=need_bwd, cond=condc, fused_bwd_ok=pitches is None)
+        prep = _Prepared(cfg, W, need_bwd=need_bwd, cond=condc, fused_bwd_ok=pitches is None,
+                         rows=mels.shape[0] * (mels.shape[2] // cfg.ns + 2 * ROW_PAD))
         # one random word on the device (torch's graph-safe generator); kept for the backward, which regenerates the masks
         seed = torch.randint(0, 2 ** 31 - 1, (1,), device=mels.device, dtype=torch.int32) if drop_p > 0 else None
         pitch = (pitches.detach(), pitch_w.detach().contiguous(), pitch_b.detach().contiguous()) if pitches is not None else None
