@@ -473,6 +473,8 @@ def main():
     ap.add_argument("--no-f32-key", action="store_true", help="skip the extra `f32` key (the same step in HIP_Precision f32, timed in a child process)")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward + losses + backward only (round 1's definition of the step); "
                     "default: the whole Train_Step of Train.py:193-233 including clip_grad_norm_, RAdam and the Noam schedule")
+    ap.add_argument("--timeline", action="store_true", help="diagnostics: stamp kernels inside the captured step (decoder flows, encoder milestones); "
+                    "prints when each stream reached them in one replay (stderr) - adds ~40 tiny launches to the step")
     ap.add_argument("--tune", action="append", default=[], help="A/B measurements: key=value entries of glow_tts_amd.decoder.TUNE (e.g. wgrad_wide=0)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on device 0 (multi-rank smoke test on a single-GPU box)")
     ap.add_argument("--no-overlap", action="store_true", help="data parallel: one graph + one gradient exchange instead of the two-graph overlap")
@@ -528,6 +530,8 @@ def main():
     for kv in args.tune:
         k, v = kv.split("=")
         _dec.TUNE[k] = type(_dec.TUNE[k])(int(v))
+    if args.timeline:
+        _dec.STAMPS["buf"] = torch.zeros(4096, dtype=torch.int64, device=dev)
     from glow_tts_amd.distributed import FlatGradReducer, actnorm_stats_allreduce
     model, mle_loss, hp = build_model(args.precision, dev, cfg["mode"], cfg["spk_type"])
     reducer = None
@@ -687,6 +691,18 @@ def main():
     one_step()
     elapsed, loss = timed_window()                              # the reported window: exactly --steps steps
     extra = [timed_window()[0] for _ in range(max(0, args.windows))]
+    if args.timeline and rank == 0:
+        # the captured pass stamped last: its slots are the last occurrence of every name; one more replay fills them
+        torch.cuda.synchronize(); one_step(); torch.cuda.synchronize()
+        names, buf = _dec.STAMPS["names"], _dec.STAMPS["buf"].cpu()
+        last = {n: i for i, n in enumerate(names)}
+        ev = sorted(((int(buf[i]), n) for n, i in last.items() if int(buf[i]) > 0))
+        t0 = ev[0][0]
+        print("[timeline] us since the first stamp of one replayed step (wall counter, 10 ns ticks):", file=sys.stderr)
+        prev = t0
+        for t, n in ev:
+            print(f"[timeline] {(t - t0) / 100.0:9.1f}  (+{(t - prev) / 100.0:7.1f})  {n}", file=sys.stderr)
+            prev = t
     if dp:
         # every gradient must have gone through the exchange: reduced gradients are identical on all ranks, unreduced ones are not
         # (different utterances and dropout streams per rank)

@@ -34,7 +34,8 @@ def _L():
         L.glowtts_layernorm_fwd_io.argtypes = [c_p] * 8 + [c_i64, c_int, c_f, c_int, c_f, c_u32, c_p, c_p, c_p]
         L.glowtts_layernorm_scratch_floats.argtypes = [c_i64, c_int]
         L.glowtts_layernorm_scratch_floats.restype = c_i64
-        L.glowtts_layernorm_bwd_io.argtypes = [c_p] * 9 + [c_i64, c_int, c_int, c_f, c_p, c_p]
+        L.glowtts_layernorm_bwd_io.argtypes = [c_p] * 9 + [c_i64, c_int, c_int, c_f, c_p, c_p, c_f, c_p]
+        L.glowtts_colsum_batched.argtypes = [c_p, c_p, c_int, c_int, c_int, c_i64, c_i64, c_p]
         L.glowtts_gate_bwd_io.argtypes = [c_p] * 4 + [c_i64, c_int, c_f, c_int, c_p]
         L.glowtts_embedding_fwd.argtypes = [c_p] * 4 + [c_int] * 3 + [c_f, c_p]
         L.glowtts_embedding_bwd.argtypes = [c_p] * 4 + [c_int] * 4 + [c_f, c_p]
@@ -73,6 +74,20 @@ class WgradTape:
 
     def __init__(self):
         self.jobs = []
+        self.ln_count, self.ln = 0, None           # LayerNorms of the block functions: their gamma / beta partials are reduced by ONE launch
+
+    def ln_slot(self, R, C, device):
+        """-> (scratch [nfloats], gb [2C]) of the next LayerNorm backward: slices of two buffers that `flush` reduces with one
+        glowtts_colsum_batched (every LayerNorm registered through `ln_count` in the forward has the same shape)."""
+        if self.ln is None:
+            nf = _L().glowtts_layernorm_scratch_floats(R, C)
+            self.ln = {"scratch": torch.empty(self.ln_count, nf, device=device), "gb": torch.empty(self.ln_count, 2 * C, device=device),
+                       "used": 0, "nblk": nf // (2 * C), "C": C, "R": R}
+        st = self.ln
+        assert st["used"] < self.ln_count and (st["R"], st["C"]) == (R, C)
+        i = st["used"]
+        st["used"] += 1
+        return st["scratch"][i], st["gb"][i]
 
     def add(self, dz, x, O, ca, taps, precision, dw, db):
         self.jobs.append((dz, x, O, ca, taps, precision, dw, db))
@@ -91,6 +106,12 @@ class WgradTape:
             g.upload(self.jobs[0][0].device)
             g.launch_segment(0)
         self.jobs = []        # (dz / x stay referenced by the launched work's stream ordering: same stream, freed after)
+        if self.ln is not None:
+            st = self.ln
+            assert st["used"] == self.ln_count, "a LayerNorm of the block functions did not run its backward"
+            _lib.check(_L().glowtts_colsum_batched(st["scratch"].data_ptr(), st["gb"].data_ptr(), st["nblk"], 2 * st["C"], st["used"],
+                                                   st["scratch"].shape[1], 2 * st["C"], _lib.stream()), "glowtts_colsum_batched")
+            self.ln = None
 
 
 class ParamGate(torch.autograd.Function):
@@ -104,7 +125,10 @@ class ParamGate(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        from .decoder import stamp
+        stamp("enc_dgrads_done")
         ctx.tape.flush()
+        stamp("enc_wgrads_done")
         return (None,) + grads
 
 
@@ -133,7 +157,7 @@ class ConvRows(torch.autograd.Function):
             assert precision == ops.BF16, "bf16-stored rows exist in bf16 mode only"
             a = x
         else:
-            a = xb.contiguous() if (xb is not None and precision == ops.BF16 and Ci2 % 32 == 0 and Ci2 == Cin) else None
+            a = xb.contiguous() if (xb is not None and precision == ops.BF16 and Ci2 % 32 == 0 and Ci2 == Cin and (k > 1 or Ci2 % 64 == 0)) else None
             assert a is None or a.shape == x.shape
         assert not out_bf16 or (a is not None and residual is None)
         pw = packs[0] if packs is not None else ops.pack_weight(w.detach(), precision=precision)
@@ -160,6 +184,9 @@ class ConvRows(torch.autograd.Function):
         O, _, k = w.shape
         dy = dy.contiguous()
         bf = torch.bfloat16
+        # the data gradient is a conv with K = O: the LDS-DMA kernel takes whole 32-channel chunks, its 1x1 form pairs of them (Project's
+        # 160 outputs do not qualify; the register-staged kernel on a bf16-stored operand measured 60-165 us there against 10 on fp32 rows)
+        bfpath = bfpath and O % 32 == 0 and (k > 1 or O % 64 == 0)
         if gated:                                              # d(pre-activation): relu / dropout cut exactly where out == 0
             dz = torch.empty(R, O, device=dy.device, dtype=bf if bfpath else torch.float32)
             io = (1 if dy.dtype == bf else 0) | (2 if out.dtype == bf else 0) | (4 if bfpath else 0)
@@ -227,7 +254,7 @@ class LayerNormRows(torch.autograd.Function):
         gb = torch.empty(2 * C, device=s.device)
         scratch = torch.empty(L.glowtts_layernorm_scratch_floats(R, C), device=s.device)
         _lib.check(L.glowtts_layernorm_bwd_io(dy.data_ptr(), _sp(y), s.data_ptr(), stats.data_ptr(), gamma.data_ptr(), _sp(rowmask), ds.data_ptr(),
-                                              gb.data_ptr(), scratch.data_ptr(), R, C, int(gated), drop_p, None, _lib.stream()), "glowtts_layernorm_bwd_io")
+                                              gb.data_ptr(), scratch.data_ptr(), R, C, int(gated), drop_p, None, None, 1.0, _lib.stream()), "glowtts_layernorm_bwd_io")
         return ds, (ds if has_b else None), gb[:C], gb[C:], None, None, None, None, None, None
 
 
@@ -239,6 +266,137 @@ def layernorm_rows(a, b, gamma, beta, rowmask, relu=False, drop_p=0.0, seed=0, s
     y = LayerNormRows.apply(a, b, gamma, beta, rowmask, relu, float(drop_p), seed, seed_t, yb)
     y._bf16 = yb
     return y
+
+
+
+def _conv_launch(a, pw, ci, R, k, flags, n, bias, rowmask, out, in0=None, drop_p=0.0, seed=0, seed_t=None, a_bf=True):
+    io = (ops.IO_A_BF16 if a_bf else 0) | (ops.IO_OUT0_BF16 if out.dtype == torch.bfloat16 else 0)
+    ops.conv_cl(a, pw, ci, R, lda=ci, pad=(k - 1) // 2, epi=ops.EPI_LINEAR, flags=flags | (ops.F_ADD_IN0 if in0 is not None else 0), n=n,
+                bias=bias, rowmask=rowmask, in0=in0, ldi0=n, out0=out, ld0=n, drop_p=drop_p, seed=seed, seed_t=seed_t, io_flags=io)
+
+
+class FFNBlock(torch.autograd.Function):
+    """x2 = LayerNorm_1( Dropout(Conv_1(Dropout(ReLU(Conv_0(x1 * mask))) * mask)) * mask + x1 )   (Modules.py:565-571), bf16-stored rows.
+
+    One autograd node instead of three: its backward is the hand-ordered chain  LayerNorm backward (which also writes Conv_1's gate
+    gradient: no separate gate pass) -> Conv_1 data gradient -> gate -> Conv_0 data gradient + the residual branch's gradient in its
+    epilogue (no separate add) - 4 launches on the encoder stream's dependent chain instead of 8; weight gradients and the LayerNorm
+    parameter gradients are deferred to the tape (grouped launches at the end of the encoder's backward)."""
+
+    @staticmethod
+    def forward(ctx, x1, x1b, w0, b0, w1, b1, gamma, beta, rowmask, drop_p, seeds, seed_t, tape, packs0, packs1):
+        R, C = x1.shape
+        O0, k = w0.shape[0], w0.shape[2]
+        dev = x1.device
+        bf = torch.bfloat16
+        dflag = ops.F_DROPOUT if drop_p > 0 else 0
+        h0 = torch.empty(R, O0, device=dev, dtype=bf)
+        _conv_launch(x1b, packs0[0], C, R, k, ops.F_BIAS | ops.F_RELU | ops.F_MASK | dflag, O0, b0.detach(), rowmask, h0, drop_p=drop_p, seed=seeds[0], seed_t=seed_t)
+        h1 = torch.empty(R, C, device=dev)
+        _conv_launch(h0, packs1[0], O0, R, k, ops.F_BIAS | ops.F_MASK | dflag, C, b1.detach(), rowmask, h1, drop_p=drop_p, seed=seeds[1], seed_t=seed_t)
+        y, yb, s_, stats = torch.empty_like(x1), torch.empty(R, C, device=dev, dtype=bf), torch.empty_like(x1), torch.empty(R, 2, device=dev)
+        _lib.check(_L().glowtts_layernorm_fwd_io(h1.data_ptr(), x1.data_ptr(), s_.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rowmask.data_ptr(),
+                                                 y.data_ptr(), stats.data_ptr(), R, C, 1e-4, 0, 0.0, 0, None, yb.data_ptr(), _lib.stream()),
+                   "glowtts_layernorm_fwd_io")
+        tape.ln_count += 1
+        ctx.save_for_backward(x1b, h0, h1 if drop_p > 0 else None, s_, stats, gamma, rowmask, w0, w1)
+        ctx.misc = (tape, packs0[1], packs1[1], float(drop_p))
+        ctx.mark_non_differentiable(yb)
+        return y, yb
+
+    @staticmethod
+    def backward(ctx, dy, _dyb):
+        x1b, h0, h1, s_, stats, gamma, rowmask, w0, w1 = ctx.saved_tensors
+        tape, pwt0, pwt1, drop_p = ctx.misc
+        R, C = s_.shape
+        O0, k = w0.shape[0], w0.shape[2]
+        dev = s_.device
+        bf = torch.bfloat16
+        L = _L()
+        scale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
+        dy = dy.contiguous()
+        ds, dz1 = torch.empty_like(s_), torch.empty(R, C, device=dev, dtype=bf)
+        scratch, gb = tape.ln_slot(R, C, dev)
+        # LayerNorm_1 backward; dz1 = d(Conv_1 pre-activation): through the conv's dropout gate when there is one, else ds * mask = ds
+        _lib.check(L.glowtts_layernorm_bwd_io(dy.data_ptr(), None, s_.data_ptr(), stats.data_ptr(), gamma.data_ptr(), rowmask.data_ptr(), ds.data_ptr(),
+                                              None, scratch.data_ptr(), R, C, 0, 0.0, dz1.data_ptr(), _sp(h1), scale, _lib.stream()), "glowtts_layernorm_bwd_io")
+        dh = torch.empty(R, O0, device=dev, dtype=bf)
+        _conv_launch(dz1, pwt1, C, R, k, 0, O0, None, None, dh)                                     # Conv_1 data gradient
+        dz0 = torch.empty(R, O0, device=dev, dtype=bf)
+        _lib.check(L.glowtts_gate_bwd_io(dh.data_ptr(), h0.data_ptr(), rowmask.data_ptr(), dz0.data_ptr(), R, O0, scale, 7, _lib.stream()), "glowtts_gate_bwd_io")
+        dx1 = torch.empty(R, C, device=dev)
+        _conv_launch(dz0, pwt0, O0, R, k, 0, C, None, None, dx1, in0=ds)                            # Conv_0 data gradient + the residual branch (ds)
+        dw0, db0 = torch.empty_like(w0), torch.empty(O0, device=dev)
+        dw1, db1 = torch.empty_like(w1), torch.empty(C, device=dev)
+        tape.add(dz0, x1b, O0, C, k, ops.BF16, dw0, db0)
+        tape.add(dz1, h0, C, O0, k, ops.BF16, dw1, db1)
+        return dx1, None, dw0, db0, dw1, db1, gb[:C], gb[C:], None, None, None, None, None, None, None
+
+
+class AttentionBlock(torch.autograd.Function):
+    """x1 = LayerNorm_0( Dropout(Projection(RPR_attention(QKV(x)))) + x )   (Modules.py:560-562, RPR_MHA.py:82-128), bf16-stored rows.
+    Backward chain: LayerNorm backward (+ the projection's dropout gate) -> projection data gradient -> attention backward -> QKV data
+    gradient + the residual branch's gradient in its epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, xb, wqkv, bqkv, relk, relv, wp, bp, gamma, beta, rowmask, B, Tp, H, win, drop_p, seeds, seed_t, tape, packs_qkv, packs_p):
+        R, C = x.shape
+        dev = x.device
+        bf = torch.bfloat16
+        L = _L()
+        D = C // H
+        dflag = ops.F_DROPOUT if drop_p > 0 else 0
+        qkv = torch.empty(R, 3 * C, device=dev)
+        _conv_launch(xb, packs_qkv[0], C, R, 1, ops.F_BIAS, 3 * C, bqkv.detach(), rowmask, qkv)
+        att = torch.empty(R, C, device=dev)
+        P = torch.empty(B, H, Tp, Tp, device=dev)
+        rk, rv = relk.detach().contiguous(), relv.detach().contiguous()
+        _lib.check(L.glowtts_rpr_attention_fwd_prec(qkv.data_ptr(), rk.data_ptr(), rv.data_ptr(), rowmask.data_ptr(), att.data_ptr(), P.data_ptr(),
+                                                    B, Tp, H, D, win, float(drop_p), int(seeds[0]) & 0xFFFFFFFF, _sp(seed_t), ops.BF16, _lib.stream()),
+                   "glowtts_rpr_attention_fwd_prec")
+        proj = torch.empty(R, C, device=dev)
+        _conv_launch(att, packs_p[0], C, R, 1, ops.F_BIAS | dflag, C, bp.detach(), rowmask, proj, drop_p=drop_p, seed=seeds[1], seed_t=seed_t, a_bf=False)
+        y, yb, s_, stats = torch.empty_like(x), torch.empty(R, C, device=dev, dtype=bf), torch.empty_like(x), torch.empty(R, 2, device=dev)
+        _lib.check(L.glowtts_layernorm_fwd_io(proj.data_ptr(), x.data_ptr(), s_.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rowmask.data_ptr(),
+                                              y.data_ptr(), stats.data_ptr(), R, C, 1e-4, 0, 0.0, 0, None, yb.data_ptr(), _lib.stream()), "glowtts_layernorm_fwd_io")
+        tape.ln_count += 1
+        ctx.save_for_backward(xb, qkv, rk, rv, P, att, proj if drop_p > 0 else None, s_, stats, gamma, rowmask, wqkv, wp, seed_t)
+        ctx.misc = (tape, packs_qkv[1], packs_p[1], float(drop_p), B, Tp, H, win, int(seeds[0]) & 0xFFFFFFFF)
+        ctx.mark_non_differentiable(yb)
+        return y, yb
+
+    @staticmethod
+    def backward(ctx, dy, _dyb):
+        xb, qkv, rk, rv, P, att, proj, s_, stats, gamma, rowmask, wqkv, wp, seed_t = ctx.saved_tensors
+        tape, pwt_qkv, pwt_p, drop_p, B, Tp, H, win, aseed = ctx.misc
+        R, C = s_.shape
+        D = C // H
+        dev = s_.device
+        bf = torch.bfloat16
+        L = _L()
+        scale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
+        dy = dy.contiguous()
+        ds, dzp = torch.empty_like(s_), torch.empty(R, C, device=dev, dtype=bf)
+        scratch, gb = tape.ln_slot(R, C, dev)
+        _lib.check(L.glowtts_layernorm_bwd_io(dy.data_ptr(), None, s_.data_ptr(), stats.data_ptr(), gamma.data_ptr(), rowmask.data_ptr(), ds.data_ptr(),
+                                              None, scratch.data_ptr(), R, C, 0, 0.0, dzp.data_ptr(), _sp(proj), scale, _lib.stream()), "glowtts_layernorm_bwd_io")
+        datt = torch.empty(R, C, device=dev)
+        _conv_launch(dzp, pwt_p, C, R, 1, 0, C, None, None, datt)                                     # projection data gradient
+        nw = 2 * win + 1
+        dS = torch.empty(B, H, Tp, Tp, device=dev)
+        dqkv = torch.empty_like(qkv)
+        drel = torch.empty(2, nw, D, device=dev)
+        ascr = torch.empty(L.glowtts_rpr_attention_scratch_floats(B, Tp, H, D, win) + 2 * nw * D, device=dev)
+        _lib.check(L.glowtts_rpr_attention_bwd_prec(qkv.data_ptr(), rk.data_ptr(), rv.data_ptr(), rowmask.data_ptr(), P.data_ptr(), datt.data_ptr(),
+                                                    dS.data_ptr(), dqkv.data_ptr(), drel[0].data_ptr(), drel[1].data_ptr(), ascr.data_ptr(), B, Tp, H, D, win,
+                                                    drop_p, aseed, _sp(seed_t), ops.BF16, _lib.stream()), "glowtts_rpr_attention_bwd_prec")
+        dx = torch.empty(R, C, device=dev)
+        _conv_launch(dqkv, pwt_qkv, 3 * C, R, 1, 0, C, None, None, dx, in0=ds, a_bf=False)            # QKV data gradient + the residual branch (ds)
+        dwq, dbq = torch.empty_like(wqkv), torch.empty(3 * C, device=dev)
+        dwp, dbp = torch.empty_like(wp), torch.empty(C, device=dev)
+        tape.add(dqkv, xb, 3 * C, C, 1, ops.BF16, dwq, dbq)
+        tape.add(dzp.float(), att, C, C, 1, ops.BF16, dwp, dbp)       # (the attention output is fp32 rows: the weight-gradient kernel has no bf16 x fp32 form)
+        return (dx, None, dwq, dbq, drel[0].view(1, nw, D), drel[1].view(1, nw, D), dwp, dbp, gb[:C], gb[C:]) + (None,) * 11
 
 
 class EmbeddingRows(torch.autograd.Function):
@@ -258,12 +416,14 @@ class EmbeddingRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d):
+        from .decoder import stamp
         tokens, rowmask = ctx.saved_tensors
         V, C, scale = ctx.cfg
         B, T = tokens.shape
         dt = torch.empty(V, C, device=d.device)
         _lib.check(_L().glowtts_embedding_bwd(tokens.data_ptr(), d.contiguous().data_ptr(), rowmask.data_ptr(), dt.data_ptr(), V, B, T, C, scale,
                                               _lib.stream()), "glowtts_embedding_bwd")
+        stamp("enc_bwd_end")
         return None, dt, None, None
 
 

@@ -119,6 +119,15 @@ __global__ __launch_bounds__(256) void mfma_clock_probe_kernel(long long* out, i
 }
 }  // namespace
 
+__global__ void stamp_kernel(long long* slot) { if (threadIdx.x == 0) *slot = wall_clock64(); }
+
+extern "C" int glowtts_debug_stamp(long long* slot, void* stream)
+{
+    if (!slot) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), slot);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
 extern "C" int glowtts_mfma_clock_probe(long long* out, int nwg, int iters, int* wall_khz, void* stream)
 {
     if (!out || nwg <= 0 || iters <= 0) return GLOWTTS_E_ARG;

@@ -89,7 +89,8 @@ template <int KT>
 __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ s,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* __restrict__ rowmask, float* __restrict__ ds, float* __restrict__ partial,
-                                                     long rows, int C, int gated, float drop_p, int rows_per_block, uint16_t* __restrict__ dsb)
+                                                     long rows, int C, int gated, float drop_p, int rows_per_block, uint16_t* __restrict__ dsb,
+                                                     const float* __restrict__ gate_out, float gate_scale)
 {
     extern __shared__ float red[];                 // [LN_BWD_WAVES][2][C]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -128,7 +129,9 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const float* 
             if (c < C) {
                 const float g = rstd * (dz[k] - s1 - xh[k] * s2);
                 ds[r * C + c] = g;
-                if (dsb) dsb[r * C + c] = f2bf(g);
+                // bf16 copy for the conv that produced the LayerNorm input: as is, or already through that conv's dropout / relu gate
+                // (d(pre-activation) = ds * (out != 0 ? 1 / keep : 0): saves the separate gate pass over the rows)
+                if (dsb) dsb[r * C + c] = f2bf(gate_out ? (gate_out[r * C + c] != 0.f ? g * gate_scale : 0.f) : g);
             }
         }
     }
@@ -507,28 +510,32 @@ constexpr int LN_BWD_RPB = LN_BWD_WAVES;  // rows per workgroup of ln_bwd_kernel
 extern "C" int64_t glowtts_layernorm_scratch_floats(int64_t rows, int C) { return ((rows + LN_BWD_RPB - 1) / LN_BWD_RPB) * 2 * (int64_t)C; }
 
 extern "C" int glowtts_layernorm_bwd_io(const float* dy, const float* y, const float* s, const float* stats, const float* gamma, const float* rowmask,
-                                        float* ds, float* dgamma_dbeta /* [2C] */, float* scratch, int64_t rows, int C, int gated, float drop_p,
-                                        uint16_t* ds_bf16, void* stream)
+                                        float* ds, float* dgamma_dbeta /* [2C] or NULL */, float* scratch, int64_t rows, int C, int gated, float drop_p,
+                                        uint16_t* ds_bf16, const float* gate_out, float gate_scale, void* stream)
 {
-    if (!dy || !s || !stats || !gamma || !ds || !dgamma_dbeta || !scratch || rows < 1 || C < 1 || C > 64 * LN_MAXK || (gated && !y)) return GLOWTTS_E_ARG;
+    if (!dy || !s || !stats || !gamma || !ds || !scratch || rows < 1 || C < 1 || C > 64 * LN_MAXK || (gated && !y) || (gate_out && !ds_bf16)) return GLOWTTS_E_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int rpb = LN_BWD_RPB;
     const int nblk = (int)((rows + rpb - 1) / rpb);
     const int K = (C + 63) / 64;
-    if (K == 3)      hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(nblk), dim3(LN_BWD_WAVES * 64), 2 * LN_BWD_WAVES * C * sizeof(float), st, dy, y, s, stats, gamma, rowmask, ds, scratch, (long)rows, C, gated, drop_p, rpb, ds_bf16);
-    else if (K == 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nblk), dim3(LN_BWD_WAVES * 64), 2 * LN_BWD_WAVES * C * sizeof(float), st, dy, y, s, stats, gamma, rowmask, ds, scratch, (long)rows, C, gated, drop_p, rpb, ds_bf16);
+#define LN_BWD_ARGS dy, y, s, stats, gamma, rowmask, ds, scratch, (long)rows, C, gated, drop_p, rpb, ds_bf16, gate_out, gate_scale
+    if (K == 3)      hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(nblk), dim3(LN_BWD_WAVES * 64), 2 * LN_BWD_WAVES * C * sizeof(float), st, LN_BWD_ARGS);
+    else if (K == 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nblk), dim3(LN_BWD_WAVES * 64), 2 * LN_BWD_WAVES * C * sizeof(float), st, LN_BWD_ARGS);
     else {
         if (2 * LN_BWD_WAVES * C * sizeof(float) > 64 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GLOWTTS_E_LAUNCH;
-        hipLaunchKernelGGL(ln_bwd_kernel<0>, dim3(nblk), dim3(LN_BWD_WAVES * 64), 2 * LN_BWD_WAVES * C * sizeof(float), st, dy, y, s, stats, gamma, rowmask, ds, scratch, (long)rows, C, gated, drop_p, rpb, ds_bf16);
+        hipLaunchKernelGGL(ln_bwd_kernel<0>, dim3(nblk), dim3(LN_BWD_WAVES * 64), 2 * LN_BWD_WAVES * C * sizeof(float), st, LN_BWD_ARGS);
     }
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, st, scratch, dgamma_dbeta, nblk, 2 * C);
+#undef LN_BWD_ARGS
+    // dgamma_dbeta == NULL: the per-workgroup partials stay in `scratch` ([ceil(rows / 16)][2C]) for one glowtts_colsum_batched over several calls
+    if (dgamma_dbeta) hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, st, scratch, dgamma_dbeta, nblk, 2 * C);
     RET_LAUNCH();
 }
 extern "C" int glowtts_layernorm_bwd(const float* dy, const float* y, const float* s, const float* stats, const float* gamma, const float* rowmask,
                                      float* ds, float* dgamma_dbeta /* [2C] */, float* scratch, int64_t rows, int C, int gated, float drop_p, void* stream)
 {
-    return glowtts_layernorm_bwd_io(dy, y, s, stats, gamma, rowmask, ds, dgamma_dbeta, scratch, rows, C, gated, drop_p, nullptr, stream);
+    if (!dgamma_dbeta) return GLOWTTS_E_ARG;
+    return glowtts_layernorm_bwd_io(dy, y, s, stats, gamma, rowmask, ds, dgamma_dbeta, scratch, rows, C, gated, drop_p, nullptr, nullptr, 1.f, stream);
 }
 
 extern "C" int glowtts_gate_bwd_io(const void* dy, const void* out, const float* rowmask, void* dz, int64_t rows, int C, float scale, int io_flags, void* stream)

@@ -115,7 +115,19 @@ TAIL = {"defer": False, "pending": []}
 #       all 12 flows 6.33 vs 5.90 ms/step, 9 flows 5.95.  The encoder's backward has drained by the time the decoder's backward is half way:
 #       the last 6 flows fused 5.70 vs 5.85 and 5.82 vs 5.92 ms/step on two boxes
 #   fused_wn: the coupling network of a flow (Start .. End + coupling) as ONE launch (csrc/wavenet_fused.hip) where its shape contract holds
-TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_fwd_skip": 0}
+TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": 0}
+STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
+
+
+def stamp(name):
+    """Diagnostics: record when the current stream reaches this point (one tiny launch; only while tools/step_timeline.py armed it)."""
+    if STAMPS["buf"] is None:
+        return
+    i = len(STAMPS["names"])
+    STAMPS["names"].append(name)
+    _L().glowtts_debug_stamp.argtypes = [c_void_p, c_void_p]
+    _lib.check(_L().glowtts_debug_stamp(STAMPS["buf"].data_ptr() + 8 * i, _lib.stream()), "glowtts_debug_stamp")
+
 WN_SLAB = 24576                          # GLOWTTS_WN_SLAB_BYTES
 TAIL_STACKS = ("start_g", "start_v", "start_b", "rs_g", "rs_v", "rs_b", "rsl_g", "rsl_v", "rsl_b", "end_w", "end_b")
 
@@ -314,23 +326,25 @@ class _Prepared:
             nfb = F_ if (nwg is not None and 4 * nwg <= 3 * cus) else F_ // 2
         else:
             nfb = min(int(nfb), F_)                             # flows 0 .. nfb-1 take the fused kernel
+        f0 = min(max(int(TUNE["fused_wn_bwd_from"]), 0), F_ - nfb)               # (experiments: the fused flows are f0 .. f0 + nfb - 1)
         if need_bwd and self.wn_img is not None and fused_bwd_ok and nfb > 0:
-            self.wn_img_t = torch.empty_like(self.wn_img[:nfb])                # (flows 0 .. nfb-1 only)
-            _lib.check(L.glowtts_wavenet_pack_images(_lib.ptr(W["w_start"].contiguous()), _lib.ptr(W["w_in"].contiguous()),
-                                                     _lib.ptr(W["w_rs"].contiguous()) if Lw > 1 else None, _lib.ptr(W["w_rs_last"].contiguous()),
-                                                     _lib.ptr(W["w_end"].contiguous()), nfb, Lw, C // 2, None, _lib.ptr(self.wn_img_t), _lib.stream()),
+            self.wn_img_t = torch.empty_like(self.wn_img[:nfb])                # (the fused flows only)
+            _lib.check(L.glowtts_wavenet_pack_images(_lib.ptr(W["w_start"][f0:]), _lib.ptr(W["w_in"][f0:]),
+                                                     _lib.ptr(W["w_rs"][f0:]) if Lw > 1 else None, _lib.ptr(W["w_rs_last"][f0:]),
+                                                     _lib.ptr(W["w_end"][f0:]), nfb, Lw, C // 2, None, _lib.ptr(self.wn_img_t), _lib.stream()),
                        "wavenet_pack_images(bwd)")
         else:
             nfb = 0
-        if need_bwd and nfb < F_:                                              # per-conv transposed images of flows nfb .. F-1 (element i = flow nfb + i)
+        c0 = nfb if f0 == 0 else 0                                             # per-conv transposed images: flows c0 .. F-1 (element i = flow c0 + i)
+        if need_bwd and c0 < F_:
             self.pk.update({
-                "start_t": PackedBatch(W["w_start"][nfb:], True, ops.PERM_NONE, 0, P),
-                "in_t": PackedBatch(w_in[nfb * Lw:], True, ops.PERM_PAIR, H, P),
-                "rs_last_t": PackedBatch(W["w_rs_last"][nfb:], True, ops.PERM_NONE, 0, P),
-                "end_t": PackedBatch(W["w_end"][nfb:], True, ops.PERM_PAIR, C // 2, P),
+                "start_t": PackedBatch(W["w_start"][c0:], True, ops.PERM_NONE, 0, P),
+                "in_t": PackedBatch(w_in[c0 * Lw:], True, ops.PERM_PAIR, H, P),
+                "rs_last_t": PackedBatch(W["w_rs_last"][c0:], True, ops.PERM_NONE, 0, P),
+                "end_t": PackedBatch(W["w_end"][c0:], True, ops.PERM_PAIR, C // 2, P),
             })
             if Lw > 1:
-                self.pk["rs_t"] = PackedBatch(W["w_rs"][nfb:].reshape((F_ - nfb) * (Lw - 1), 2 * H, H, 1), True, ops.PERM_NONE, 0, P)
+                self.pk["rs_t"] = PackedBatch(W["w_rs"][c0:].reshape((F_ - c0) * (Lw - 1), 2 * H, H, 1), True, ops.PERM_NONE, 0, P)
         self.ldo = self.pk["end"].npad
         self.ldin = self.pk["in"].npad
         self.cond, self._H, self._Lw = cond, H, Lw
@@ -356,9 +370,9 @@ class _Prepared:
                 else:
                     p.rs[l] = pkf["rs_last"].at(f)
                     p.b_rs[l] = W["b_rs_last"][f].data_ptr()
-            p.wn_img_t = self.wn_img_t[f].data_ptr() if f < nfb else None
+            p.wn_img_t = self.wn_img_t[f - f0].data_ptr() if f0 <= f < f0 + nfb else None
             if need_bwd and p.wn_img_t is None:
-                fc = f - nfb
+                fc = f - c0
                 p.start_t = self.pk["start_t"].at(fc)
                 p.end_t = self.pk["end_t"].at(fc)
                 for l in range(Lw):
@@ -462,6 +476,7 @@ def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
     buf = _Buffers(cfg, prep, R, mels.device)
     _, rowmask, T = squeeze_rows(cfg, mels, lengths, out=buf.x[0])
     prow = pitch_rows(cfg, pitch[0], rowmask, B, T) if pitch is not None else None
+    stamp("dec_fwd_begin")
     for f in range(cfg.F):
         if pitch is not None:
             cr = _cond_rows(cfg, prep, f, prow, pitch[1], pitch[2], T + 2 * ROW_PAD)
@@ -470,6 +485,7 @@ def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
         dims = _dims(cfg, B, T, drop_p, seed, f)
         _lib.check(L.glowtts_flow_forward(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(acts), _lib.stream()),
                    "glowtts_flow_forward")
+    stamp("dec_fwd_end")
     z = unsqueeze_rows(cfg, buf.x[cfg.F], lengths, B, Tm)
     part = torch.empty(cfg.F * B, device=mels.device)
     logdet = torch.empty(B, device=mels.device)
@@ -662,6 +678,7 @@ class DecoderFunction(torch.autograd.Function):
         halves = len(gk.segments)
         main = torch.cuda.current_stream()
         side = _wgrad_stream(dev)
+        stamp("dec_bwd_begin")
         for f in order:
             g = FlowGrads()
             g.dx, g.dlogdet, g.douts, g.dskip = dx.data_ptr(), dld.data_ptr(), douts[f].data_ptr(), dskip[f].data_ptr()
@@ -682,6 +699,7 @@ class DecoderFunction(torch.autograd.Function):
             dims = _dims(cfg, B, T, ctx.drop[0], ctx.drop[1], f)
             _lib.check(L.glowtts_flow_backward(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(acts), ctypes.byref(g),
                                                _lib.stream()), "glowtts_flow_backward")
+            stamp(f"dec_bwd_flow{f}")
             if halves > 1:
                 per = -(-len(order) // halves)
                 pos = order.index(f) + 1
@@ -705,6 +723,7 @@ class DecoderFunction(torch.autograd.Function):
         else:
             for grp in (gk, gp, g1):
                 grp.launch_segment(0)
+        stamp("dec_wgrads_done")
         _lib.check(L.glowtts_colsum_batched(scratch.data_ptr(), d_an.data_ptr(), L.glowtts_actnorm_bwd_blocks(R), 2 * C + 16, F_, nscr, 2 * C + 16, _lib.stream()),
                    "glowtts_colsum_batched")
         # + the log-determinant terms of the parameters (Modules.py:694, 747): logdet_b += (sum logs + logdet(W) C/4) * len_b

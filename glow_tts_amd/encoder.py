@@ -16,9 +16,15 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from .conv_fn import EmbeddingRows, ParamGate, RPRAttention, WgradTape, bf16_of, conv_rows, layernorm_rows
+from .conv_fn import AttentionBlock, EmbeddingRows, FFNBlock, ParamGate, RPRAttention, WgradTape, bf16_of, conv_rows, layernorm_rows
 
 ROW_PAD = 2
+
+
+def _with_bf16(y, yb):
+    """Attaches the bf16 copy of fp32 rows (see conv_fn.bf16_of)."""
+    y._bf16 = yb
+    return y
 
 
 def from_rows(rows_btc):
@@ -62,6 +68,13 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
         gated = [k for k, v in Pc.items() if k.startswith(prefix) and k.endswith(".weight") and v.dim() == 3 and v.requires_grad
                  and not k.endswith(fused)]
         gated += [k[:-len(".weight")] + ".bias" for k in gated if (k[:-len(".weight")] + ".bias") in Pc]
+        if precision == ops.BF16 and C % 64 == 0:
+            # the transformer's LayerNorm parameters too: the block functions (conv_fn.FFNBlock / AttentionBlock) leave their gradients to the
+            # tape's one batched reduction, so they must reach autograd's accumulation BEHIND the gate's flush like the conv weights do
+            for i in range(e.Transformer.Stacks):
+                for j in (0, 1):
+                    q = f"{prefix}.layer_Dict.Transformer.layer_Dict.ANCRDCN_{i}.layer_Dict.LayerNorm_{j}"
+                    gated += [q + ".weight", q + ".bias"]
         if gated:
             tape = WgradTape()
             for k, v in zip(gated, ParamGate.apply(tape, *[Pc[k] for k in gated])):
@@ -97,6 +110,8 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
         return layernorm_rows(a, b, P[name + ".weight"], P[name + ".bias"], rmf, relu=relu, drop_p=p_, seed=nseed(), seed_t=seed_t,
                               want_bf16=bf_rows)
 
+    from .decoder import stamp
+    stamp("enc_fwd_begin")
     x = EmbeddingRows.apply(tokens, P[prefix + ".layer_Dict.Embedding.weight"], rmf, math.sqrt(C))          # :267
     # Prenet :438-489   Conv(x*mask) -> LayerNorm -> ReLU -> Dropout, x3; Conv1x1 + residual; *mask
     res = x
@@ -104,6 +119,9 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
         q = f"{prefix}.layer_Dict.Prenet.layer_Dict.CLRD_{i}.layer_Dict"
         x = ln(conv(x, q + ".Conv"), None, q + ".LayerNorm", relu=True, drop=e.Prenet.Dropout_Rate)
     x = conv(x, prefix + ".layer_Dict.Prenet.layer_Dict.Conv1x1", mask_out=True, residual=res)
+    blocks = bf_rows and C % 64 == 0 and tape is not None and packset is not None
+    if blocks and bf16_of(x) is None:
+        x = _with_bf16(x, x.detach().to(torch.bfloat16))               # (the prenet's last conv writes fp32 rows)
     # Transformer :492-573
     dr = e.Transformer.Dropout_Rate
     H = e.Transformer.Attention.Heads
@@ -111,6 +129,17 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
     for i in range(e.Transformer.Stacks):
         q = f"{prefix}.layer_Dict.Transformer.layer_Dict.ANCRDCN_{i}.layer_Dict"
         a = q + ".Attention"
+        if blocks:
+            # bf16-stored rows, training: two autograd nodes per layer whose backward chains are hand-ordered (conv_fn.AttentionBlock / FFNBlock)
+            pdr = float(dr) if training else 0.0
+            x = _with_bf16(*AttentionBlock.apply(x, bf16_of(x), Pc[a + ".QKV.weight"], Pc[a + ".QKV.bias"], P[a + ".weight_K"], P[a + ".weight_V"],
+                                                 Pc[a + ".layer_Dict.Projection.weight"], Pc[a + ".layer_Dict.Projection.bias"],
+                                                 Pc[q + ".LayerNorm_0.weight"], Pc[q + ".LayerNorm_0.bias"], rmf, B, Tp, H, win, pdr, (nseed(), nseed()), seed_t,
+                                                 tape, packset.get(a + ".QKV"), packset.get(a + ".layer_Dict.Projection")))
+            x = _with_bf16(*FFNBlock.apply(x, bf16_of(x), Pc[q + ".Conv_0.weight"], Pc[q + ".Conv_0.bias"], Pc[q + ".Conv_1.weight"], Pc[q + ".Conv_1.bias"],
+                                           Pc[q + ".LayerNorm_1.weight"], Pc[q + ".LayerNorm_1.bias"], rmf, pdr, (nseed(), nseed()), seed_t, tape,
+                                           packset.get(q + ".Conv_0"), packset.get(q + ".Conv_1")))
+            continue
         qkv = conv(x, a + ".QKV")                                                                            # RPR_MHA.py:82-84 (one fused 1x1 conv)
         att = RPRAttention.apply(qkv, P[a + ".weight_K"], P[a + ".weight_V"], rmf, B, Tp, H, win,
                                  float(dr) if training else 0.0, nseed(), seed_t, precision)                 # RPR_MHA.py:95-128
@@ -120,6 +149,7 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
         h = conv(h, q + ".Conv_1", mask_out=True, drop=dr)                                                   # :568-569 (x*mask at :571)
         x = ln(h, x, q + ".LayerNorm_1")                                                                     # :571
     proj = conv(x, prefix + ".layer_Dict.Project", mask_out=True).view(B, Tp, -1)
+    stamp("enc_fwd_project")
     M = hp.Sound.Mel_Dim
     proj = from_rows(proj)
     mean, log_std = proj[:, :M].contiguous(), proj[:, M:].contiguous()      # (here, on the encoder stream: the consumers need dense rows)

@@ -42,6 +42,9 @@ int glowtts_launch_log_dump(char *buf, int buflen);
  * (host pointer, optional) receives the wall counter's rate.  cycles / ticks * rate = the clock the chip holds under a dense bf16 MFMA
  * load, which on MI355X is well below the 2.4 GHz the 2.5 PFLOP/s datasheet peak assumes. */
 int glowtts_mfma_clock_probe(long long *out, int nwg, int iters, int *wall_khz, void *stream);
+/* Diagnostics: a one-thread kernel that writes the constant-rate wall counter (the rate glowtts_mfma_clock_probe reports) to *slot when the
+ * stream reaches it - a timeline of a replayed hipGraph from inside the graph (tools/step_timeline.py). */
+int glowtts_debug_stamp(long long *slot, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Monotonic Alignment Search.
@@ -476,10 +479,13 @@ int64_t glowtts_layernorm_scratch_floats(int64_t rows, int C);
 /* ds = dL/d(a + b); dgamma_dbeta [2C].  gated != 0: the forward applied relu and/or dropout, y is its output (zero where cut). */
 int glowtts_layernorm_bwd(const float *dy, const float *y, const float *s, const float *stats, const float *gamma, const float *rowmask,
                           float *ds, float *dgamma_dbeta, float *scratch, int64_t rows, int C, int gated, float drop_p, void *stream);
-/* same, and ds_bf16 (may be NULL) additionally receives ds rounded to bf16 */
+/* same, and: ds_bf16 (may be NULL) additionally receives ds rounded to bf16 - with gate_out ([rows][C] fp32, the forward output of the conv
+ * that produced the LayerNorm input) as d(pre-activation) of that conv, ds * (gate_out != 0 ? gate_scale : 0), i.e. through its relu /
+ * dropout gate; dgamma_dbeta == NULL leaves the per-workgroup partials in `scratch` ([glowtts_layernorm_scratch_floats / (2C)][2C]) for one
+ * glowtts_colsum_batched over several calls. */
 int glowtts_layernorm_bwd_io(const float *dy, const float *y, const float *s, const float *stats, const float *gamma, const float *rowmask,
                              float *ds, float *dgamma_dbeta, float *scratch, int64_t rows, int C, int gated, float drop_p,
-                             uint16_t *ds_bf16, void *stream);
+                             uint16_t *ds_bf16, const float *gate_out, float gate_scale, void *stream);
 /* dz = dy * (out != 0 ? scale : 0) * rowmask : backward gate of relu / dropout given the forward output */
 int glowtts_gate_bwd(const float *dy, const float *out, const float *rowmask, float *dz, int64_t rows, int C, float scale, void *stream);
 /* io_flags: 1 = dy, 2 = out, 4 = dz stored as bf16 instead of fp32 (C a multiple of 4) */

@@ -24,6 +24,8 @@ TABLE = [
     ("wgrad_kernel<bool _Accum, int, E, 0, true, true, true>", "weight gradients, Res_Skip 1x1 group", 12 * 7 * 2.0 * R * 192 * 192, 12 * 7 * R * 768),
     ("wgrad_kernel<bool _Accum, int, E, 0, false, false, true>", "weight gradients, Start / End group (fp32 operands)", 12 * 2.0 * R * (192 * 80 + 160 * 192), 12 * R * (768 + 320 + 768 + 768)),
     ("conv_cl_kernel<bool _Accum, int, E, 2, 4, 1, 0, 3", "encoder FFN conv k=3 (192<->768, fp32 rows)", 2.0 * RT * 768 * 192 * 3, RT * (768 + 3072) * 1.0),
+    ("conv_dma_kernel<0, 3", "encoder k=3 convs on bf16 rows (FFN 192<->768 forward + data gradients, duration predictor; priced as FFN)", 2.0 * RT * 768 * 192 * 3, RT * (384 + 1536) * 1.0),
+    ("conv_dma_kernel<0, 1", "encoder 1x1 convs on bf16 rows (QKV 192->576 and data gradients; priced as QKV)", 2.0 * RT * 576 * 192, RT * (384 + 2304) * 1.0),
     ("attn_bwd_mfma_kernel", "relative-position attention backward (1 layer)", 32 * 2 * 2.5 * 8.0 * 120 * 120 * 96, 32 * (120 * 576 * 4 * 2 + 2 * 120 * 120 * 4)),
     ("attn_fwd_mfma_kernel", "relative-position attention forward (1 layer)", 32 * 2 * 8.0 * 120 * 120 * 96, 32 * (120 * 576 * 4 + 120 * 192 * 4 + 2 * 120 * 120 * 4)),
     ("ln_bwd_kernel", "LayerNorm backward", 0.0, None),
@@ -45,6 +47,9 @@ for r in rows[: int(sys.argv[2]) if len(sys.argv) > 2 else 16]:
     hit = next((t for t in TABLE if t[0] in name), None)
     label = hit[1] if hit else name[:70]
     fl, by = (hit[2], hit[3]) if hit else (0.0, None)
+    if hit and "wgrad_kernel" in hit[0] and calls > 1.5:        # the demangled name hides the tap count: the encoder's groups share the row
+        label += " + the encoder's group of the same storage types (averaged: not priced)"
+        fl, by = 0.0, None
     tf = fl / (avg * 1e-6) / 1e12 if fl else None
     gb = by / (avg * 1e-6) / 1e9 if by else None
     print(f"| {label} | {calls:.1f} | {avg:.1f} | {per_step:.0f} | " + (f"{tf:.0f} | {tf / PEAK_TF:.3f}" if tf else "- | -") + " | "
