@@ -185,7 +185,7 @@ class ConvRows(torch.autograd.Function):
         dy = dy.contiguous()
         bf = torch.bfloat16
         # the data gradient is a conv with K = O: the LDS-DMA kernel takes whole 32-channel chunks, its 1x1 form pairs of them (Project's
-        # 160 outputs do not qualify; the register-staged kernel on a bf16-stored operand measured 60-165 us there against 10 on fp32 rows)
+        # 160 outputs do not qualify: the register-staged kernel serves it, from fp32 rows - no conversion pass, same 6-7 us)
         bfpath = bfpath and O % 32 == 0 and (k > 1 or O % 64 == 0)
         if gated:                                              # d(pre-activation): relu / dropout cut exactly where out == 0
             dz = torch.empty(R, O, device=dy.device, dtype=bf if bfpath else torch.float32)

@@ -13,7 +13,7 @@ R = B * (T + 4)
 SHAPES = [("QKV 1x1", 192, 576, 1, 0), ("Projection 1x1", 192, 192, 1, ops.F_DROPOUT), ("Conv_0 k=3", 192, 768, 3, ops.F_RELU | ops.F_MASK | ops.F_DROPOUT),
           ("Conv_1 k=3", 768, 192, 3, ops.F_MASK | ops.F_DROPOUT), ("Conv_1^T k=3", 192, 768, 3, 0), ("Conv_0^T k=3", 768, 192, 3, 0),
           ("QKV^T 1x1", 576, 192, 1, 0), ("Prenet k=5", 192, 192, 5, 0), ("DP k=3", 192, 256, 3, ops.F_RELU | ops.F_MASK | ops.F_DROPOUT),
-          ("DP^T k=3", 256, 192, 3, 0)]
+          ("DP^T k=3", 256, 192, 3, 0), ("Project 1x1", 192, 160, 1, ops.F_MASK), ("Project^T 1x1", 160, 192, 1, 0), ("DP0+spk k=3", 448, 256, 3, ops.F_RELU | ops.F_MASK | ops.F_DROPOUT)]
 n = 50
 st = torch.cuda.Stream()
 rowmask = torch.ones(R, device="cuda")
