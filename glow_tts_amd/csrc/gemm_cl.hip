@@ -1370,6 +1370,14 @@ inline bool dma_prefers_96(const glowtts_conv_args& a)
     return force == 3 && (a.npad % 96) == 0;
 }
 
+// 32-column strips (NI = 1) for k-tap convs whose 64-column tiling would leave half the chip idle (the text encoder's 768 -> 192 FFN
+// convs at B = 32: 31 row tiles x 3 strips = 93 workgroups): twice the workgroups, half the MFMAs on each wave's dependent chain.
+inline bool dma_prefers_32(const glowtts_conv_args& a)
+{
+    const long tiles64 = (long)(((a.rows + 31) / 32 + 3) / 4) * (a.npad / 64);
+    return GLOWTTS_TUNABLE("GLOWTTS_DMA_NI1", 1) != 0 && (a.npad % 32) == 0 && 2 * tiles64 <= num_cus();
+}
+
 template <int EPI, int TAPS, int NI = 2>
 int launch_dma(const glowtts_conv_args& a, hipStream_t s)
 {
@@ -1503,7 +1511,7 @@ int launch_prec(const glowtts_conv_args& a, hipStream_t s)
             if (a.epi == GLOWTTS_EPI_GATE && a.taps == 5) return launch_dma<GLOWTTS_EPI_GATE, 5>(a, s);
             if (a.epi == GLOWTTS_EPI_LINEAR && a.taps == 5) return dma_prefers_96(a) ? launch_dma<GLOWTTS_EPI_LINEAR, 5, 3>(a, s) : launch_dma<GLOWTTS_EPI_LINEAR, 5>(a, s);
             if (a.epi == GLOWTTS_EPI_GATE && a.taps == 3) return launch_dma<GLOWTTS_EPI_GATE, 3>(a, s);
-            if (a.epi == GLOWTTS_EPI_LINEAR && a.taps == 3) return launch_dma<GLOWTTS_EPI_LINEAR, 3>(a, s);
+            if (a.epi == GLOWTTS_EPI_LINEAR && a.taps == 3) return dma_prefers_32(a) ? launch_dma<GLOWTTS_EPI_LINEAR, 3, 1>(a, s) : launch_dma<GLOWTTS_EPI_LINEAR, 3>(a, s);
             if (a.epi == GLOWTTS_EPI_RESSKIP && a.taps == 1) return launch_dma<GLOWTTS_EPI_RESSKIP, 1>(a, s);
             if (a.epi == GLOWTTS_EPI_DGATE && a.taps == 1) return launch_dma<GLOWTTS_EPI_DGATE, 1>(a, s);
             if (a.epi == GLOWTTS_EPI_LINEAR && a.taps == 1) return launch_dma<GLOWTTS_EPI_LINEAR, 1>(a, s);

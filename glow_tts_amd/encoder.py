@@ -33,7 +33,7 @@ def from_rows(rows_btc):
 
 
 def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training=False, prefix="layer_Dict.Encoder",
-                    precision=1, cache=None):
+                    precision=1, cache=None, on_prior_ready=None):
     """Modules.py:262-284 -> mean [B,mel,T], log_std [B,mel,T], log_durations [B,1,T] (channel-first, like the reference)."""
     e = hp.Encoder
     C = e.Channels
@@ -153,6 +153,8 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
     M = hp.Sound.Mel_Dim
     proj = from_rows(proj)
     mean, log_std = proj[:, :M].contiguous(), proj[:, M:].contiguous()      # (here, on the encoder stream: the consumers need dense rows)
+    if on_prior_ready is not None:
+        on_prior_ready()         # the log-prior / MAS side of the step can start: what follows (duration predictor) is only needed by the losses
     # Duration predictor on detached features (:277-282, 602-618)
     d, db = x.detach(), bf16_of(x)
     cond = None

@@ -314,9 +314,11 @@ class GlowTTS(torch.nn.Module):
             self._enc_stream = torch.cuda.Stream()
         side = self._enc_stream if self.overlap_encoder else main
         side.wait_stream(main)
+        prior_ready = torch.cuda.Event() if side is not main else None
         with torch.cuda.stream(side):
             mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, self.training, precision=self.dec_cfg.precision,
-                                                             cache=self._enc_cache)
+                                                             cache=self._enc_cache,
+                                                             on_prior_ready=(lambda: prior_ready.record(side)) if prior_ready is not None else None)
         stacks = self._stacks(P)
         cond = stacks.conditioning(spk, pro)
         pitch_w, pitch_b = stacks.pitch_weights()
@@ -330,7 +332,9 @@ class GlowTTS(torch.nn.Module):
         z, log_dets, z_rows = decoder.DecoderFunction.apply(self.dec_cfg, mels, mel_lengths, cond, drop_p, pitches, pitch_w if pitches is not None else None,
                                                             pitch_b if pitches is not None else None, *W)
         if side is not main:
-            main.wait_stream(side)
+            # the log-prior needs mean / log_std only: the duration predictor still runs on the encoder's stream (joined below, before the
+            # losses read log_dur) - the encoder's forward is what this point of the step waits for (timeline)
+            main.wait_event(prior_ready)
             for t_ in (mean, log_std, log_dur):
                 t_.record_stream(main)
         ns = int(hp.Decoder.Num_Squeeze)
