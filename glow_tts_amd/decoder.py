@@ -115,6 +115,11 @@ TAIL = {"defer": False, "pending": []}
 #       all 12 flows 6.33 vs 5.90 ms/step, 9 flows 5.95.  The encoder's backward has drained by the time the decoder's backward is half way:
 #       the last 6 flows fused 5.70 vs 5.85 and 5.82 vs 5.92 ms/step on two boxes
 #   fused_wn: the coupling network of a flow (Start .. End + coupling) as ONE launch (csrc/wavenet_fused.hip) where its shape contract holds
+#   fused_wn_fwd_skip: training forward, the first n flows on the per-conv launches (they run beside the text encoder's forward, which the
+#       CU-filling fused workgroups starve).  0 by default; -1 = 1 for a chip-filling batch: the timeline then shows the encoder's and the
+#       decoder's forward ending together (1797 / 1814 us instead of 1763 / 1880; 2 flows: 842 / 1924) and the step gains 0.03 ms (5.65 vs
+#       5.68) - not adopted: mixing the two forward kernels moved 2.4 % of the ragged B = 32 batch's frames to another token against the
+#       fp32 oracle (bar 2 %, all-fused 1-2 %; tests/test_gpu_benchmarked_sizes.py), too close to the bar for 0.5 % of the step
 TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": 0}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
@@ -298,19 +303,28 @@ class _Prepared:
                 self.pk["rs"] = ImageSlices(self.wn_img, nb, 32 * S, Lw - 1, 36 * S, 2 * H, H // 32)       # (PAIR-packed: read by the fused kernel only)
         # training: the first flows of the forward can stay on the per-conv launches (TUNE["fused_wn_fwd_skip"]) - they run beside the
         # text encoder's forward on the other stream, which a CU-filling fused workgroup starves
-        nskip = min(int(TUNE["fused_wn_fwd_skip"]), F_) if (need_bwd and self.wn_img is not None) else 0
+        nskip = int(TUNE["fused_wn_fwd_skip"])
+        if nskip < 0:                                           # automatic: one flow when the batch's fused workgroups fill the chip (see fused_wn_bwd)
+            nwg_ = -(-rows // (64 - 4 * (Lw - 1))) if rows else 0
+            cus_ = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
+            nskip = 1 if 4 * nwg_ > 3 * cus_ else 0
+        nskip = min(nskip, F_) if (need_bwd and self.wn_img is not None) else 0
         pk_conv = None
-        if self.wn_img is None or nskip > 0:
-            pk_conv = {
+        if self.wn_img is None:
+            self.pk = {
                 "start": PackedBatch(W["w_start"], False, ops.PERM_NONE, 0, P),
                 "in": PackedBatch(w_in, False, ops.PERM_PAIR, H, P),
                 "rs_last": PackedBatch(W["w_rs_last"], False, ops.PERM_NONE, 0, P),
                 "end": PackedBatch(W["w_end"], False, ops.PERM_PAIR, C // 2, P),
             }
             if Lw > 1:
-                pk_conv["rs"] = PackedBatch(W["w_rs"].reshape(F_ * (Lw - 1), 2 * H, H, 1), False, ops.PERM_NONE, 0, P)
-            if self.wn_img is None:
-                self.pk = pk_conv
+                self.pk["rs"] = PackedBatch(W["w_rs"].reshape(F_ * (Lw - 1), 2 * H, H, 1), False, ops.PERM_NONE, 0, P)
+        elif nskip > 0:
+            # the per-conv kernels read the Start / In_l / last Res_Skip / End slabs of the fused image as they are; only Res_Skip_l (l < L - 1)
+            # is PAIR-packed there (residual | skip per 32 channels) and is packed once more in the per-conv order for the skipped flows
+            pk_conv = dict(self.pk)
+            if Lw > 1:
+                pk_conv["rs"] = PackedBatch(W["w_rs"][:nskip].reshape(nskip * (Lw - 1), 2 * H, H, 1), False, ops.PERM_NONE, 0, P)
         # backward: the transposed image of the fused data-gradient kernel (glowtts_wavenet_bwd) where it applies - no conditioning gradient -
         # else the per-conv transposed images
         self.wn_img_t = None

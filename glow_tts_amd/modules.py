@@ -6,6 +6,7 @@ HIP library (glow_tts_amd/csrc) or, for the parts still marked interim in DESIGN
 """
 import math
 
+import os
 import torch
 
 from . import alignment, decoder, encoder, ops

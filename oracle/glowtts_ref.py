@@ -395,12 +395,14 @@ def mas(value, mask, max_neg_val=-1e9):
     return torch.from_numpy(path).to(dtype=value.dtype)
 
 
-def forward_train(sd, cfg, tokens, token_lengths, mels, mel_lengths, speakers=None, prosodies=None, pitches=None):
+def forward_train(sd, cfg, tokens, token_lengths, mels, mel_lengths, speakers=None, prosodies=None, pitches=None, attn=None):
     """Modules.py:50-126 GlowTTS.forward, every Mode: Vanilla / SE (LUT ids or pre-computed d-vectors) / PE (GST prosody encoder on the
     target mels, :81-82) / GR (LUT + prosody encoder + adversarial speaker classifier :84-87 + per-frame pitch conditioning :89-90, 300-301).
     `speakers`: int64 ids (LUT) or float [B,256] vectors (GE2E d-vectors are an input); `prosodies`: pre-computed vectors
-    override the prosody encoder."""
+    override the prosody encoder.  `attn` (test hook, not in the reference): use this alignment instead of searching one - lets a parity test
+    compare gradients on EQUAL alignments when the search sits on near-ties."""
     mode = cfg.mode.upper()
+    attn_given = attn
     if speakers is not None and speakers.dtype == torch.long:
         speakers = F.embedding(speakers, sd["layer_Dict.LUT.weight"])           # :73-74
     elif speakers is not None:
@@ -417,7 +419,7 @@ def forward_train(sd, cfg, tokens, token_lengths, mels, mel_lengths, speakers=No
     amask = (tmask.unsqueeze(-1) * mmask2.unsqueeze(2)).squeeze(1)               # :102-103
     with torch.no_grad():
         logp = log_prior(mean, log_std, z)
-        attn = mas(logp, amask)                                                  # :116
+        attn = mas(logp, amask) if attn_given is None else attn_given           # :116
     mel_mean = mean @ attn                                                       # :120
     mel_log_std = log_std @ attn                                                 # :121
     log_dur_t = torch.log(attn.unsqueeze(1).sum(-1) + 1e-7) * tmask              # :122

@@ -114,18 +114,41 @@ def check_bf16(case, r):
     mmask = O.mask_from_lengths(case["ml"], TM)
     differ = ((r["attn"] != o["attn"]).any(1).float() * mmask[:, 0]).sum().item() / mmask.sum().item()
     assert abs(r["mle"] - case["mle"]) <= 1e-3, (r["mle"], case["mle"])
-    assert differ <= 0.02, differ                     # (random-init scores are near-ties: 0.94 % at B = 32 Set F, 0 % at B = 4)
     assert ((r["z"] - o["z"]) * mmask).abs().max() <= 0.1
+    # Alignment.  On a random-init model the log-prior scores are near-ties and the NUMBER of frames whose token differs from the fp32
+    # oracle's path is chaotic in the last bits: on the ragged Set V 0.65 % and 2.46 % for two builds of the encoder's FFN convs that are
+    # equally accurate (both 2e-6 from an fp64 reference, tools/check_ni1.py) and differ only in fp32 summation order.  What is tested
+    # instead is the QUALITY of the path in the oracle's own terms: its total score on the oracle's fp32 score matrix must reach the
+    # oracle's optimum to 1e-3 of the mean score magnitude per frame - a quarter of one bf16 ulp of the scores this path searched on
+    # (observed 2e-4 with 2.5 % of the frames moved; an O(1) score bug loses 0.1-1) - and the count stays below 5 % as a tripwire.
+    logp = o["logp"]                                                      # [B, T_tok, T_mel/ns... as the oracle lays it out]
+    want_score = (logp * o["attn"]).sum((1, 2))
+    got_score = (logp * r["attn"][:, :, :logp.shape[2]]).sum((1, 2))
+    frames = o["attn"].sum((1, 2)).clamp_min(1)
+    spread = (logp * o["attn"]).abs().sum((1, 2)) / frames
+    deficit = ((want_score - got_score) / frames / spread.clamp_min(1e-6)).max().item()
+    print(f"frames aligned differently from the fp32 oracle: {100 * differ:.2f} %; worst per-frame score deficit of this path on the oracle's scores: {deficit:.2e}")
+    assert deficit <= 1e-3 and differ <= 0.05, (deficit, differ)
+    # Gradients: against the oracle evaluated ON THIS PATH'S alignment (O.forward_train(attn=...)), so that the comparison measures the
+    # arithmetic, not which of two near-tied paths the search took
+    grads = case["grads"]
+    if differ > 0:
+        sdg = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in case["sd"].items()}
+        cfg = O.Cfg.from_yaml_dict(_hp(case["mode"], "f32"))
+        out = O.forward_train(sdg, cfg, case["tokens"], case["tl"], case["mels"], case["ml"], case["spk"], attn=r["attn"][:, :, :logp.shape[2]].to(o["attn"].dtype))
+        mle, length = O.train_losses(out, case["ml"], cfg)
+        (mle + length).backward()
+        grads = {k: v.grad for k, v in sdg.items() if v.grad is not None}
     rep = []
-    for k, want in case["grads"].items():
+    for k, want in grads.items():
         if "Decoder" not in k:
             continue
         a, b = r["grads"][k].flatten().double(), want.flatten().double()
         rep.append(((a @ b / (a.norm() * b.norm() + 1e-30)).item(), (a.norm() / (b.norm() + 1e-30)).item(), k))
     rep.sort()
-    print(f"bf16 {case['mode']} B={len(case['tl'])}: |dNLL| {abs(r['mle'] - case['mle']):.2e}, frames aligned differently {100 * differ:.3f} %, worst decoder gradients {rep[:2]}")
+    print(f"bf16 {case['mode']} B={len(case['tl'])}: |dNLL| {abs(r['mle'] - case['mle']):.2e}, worst decoder gradients (oracle on the same alignment) {rep[:2]}")
     for cos, ratio, k in rep:
-        assert cos >= 0.995 and 0.97 <= ratio <= 1.03, (k, cos, ratio)
+        assert cos >= 0.9995 and 0.995 <= ratio <= 1.005, (k, cos, ratio)      # (observed >= 0.99990 / 0.9990 .. 1.0012 on equal alignments)
 
 
 def _set_v(B, seed):
@@ -156,7 +179,10 @@ def test_config2_batch32_bf16(config2_case):
     launch_reset()
     r = run_hip(config2_case, "bf16")
     counts = launch_counts()
-    assert sum(n for k, n in counts.items() if k.startswith("wn_fwd<")) == 12, counts      # the benchmarked forward kernel served it
+    # the benchmarked kernels served it: 12 fused forward launches; the backward's last 5 flows on the fused data-gradient kernel
+    # (decoder.TUNE["fused_wn_bwd"]: the automatic choice for a chip-filling batch)
+    assert sum(n for k, n in counts.items() if k.startswith("wn_fwd<")) == 12, counts
+    assert sum(n for k, n in counts.items() if k.startswith("wn_bwd<")) == 5, counts
     check_bf16(config2_case, r)
 
 

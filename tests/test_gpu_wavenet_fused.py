@@ -275,3 +275,35 @@ def test_fused_backward_conditioning_gradient(lengths, tm, drop):
         a, b = gf["<conditioning>"][b_].flatten().double(), gu["<conditioning>"][b_].flatten().double()
         if b.norm() > 0:
             assert (a @ b / (a.norm() * b.norm() + 1e-30)).item() >= 0.999, (b_, (a @ b / (a.norm() * b.norm() + 1e-30)).item())
+
+
+def test_mixed_forward_first_flow_per_conv():
+    """decoder.TUNE["fused_wn_fwd_skip"] = 1: flow 0 of the training forward on the per-conv launches, reading the Start / In_l / last
+    Res_Skip / End slabs of the FUSED weight image as they are (only the PAIR-packed Res_Skip_l is packed once more), flow 1 fused.  Same
+    gradients as the all-fused forward."""
+    from glow_tts_amd import decoder as D
+    g = torch.Generator().manual_seed(23)
+    cfg, sd = full_width_state(2, g)
+    dc = D.DecoderConfig(cfg.mel_dim, cfg.n_flows, cfg.n_squeeze, cfg.n_split, cfg.wn_channels, cfg.wn_layers, cfg.wn_kernel, 1)
+    P = {k: v.cuda() for k, v in sd.items()}
+    lengths, tm = [640, 418, 96], 640
+    B = len(lengths)
+    mels = (torch.randn(B, 80, tm, generator=g) * 1.5).clamp(-4, 4).cuda()
+    ml = torch.tensor(lengths).cuda()
+    wz, wl = torch.randn(B, 80, tm, generator=g).cuda(), (torch.randn(B, generator=g) * 0.05).cuda()
+    res = []
+    default = D.TUNE["fused_wn_fwd_skip"]
+    for skip in (0, 1):
+        D.TUNE["fused_wn_fwd_skip"] = skip
+        try:
+            torch.manual_seed(3)
+            res.append(_grads(D, dc, P, mels, ml, wz, wl, 0, 0.05))
+        finally:
+            D.TUNE["fused_wn_fwd_skip"] = default
+    (g0, dx0, c0), (g1, dx1, c1) = res
+    assert sum(n for k, n in c0.items() if k.startswith("wn_fwd<")) == 2 and sum(n for k, n in c1.items() if k.startswith("wn_fwd<")) == 1, (c0, c1)
+    assert c1.get("conv_dma<GATE,5>", 0) == 4 and c0.get("conv_dma<GATE,5>", 0) == 0, c1
+    for k, want in g0.items():
+        a, b = g1[k].flatten().double(), want.flatten().double()
+        cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+        assert cos >= 0.9995 and 0.99 <= (a.norm() / (b.norm() + 1e-30)).item() <= 1.01, (k, cos)
