@@ -27,6 +27,7 @@
 #include "launch_log.h"
 #include "tunable.h"
 #include <algorithm>
+#include "mas_common.h"
 
 namespace {
 
@@ -38,7 +39,8 @@ __device__ __forceinline__ float wave_shr1(float v, float lane0_value) {
 
 // bits = (bits << 1) | (a < b)      (v_cmp -> VCC, v_addc_co: bits + bits + carry-in)
 __device__ __forceinline__ void push_lt_bit(unsigned int& bits, float a, float b) {
-    asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(a), "v"(b) : "vcc");
+    // (s_nop 1: on gfx950 a VALU that reads VCC written by a VALU needs two wait states; nothing inside an asm string is padded by hipcc)
+    asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(a), "v"(b) : "vcc");
 }
 
 // Off the diagonal (x != y) the back-pointer test `Q[x][y-1] < Q[x-1][y-1]` (core.pyx:34) and the forward maximum `v_prev > v_cur`
@@ -47,7 +49,7 @@ __device__ __forceinline__ void push_lt_bit(unsigned int& bits, float a, float b
 __device__ __forceinline__ float push_lt_bit_and_max(unsigned int& bits, float q_cur, float v_prev) {
     float m;
     // (the select first: v_addc_co overwrites VCC with its carry-out)
-    asm volatile("v_cmp_lt_f32 vcc, %2, %3\n\tv_cndmask_b32 %1, %2, %3, vcc\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+    asm volatile("v_cmp_lt_f32 vcc, %2, %3\n\ts_nop 1\n\tv_cndmask_b32 %1, %2, %3, vcc\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
                  : "+v"(bits), "=&v"(m) : "v"(q_cur), "v"(v_prev) : "vcc");
     return m;
 }
@@ -64,29 +66,9 @@ __global__ __launch_bounds__(64) void mas_dp_kernel(const float* __restrict__ va
     const int lane = threadIdx.x;
     const int tx = t_xs[b], ty = t_ys[b];
     int32_t* idx_b = idx_out ? idx_out + (size_t)b * Ty : nullptr;
-    if (tx < 1 || ty < 0 || tx > Tx || ty > Ty) {             // lengths outside the tensors: empty alignment
-        if (idx_b) for (int y = lane; y < Ty; y += 64) idx_b[y] = -1;
-        return;
-    }
     const float* vb = value + (size_t)b * Tx * Ty;
-    if (ty < tx) {
-        // More tokens than frames: no monotonic alignment exists.  core.pyx:15-17's loops are then empty for every column (lo >= hi), `value`
-        // stays as it was passed in, and the backtrack (:31-35) walks those RAW inputs from row t_x - 1; reproduced literally (a serial,
-        // wave-uniform walk: not a case a model produces; the test at y == 0 cannot change the path any more and is skipped).
-        int index = tx - 1;
-        for (int y = ty - 1; y >= 0; --y) {
-            if (idx_b && lane == 0) idx_b[y] = index;
-            if (y > 0 && index != 0) {
-                const float a = TR ? vb[(size_t)(y - 1) * Tx + index] : vb[(size_t)index * Ty + y - 1];
-                const float c = TR ? vb[(size_t)(y - 1) * Tx + index - 1] : vb[(size_t)(index - 1) * Ty + y - 1];
-                if (index == y || a < c) index -= 1;
-            }
-        }
-        if (idx_b) for (int y = max(ty, 0) + lane; y < Ty; y += 64) idx_b[y] = -1;
-        return;
-    }
+    if (mas_degenerate<TR>(vb, idx_b, tx, ty, Tx, Ty, lane)) return;
     float* qb = WRITEQ ? q_out + (size_t)b * Tx * Ty : nullptr;
-    const int nblk = (ty + 31) >> 5;
 
     // row pointers (rows >= Tx are clamped: they are never inside the band)
     const float* rowp[R];
@@ -203,32 +185,7 @@ __global__ __launch_bounds__(64) void mas_dp_kernel(const float* __restrict__ va
     int it = 0;
     for (; it < it_diag; ++it) iteration(it, std::true_type{});
     for (; it < niter; ++it) iteration(it, std::false_type{});
-    __syncthreads();
-
-    // ---- backtrack (core.pyx:31-35): wave-uniform walk, one step per row change ----
-    int index = tx - 1;
-    for (int blk = nblk - 1; blk >= 0; --blk) {
-        const int i0 = index;
-        const int row = i0 - lane;
-        unsigned int W = 0u;
-        if (lane <= 32 && row >= 0) W = dec[(blk * R + (row % R)) * 64 + (row / R)];
-        int myidx = -1;
-        int yy = min(31, ty - 1 - blk * 32);                    // highest column of this block inside the utterance
-        while (yy >= 0) {
-            if (lane <= yy) myidx = index;                       // path[index][y] = 1 for every column down to the move
-            if (index == 0) break;
-            const unsigned int w = __builtin_amdgcn_readlane(W, i0 - index);
-            const unsigned int masked = w & (0xFFFFFFFFu << (31 - yy));            // columns <= yy
-            const int c_bit = masked ? 31 - (__builtin_ffs(masked) - 1) : -1;       // highest column <= yy whose bit is set
-            const int c_diag = index - blk * 32;                                    // forced move where index == y
-            const int c_move = max(c_bit, (c_diag >= 0 && c_diag <= yy) ? c_diag : -1);
-            if (c_move < 0) break;                                                   // stays on this row for the rest of the block
-            index = __builtin_amdgcn_readfirstlane(index - 1);
-            yy = c_move - 1;
-        }
-        if (idx_b && lane < 32 && blk * 32 + lane < Ty) idx_b[blk * 32 + lane] = (blk * 32 + lane < ty) ? myidx : -1;
-    }
-    if (idx_b) for (int y = nblk * 32 + lane; y < Ty; y += 64) idx_b[y] = -1;
+    mas_backtrack<R>(dec, idx_b, tx, ty, Ty, lane);
 }
 
 template <typename T>
@@ -289,6 +246,9 @@ int launch_dp(const float* value, const int32_t* t_xs, const int32_t* t_ys, int3
     const bool al = (reinterpret_cast<uintptr_t>(value) & 15) == 0;
     void (*k)(const float*, const int32_t*, const int32_t*, int32_t*, float*, int, int, float);
     bool vec_used;
+    if (transposed && R == 2 && al && (Tx % 2 == 0) && (int64_t)Tx * Ty * 4 < ((int64_t)1 << 31) && GLOWTTS_TUNABLE("GLOWTTS_MAS_DP2", 1)) {
+        return glowtts_detail::launch_mas_dp2(value, t_xs, t_ys, idx_out, q_out, B, Tx, Ty, neg, lds, s);
+    }
     if (transposed) {
         const bool vec = al && (R == 2 || R == 4) && (Tx % R == 0) && (((size_t)Tx * sizeof(float)) % (R * sizeof(float)) == 0) && Tx >= R;
         vec_used = vec;

@@ -137,7 +137,7 @@ def hip_mas_t(v, tx, ty, want_q=True):
     _lib.check(L.glowtts_mas_dp_f32_t(_lib.ptr(vt), _lib.ptr(txd), _lib.ptr(tyd), _lib.ptr(idx), _lib.ptr(qt), B, Tx, Ty, -1e9, _lib.stream()), "mas_t")
     path = ma.path_from_idx(idx, Tx, torch.int32)
     torch.cuda.synchronize()
-    kinds = [k for k in launch_counts() if k.startswith("mas_dp<")]
+    kinds = [k for k in launch_counts() if k.startswith("mas_dp<") or k.startswith("mas_dp2<")]
     q = np.ascontiguousarray(qt.cpu().numpy().transpose(0, 2, 1)) if want_q else None
     return path.cpu().numpy(), idx.cpu().numpy(), q, kinds
 
@@ -151,12 +151,14 @@ def test_transposed_golden_vectors(name, golden_dir):
     assert np.bitwise_xor.reduce(q.view(np.uint32).ravel()) == d[f"{name}/q_xor"]
     _, q_ref = mas_ref.maximum_path_c(v, tx, ty, return_q=True)
     assert np.array_equal(q.view(np.uint32), q_ref.view(np.uint32))
-    assert kinds and all(k.endswith(",t>") for k in kinds), kinds
+    assert kinds and all(k.endswith(",t>") or k.startswith("mas_dp2<") for k in kinds), kinds
 
 
-# (Tx, Ty, B, kernel variant expected): R = ceil(Tx / 64) rounded to an instantiated value; vector loads iff R in {2, 4} and Tx % R == 0
+# (Tx, Ty, B, kernel variant expected): R = ceil(Tx / 64) rounded to an instantiated value; vector loads iff R in {2, 4} and Tx % R == 0;
+# "dp2": two rows per lane with an even T_tok take the hand-scheduled production kernel mas_dp2_kernel (mas_dp2.hip)
 T_SHAPES = [(1, 9, 3, "R1,scalar"), (63, 200, 3, "R1,scalar"), (64, 300, 3, "R1,scalar"), (65, 301, 3, "R2,scalar"),
-            (120, 800, 8, "R2,vec"), (128, 640, 4, "R2,vec"), (129, 403, 3, "R3,scalar"), (192, 500, 3, "R3,scalar"),
+            (66, 67, 3, "dp2"), (100, 100, 3, "dp2"), (126, 127, 3, "dp2"), (128, 129, 3, "dp2"), (70, 1000, 3, "dp2"),
+            (120, 800, 8, "dp2"), (128, 640, 4, "dp2"), (129, 403, 3, "R3,scalar"), (192, 500, 3, "R3,scalar"),
             (200, 1000, 4, "R4,vec"), (254, 700, 2, "R4,scalar"), (256, 1024, 2, "R4,vec"), (257, 999, 2, "R6,scalar"),
             (384, 901, 2, "R6,scalar"), (400, 1201, 2, "R8,scalar"), (512, 1024, 2, "R8,scalar")]
 
@@ -174,14 +176,14 @@ def test_transposed_random_vs_oracle(Tx, Ty, B, variant):
     v = (v * mask).astype(np.float32)
     want, q_ref = mas_ref.maximum_path_c(v, tx, ty, return_q=True)
     path, idx, q, kinds = hip_mas_t(v, tx, ty)
-    assert kinds == [f"mas_dp<{variant},q,t>"], kinds
+    assert kinds == (["mas_dp2<q>"] if variant == "dp2" else [f"mas_dp<{variant},q,t>"]), kinds
     assert np.array_equal(path, want)
     assert np.array_equal(q.view(np.uint32), q_ref.view(np.uint32))
     for b in range(B):
         assert (idx[b, ty[b]:] == -1).all() and (idx[b, :ty[b]] == want[b, :, :ty[b]].argmax(0)).all()
     # and without q_out_t (the instantiation the training step uses)
     path2, _, _, kinds2 = hip_mas_t(v, tx, ty, want_q=False)
-    assert kinds2 == [f"mas_dp<{variant},noq,t>"], kinds2
+    assert kinds2 == (["mas_dp2<noq>"] if variant == "dp2" else [f"mas_dp<{variant},noq,t>"]), kinds2
     assert np.array_equal(path2, want)
 
 
