@@ -120,7 +120,10 @@ TAIL = {"defer": False, "pending": []}
 #       decoder's forward ending together (1797 / 1814 us instead of 1763 / 1880; 2 flows: 842 / 1924) and the step gains 0.03 ms (5.65 vs
 #       5.68) - not adopted: mixing the two forward kernels moved 2.4 % of the ragged B = 32 batch's frames to another token against the
 #       fp32 oracle (bar 2 %, all-fused 1-2 %; tests/test_gpu_benchmarked_sizes.py), too close to the bar for 0.5 % of the step
-TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": 0}
+#   bwd_packs_side / enc_priority: two scheduling experiments of round 3, both off: the backward-only weight images
+#       packed on a third stream joined when the backward starts (5.61 / 5.67 vs 5.68 / 5.66 ms/step: inside the spread); the encoder's
+#       stream at high priority (-1: 9.1 vs 5.6 ms/step - its ~170 short launches then take the CUs from under the chip-filling kernels)
+TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": 0, "bwd_packs_side": 0, "enc_priority": 0}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
@@ -151,6 +154,13 @@ def flush_tail_wgrads():
     """Issues, on the current stream, the launches queued by the last backward under `defer_tail_wgrads()` (kept for re-capture)."""
     for fn in TAIL["pending"]:
         fn()
+
+
+def _pack_stream(device):
+    key = "pack:" + str(device)
+    if key not in _WSTREAM:
+        _WSTREAM[key] = torch.cuda.Stream(device=device)
+    return _WSTREAM[key]
 
 
 def _wgrad_stream(device):
@@ -342,6 +352,13 @@ class _Prepared:
         else:
             nfb = min(int(nfb), F_)                             # flows 0 .. nfb-1 take the fused kernel
         f0 = min(max(int(TUNE["fused_wn_bwd_from"]), 0), F_ - nfb)               # (experiments: the fused flows are f0 .. f0 + nfb - 1)
+        # (experiment, TUNE["bwd_packs_side"]: the images only the backward reads are packed on a stream of their own, joined when the backward starts)
+        self.bwd_side = None
+        main_s = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        if need_bwd and TUNE["bwd_packs_side"] and main_s is not None:
+            self.bwd_side = _pack_stream(dev)
+            self.bwd_side.wait_stream(main_s)
+            torch.cuda.set_stream(self.bwd_side)
         if need_bwd and self.wn_img is not None and fused_bwd_ok and nfb > 0:
             self.wn_img_t = torch.empty_like(self.wn_img[:nfb])                # (the fused flows only)
             _lib.check(L.glowtts_wavenet_pack_images(_lib.ptr(W["w_start"][f0:]), _lib.ptr(W["w_in"][f0:]),
@@ -360,6 +377,11 @@ class _Prepared:
             })
             if Lw > 1:
                 self.pk["rs_t"] = PackedBatch(W["w_rs"][c0:].reshape((F_ - c0) * (Lw - 1), 2 * H, H, 1), True, ops.PERM_NONE, 0, P)
+        if self.bwd_side is not None:
+            torch.cuda.set_stream(main_s)
+            for t in [self.wn_img_t] + [self.pk[k].data for k in ("start_t", "in_t", "rs_last_t", "end_t", "rs_t") if k in self.pk]:
+                if t is not None:
+                    t.record_stream(main_s)
         self.ldo = self.pk["end"].npad
         self.ldin = self.pk["in"].npad
         self.cond, self._H, self._Lw = cond, H, Lw
@@ -633,6 +655,8 @@ class DecoderFunction(torch.autograd.Function):
         W = prep.keep
         B, Cm, Tm = ctx.mel_shape
         dev = dz.device
+        if getattr(prep, "bwd_side", None) is not None:
+            torch.cuda.current_stream(dev).wait_stream(prep.bwd_side)
         F_, Lw, H, C = cfg.F, cfg.L, cfg.H, cfg.C
         dx, _, _ = squeeze_rows(cfg, dz.contiguous(), ctx.lengths, want_mask=False)
         R = dx.shape[0]

@@ -312,7 +312,7 @@ class GlowTTS(torch.nn.Module):
         # two backward passes overlap as well.
         main = torch.cuda.current_stream()
         if self._enc_stream is None:
-            self._enc_stream = torch.cuda.Stream()
+            self._enc_stream = torch.cuda.Stream(priority=int(decoder.TUNE["enc_priority"]))      # (experiment: -1 = high priority)
         side = self._enc_stream if self.overlap_encoder else main
         side.wait_stream(main)
         prior_ready = torch.cuda.Event() if side is not main else None

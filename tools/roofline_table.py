@@ -33,7 +33,7 @@ TABLE = [
     ("pack_weight_kernel", "weight packing (fp32 -> bf16 tile order)", 0.0, None),
     ("radam_kernel", "RAdam update (28.6 M parameters)", 0.0, 28.6e6 * 4 * 7),
     ("multi_sqnorm_kernel", "gradient norm", 0.0, 28.6e6 * 4),
-    ("mas_dp_kernel", "MAS dynamic programme (32 utterances, 120 x 800)", 0.0, 32 * 8 * 120 * 800),
+    ("mas_dp2_kernel", "MAS dynamic programme + backtrack (32 utterances, 120 x 800)", 0.0, 32 * 8 * 120 * 800),
 ]
 PEAK_TF, PEAK_GB = 2500.0, 8000.0
 
