@@ -36,6 +36,10 @@ constexpr int LN_MAXK = 16;          // channels per lane: C <= 1024
 __device__ __forceinline__ uint16_t f2bf(float v) { const __bf16 b = (__bf16)v; return *reinterpret_cast<const uint16_t*>(&b); }
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
 
+// KT > 0: C == 64 * KT exactly (192- and 256-channel rows: every row of the encoder): no per-element predicates, and EVERY load of the row -
+// a, b, gamma, beta, the row mask - is issued before the first use.  (The generic form below loads under `if (c < C)`: hipcc then branches
+// around each load and waits for it before it issues the next - ten dependent round trips to L2 per row, 6.7 us per launch for 3 MB.)
+template <int KT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ s_out,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ rowmask, float* __restrict__ y, float* __restrict__ stats,
@@ -45,6 +49,50 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ a
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= rows) return;
+    if constexpr (KT > 0) {
+        constexpr int CC = 64 * KT;
+        const float* ar = a + r * CC + lane;
+        float v[KT], bv[KT], gm[KT], bt[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) v[k] = ar[64 * k];
+        if (b) {
+            const float* br = b + r * CC + lane;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) bv[k] = br[64 * k];
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k) { gm[k] = gamma[lane + 64 * k]; bt[k] = beta[lane + 64 * k]; }
+        const float m = rowmask ? rowmask[r] : 1.f;
+        if (seed_ptr) seed += *seed_ptr;
+        if (b) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) v[k] += bv[k];
+        }
+        if (s_out) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) s_out[r * CC + lane + 64 * k] = v[k];
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) sum += v[k];
+        const float mean = wave_sum(sum) / CC;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) { const float d = v[k] - mean; sq += d * d; }
+        const float rstd = rsqrtf(wave_sum(sq) / CC + eps);
+        if (lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+        const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const int c = lane + 64 * k;
+            float o = (v[k] - mean) * rstd * gm[k] + bt[k];
+            if (relu) o = fmaxf(o, 0.f);
+            if (drop_p > 0.f) o *= drop_scale(seed, (uint32_t)(r * CC + c), drop_p, ik);
+            y[r * CC + c] = o * m;
+            if (yb) yb[r * CC + c] = f2bf(o * m);          // the same rows as an MFMA operand (LDS-DMA convs read raw bf16)
+        }
+        return;
+    }
     if (seed_ptr) seed += *seed_ptr;
     const int K = (C + 63) / 64;
     float v[LN_MAXK];
@@ -102,6 +150,50 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void ln_bwd_kernel(const float* 
     for (int k = 0; k < KM; ++k) { accg[k] = 0.f; accb[k] = 0.f; }
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min(rows, r0 + rows_per_block);
+    if constexpr (KT > 0) {
+        // C == 64 * KT exactly (the launcher picks KT only then): no per-element predicates and every load of the row - statistics, mask,
+        // dy, y, s, the conv's kept output - issued before the first use (under `if (c < C)` each was a dependent round trip to L2:
+        // 12.8-14.9 us per launch inside the step)
+        constexpr int CC = 64 * KT;
+        float gm[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) gm[k] = gamma[lane + 64 * k];
+        for (long r = r0 + wave; r < r1; r += LN_BWD_WAVES) {
+            const long o = r * CC + lane;
+            float dyv[KT], yv[KT], sv[KT], gv[KT];
+            const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+            const float m = rowmask ? rowmask[r] : 1.f;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) { dyv[k] = dy[o + 64 * k]; sv[k] = s[o + 64 * k]; }
+            if (gated) {
+#pragma unroll
+                for (int k = 0; k < KT; ++k) yv[k] = y[o + 64 * k];
+            }
+            const bool gout = dsb && gate_out;
+            if (gout) {
+#pragma unroll
+                for (int k = 0; k < KT; ++k) gv[k] = gate_out[o + 64 * k];
+            }
+            float dz[KT], xh[KT];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                float d = dyv[k] * m;
+                if (gated) d = (yv[k] != 0.f) ? d * ik : 0.f;
+                const float x = (sv[k] - mean) * rstd;
+                accg[k] += d * x; accb[k] += d;
+                d *= gm[k];
+                dz[k] = d; xh[k] = x; s1 += d; s2 += d * x;
+            }
+            s1 = wave_sum(s1) / CC; s2 = wave_sum(s2) / CC;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const float g = rstd * (dz[k] - s1 - xh[k] * s2);
+                ds[o + 64 * k] = g;
+                if (dsb) dsb[o + 64 * k] = f2bf(gout ? (gv[k] != 0.f ? g * gate_scale : 0.f) : g);
+            }
+        }
+    } else
     for (long r = r0 + wave; r < r1; r += LN_BWD_WAVES) {
         const float mean = stats[2 * r], rstd = stats[2 * r + 1];
         const float m = rowmask ? rowmask[r] : 1.f;
@@ -495,8 +587,13 @@ extern "C" int glowtts_layernorm_fwd_io(const float* a, const float* b, float* s
                                         const uint32_t* seed_ptr, uint16_t* y_bf16, void* stream)
 {
     if (!a || !gamma || !beta || !y || !stats || rows < 1 || C < 1 || C > 64 * LN_MAXK || (b && !s_out)) return GLOWTTS_E_ARG;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       a, b, s_out, gamma, beta, rowmask, y, stats, (long)rows, C, eps, relu, drop_p, seed, seed_ptr, y_bf16);
+#define LN_FWD_ARGS a, b, s_out, gamma, beta, rowmask, y, stats, (long)rows, C, eps, relu, drop_p, seed, seed_ptr, y_bf16
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (C == 192)      hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, dim3(256), 0, st, LN_FWD_ARGS);
+    else if (C == 256) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, st, LN_FWD_ARGS);
+    else               hipLaunchKernelGGL(ln_fwd_kernel<0>, grid, dim3(256), 0, st, LN_FWD_ARGS);
+#undef LN_FWD_ARGS
     RET_LAUNCH();
 }
 extern "C" int glowtts_layernorm_fwd(const float* a, const float* b, float* s_out, const float* gamma, const float* beta, const float* rowmask,
@@ -517,10 +614,9 @@ extern "C" int glowtts_layernorm_bwd_io(const float* dy, const float* y, const f
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int rpb = LN_BWD_RPB;
     const int nblk = (int)((rows + rpb - 1) / rpb);
-    const int K = (C + 63) / 64;
 #define LN_BWD_ARGS dy, y, s, stats, gamma, rowmask, ds, scratch, (long)rows, C, gated, drop_p, rpb, ds_bf16, gate_out, gate_scale
-    if (K == 3)      hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(nblk), dim3(LN_BWD_WAVES * 64), 2 * LN_BWD_WAVES * C * sizeof(float), st, LN_BWD_ARGS);
-    else if (K == 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nblk), dim3(LN_BWD_WAVES * 64), 2 * LN_BWD_WAVES * C * sizeof(float), st, LN_BWD_ARGS);
+    if (C == 192)      hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(nblk), dim3(LN_BWD_WAVES * 64), 2 * LN_BWD_WAVES * C * sizeof(float), st, LN_BWD_ARGS);
+    else if (C == 256) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nblk), dim3(LN_BWD_WAVES * 64), 2 * LN_BWD_WAVES * C * sizeof(float), st, LN_BWD_ARGS);
     else {
         if (2 * LN_BWD_WAVES * C * sizeof(float) > 64 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GLOWTTS_E_LAUNCH;
@@ -637,17 +733,38 @@ __device__ __forceinline__ float half_sum(float v) {
 }
 __device__ __forceinline__ int acc_row(int reg, int lhi) { return (reg & 3) + 8 * (reg >> 2) + 4 * lhi; }
 
-// rows [0, nrows) x D floats of a [*, ld]-strided global tile -> LDS [128 or 32][LD] (rows >= nrows zero), all 256 threads
+// rows [0, nrows) x D floats of a [*, ld]-strided global tile -> LDS [ROWS][LD] (rows >= nrows zero), NT threads (a workgroup, or one
+// wave with NT = 64).  The loads of a pass are issued TOGETHER, unconditionally (rows past the end re-read row 0 and are zeroed on the way to
+// LDS), and only then written: as a loop of "if (row < nrows) load; store" hipcc waits for every load before the next one is issued - 12
+// dependent L2 / HBM round trips per 128 x 96 operand, which is what the attention kernels spent most of their time on (round 3: forward
+// 36 -> see DESIGN.md section 5).
+constexpr int stage_chunk(int it) { int c = it < 12 ? it : 12; while (it % c) --c; return c; }      // loads in flight per pass: the largest divisor <= 12
 template <int D, int LD, int ROWS, int NT = 256>
 __device__ __forceinline__ void stage_rows(float* dst, const float* src, long ld, int nrows, int tid)
 {
-    constexpr int Q4 = D / 4;
-    for (int i = tid; i < ROWS * Q4; i += NT) {
-        const int r = i / Q4, c = (i - r * Q4) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < nrows) v = *reinterpret_cast<const float4*>(src + (long)r * ld + c);
-        float* o = dst + r * LD + c;
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    constexpr int Q4 = D / 4, N = ROWS * Q4, IT = (N + NT - 1) / NT, CH = stage_chunk(IT);
+    static_assert(IT % CH == 0, "passes of equal size");
+    if (nrows <= 0) {                              // (uniform) nothing to read: e.g. a wave whose 32 rows lie past the utterance
+        for (int i = tid; i < N; i += NT) { const int r = i / Q4, c = (i - r * Q4) * 4; float* o = dst + r * LD + c; o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; }
+        return;
+    }
+#pragma unroll 1
+    for (int p0 = 0; p0 < IT; p0 += CH) {
+        float4 v[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int i = tid + (p0 + u) * NT, r = i / Q4, c = (i - r * Q4) * 4;
+            const bool ok = (N % NT == 0 || i < N) && r < nrows;
+            v[u] = *reinterpret_cast<const float4*>(src + (ok ? (long)r * ld + c : 0L));
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int i = tid + (p0 + u) * NT, r = i / Q4, c = (i - r * Q4) * 4;
+            if (N % NT != 0 && i >= N) continue;
+            const bool ok = r < nrows;
+            float* o = dst + r * LD + c;
+            o[0] = ok ? v[u].x : 0.f; o[1] = ok ? v[u].y : 0.f; o[2] = ok ? v[u].z : 0.f; o[3] = ok ? v[u].w : 0.f;
+        }
     }
 }
 
@@ -673,18 +790,18 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
 
     stage_rows<D, LD, AT_TP>(KV, base + C, ld, Tp, tid);
     stage_rows<D, LD, 32>(RL, relk, D, nw, tid);
-    {   // this wave's 32 query rows -> A fragments (through its own P region)
-        constexpr int Q4 = D / 4;
-        for (int i = lane; i < 32 * Q4; i += 64) {
-            const int r = i / Q4, c = (i - r * Q4) * 4, qi = wave * 32 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (qi < Tp) v = *reinterpret_cast<const float4*>(base + (long)qi * ld + c);
-            float* o = myP + r * LD + c;
-            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-        }
-    }
+    // this wave's 32 query rows -> A fragments (through its own P region)
+    stage_rows<D, LD, 32, 64>(myP, base + (long)wave * 32 * ld, ld, Tp - wave * 32, lane);
     __syncthreads();
     // ---- phase 1: scores ----
+    // (the row / column masks the softmax needs: all loads issued here, ahead of the MFMAs - inside the softmax loop each was a
+    // dependent round trip to L2 per accumulator row)
+    const float* rm = rowmask + (long)b * Tp;
+    float mi_[16], mj[4];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) { const int i = 32 * wave + acc_row(reg, lhi); mi_[reg] = rm[min(i, Tp - 1)]; }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) mj[nt] = rm[min(32 * nt + l31, Tp - 1)];
     f32x16 S[4], R;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { S[0][r] = 0.f; S[1][r] = 0.f; S[2][r] = 0.f; S[3][r] = 0.f; R[r] = 0.f; }
@@ -703,14 +820,12 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
 
     const float isd = rsqrtf((float)D);
     const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    const float* rm = rowmask + (long)b * Tp;
-    float mj[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { const int j = 32 * nt + l31; mj[nt] = j < Tp ? rm[j] : 0.f; }
+    for (int nt = 0; nt < 4; ++nt) mj[nt] = (32 * nt + l31 < Tp) ? mj[nt] : 0.f;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int row = acc_row(reg, lhi), i = 32 * wave + row;
-        const float mi = i < Tp ? rm[i] : 0.f;
+        const float mi = i < Tp ? mi_[reg] : 0.f;
         float sc[4], mx = -3.0e38f;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -804,17 +919,20 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
     // ---- phase 1: dPd, D_i, dS (registers), Pd (LDS) ----
     stage_rows<D, LD, AT_TP>(KV, base + 2 * C, ld, Tp, tid);
     stage_rows<D, LD, 32>(RL, relv, D, nw, tid);
+    stage_rows<D, LD, 32, 64>(myP, dob + (long)wave * 32 * C, C, Tp - wave * 32, lane);
+    __syncthreads();
+    // the forward's probabilities of this wave's 16 x 4 accumulator cells: all loads issued here, ahead of the MFMAs (inside the loop below
+    // every accumulator row waited for its own round trip to L2)
+    float p0r[16][4];
     {
-        constexpr int Q4 = D / 4;
-        for (int i = lane; i < 32 * Q4; i += 64) {
-            const int r = i / Q4, c = (i - r * Q4) * 4, qi = wave * 32 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (qi < Tp) v = *reinterpret_cast<const float4*>(dob + (long)qi * C + c);
-            float* o = myP + r * LD + c;
-            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        const float* Pb = P + ((long)b * H + h) * Tp * Tp;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = 32 * wave + acc_row(reg, lhi);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) { const int j = 32 * nt + l31; p0r[reg][nt] = Pb[(i < Tp && j < Tp) ? (long)i * Tp + j : 0L]; }
         }
     }
-    __syncthreads();
     f32x16 S[4], R;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { S[0][r] = 0.f; S[1][r] = 0.f; S[2][r] = 0.f; S[3][r] = 0.f; R[r] = 0.f; }
@@ -835,14 +953,13 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int row = acc_row(reg, lhi), i = 32 * wave + row;
-        const float* Pg = P + (((long)b * H + h) * Tp + i) * Tp;
         float p0[4], kd[4], dsum = 0.f;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int j = 32 * nt + l31, dd = j - i + win;
             float dpd = S[nt][reg];
             if (dd >= 0 && dd < nw) dpd += myR[row * 33 + dd];
-            p0[nt] = (i < Tp && j < Tp) ? Pg[j] : 0.f;
+            p0[nt] = (i < Tp && j < Tp) ? p0r[reg][nt] : 0.f;
             float keep = 1.f;
             if (drop_p > 0.f) keep = drop_scale(seed, (uint32_t)((((long)b * H + h) * Tp + i) * Tp + j), drop_p, ik);
             kd[nt] = keep * dpd;

@@ -109,7 +109,7 @@ TAIL = {"defer": False, "pending": []}
 #   ActNorm / 1x1 backward pass; wgrad_split: weight gradients in n segments on a second stream (1 = one grouped launch per class);
 #   act_bf16: WaveNet state / gates / gate gradients stored as bf16 in bf16 precision
 #   fused_wn_bwd: its data gradients likewise (csrc/wavenet_fused_bwd.hip; every mode but GR's per-frame pitch), for flows 0 .. n-1 - the flows the backward
-#       reaches LAST.  n: a count, True = all flows, -1 (default) = automatic: all flows when the batch leaves a quarter of the CUs free, else 5 of 12.  Alone the fused kernel is faster than the ten launches it
+#       reaches LAST.  n: a count, True = all flows, -1 (default) = automatic: all flows when the batch leaves a quarter of the CUs free, else 7 of 12 (5 until the encoder's attention backward got shorter).  Alone the fused kernel is faster than the ten launches it
 #       replaces (126 vs 155 us per flow, 151 vs 178 with cold caches: tools/bench_wn.py), but a workgroup that owns a whole CU (150 KB of LDS,
 #       3 x 168 VGPRs per SIMD) for 126 us leaves the encoder stream's backward no CU to share, and while that stream is busy the step LOSES:
 #       all 12 flows 6.33 vs 5.90 ms/step, 9 flows 5.95.  The encoder's backward has drained by the time the decoder's backward is half way:
@@ -344,11 +344,13 @@ class _Prepared:
         elif int(nfb) < 0:
             # automatic: a fused workgroup owns its CU.  A batch whose 52-row windows leave a quarter of the CUs free (B = 16 x 800 frames: 125
             # workgroups) shares the chip with the encoder stream anyway - every flow takes the fused kernel (config 4: 4.28 vs 4.68 ms/step);
-            # a chip-filling one (B = 32: 249) only the last 5 of 12 flows: there the in-graph timeline (bench.py --timeline) shows the two
-            # streams finishing their weight gradients together (4 flows: decoder last by 0.5 ms; 6: encoder last by 0.06 ms)
+            # a chip-filling one (B = 32: 249) only the last 7 of 12 flows: there the in-graph timeline (bench.py --timeline) shows the two
+            # streams finishing their weight gradients together.  (It was 5 of 12 until the encoder's attention kernels stopped waiting for
+            # every load of their operand staging - backward 81 -> 46 us, forward 36 -> 25 us per layer: with the shorter encoder backward
+            # 6 / 7 / 8 / 9 / 10 / 12 fused flows measure 5.61 / 5.54-5.59 / 5.54-5.61 / 5.59-5.73 / 5.88 / 6.08 ms/step against 5.58-5.66 for 5.)
             nwg = -(-rows // (64 - 4 * (Lw - 1))) if rows else None
             cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
-            nfb = F_ if (nwg is not None and 4 * nwg <= 3 * cus) else max(1, (5 * F_) // 12)
+            nfb = F_ if (nwg is not None and 4 * nwg <= 3 * cus) else max(1, (7 * F_) // 12)
         else:
             nfb = min(int(nfb), F_)                             # flows 0 .. nfb-1 take the fused kernel
         f0 = min(max(int(TUNE["fused_wn_bwd_from"]), 0), F_ - nfb)               # (experiments: the fused flows are f0 .. f0 + nfb - 1)
