@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ a
 
 // backward: dz = dy * mask * gate(y) ; ds = rstd (g dz - mean(g dz) - xhat mean(g dz xhat)) ; partial dgamma / dbeta per block
 // gate(y): relu and/or dropout -> (y != 0) * 1/(1-p)   (y is the forward output: zero exactly where relu / dropout / mask cut)
-// KT: compile-time ceil(C / 64) (3 for the 192-channel encoder, 4 for the duration predictor; 0 = generic): the per-lane arrays then have exactly
-// KT entries.  ONE row per wavefront, 16 wavefronts = 16 rows per workgroup: every load of the pass is in flight at once (four waves walking
+// KT: C / 64 for the exact widths 192 (encoder) and 256 (duration predictor), 0 = generic: the per-lane arrays then have exactly KT entries,
+// there are no per-element predicates and every load of a row is issued before the first use.  ONE row per wavefront, 16 wavefronts = 16 rows per workgroup: every load of the pass is in flight at once (four waves walking
 // four rows each in dependent round trips to HBM took 22.6 us for 12 MB, 6 % of HBM bandwidth; now 9) and the second stage still sums only
 // rows / 16 partials per column.
 constexpr int LN_BWD_WAVES = 16;

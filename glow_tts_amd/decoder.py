@@ -123,7 +123,7 @@ TAIL = {"defer": False, "pending": []}
 #   bwd_packs_side / enc_priority: two scheduling experiments of round 3, both off: the backward-only weight images
 #       packed on a third stream joined when the backward starts (5.61 / 5.67 vs 5.68 / 5.66 ms/step: inside the spread); the encoder's
 #       stream at high priority (-1: 9.1 vs 5.6 ms/step - its ~170 short launches then take the CUs from under the chip-filling kernels)
-TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": 0, "bwd_packs_side": 0, "enc_priority": 0}
+TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": 0, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
@@ -292,15 +292,20 @@ class _Prepared:
         _lib.check(L.glowtts_inv1x1_prepare(_lib.ptr(W["inv_w"].contiguous()), _lib.ptr(self.winfo), F_, _lib.stream()), "inv1x1_prepare")
         w_in = W["w_in"].reshape(F_ * Lw, 2 * H, H, cfg.k)
         self.wn_img = None
+        ksplit = 0
         if fused_wn_supported(cfg):
             # one image per flow holding every forward weight of its coupling network as 24-KiB slabs (glowtts_wavenet_pack_images)
             nb = c_i64(0)
             _lib.check(L.glowtts_wavenet_image_bytes(Lw, 0, ctypes.byref(nb)), "wavenet_image_bytes")
             nb = nb.value
             self.wn_img = torch.empty(F_, nb, dtype=torch.uint8, device=dev)
+            # (experiment, TUNE["fwd_packs_split"] = k: only the first k flows' images here, the others on the side stream below - the
+            # decoder's first flow then waits for k flows' worth of packing instead of twelve)
+            ksplit = int(TUNE["fwd_packs_split"]) if (need_bwd and dev.type == "cuda") else 0
+            ksplit = ksplit if 0 < ksplit < F_ else 0
             _lib.check(L.glowtts_wavenet_pack_images(_lib.ptr(W["w_start"].contiguous()), _lib.ptr(W["w_in"].contiguous()),
                                                      _lib.ptr(W["w_rs"].contiguous()) if Lw > 1 else None, _lib.ptr(W["w_rs_last"].contiguous()),
-                                                     _lib.ptr(W["w_end"].contiguous()), F_, Lw, C // 2, _lib.ptr(self.wn_img), None, _lib.stream()),
+                                                     _lib.ptr(W["w_end"].contiguous()), ksplit or F_, Lw, C // 2, _lib.ptr(self.wn_img), None, _lib.stream()),
                        "wavenet_pack_images")
             S = WN_SLAB
             self.pk = {
@@ -357,10 +362,17 @@ class _Prepared:
         # (experiment, TUNE["bwd_packs_side"]: the images only the backward reads are packed on a stream of their own, joined when the backward starts)
         self.bwd_side = None
         main_s = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
-        if need_bwd and TUNE["bwd_packs_side"] and main_s is not None:
+        self.fwd_side_from = None
+        if need_bwd and (TUNE["bwd_packs_side"] or ksplit) and main_s is not None:
             self.bwd_side = _pack_stream(dev)
             self.bwd_side.wait_stream(main_s)
             torch.cuda.set_stream(self.bwd_side)
+            if ksplit:
+                self.fwd_side_from = ksplit
+                _lib.check(L.glowtts_wavenet_pack_images(_lib.ptr(W["w_start"][ksplit:]), _lib.ptr(W["w_in"][ksplit:]),
+                                                         _lib.ptr(W["w_rs"][ksplit:]) if Lw > 1 else None, _lib.ptr(W["w_rs_last"][ksplit:]),
+                                                         _lib.ptr(W["w_end"][ksplit:]), F_ - ksplit, Lw, C // 2, _lib.ptr(self.wn_img[ksplit:]), None,
+                                                         _lib.stream()), "wavenet_pack_images(rest)")
         if need_bwd and self.wn_img is not None and fused_bwd_ok and nfb > 0:
             self.wn_img_t = torch.empty_like(self.wn_img[:nfb])                # (the fused flows only)
             _lib.check(L.glowtts_wavenet_pack_images(_lib.ptr(W["w_start"][f0:]), _lib.ptr(W["w_in"][f0:]),
@@ -520,6 +532,8 @@ def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
         if pitch is not None:
             cr = _cond_rows(cfg, prep, f, prow, pitch[1], pitch[2], T + 2 * ROW_PAD)
             prep.set_cond_rows(f, cr)
+        if getattr(prep, "fwd_side_from", None) == f:
+            torch.cuda.current_stream(mels.device).wait_stream(prep.bwd_side)
         acts = buf.acts(f, cfg.L, rowmask)
         dims = _dims(cfg, B, T, drop_p, seed, f)
         _lib.check(L.glowtts_flow_forward(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(acts), _lib.stream()),

@@ -64,7 +64,9 @@ int glowtts_mas_dp_f32(const float *value, const int32_t *t_xs, const int32_t *t
                        int32_t *idx_out, float *q_out, int B, int Tx, int Ty,
                        float max_neg_val, void *stream);
 /* Same search on the transposed score matrix value_t [B][Ty][Tx] (token index contiguous) - the layout the
- * fused log-prior GEMM writes, where one frame of scores is one coalesced row.  q_out_t likewise transposed. */
+ * fused log-prior GEMM writes, where one frame of scores is one coalesced row.  q_out_t likewise transposed.
+ * 64 < Tx <= 128 with Tx even and value_t 16-byte aligned (the training shapes) takes the hand-scheduled kernel of
+ * csrc/mas_dp2.hip; every other shape the general one of csrc/mas.hip.  Same results bit for bit. */
 int glowtts_mas_dp_f32_t(const float *value_t, const int32_t *t_xs, const int32_t *t_ys,
                          int32_t *idx_out, float *q_out_t, int B, int Tx, int Ty,
                          float max_neg_val, void *stream);
