@@ -116,14 +116,14 @@ TAIL = {"defer": False, "pending": []}
 #       the last 6 flows fused 5.70 vs 5.85 and 5.82 vs 5.92 ms/step on two boxes
 #   fused_wn: the coupling network of a flow (Start .. End + coupling) as ONE launch (csrc/wavenet_fused.hip) where its shape contract holds
 #   fused_wn_fwd_skip: training forward, the first n flows on the per-conv launches (they run beside the text encoder's forward, which the
-#       CU-filling fused workgroups starve).  0 by default; -1 = 1 for a chip-filling batch: the timeline then shows the encoder's and the
-#       decoder's forward ending together (1797 / 1814 us instead of 1763 / 1880; 2 flows: 842 / 1924) and the step gains 0.03 ms (5.65 vs
-#       5.68) - not adopted: mixing the two forward kernels moved 2.4 % of the ragged B = 32 batch's frames to another token against the
-#       fp32 oracle (bar 2 %, all-fused 1-2 %; tests/test_gpu_benchmarked_sizes.py), too close to the bar for 0.5 % of the step
+#       CU-filling fused workgroups starve).  -1 (default) = automatic: 1 for a chip-filling batch, else 0.  The encoder's forward is what the
+#       first half of the step waits for (enc_fwd_project 87 us after dec_fwd_end with every flow fused); one per-conv flow gives it the
+#       CUs it needs: 5.55 / 5.56 vs 5.61 / 5.59 ms/step (2 flows: 5.57 / 5.56), same box, alternating runs.  (Round 3's first measurement,
+#       before the alignment test compared path QUALITY instead of a count of moved frames, had left it off.)
 #   bwd_packs_side / enc_priority: two scheduling experiments of round 3, both off: the backward-only weight images
 #       packed on a third stream joined when the backward starts (5.61 / 5.67 vs 5.68 / 5.66 ms/step: inside the spread); the encoder's
 #       stream at high priority (-1: 9.1 vs 5.6 ms/step - its ~170 short launches then take the CUs from under the chip-filling kernels)
-TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": 0, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0}
+TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
