@@ -123,7 +123,7 @@ TAIL = {"defer": False, "pending": []}
 #   bwd_packs_side / enc_priority: two scheduling experiments of round 3, both off: the backward-only weight images
 #       packed on a third stream joined when the backward starts (5.61 / 5.67 vs 5.68 / 5.66 ms/step: inside the spread); the encoder's
 #       stream at high priority (-1: 9.1 vs 5.6 ms/step - its ~170 short launches then take the CUs from under the chip-filling kernels)
-TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0, "enc_pack_split": 0}
+TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 

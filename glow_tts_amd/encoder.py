@@ -32,27 +32,6 @@ def from_rows(rows_btc):
     return rows_btc[:, ROW_PAD:-ROW_PAD].transpose(1, 2)
 
 
-_ENC_PACK_STREAM = {}
-
-
-def _enc_pack_stream(device):
-    key = str(device)
-    if key not in _ENC_PACK_STREAM:
-        _ENC_PACK_STREAM[key] = torch.cuda.Stream(device=device)
-    return _ENC_PACK_STREAM[key]
-
-
-class _PackPair:
-    """Two ops.PackSet objects behind one get()."""
-
-    def __init__(self, a, b):
-        self.a, self.b = a, b
-
-    def get(self, key):
-        return self.a.get(key) if (key, False) in self.a.packed and (key, True) in self.a.packed else (
-            (self.a.packed[(key, False)], self.b.packed.get((key, True))) if (key, False) in self.a.packed else self.b.get(key))
-
-
 def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training=False, prefix="layer_Dict.Encoder",
                     precision=1, cache=None, on_prior_ready=None):
     """Modules.py:262-284 -> mean [B,mel,T], log_std [B,mel,T], log_durations [B,1,T] (channel-first, like the reference)."""
@@ -108,34 +87,11 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
                  if k.startswith(prefix) and k.endswith(".weight") and v.dim() == 3 and v.shape[0] > 1
                  and not k.endswith((".Query.weight", ".Key.weight", ".Value.weight"))
                  for tr in ((False, True) if torch.is_grad_enabled() else (False,))]
-        from . import decoder as _dec
-        split = bool(_dec.TUNE.get("enc_pack_split", 0)) and tokens.is_cuda and torch.is_grad_enabled()
-        if split:
-            # (experiment) the prenet's forward images on this stream, every other image on a side stream that is joined before the first
-            # transformer layer: the encoder's first conv then waits for ~5 us of packing instead of 35
-            first = [it for it in items if ".Prenet." in it[0] and not it[2]]
-            rest = [it for it in items if not (".Prenet." in it[0] and not it[2])]
-            sets = []
-            for tag, its in (("a", first), ("b", rest)):
-                slot = ("packset", tag, precision, True)
-                ps = cache.get(slot)
-                if ps is None or ps.sig != ops.PackSet.signature(its):
-                    ps = cache[slot] = ops.PackSet(its, precision)
-                sets.append(ps)
-            sets[0].run()
-            cur = torch.cuda.current_stream(dev)
-            pack_side = _enc_pack_stream(dev)
-            pack_side.wait_stream(cur)
-            with torch.cuda.stream(pack_side):
-                sets[1].run()
-            packset = _PackPair(sets[0], sets[1])
-        else:
-            pack_side = None
-            slot = ("packset", precision, torch.is_grad_enabled())
-            packset = cache.get(slot)
-            if packset is None or packset.sig != ops.PackSet.signature(items):
-                packset = cache[slot] = ops.PackSet(items, precision)
-            packset.run()
+        slot = ("packset", precision, torch.is_grad_enabled())
+        packset = cache.get(slot)
+        if packset is None or packset.sig != ops.PackSet.signature(items):
+            packset = cache[slot] = ops.PackSet(items, precision)
+        packset.run()
 
     # bf16 mode: every LayerNorm also writes its rows as bf16 and the convs that read them (and chains of convs) run on bf16-stored
     # operands - the LDS-DMA kernel instead of the register-staged one (fp32 -> bf16 in the loop); see conv_fn.ConvRows
@@ -166,8 +122,6 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
     blocks = bf_rows and C % 64 == 0 and tape is not None and packset is not None
     if blocks and bf16_of(x) is None:
         x = _with_bf16(x, x.detach().to(torch.bfloat16))               # (the prenet's last conv writes fp32 rows)
-    if cache is not None and pack_side is not None:
-        torch.cuda.current_stream(dev).wait_stream(pack_side)
     # Transformer :492-573
     dr = e.Transformer.Dropout_Rate
     H = e.Transformer.Attention.Heads
