@@ -195,6 +195,16 @@ def test_transposed_ties_sentinel_scale_and_full_size():
     want, q_ref = mas_ref.maximum_path_c(v, tx, ty, return_q=True)
     path, _, q, _ = hip_mas_t(v, tx, ty)
     assert np.array_equal(path, want) and np.array_equal(q.view(np.uint32), q_ref.view(np.uint32))
+    # the same on the hand-scheduled kernel's shapes (two rows per lane), with scores large enough that cumulative sums pass the -1e9
+    # sentinel of row -1 and of the diagonal: core.pyx then prefers the sentinel (max(v_cur, max_neg_val)), and so must the kernel
+    for (B, Tx, Ty, scale) in [(5, 100, 340, 1e6), (4, 128, 200, 2e7), (3, 66, 90, 3e7)]:
+        v = (np.round(rng.normal(-3, 2, (B, Tx, Ty))) * scale).astype(np.float32)
+        tx = np.full(B, Tx, np.int32); ty = np.full(B, Ty, np.int32)
+        tx[-1], ty[-1] = Tx - 7, Ty - 31
+        want, q_ref = mas_ref.maximum_path_c(v, tx, ty, return_q=True)
+        path, _, q, kinds = hip_mas_t(v, tx, ty)
+        assert kinds == ["mas_dp2<q>"], kinds
+        assert np.array_equal(path, want) and np.array_equal(q.view(np.uint32), q_ref.view(np.uint32)), (Tx, Ty, scale)
     # BASELINE size, ragged (Set V of SURVEY 8d): B = 32, 120 x 800 and the reference's maximum 200 x 1000
     for (B, Tx, Ty) in [(32, 120, 800), (32, 200, 1000)]:
         v = rng.normal(-100, 30, (B, Tx, Ty)).astype(np.float32)
