@@ -1083,16 +1083,7 @@ __global__ __launch_bounds__(128) void attn_fwd_long_kernel(const float* __restr
     float* myP = PT + wave * 32 * ATL_LDP;
     float* myR = RQ + wave * 32 * 33;
     stage_rows<D, LD, 32, 128>(RL, relk, D, nw, tid);
-    {
-        constexpr int Q4 = D / 4;
-        for (int i = lane; i < 32 * Q4; i += 64) {
-            const int r = i / Q4, c = (i - r * Q4) * 4, qi = q0 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (qi < Tp) v = *reinterpret_cast<const float4*>(base + (long)qi * ld + c);
-            float* o = myP + r * LD + c;
-            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-        }
-    }
+    stage_rows<D, LD, 32, 64>(myP, base + (long)q0 * ld, ld, Tp - q0, lane);          // this wave's 32 query rows
     f32x16 S[8], R;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -1120,13 +1111,17 @@ __global__ __launch_bounds__(128) void attn_fwd_long_kernel(const float* __restr
     const float isd = rsqrtf((float)D);
     const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     const float* rm = rowmask + (long)b * Tp;
-    float mj[8];
+    float mj[8], mi_[16];                          // (all mask loads issued together: see attn_fwd_mfma_kernel)
 #pragma unroll
-    for (int t = 0; t < 8; ++t) { const int j = 32 * t + l31; mj[t] = j < Tp ? rm[j] : 0.f; }
+    for (int t = 0; t < 8; ++t) mj[t] = rm[min(32 * t + l31, Tp - 1)];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) mi_[reg] = rm[min(q0 + acc_row(reg, lhi), Tp - 1)];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) mj[t] = (32 * t + l31 < Tp) ? mj[t] : 0.f;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int row = acc_row(reg, lhi), i = q0 + row;
-        const float mi = i < Tp ? rm[i] : 0.f;
+        const float mi = i < Tp ? mi_[reg] : 0.f;
         float sc[8], mx = -3.0e38f;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -1214,16 +1209,7 @@ __global__ __launch_bounds__(128) void attn_bwd_long_q_kernel(const float* __res
     float* mypart = part + ((((long)b * H + h) * nqb + qb) * 2 + wave) * 2 * nw * D;
     // ---- phase 1: dPd, D_i, dS (registers + global), Pd (LDS) ----
     stage_rows<D, LD, 32, 128>(RL, relv, D, nw, tid);
-    {
-        constexpr int Q4 = D / 4;
-        for (int i = lane; i < 32 * Q4; i += 64) {
-            const int r = i / Q4, c = (i - r * Q4) * 4, qi = q0 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (qi < Tp) v = *reinterpret_cast<const float4*>(dob + (long)qi * C + c);
-            float* o = myP + r * LD + c;
-            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-        }
-    }
+    stage_rows<D, LD, 32, 64>(myP, dob + (long)q0 * C, C, Tp - q0, lane);             // this wave's 32 rows of dO
     f32x16 S[8], R;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -1250,18 +1236,29 @@ __global__ __launch_bounds__(128) void attn_bwd_long_q_kernel(const float* __res
     __syncthreads();
     const float isd = rsqrtf((float)D);
     const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    // the forward's probabilities of an accumulator row: its eight loads issued together, unconditionally, one row AHEAD of their use
+    // (`(i < Tp && j < Tp) ? Pg[j] : 0` in the loop made hipcc wait for each of the 128 loads of a wave before issuing the next)
+    const float* Pb = P + ((long)b * H + h) * Tp * Tp;
+    auto load_p = [&](int reg, float (&dst)[8]) {
+        const int i = q0 + acc_row(reg, lhi);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const int j = 32 * t + l31; dst[t] = Pb[(i < Tp && j < Tp) ? (long)i * Tp + j : 0L]; }
+    };
+    float pnext[8];
+    load_p(0, pnext);
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int row = acc_row(reg, lhi), i = q0 + row;
-        const float* Pg = P + (((long)b * H + h) * Tp + i) * Tp;
         float* dSr = dSg + (((long)b * H + h) * Tp + i) * Tp;
         float p0[8], kd[8], dsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) p0[t] = (i < Tp && 32 * t + l31 < Tp) ? pnext[t] : 0.f;
+        if (reg + 1 < 16) load_p(reg + 1, pnext);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int j = 32 * t + l31, dd = j - i + win;
             float dpd = S[t][reg];
             if (dd >= 0 && dd < nw) dpd += myR[row * 33 + dd];
-            p0[t] = (i < Tp && j < Tp) ? Pg[j] : 0.f;
             float keep = 1.f;
             if (drop_p > 0.f) keep = drop_scale(seed, (uint32_t)((((long)b * H + h) * Tp + i) * Tp + j), drop_p, ik);
             kd[t] = keep * dpd;
