@@ -147,6 +147,8 @@ def pitch_generate(audio, hp):
     the smoothing sigma of Hyper_Parameters.yaml take effect.  Reproduced as is."""
     s = hp.Sound
     pitch = yin_pitch(audio, s.Sample_Rate, harmo_thresh=1.0 - float(s.Confidence_Threshold))
+    if pitch.size == 0:                                   # a clip shorter than one analysis window after trimming: no frames, no track
+        return np.zeros(0, dtype=np.float32)
     if float(s.Gaussian_Smoothing_Sigma) > 0.0:
         from scipy.ndimage import gaussian_filter1d
         pitch = gaussian_filter1d(pitch, sigma=float(s.Gaussian_Smoothing_Sigma))

@@ -159,7 +159,8 @@ class ConvRows(torch.autograd.Function):
         else:
             a = xb.contiguous() if (xb is not None and precision == ops.BF16 and Ci2 % 32 == 0 and Ci2 == Cin and (k > 1 or Ci2 % 64 == 0)) else None
             assert a is None or a.shape == x.shape
-        assert not out_bf16 or (a is not None and residual is None)
+        # (bf16 output comes from the bf16-operand kernels only: a shape they do not serve - e.g. 96 or 160 channels with k = 1 - keeps fp32 rows)
+        out_bf16 = bool(out_bf16 and (a is not None) and residual is None)
         pw = packs[0] if packs is not None else ops.pack_weight(w.detach(), precision=precision)
         out = torch.empty(R, O, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
         flags = (ops.F_BIAS if b is not None else 0) | (ops.F_RELU if relu else 0) | (ops.F_MASK if mask_out else 0) | \

@@ -132,6 +132,8 @@ def stamp(name):
     if STAMPS["buf"] is None:
         return
     i = len(STAMPS["names"])
+    if i >= STAMPS["buf"].numel():                       # (an armed eager run of many steps: the buffer is full, stop stamping)
+        return
     STAMPS["names"].append(name)
     _L().glowtts_debug_stamp.argtypes = [c_void_p, c_void_p]
     _lib.check(_L().glowtts_debug_stamp(STAMPS["buf"].data_ptr() + 8 * i, _lib.stream()), "glowtts_debug_stamp")
@@ -340,6 +342,9 @@ class _Prepared:
             pk_conv = dict(self.pk)
             if Lw > 1:
                 pk_conv["rs"] = PackedBatch(W["w_rs"][:nskip].reshape(nskip * (Lw - 1), 2 * H, H, 1), False, ops.PERM_NONE, 0, P)
+        # (the per-flow structs below hold raw pointers into this image: it lives as long as they do - ADVICE r3: as a local it went back to
+        # the caching allocator / the graph pool at the end of __init__ while flow 0's launches still read it)
+        self.pk_conv = pk_conv
         # backward: the transposed image of the fused data-gradient kernel (glowtts_wavenet_bwd) where it applies - no conditioning gradient -
         # else the per-conv transposed images
         self.wn_img_t = None
