@@ -1584,6 +1584,7 @@ int pack_batched(const float* w, int batch, int O, int I, int taps, int transpos
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long total = (long)taps * kchunks * npad * KC;
     const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+    GLOWTTS_NOTE_STATIC("pack_weight");
     if (precision == GLOWTTS_BF16)
         hipLaunchKernelGGL(pack_weight_kernel<__bf16>, dim3(blocks, batch), dim3(256), 0, s, w, static_cast<__bf16*>(packed), O, I, taps, transpose, perm, perm_h, N, kchunks * KC, npad, kchunks,
                            inner, outer_stride, inner_stride, w_stride);

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/glowtts_hip.h"
+#include "launch_log.h"
 
 namespace {
 
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __rest
 extern "C" int glowtts_weightnorm_fwd(const float* v, const float* g, float* w, float* inv_norm, int64_t rows, int cols, void* stream)
 {
     if (!v || !g || !w || !inv_norm || rows < 1 || cols < 1) return GLOWTTS_E_ARG;
+    GLOWTTS_NOTE_STATIC("weightnorm_fwd");
     hipLaunchKernelGGL(weightnorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), v, g, w, inv_norm, (long)rows, cols);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }

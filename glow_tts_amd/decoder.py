@@ -84,6 +84,9 @@ def _L():
         L.glowtts_decoder_param_grads.argtypes = [c_void_p] * 7 + [c_int] * 4 + [c_void_p]
         L.glowtts_wavenet_image_bytes.argtypes = [c_int, c_int, ctypes.POINTER(c_i64)]
         L.glowtts_wavenet_pack_images.argtypes = [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 3
+        L.glowtts_prep_job_init.argtypes = [c_void_p] * 4 + [c_int] * 8 + [c_void_p] + [c_i64] * 4 + [c_int, ctypes.POINTER(c_int)]
+        L.glowtts_prep_launch.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
+        L.glowtts_wavenet_prep_jobs.argtypes = [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)] + [c_void_p] * 13 + [c_int] * 3 + [c_void_p, c_int, c_void_p]
         _declared = True
     return L
 
@@ -94,6 +97,41 @@ class WgradJob(ctypes.Structure):
                 ("lddy", c_i64), ("ldx", c_i64),
                 ("m", c_int), ("ca", c_int), ("xpro", c_int), ("perm", c_int), ("perm_h", c_int),
                 ("tile0", c_int), ("mt", c_int), ("nt", c_int), ("reserved", c_i64)]
+
+
+class PrepJob(ctypes.Structure):
+    """Mirror of `glowtts_prep_job` (weight norm + packing of one conv class into one image, csrc/prep_ops.hip)."""
+    _fields_ = [("v", c_void_p), ("g", c_void_p), ("inv_out", c_void_p), ("packed", c_void_p),
+                ("outer_stride", c_i64), ("inner_stride", c_i64), ("w_stride", c_i64), ("g_stride", c_i64),
+                ("batch", c_int), ("inner", c_int), ("O", c_int), ("I", c_int), ("taps", c_int), ("transpose", c_int), ("perm", c_int), ("perm_h", c_int),
+                ("o_ext", c_int), ("npad", c_int), ("kchunks", c_int), ("tiles", c_int), ("block0", c_int), ("reserved", c_int)]
+
+
+class PrepJobs:
+    """Collects the weight-preparation jobs of a training step (every image of the decoder's convs, straight from the weight-norm pairs) and
+    issues them as ONE launch (glowtts_prep_launch)."""
+    CAP = 24                             # GLOWTTS_PREP_MAX_JOBS
+
+    def __init__(self):
+        self.jobs = (PrepJob * self.CAP)()
+        self.n, self.blocks, self.max_cols = c_int(0), c_int(0), 1
+        self.keep = []                       # tensors the jobs point into
+
+    def add(self, v, g, inv, batch, inner, O, I, taps, transpose, perm, perm_h, packed_ptr, outer_stride, inner_stride=0, w_stride=0, g_stride=0):
+        if self.n.value >= self.CAP:
+            raise _lib.GlowTTSHipError("too many weight-preparation jobs")
+        nb = c_int(0)
+        _lib.check(_L().glowtts_prep_job_init(ctypes.byref(self.jobs[self.n.value]), v, g, inv, batch, inner, O, I, taps, int(transpose), perm, perm_h,
+                                              packed_ptr, outer_stride, inner_stride, w_stride, g_stride, self.blocks.value, ctypes.byref(nb)), "prep_job_init")
+        self.n.value += 1
+        self.blocks.value += nb.value
+        self.max_cols = max(self.max_cols, I * taps)
+
+    def launch(self, device):
+        if self.n.value == 0:
+            return
+        # (the table is a HOST array: it travels in the launch's argument segment - no copy node in a captured step)
+        _lib.check(_L().glowtts_prep_launch(ctypes.cast(self.jobs, c_void_p), self.n.value, self.blocks.value, self.max_cols, _lib.stream()), "glowtts_prep_launch")
 
 
 _WSTREAM = {}
@@ -123,7 +161,9 @@ TAIL = {"defer": False, "pending": []}
 #   bwd_packs_side / enc_priority: two scheduling experiments of round 3, both off: the backward-only weight images
 #       packed on a third stream joined when the backward starts (5.61 / 5.67 vs 5.68 / 5.66 ms/step: inside the spread); the encoder's
 #       stream at high priority (-1: 9.1 vs 5.6 ms/step - its ~170 short launches then take the CUs from under the chip-filling kernels)
-TUNE = {"wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0}
+#   prep_fused: training on the fused bf16 path forms w = g v / ||v|| and every weight image in ONE launch (csrc/prep_ops.hip) instead of 4 weight-norm +
+#       ~22 packing launches (0.42 -> ~0.1 ms at the head of the step, round 4)
+TUNE = {"prep_fused": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
@@ -228,7 +268,9 @@ class WgradGroup:
 class PackedBatch:
     """`batch` same-shape conv weights packed by one launch; element i is the i-th weight."""
 
-    def __init__(self, w, transpose, perm, perm_h, precision):
+    def __init__(self, w, transpose, perm, perm_h, precision, g=None, jobs=None):
+        """jobs (a PrepJobs) given: `w` is weight_v (g: weight_g [batch, O, 1, 1], or None for a plain weight) and the image is produced by the
+        step's one weight-preparation launch instead of a launch of its own."""
         L = _L()
         w = w.contiguous()
         self.batch, O, I, taps = w.shape
@@ -238,6 +280,12 @@ class PackedBatch:
         self.npad, self.kchunks = npad.value, kch.value
         self.stride = taps * self.kchunks * self.npad * 64
         self.data = torch.empty(self.batch * self.stride, dtype=torch.uint8, device=w.device)
+        if jobs is not None:
+            assert precision == ops.BF16
+            jobs.add(w.data_ptr(), g.data_ptr() if g is not None else None, None, self.batch, 1, O, I, taps, transpose, perm, perm_h,
+                     self.data.data_ptr(), self.stride)
+            jobs.keep += [w, g, self.data]
+            return
         _lib.check(L.glowtts_pack_weight_batched(_lib.ptr(w), *args, _lib.ptr(self.data), None, None, _lib.stream()), "pack")
 
     def at(self, i):
@@ -277,22 +325,65 @@ class DecoderConfig:
 
 WEIGHT_KEYS = ("an_logs", "an_bias", "inv_w", "w_start", "b_start", "w_in", "b_in", "w_rs", "b_rs",
                "w_rs_last", "b_rs_last", "w_end", "b_end")
+# DecoderFunction's other calling form (training on the fused bf16 path): the four weight-normalised convs arrive as their (weight_g, weight_v)
+# stacks and the function forms w = g v / ||v|| inside its one weight-preparation launch (and applies the weight-norm backward itself)
+WN_KEYS = ("w_start", "w_in", "w_rs", "w_rs_last")
+WEIGHT_KEYS_GV = ("an_logs", "an_bias", "inv_w", "g_start", "v_start", "b_start", "g_in", "v_in", "b_in", "g_rs", "v_rs", "b_rs",
+                  "g_rs_last", "v_rs_last", "b_rs_last", "w_end", "b_end")
 
 
 class _Prepared:
     """Packed weight images + per-flow parameter structs for one set of stacked weights."""
 
-    def __init__(self, cfg, W, need_bwd, cond=None, fused_bwd_ok=True, rows=None):
+    def __init__(self, cfg, W, need_bwd, cond=None, fused_bwd_ok=True, rows=None, GV=None):
         """fused_bwd_ok = False: the backward needs what only the per-conv kernels produce (GR mode: the per-row pitch conditioning and the
-        Pitch_l weight gradient).  rows: B * (T + 4) of the batch this is prepared for (sizes the automatic choice of TUNE["fused_wn_bwd"])."""
+        Pitch_l weight gradient).  rows: B * (T + 4) of the batch this is prepared for (sizes the automatic choice of TUNE["fused_wn_bwd"]).
+        GV (training, bf16, fused coupling network): {"w_start" | "w_in" | "w_rs" | "w_rs_last": (weight_g, weight_v)} stacked like W's entries, which
+        are then absent from W - every image is produced from the weight-norm pairs by ONE launch (csrc/prep_ops.hip; `self.inv` keeps 1 / ||v||
+        per class for the weight-norm backward) instead of 4 weight-norm + ~22 packing launches at the head of every step."""
         L = _L()
         F_, H, C, Lw = cfg.F, cfg.H, cfg.C, cfg.L
         P = cfg.precision
-        dev = W["w_in"].device
+        dev = W["an_logs"].device
         self.keep = W
         self.winfo = torch.empty(F_, 36, device=dev)
         _lib.check(L.glowtts_inv1x1_prepare(_lib.ptr(W["inv_w"].contiguous()), _lib.ptr(self.winfo), F_, _lib.stream()), "inv1x1_prepare")
-        w_in = W["w_in"].reshape(F_ * Lw, 2 * H, H, cfg.k)
+        jobs = PrepJobs() if GV is not None else None
+        self.inv = None
+        if GV is not None:
+            assert fused_wn_supported(cfg) and P == ops.BF16, "weight preparation from (g, v) serves the fused bf16 path"
+            self.inv = {"w_start": torch.empty(F_, H, device=dev), "w_in": torch.empty(F_, Lw, 2 * H, device=dev),
+                        "w_rs": torch.empty(F_, max(Lw - 1, 1), 2 * H, device=dev), "w_rs_last": torch.empty(F_, H, device=dev)}
+
+        def src(key, sl=slice(None)):
+            """(weight or weight_v, weight_g or None) of class `key`, flows `sl`"""
+            if GV is not None and key in GV:
+                return GV[key][1][sl], GV[key][0][sl]
+            return W[key][sl], None
+
+        def batch(key, sl, shape, transpose, perm, perm_h):
+            w, g = src(key, sl)
+            return PackedBatch(w.reshape(shape), transpose, perm, perm_h, P, g=g, jobs=jobs)
+
+        def images(sl, nflows, img_fwd, nbwd, img_bwd, with_inv):
+            """the fused kernels' weight images of flows `sl` (forward: nflows of them; transposed: the first nbwd)"""
+            if GV is None:
+                _lib.check(L.glowtts_wavenet_pack_images(_lib.ptr(W["w_start"][sl]), _lib.ptr(W["w_in"][sl]), _lib.ptr(W["w_rs"][sl]) if Lw > 1 else None,
+                                                         _lib.ptr(W["w_rs_last"][sl]), _lib.ptr(W["w_end"][sl]), nflows if img_fwd is not None else nbwd, Lw, C // 2,
+                                                         _lib.ptr(img_fwd), _lib.ptr(img_bwd), _lib.stream()), "wavenet_pack_images")
+                return
+            a = []
+            for key in ("w_start", "w_in", "w_rs", "w_rs_last"):
+                g, v = GV[key]
+                inv = self.inv[key] if with_inv else None
+                if key == "w_rs" and Lw == 1:
+                    a += [None, None, None]
+                else:
+                    a += [v[sl].data_ptr(), g[sl].data_ptr(), inv[sl].data_ptr() if inv is not None else None]
+            _lib.check(L.glowtts_wavenet_prep_jobs(ctypes.cast(jobs.jobs, c_void_p), PrepJobs.CAP, ctypes.byref(jobs.n), ctypes.byref(jobs.blocks), *a,
+                                                   W["w_end"][sl].data_ptr(), nflows, Lw, C // 2, _lib.ptr(img_fwd), nbwd, _lib.ptr(img_bwd)), "wavenet_prep_jobs")
+            jobs.max_cols = max(jobs.max_cols, H * cfg.k)
+
         self.wn_img = None
         ksplit = 0
         if fused_wn_supported(cfg):
@@ -303,12 +394,9 @@ class _Prepared:
             self.wn_img = torch.empty(F_, nb, dtype=torch.uint8, device=dev)
             # (experiment, TUNE["fwd_packs_split"] = k: only the first k flows' images here, the others on the side stream below - the
             # decoder's first flow then waits for k flows' worth of packing instead of twelve)
-            ksplit = int(TUNE["fwd_packs_split"]) if (need_bwd and dev.type == "cuda") else 0
+            ksplit = int(TUNE["fwd_packs_split"]) if (need_bwd and dev.type == "cuda" and GV is None) else 0
             ksplit = ksplit if 0 < ksplit < F_ else 0
-            _lib.check(L.glowtts_wavenet_pack_images(_lib.ptr(W["w_start"].contiguous()), _lib.ptr(W["w_in"].contiguous()),
-                                                     _lib.ptr(W["w_rs"].contiguous()) if Lw > 1 else None, _lib.ptr(W["w_rs_last"].contiguous()),
-                                                     _lib.ptr(W["w_end"].contiguous()), ksplit or F_, Lw, C // 2, _lib.ptr(self.wn_img), None, _lib.stream()),
-                       "wavenet_pack_images")
+            images(slice(None), ksplit or F_, self.wn_img, 0, None, True)
             S = WN_SLAB
             self.pk = {
                 "start": ImageSlices(self.wn_img, nb, 0, 1, 0, 192, 3),
@@ -327,21 +415,22 @@ class _Prepared:
             nskip = 1 if 4 * nwg_ > 3 * cus_ else 0
         nskip = min(nskip, F_) if (need_bwd and self.wn_img is not None) else 0
         pk_conv = None
+        all_f = slice(None)
         if self.wn_img is None:
             self.pk = {
-                "start": PackedBatch(W["w_start"], False, ops.PERM_NONE, 0, P),
-                "in": PackedBatch(w_in, False, ops.PERM_PAIR, H, P),
-                "rs_last": PackedBatch(W["w_rs_last"], False, ops.PERM_NONE, 0, P),
-                "end": PackedBatch(W["w_end"], False, ops.PERM_PAIR, C // 2, P),
+                "start": batch("w_start", all_f, (F_, H, C // 2, 1), False, ops.PERM_NONE, 0),
+                "in": batch("w_in", all_f, (F_ * Lw, 2 * H, H, cfg.k), False, ops.PERM_PAIR, H),
+                "rs_last": batch("w_rs_last", all_f, (F_, H, H, 1), False, ops.PERM_NONE, 0),
+                "end": batch("w_end", all_f, (F_, C, H, 1), False, ops.PERM_PAIR, C // 2),
             }
             if Lw > 1:
-                self.pk["rs"] = PackedBatch(W["w_rs"].reshape(F_ * (Lw - 1), 2 * H, H, 1), False, ops.PERM_NONE, 0, P)
+                self.pk["rs"] = batch("w_rs", all_f, (F_ * (Lw - 1), 2 * H, H, 1), False, ops.PERM_NONE, 0)
         elif nskip > 0:
             # the per-conv kernels read the Start / In_l / last Res_Skip / End slabs of the fused image as they are; only Res_Skip_l (l < L - 1)
             # is PAIR-packed there (residual | skip per 32 channels) and is packed once more in the per-conv order for the skipped flows
             pk_conv = dict(self.pk)
             if Lw > 1:
-                pk_conv["rs"] = PackedBatch(W["w_rs"][:nskip].reshape(nskip * (Lw - 1), 2 * H, H, 1), False, ops.PERM_NONE, 0, P)
+                pk_conv["rs"] = batch("w_rs", slice(0, nskip), (nskip * (Lw - 1), 2 * H, H, 1), False, ops.PERM_NONE, 0)
         # (the per-flow structs below hold raw pointers into this image: it lives as long as they do - ADVICE r3: as a local it went back to
         # the caching allocator / the graph pool at the end of __init__ while flow 0's launches still read it)
         self.pk_conv = pk_conv
@@ -368,39 +457,37 @@ class _Prepared:
         self.bwd_side = None
         main_s = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
         self.fwd_side_from = None
-        if need_bwd and (TUNE["bwd_packs_side"] or ksplit) and main_s is not None:
+        if need_bwd and GV is None and (TUNE["bwd_packs_side"] or ksplit) and main_s is not None:
             self.bwd_side = _pack_stream(dev)
             self.bwd_side.wait_stream(main_s)
             torch.cuda.set_stream(self.bwd_side)
             if ksplit:
                 self.fwd_side_from = ksplit
-                _lib.check(L.glowtts_wavenet_pack_images(_lib.ptr(W["w_start"][ksplit:]), _lib.ptr(W["w_in"][ksplit:]),
-                                                         _lib.ptr(W["w_rs"][ksplit:]) if Lw > 1 else None, _lib.ptr(W["w_rs_last"][ksplit:]),
-                                                         _lib.ptr(W["w_end"][ksplit:]), F_ - ksplit, Lw, C // 2, _lib.ptr(self.wn_img[ksplit:]), None,
-                                                         _lib.stream()), "wavenet_pack_images(rest)")
+                images(slice(ksplit, None), F_ - ksplit, self.wn_img[ksplit:], 0, None, False)
         if need_bwd and self.wn_img is not None and fused_bwd_ok and nfb > 0:
             self.wn_img_t = torch.empty_like(self.wn_img[:nfb])                # (the fused flows only)
-            _lib.check(L.glowtts_wavenet_pack_images(_lib.ptr(W["w_start"][f0:]), _lib.ptr(W["w_in"][f0:]),
-                                                     _lib.ptr(W["w_rs"][f0:]) if Lw > 1 else None, _lib.ptr(W["w_rs_last"][f0:]),
-                                                     _lib.ptr(W["w_end"][f0:]), nfb, Lw, C // 2, None, _lib.ptr(self.wn_img_t), _lib.stream()),
-                       "wavenet_pack_images(bwd)")
+            images(slice(f0, None), nfb, None, nfb, self.wn_img_t, False)
         else:
             nfb = 0
         c0 = nfb if f0 == 0 else 0                                             # per-conv transposed images: flows c0 .. F-1 (element i = flow c0 + i)
         if need_bwd and c0 < F_:
+            rest, nr = slice(c0, None), F_ - c0
             self.pk.update({
-                "start_t": PackedBatch(W["w_start"][c0:], True, ops.PERM_NONE, 0, P),
-                "in_t": PackedBatch(w_in[c0 * Lw:], True, ops.PERM_PAIR, H, P),
-                "rs_last_t": PackedBatch(W["w_rs_last"][c0:], True, ops.PERM_NONE, 0, P),
-                "end_t": PackedBatch(W["w_end"][c0:], True, ops.PERM_PAIR, C // 2, P),
+                "start_t": batch("w_start", rest, (nr, H, C // 2, 1), True, ops.PERM_NONE, 0),
+                "in_t": batch("w_in", rest, (nr * Lw, 2 * H, H, cfg.k), True, ops.PERM_PAIR, H),
+                "rs_last_t": batch("w_rs_last", rest, (nr, H, H, 1), True, ops.PERM_NONE, 0),
+                "end_t": batch("w_end", rest, (nr, C, H, 1), True, ops.PERM_PAIR, C // 2),
             })
             if Lw > 1:
-                self.pk["rs_t"] = PackedBatch(W["w_rs"][c0:].reshape((F_ - c0) * (Lw - 1), 2 * H, H, 1), True, ops.PERM_NONE, 0, P)
+                self.pk["rs_t"] = batch("w_rs", rest, (nr * (Lw - 1), 2 * H, H, 1), True, ops.PERM_NONE, 0)
         if self.bwd_side is not None:
             torch.cuda.set_stream(main_s)
             for t in [self.wn_img_t] + [self.pk[k].data for k in ("start_t", "in_t", "rs_last_t", "end_t", "rs_t") if k in self.pk]:
                 if t is not None:
                     t.record_stream(main_s)
+        if jobs is not None:
+            jobs.launch(dev)
+            self.prep_jobs = jobs                                              # (keeps the job table and the tensors it points into)
         self.ldo = self.pk["end"].npad
         self.ldin = self.pk["in"].npad
         self.cond, self._H, self._Lw = cond, H, Lw
@@ -645,12 +732,19 @@ class DecoderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, mels, lengths, cond, drop_p, pitches, pitch_w, pitch_b, *weights):
         """pitches [B, Tm] / pitch_w [F, L, 2H, ns] / pitch_b [F, L, 2H]: the GR-mode per-frame pitch conditioning (Modules.py:867-869), else None."""
-        W = dict(zip(WEIGHT_KEYS, [w.detach().contiguous() for w in weights]))
+        GV = None
+        if len(weights) == len(WEIGHT_KEYS_GV):
+            A = dict(zip(WEIGHT_KEYS_GV, [w.detach().contiguous() for w in weights]))
+            GV = {k: (A.pop("g" + k[1:]), A.pop("v" + k[1:])) for k in WN_KEYS}
+            W = A
+        else:
+            W = dict(zip(WEIGHT_KEYS, [w.detach().contiguous() for w in weights]))
         need_bwd = any(w.requires_grad for w in weights) or mels.requires_grad or (cond is not None and cond.requires_grad) or \
             (pitch_w is not None and pitch_w.requires_grad)
         condc = cond.detach().contiguous() if cond is not None else None
         prep = _Prepared(cfg, W, need_bwd=need_bwd, cond=condc, fused_bwd_ok=pitches is None,
-                         rows=mels.shape[0] * (mels.shape[2] // cfg.ns + 2 * ROW_PAD))
+                         rows=mels.shape[0] * (mels.shape[2] // cfg.ns + 2 * ROW_PAD), GV=GV)
+        ctx.GV = GV
         # one random word on the device (torch's graph-safe generator); kept for the backward, which regenerates the masks
         seed = torch.randint(0, 2 ** 31 - 1, (1,), device=mels.device, dtype=torch.int32) if drop_p > 0 else None
         pitch = (pitches.detach(), pitch_w.detach().contiguous(), pitch_b.detach().contiguous()) if pitches is not None else None
@@ -682,7 +776,9 @@ class DecoderFunction(torch.autograd.Function):
         dx, _, _ = squeeze_rows(cfg, dz.contiguous(), ctx.lengths, want_mask=False)
         R = dx.shape[0]
         dld = dlogdet.contiguous() if dlogdet is not None else torch.zeros(B, device=dev)
-        G = {k: torch.empty_like(W[k]) for k in WEIGHT_KEYS}      # every entry is fully written below (weight-gradient launches store, not accumulate)
+        GV = ctx.GV
+        # every entry is fully written below (weight-gradient launches store, not accumulate)
+        G = {k: torch.empty_like(GV[k][1] if (GV is not None and k in GV) else W[k]) for k in WEIGHT_KEYS}
         d_an = torch.empty(F_, 2 * C + 16, device=dev)
         # every flow / layer keeps its own gradient buffers: the weight gradients of ALL flows are computed afterwards by
         # two grouped launches (k-tap problems, 1x1 problems) whose tiles fill the chip without split-K or atomics
@@ -783,6 +879,26 @@ class DecoderFunction(torch.autograd.Function):
         else:
             for grp in (gk, gp, g1):
                 grp.launch_segment(0)
+        # weight-norm backward of the (g, v) form (Modules.py:766, 818, 825): d g, d v from d w; the classes whose d w comes from the deferrable
+        # 1x1 groups are queued behind them
+        GVgrad = {}
+        if GV is not None:
+            for k in WN_KEYS:
+                g_, v_ = GV[k]
+                if v_.numel() == 0:
+                    GVgrad[k] = (torch.zeros_like(g_), torch.zeros_like(v_))
+                    continue
+                cols = v_.shape[-1] * v_.shape[-2]
+                rows_ = v_.numel() // cols
+                dv, dg = torch.empty_like(v_), torch.empty_like(g_)
+                GVgrad[k] = (dg, dv)
+                run = lambda k=k, g_=g_, v_=v_, dv=dv, dg=dg, rows_=rows_, cols=cols, inv=prep.inv[k], dw=G[k]: _lib.check(
+                    L.glowtts_weightnorm_bwd(dw.data_ptr(), v_.data_ptr(), g_.data_ptr(), inv.data_ptr(), dv.data_ptr(), dg.data_ptr(), rows_, cols, _lib.stream()),
+                    "glowtts_weightnorm_bwd")
+                if TAIL["defer"] and halves == 1 and k != "w_in":
+                    TAIL["pending"].append(run)
+                else:
+                    run()
         stamp("dec_wgrads_done")
         _lib.check(L.glowtts_colsum_batched(scratch.data_ptr(), d_an.data_ptr(), L.glowtts_actnorm_bwd_blocks(R), 2 * C + 16, F_, nscr, 2 * C + 16, _lib.stream()),
                    "glowtts_colsum_batched")
@@ -799,6 +915,15 @@ class DecoderFunction(torch.autograd.Function):
             dpb = dcond[:B].sum(0).view(F_, Lw, 2 * H)
             dpw = dcond[B:].view(npit, F_, Lw, 2 * H).permute(1, 2, 3, 0).contiguous()
             dcond = dcond[:B]
+        if GV is not None:
+            out = []
+            for k in WEIGHT_KEYS_GV:
+                wk = "w" + k[1:]
+                if k[0] in "gv" and wk in GVgrad:
+                    out.append(GVgrad[wk][0 if k[0] == "g" else 1])
+                else:
+                    out.append(G[k].view_as(W[k]))
+            return (None, dmel, None, dcond, None, None, dpw, dpb) + tuple(out)
         return (None, dmel, None, dcond, None, None, dpw, dpb) + tuple(G[k].view_as(W[k]) for k in WEIGHT_KEYS)
 
 
@@ -946,11 +1071,20 @@ class DecoderStacks:
         """Parameters whose gradients are produced by the deferrable tail of the backward (see TAIL)."""
         return [p for k in TAIL_STACKS if k in self.S for p in self.S[k].leaves]
 
-    def weights(self):
-        """The stacked effective weights in WEIGHT_KEYS order (differentiable w.r.t. the leaves)."""
+    def weights(self, gv=False):
+        """The stacked effective weights in WEIGHT_KEYS order (differentiable w.r.t. the leaves); gv = True: WEIGHT_KEYS_GV order - the
+        weight-normalised convs as their (weight_g, weight_v) stacks, for DecoderFunction's one-launch weight preparation."""
         S, cfg = self.S, self.cfg
         F_, L = cfg.F, cfg.L
         t = lambda k: S[k].tensor()
+        if gv:
+            if L > 1:
+                rs = (t("rs_g"), t("rs_v"), t("rs_b"))
+            else:
+                dev = S["in_v"].leaves[0].device
+                rs = (torch.zeros(F_, 0, 2 * cfg.H, 1, 1, device=dev), torch.zeros(F_, 0, 2 * cfg.H, cfg.H, 1, device=dev), torch.zeros(F_, 0, 2 * cfg.H, device=dev))
+            return (t("an_logs").view(F_, -1), t("an_bias").view(F_, -1), t("inv_w"), t("start_g"), t("start_v"), t("start_b"),
+                    t("in_g"), t("in_v"), t("in_b")) + rs + (t("rsl_g"), t("rsl_v"), t("rsl_b"), t("end_w"), t("end_b"))
         wn = lambda tag: WeightNorm.apply(t(tag + "_g"), t(tag + "_v"), (tag + "_v") in TAIL_STACKS)
         if L > 1:
             w_rs, b_rs = wn("rs"), t("rs_b")

@@ -20,9 +20,9 @@ extern "C" {
 #define GLOWTTS_OK            0
 #define GLOWTTS_E_ARG        -1   /* bad argument / unsupported size */
 #define GLOWTTS_E_LAUNCH     -2   /* hip launch error */
-#define GLOWTTS_ABI_VERSION    2
+#define GLOWTTS_ABI_VERSION    3
 
-/* Library / device identification.  Returns the ABI version (currently 2: glowtts_flow_params grew wn_img / wn_img_t; round 2's additions to
+/* Library / device identification.  Returns the ABI version (currently 3: round 4 added glowtts_prep_job / glowtts_prep_launch / glowtts_wavenet_prep_jobs; 2: glowtts_flow_params grew wn_img / wn_img_t; round 2's additions to
  * glowtts_mle_loss_bwd, glowtts_flow_params.cond_rows and glowtts_flow_grads.pitch_rows belong to version 2 as well). */
 int glowtts_abi_version(void);
 /* Writes the gfx arch string of device 0 into buf (host pointer).  0 on success. */
@@ -140,6 +140,28 @@ int glowtts_pack_weight_batched(const float *w, int batch, int O, int I, int tap
  * w_stride: elements between consecutive source weights (0 = O * I * taps; larger: each weight is the leading [O] slice of a bigger tensor). */
 int glowtts_pack_weight_strided(const float *w, int batch, int inner, int O, int I, int taps, int transpose, int perm, int perm_h,
                                 int precision, void *packed, int64_t outer_stride, int64_t inner_stride, int64_t w_stride, void *stream);
+
+/* Weight preparation of a training step in ONE launch (round 4; replaces glowtts_weightnorm_fwd + the glowtts_pack_weight_* launches of the decoder:
+ * Modules.py:766, 818, 825 weight_norm + the tile images of every conv).  A job = one glowtts_pack_weight_strided call whose source is the
+ * weight-norm pair (v [batch][O][I][taps], g [batch][O]) instead of w: w = g * v / ||v|| (norm over (I, taps) per output channel, old-style
+ * torch weight_norm) is formed on the fly in fp32, rounded to bf16 exactly as the two-step path rounds it, and never written.  g == NULL: v is a
+ * plain weight.  inv_out (optional) [batch][O] receives 1 / ||v|| for glowtts_weightnorm_bwd.  g_stride: elements between consecutive convs'
+ * g / inv_out rows (0 = O; larger when a job covers the leading [O] slice of a bigger conv).  bf16 images only.  I * taps <= 1024.
+ * Jobs are a HOST array (fill with glowtts_prep_job_init, block0 = running sum of *blocks_out; at most GLOWTTS_PREP_MAX_JOBS per launch): the launch
+ * carries the table in its argument segment, so a captured step needs no copy node for it. */
+#define GLOWTTS_PREP_MAX_JOBS 24
+typedef struct glowtts_prep_job {
+    const float *v; const float *g; float *inv_out; void *packed;
+    int64_t outer_stride, inner_stride, w_stride, g_stride;
+    int batch, inner, O, I, taps, transpose, perm, perm_h;
+    int o_ext, npad, kchunks, tiles;       /* derived (glowtts_prep_job_init) */
+    int block0, reserved;
+} glowtts_prep_job;
+int glowtts_prep_job_init(glowtts_prep_job *job /* host */, const float *v, const float *g, float *inv_out, int batch, int inner, int O, int I, int taps,
+                          int transpose, int perm, int perm_h, void *packed, int64_t outer_stride, int64_t inner_stride, int64_t w_stride,
+                          int64_t g_stride, int block0, int *blocks_out /* host */);
+/* max_cols = the largest I * taps among the jobs (sizes the LDS tile) */
+int glowtts_prep_launch(const glowtts_prep_job *host_jobs, int njobs, int total_blocks, int max_cols, void *stream);
 
 #define GLOWTTS_APRO_NONE    0
 #define GLOWTTS_APRO_PAIRMUL 1  /* a[r][c] = A[r][2c] * A[r][2c+1]   (tanh*sigmoid gates, Modules.py:885-887) */
@@ -426,6 +448,13 @@ int glowtts_wavenet_image_bytes(int L, int transposed, int64_t *bytes_out /* hos
  * img_bwd != NULL, F images of the transposed weights for the fused backward; image f starts at f * glowtts_wavenet_image_bytes(). */
 int glowtts_wavenet_pack_images(const float *w_start, const float *w_in, const float *w_rs, const float *w_rs_last, const float *w_end,
                                 int F, int L, int C2, void *img_fwd, void *img_bwd, void *stream);
+/* The same images described as glowtts_prep_job entries (host array `jobs`, capacity max_jobs; appends at *njobs and advances *njobs / *block), from
+ * the weight-norm pairs of the four normalised convs (v_* / g_* stacked like w_* above) and the plain End weight.  img_fwd: F forward images (its jobs
+ * also write inv_* [F (* L)][O]); img_bwd: the transposed images of the first F_bwd flows (either may be NULL). */
+int glowtts_wavenet_prep_jobs(glowtts_prep_job *jobs, int max_jobs, int *njobs, int *block,
+                              const float *v_start, const float *g_start, float *inv_start, const float *v_in, const float *g_in, float *inv_in,
+                              const float *v_rs, const float *g_rs, float *inv_rs, const float *v_rsl, const float *g_rsl, float *inv_rsl,
+                              const float *w_end, int F, int L, int C2, void *img_fwd, int F_bwd, void *img_bwd);
 /* xsrc [R][C]: channels [0, C/2) = x_a (WaveNet input), [C/2, C) = x_b; writes x_b' = m + exp(logs) x_b (reverse: (x_b - m) exp(-logs)),
  * masked, to xdst[r][C/2 ...].  keep != 0: fills a->hs / gates / acts / skip / outs (the activations glowtts_flow_backward reads).
  * Needs p->wn_img. */

@@ -20,6 +20,8 @@ typedef __amdgpu_buffer_rsrc_t Rsrc;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 __device__ __forceinline__ int swz(int row, int q) { return row * 64 + ((q ^ ((row >> 2) & 3)) << 4); }
+// slot swizzle under which the fragment reads of v_mfma_f32_16x16x32_bf16 (lane = (row & 15, slot lane >> 4)) are bank-conflict-free at any row shift
+__device__ __forceinline__ int swz16(int row, int q) { return row * 64 + ((q ^ (((row >> 2) & 1) << 1)) << 4); }
 __device__ __forceinline__ f32x16 mfma(const Chunk16& a, const Chunk16& b, const f32x16& c)
 {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
@@ -584,9 +586,9 @@ __global__ __launch_bounds__(NW * 64) void ring_loop(const unsigned char* __rest
                 const unsigned char* slot = RING + ((s + h) & 3) * 24576;
                 const int kc = (s + h) % KCH, t = ((s + h) / KCH) % 5;
 #pragma unroll
-                for (int r = 0; r < 2; ++r) fa[h][r] = *reinterpret_cast<const Chunk16*>(XT + kc * (XR * 64) + swz(rf * 32 + r * 16 + l15 + t, lq));
+                for (int r = 0; r < 2; ++r) fa[h][r] = *reinterpret_cast<const Chunk16*>(XT + kc * (XR * 64) + (MF16 == 2 ? swz16(rf * 32 + r * 16 + l15 + t, lq) : swz(rf * 32 + r * 16 + l15 + t, lq)));
 #pragma unroll
-                for (int c = 0; c < 4; ++c) fb[h][c] = *reinterpret_cast<const Chunk16*>(slot + swz(pi * 64 + c * 16 + l15, lq));
+                for (int c = 0; c < 4; ++c) fb[h][c] = *reinterpret_cast<const Chunk16*>(slot + (MF16 == 2 ? swz16(pi * 64 + c * 16 + l15, lq) : swz(pi * 64 + c * 16 + l15, lq)));
                 if (DMA_FIRST) issue(s + h + 3);
                 mma(h ^ 1);
                 if (!DMA_FIRST) issue(s + h + 3);
@@ -820,6 +822,8 @@ int main(int argc, char** argv)
             run_ring<0, 1>("32x32x16, DMA before the MFMAs", wimg, out, clk, 144, grid);
             run_ring<1, 0>("16x16x32, DMA behind the MFMAs", wimg, out, clk, 144, grid);
             run_ring<1, 1>("16x16x32, DMA before the MFMAs", wimg, out, clk, 144, grid);
+            run_ring<2, 0>("16x16x32, conflict-free swizzle, DMA behind", wimg, out, clk, 144, grid);
+            run_ring<2, 1>("16x16x32, conflict-free swizzle, DMA before", wimg, out, clk, 144, grid);
         }
         return 0;
     }
