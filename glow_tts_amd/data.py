@@ -171,6 +171,68 @@ def read_inference_prompts(path, token_dict=None):
     return out
 
 
+
+class InferenceDataset(torch.utils.data.Dataset):
+    """`Datasets.Inference_Dataset` (Datasets.py:131-165): the prompts of the inference TSV (`hp.Train.Inference_Pattern_File_in_Train`) as
+    (token, length scale, speaker, mel for GE2E, mel for prosody, pitch, label, text).  The reference runs `Pattern_Generate` on the three wav
+    columns of every record whatever the Mode; here a reference wav is only decoded when the Mode reads it (GE2E d-vectors / PE-GR prosody /
+    GR pitch) - the other entries are one-frame placeholders that `Trainer.Inference_Step` drops, so a Vanilla run needs no wav files."""
+
+    def __init__(self, pattern_path, token_dict, hp, use_cache=False):
+        self.records = [r for r in read_inference_prompts(pattern_path, token_dict) if r.get("token") is not None]
+        self.hp, self.use_cache, self.cache = hp, use_cache, {}
+        mode = hp.Mode.upper()
+        self.need_ge2e = mode in ("SE", "GR") and hp.Speaker_Embedding.Type.upper() == "GE2E"
+        self.need_prosody = mode in ("PE", "GR")
+        self.need_pitch = mode == "GR"
+
+    def __len__(self):
+        return len(self.records)
+
+    def __getitem__(self, idx):
+        if idx in self.cache:
+            return self.cache[idx]
+        r = self.records[idx]
+        mel_dim = int(self.hp.Sound.Mel_Dim)
+        blank_mel, blank_pitch = np.full((1, mel_dim), -float(self.hp.Sound.Max_Abs_Mel), np.float32), np.zeros(1, np.float32)
+
+        def ref(path, with_pitch=False):
+            from . import audio
+            return audio.pattern_from_wav(path, self.hp, with_pitch=with_pitch)
+        mel_ge2e = ref(r["wav_for_ge2e"])[0] if self.need_ge2e else blank_mel
+        mel_pro = ref(r["wav_for_prosody"])[0] if self.need_prosody else blank_mel
+        pitch = ref(r["wav_for_pitch"], with_pitch=True)[1] if self.need_pitch else blank_pitch
+        pattern = (r["token"], r["length_scale"], r["speaker"], mel_ge2e, mel_pro, pitch, r["label"], r["text"])
+        if self.use_cache:
+            self.cache[idx] = pattern
+        return pattern
+
+
+class InferenceCollater:
+    """`Datasets.Inference_Collater` (Datasets.py:252-275): -> tokens [B, Tt], token_lengths, mels_for_prosody [B, Mel, T], its lengths, speakers,
+    mels_for_ge2e (the slice stack of `mels_for_ge2e`, [B * Samples, Mel, Slice]), pitches [B, T], pitch_lengths, length_scales, labels, texts."""
+
+    def __init__(self, token_dict, hp):
+        self.end, self.hp = int(token_dict["<E>"]), hp
+        self.need_ge2e = hp.Mode.upper() in ("SE", "GR") and hp.Speaker_Embedding.Type.upper() == "GE2E"
+
+    def __call__(self, batch):
+        tokens, scales, speakers, mels_ge2e, mels_pro, pitches, labels, texts = zip(*batch)
+        hp = self.hp
+        tl = [t.shape[0] for t in tokens]
+        tok = np.stack([np.pad(t, [0, max(tl) - t.shape[0]], constant_values=self.end) for t in tokens])
+        pl = [m.shape[0] for m in mels_pro]
+        pro = np.stack([np.pad(m, [[0, max(pl) - m.shape[0]], [0, 0]], constant_values=-float(hp.Sound.Max_Abs_Mel)) for m in mels_pro])
+        pil = [p.shape[0] for p in pitches]
+        pit = np.stack([np.pad(p, [0, max(pil) - p.shape[0]], constant_values=0.0) for p in pitches])
+        ge = hp.Speaker_Embedding.GE2E.Inference
+        ge2e = mels_for_ge2e(list(mels_ge2e), int(ge.Samples), int(ge.Slice_Length), int(ge.Overlap_Length)) if self.need_ge2e \
+            else np.zeros((len(batch), 1, int(hp.Sound.Mel_Dim)), np.float32)
+        return (torch.from_numpy(tok.astype(np.int64)), torch.tensor(tl, dtype=torch.int64), torch.from_numpy(pro.astype(np.float32)).transpose(2, 1).contiguous(),
+                torch.tensor(pl, dtype=torch.int64), torch.tensor(speakers, dtype=torch.int64), torch.from_numpy(np.asarray(ge2e, np.float32)).transpose(2, 1).contiguous(),
+                torch.from_numpy(pit.astype(np.float32)), torch.tensor(pil, dtype=torch.int64), torch.tensor(scales, dtype=torch.float32), list(labels), list(texts))
+
+
 def _bucket(n, buckets, multiple):
     if buckets:
         i = bisect.bisect_left(buckets, n)

@@ -44,6 +44,16 @@ def global_frame_weight(local_frames):
     return local_frames.to(torch.float32) / tot
 
 
+def global_token_extent(local_max):
+    """local_max: 0-d tensor (this rank's longest text).  Returns the longest text of the GLOBAL batch (all-reduce MAX): the extent over which
+    the reference's duration MSE (Train.py:210, a mean over B x longest text of the batch) is taken when the batch is sharded."""
+    if not is_dist():
+        return local_max
+    t = local_max.detach().clone().to(torch.float32)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
 def global_batch_weight(local_utterances, device=None):
     """local / global utterance count: the factor for losses that are means over the padded batch (the duration MSE, Train.py:211) when
     ranks hold different numbers of utterances (equal shards: 1 / world)."""

@@ -158,7 +158,7 @@ def test_hot_kernels_use_no_scratch_memory(tmp_path):
         for name, scratch, vgpr in re.findall(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)", notes, re.S):
             kernels[name] = (int(scratch), int(vgpr))
     assert len(kernels) > 100
-    hot = [r"wn_fwd_kernelILb1ELb0ELi0E", r"wn_bwd_kernel", r"conv_dma_kernelILi\dELi\dELi2ELb0E", r"conv_chain_kernel", r"conv_skinny_kernel", r"wgrad_kernel", r"attn_(fwd|bwd)_mfma_kernel",
+    hot = [r"wn_fwd_kernelILb1ELb0ELb1ELb0ELi0E", r"wn_bwd_kernel", r"conv_dma_kernelILi\dELi\dELi2ELb0E", r"conv_chain_kernel", r"conv_skinny_kernel", r"wgrad_kernel", r"attn_(fwd|bwd)_mfma_kernel",
            r"mas_dp_kernelILi[12]E", r"mas_dp2_kernel", r"ln_(fwd|bwd)_kernel", r"actnorm_inv", r"gate_bwd_kernel", r"mas_path_linear_kernel", r"expand_fwd4_kernel",
            r"squeeze_kernel", r"optim|radam|adam"]
     seen = {h: 0 for h in hot}

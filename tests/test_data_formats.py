@@ -181,3 +181,29 @@ def test_collater_matches_the_reference_collater_bit_for_bit():
         assert got.dtype == want.dtype and got.shape == want.shape, (name, got.dtype, want.dtype, got.shape, want.shape)
         assert torch.equal(got, want), name
     assert data.Collater().end == 1                                                          # '<E>' (Token.yaml: '<S>' 0, '<E>' 1)
+
+
+def test_inference_dataset_and_collater_follow_the_reference_layout(tmp_path):
+    """`Datasets.Inference_Dataset` / `Inference_Collater` (Datasets.py:131-165, 252-275): the 11-tuple `Trainer.Inference_Step` takes; a Vanilla
+    run decodes no reference wav (placeholders of one frame)."""
+    import yaml
+    import torch
+    from glow_tts_amd import data
+    from glow_tts_amd.hparams import Recursive_Parse
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(repo, "glow_tts_amd", "Hyper_Parameters.default.yaml")) as f:
+        hp = Recursive_Parse(yaml.safe_load(f))
+    token_dict = data.make_token_dict(["HELLO WORLD.", "A LONGER SENTENCE, WITH COMMAS!"])
+    tsv = tmp_path / "prompts.txt"
+    tsv.write_text("Label\tText\tLength_Scale\tSpeaker\tGE2E\tProsody\tPitch\n"
+                   "A\tHello world.\t1.0\t3\tx.wav\ty.wav\tz.wav\n"
+                   "B\tA longer sentence, with commas!\t1.25\t0\tx.wav\ty.wav\tz.wav\n", encoding="utf-8")
+    ds = data.InferenceDataset(str(tsv), token_dict, hp)
+    assert len(ds) == 2
+    out = data.InferenceCollater(token_dict, hp)([ds[0], ds[1]])
+    tokens, tl, pro, pl, spk, ge2e, pit, pil, scales, labels, texts = out
+    assert tokens.dtype == torch.int64 and tokens.shape == (2, int(tl.max())) and tl.tolist() == [len(ds[0][0]), len(ds[1][0])]
+    assert int(tokens[0, 0]) == token_dict["<S>"] and int(tokens[0, tl[0] - 1]) == token_dict["<E>"] and bool((tokens[0, tl[0]:] == token_dict["<E>"]).all())
+    assert pro.shape == (2, int(hp.Sound.Mel_Dim), 1) and pl.tolist() == [1, 1] and pit.shape == (2, 1) and pil.tolist() == [1, 1]
+    assert spk.tolist() == [3, 0] and scales.tolist() == [1.0, 1.25] and labels == ["A", "B"] and texts[0] == ds[0][7]
