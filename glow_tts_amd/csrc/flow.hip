@@ -161,7 +161,7 @@ extern "C" int glowtts_flow_forward(const glowtts_flow_dims* d, const glowtts_fl
     const Ctx c = make_ctx(d, p, a, stream);
     // ActNorm + invertible 1x1                                                 Modules.py:693-694, 738-756
     // (x_a passes through, Modules.py:808: written to xout by the same kernel)
-    CHECK(glowtts_actnorm_inv1x1_pass(a->xin, a->xmid, a->xout, p->an_logs, p->an_bias, p->winfo, a->rowmask, c.R, d->C, stream));
+    CHECK(glowtts_actnorm_inv1x1_pass_bf(a->xin, a->xmid, a->xout, a->xa_bf, p->an_logs, p->an_bias, p->winfo, a->rowmask, c.R, d->C, stream));
     return coupling_net(c, a->xmid, a->xout, false, true);
 }
 
@@ -278,7 +278,7 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
             q.a = dins; q.lda = ldin; q.ca = ldin; q.n = H; q.epi = GLOWTTS_EPI_LINEAR;
             q.flags = GLOWTTS_F_MASK | (last ? 0 : GLOWTTS_F_ADD_IN0);
             q.in0 = last ? nullptr : dnext; q.ldi0 = H; q.out0 = dthis; q.ld0 = H;
-            q.io_flags = bf ? (GLOWTTS_IO_A_BF16 | (bfg && !last ? GLOWTTS_IO_IN0_BF16 : 0) | (bfg && l > 0 ? GLOWTTS_IO_OUT0_BF16 : 0)) : 0;
+            q.io_flags = bf ? (GLOWTTS_IO_A_BF16 | (bfg && !last ? GLOWTTS_IO_IN0_BF16 : 0) | (bfg && (l > 0 || g->dh0_bf16) ? GLOWTTS_IO_OUT0_BF16 : 0)) : 0;
             CHECK(glowtts_conv_cl(&q, stream));
         }
         if (wg) {   // In_l weight gradient
@@ -292,11 +292,15 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
     // 4. Start conv: data gradient accumulates into d x_a, weight gradient
     {
         glowtts_conv_args q = base_args(c, p->start_t, 1);
+        const bool h0bf = bfg && g->dh0_bf16;      // d h0 stored as bf16 rows (the deferred weight gradient then takes (d h0, acts->xa_bf) as raw bf16 operands)
         q.a = dh0; q.lda = H; q.ca = H; q.n = C2; q.epi = GLOWTTS_EPI_LINEAR; q.flags = GLOWTTS_F_ACCUM;
-        q.out0 = g->dx; q.ld0 = C;
+        q.out0 = g->dx; q.ld0 = C; q.io_flags = h0bf ? GLOWTTS_IO_A_BF16 : 0;
         CHECK(glowtts_conv_cl(&q, stream));
         if (wg) {
-            glowtts_wgrad_args w = wargs(dh0, H, H, a->xmid, C, C2, 1, g->dw_start, g->db_start);
+            if (h0bf && !a->xa_bf) return GLOWTTS_E_ARG;
+            glowtts_wgrad_args w = h0bf ? wargs(dh0, H, H, reinterpret_cast<const float*>(a->xa_bf), C2, C2, 1, g->dw_start, g->db_start)
+                                        : wargs(dh0, H, H, a->xmid, C, C2, 1, g->dw_start, g->db_start);
+            if (h0bf) w.io_flags = GLOWTTS_WIO_DY_BF16 | GLOWTTS_WIO_X_BF16;
             CHECK(glowtts_wgrad_cl(&w, stream));
         }
     }

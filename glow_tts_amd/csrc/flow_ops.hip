@@ -111,11 +111,17 @@ __global__ void inv4x4_kernel(const float* __restrict__ W, float* __restrict__ o
 // ActNorm + invertible 1x1, forward and inverse, one pass over the rows.
 // thread = (row, group g): channels {2g, 2g+1, C/2+2g, C/2+2g+1} <-> split index 0..3  (Modules.py:738-740)
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t an_pack_bf16x2(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return *reinterpret_cast<uint32_t*>(&v);
+}
+
 template <bool REVERSE>
 __global__ __launch_bounds__(256) void actnorm_inv_kernel(const float* __restrict__ xin, float* __restrict__ xout,
                                                           const float* __restrict__ logs, const float* __restrict__ bias,
                                                           const float* __restrict__ winfo, const float* __restrict__ rowmask,
-                                                          long rows, int C, float* __restrict__ xpass)
+                                                          long rows, int C, float* __restrict__ xpass, uint32_t* __restrict__ xa_bf = nullptr)
 {
     // xpass (forward only, may be null): the first C/2 output channels are also written there - the coupling layer passes x_a
     // through unchanged (Modules.py:808), so the flow's output buffer gets its first half without a separate copy kernel
@@ -149,6 +155,7 @@ __global__ __launch_bounds__(256) void actnorm_inv_kernel(const float* __restric
         *reinterpret_cast<float2*>(xout + r * C + 2 * g) = make_float2(o[0], o[1]);
         *reinterpret_cast<float2*>(xout + r * C + C2 + 2 * g) = make_float2(o[2], o[3]);
         if (!REVERSE && xpass) *reinterpret_cast<float2*>(xpass + r * C + 2 * g) = make_float2(o[0], o[1]);
+        if (!REVERSE && xa_bf) xa_bf[(r * C2 + 2 * g) >> 1] = an_pack_bf16x2(o[0], o[1]);      // x_a as bf16 rows [rows][C/2] (Start conv weight gradient operand)
     }
 }
 
@@ -579,6 +586,15 @@ extern "C" int glowtts_actnorm_inv1x1_pass(const float* xin, float* xout, float*
     if (!xin || !xout || !xpass || !logs || !bias || !winfo || !rowmask || rows < 1 || C < 4 || (C & 3)) return GLOWTTS_E_ARG;
     hipLaunchKernelGGL(actnorm_inv_kernel<false>, dim3(grid_for(rows * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream),
                        xin, xout, logs, bias, winfo, rowmask, (long)rows, C, xpass == xout ? (float*)nullptr : xpass);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_actnorm_inv1x1_pass_bf(const float* xin, float* xout, float* xpass, void* xa_bf, const float* logs, const float* bias, const float* winfo,
+                                              const float* rowmask, int64_t rows, int C, void* stream)
+{
+    if (!xin || !xout || !logs || !bias || !winfo || !rowmask || rows < 1 || C < 4 || (C & 3)) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(actnorm_inv_kernel<false>, dim3(grid_for(rows * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       xin, xout, logs, bias, winfo, rowmask, (long)rows, C, (xpass == xout || !xpass) ? (float*)nullptr : xpass, static_cast<uint32_t*>(xa_bf));
     RET_LAUNCH();
 }
 

@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(CH_WN * CH_WM * 64) void conv_chain_kernel(const gl
 // of different fragments drift apart, so loads, MFMAs and stores of neighbours overlap.  Registers: KS16 * 8 (A) + KS16 * NI * 4 (B) +
 // NI * 16 (accumulators) <= ~340 for K = 192, NI = 3: one wave per SIMD, which is all this problem size offers anyway.
 // ------------------------------------------------------------------------------------------------
-template <int KS16 /* 16-wide k steps = ca / 16 */, int NI /* 32-column fragments */>
+template <int KS16 /* 16-wide k steps = ca / 16 */, int NI /* 32-column fragments */, bool ABF = false /* A rows stored as bf16: the fragments are raw copies */>
 __global__ __launch_bounds__(64) void conv_skinny_kernel(const glowtts_conv_args pin)
 {
     typedef __bf16 CT;
@@ -1265,10 +1265,15 @@ __global__ __launch_bounds__(64) void conv_skinny_kernel(const glowtts_conv_args
     row = row < p.rows ? row : p.rows - 1;                                   // clamped: rows past the end are dropped by the epilogue
     const float* arow = p.a + (long)row * p.lda + lhi * 8;
     f32x4 araw[KS16][2];
+    Chunk16 abf[KS16];
 #pragma unroll
     for (int s = 0; s < KS16; ++s) {
-        araw[s][0] = *reinterpret_cast<const f32x4*>(arow + s * 16);
-        araw[s][1] = *reinterpret_cast<const f32x4*>(arow + s * 16 + 4);
+        if constexpr (ABF) {
+            abf[s] = *reinterpret_cast<const Chunk16*>(reinterpret_cast<const unsigned char*>(p.a) + ((long)row * p.lda + s * 16 + lhi * 8) * 2);
+        } else {
+            araw[s][0] = *reinterpret_cast<const f32x4*>(arow + s * 16);
+            araw[s][1] = *reinterpret_cast<const f32x4*>(arow + s * 16 + 4);
+        }
     }
     Chunk16 bfr[KS16][NI];
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w);
@@ -1285,8 +1290,11 @@ __global__ __launch_bounds__(64) void conv_skinny_kernel(const glowtts_conv_args
 #pragma unroll
     for (int s = 0; s < KS16; ++s) {
         Chunk16 af;
-        af[0] = pack_bf16x2(araw[s][0][0], araw[s][0][1]); af[1] = pack_bf16x2(araw[s][0][2], araw[s][0][3]);
-        af[2] = pack_bf16x2(araw[s][1][0], araw[s][1][1]); af[3] = pack_bf16x2(araw[s][1][2], araw[s][1][3]);
+        if constexpr (ABF) af = abf[s];
+        else {
+            af[0] = pack_bf16x2(araw[s][0][0], araw[s][0][1]); af[1] = pack_bf16x2(araw[s][0][2], araw[s][0][3]);
+            af[2] = pack_bf16x2(araw[s][1][0], araw[s][1][1]); af[3] = pack_bf16x2(araw[s][1][2], araw[s][1][3]);
+        }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
             acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&af), *reinterpret_cast<const bf16x8*>(&bfr[s][ni]), acc[0][ni], 0, 0, 0);
@@ -1294,11 +1302,11 @@ __global__ __launch_bounds__(64) void conv_skinny_kernel(const glowtts_conv_args
     conv_epilogue<CT, 1, NI, GLOWTTS_EPI_LINEAR, false>(p, acc, m0, 0, 32, 0, 0, lane, lane, nullptr);
 }
 
-template <int KS16, int NI>
+template <int KS16, int NI, bool ABF = false>
 int launch_skinny(const glowtts_conv_args& a, hipStream_t s)
 {
-    GLOWTTS_NOTE_STATIC("conv_skinny<%d,%d>", KS16 * 16, NI * 32);
-    hipLaunchKernelGGL((conv_skinny_kernel<KS16, NI>), dim3((a.rows + 31) / 32), dim3(64), 0, s, a);
+    GLOWTTS_NOTE_STATIC("conv_skinny<%d,%d%s>", KS16 * 16, NI * 32, ABF ? ",abf16" : "");
+    hipLaunchKernelGGL((conv_skinny_kernel<KS16, NI, ABF>), dim3((a.rows + 31) / 32), dim3(64), 0, s, a);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
@@ -1306,10 +1314,14 @@ int launch_skinny(const glowtts_conv_args& a, hipStream_t s)
 inline int try_skinny(const glowtts_conv_args& a, hipStream_t s)
 {
     if (!(GLOWTTS_TUNABLE("GLOWTTS_SKINNY", 1) && a.precision == GLOWTTS_BF16 && a.taps == 1 && a.epi == GLOWTTS_EPI_LINEAR && a.apro == GLOWTTS_APRO_NONE &&
-          !(a.io_flags & (GLOWTTS_IO_A_BF16 | GLOWTTS_IO_IN0_BF16)) && !a.a2 && a.batch <= 1 && !(a.flags & (GLOWTTS_F_COLMASK | GLOWTTS_F_DROPOUT)) &&
+          !(a.io_flags & GLOWTTS_IO_IN0_BF16) && !a.a2 && a.batch <= 1 && !(a.flags & (GLOWTTS_F_COLMASK | GLOWTTS_F_DROPOUT)) &&
           (a.ca % 16) == 0 && a.lda >= a.ca && (a.lda & 3) == 0 && a.kchunks * 32 >= a.ca && a.rows >= 32)) return -1;
     const int ni = (a.n + 31) / 32;
     if (ni * 32 > a.npad) return -1;
+    if (a.io_flags & GLOWTTS_IO_A_BF16) {                                        // bf16-stored A rows: the Start data gradient on bf16 d h0
+        if (a.ca == 192 && ni == 3 && (a.lda & 7) == 0 && !(a.io_flags & GLOWTTS_IO_OUT0_BF16)) return launch_skinny<12, 3, true>(a, s);
+        return -1;
+    }
     switch (a.ca / 16) {
         case 5:  if (ni == 6) return launch_skinny<5, 6>(a, s); break;           // Start conv: 80 -> 192
         case 12: if (ni == 3) return launch_skinny<12, 3>(a, s);                 // Start data gradient: 192 -> 80

@@ -60,6 +60,7 @@ struct wn_fwd_args {
     float drop_p; uint32_t seed; const uint32_t* seed_ptr;
     void* hs[WN_MAXL]; void* gates[WN_MAXL]; void* acts[WN_MAXL];       // kept (bf16)
     float* skip; float* outs; int64_t ldo;                              // kept (fp32)
+    void* skip_bf;                                                      // kept (bf16 copy of skip, [rows][192]; may be null)
     long long* tl;                                                      // tools builds (ABL & 16): per-workgroup phase stamps [grid][32]
 };
 
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(WN_NT) void wn_fwd_kernel(const wn_fwd_args p)
     // 16-byte copy of the valid rows of an LDS tile [6 chunks][trows][64 B] to a bf16 rows tensor [rows][192]
     auto copy_out = [&](const unsigned char* tile, int trows, int row_off, void* dst) __attribute__((always_inline)) {
         if constexpr ((ABL & 32) != 0) return;
-        const Rsrc rd = mk_rsrc(dst, (long)p.rows * (WN_H * 2));
+        const Rsrc rd = mk_rsrc(dst, dst ? (long)p.rows * (WN_H * 2) : 0);
         int tid_ = tid;
         asm volatile("" : "+v"(tid_));                         // (opaque: keeps this address arithmetic out of the registers that live across the GEMM loops)
 #pragma unroll
@@ -567,12 +568,16 @@ __global__ __launch_bounds__(WN_NT) void wn_fwd_kernel(const wn_fwd_args p)
             else if (j == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
+            constexpr int XS = keep ? XC : 0;                  // the skip copy-out's stores, issued behind slab j = 0's wait
             if (j == 0)      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(4 + XG + 16) : "memory");
-            else if (j == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(2 + XG + 16) : "memory");
-            else             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(XG + 16) : "memory");
+            else if (j == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(2 + XG + 16 + XS) : "memory");
+            else             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(XG + 16 + XS) : "memory");
         }
         const unsigned char* slot = wn_smem + OFF_RING + (snext & (WN_NS - 1)) * WN_SLAB;
         ++snext;
+        // the bf16 skip sum (the End conv's operand tile) also goes out: X of the End conv's weight gradient at half the bytes (a null pointer
+        // gives an empty descriptor: the two stores are issued and dropped, the counts above stay static)
+        if (keep && j == 0) copy_out(XT, WN_WIN, halo, p.skip_bf);
         if (wave < 6) {
             const int ble = swz16(l15e, lqe);
 #pragma unroll
@@ -722,7 +727,7 @@ extern "C" int glowtts_wavenet_fwd(const glowtts_flow_dims* d, const glowtts_flo
             if (!a->hs[l] || !a->gates[l] || !a->acts[l]) return GLOWTTS_E_ARG;
             k.hs[l] = a->hs[l]; k.gates[l] = a->gates[l]; k.acts[l] = a->acts[l];
         }
-        k.skip = a->skip; k.outs = a->outs; k.ldo = p->end.npad;
+        k.skip = a->skip; k.outs = a->outs; k.ldo = p->end.npad; k.skip_bf = a->skip_bf;
     }
     const int nvalid = WN_WIN - 2 * WN_PAD * (d->L - 1);
     const dim3 grid((unsigned)((R + nvalid - 1) / nvalid));

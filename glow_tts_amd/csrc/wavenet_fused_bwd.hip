@@ -54,7 +54,8 @@ struct wn_bwd_args {
     float drop_p; uint32_t seed; const uint32_t* seed_ptr;
     void* dskip;                                  // out: bf16 [rows][H]
     void* dins[WN_MAXL]; int64_t ldin;            // out: bf16 [rows][ldin] PAIR-packed (da | ds per 32 channels)
-    void* dh[WN_MAXL];                            // out: d x_l, l >= 1 bf16 [rows][H]; l = 0 fp32 [rows][H]
+    void* dh[WN_MAXL];                            // out: d x_l, l >= 1 bf16 [rows][H]; l = 0 fp32 [rows][H] (bf16 like the others when dh0_bf16)
+    int dh0_bf16;
     float* dx; int64_t lddx;                      // in / out: [rows][lddx] fp32, channels [0, C2) += d x_a
     float* dcond; int64_t ldcond;                 // COND: d conditioning [utterances][ldcond], layer l at + l * 2 H; ACCUMULATED (atomic adds)
 };
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
             tile_bases(rb, tb);
             unsigned char* const xc = DX + cf * (WN_WIN * 64);
             const float* const mk = MK + rb + WN_PAD;
-            const Rsrc r0 = mk_rsrc(p.dh[0], l == 0 ? (long)p.rows * (WN_H * 4) : 0);
+            const Rsrc r0 = mk_rsrc(p.dh[0], (l == 0 && !p.dh0_bf16) ? (long)p.rows * (WN_H * 4) : 0);
             const uint32_t v00 = (uint32_t)((t0 + rb) * (WN_H * 4) + jch * 4);
             const uint32_t own0 = (uint32_t)(rb - halo);
 #pragma unroll
@@ -451,6 +452,8 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
 #pragma unroll 1
     for (int j = 0; j < 2; ++j) {
         const unsigned char* slot = begin_step();
+        // d x_0 as bf16 rows (DY of the Start conv's weight gradient): the finished tile, 16 bytes per store, behind the step's barrier
+        if (j == 0 && p.dh0_bf16) copy_out(DX, WN_WIN, halo, p.dh[0], WN_H * 2, 64, 0);
         if (cf < 3) {
             Chunk16 fa[3][2], fb[3][2];
 #pragma unroll
@@ -551,6 +554,7 @@ extern "C" int glowtts_wavenet_bwd(const glowtts_flow_dims* d, const glowtts_flo
     for (int l = 0; l < d->L; ++l) {
         if (!a->gates[l] || !g->dins[l] || !g->dh[l]) return GLOWTTS_E_ARG;
         k.gates[l] = a->gates[l]; k.dins[l] = g->dins[l]; k.dh[l] = g->dh[l];
+        k.dh0_bf16 = g->dh0_bf16;
     }
     const int nvalid = WN_WIN - 2 * WN_PAD * (d->L - 1);
     const dim3 grid((unsigned)((R + nvalid - 1) / nvalid));

@@ -197,6 +197,8 @@ class InferenceDataset(torch.utils.data.Dataset):
         blank_mel, blank_pitch = np.full((1, mel_dim), -float(self.hp.Sound.Max_Abs_Mel), np.float32), np.zeros(1, np.float32)
 
         def ref(path, with_pitch=False):
+            if str(path).lower().endswith(".npy"):             # a pre-computed mel [T, Mel] (as `Inferencer` accepts); no pitch track
+                return np.load(path).astype(np.float32), blank_pitch
             from . import audio
             return audio.pattern_from_wav(path, self.hp, with_pitch=with_pitch)
         mel_ge2e = ref(r["wav_for_ge2e"])[0] if self.need_ge2e else blank_mel

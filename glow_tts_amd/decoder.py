@@ -39,7 +39,7 @@ class FlowParams(ctypes.Structure):
 class FlowActs(ctypes.Structure):
     _fields_ = [("xin", c_void_p), ("xmid", c_void_p), ("xout", c_void_p),
                 ("hs", c_void_p * MAXL), ("gates", c_void_p * MAXL), ("skip", c_void_p), ("outs", c_void_p),
-                ("rowmask", c_void_p), ("acts", c_void_p * MAXL), ("skip_bf", c_void_p)]
+                ("rowmask", c_void_p), ("acts", c_void_p * MAXL), ("skip_bf", c_void_p), ("xa_bf", c_void_p)]
 
 
 class FlowGrads(ctypes.Structure):
@@ -51,7 +51,7 @@ class FlowGrads(ctypes.Structure):
                 ("dw_rs", c_void_p * MAXL), ("db_rs", c_void_p * MAXL),
                 ("dw_end", c_void_p), ("db_end", c_void_p), ("dcond", c_void_p), ("douts_bf", c_void_p),
                 ("coupling_done", c_int), ("prev_xmid", c_void_p), ("prev_outs", c_void_p), ("prev_douts", c_void_p), ("prev_douts_bf", c_void_p),
-                ("pitch_rows", c_void_p), ("pitch_ns", c_int)]
+                ("pitch_rows", c_void_p), ("pitch_ns", c_int), ("dh0_bf16", c_int)]
 
 
 _declared = False
@@ -579,6 +579,8 @@ class _Buffers:
         self.skipb = torch.empty(F_, R, H, device=dev, dtype=torch.bfloat16) if cfg.act_bf16 else None      # bf16 copy of skip (End conv operand)
         self.skip = torch.empty(F_, R, H, device=dev)
         self.outs = torch.empty(F_, R, prep.ldo, device=dev)
+        # bf16 copy of x_a = xmid[:, :C/2] (written by the flow's ActNorm + 1x1 pass): X of the Start conv's weight gradient
+        self.xa_bf = torch.empty(F_, R, C // 2, device=dev, dtype=torch.bfloat16) if (cfg.act_bf16 and (C // 2) % 8 == 0) else None
 
     def acts(self, f, L, rowmask):
         a = FlowActs()
@@ -590,6 +592,8 @@ class _Buffers:
                 a.acts[l] = self.actp[f, l].data_ptr()
         if self.skipb is not None:
             a.skip_bf = self.skipb[f].data_ptr()
+        if self.xa_bf is not None:
+            a.xa_bf = self.xa_bf[f].data_ptr()
         a.skip, a.outs, a.rowmask = self.skip[f].data_ptr(), self.outs[f].data_ptr(), rowmask.data_ptr()
         return a
 
@@ -783,11 +787,16 @@ class DecoderFunction(torch.autograd.Function):
         # every flow / layer keeps its own gradient buffers: the weight gradients of ALL flows are computed afterwards by
         # two grouped launches (k-tap problems, 1x1 problems) whose tiles fill the chip without split-K or atomics
         douts = torch.empty(F_, R, prep.ldo, device=dev)           # (pad columns are zeroed by the coupling backward kernel)
-        douts_bf = torch.empty(R, prep.ldo, device=dev, dtype=torch.bfloat16) if cfg.act_bf16 else None      # bf16 copy, reused by every flow
+        # bf16 copy of d(m, logs): the End data gradient's operand and (round 4) DY of the End conv's weight gradient - one per flow, like everything the
+        # deferred weight-gradient launches read
+        douts_bf = torch.empty(F_, R, prep.ldo, device=dev, dtype=torch.bfloat16) if cfg.act_bf16 else None
         fuse = TUNE["fuse_coupling_bwd"]
         dins = (torch.empty if prep.ldin == 2 * H else torch.zeros)(F_, Lw, R, prep.ldin, device=dev, dtype=cfg.act_dtype)    # only pad columns need zeros
         dskip = torch.empty(F_, R, H, device=dev, dtype=cfg.act_dtype)
-        dh0 = torch.empty(F_, R, H, device=dev)                                       # d h0: fp32 (feeds the fp32 Start conv gradients)
+        # d h0: bf16 like d x_l (round 4: the Start conv's data gradient reads bf16 rows, its weight gradient raw bf16 operands) where the
+        # bf16 copy of x_a exists; else fp32
+        h0bf = bool(cfg.act_bf16 and buf.xa_bf is not None and buf.skipb is not None)
+        dh0 = torch.empty(F_, R, H, device=dev, dtype=cfg.act_dtype if h0bf else torch.float32)
         dhn = torch.empty(F_, max(Lw - 1, 1), R, H, device=dev, dtype=cfg.act_dtype)       # d x_l, l >= 1
         dh_ptr = lambda f, l: dh0[f].data_ptr() if l == 0 else dhn[f, l - 1].data_ptr()
         nscr = L.glowtts_actnorm_stats_scratch_floats(R, C)
@@ -805,8 +814,12 @@ class DecoderFunction(torch.autograd.Function):
         for f in order:       # weight-gradient problems of every flow (autograd of Modules.py:791,861,871,793): all pointers are known up front
             # End conv: fp32 (m, logs) gradients x fp32 skip sum, in the Start conv's launch (a launch costs one tile time whatever its tile
             # count up to the CU count: a separate launch for these 72 tiles was +0.15 ms, inside the Res_Skip launch +0.10 ms)
-            g1.add(douts[f].data_ptr(), prep.ldo, prep.ldo, buf.skip[f].data_ptr(), H, H, G["w_end"][f].data_ptr(), G["b_end"][f].data_ptr(),
-                   perm=ops.PERM_PAIR, perm_h=C2)
+            if h0bf:      # raw bf16 operands: the End / Start problems ride in the Res_Skip group's launch (same rows, 1 tap, 16-byte items)
+                gp.add(douts_bf[f].data_ptr(), prep.ldo, prep.ldo, buf.skipb[f].data_ptr(), H, H, G["w_end"][f].data_ptr(), G["b_end"][f].data_ptr(),
+                       perm=ops.PERM_PAIR, perm_h=C2)
+            else:
+                g1.add(douts[f].data_ptr(), prep.ldo, prep.ldo, buf.skip[f].data_ptr(), H, H, G["w_end"][f].data_ptr(), G["b_end"][f].data_ptr(),
+                       perm=ops.PERM_PAIR, perm_h=C2)
             for l in range(Lw):
                 gates, ldg = (buf.actp[f, l].data_ptr(), H) if bf else (buf.gates[f, l].data_ptr(), 2 * H)
                 if l == Lw - 1:
@@ -816,7 +829,10 @@ class DecoderFunction(torch.autograd.Function):
                     gp.add(dskip[f].data_ptr(), H, H, gates, ldg, H, G["w_rs"][f, l].data_ptr() + 4 * H * H, G["b_rs"][f, l].data_ptr() + 4 * H)
                 gk.add(dins[f, l].data_ptr(), prep.ldin, prep.ldin, buf.hs[f, l].data_ptr(), H, H, G["w_in"][f, l].data_ptr(), G["b_in"][f, l].data_ptr(),
                        perm=ops.PERM_PAIR, perm_h=H)
-            g1.add(dh0[f].data_ptr(), H, H, buf.xmid[f].data_ptr(), C, C2, G["w_start"][f].data_ptr(), G["b_start"][f].data_ptr())
+            if h0bf:
+                gp.add(dh0[f].data_ptr(), H, H, buf.xa_bf[f].data_ptr(), C2, C2, G["w_start"][f].data_ptr(), G["b_start"][f].data_ptr())
+            else:
+                g1.add(dh0[f].data_ptr(), H, H, buf.xmid[f].data_ptr(), C, C2, G["w_start"][f].data_ptr(), G["b_start"][f].data_ptr())
             # TUNE["wgrad_split"] = n: weight gradients in n segments, each launched on a second stream as soon as its flows' chain is
             # done (default 1: one launch per class after the chain; see DESIGN.md for the measurements)
             nseg = int(TUNE["wgrad_split"])
@@ -838,12 +854,13 @@ class DecoderFunction(torch.autograd.Function):
         for f in order:
             g = FlowGrads()
             g.dx, g.dlogdet, g.douts, g.dskip = dx.data_ptr(), dld.data_ptr(), douts[f].data_ptr(), dskip[f].data_ptr()
-            g.douts_bf = douts_bf.data_ptr() if douts_bf is not None else None
+            g.douts_bf = douts_bf[f].data_ptr() if douts_bf is not None else None
+            g.dh0_bf16 = int(h0bf)
             # the last kernel of this flow's backward also applies the coupling backward of the flow that runs next (f - 1)
             g.coupling_done = int(fuse and f != order[0])
             if fuse and f > 0:
                 g.prev_xmid, g.prev_outs, g.prev_douts = buf.xmid[f - 1].data_ptr(), buf.outs[f - 1].data_ptr(), douts[f - 1].data_ptr()
-                g.prev_douts_bf = douts_bf.data_ptr() if douts_bf is not None else None
+                g.prev_douts_bf = douts_bf[f - 1].data_ptr() if douts_bf is not None else None
             g.scratch, g.d_an, g.defer_wgrad = scratch[f].data_ptr(), None, 1
             for l in range(Lw):
                 g.dh[l], g.dins[l] = dh_ptr(f, l), dins[f, l].data_ptr()

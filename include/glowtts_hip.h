@@ -254,6 +254,9 @@ int glowtts_inv1x1_prepare(const float *W, float *winfo, int F, void *stream);
 int glowtts_actnorm_inv1x1(const float *xin, float *xout, const float *logs, const float *bias,
                            const float *winfo, const float *rowmask, int64_t rows, int C, int reverse, void *stream);
 /* forward form that also writes the first C/2 output channels to xpass (the coupling layer's pass-through half, Modules.py:808) */
+/* ... and (xa_bf != NULL) a bf16 copy of the first C/2 output channels [rows][C/2] (glowtts_flow_acts.xa_bf) */
+int glowtts_actnorm_inv1x1_pass_bf(const float *xin, float *xout, float *xpass, void *xa_bf, const float *logs, const float *bias, const float *winfo,
+                                   const float *rowmask, int64_t rows, int C, void *stream);
 int glowtts_actnorm_inv1x1_pass(const float *xin, float *xout, float *xpass, const float *logs, const float *bias, const float *winfo,
                                 const float *rowmask, int64_t rows, int C, void *stream);
 /* ActNorm data-dependent init statistics (Modules.py:698-703): stats [2C+1] = { sum x*m [C], sum x^2*m [C], sum m }.
@@ -392,6 +395,8 @@ typedef struct glowtts_flow_acts {        /* rows tensors, R = B*(T+2*PAD) rows 
     const float *rowmask;                 /* [R] */
     float *acts[GLOWTTS_MAX_WN_LAYERS];   /* act_bf16 only (else NULL): [R][H] bf16 tanh * sigmoid of layer l                (kept) */
     float *skip_bf;                       /* act_bf16 only (else NULL): [R][H] bf16 copy of `skip` (End conv / its weight gradient) (kept) */
+    void *xa_bf;                          /* optional (ABI 3): [R][C/2] bf16 copy of xmid[:, :C/2] = x_a, written by the flow's ActNorm + 1x1 pass: the X operand
+                                           * of the Start conv's weight gradient at half the bytes (kept) */
 } glowtts_flow_acts;
 
 typedef struct glowtts_flow_grads {       /* backward outputs; weight grads are ADDED (zero them first) */
@@ -422,6 +427,8 @@ typedef struct glowtts_flow_grads {       /* backward outputs; weight grads are 
      * epilogue.  pitch_rows [R][pitch_ns] (the squeezed pitch in the rows layout, pitch_ns <= 2) or NULL; when given, `dcond` has
      * B + pitch_ns rows and row B + j accumulates that sum for tap j (columns as in the rows above). */
     const float *pitch_rows; int pitch_ns;
+    int dh0_bf16;                         /* ABI 3: dh[0] is stored as bf16 like dh[l >= 1] (act_bf16 only): the Start conv's data gradient reads it as bf16 rows and its
+                                           * weight gradient takes it as a raw bf16 operand (with acts->xa_bf as X) */
 } glowtts_flow_grads;
 
 /* training forward: xin -> xout, fills every kept buffer of `acts` */

@@ -313,12 +313,16 @@ def inv1x1(sd, p, x, mask, cfg, reverse):
     return z, logdet
 
 
-def wavenet(sd, p, x, mask, cfg, speakers=None, prosodies=None, pitches=None):
-    """Modules.py:858-887 (k=5 'same' conv, NOT dilated / NOT causal)."""
+def wavenet(sd, p, x, mask, cfg, speakers=None, prosodies=None, pitches=None, drop=None):
+    """Modules.py:858-887 (k=5 'same' conv, NOT dilated / NOT causal).  drop (test hook; eval mode when None): callable(p, layer, ins) -> the
+    In_l output after the WaveNet dropout of Modules.py:861-862 - a parity test injects the keep masks the HIP path drew, since torch's
+    generator cannot be matched."""
     out = torch.zeros_like(x)
     H = cfg.wn_channels
     for i in range(cfg.wn_layers):
         ins = conv(sd, f"{p}.layer_Dict.In_{i}", x, (cfg.wn_kernel - 1) // 2)
+        if drop is not None:
+            ins = drop(p, i, ins)                                                # :862
         if speakers is not None:
             ins = ins + conv(sd, f"{p}.layer_Dict.Speaker_{i}", speakers.unsqueeze(2))
         if prosodies is not None:
@@ -335,12 +339,12 @@ def wavenet(sd, p, x, mask, cfg, speakers=None, prosodies=None, pitches=None):
     return out * mask
 
 
-def coupling(sd, p, x, mask, cfg, reverse, speakers=None, prosodies=None, pitches=None):
+def coupling(sd, p, x, mask, cfg, reverse, speakers=None, prosodies=None, pitches=None, drop=None):
     """Modules.py:780-810."""
     C = x.shape[1]
     xa, xb = x[:, :C // 2], x[:, C // 2:]
     h = conv(sd, p + ".layer_Dict.Start", xa) * mask
-    h = wavenet(sd, p + ".layer_Dict.WaveNet", h, mask, cfg, speakers, prosodies, pitches)
+    h = wavenet(sd, p + ".layer_Dict.WaveNet", h, mask, cfg, speakers, prosodies, pitches, drop)
     outs = conv(sd, p + ".layer_Dict.End", h)
     m, logs = outs[:, :C // 2], outs[:, C // 2:]
     if reverse:
@@ -351,8 +355,8 @@ def coupling(sd, p, x, mask, cfg, reverse, speakers=None, prosodies=None, pitche
 
 
 def decoder(sd, x, mask, cfg, reverse=False, speakers=None, prosodies=None, pitches=None,
-            p="layer_Dict.Decoder"):
-    """Modules.py:298-309.  Returns (z, log_dets [B] or None, mask)."""
+            p="layer_Dict.Decoder", drop=None):
+    """Modules.py:298-309.  Returns (z, log_dets [B] or None, mask).  drop: see `wavenet`."""
     x, sm = squeeze(x, mask, cfg.n_squeeze)
     if pitches is not None:
         pitches, _ = squeeze(pitches.unsqueeze(1), mask, cfg.n_squeeze)
@@ -367,7 +371,7 @@ def decoder(sd, x, mask, cfg, reverse=False, speakers=None, prosodies=None, pitc
         else:
             x, l0 = actnorm(sd, q + ".0", x, sm, False)
             x, l1 = inv1x1(sd, q + ".1", x, sm, cfg, False)
-            x, l2 = coupling(sd, q + ".2", x, sm, cfg, False, speakers, prosodies, pitches)
+            x, l2 = coupling(sd, q + ".2", x, sm, cfg, False, speakers, prosodies, pitches, drop)
             logdets += [l0, l1, l2]
     x, m = unsqueeze(x, sm, cfg.n_squeeze)
     return x, (None if reverse else torch.stack(logdets).sum(0)), m

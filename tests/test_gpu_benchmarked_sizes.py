@@ -25,19 +25,19 @@ pytestmark = pytest.mark.gpu
 TT, TM = 120, 800
 
 
-def _hp(mode, precision):
+def _hp(mode, precision, spk_type="LUT"):
     from glow_tts_amd import hparams
     d = copy.deepcopy(hparams.load_yaml(hparams.DEFAULT_YAML))
     d["Mode"] = mode
     d["HIP_Precision"] = precision
-    d["Speaker_Embedding"]["Type"] = "LUT"
+    d["Speaker_Embedding"]["Type"] = spk_type
     return d
 
 
-def _build(mode, precision, sd=None):
+def _build(mode, precision, sd=None, spk_type="LUT"):
     from glow_tts_amd.hparams import Recursive_Parse
     from glow_tts_amd.modules import GlowTTS
-    model = GlowTTS(Recursive_Parse(_hp(mode, precision)))
+    model = GlowTTS(Recursive_Parse(_hp(mode, precision, spk_type)))
     if sd is not None:
         model.load_state_dict(sd, strict=True)
         for f in model.layer_Dict["Decoder"].layer_Dict["Flows"]:
@@ -45,12 +45,15 @@ def _build(mode, precision, sd=None):
     return model
 
 
-def make_case(mode, tok_len, mel_len, seed):
+def make_case(mode, tok_len, mel_len, seed, spk_type="LUT", f64=False):
     """Seeded full-size model (End conv not zero, Modules.py:773-778 would hide the WaveNet), ActNorm initialised from the batch by the
-    f32 HIP path; oracle outputs, losses and gradients on the same state dict and batch."""
+    f32 HIP path; oracle outputs, losses and gradients on the same state dict and batch.  spk_type "GE2E": the speakers are L2-normalised
+    d-vectors [B, 256] (BASELINE config 4; the GE2E network itself is not part of the path).  f64: additionally the oracle's gradients in
+    FLOAT64 on the fp32 oracle's alignment (`grads64`) - at B = 32 the fp32 oracle's own summation noise (7e-3 of a tensor's largest entry,
+    tools/grad_noise_check.py) is larger than this path's error, so the fp64 run is the comparator."""
     B = len(tok_len)
     torch.manual_seed(seed)
-    model = _build(mode, "f32")
+    model = _build(mode, "f32", spk_type=spk_type)
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for f in model.layer_Dict["Decoder"].layer_Dict["Flows"]:
@@ -64,26 +67,45 @@ def make_case(mode, tok_len, mel_len, seed):
     for b in range(B):                                   # the reference's padding (Datasets.py:225-250)
         tokens[b, tok_len[b]:] = 1
         mels[b, :, mel_len[b]:] = -4.0
-    spk = torch.randint(0, 109, (B,), generator=g) if mode == "SE" else None
+    spk = None
+    if mode == "SE":
+        if spk_type == "GE2E":
+            spk = torch.randn(B, 256, generator=g)
+            spk = spk / spk.norm(dim=1, keepdim=True)
+        else:
+            spk = torch.randint(0, 109, (B,), generator=g)
+    ge2e = spk_type == "GE2E"
     model = model.cuda().eval()
+    spk_args = lambda dev: (None, spk.to(dev)) if ge2e else ((spk.to(dev) if spk is not None else None), None)
     with torch.no_grad():
-        model(tokens.cuda(), tl.cuda(), mels.cuda(), ml.cuda(), spk.cuda() if spk is not None else None, None, None)      # ActNorm data init
+        model(tokens.cuda(), tl.cuda(), mels.cuda(), ml.cuda(), *spk_args("cuda"), None)      # ActNorm data init
     torch.cuda.synchronize()
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    cfg = O.Cfg.from_yaml_dict(_hp(mode, "f32"))
+    cfg = O.Cfg.from_yaml_dict(_hp(mode, "f32", spk_type))
     sdg = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
     out = O.forward_train(sdg, cfg, tokens, tl, mels, ml, spk)
     mle, length = O.train_losses(out, ml, cfg)
     (mle + length).backward()
-    return dict(mode=mode, sd=sd, tokens=tokens, tl=tl, mels=mels, ml=ml, spk=spk, out={k: v.detach() for k, v in out.items() if v is not None},
+    case = dict(mode=mode, spk_type=spk_type, sd=sd, tokens=tokens, tl=tl, mels=mels, ml=ml, spk=spk, out={k: v.detach() for k, v in out.items() if v is not None},
                 mle=mle.item(), length=length.item(), grads={k: v.grad for k, v in sdg.items() if v.grad is not None})
+    if f64:
+        sd64 = {k: (v.double() if v.is_floating_point() else v).clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+        spk64 = spk.double() if (spk is not None and spk.is_floating_point()) else spk
+        out64 = O.forward_train(sd64, cfg, tokens, tl, mels.double(), ml, spk64, attn=out["attn"].detach().double())
+        mle64, length64 = O.train_losses(out64, ml, cfg)
+        (mle64 + length64).backward()
+        case["grads64"] = {k: v.grad for k, v in sd64.items() if v.grad is not None}
+        case["mle64"] = mle64.item()
+    return case
 
 
-def run_hip(case, precision):
+def run_hip(case, precision, train=False, drop_seed=None):
     from glow_tts_amd.modules import MLE_Loss
-    model = _build(case["mode"], precision, case["sd"]).cuda().eval()
+    model = _build(case["mode"], precision, case["sd"], spk_type=case.get("spk_type", "LUT")).cuda().eval()
     c = lambda k: case[k].cuda()
-    z, mm, ms, ld, dur, durt, attn, _ = model(c("tokens"), c("tl"), c("mels"), c("ml"), c("spk") if case["spk"] is not None else None, None, None)
+    ge2e = case.get("spk_type", "LUT") == "GE2E"
+    spk = c("spk") if case["spk"] is not None else None
+    z, mm, ms, ld, dur, durt, attn, _ = model(c("tokens"), c("tl"), c("mels"), c("ml"), None if ge2e else spk, spk if ge2e else None, None)
     mle = MLE_Loss(model.hp)(z=z, mean=mm, std=ms, log_dets=ld, lengths=c("ml"))
     length = torch.nn.functional.mse_loss(dur, durt)
     (mle + length).backward()
@@ -93,20 +115,22 @@ def run_hip(case, precision):
                 grads={k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None})
 
 
-def check_f32(case, r, grad_tol=5e-3):
+def check_f32(case, r, grad_tol=5e-3, grad_tol64=None):
+    """grad_tol64: compare the gradients with the FLOAT64 oracle run (case built with f64 = True) at that bar instead of the fp32 one."""
     o = case["out"]
     mmask = O.mask_from_lengths(case["ml"], TM)
     assert torch.equal(r["attn"], o["attn"]), f"{(r['attn'] != o['attn']).any(1).sum().item()} frames aligned differently"
     assert ((r["z"] - o["z"]) * mmask).abs().max() <= 1e-3
     assert abs(r["mle"] - case["mle"]) <= 1e-3 and abs(r["length"] - case["length"]) <= 1e-3, (r["mle"], case["mle"])
     worst = ("", 0.0)
-    for k, want in case["grads"].items():
+    ref, tol = (case["grads64"], grad_tol64) if grad_tol64 is not None else (case["grads"], grad_tol)
+    for k, want in ref.items():
         got = r["grads"].get(k)
-        got = got if got is not None else torch.zeros_like(want)
+        got = got.to(want.dtype) if got is not None else torch.zeros_like(want)
         err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-6)
         worst = max(worst, (k, err), key=lambda t: t[1])
-        assert err <= grad_tol, (k, err)
-    print(f"f32 {case['mode']} B={len(case['tl'])}: NLL {r['mle']:.6f} vs oracle {case['mle']:.6f}; worst gradient {worst}")
+        assert err <= tol, (k, err)
+    print(f"f32 {case['mode']} B={len(case['tl'])}: NLL {r['mle']:.6f} vs oracle {case['mle']:.6f}; worst gradient vs the {'float64' if grad_tol64 is not None else 'fp32'} oracle {worst}")
 
 
 def check_bf16(case, r):
@@ -134,7 +158,7 @@ def check_bf16(case, r):
     grads = case["grads"]
     if differ > 0:
         sdg = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in case["sd"].items()}
-        cfg = O.Cfg.from_yaml_dict(_hp(case["mode"], "f32"))
+        cfg = O.Cfg.from_yaml_dict(_hp(case["mode"], "f32", case.get("spk_type", "LUT")))
         out = O.forward_train(sdg, cfg, case["tokens"], case["tl"], case["mels"], case["ml"], case["spk"], attn=r["attn"][:, :, :logp.shape[2]].to(o["attn"].dtype))
         mle, length = O.train_losses(out, case["ml"], cfg)
         (mle + length).backward()
@@ -164,13 +188,14 @@ def _set_v(B, seed):
 def config2_case(request):
     B = 32
     tl, ml = ([120] * B, [800] * B) if request.param == "set_f" else _set_v(B, 5)
-    return make_case("Vanilla", tl, ml, 2025)
+    return make_case("Vanilla", tl, ml, 2025, f64=True)
 
 
 def test_config2_batch32_f32(config2_case):
-    # gradient bar 1e-2 at B = 32: the fp32 ORACLE is the noisy side here - tools/grad_noise_check.py (oracle re-run in float64 on the Set V
-    # case): FFN Conv_0 weight gradient oracle-f32 vs f64 7.1e-3 of the largest entry, this path's f32 vs f64 6.1e-4 (B = 4 cases keep 5e-3)
-    check_f32(config2_case, run_hip(config2_case, "f32"), grad_tol=1e-2)
+    # Gradients against the oracle run in FLOAT64 (on the fp32 oracle's alignment), bar 2e-3 of the tensor's largest entry: at B = 32 the fp32
+    # oracle is the noisy side (tools/grad_noise_check.py: FFN Conv_0 weight gradient oracle-f32 vs f64 7.1e-3, this path's f32 vs f64 6.1e-4),
+    # which is why round 3 had to loosen the fp32-vs-fp32 bar to 1e-2
+    check_f32(config2_case, run_hip(config2_case, "f32"), grad_tol64=2e-3)
 
 
 def test_config2_batch32_bf16(config2_case):
@@ -185,6 +210,29 @@ def test_config2_batch32_bf16(config2_case):
     assert sum(n for k, n in counts.items() if k.startswith("wn_fwd<")) == 11, counts
     assert sum(n for k, n in counts.items() if k.startswith("wn_bwd<")) == 7, counts
     check_bf16(config2_case, r)
+
+
+def test_config3_batch32_speaker_lut():
+    """BASELINE config 3 at ITS per-GPU batch (SE, LUT of 109 speakers, B = 32 x 800 frames): the shape profiles/*_bench_config3.json times - the
+    conditioning gradient accumulated per utterance run at the chip-filling launch shapes (Modules.py:73-74, 863-866)."""
+    case = make_case("SE", [120] * 32, [800] * 32, 31, f64=True)
+    check_f32(case, run_hip(case, "f32"), grad_tol64=2e-3)
+    check_bf16(case, run_hip(case, "bf16"))
+
+
+def test_config4_batch16_ge2e_dvectors():
+    """BASELINE config 4 at its per-GPU batch (SE, GE2E d-vectors [B, 256], B = 16 x 800 frames): 125 fused workgroups leave CUs free, so the
+    backward takes the fused data-gradient kernel on ALL flows (decoder.TUNE["fused_wn_bwd"] automatic) - asserted - with the conditioning
+    gradient accumulated inside it (Modules.py:75-77, 863-866)."""
+    from helpers import launch_counts, launch_reset
+    tl, ml = _set_v(16, 11)
+    case = make_case("SE", tl, ml, 41, spk_type="GE2E", f64=True)
+    check_f32(case, run_hip(case, "f32"), grad_tol64=2e-3)
+    launch_reset()
+    r = run_hip(case, "bf16")
+    counts = launch_counts()
+    assert sum(n for k, n in counts.items() if k.startswith("wn_bwd<")) == 12, counts
+    check_bf16(case, r)
 
 
 @pytest.mark.parametrize("mode", ["SE", "PE"])

@@ -47,12 +47,12 @@ def _case(spk_dim, seed):
     return cfg, sd, mels, ml, spk, wz, wl
 
 
-def _oracle_grads(cfg, sd, mels, ml, spk, wz, wl):
+def _oracle_grads(cfg, sd, mels, ml, spk, wz, wl, drop=None):
     sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     x = mels.clone().requires_grad_(True)
     s = spk.clone().requires_grad_(True) if spk is not None else None
     mask = O.mask_from_lengths(ml, mels.shape[2])
-    zo, ldo, _ = O.decoder(sdg, x, mask, cfg, speakers=s)
+    zo, ldo, _ = O.decoder(sdg, x, mask, cfg, speakers=s, drop=drop)
     ((zo * wz).sum() + (ldo * wl).sum()).backward()
     return zo.detach(), ldo.detach(), {k: v.grad for k, v in sdg.items()}, x.grad, (s.grad if s is not None else None)
 
@@ -114,8 +114,9 @@ def test_full_width_backward_bf16_takes_the_benchmarked_kernels(spk_dim):
     assert _count(counts, "conv_dma<DGATE,1>") == (N_FLOWS - nfb) * (L - 1), counts
     assert _count(counts, "conv_chain<LINEAR,DGATE>") == N_FLOWS - nfb, counts
     assert _count(counts, "wgrad<5,bf16,dybf16,xbf16,wide>/grouped") == 1, counts        # all In_l weight gradients: one grouped launch
-    assert _count(counts, "wgrad<1,bf16,dybf16,xbf16,wide>/grouped") == 1, counts        # Res_Skip_l
-    assert _count(counts, "wgrad<1,bf16,dyf32,xf32,wide>/grouped") == 1, counts          # Start / End
+    # Res_Skip_l AND (round 4) Start / End, whose operands - d h0, x_a, d(m, logs), the skip sum - now exist as bf16 rows: one launch, no fp32 staging
+    assert _count(counts, "wgrad<1,bf16,dybf16,xbf16,wide>/grouped") == 1, counts
+    assert _count(counts, "wgrad<1,bf16,dyf32,xf32") == 0, counts
     assert _count(counts, "conv_cl<GATE") == 0 and _count(counts, "conv_cl<RESSKIP") == 0 and _count(counts, "conv_cl<DGATE") == 0, counts
     mask = O.mask_from_lengths(case[3], TM)
     rms = lambda t: t.double().pow(2).mean().sqrt().item()
@@ -175,3 +176,61 @@ def test_full_width_dropout_masks_agree_between_forward_backward_and_precisions(
     if ds32 is not None:
         a, b = ds16.flatten().double(), ds32.flatten().double()
         assert (a @ b / (a.norm() * b.norm())).item() >= 0.98
+
+
+def _hip_keep_multipliers(seed_word, flow, layer, B, T, H, p):
+    """The WaveNet dropout multipliers the HIP epilogues draw (csrc/device_common.h: drop_rowkey / drop_colkey / drop_draw), restated with
+    numpy uint32 arithmetic: [B, 2H, T] for gate pre-activation channel (tanh j | sigmoid H + j) of squeezed frame t of utterance b.
+    Row index = position in the rows layout [B][T + 4] (two pad rows in front of every utterance)."""
+    import numpy as np
+    u = lambda v: np.asarray(v, dtype=np.uint64) & 0xFFFFFFFF
+    thr = int(p * 65536.0 + 0.5)
+    ik = np.float32(65536.0) / np.float32(65536.0 - thr)
+    seed = (1000003 * flow + int(seed_word) + layer) & 0xFFFFFFFF
+    rows = (np.arange(B)[:, None] * (T + 4) + 2 + np.arange(T)[None, :]).astype(np.uint64)            # [B, T]
+    x = u(rows * 0x9E3779B1 + seed)
+    x ^= x >> 16
+    x = u(x * 0x85EBCA6B)
+    x ^= x >> 13
+    ck = u((np.arange(H, dtype=np.uint64) + 1) * 0x27D4EB2F)                                          # [H]
+    d = u((x[:, None, :] ^ ck[None, :, None]) * 0xC2B2AE35)                                           # [B, H, T]
+    d ^= d >> 16
+    keep_t, keep_s = (d & 0xFFFF) >= thr, (d >> 16) >= thr
+    m = np.concatenate([keep_t, keep_s], 1).astype(np.float32) * ik
+    return torch.from_numpy(m)
+
+
+def test_full_width_backward_f32_in_train_mode_with_the_same_dropout_masks():
+    """Training mode (Modules.py:861-862 WaveNet dropout, p = 0.1): the keep masks of the HIP path - a counter hash of (seed word, flow, layer,
+    row, channel pair) regenerated by the backward kernels - are restated on the host and INJECTED into the oracle, whose forward and
+    torch.autograd backward then see the same network: outputs and every gradient at the eval-mode bars (until now train
+    mode was covered by mask statistics and forward / backward consistency only)."""
+    p_drop = 0.1
+    case = _case(0, 777)
+    cfg, sd, mels, ml = case[0], case[1], case[2], case[3]
+    T, H = TM // cfg.n_squeeze, cfg.wn_channels
+    torch.manual_seed(99)
+    seed_word = int(torch.randint(0, 2 ** 31 - 1, (1,), device="cuda", dtype=torch.int32).item())     # the word DecoderFunction will draw
+    masks = {}
+
+    def drop(pfx, layer, ins):
+        flow = int(pfx.split(".Flows.")[1].split(".")[0])
+        key = (flow, layer)
+        if key not in masks:
+            masks[key] = _hip_keep_multipliers(seed_word, flow, layer, B, T, H, p_drop)
+        return ins * masks[key].to(ins.dtype)
+    zo, ldo, go, dxo, _ = _oracle_grads(*case, drop=drop)
+    torch.manual_seed(99)
+    z, ld, g, dx, _, counts = _hip_grads(*case, precision=0, drop_p=p_drop)
+    kept = torch.stack([m.ne(0).float().mean() for m in masks.values()]).mean().item()
+    assert len(masks) == N_FLOWS * 4 and abs(kept - (1 - p_drop)) < 5e-3, (len(masks), kept)
+    assert (z - zo).abs().max() <= 2e-4, (z - zo).abs().max()
+    assert ((ld - ldo).abs() <= 1e-3 * ldo.abs().clamp_min(1.0)).all()
+    worst = ("", 0.0)
+    for k, want in go.items():
+        err = (g[k] - want).abs().max().item() / (want.abs().max().item() + 1e-6)
+        worst = max(worst, (k, err), key=lambda t: t[1])
+        assert err <= 2e-3, (k, err)
+    mask = O.mask_from_lengths(ml, TM)
+    assert ((dx - dxo) * mask).abs().max() <= 2e-3 * dxo.abs().max()
+    print("train mode, f32, same dropout masks: worst gradient", worst, "kept fraction", kept)

@@ -43,6 +43,13 @@ def _make_dataset(root, mode):
         hp["Train"][key]["Mel_Length"] = {"Min": 2, "Max": 400}
         hp["Train"][key]["Text_Length"] = {"Min": 1, "Max": 60}
     hp["Train"].update(Batch_Size=4, Max_Step=9, Checkpoint_Save_Interval=4, Logging_Interval=3, Evaluation_Interval=100, Use_Pattern_Cache=True)
+    # the prompts `Trainer.Inference_Epoch` synthesises every Inference_Interval steps (Train.py:91-93, 259-260, 445-461); reference mels as .npy
+    np.save(os.path.join(root, "ref.npy"), rng.normal(0, 1.5, (57, 12)).clip(-4, 4).astype(np.float32))
+    with open(os.path.join(root, "prompts.txt"), "w") as f:
+        f.write("Label\tText\tLength_Scale\tSpeaker\tGE2E\tProsody\tPitch\n")
+        for i, text in enumerate(TEXTS[:4]):
+            f.write(f"P{i}\t{text}\t{1.0 + 0.1 * i}\t{i % 5}\t{root}/ref.npy\t{root}/ref.npy\t{root}/ref.npy\n")
+    hp["Train"].update(Inference_Interval=5, Inference_Pattern_File_in_Train=os.path.join(root, "prompts.txt"))
     hp["Checkpoint_Path"] = os.path.join(root, "Checkpoint")
     hp["Inference_Batch_Size"] = 3
     hp["Inference_Path"] = os.path.join(root, "Inference")
@@ -60,6 +67,12 @@ def test_train_resume_and_inference(mode, tmp_path):
     tr = Trainer(steps=0, hp=hp)
     tr.Train()
     assert tr.steps >= hp.Train.Max_Step
+    # Inference_Epoch ran when the step counter crossed Inference_Interval = 5: one .npy per prompt, batches of Inference_Batch_Size = 3
+    got = sorted(os.listdir(os.path.join(hp.Inference_Path, "Step-5", "NPY")))
+    assert got == [f"P{i}.npy" for i in range(4)], got
+    for f in got:
+        m = np.load(os.path.join(hp.Inference_Path, "Step-5", "NPY", f))
+        assert m.ndim == 2 and m.shape[1] == 12 and m.shape[0] >= 1 and np.isfinite(m).all()
     # the evaluation epoch ran forward AND inference on the dev batches (Train.py:279-316); Inference_Step names its files like the reference
     mp, a_train, a_inf, _ = tr.last_Evaluation
     assert torch.isfinite(mp).all() and a_train.shape[:2] == a_inf.shape[:2] and mp.shape[1] == 12
