@@ -475,6 +475,7 @@ def main():
                     "default: the whole Train_Step of Train.py:193-233 including clip_grad_norm_, RAdam and the Noam schedule")
     ap.add_argument("--timeline", action="store_true", help="diagnostics: stamp kernels inside the captured step (decoder flows, encoder milestones); "
                     "prints when each stream reached them in one replay (stderr) - adds ~40 tiny launches to the step")
+    ap.add_argument("--graph-execs", type=int, default=1, help="experiment: capture the step n times and replay the instances round-robin")
     ap.add_argument("--tune", action="append", default=[], help="A/B measurements: key=value entries of glow_tts_amd.decoder.TUNE (e.g. wgrad_wide=0)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on device 0 (multi-rank smoke test on a single-GPU box)")
     ap.add_argument("--no-overlap", action="store_true", help="data parallel: one graph + one gradient exchange instead of the two-graph overlap")
@@ -563,6 +564,7 @@ def main():
     from glow_tts_amd.distributed import global_frame_weight
     mode = "eager"
     graph = tail_graph = opt_graph = early = tail = None
+    extra_graphs, rr = [], [0]
     keep = []                                                   # pinned job tables owned by the captured graphs
     side = torch.cuda.Stream() if args.graph else None
     if args.graph:
@@ -632,6 +634,13 @@ def main():
                         static_loss = fwd_bwd()
                     if opt is not None and not dp:
                         uncount_capture_pass()
+                    for _ in range(max(0, args.graph_execs - 1) if not dp else 0):
+                        gx = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gx, capture_error_mode="global"):
+                            fwd_bwd()
+                        if opt is not None:
+                            uncount_capture_pass()
+                        extra_graphs.append(gx)
                 if opt is not None and dp:
                     # data parallel: the update reads the REDUCED gradients, so it is its own graph behind the exchange
                     opt_graph = torch.cuda.CUDAGraph()
@@ -658,7 +667,11 @@ def main():
         if graph is not None:
             if opt is not None and not dp:
                 opt[0].advance_host()                           # this step's hyper-parameter words, stream-ordered before the replay
-            graph.replay()
+            if extra_graphs:
+                rr[0] = (rr[0] + 1) % (len(extra_graphs) + 1)
+                (graph if rr[0] == 0 else extra_graphs[rr[0] - 1]).replay()
+            else:
+                graph.replay()
             if tail_graph is not None:
                 pending = early.begin()
                 tail_graph.replay()

@@ -163,7 +163,7 @@ TAIL = {"defer": False, "pending": []}
 #       stream at high priority (-1: 9.1 vs 5.6 ms/step - its ~170 short launches then take the CUs from under the chip-filling kernels)
 #   prep_fused: training on the fused bf16 path forms w = g v / ||v|| and every weight image in ONE launch (csrc/prep_ops.hip) instead of 4 weight-norm +
 #       ~22 packing launches (0.42 -> ~0.1 ms at the head of the step, round 4)
-TUNE = {"prep_fused": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0}
+TUNE = {"prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
@@ -346,6 +346,7 @@ class _Prepared:
         P = cfg.precision
         dev = W["an_logs"].device
         self.keep = W
+        stamp("dec_prepared_begin")
         self.winfo = torch.empty(F_, 36, device=dev)
         _lib.check(L.glowtts_inv1x1_prepare(_lib.ptr(W["inv_w"].contiguous()), _lib.ptr(self.winfo), F_, _lib.stream()), "inv1x1_prepare")
         jobs = PrepJobs() if GV is not None else None
@@ -412,7 +413,7 @@ class _Prepared:
         if nskip < 0:                                           # automatic: one flow when the batch's fused workgroups fill the chip (see fused_wn_bwd)
             nwg_ = -(-rows // (64 - 4 * (Lw - 1))) if rows else 0
             cus_ = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
-            nskip = 1 if 4 * nwg_ > 3 * cus_ else 0
+            nskip = 3 if 4 * nwg_ > 3 * cus_ else 0             # (round 4, with the early weight preparation: 1 / 2 / 3 / 4 flows = 5.36 / 5.31 / 5.28 / 5.29 ms/step on one box)
         nskip = min(nskip, F_) if (need_bwd and self.wn_img is not None) else 0
         pk_conv = None
         all_f = slice(None)
@@ -486,7 +487,9 @@ class _Prepared:
                 if t is not None:
                     t.record_stream(main_s)
         if jobs is not None:
+            stamp("dec_prep_begin")
             jobs.launch(dev)
+            stamp("dec_prep_end")
             self.prep_jobs = jobs                                              # (keeps the job table and the tensors it points into)
         self.ldo = self.pk["end"].npad
         self.ldin = self.pk["in"].npad
@@ -730,6 +733,29 @@ def actnorm_data_init(cfg, W, mels, lengths, cond=None, allreduce=None, pitch=No
             bufs.reverse()
 
 
+# The weight preparation of a training step can be issued BEFORE the text encoder is launched on its stream (modules.GlowTTS.forward): inside a
+# replayed hipGraph the decoder's branch otherwise starts ~180 us after the encoder's (measured with in-graph stamps: the runtime reaches the nodes of
+# the second branch late), and the 80-us preparation launch sat behind that.  `early_prepare` builds the _Prepared; DecoderFunction.forward picks it up.
+EARLY = {"prep": None, "key": None}
+
+
+def _split_gv(weights):
+    A = dict(zip(WEIGHT_KEYS_GV, [w.detach().contiguous() for w in weights]))
+    GV = {k: (A.pop("g" + k[1:]), A.pop("v" + k[1:])) for k in WN_KEYS}
+    return A, GV
+
+
+def early_prepare(cfg, weights, mel_shape, fused_bwd_ok=True):
+    """weights: DecoderStacks.weights(gv=True).  Must be followed by DecoderFunction.apply on the same weights in the same forward."""
+    if len(weights) != len(WEIGHT_KEYS_GV):
+        return
+    W, GV = _split_gv(weights)
+    need_bwd = any(w.requires_grad for w in weights)
+    EARLY["prep"] = _Prepared(cfg, W, need_bwd=need_bwd, cond=None, fused_bwd_ok=fused_bwd_ok,
+                              rows=mel_shape[0] * (mel_shape[2] // cfg.ns + 2 * ROW_PAD), GV=GV)
+    EARLY["key"] = (tuple(w.data_ptr() for w in weights), need_bwd, bool(fused_bwd_ok), GV)
+
+
 class DecoderFunction(torch.autograd.Function):
     """z, logdet = Decoder(mels)   with autograd through the hand-written backward kernels."""
 
@@ -738,16 +764,20 @@ class DecoderFunction(torch.autograd.Function):
         """pitches [B, Tm] / pitch_w [F, L, 2H, ns] / pitch_b [F, L, 2H]: the GR-mode per-frame pitch conditioning (Modules.py:867-869), else None."""
         GV = None
         if len(weights) == len(WEIGHT_KEYS_GV):
-            A = dict(zip(WEIGHT_KEYS_GV, [w.detach().contiguous() for w in weights]))
-            GV = {k: (A.pop("g" + k[1:]), A.pop("v" + k[1:])) for k in WN_KEYS}
-            W = A
+            W, GV = _split_gv(weights)
         else:
             W = dict(zip(WEIGHT_KEYS, [w.detach().contiguous() for w in weights]))
         need_bwd = any(w.requires_grad for w in weights) or mels.requires_grad or (cond is not None and cond.requires_grad) or \
             (pitch_w is not None and pitch_w.requires_grad)
         condc = cond.detach().contiguous() if cond is not None else None
-        prep = _Prepared(cfg, W, need_bwd=need_bwd, cond=condc, fused_bwd_ok=pitches is None,
-                         rows=mels.shape[0] * (mels.shape[2] // cfg.ns + 2 * ROW_PAD), GV=GV)
+        early, ekey = EARLY["prep"], EARLY["key"]
+        EARLY["prep"] = EARLY["key"] = None
+        if early is not None and GV is not None and ekey[0] == tuple(w.data_ptr() for w in weights) and ekey[1] == need_bwd and ekey[2] == (pitches is None):
+            prep, GV = early, ekey[3]                           # (issued before the encoder's launches; the same weights)
+            prep.set_cond(condc)
+        else:
+            prep = _Prepared(cfg, W, need_bwd=need_bwd, cond=condc, fused_bwd_ok=pitches is None,
+                             rows=mels.shape[0] * (mels.shape[2] // cfg.ns + 2 * ROW_PAD), GV=GV)
         ctx.GV = GV
         # one random word on the device (torch's graph-safe generator); kept for the backward, which regenerates the masks
         seed = torch.randint(0, 2 ** 31 - 1, (1,), device=mels.device, dtype=torch.int32) if drop_p > 0 else None

@@ -309,19 +309,28 @@ class GlowTTS(torch.nn.Module):
         # Encoder and decoder are independent until the log-prior: the encoder runs on its own HIP stream, concurrently with the
         # flow decoder whose latency-bound kernels leave CUs idle.  autograd replays each backward on its forward stream, so the
         # two backward passes overlap as well.
+        decoder.stamp("fwd_enter_main")
+        # the decoder's weight preparation goes out first: see decoder.EARLY
+        stacks = self._stacks(P)
+        use_gv = bool(decoder.TUNE["prep_fused"] and torch.is_grad_enabled() and decoder.fused_wn_supported(self.dec_cfg) and
+                      self.dec_cfg.precision == ops.BF16)
+        W = stacks.weights(gv=use_gv)
         main = torch.cuda.current_stream()
         if self._enc_stream is None:
             self._enc_stream = torch.cuda.Stream(priority=int(decoder.TUNE["enc_priority"]))      # (experiment: -1 = high priority)
         side = self._enc_stream if self.overlap_encoder else main
         side.wait_stream(main)
         prior_ready = torch.cuda.Event() if side is not main else None
+        # (behind the fork: the encoder's stream does not wait for it)
+        if use_gv and decoder.TUNE["prep_early"] and all(f.layers[0].initialized for f in self._flows()):
+            decoder.early_prepare(self.dec_cfg, W, mels.shape, fused_bwd_ok=(pitches is None or "Pitch_v" not in stacks.S))
         with torch.cuda.stream(side):
             # (the token mask is the encoder's: built on its stream, so that the decoder's chain starts with its own weight preparation)
             token_mask = self.Mask_Generate(token_lengths, tokens.shape[1])
             mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, self.training, precision=self.dec_cfg.precision,
                                                              cache=self._enc_cache,
                                                              on_prior_ready=(lambda: prior_ready.record(side)) if prior_ready is not None else None)
-        stacks = self._stacks(P)
+        decoder.stamp("main_after_enc_launch")
         cond = stacks.conditioning(spk, pro)
         pitch_w, pitch_b = stacks.pitch_weights()
         if pitch_w is None:
@@ -329,10 +338,7 @@ class GlowTTS(torch.nn.Module):
         elif pitches is None:
             raise ValueError("GR mode needs `pitches` [Batch, Mel_t] (Modules.py:58, 867-869)")
         self._maybe_init_actnorm(P, mels, mel_lengths, cond, None if pitches is None else (pitches, pitch_w.detach(), pitch_b.detach()))
-        # (training on the fused bf16 path: the weight-norm pairs themselves - DecoderFunction prepares every weight image in one launch)
-        use_gv = bool(decoder.TUNE["prep_fused"] and torch.is_grad_enabled() and decoder.fused_wn_supported(self.dec_cfg) and
-                      self.dec_cfg.precision == ops.BF16)
-        W = stacks.weights(gv=use_gv)
+        # (training on the fused bf16 path: W holds the weight-norm pairs themselves - every weight image was prepared by one launch above)
         drop_p = float(hp.Decoder.Affine_Coupling.WaveNet.Dropout_Rate) if self.training else 0.0      # Modules.py:854-862
         z, log_dets, z_rows = decoder.DecoderFunction.apply(self.dec_cfg, mels, mel_lengths, cond, drop_p, pitches, pitch_w if pitches is not None else None,
                                                             pitch_b if pitches is not None else None, *W)
