@@ -325,6 +325,7 @@ class GlowTTS(torch.nn.Module):
         if use_gv and decoder.TUNE["prep_early"] and all(f.layers[0].initialized for f in self._flows()):
             decoder.early_prepare(self.dec_cfg, W, mels.shape, fused_bwd_ok=(pitches is None or "Pitch_v" not in stacks.S))
         with torch.cuda.stream(side):
+            decoder.stamp("enc_branch_first_node")
             # (the token mask is the encoder's: built on its stream, so that the decoder's chain starts with its own weight preparation)
             token_mask = self.Mask_Generate(token_lengths, tokens.shape[1])
             mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, self.training, precision=self.dec_cfg.precision,
