@@ -475,6 +475,7 @@ def main():
                     "default: the whole Train_Step of Train.py:193-233 including clip_grad_norm_, RAdam and the Noam schedule")
     ap.add_argument("--timeline", action="store_true", help="diagnostics: stamp kernels inside the captured step (decoder flows, encoder milestones); "
                     "prints when each stream reached them in one replay (stderr) - adds ~40 tiny launches to the step")
+    ap.add_argument("--sync-each", action="store_true", help="experiment: synchronise after every step (no replay is enqueued ahead) and report the host time of a replay call")
     ap.add_argument("--graph-execs", type=int, default=1, help="experiment: capture the step n times and replay the instances round-robin")
     ap.add_argument("--tune", action="append", default=[], help="A/B measurements: key=value entries of glow_tts_amd.decoder.TUNE (e.g. wgrad_wide=0)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on device 0 (multi-rank smoke test on a single-GPU box)")
@@ -687,11 +688,19 @@ def main():
             return static_loss
         return train_step(model, mle_loss, batch, cond, reducer, world, opt)
 
+    host_replay = []
+
     def timed_window():
         barrier()
         t0 = time.time()
         for _ in range(args.steps):
-            out = one_step()
+            if args.sync_each:
+                h0 = time.time()
+                out = one_step()
+                host_replay.append(time.time() - h0)
+                torch.cuda.synchronize()
+            else:
+                out = one_step()
         barrier()
         el = time.time() - t0
         if dp:
@@ -703,6 +712,8 @@ def main():
 
     one_step()
     elapsed, loss = timed_window()                              # the reported window: exactly --steps steps
+    if args.sync_each and rank == 0:
+        print(f"[sync-each] host time of one step's enqueue (replay call): median {sorted(host_replay)[len(host_replay) // 2] * 1e6:.0f} us", file=sys.stderr)
     extra = [timed_window()[0] for _ in range(max(0, args.windows))]
     if args.timeline and rank == 0:
         # the captured pass stamped last: its slots are the last occurrence of every name; one more replay fills them
