@@ -717,7 +717,12 @@ def main():
     extra = [timed_window()[0] for _ in range(max(0, args.windows))]
     if args.timeline and rank == 0:
         # the captured pass stamped last: its slots are the last occurrence of every name; one more replay fills them
-        torch.cuda.synchronize(); one_step(); torch.cuda.synchronize()
+        # (four replays enqueued back to back: the stamps are those of the LAST one, whose launches were enqueued while its predecessors ran -
+        # a single replay on an idle GPU exposes the host's enqueue order: the branch enqueued second then starts ~200 us late)
+        torch.cuda.synchronize()
+        for _ in range(4):
+            one_step()
+        torch.cuda.synchronize()
         names, buf = _dec.STAMPS["names"], _dec.STAMPS["buf"].cpu()
         last = {n: i for i, n in enumerate(names)}
         ev = sorted(((int(buf[i]), n) for n, i in last.items() if int(buf[i]) > 0))
