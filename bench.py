@@ -91,8 +91,12 @@ def build_model(precision, device, mode="Vanilla", spk_type="LUT"):
 def forward_losses(model, mle_loss, batch, cond):
     tokens, tl, mels, ml = batch
     z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, _, _ = model(tokens, tl, mels, ml, cond[0], cond[1], None)
+    from glow_tts_amd.modules import Beside
+    with Beside(model) as beside:                                                        # (as Trainer._losses: beside the MLE reduction)
+        beside.uses(log_dur, log_dur_t)
+        length = torch.nn.functional.mse_loss(log_dur, log_dur_t)                        # Train.py:203-211
     mle = mle_loss(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=ml)
-    length = torch.nn.functional.mse_loss(log_dur, log_dur_t)                            # Train.py:203-211
+    beside.join(length)
     return mle, length
 
 

@@ -84,17 +84,22 @@ def maximum_path_t(value_t, token_lengths, mel_lengths, max_neg_val=-1e9):
 
 
 class ExpandPrior(torch.autograd.Function):
-    """src @ attentions for one-hot-per-frame attentions (Modules.py:120-121): gather by the MAS token index."""
+    """src @ attentions for one-hot-per-frame attentions (Modules.py:120-121): gather by the MAS token index.
+
+    bwd_stream: the stream `src` was produced on when that is not the caller's (the text encoder's, GlowTTS.forward).  The backward - a
+    frames -> tokens reduction that only the encoder's backward consumes - is then launched THERE, behind the caller's stream: the flow
+    decoder's backward, next on the caller's stream, does not queue behind it (2 x ~10 us per step), and the consumers, which autograd
+    replays on that same stream, are ordered behind it by the stream itself."""
 
     @staticmethod
-    def forward(ctx, src, idx):
+    def forward(ctx, src, idx, bwd_stream=None):
         src = src.contiguous()
         B, C, Tx = src.shape
         Ty = idx.shape[1]
         out = torch.empty(B, C, Ty, device=src.device)
         _lib.check(_lib2().glowtts_expand_fwd(_lib.ptr(src), _lib.ptr(idx), _lib.ptr(out), B, C, Tx, Ty, _lib.stream()), "glowtts_expand_fwd")
         ctx.save_for_backward(idx)
-        ctx.Tx = Tx
+        ctx.Tx, ctx.bwd_stream = Tx, bwd_stream
         return out
 
     @staticmethod
@@ -102,9 +107,20 @@ class ExpandPrior(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         dout = dout.contiguous()
         B, C, Ty = dout.shape
-        dsrc = torch.empty(B, C, ctx.Tx, device=dout.device)
-        _lib.check(_lib2().glowtts_expand_bwd(_lib.ptr(dout), _lib.ptr(idx), _lib.ptr(dsrc), B, C, ctx.Tx, Ty, _lib.stream()), "glowtts_expand_bwd")
-        return dsrc, None
+        cur, s = torch.cuda.current_stream(), ctx.bwd_stream
+
+        def run():
+            dsrc = torch.empty(B, C, ctx.Tx, device=dout.device)
+            _lib.check(_lib2().glowtts_expand_bwd(_lib.ptr(dout), _lib.ptr(idx), _lib.ptr(dsrc), B, C, ctx.Tx, Ty, _lib.stream()), "glowtts_expand_bwd")
+            return dsrc
+        if s is None or s == cur:
+            return run(), None, None
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            dsrc = run()
+        dout.record_stream(s)
+        idx.record_stream(s)
+        return dsrc, None, None
 
 
 @torch.no_grad()

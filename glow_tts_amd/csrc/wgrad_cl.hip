@@ -371,6 +371,265 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const glowtts_wgrad_job singl
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// wgrad_dma_kernel (round 4): the same weight gradient for problems whose operands are BOTH bf16 rows tensors with no prologue (the decoder's In_l
+// group: 36 problems of 384 x 192 x 5 taps over 12 928 rows), rebuilt on what tools/wn_lab.hip measured:
+//   * ds_read_b64_tr_b16 delivers ~118 B/clk per CU (profiles/r04_wn_lab_tr.txt), not the 256 of plain 8-byte reads: the staged kernel's 32 x 32
+//     (x taps) wave tiles need 1.2 transposing reads per 16x16x32-equivalent MFMA - ~1 950 clocks of reads per workgroup step against 1 280 of MFMAs.
+//     Wave tiles of 96 (o) x 32 (c) x taps here: 0.53 reads per MFMA, 240 accumulators a wave at 5 taps, one workgroup of four waves per CU.
+//   * operands go global -> LDS by LDS-DMA (buffer_load ... lds, 16 bytes per lane): no VGPR staging, no ds_write (316 of the staged kernel's 1 280
+//     MFMA clocks per step).  Rows outside [0, rows) - the tap halo, a partial last step - read as zeros through the descriptor's bounds check.
+//   * v_mfma_f32_16x16x32_bf16: between back-to-back 32x32x16 MFMAs a SIMD issues no vector-memory instruction.
+//   * tiles stay row-major (that is how the DMA delivers them), padded so that every transposing read is conflict-free AND addressed by one
+//     lane-constant register plus an immediate; ds_read_b64_tr_b16 transposes.
+//   * one software pipeline across steps: fragments two iterations ahead, DMAs two to three steps ahead, one barrier per step (below).
+// Alone on the chip, the In_l group: 338 us (1.01 PFLOP/s, 216 workgroups) against 491-540 us for the staged kernel; MFMAs alone 216 us, DMAs
+// alone 155 us, reads alone 114 us (tools/bench_wgrad.py and its ablations).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+typedef int i32x4w __attribute__((ext_vector_type(4)));
+constexpr int DBK = 64, DBMO = 192, DNW = 4, DNT = DNW * 64;
+constexpr int DMO = 6;                                       // 16-channel o fragments of a wave tile; waves: 2 (o halves of 96) x 2 (c halves)
+// LDS layouts, chosen so that EVERY fragment read is one lane-constant VGPR plus an immediate (the 56 reads of a step with XOR-swizzled natural rows took ~30
+// address registers and spilled the accumulator tile).  The k index of the MFMA is free as long as both operands agree: element e = r + 4 h of lane group
+// kg is tile row 32 k + kg + 4 r + 16 h, so the 16 lane rows of one transposing read are 16 CONSECUTIVE tile rows.
+// Both tiles are row-major with rows of (tile channels x 2 + 32 pad) bytes - an odd multiple of 32: the 16 consecutive rows x 32 bytes of a read land on the 8
+// bank groups twice each (the minimum for 512 bytes) at any tap shift.  (A fragment-ordered DY tile - 512 contiguous bytes per read, no pad - reads as well
+// but its DMAs gather 64-byte pieces of 16 rows each and ran at ~24 B/clk per CU; whole 384-byte rows per instruction restore the streaming rate.)
+// The DMA places any 16 global bytes at any 16 LDS bytes (per-lane source offsets), so both layouts cost nothing to produce; pad lanes fetch zeros from beyond
+// the descriptor.
+constexpr int DYRS = DBMO * 2 + 32, DDY_BYTES = DBK * DYRS, DNDY = DDY_BYTES / 1024;       // 416-byte rows, 26 KiB = 26 DMA instructions per stage
+static_assert(DDY_BYTES % 1024 == 0 && DYRS % 64 == 32, "DY tile geometry");
+// Tile shape per tap count.  k taps re-use a DY fragment k times, so 5 taps are MFMA-bound on a 192 x 64 tile (240 accumulators a wave); at 1 tap the same
+// tile would move 35 KiB per 384 MFMA clocks - the one-tap kernel takes ALL of a 192-channel input per tile instead (192 x 192: DY is read once, 144
+// accumulators, 51 KiB per 1 152 MFMA clocks) and runs on as few CUs as it has tiles, leaving the rest of the chip to the launches beside it.
+template <int TAPS> struct DCfg {
+    static constexpr int NC = TAPS == 1 ? 6 : 2;             // 16-channel c fragments of a wave tile
+    static constexpr int BNC = 2 * 16 * NC;                  // tile input channels: 192 / 64
+    static constexpr int XRS = BNC * 2 + 32;                 // X row stride in LDS: 416 / 160 bytes
+    static constexpr int X_BYTES = (DBK + TAPS - 1) * XRS;   // rows of a step + the tap halo
+    static constexpr int STAGE = DDY_BYTES + X_BYTES;        // 53 248 (x 3 stages) / 37 504 (x 4 stages) bytes: one workgroup per CU
+    static constexpr int STAGES = TAPS == 1 ? 3 : 4;
+    static constexpr int NDMA = DNDY + (X_BYTES + 1023) / 1024;
+    static constexpr int SLOTS = (NDMA + DNW - 1) / DNW;     // DMA instructions per wave and stage: 13 / 9
+    static_assert(XRS % 64 == 32 && STAGE % 16 == 0 && STAGES * STAGE <= 160 * 1024, "LDS geometry");
+};
+
+// The 240 accumulator registers of a wave live in AGPRs BY CONSTRUCTION: left to the register allocator the 5-tap kernel came out with 428 v_accvgpr moves and
+// scratch reloads (each behind an s_waitcnt vmcnt(0) that also waits for the DMAs in flight) inside the step loop.
+static __device__ __forceinline__ void mfma_acc(f32x4w& c, const bf16x8& a, const bf16x8& b)
+{
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(DNT) void wgrad_dma_kernel(const glowtts_wgrad_job* __restrict__ table, const WCommon cm)
+{
+    typedef DCfg<TAPS> K;
+    constexpr int DNC = K::NC, DBNC = K::BNC, DXRS = K::XRS, DX_BYTES = K::X_BYTES, DSTAGE = K::STAGE, DSTAGES = K::STAGES, DNDMA = K::NDMA, DSLOTS = K::SLOTS;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char dsm[];
+    int tile = blockIdx.x;
+    if (cm.xcd) {
+        const int G = gridDim.x, q = G >> 3, r = G & 7, x = tile & 7, k = tile >> 3;
+        tile = x * q + min(x, r) + k;
+    }
+    int lo = 0, hi = cm.njobs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[mid].tile0 <= tile) lo = mid; else hi = mid - 1; }
+    const glowtts_wgrad_job p = table[lo];
+    tile -= p.tile0;
+    const int tile_o = tile % p.mt, tile_c = tile / p.mt;
+    const int o0 = tile_o * DBMO, c0 = tile_c * DBNC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                 // wave tile: o [96 wm, + 96) x c [16 NC wn, + 16 NC)
+    const int s16 = lane & 15, kg = lane >> 4;
+    const int nsteps = (cm.rows + DBK - 1) / DBK;
+    // buffer descriptors by hand (raw buffer, 32-bit offsets checked against the byte size) for the DMA below, which is issued from inline assembly: through the
+    // builtin the compiler orders every later LDS read behind it with s_waitcnt vmcnt(0) - a full memory round trip at the head of every step
+    auto make_rsrc = [](const void* ptr, int64_t bytes) __attribute__((always_inline)) -> i32x4w {
+        const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+        return i32x4w{(int)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), (int)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32) & 0xFFFF),
+                      (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+    };
+    const i32x4w rdy = make_rsrc(p.dy, (int64_t)cm.rows * p.lddy * 2), rx = make_rsrc(p.x, (int64_t)cm.rows * p.ldx * 2);
+    // ---- this wave's DMA slots per stage: slot j = instruction SLOTS wave + j (those past the last repeat it: same bytes to the same place, and every wave counts SLOTS).
+    // Per-lane byte offsets inside the operand for step 0; + 64 rows per step ----
+    // (branch-free: q is a wave-uniform run-time value.)  The last X instruction is pulled back to END at the tile's end - it overlaps its predecessor
+    // with the same data - so that nothing is written into the next stage.
+    uint32_t voff[DSLOTS];
+    auto x_base = [](int q) __attribute__((always_inline)) -> int { const int b = (q - DNDY) * 1024; return b > DX_BYTES - 1024 ? DX_BYTES - 1024 : b; };
+#pragma unroll
+    for (int j = 0; j < DSLOTS; ++j) {
+        int q = wave * DSLOTS + j;
+        q = q >= DNDMA ? DNDMA - 1 : q;
+        // padded rows; pad bytes come from beyond any operand, X rows in front of the tensor wrap past the descriptor's size (zeros both)
+        const int Pd = q * 1024 + lane * 16, rowd = Pd / DYRS, wd = Pd % DYRS;
+        const uint32_t vd = wd < DBMO * 2 ? (uint32_t)((rowd * p.lddy + o0) * 2 + wd) : 0x80000000u;
+        const int P = x_base(q) + lane * 16, rowx = P / DXRS, w = P % DXRS;
+        const uint32_t vx = w < DBNC * 2 ? (uint32_t)(((rowx - cm.pad) * p.ldx + c0) * 2 + w) : 0x80000000u;
+        voff[j] = q < DNDY ? vd : vx;
+    }
+    const uint32_t stepdy = (uint32_t)(DBK * p.lddy * 2), stepx = (uint32_t)(DBK * p.ldx * 2);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(void __attribute__((address_space(3)))*)dsm;
+    auto issue = [&](int step) __attribute__((always_inline)) {        // (called for steps 0, 1, 2, ... in order: the offsets advance in place)
+        const uint32_t st = lds0 + (uint32_t)((step % DSTAGES) * DSTAGE);
+#pragma unroll
+        for (int j = 0; j < DSLOTS; ++j) {
+            int q = wave * DSLOTS + j;
+            q = q >= DNDMA ? DNDMA - 1 : q;
+            const bool isx = q >= DNDY;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(st + (uint32_t)(isx ? DDY_BYTES + x_base(q) : q * 1024));
+            const i32x4w rs = isx ? rx : rdy;
+            asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voff[j]), "s"(rs), "s"(dst) : "memory", "m0");
+            voff[j] += isx ? stepx : stepdy;
+        }
+    };
+
+    f32x4w acc[DMO][DNC][TAPS];
+    float bsum[DMO];                                         // dbias partial of this lane: DY column 64 wm + 16 mo + s16, the rows of its k group
+#pragma unroll
+    for (int mo = 0; mo < DMO; ++mo) {
+        bsum[mo] = 0.f;
+#pragma unroll
+        for (int nc = 0; nc < DNC; ++nc)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[mo][nc][t] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool want_bias = (p.dbias != nullptr) && tile_c == 0 && wn == 0;
+
+    auto tr = [](const unsigned char* ptr) __attribute__((always_inline)) -> s16x4 {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ptr));
+    };
+    const int a_lane = (kg + 4 * (s16 >> 2)) * DYRS + wm * (DMO * 32) + (s16 & 3) * 8;            // + (32 k + 16 h) * 416 + mo * 32
+    const int b_lane = DDY_BYTES + (kg + 4 * (s16 >> 2)) * DXRS + wn * (DNC * 32) + (s16 & 3) * 8;   // + (32 k + 16 h + t) * XRS + nc * 32
+
+    // ---- one software pipeline over ALL (step, k block, tap) iterations.  With one wave per SIMD nobody else fills a wave's stalls, so nothing may wait for
+    // what was just asked for: the B fragments are read PF iterations ahead (a ring of RING sets; NIT is a multiple of RING, so the slot of an iteration is
+    // static across steps), the A fragments of the next k block replace the current ones as soon as their last MFMA has been issued, and both run across
+    // the step boundary: the step's only barrier sits PF iterations before its end - there every wave's DMAs of step s + 1 have landed (with four stages those of
+    // s + 2 may fly) and every wave has left step s - 1, whose stage the DMAs of step s + STAGES - 1 are then issued into.  Every step issues its DSLOTS DMAs, past the end
+    // too (rows beyond the operands read as zeros into a stage nobody reads any more), so the wait count is a constant; the reads that run ahead of the
+    // last step fetch stale bytes that no MFMA consumes. ----
+    constexpr int NIT = (DBK / 32) * TAPS, RING = TAPS == 1 ? 2 : TAPS, PF = TAPS == 1 ? 1 : 2;
+    static_assert(NIT % RING == 0 && PF < RING && DSTAGES >= 3, "pipeline geometry");
+    bf16x8 af[DMO], bfr[RING][DNC];
+    auto readA1 = [&](const unsigned char* base, int k32, int mo) __attribute__((always_inline)) {
+        s16x4 tmp[2] = {tr(base + (32 * k32) * DYRS + mo * 32), tr(base + (32 * k32 + 16) * DYRS + mo * 32)};
+        af[mo] = *reinterpret_cast<bf16x8*>(tmp);
+    };
+    auto readB = [&](const unsigned char* base, int it) __attribute__((always_inline)) {
+        const int k32 = it / TAPS, t = it % TAPS;
+#pragma unroll
+        for (int nc = 0; nc < DNC; ++nc) {
+            s16x4 tmp[2] = {tr(base + (32 * k32 + t) * DXRS + nc * 32), tr(base + (32 * k32 + 16 + t) * DXRS + nc * 32)};
+            bfr[it % RING][nc] = *reinterpret_cast<bf16x8*>(tmp);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < DSTAGES - 1; ++i) issue(i);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((DSTAGES - 2) * DSLOTS) : "memory");
+#pragma unroll
+    for (int mo = 0; mo < DMO; ++mo) readA1(dsm + a_lane, 0, mo);
+#pragma unroll
+    for (int i = 0; i < PF; ++i) readB(dsm + b_lane, i);
+    for (int s = 0; s < nsteps; ++s) {
+        const unsigned char* sa = dsm + (s % DSTAGES) * DSTAGE + a_lane;
+        const unsigned char* sb = dsm + (s % DSTAGES) * DSTAGE + b_lane;
+        const unsigned char* na = dsm + ((s + 1) % DSTAGES) * DSTAGE + a_lane;
+        const unsigned char* nb = dsm + ((s + 1) % DSTAGES) * DSTAGE + b_lane;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int k32 = it / TAPS, t = it % TAPS;
+            if (it == NIT - PF) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((DSTAGES - 3) * DSLOTS) : "memory");
+                issue(s + DSTAGES - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (it + PF < NIT) readB(sb, it + PF);
+            else               readB(nb, it + PF - NIT);
+            __builtin_amdgcn_sched_barrier(0);
+            if (want_bias && t == 0) {                       // (VALU, in the shadow of the MFMAs; one wave of four in a third of the tiles)
+#pragma unroll
+                for (int mo = 0; mo < DMO; ++mo) {
+                    const uint32_t* w = reinterpret_cast<const uint32_t*>(&af[mo]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bsum[mo] += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xFFFF0000u);
+                }
+            }
+#pragma unroll
+            for (int nc = 0; nc < DNC; ++nc)
+#pragma unroll
+                for (int mo = 0; mo < DMO; ++mo) {
+                    mfma_acc(acc[mo][nc][t], af[mo], bfr[it % RING][nc]);
+                    if (nc == DNC - 1 && t == TAPS - 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (it + 1 < NIT) readA1(sa, k32 + 1, mo);
+                        else              readA1(na, 0, mo);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // (the last MFMAs' results are read below by instructions the compiler does not know to depend on an MFMA)
+    // ---- epilogue: dW[o][c][t]; accumulator element i of fragment (mo, nc): o column 64 wm + 16 mo + 4 kg + i, c = 16 NC wn + 16 nc + s16 ----
+    if (want_bias) {                                         // the four k groups of a column: lanes s16, s16 + 16, + 32, + 48
+#pragma unroll
+        for (int mo = 0; mo < DMO; ++mo) {
+            float v = bsum[mo];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int pcol = o0 + wm * (16 * DMO) + mo * 16 + s16;
+            int o = pcol;
+            bool ok = pcol < p.m;
+            if (p.perm == GLOWTTS_PERM_PAIR) {
+                const int j = (pcol >> 6) * 32 + (pcol & 31);
+                ok = ok && j < p.perm_h;
+                o = ((pcol >> 5) & 1) * p.perm_h + j;
+            }
+            if (ok && kg == 0) p.dbias[o] = v;
+        }
+    }
+#pragma unroll
+    for (int mo = 0; mo < DMO; ++mo)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pcol = o0 + wm * (16 * DMO) + mo * 16 + 4 * kg + i;            // DY column (possibly PAIR-packed)
+            int o = pcol;
+            bool ok = pcol < p.m;
+            if (p.perm == GLOWTTS_PERM_PAIR) {
+                const int j = (pcol >> 6) * 32 + (pcol & 31);
+                ok = ok && j < p.perm_h;
+                o = ((pcol >> 5) & 1) * p.perm_h + j;
+            }
+            if (!ok) continue;
+#pragma unroll
+            for (int nc = 0; nc < DNC; ++nc) {
+                const int c = c0 + wn * (DNC * 16) + nc * 16 + s16;
+                if (c < p.ca) {
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t) p.dw[((long)o * p.ca + c) * TAPS + t] = acc[mo][nc][t][i];
+                }
+            }
+        }
+}
+
+// the big decoder group qualifies when every job does: checked on the host by the caller (glowtts_wgrad_grouped_io, WIO_DMA)
+template <int TAPS>
+int launch_wgrad_dma(const glowtts_wgrad_job* table, const WCommon& cm, dim3 grid, hipStream_t s)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, DCfg<TAPS>::STAGES * DCfg<TAPS>::STAGE) != hipSuccess) return GLOWTTS_E_LAUNCH;
+        attr_done = true;
+    }
+    GLOWTTS_NOTE_STATIC("wgrad_dma<%d>/grouped", TAPS);
+    hipLaunchKernelGGL((wgrad_dma_kernel<TAPS>), grid, dim3(DNT), DCfg<TAPS>::STAGES * DCfg<TAPS>::STAGE, s, table, cm);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
 template <typename CT, int XPRO, bool DYBF, bool XBF, bool WIDE = false>
 int launch_x(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const WCommon& cm, int taps, dim3 grid, hipStream_t s)
 {
@@ -447,6 +706,20 @@ extern "C" int glowtts_wgrad_grouped_io(const glowtts_wgrad_job* dev_jobs, int n
 {
     if (!dev_jobs || njobs < 1 || total_tiles < 1 || rows < 1) return GLOWTTS_E_ARG;
     if (splits < 1) splits = 1;
+    if (io_flags & GLOWTTS_WIO_DMA) {
+        // the caller promises: bf16 precision, both operands bf16 rows, no prologue, (mt, nt) of every job counted in 192 x 64 tiles (192 x 192 at one tap), 16-byte
+        // aligned operands and row strides, operands below 2 GiB; no split-K, no accumulation
+        if (precision != GLOWTTS_BF16 || xpro != GLOWTTS_APRO_NONE || splits != 1 || accumulate || pad != (taps - 1) / 2 ||
+            (io_flags & (GLOWTTS_WIO_DY_BF16 | GLOWTTS_WIO_X_BF16)) != (GLOWTTS_WIO_DY_BF16 | GLOWTTS_WIO_X_BF16)) return GLOWTTS_E_ARG;
+        WCommon cmd{rows, pad, 0, njobs, xcd_mode()};
+        hipStream_t sd = static_cast<hipStream_t>(stream);
+        switch (taps) {
+            case 1: return launch_wgrad_dma<1>(dev_jobs, cmd, dim3(total_tiles), sd);
+            case 3: return launch_wgrad_dma<3>(dev_jobs, cmd, dim3(total_tiles), sd);
+            case 5: return launch_wgrad_dma<5>(dev_jobs, cmd, dim3(total_tiles), sd);
+            default: return GLOWTTS_E_ARG;
+        }
+    }
     glowtts_wgrad_job dummy;
     memset(&dummy, 0, sizeof(dummy));
     dummy.mt = 1; dummy.nt = 1;

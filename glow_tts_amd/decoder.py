@@ -163,7 +163,7 @@ TAIL = {"defer": False, "pending": []}
 #       stream at high priority (-1: 9.1 vs 5.6 ms/step - its ~170 short launches then take the CUs from under the chip-filling kernels)
 #   prep_fused: training on the fused bf16 path forms w = g v / ||v|| and every weight image in ONE launch (csrc/prep_ops.hip) instead of 4 weight-norm +
 #       ~22 packing launches (0.42 -> ~0.1 ms at the head of the step, round 4)
-TUNE = {"prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0}
+TUNE = {"wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
@@ -222,24 +222,38 @@ class WgradGroup:
         self.table = None
         # 16-byte staging items (glowtts_wgrad WIO_WIDE): both operands bf16, no prologue, and every job 8-channel / 16-byte aligned
         self._wide = io_flags in (0, ops.WIO_DY_BF16 | ops.WIO_X_BF16) and xpro == ops.APRO_NONE and precision == ops.BF16 and TUNE["wgrad_wide"]
+        # the LDS-DMA / 16x16x32 kernel (csrc/wgrad_cl.hip wgrad_dma_kernel): both operands bf16 rows
+        self._dma = self._wide and io_flags == (ops.WIO_DY_BF16 | ops.WIO_X_BF16) and bool(TUNE["wgrad_dma"]) and (taps > 1 or bool(TUNE["wgrad_dma_k1"]))
 
     def add(self, dy, lddy, m, x, ldx, ca, dw, dbias, perm=ops.PERM_NONE, perm_h=0):
         j = WgradJob()
         j.dy, j.x, j.dw, j.dbias, j.lddy, j.ldx = dy, x, dw, dbias, lddy, ldx
         j.m, j.ca, j.xpro, j.perm, j.perm_h = m, ca, self.xpro, perm, perm_h
-        j.mt, j.nt, j.tile0 = (m + 127) // 128, (ca + 63) // 64, self._tiles
         if (m | ca | lddy | ldx) & 7 or (dy | x) & 15:
             self._wide = False
-        self._tiles += j.mt * j.nt
+        if not self._wide or (self.rows + 512) * max(lddy, ldx) * 2 >= 2 ** 31:    # (the DMAs run three steps past the end; 32-bit buffer offsets)
+            self._dma = False
         self.jobs.append(j)
 
     def end_segment(self):
-        self.segments.append((self._start, len(self.jobs) - self._start, self._tiles))
-        self._start, self._tiles = len(self.jobs), 0
+        self.segments.append((self._start, len(self.jobs) - self._start, 0))
+        self._start = len(self.jobs)
+
+    def _tile(self):
+        """Tile geometry of every job, once the group's kernel is known (the DMA kernel works on 192 x 64 tiles - 192 x 192 at one tap -, the staged one on 128 x 64)."""
+        dma = self._dma and self._wide
+        bm, bn = (192, 192 if self.taps == 1 else 64) if dma else (128, 64)
+        for i, (start, n, _) in enumerate(self.segments):
+            tiles = 0
+            for j in self.jobs[start:start + n]:
+                j.mt, j.nt, j.tile0 = (j.m + bm - 1) // bm, (j.ca + bn - 1) // bn, tiles
+                tiles += j.mt * j.nt
+            self.segments[i] = (start, n, tiles)
 
     def upload(self, device):
         if not self.jobs:
             return
+        self._tile()
         # (a captured step gets a pinned table of its own: _lib.staged_upload)
         self.table = _lib.staged_upload(bytes((WgradJob * len(self.jobs))(*self.jobs)), device)
 
@@ -249,6 +263,8 @@ class WgradGroup:
         groups = [g for g in groups if g.jobs]
         if not groups:
             return
+        for g in groups:
+            g._tile()
         raws = [bytes((WgradJob * len(g.jobs))(*g.jobs)) for g in groups]
         table = _lib.staged_upload(b"".join(raws), device)
         off = 0
@@ -261,7 +277,8 @@ class WgradGroup:
         if n == 0:
             return
         _lib.check(_L().glowtts_wgrad_grouped_io(self.table.data_ptr() + start * ctypes.sizeof(WgradJob), n, tiles, self.rows, self.taps,
-                                                 (self.taps - 1) // 2, self.xpro, self.precision, 1, 0, self.io_flags | (ops.WIO_WIDE if self._wide else 0), _lib.stream()),
+                                                 (self.taps - 1) // 2, self.xpro, self.precision, 1, 0,
+                                                 self.io_flags | (ops.WIO_WIDE if self._wide else 0) | (ops.WIO_DMA if (self._dma and self._wide) else 0), _lib.stream()),
                    "glowtts_wgrad_grouped_io")
 
 

@@ -363,8 +363,9 @@ class GlowTTS(torch.nn.Module):
             idx.record_stream(side)
         with torch.cuda.stream(side):
             attn = path_from_idx(idx, tokens.shape[1], torch.float32)
-        mel_mean = alignment.ExpandPrior.apply(mean, idx)                                            # Modules.py:120 (gather by the MAS index)
-        mel_log_std = alignment.ExpandPrior.apply(log_std, idx)                                      # Modules.py:121
+        bwd_side = side if (side is not main and torch.is_grad_enabled()) else None
+        mel_mean = alignment.ExpandPrior.apply(mean, idx, bwd_side)                                  # Modules.py:120 (gather by the MAS index)
+        mel_log_std = alignment.ExpandPrior.apply(log_std, idx, bwd_side)                            # Modules.py:121
         log_dur_targets = alignment.duration_targets(idx, token_lengths, tokens.shape[1])            # Modules.py:122
         if side is not main:
             main.wait_stream(side)
@@ -373,6 +374,12 @@ class GlowTTS(torch.nn.Module):
         if "Speaker_Classifier_GR" in self.layer_Dict:
             classified = self.layer_Dict["Speaker_Classifier_GR"](pro)                                    # Modules.py:84-87
         return z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_targets, attn, classified
+
+    def aux_stream(self):
+        """The stream the last forward ran the text encoder on, or None when that was the caller's own: work that only the encoder's side
+        of the step consumes (the duration loss and its backward) can be queued there instead of in front of the flow decoder's backward
+        (`Beside`)."""
+        return self._enc_stream if (self.overlap_encoder and self._enc_stream is not None) else None
 
     # ---------------------------------------------------------------- inverse flow
     @torch.no_grad()
@@ -450,6 +457,47 @@ class GlowTTS(torch.nn.Module):
         upto = (torch.arange(Ty, device=masks.device)[None, None, :] < cum[:, :, None]).to(masks.dtype)
         prev = torch.nn.functional.pad(upto, [0, 0, 1, 0])[:, :-1]
         return (upto - prev) * masks
+
+
+class Beside:
+    """`with Beside(model) as b: length = ...` queues the block on model.aux_stream(), behind everything the caller's stream holds at that
+    point; `b.join(*tensors)` makes the caller's stream wait for it (call it as late as the results are needed: what the caller queues in
+    between runs concurrently).  autograd replays each backward on its forward's stream, so the block's backward leaves the caller's stream
+    as well.  Without an auxiliary stream the block simply runs in place."""
+
+    def __init__(self, model):
+        self.main = torch.cuda.current_stream()
+        aux = model.aux_stream() if hasattr(model, "aux_stream") else None
+        self.aux = aux if (aux is not None and aux != self.main) else None
+        self._ctx = None
+
+    def __enter__(self):
+        if self.aux is not None:
+            self.aux.wait_stream(self.main)
+            self._ctx = torch.cuda.stream(self.aux)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+            self._ctx = None
+        return False
+
+    def uses(self, *tensors):
+        """Tensors of the caller's stream that the block reads (the caching allocator must not hand their memory out while it runs)."""
+        if self.aux is not None:
+            for t in tensors:
+                if torch.is_tensor(t):
+                    t.record_stream(self.aux)
+        return self
+
+    def join(self, *tensors):
+        if self.aux is not None:
+            self.main.wait_stream(self.aux)
+            for t in tensors:
+                if torch.is_tensor(t):
+                    t.record_stream(self.main)
 
 
 class MLE_Loss(torch.nn.modules.loss._Loss):

@@ -12,7 +12,7 @@ PERM_NONE, PERM_PAIR = 0, 1
 APRO_NONE, APRO_PAIRMUL, APRO_SQNEG = 0, 1, 2
 EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_DGATE = 0, 1, 2, 3, 4
 IO_A_BF16, IO_IN0_BF16, IO_OUT0_BF16 = 1, 2, 4      # glowtts_conv_args.io_flags
-WIO_DY_BF16, WIO_X_BF16, WIO_WIDE = 1, 2, 4           # glowtts_wgrad_args.io_flags
+WIO_DY_BF16, WIO_X_BF16, WIO_WIDE, WIO_DMA = 1, 2, 4, 8           # glowtts_wgrad_args.io_flags (DMA: grouped launches only)
 F_BIAS, F_RELU, F_ADD_IN0, F_MASK, F_ACCUM, F_FIRST, F_LAST, F_REVERSE, F_COLMASK, F_DROPOUT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 

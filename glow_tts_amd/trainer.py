@@ -117,20 +117,27 @@ class Trainer:
         global batch's mel frames, a 0-d device tensor computed outside the captured step (`distributed.global_frame_weight`)."""
         z, mel_Mean, mel_Log_Std, log_Dets, log_Durations, log_Duration_Targets, _, classified = model(
             tokens, token_lengths, mels, mel_lengths, speakers, mels_for_ge2e, pitches)
-        mle = self.criterion_Dict["MLE"](z=z, mean=mel_Mean, std=mel_Log_Std, log_dets=log_Dets, lengths=mel_lengths)
+        # the duration loss (and, GR, the speaker classifier's) on the encoder's stream, beside the MLE reduction: neither they nor their backward
+        # sit in front of the flow decoder's backward on this stream
+        from .modules import Beside
         if self.world > 1 and token_extent is None:
             from .distributed import global_token_extent
             token_extent = global_token_extent(token_lengths.max())
-        length = duration_loss(log_Durations, log_Duration_Targets, token_lengths, token_extent)
+        with Beside(model) as beside:
+            beside.uses(log_Durations, log_Duration_Targets, token_lengths, token_extent, classified, speakers)
+            length = duration_loss(log_Durations, log_Duration_Targets, token_lengths, token_extent)
+            ce = self.criterion_Dict["CE"](classified, speakers) if classified is not None else None
+            rest = length + ce if ce is not None else length
+        mle = self.criterion_Dict["MLE"](z=z, mean=mel_Mean, std=mel_Log_Std, log_dets=log_Dets, lengths=mel_lengths)
+        beside.join(length, ce, rest)
         total = mle + length
-        ce = self.criterion_Dict["CE"](classified, speakers) if classified is not None else None
         if self.world > 1:
             if frame_weight is None:
                 from .distributed import global_frame_weight
                 frame_weight = global_frame_weight(mel_lengths.sum())
-            loss = mle * frame_weight + (length + (ce if ce is not None else 0.0)) / self.world
+            loss = mle * frame_weight + rest / self.world
         else:
-            loss = total + (ce if ce is not None else 0.0)
+            loss = mle + rest
         comp = torch.stack([mle.detach(), length.detach(), total.detach(), ce.detach() if ce is not None else torch.zeros((), device=mle.device)])
         return loss, comp
 

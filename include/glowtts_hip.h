@@ -326,6 +326,8 @@ typedef struct glowtts_wgrad_args {
 #define GLOWTTS_WIO_X_BF16  2
 #define GLOWTTS_WIO_WIDE    4   /* bf16 precision, no prologue, both operands stored alike (both bf16 or both fp32): the caller promises m, ca, lddy,
                                   ldx multiples of 8 and 16-byte aligned dy / x for EVERY job: operands are then staged 8 channels per item */
+#define GLOWTTS_WIO_DMA     8   /* glowtts_wgrad_grouped_io only (ABI 3): the LDS-DMA / 16x16x32 kernel; on top of WIDE with both operands bf16 the caller promises that every
+                                 * job's m is a multiple of 128 and ca a multiple of 64, operands below 2 GiB, splits = 1, no accumulation */
 int glowtts_wgrad_cl(const glowtts_wgrad_args *args /* host pointer */, void *stream);
 
 /* Grouped form: many weight-gradient problems that share (rows, taps, pad, precision) in ONE launch, so that the

@@ -247,7 +247,7 @@ def test_wgrad_wide_staging_is_bit_identical(bf_io, taps):
         for dy, x, dw, db, (m, ca) in zip(dys, xs, dws, dbs, shapes):
             g.add(dy.data_ptr(), m, m, x.data_ptr(), ca, ca, dw.data_ptr(), db.data_ptr())
         assert g._wide
-        g._wide = wide
+        g._wide, g._dma = wide, False          # (the staged kernel's two staging widths; the DMA kernel has its own test below)
         g.end_segment(); g.upload(torch.device("cuda")); g.launch_segment(0)
         torch.cuda.synchronize()
         outs.append((dws, dbs))
@@ -258,3 +258,55 @@ def test_wgrad_wide_staging_is_bit_identical(bf_io, taps):
     ref = torch.einsum("ro,rc->oc", dys[3].float(), xs[3].float()) if taps == 1 else None
     if ref is not None:
         assert (outs[1][0][3][:, :, 0] - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("taps,R", [(5, 1212), (1, 1216), (3, 640), (5, 64)])
+def test_wgrad_dma_kernel_matches_the_staged_kernel_and_float64(taps, R):
+    """Round 4: `wgrad_dma_kernel` (LDS-DMA staging into fragment-ordered / padded-row tiles, 16x16x32 MFMAs on 96 x 32 x taps wave tiles; GLOWTTS_WIO_DMA)
+    against the register-staged kernel on the same grouped problems (same bf16 operands, fp32 accumulation in another order: 1e-5 of the tensor's
+    largest entry) and against a float64 contraction.  Rows not a multiple of the 64-row step (the last step and the tap halo read zeros through the
+    buffer descriptor), PAIR-permuted output channels, bias sums beside the MFMAs, several jobs per launch, shapes that do not fill a tile (the End conv's 2 x 80 PAIR-packed output channels,
+    the Start conv's 80 input channels: the tile reads on into the next row and the store masks it)."""
+    from glow_tts_amd import decoder as D, ops
+    D._L()
+    torch.manual_seed(17)
+    pad = (taps - 1) // 2
+    shapes = [(384, 192, ops.PERM_PAIR, 192), (192, 64, ops.PERM_NONE, 0), (576, 128, ops.PERM_PAIR, 288), (192, 192, ops.PERM_PAIR, 80), (192, 80, ops.PERM_NONE, 0), (200, 72, ops.PERM_NONE, 0)]
+    io = ops.WIO_DY_BF16 | ops.WIO_X_BF16
+    dys = [(torch.randn(R, m, device="cuda") * 0.5).to(torch.bfloat16) for m, _, _, _ in shapes]
+    xs = [torch.randn(R, ca, device="cuda").to(torch.bfloat16) for _, ca, _, _ in shapes]
+    outs = []
+    for dma in (False, True):
+        g = D.WgradGroup(R, taps, ops.BF16, io_flags=io, tag=f"d{int(dma)}")
+        dws = [torch.full((m, ca, taps), 7.0, device="cuda") for m, ca, _, _ in shapes]
+        dbs = [torch.full((m,), 7.0, device="cuda") for m, _, _, _ in shapes]
+        for dy, x, dw, db, (m, ca, perm, ph) in zip(dys, xs, dws, dbs, shapes):
+            g.add(dy.data_ptr(), m, m, x.data_ptr(), ca, ca, dw.data_ptr(), db.data_ptr(), perm=perm, perm_h=ph)
+        assert g._wide
+        g._dma = dma                          # (decoder.TUNE decides per tap count in the product; forced here)
+        from helpers import launch_counts, launch_reset
+        launch_reset()
+        g.end_segment(); g.upload(torch.device("cuda")); g.launch_segment(0)
+        torch.cuda.synchronize()
+        lc = launch_counts()
+        assert (sum(n for k, n in lc.items() if k.startswith("wgrad_dma<")) == 1) == dma, lc
+        outs.append((dws, dbs))
+    for i, (m, ca, perm, ph) in enumerate(shapes):
+        a, b = outs[0][0][i], outs[1][0][i]
+        assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item(), (i, (a - b).abs().max().item())
+        assert (outs[0][1][i] - outs[1][1][i]).abs().max().item() <= 1e-4 * max(1.0, outs[0][1][i].abs().max().item())
+        # float64: dW[o][c][t] = sum_r DY[r][col(o)] X[r + t - pad][c]; PAIR: output channel h * H + 32 p + j sits in DY column 64 p + 32 h + j
+        dy64, x64 = dys[i].double(), xs[i].double()
+        nout = m
+        if perm == ops.PERM_PAIR:
+            nout = 2 * ph                                              # (2 x 80 output channels sit in 192 PAIR-packed columns)
+            o = torch.arange(nout, device="cuda")
+            h, jj = o // ph, o % ph
+            col = (jj // 32) * 64 + h * 32 + jj % 32
+            dy64 = dy64[:, col]
+        xp = torch.nn.functional.pad(x64, (0, 0, pad, pad))
+        ref = torch.stack([dy64.t() @ xp[t:t + R] for t in range(taps)], dim=2)
+        assert (b[:nout].double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+        assert (outs[1][1][i][:nout].double() - dy64.sum(0)).abs().max().item() <= 1e-4 * max(1.0, dy64.sum(0).abs().max().item())
+        assert bool((b[nout:] == 7.0).all()) and bool((outs[1][1][i][nout:] == 7.0).all())          # nothing written past the real output channels

@@ -628,6 +628,45 @@ static void run_ring(const char* name, const unsigned char* img, float* out, uns
            ms * 1e6 / n / nslab, (double)h[h.size() / 2] / nslab, 2.0 * 64 * 384 * 32 * nslab * grid / (ms * 1e-3 / n) * 1e-12);
 }
 
+
+// ---------------------------------------------------------------- (4) throughput of the transposing LDS read (what bounds the weight-gradient kernels?)
+// PAT 0: ds_read_b64, lane-linear (reference);  1: ds_read_b64_tr_b16, the register-staged wgrad kernel's pattern (32x32x16 fragments: 16-lane group g reads 4
+// rows x 32 B, groups 0 / 1 = two column halves of the same rows, row pitch 320 B);  2: wgrad_dma_kernel's DY pattern (16x16x32 fragments: group g reads rows
+// r + 8 g .., swizzled 256-byte rows);  3: its X pattern (128-byte rows) at tap shift 1
+typedef short s16x4l __attribute__((ext_vector_type(4)));
+template <int PAT>
+__global__ __launch_bounds__(1024) void tr_probe(unsigned long long* out, float* sink)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char sm[64 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 16 * 1024; i += blockDim.x) reinterpret_cast<uint32_t*>(sm)[i] = i;
+    __syncthreads();
+    const int s = lane & 15, g = lane >> 4, lhi = lane >> 5, gq = (lane >> 4) & 1;
+    int addr;
+    if (PAT == 0) addr = lane * 8;
+    else if (PAT == 1) addr = (8 * lhi + (s >> 2)) * 320 + (gq * 16 + 4 * (s & 3)) * 2;
+    else if (PAT == 2) { const int row = 8 * g + (s >> 2); addr = row * 256 + ((((0 ^ (row & 3)) & 3) << 2 | ((0 ^ ((row >> 3) & 1)) << 1) | ((s & 3) >> 1)) << 4) + 8 * (s & 1); }
+    else { const int row = 8 * g + (s >> 2) + 1; addr = row * 128 + (((((0 ^ ((row >> 1) & 1)) & 1) << 2) | ((0 ^ ((row >> 3) & 1)) << 1) | ((s & 3) >> 1)) << 4) + 8 * (s & 1); }
+    addr += (wave & 3) * 8192;
+    s16x4l acc = {0, 0, 0, 0};
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < 64; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s16x4l v;
+            if (PAT == 0) v = *reinterpret_cast<const s16x4l*>(sm + addr + u * 512 * (PAT == 0));
+            else v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4l __attribute__((address_space(3)))*)(sm + addr + u * 16 * (PAT == 1 ? 320 : (PAT == 2 ? 256 : 128)) % 8192));
+            acc ^= v;
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) { out[(blockIdx.x * 16 + wave) * 2] = t1 - t0; out[(blockIdx.x * 16 + wave) * 2 + 1] = t2 - t0; }
+    sink[blockIdx.x * blockDim.x + tid] = (float)(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]);
+}
+
 // ---------------------------------------------------------------- (3) how fast can ONE CU take in a weight stream from L2?
 // KIND 0: global_load_dwordx4 -> VGPR; 1: buffer_load_dwordx4; 2: buffer_load sc1; 3: buffer_load sc0 sc1; 4: global_load_lds_dwordx4 (LDS-DMA into a ring,
 // nothing reads it); 5: global_load_dwordx2 -> VGPR; 6: buffer_load nt
@@ -816,6 +855,28 @@ int main(int argc, char** argv)
         return 0;
     }
 
+
+    if (argc > 2 && !strcmp(argv[2], "tr")) {
+        unsigned long long* o2; float* sk2;
+        CK(hipMalloc(&o2, 256 * 16 * 2 * 8)); CK(hipMalloc(&sk2, 256 * 1024 * 4));
+        const char* nm[4] = {"ds_read_b64 linear", "tr_b16, staged-kernel pattern", "tr_b16, dma-kernel DY pattern", "tr_b16, dma-kernel X pattern (tap 1)"};
+        for (int pat = 0; pat < 4; ++pat)
+            for (int nw : {4, 8, 16}) {
+                for (int rep = 0; rep < 2; ++rep) {
+                    if (pat == 0) hipLaunchKernelGGL(tr_probe<0>, dim3(256), dim3(nw * 64), 0, 0, o2, sk2);
+                    if (pat == 1) hipLaunchKernelGGL(tr_probe<1>, dim3(256), dim3(nw * 64), 0, 0, o2, sk2);
+                    if (pat == 2) hipLaunchKernelGGL(tr_probe<2>, dim3(256), dim3(nw * 64), 0, 0, o2, sk2);
+                    if (pat == 3) hipLaunchKernelGGL(tr_probe<3>, dim3(256), dim3(nw * 64), 0, 0, o2, sk2);
+                }
+                CK(hipDeviceSynchronize());
+                std::vector<unsigned long long> h(256 * 16 * 2);
+                CK(hipMemcpy(h.data(), o2, h.size() * 8, hipMemcpyDeviceToHost));
+                double all = 0;
+                for (int w = 0; w < nw; ++w) all = std::max(all, (double)h[(7 * 16 + w) * 2 + 1]);
+                printf("tr    %-40s %2d waves: 512 reads per wave, all done after %7.0f clk = %5.1f B/clk/CU\n", nm[pat], nw, all, 512.0 * 512 * nw / all);
+            }
+        return 0;
+    }
     if (argc > 2 && !strcmp(argv[2], "ring")) {
         for (int grid : {249, 8}) {
             run_ring<0, 0>("today: 32x32x16, DMA behind the MFMAs", wimg, out, clk, 144, grid);
