@@ -484,6 +484,8 @@ def main():
     ap.add_argument("--tune", action="append", default=[], help="A/B measurements: key=value entries of glow_tts_amd.decoder.TUNE (e.g. wgrad_wide=0)")
     ap.add_argument("--one-device", action="store_true", help="all ranks on device 0 (multi-rank smoke test on a single-GPU box)")
     ap.add_argument("--no-overlap", action="store_true", help="data parallel: one graph + one gradient exchange instead of the two-graph overlap")
+    ap.add_argument("--dp-skip-reduce", action="store_true", help="diagnosis (WRONG results for N > 1): the data-parallel step's graphs without the gradient "
+                    "exchange between them - what splitting the step into graphs costs by itself")
     ap.add_argument("--force-dist", action="store_true", help="run the data-parallel code path (process group, two-graph overlap, all-reduces) "
                     "even with one rank: exercises RCCL on a single-GPU box")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to smoke-test the "
@@ -632,8 +634,8 @@ def main():
                     with torch.cuda.graph(tail_graph, pool=graph.pool(), capture_error_mode="thread_local"):
                         D.flush_tail_wgrads()
                     tail_ids = {id(p) for p in model._dec_stacks.tail_leaves()}
-                    early = FlatGradReducer([p for p in model.parameters() if id(p) not in tail_ids])
-                    tail = FlatGradReducer([p for p in model.parameters() if id(p) in tail_ids])
+                    early = FlatGradReducer([p for p in model.parameters() if id(p) not in tail_ids], static=True)
+                    tail = FlatGradReducer([p for p in model.parameters() if id(p) in tail_ids], static=True)
                 else:
                     with torch.cuda.graph(graph, capture_error_mode="thread_local" if dp else "global"):
                         static_loss = fwd_bwd()
@@ -678,11 +680,12 @@ def main():
             else:
                 graph.replay()
             if tail_graph is not None:
-                pending = early.begin()
+                pending = early.begin() if not args.dp_skip_reduce else None
                 tail_graph.replay()
-                tail.reduce(average=False)
-                early.finish(pending)
-            elif reducer is not None:
+                if not args.dp_skip_reduce:
+                    tail.reduce(average=False)
+                    early.finish(pending)
+            elif reducer is not None and not args.dp_skip_reduce:
                 reducer.reduce(average=False)
             if opt_graph is not None:
                 opt[0].advance_host()

@@ -8,6 +8,7 @@ glowtts_decoder_logdet).  This file only marshals pointers: weights arrive as *s
 the kernels.  There is no CPU fallback.
 """
 import ctypes
+import math
 
 import torch
 
@@ -347,6 +348,10 @@ WEIGHT_KEYS = ("an_logs", "an_bias", "inv_w", "w_start", "b_start", "w_in", "b_i
 WN_KEYS = ("w_start", "w_in", "w_rs", "w_rs_last")
 WEIGHT_KEYS_GV = ("an_logs", "an_bias", "inv_w", "g_start", "v_start", "b_start", "g_in", "v_in", "b_in", "g_rs", "v_rs", "b_rs",
                   "g_rs_last", "v_rs_last", "b_rs_last", "w_end", "b_end")
+
+
+# classes whose gradients come out of the deferrable tail of the backward (TAIL_STACKS, by weight key): everything but ActNorm / the 1x1 mixing / In_l
+_TAIL_OF = {k: not (k.startswith(("an_", "inv_")) or k.endswith("_in")) for k in set(WEIGHT_KEYS + WEIGHT_KEYS_GV)}
 
 
 class _Prepared:
@@ -829,7 +834,31 @@ class DecoderFunction(torch.autograd.Function):
         dld = dlogdet.contiguous() if dlogdet is not None else torch.zeros(B, device=dev)
         GV = ctx.GV
         # every entry is fully written below (weight-gradient launches store, not accumulate)
-        G = {k: torch.empty_like(GV[k][1] if (GV is not None and k in GV) else W[k]) for k in WEIGHT_KEYS}
+        # The gradients this function RETURNS live in two arenas - one for the classes of the deferrable tail (TAIL_STACKS), one for the rest -, each
+        # class a gap-free view: the leaves' .grad are views of them (LeafStack), so a data-parallel step exchanges the decoder's gradients with ONE
+        # collective per arena instead of one per class (distributed.FlatGradReducer reduces storages that its gradients tile; a collective costs
+        # ~25 us of launch and stream hand-over whatever its size).  Weight-normalised classes return (d g, d v); their d w is an intermediate.
+        def arenas(shapes):
+            out = {}
+            for tail in (False, True):
+                ks = [k for k in shapes if (_TAIL_OF.get(k, False)) == tail]
+                sizes = [int(math.prod(shapes[k])) for k in ks]
+                padded = [(n + 3) & ~3 for n in sizes]                       # (16-byte aligned classes)
+                flat = (torch.empty if padded == sizes else torch.zeros)(sum(padded), device=dev)
+                off = 0
+                for k, n, npad in zip(ks, sizes, padded):
+                    out[k] = flat[off:off + n].view(shapes[k])
+                    off += npad
+            return out
+        ret_shapes = {}
+        for k in (WEIGHT_KEYS_GV if GV is not None else WEIGHT_KEYS):
+            wk = "w" + k[1:]
+            if GV is not None and k[0] in "gv" and wk in GV:
+                ret_shapes[k] = tuple(GV[wk][0 if k[0] == "g" else 1].shape)
+            else:
+                ret_shapes[k] = tuple(W[k].shape)
+        RET = arenas(ret_shapes)
+        G = {k: (RET[k] if k in RET else torch.empty_like(GV[k][1] if (GV is not None and k in GV) else W[k])) for k in WEIGHT_KEYS}
         d_an = torch.empty(F_, 2 * C + 16, device=dev)
         # every flow / layer keeps its own gradient buffers: the weight gradients of ALL flows are computed afterwards by
         # two grouped launches (k-tap problems, 1x1 problems) whose tiles fill the chip without split-K or atomics
@@ -954,7 +983,7 @@ class DecoderFunction(torch.autograd.Function):
                     continue
                 cols = v_.shape[-1] * v_.shape[-2]
                 rows_ = v_.numel() // cols
-                dv, dg = torch.empty_like(v_), torch.empty_like(g_)
+                dv, dg = RET["v" + k[1:]], RET["g" + k[1:]]
                 GVgrad[k] = (dg, dv)
                 run = lambda k=k, g_=g_, v_=v_, dv=dv, dg=dg, rows_=rows_, cols=cols, inv=prep.inv[k], dw=G[k]: _lib.check(
                     L.glowtts_weightnorm_bwd(dw.data_ptr(), v_.data_ptr(), g_.data_ptr(), inv.data_ptr(), dv.data_ptr(), dg.data_ptr(), rows_, cols, _lib.stream()),

@@ -72,9 +72,12 @@ class FlatGradReducer:
       * the remaining small tensors are concatenated into flat buckets, reduced, and copied back.
     Buckets follow reverse parameter order, i.e. the order the backward pass produces them."""
 
-    def __init__(self, params, bucket_bytes=64 << 20, direct_bytes=1 << 20):
+    def __init__(self, params, bucket_bytes=64 << 20, direct_bytes=8 << 20, static=False):
+        """static: the gradients keep their addresses from call to call (a replayed hipGraph of the step writes them in place): the plan and the
+        flat buckets are built on the first call and kept - no per-step Python over hundreds of parameters, no allocation."""
         self.params = [p for p in params if p.requires_grad]
-        self.bucket_bytes, self.direct_bytes = bucket_bytes, direct_bytes
+        self.bucket_bytes, self.direct_bytes, self.static = bucket_bytes, direct_bytes, static
+        self._kept = None
 
     def _plan(self):
         """-> (direct: list of flat tensors aliasing gradient storages, buckets: list of lists of gradient tensors)."""
@@ -87,8 +90,10 @@ class FlatGradReducer:
         direct, small = [], []
         for gs in groups.values():
             gs = sorted(gs, key=lambda t: t.storage_offset())
-            covered = all(t.is_contiguous() for t in gs) and all(a.storage_offset() + a.numel() == b.storage_offset() for a, b in zip(gs, gs[1:]))
-            total = sum(t.numel() for t in gs)
+            # the gradients tile one span of the storage (alignment gaps of a few elements allowed: decoder.DecoderFunction's arenas pad classes to
+            # 16 bytes and zero the pad)
+            covered = all(t.is_contiguous() for t in gs) and all(0 <= b.storage_offset() - (a.storage_offset() + a.numel()) < 4 for a, b in zip(gs, gs[1:]))
+            total = gs[-1].storage_offset() + gs[-1].numel() - gs[0].storage_offset()
             if covered and len({t.dtype for t in gs}) == 1 and total * gs[0].element_size() >= self.direct_bytes:
                 direct.append(torch.empty(0, dtype=gs[0].dtype, device=gs[0].device).set_(gs[0].untyped_storage(), gs[0].storage_offset(), (total,)))
             else:
@@ -104,30 +109,39 @@ class FlatGradReducer:
             buckets.append(cur)
         return direct, buckets
 
+    def _views(self, flat, bucket):
+        return [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in bucket]), bucket)]
+
     def begin(self):
         """Issues the SUM all-reduces (asynchronously, on the process group's stream) and returns the state `finish` needs.  Work that does
         not touch these gradients may be launched in between: it overlaps the exchange."""
         if not is_dist():
             return None
-        direct, buckets = self._plan()
-        works = [dist.all_reduce(f, op=dist.ReduceOp.SUM, async_op=True) for f in direct]
-        flats = [torch.cat([g.reshape(-1) for g in b]) for b in buckets]
-        works += [dist.all_reduce(f, op=dist.ReduceOp.SUM, async_op=True) for f in flats]
-        return direct, buckets, flats, works
+        if self.static and self._kept is not None:
+            direct, buckets, flats, views = self._kept
+            for b, v in zip(buckets, views):
+                torch._foreach_copy_(v, b)
+        else:
+            direct, buckets = self._plan()
+            flats = [torch.cat([g.reshape(-1) for g in b]) for b in buckets]
+            views = [self._views(f, b) for f, b in zip(flats, buckets)]
+            if self.static:
+                self._kept = (direct, buckets, flats, views)
+        works = [dist.all_reduce(f, op=dist.ReduceOp.SUM, async_op=True) for f in direct + flats]
+        return direct, buckets, flats, views, works
 
     def finish(self, state, average=False):
         if state is None:
             return
-        direct, buckets, flats, works = state
+        direct, buckets, flats, views, works = state
         for w in works:
             w.wait()
         if average:
             ws = dist.get_world_size()
             for f in direct + flats:
                 f.div_(ws)
-        for b, flat in zip(buckets, flats):
-            torch._foreach_copy_(b, list(flat.split([g.numel() for g in b])) if all(g.dim() == 1 for g in b)
-                                 else [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in b]), b)])
+        for b, v in zip(buckets, views):
+            torch._foreach_copy_(b, v)
 
     def reduce(self, average=False):
         """SUM (or mean) all-reduce of every parameter gradient, in place."""

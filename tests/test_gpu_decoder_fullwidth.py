@@ -113,7 +113,8 @@ def test_full_width_backward_bf16_takes_the_benchmarked_kernels(spk_dim):
     assert _count(counts, "conv_dma<LINEAR,5>") == (N_FLOWS - nfb) * L, counts           # In_l data gradient
     assert _count(counts, "conv_dma<DGATE,1>") == (N_FLOWS - nfb) * (L - 1), counts
     assert _count(counts, "conv_chain<LINEAR,DGATE>") == N_FLOWS - nfb, counts
-    assert _count(counts, "wgrad<5,bf16,dybf16,xbf16,wide>/grouped") == 1, counts        # all In_l weight gradients: one grouped launch
+    # all In_l weight gradients: one grouped launch of the LDS-DMA kernel (round 4: 192 x 64 x 5-tap tiles, csrc/wgrad_cl.hip wgrad_dma_kernel)
+    assert _count(counts, "wgrad_dma<5>/grouped") == 1 and _count(counts, "wgrad<5,") == 0, counts
     # Res_Skip_l AND (round 4) Start / End, whose operands - d h0, x_a, d(m, logs), the skip sum - now exist as bf16 rows: one launch, no fp32 staging
     assert _count(counts, "wgrad<1,bf16,dybf16,xbf16,wide>/grouped") == 1, counts
     assert _count(counts, "wgrad<1,bf16,dyf32,xf32") == 0, counts
