@@ -473,6 +473,7 @@ def main():
     ap.add_argument("--ragged", action="store_true", help="Set V (ragged lengths) instead of Set F (fixed)")
     ap.add_argument("--windows", type=int, default=10, help="extra timed windows of --steps steps after the reported one (median / spread keys)")
     ap.add_argument("--tokens", type=int, default=120, help="padded token length (experiments)")
+    ap.add_argument("--frames", type=int, default=800, help="padded mel length (experiments; the metric is quoted on 800)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-key", action="store_true", help="skip the extra `f32` key (the same step in HIP_Precision f32, timed in a child process)")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward + losses + backward only (round 1's definition of the step); "
@@ -556,7 +557,7 @@ def main():
                           eps=hp.Train.ADAM.Epsilon, weight_decay=hp.Train.Weight_Decay)
         opt = (optimizer, Modified_Noam_Scheduler(optimizer, base=hp.Train.Learning_Rate.Base), hp.Train.Gradient_Norm)
     torch.manual_seed(4321 + rank)                              # dropout streams differ per rank; the replicas' weights do not
-    B, Tt, Tm = args.batch or cfg["batch"], args.tokens, 800
+    B, Tt, Tm = args.batch or cfg["batch"], args.tokens, args.frames
     batch = synthetic_batch(B, Tt, Tm, 80, 1234 + rank, dev, ragged=args.ragged)
     cond = conditioning_inputs(cfg, B, 1234 + rank, dev, hp)
 

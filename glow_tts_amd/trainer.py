@@ -12,7 +12,7 @@ from collections import defaultdict
 
 import torch
 
-from . import checkpoint, data
+from . import checkpoint, data, encoder
 from .hparams import get_hp
 from .modules import GlowTTS, MLE_Loss
 from .optim import Modified_Noam_Scheduler, RAdam, clip_grad_norm_
@@ -30,8 +30,24 @@ def duration_loss(log_durations, log_duration_targets, token_lengths, extent=Non
     return (d * d).sum() / (d.shape[0] * ext.to(d.dtype))
 
 
-def default_buckets(max_len, step):
-    return list(range(step, int(math.ceil(max_len / step)) * step + 1, step))
+def default_buckets(max_len, step, multiple=1, offset=0):
+    """Ascending padded lengths: the multiples of `step` below `max_len`, then `max_len` itself (rounded up to `multiple`) - the longest
+    pattern the filters admit needs no more padding than that (a top bucket of ceil(max / step) * step - 896 frames for the yaml's 800 - was 23 %
+    slower per step than the 800-frame shape, see `mel_bucket_step`)."""
+    top = int(math.ceil(max_len / multiple)) * multiple
+    return [b + offset for b in range(step, top - offset, step) if b + offset > 0] + [top]
+
+
+def mel_bucket_step(hp):
+    """Frames per mel bucket step: the rows ONE workgroup of the fused coupling-network kernels owns (csrc/wavenet_fused.hip: a 64-row window
+    less a 2-row halo per remaining layer on each side, 52 rows at 4 layers) times Num_Squeeze.  Those kernels run one workgroup per 52 rows of
+    the batch's row tensor (every utterance: T / Num_Squeeze + 2 x ROW_PAD rows), so padding inside a window is free for them while one window
+    more per utterance is B workgroups more: buckets of 104 k - 8 frames make every utterance exactly k windows, and at B = 32 the 824-frame
+    bucket is the last that fits the chip's 256 CUs in one round (832 frames: 259 workgroups, a second round for every one of the step's 19 fused
+    launches - 6.29 vs 5.2 ms per step measured; 896 frames: 7.2 ms)."""
+    wn = hp.Decoder.Affine_Coupling.WaveNet
+    owned = 64 - 2 * ((int(wn.Kernel_Size) - 1) // 2) * (int(wn.Num_Layers) - 1)
+    return max(16, owned) * int(hp.Decoder.Num_Squeeze)
 
 
 class Trainer:
@@ -66,8 +82,12 @@ class Trainer:
         ge = hp.Speaker_Embedding.GE2E.Inference
         ge2e = (ge.Samples, ge.Slice_Length, ge.Overlap_Length) if (hp.Mode.upper() in ("SE", "GR") and hp.Speaker_Embedding.Type.upper() == "GE2E") else None
         buckets = getattr(hp, "HIP_Buckets", None)          # optional extra yaml key: {Mel: [...], Token: [...]} padded shapes (one hipGraph each)
-        mel_b = list(buckets.Mel) if buckets is not None else default_buckets(hp.Train.Train_Pattern.Mel_Length.Max, 128)
-        tok_b = list(buckets.Token) if buckets is not None else default_buckets(hp.Train.Train_Pattern.Text_Length.Max + 2, 32)
+        mel_b = list(buckets.Mel) if buckets is not None else default_buckets(hp.Train.Train_Pattern.Mel_Length.Max, mel_bucket_step(hp), int(hp.Decoder.Num_Squeeze),
+                                                                              offset=-2 * encoder.ROW_PAD * int(hp.Decoder.Num_Squeeze))
+        # token buckets: the encoder's rows carry 2 x GLOWTTS_ROW_PAD zero rows per utterance and its attention kernels work on 32-row tiles, the one-workgroup
+        # MFMA kernels up to 128 rows: buckets of 32 k - 4 tokens fill whole tiles, and 124 tokens (not 128) is the longest text on the fast kernels -
+        # a 128-token bucket ran the step at 6.1 instead of 5.2 ms (attention forward 25 -> 63 us, backward 41 -> 166 us, x 6 blocks)
+        tok_b = list(buckets.Token) if buckets is not None else default_buckets(hp.Train.Train_Pattern.Text_Length.Max + 2, 32, offset=-2 * encoder.ROW_PAD)
         # Collation (unpickling, padding to the shape bucket): in worker processes like the reference's DataLoader(num_workers = hp.Train.Num_Workers,
         # pin_memory = True) (Train.py:100-107) - at ~6 ms per B = 32 step one Python thread cannot unpickle and pad 5 300 utterances per second.
         # Workers return plain CPU tensors, the loader's pin thread stages them in pinned memory, `_batch_to_device` issues the async copy.
