@@ -475,6 +475,8 @@ def main():
     ap.add_argument("--tokens", type=int, default=120, help="padded token length (experiments)")
     ap.add_argument("--frames", type=int, default=800, help="padded mel length (experiments; the metric is quoted on 800)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-run", action="store_true", help="for rocprofv3 --kernel-trace: skip the MAS and roofline legs (their launches would be counted "
+                    "into the per-step kernel statistics); use with --windows 0 --no-cpu-baseline --no-f32-key")
     ap.add_argument("--no-f32-key", action="store_true", help="skip the extra `f32` key (the same step in HIP_Precision f32, timed in a child process)")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward + losses + backward only (round 1's definition of the step); "
                     "default: the whole Train_Step of Train.py:193-233 including clip_grad_norm_, RAdam and the Noam schedule")
@@ -813,10 +815,11 @@ def main():
             "windows": {"n": len(ms), "steps_each": args.steps, "ms_per_step_median": round(statistics.median(ms), 3),
                         "ms_per_step_min": round(min(ms), 3), "ms_per_step_max": round(max(ms), 3)},
             "model_tflops": round(tflops, 2),
-            "mas_us_per_utt": round(mas_us_per_utt(B, Tt, Tm), 3),
-            "mas": mas_keys(B, Tt, Tm),
-            "roofline": roofline(args.precision, B, Tm // 2, tflops / world),
         }
+        if not args.profile_run:                              # (kernel-trace runs: only the step's own launches, so calls per step come out as integers)
+            out["mas_us_per_utt"] = round(mas_us_per_utt(B, Tt, Tm), 3)
+            out["mas"] = mas_keys(B, Tt, Tm)
+            out["roofline"] = roofline(args.precision, B, Tm // 2, tflops / world)
         if fwd_bwd_only is not None:
             out["fwd_bwd_only"] = {"ms_per_step": round(1e3 * fwd_bwd_only, 3), "value": round(frames / fwd_bwd_only, 1),
                                    "note": "forward + losses + backward without the parameter update (the step round 1 reported)"}

@@ -7,7 +7,7 @@ TAG=${1:-step}; shift
 STEPS=20; WARM=5
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o run -- python $REPO/bench.py --steps $STEPS --warmup $WARM --windows 0 --no-cpu-baseline "$@" > $REPO/gpurun_out/${TAG}_bench.json 2> /tmp/prof_$TAG.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o run -- python $REPO/bench.py --steps $STEPS --warmup $WARM --windows 0 --no-cpu-baseline --no-f32-key --profile-run "$@" > $REPO/gpurun_out/${TAG}_bench.json 2> /tmp/prof_$TAG.err
 python - "$TAG" "$REPO" <<'PY'
 import csv, glob, sys, collections
 tag, repo = sys.argv[1], sys.argv[2]
