@@ -32,9 +32,43 @@ def from_rows(rows_btc):
     return rows_btc[:, ROW_PAD:-ROW_PAD].transpose(1, 2)
 
 
+class _PackSets:
+    """The encoder's weight images as two `ops.PackSet`s (see encoder_forward): `run` launches the first on the current stream, the second on a stream
+    of its own, and returns the function that joins it."""
+
+    def __init__(self, sets, sig):
+        self.sets, self.sig = sets, sig
+
+    def get(self, key):
+        for st in self.sets:
+            if (key, False) in st.packed:
+                fwd = st.packed[(key, False)]
+                break
+        tr = None
+        for st in self.sets:
+            if (key, True) in st.packed:
+                tr = st.packed[(key, True)]
+        return fwd, tr
+
+    def run(self, aux):
+        """aux: a stream the CALLER has forked from the step's origin stream (a stream forked from the encoder's own - a fork of a fork - made
+        hipStreamEndCapture crash on ROCm 7.2), or None: everything on the current stream."""
+        self.sets[0].run()
+        if len(self.sets) == 1:
+            return None
+        if aux is None:
+            self.sets[1].run()
+            return None
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(aux):
+            self.sets[1].run()
+        return lambda: cur.wait_stream(aux)
+
+
 def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training=False, prefix="layer_Dict.Encoder",
-                    precision=1, cache=None, on_prior_ready=None):
-    """Modules.py:262-284 -> mean [B,mel,T], log_std [B,mel,T], log_durations [B,1,T] (channel-first, like the reference)."""
+                    precision=1, cache=None, on_prior_ready=None, pack_stream=None):
+    """Modules.py:262-284 -> mean [B,mel,T], log_std [B,mel,T], log_durations [B,1,T] (channel-first, like the reference).
+    pack_stream: a stream forked from the step's origin stream for the second weight-packing launch (see `_PackSets.run`)."""
     e = hp.Encoder
     C = e.Channels
     B, T = tokens.shape
@@ -80,18 +114,27 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
             for k, v in zip(gated, ParamGate.apply(tape, *[Pc[k] for k in gated])):
                 Pc[k] = v
 
-    # every conv weight (and, when training, its transpose for the data gradient) is packed into MFMA tile order by one launch
+    # every conv weight (and, when training, its transpose for the data gradient) is packed into MFMA tile order: the prenet's forward images - what the
+    # first convs wait for - by one small launch on this stream, everything else (the transformer's, the projection's, the duration predictor's images and
+    # every transposed image, 95 % of the bytes) by a second launch on a stream of its own that is joined in front of the transformer: the encoder's chain is
+    # what the first half of the step waits for, and one launch for all images kept its first conv ~85 us behind the step's start
     packset = None
     if cache is not None:
         items = [(k[:-len(".weight")], v, tr) for k, v in Pc.items()
                  if k.startswith(prefix) and k.endswith(".weight") and v.dim() == 3 and v.shape[0] > 1
                  and not k.endswith((".Query.weight", ".Key.weight", ".Value.weight"))
                  for tr in ((False, True) if torch.is_grad_enabled() else (False,))]
+        head = [it for it in items if ".Prenet." in it[0] and not it[2]]
+        rest = [it for it in items if not (".Prenet." in it[0] and not it[2])]
         slot = ("packset", precision, torch.is_grad_enabled())
         packset = cache.get(slot)
         if packset is None or packset.sig != ops.PackSet.signature(items):
-            packset = cache[slot] = ops.PackSet(items, precision)
-        packset.run()
+            from .decoder import TUNE
+            parts = (head, rest) if TUNE["enc_pack_split"] else (items,)
+            packset = cache[slot] = _PackSets([ops.PackSet(part, precision) for part in parts if part], ops.PackSet.signature(items))
+        pack_join = packset.run(pack_stream)
+    else:
+        pack_join = None
 
     # bf16 mode: every LayerNorm also writes its rows as bf16 and the convs that read them (and chains of convs) run on bf16-stored
     # operands - the LDS-DMA kernel instead of the register-staged one (fp32 -> bf16 in the loop); see conv_fn.ConvRows
@@ -119,6 +162,8 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
         q = f"{prefix}.layer_Dict.Prenet.layer_Dict.CLRD_{i}.layer_Dict"
         x = ln(conv(x, q + ".Conv"), None, q + ".LayerNorm", relu=True, drop=e.Prenet.Dropout_Rate)
     x = conv(x, prefix + ".layer_Dict.Prenet.layer_Dict.Conv1x1", mask_out=True, residual=res)
+    if pack_join is not None:
+        pack_join()                                                    # the second launch's images are needed from here on
     blocks = bf_rows and C % 64 == 0 and tape is not None and packset is not None
     if blocks and bf16_of(x) is None:
         x = _with_bf16(x, x.detach().to(torch.bfloat16))               # (the prenet's last conv writes fp32 rows)

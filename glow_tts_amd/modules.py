@@ -213,6 +213,7 @@ class GlowTTS(torch.nn.Module):
             self.layer_Dict["Prosody_Encoder"].hip_precision = prec
         self.actnorm_allreduce = None     # set by the data-parallel wrapper (glow_tts_amd.distributed)
         self._enc_stream = None
+        self._pack_stream = None
         self._pcache = None               # name -> Parameter (see _params)
         self._dec_stacks = None           # decoder.DecoderStacks: flat per-class parameter storage, built on first use
         self._enc_cache = {}              # encoder leaf stacks (fused Query/Key/Value weights)
@@ -224,7 +225,7 @@ class GlowTTS(torch.nn.Module):
     def __getstate__(self):
         # run-time caches (HIP stream, flat parameter storage views) are rebuilt on first use: keep them out of copies / pickles
         st = self.__dict__.copy()
-        st["_enc_stream"], st["_dec_stacks"], st["_enc_cache"], st["_pcache"] = None, None, {}, None
+        st["_enc_stream"], st["_pack_stream"], st["_dec_stacks"], st["_enc_cache"], st["_pcache"] = None, None, None, {}, None
         return st
 
     def __deepcopy__(self, memo):
@@ -320,6 +321,12 @@ class GlowTTS(torch.nn.Module):
             self._enc_stream = torch.cuda.Stream(priority=int(decoder.TUNE["enc_priority"]))      # (experiment: -1 = high priority)
         side = self._enc_stream if self.overlap_encoder else main
         side.wait_stream(main)
+        pack_aux = None
+        if side is not main and decoder.TUNE["enc_pack_split"]:
+            if self._pack_stream is None:
+                self._pack_stream = torch.cuda.Stream()
+            pack_aux = self._pack_stream
+            pack_aux.wait_stream(main)                        # (forked HERE, from the origin stream: see encoder._PackSets.run)
         prior_ready = torch.cuda.Event() if side is not main else None
         # (behind the fork: the encoder's stream does not wait for it)
         if use_gv and decoder.TUNE["prep_early"] and all(f.layers[0].initialized for f in self._flows()):
@@ -330,7 +337,8 @@ class GlowTTS(torch.nn.Module):
             token_mask = self.Mask_Generate(token_lengths, tokens.shape[1])
             mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, self.training, precision=self.dec_cfg.precision,
                                                              cache=self._enc_cache,
-                                                             on_prior_ready=(lambda: prior_ready.record(side)) if prior_ready is not None else None)
+                                                             on_prior_ready=(lambda: prior_ready.record(side)) if prior_ready is not None else None,
+                                                             pack_stream=pack_aux)
         decoder.stamp("main_after_enc_launch")
         cond = stacks.conditioning(spk, pro)
         pitch_w, pitch_b = stacks.pitch_weights()
