@@ -63,7 +63,9 @@ struct wn_bwd_args {
 // COND: the per-utterance conditioning joins the gate pre-activation AFTER the dropout (Modules.py:861-866): its gradient is the sum over an
 // utterance's rows of (da, ds) BEFORE the keep mask, which only exists here in registers.  Every workgroup adds the sums of its OWNED rows to
 // dcond with atomic adds, one run per utterance (as the per-conv DGATE epilogue does: order-dependent in the last bits).
-template <bool DROP, bool COND>
+// ABL (tools builds only, tools/bench_wn.py): timing ablations - 1: no weight DMAs after the prologue, 2: no MFMAs, 4: no global stores (copy-outs, d x_0, d x_a),
+// 8: no gate loads, 16: no partial-sum exchange, 32: no fragment reads in the In_l^T loop.  Wrong results by design.
+template <bool DROP, bool COND, int ABL = 0>
 __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char wb_smem[];
@@ -106,10 +108,14 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
         return wb_smem + BOFF_RING + (snext % BW_NS) * WN_SLAB;
     };
     auto end_step = [&]() __attribute__((always_inline)) {
-        if (snext + BW_NS - 1 < nslabs) issue(snext + BW_NS - 1);
+        if (!(ABL & 1) && snext + BW_NS - 1 < nslabs) issue(snext + BW_NS - 1);
         ++snext;
     };
     auto plain_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto mfma_bf16 = [](const Chunk16& a, const Chunk16& b, const f32x16& c) __attribute__((always_inline)) -> f32x16 {
+        if constexpr ((ABL & 2) != 0) { f32x16 r = c; asm volatile("" : "+v"(r) : "v"(a), "v"(b)); return r; }
+        else return ::mfma_bf16(a, b, c);
+    };
 
     // ---- prologue: d(m, logs) rows of the tile -> DT (A operand of End^T), row masks ----
     issue(0); issue(1);
@@ -141,6 +147,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
     // copy of the owned rows of an LDS tile [6 chunks][trows][64 B] to global rows: piece (chunk kc, slot q) of row r goes to
     // dst + r * row_bytes + off + kc * chunk_bytes + 16 q
     auto copy_out = [&](const unsigned char* tile, int trows, int row_off, void* dst, int row_bytes, int chunk_bytes, int off) __attribute__((always_inline)) {
+        if constexpr ((ABL & 4) != 0) return;
         const Rsrc rd = mk_rsrc(dst, (long)p.rows * row_bytes);
         int tid_ = tid;
         asm volatile("" : "+v"(tid_));
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
             for (int reg = 0; reg < 16; ++reg) {                // (rows outside the tensor: clamped garbage is fine, those rows are never stored or valid)
                 int g = g0 + frag_row(reg);
                 g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
-                gw[reg] = __builtin_amdgcn_raw_buffer_load_b32(rg, (uint32_t)(g * (2 * WN_H * 2) + jch * 4), 0, 0);
+                gw[reg] = (ABL & 8) ? 0x3f003e80u + (uint32_t)reg : __builtin_amdgcn_raw_buffer_load_b32(rg, (uint32_t)(g * (2 * WN_H * 2) + jch * 4), 0, 0);
             }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) pk[reg] = gate(acc0[reg], gw[reg], frag_row(reg));
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
         // ---- In_l^T: two K passes (da, ds) x 5 taps x 3 slabs; wave (rf, cp, kh) multiplies chunk kh of every slab; reads one step ahead ----
         zero(acc0); zero(acc1);
         {
-            Chunk16 fa[2][2], fb[2][2][2];
+            Chunk16 fa[2][2] = {}, fb[2][2][2] = {};
             auto mma = [&](auto SET_) __attribute__((always_inline)) {
                 constexpr int st = decltype(SET_)::value;
                 acc0 = mfma_bf16(fa[st][0], fb[st][0][0], acc0);
@@ -374,6 +381,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
             };
             auto reads = [&](auto SET_, const unsigned char* slot, int n) __attribute__((always_inline)) {
                 constexpr int st = decltype(SET_)::value;
+                if constexpr ((ABL & 32) != 0) { asm volatile("" : "+v"(fa[st][0]), "+v"(fa[st][1]), "+v"(fb[st][0][0]), "+v"(fb[st][0][1]), "+v"(fb[st][1][0]), "+v"(fb[st][1][1])); return; }
                 const int m = n >= 15 ? n - 15 : n, t = m / 3, jj = m - 3 * t;
                 const unsigned char* At = DT + (2 * jj + kh) * (WN_XR * 64);
 #pragma unroll
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
         {
             float* const xs = reinterpret_cast<float*>(DT);
 #pragma unroll
-            for (int rd = 0; rd < 2; ++rd) {
+            for (int rd = 0; rd < ((ABL & 16) ? 0 : 2); ++rd) {
                 plain_barrier();                                // (round 0: every wave is done reading the tile; round 1: done reading round 0)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) xs[(wave * 8 + i) * 64 + lane] = kh ? acc0[rd * 8 + i] : acc1[rd * 8 + i];
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
                 const float v = (acc0[reg] + xin) * mk[c];
                 *xp = bf16_bits(v);
                 const bool ok = own0 + (uint32_t)c < (uint32_t)lim;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r0, ok ? v00 + (uint32_t)(c * (WN_H * 4)) : OOB, 0, 0);
+                if constexpr (!(ABL & 4)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r0, ok ? v00 + (uint32_t)(c * (WN_H * 4)) : OOB, 0, 0);
             }
         }
     }
@@ -489,22 +497,41 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
         for (int reg = 0; reg < 16; ++reg) {
             const int c = frag_row(reg);
             const bool ok = cok && own0 + (uint32_t)c < (uint32_t)lim;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(old[reg] + acc0[reg]), rx, ok ? vx0 + (uint32_t)(c * (int)p.lddx * 4) : OOB, 0, 0);
+            if constexpr (!(ABL & 4)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(old[reg] + acc0[reg]), rx, ok ? vx0 + (uint32_t)(c * (int)p.lddx * 4) : OOB, 0, 0);
         }
     }
 #undef WN_TOFF
 }
 
-template <bool DROP, bool COND>
+template <bool DROP, bool COND, int ABL = 0>
 int launch_wn_bwd(const wn_bwd_args& k, dim3 grid, hipStream_t s)
 {
+#ifdef GLOWTTS_TOOLS
+    if constexpr (ABL == 0 && DROP && !COND) {
+        switch (GLOWTTS_TUNABLE("GLOWTTS_WN_BWD_ABL", 0)) {
+            case 1: return launch_wn_bwd<DROP, COND, 1>(k, grid, s);
+            case 2: return launch_wn_bwd<DROP, COND, 2>(k, grid, s);
+            case 3: return launch_wn_bwd<DROP, COND, 3>(k, grid, s);
+            case 4: return launch_wn_bwd<DROP, COND, 4>(k, grid, s);
+            case 8: return launch_wn_bwd<DROP, COND, 8>(k, grid, s);
+            case 12: return launch_wn_bwd<DROP, COND, 12>(k, grid, s);
+            case 13: return launch_wn_bwd<DROP, COND, 13>(k, grid, s);
+            case 14: return launch_wn_bwd<DROP, COND, 14>(k, grid, s);
+            case 16: return launch_wn_bwd<DROP, COND, 16>(k, grid, s);
+            case 32: return launch_wn_bwd<DROP, COND, 32>(k, grid, s);
+            case 46: return launch_wn_bwd<DROP, COND, 46>(k, grid, s);
+            case 47: return launch_wn_bwd<DROP, COND, 47>(k, grid, s);
+            default: break;
+        }
+    }
+#endif
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wn_bwd_kernel<DROP, COND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GLOWTTS_E_LAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wn_bwd_kernel<DROP, COND, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GLOWTTS_E_LAUNCH;
         attr_done = true;
     }
     GLOWTTS_NOTE_STATIC("wn_bwd<%s%s>", DROP ? "drop" : "nodrop", COND ? ",cond" : "");
-    hipLaunchKernelGGL((wn_bwd_kernel<DROP, COND>), grid, dim3(WN_NT), BW_LDS, s, k);
+    hipLaunchKernelGGL((wn_bwd_kernel<DROP, COND, ABL>), grid, dim3(WN_NT), BW_LDS, s, k);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
