@@ -1080,6 +1080,10 @@ __global__ __launch_bounds__(128) void attn_fwd_long_kernel(const float* __restr
     const int C = H * D, ld = 3 * C, nw = 2 * win + 1, q0 = qb * 64 + wave * 32;
     const float* base = qkv + (long)b * Tp * ld + h * D;
     if (seed_ptr && drop_p > 0.f) seed += *seed_ptr;
+    // rows / keys beyond Tp are zero in every staged tile and probability: their 32-key tiles and key pairs are skipped (the same bits, 256 keys' worth of
+    // matrix work only when there are 256 keys)
+    const int ntile = (Tp + 31) >> 5;
+    auto khalf = [&](int hf) __attribute__((always_inline)) -> int { const int n = (Tp - hf * 128 + 1) >> 1; return n < 0 ? 0 : (n > 64 ? 64 : n); };
     float* myP = PT + wave * 32 * ATL_LDP;
     float* myR = RQ + wave * 32 * 33;
     stage_rows<D, LD, 32, 128>(RL, relk, D, nw, tid);
@@ -1101,7 +1105,7 @@ __global__ __launch_bounds__(128) void attn_fwd_long_kernel(const float* __restr
             const int k = 2 * ks + lhi;
             const float a = myP[l31 * LD + k];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) S[hf * 4 + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[(32 * nt + l31) * LD + k], S[hf * 4 + nt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt) { if (hf * 4 + nt < ntile) S[hf * 4 + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[(32 * nt + l31) * LD + k], S[hf * 4 + nt], 0, 0, 0); }
             if (hf == 0) R = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RL[l31 * LD + k], R, 0, 0, 0);
         }
     }
@@ -1160,7 +1164,7 @@ __global__ __launch_bounds__(128) void attn_fwd_long_kernel(const float* __restr
         if (hf == 0) stage_rows<D, LD, 32, 128>(RL, relv, D, nw, tid);
         __syncthreads();
 #pragma unroll 4
-        for (int ks = 0; ks < 64; ++ks) {
+        for (int ks = 0; ks < khalf(hf); ++ks) {
             const int k = 2 * ks + lhi;
             const float a = myP[l31 * ATL_LDP + hf * 128 + k];
 #pragma unroll
@@ -1204,6 +1208,10 @@ __global__ __launch_bounds__(128) void attn_bwd_long_q_kernel(const float* __res
     const float* dob = dout + (long)b * Tp * C + h * D;
     float* dbase = dqkv + (long)b * Tp * ld + h * D;
     if (seed_ptr && drop_p > 0.f) seed += *seed_ptr;
+    // rows / keys beyond Tp are zero in every staged tile and probability: their 32-key tiles and key pairs are skipped (the same bits, 256 keys' worth of
+    // matrix work only when there are 256 keys)
+    const int ntile = (Tp + 31) >> 5;
+    auto khalf = [&](int hf) __attribute__((always_inline)) -> int { const int n = (Tp - hf * 128 + 1) >> 1; return n < 0 ? 0 : (n > 64 ? 64 : n); };
     float* myP = PT + wave * 32 * ATL_LDP;
     float* myR = RQ + wave * 32 * 33;
     float* mypart = part + ((((long)b * H + h) * nqb + qb) * 2 + wave) * 2 * nw * D;
@@ -1227,7 +1235,7 @@ __global__ __launch_bounds__(128) void attn_bwd_long_q_kernel(const float* __res
             const int k = 2 * ks + lhi;
             const float a = myP[l31 * LD + k];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) S[hf * 4 + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[(32 * nt + l31) * LD + k], S[hf * 4 + nt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt) { if (hf * 4 + nt < ntile) S[hf * 4 + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, KV[(32 * nt + l31) * LD + k], S[hf * 4 + nt], 0, 0, 0); }
             if (hf == 0) R = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RL[l31 * LD + k], R, 0, 0, 0);
         }
     }
@@ -1320,7 +1328,7 @@ __global__ __launch_bounds__(128) void attn_bwd_long_q_kernel(const float* __res
         if (hf == 0) stage_rows<D, LD, 32, 128>(RL, relk, D, nw, tid);
         __syncthreads();
 #pragma unroll 4
-        for (int ks = 0; ks < 64; ++ks) {
+        for (int ks = 0; ks < khalf(hf); ++ks) {
             const int k = 2 * ks + lhi;
             const float a = myP[l31 * ATL_LDP + hf * 128 + k];
 #pragma unroll
@@ -1363,6 +1371,11 @@ __global__ __launch_bounds__(128) void attn_bwd_long_kv_kernel(const float* __re
     const float* dob = dout + (long)b * Tp * C + h * D;
     float* dbase = dqkv + (long)b * Tp * ld + h * D;
     if (seed_ptr && drop_p > 0.f) seed += *seed_ptr;
+    // rows / keys beyond Tp are zero in every staged tile and probability: their 32-key tiles and key pairs are skipped (the same bits, 256 keys' worth of
+    // matrix work only when there are 256 keys)
+    const int ntile = (Tp + 31) >> 5;
+    (void)ntile;
+    auto khalf = [&](int hf) __attribute__((always_inline)) -> int { const int n = (Tp - hf * 128 + 1) >> 1; return n < 0 ? 0 : (n > 64 ? 64 : n); };
     const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     const float* Pb = P + ((long)b * H + h) * Tp * Tp;
     const float* Sb = dSg + ((long)b * H + h) * Tp * Tp;
@@ -1378,7 +1391,7 @@ __global__ __launch_bounds__(128) void attn_bwd_long_kv_kernel(const float* __re
             stage_rows<D, LD, 128, 128>(KV, yrows + (long)hf * 128 * yld, yld, Tp - hf * 128, tid);
             __syncthreads();
 #pragma unroll 4
-            for (int ks = 0; ks < 64; ++ks) {
+            for (int ks = 0; ks < khalf(hf); ++ks) {
                 const int il = 2 * ks + lhi;
                 const float a = XT[(hf * 128 + il) * 65 + 32 * wave + l31];
 #pragma unroll
@@ -1393,7 +1406,7 @@ __global__ __launch_bounds__(128) void attn_bwd_long_kv_kernel(const float* __re
             for (int nd = 0; nd < ND; ++nd) dst[(long)j * ld + 32 * nd + l31] = O[nd][reg];
         }
     };
-    for (int idx = tid; idx < 256 * 64; idx += 128) {       // Pd[:, block]
+    for (int idx = tid; idx < ((Tp + 1) & ~1) * 64; idx += 128) {       // Pd[:, block]
         const int i = idx >> 6, jj = idx & 63, j = j0 + jj;
         float v = 0.f;
         if (i < Tp && j < Tp) {
@@ -1404,7 +1417,7 @@ __global__ __launch_bounds__(128) void attn_bwd_long_kv_kernel(const float* __re
     }
     product(dob, C, dbase + 2 * C);                         // dV
     __syncthreads();
-    for (int idx = tid; idx < 256 * 64; idx += 128) {       // dS[:, block]
+    for (int idx = tid; idx < ((Tp + 1) & ~1) * 64; idx += 128) {       // dS[:, block]
         const int i = idx >> 6, jj = idx & 63, j = j0 + jj;
         XT[i * 65 + jj] = (i < Tp && j < Tp) ? Sb[(long)i * Tp + j] : 0.f;
     }
