@@ -32,6 +32,7 @@ def _L():
     if not _decl:
         L.glowtts_wgrad_cl.argtypes = [c_p, c_p]
         L.glowtts_layernorm_fwd_io.argtypes = [c_p] * 8 + [c_i64, c_int, c_f, c_int, c_f, c_u32, c_p, c_p, c_p]
+        L.glowtts_proj_layernorm.argtypes = [c_p, c_i64, c_p, c_int] + [c_p] * 10 + [c_i64, c_int, c_f, c_f, c_u32, c_p, c_p]
         L.glowtts_layernorm_scratch_floats.argtypes = [c_i64, c_int]
         L.glowtts_layernorm_scratch_floats.restype = c_i64
         L.glowtts_layernorm_bwd_io.argtypes = [c_p] * 9 + [c_i64, c_int, c_int, c_f, c_p, c_p, c_f, c_p]
@@ -279,6 +280,10 @@ def _conv_launch(a, pw, ci, R, k, flags, n, bias, rowmask, out, in0=None, drop_p
                 bias=bias, rowmask=rowmask, in0=in0, ldi0=n, out0=out, ld0=n, drop_p=drop_p, seed=seed, seed_t=seed_t, io_flags=io)
 
 
+# measured design switches of the block functions (tests flip them; never read from the environment)
+FUSE = {"proj_ln": True}
+
+
 class FFNBlock(torch.autograd.Function):
     """x2 = LayerNorm_1( Dropout(Conv_1(Dropout(ReLU(Conv_0(x1 * mask))) * mask)) * mask + x1 )   (Modules.py:565-571), bf16-stored rows.
 
@@ -358,11 +363,21 @@ class AttentionBlock(torch.autograd.Function):
         _lib.check(L.glowtts_rpr_attention_fwd_prec(qkv.data_ptr(), rk.data_ptr(), rv.data_ptr(), rowmask.data_ptr(), att.data_ptr(), P.data_ptr(),
                                                     B, Tp, H, D, win, float(drop_p), int(seeds[0]) & 0xFFFFFFFF, _sp(seed_t), ops.BF16, _lib.stream()),
                    "glowtts_rpr_attention_fwd_prec")
-        proj = torch.empty(R, C, device=dev)
-        _conv_launch(att, packs_p[0], C, R, 1, ops.F_BIAS | dflag, C, bp.detach(), rowmask, proj, drop_p=drop_p, seed=seeds[1], seed_t=seed_t, a_bf=False)
         y, yb, s_, stats = torch.empty_like(x), torch.empty(R, C, device=dev, dtype=bf), torch.empty_like(x), torch.empty(R, 2, device=dev)
-        _lib.check(L.glowtts_layernorm_fwd_io(proj.data_ptr(), x.data_ptr(), s_.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rowmask.data_ptr(),
-                                              y.data_ptr(), stats.data_ptr(), R, C, 1e-4, 0, 0.0, 0, None, yb.data_ptr(), _lib.stream()), "glowtts_layernorm_fwd_io")
+        pw = packs_p[0]
+        from .decoder import TUNE
+        if FUSE["proj_ln"] and TUNE["enc_proj_ln"] and C == 192 and pw.precision == ops.BF16 and pw.npad >= C and R * C * 4 < 2 ** 31:
+            # projection + dropout + residual + LayerNorm as ONE launch (csrc/gemm_cl.hip proj_ln_kernel): one link less in the encoder's forward chain
+            proj = torch.empty(R, C, device=dev) if drop_p > 0 else None
+            _lib.check(L.glowtts_proj_layernorm(att.data_ptr(), C, pw.data.data_ptr(), pw.npad, bp.detach().data_ptr(), x.data_ptr(), gamma.data_ptr(),
+                                                beta.data_ptr(), rowmask.data_ptr(), _sp(proj), s_.data_ptr(),
+                                                stats.data_ptr(), y.data_ptr(), yb.data_ptr(), R, C, 1e-4, float(drop_p), int(seeds[1]) & 0xFFFFFFFF,
+                                                _sp(seed_t), _lib.stream()), "glowtts_proj_layernorm")
+        else:
+            proj = torch.empty(R, C, device=dev)
+            _conv_launch(att, packs_p[0], C, R, 1, ops.F_BIAS | dflag, C, bp.detach(), rowmask, proj, drop_p=drop_p, seed=seeds[1], seed_t=seed_t, a_bf=False)
+            _lib.check(L.glowtts_layernorm_fwd_io(proj.data_ptr(), x.data_ptr(), s_.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rowmask.data_ptr(),
+                                                  y.data_ptr(), stats.data_ptr(), R, C, 1e-4, 0, 0.0, 0, None, yb.data_ptr(), _lib.stream()), "glowtts_layernorm_fwd_io")
         tape.ln_count += 1
         ctx.save_for_backward(xb, qkv, rk, rv, P, att, proj if drop_p > 0 else None, s_, stats, gamma, rowmask, wqkv, wp, seed_t)
         ctx.misc = (tape, packs_qkv[1], packs_p[1], float(drop_p), B, Tp, H, win, int(seeds[0]) & 0xFFFFFFFF)

@@ -1310,6 +1310,145 @@ int launch_skinny(const glowtts_conv_args& a, hipStream_t s)
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
+// ------------------------------------------------------------------------------------------------
+// proj_ln_kernel (round 4): the attention block's output projection AND the LayerNorm behind it in ONE launch (Modules.py:560-562):
+//   proj = Dropout(att W^T + bias);  s = proj + x;  y = LayerNorm_192(s) * gamma + beta, * rowmask   (+ the bf16 copy of y, the (mean, rstd) pairs)
+// conv_skinny_kernel's loads (A rows straight from global memory as MFMA fragments, the packed weight image from L2, everything issued up front).  Replaces a
+// register-staged conv launch (the skinny kernel takes no dropout) + ln_fwd_kernel on the encoder's forward chain, six times a step.
+// Arithmetic: the conv epilogue's (bias, dropout keyed by row * C + column) and ln_fwd_kernel's two-pass statistics; sums in another order.
+// ------------------------------------------------------------------------------------------------
+struct proj_ln_args {
+    const float* a; long lda;                    // attention output rows, fp32 [rows][lda]
+    const void* w; int npad;                     // packed bf16 image of the projection weight [192 -> 192]
+    const float* bias; const float* x;           // bias [192]; residual rows [rows][192]
+    const float* gamma; const float* beta; const float* rowmask;
+    float* proj;                                 // out (may be NULL): the dropped projection, kept for the LayerNorm backward's dropout gate
+    float* s; float* stats; float* y; unsigned short* yb;
+    long rows; float eps, drop_p; uint32_t seed; const uint32_t* seed_ptr;
+};
+
+__global__ __launch_bounds__(384) void proj_ln_kernel(const proj_ln_args p)
+{
+    // One workgroup = one 32-row fragment, SIX waves = its six 32-column fragments: a single wave per fragment (conv_skinny_kernel's shape) ran 20.8 us
+    // alone - 72 weight loads, 72 MFMAs and a 16-row epilogue in one dependent stream - against 13.0 us for the two launches it replaces.  Each wave loads
+    // the fragment's A rows (the other five find them in L1), its own 12 weight chunks, does 12 MFMAs; row statistics meet in LDS (two exchanges: mean, then
+    // the centred squares - ln_fwd_kernel's two passes).
+    constexpr int KS16 = 12, NW = 6, C = 192;
+    __shared__ float part[2][NW][32];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * 32;
+    // the fragment's A rows: once, coalesced, into LDS (as per-lane fragment loads - a lane per row - each of the six waves walked 32 cache lines per
+    // instruction: 17 us for the launch); rows of 196 floats: a fragment read is conflict-free
+    constexpr int LDA = C + 4;
+    __shared__ __attribute__((aligned(16))) float atile[32 * LDA];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 384 * i, r = idx / 48, c4 = idx - r * 48;
+        long gr = m0 + r;
+        gr = gr < p.rows ? gr : p.rows - 1;
+        *reinterpret_cast<f32x4*>(&atile[r * LDA + c4 * 4]) = *reinterpret_cast<const f32x4*>(p.a + gr * p.lda + c4 * 4);
+    }
+    Chunk16 bfr[KS16];
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w);
+#pragma unroll
+    for (int k = 0; k < KS16; ++k)
+        bfr[k] = *reinterpret_cast<const Chunk16*>(wb + ((size_t)((k >> 1) * p.npad + wave * 32 + l31) * 64 + (size_t)((2 * (k & 1) + lhi) * 16)));
+    // epilogue operands, asked for before the MFMAs: accumulator element reg: row = (reg & 3) + 8 (reg >> 2) + 4 lhi, column = 32 wave + l31; rows past the
+    // end are dropped / read as zero by the descriptors' bounds check
+    auto mk = [](const void* ptr, long bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000); };
+    const Rsrc rx = mk(p.x, p.rows * C * 4), rs = mk(p.s, p.rows * C * 4), ry = mk(p.y, p.rows * C * 4), ryb = mk(p.yb, p.rows * C * 2);
+    const Rsrc rpj = mk(p.proj, p.proj ? p.rows * C * 4 : 0), rst = mk(p.stats, p.rows * 8), rmk = mk(p.rowmask, p.rows * 4);
+    const int rb = m0 + 4 * lhi, col = wave * 32 + l31;
+    auto rof = [](int reg) { return (reg & 3) + 8 * (reg >> 2); };
+    float xin[16], mk16[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int r = rb + rof(reg);
+        xin[reg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (uint32_t)(r * C + col) * 4u, 0, 0));
+        mk16[reg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmk, (uint32_t)r * 4u, 0, 0));
+    }
+    const float bs = p.bias[col], gm = p.gamma[col], bt = p.beta[col];
+    uint32_t seed = p.seed;
+    if (p.seed_ptr && p.drop_p > 0.f) seed += *p.seed_ptr;
+    const bool drop = p.drop_p > 0.f;
+    const float ik = drop ? 1.f / (1.f - p.drop_p) : 1.f;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    __syncthreads();
+    f32x4 araw[KS16][2];
+#pragma unroll
+    for (int k = 0; k < KS16; ++k) {
+        araw[k][0] = *reinterpret_cast<const f32x4*>(&atile[l31 * LDA + lhi * 8 + k * 16]);
+        araw[k][1] = *reinterpret_cast<const f32x4*>(&atile[l31 * LDA + lhi * 8 + k * 16 + 4]);
+    }
+#pragma unroll
+    for (int k = 0; k < KS16; ++k) {
+        Chunk16 af;
+        af[0] = pack_bf16x2(araw[k][0][0], araw[k][0][1]); af[1] = pack_bf16x2(araw[k][0][2], araw[k][0][3]);
+        af[2] = pack_bf16x2(araw[k][1][0], araw[k][1][1]); af[3] = pack_bf16x2(araw[k][1][2], araw[k][1][3]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&af), *reinterpret_cast<const bf16x8*>(&bfr[k]), acc, 0, 0, 0);
+    }
+    // sum over the 32 lanes of a half wave, valid in its LAST lane (31 / 63): four row_shr steps inside each 16-lane row, then row_bcast:15 adds row 0's
+    // total into row 1 (row 2's into row 3) - five VALU instructions with DPP operands (as ds_bpermute shuffles the 32 sums of a lane were 960 LDS
+    // instructions per workgroup)
+    auto half_sum32 = [](float v) __attribute__((always_inline)) -> float {
+        auto dpp = [](float x, auto CTRL, auto RMASK) __attribute__((always_inline)) -> float {
+            return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(CTRL)::value, decltype(RMASK)::value, 0xF, true));
+        };
+        v += dpp(v, IC<0x111>{}, IC<0xF>{});
+        v += dpp(v, IC<0x112>{}, IC<0xF>{});
+        v += dpp(v, IC<0x114>{}, IC<0xF>{});
+        v += dpp(v, IC<0x118>{}, IC<0xF>{});
+        v += dpp(v, IC<0x142>{}, IC<0xA>{});
+        return v;
+    };
+    float v[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const uint32_t id = (uint32_t)(rb + rof(reg)) * (uint32_t)C + (uint32_t)col;
+        float t = acc[reg] + bs;
+        if (drop) {
+            t *= drop_scale(seed, id, p.drop_p, ik);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), rpj, id * 4u, 0, 0);
+        }
+        t += xin[reg];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), rs, id * 4u, 0, 0);
+        v[reg] = t;
+        const float ps = half_sum32(t);
+        if (l31 == 31) part[0][wave][4 * lhi + rof(reg)] = ps;
+    }
+    __syncthreads();
+    float mean[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int rr = 4 * lhi + rof(reg);
+        float sm = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sm += part[0][w][rr];
+        mean[reg] = sm * (1.f / C);
+        const float d = v[reg] - mean[reg];
+        const float pq = half_sum32(d * d);
+        if (l31 == 31) part[1][wave][rr] = pq;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int rr = 4 * lhi + rof(reg), r = rb + rof(reg);
+        float sq = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sq += part[1][w][rr];
+        const float rstd = rsqrtf(sq * (1.f / C) + p.eps);
+        if (wave == 0 && l31 < 2) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l31 ? rstd : mean[reg]), rst, (uint32_t)(2 * r + l31) * 4u, 0, 0);
+        const uint32_t id = (uint32_t)r * (uint32_t)C + (uint32_t)col;
+        const float o = ((v[reg] - mean[reg]) * rstd * gm + bt) * mk16[reg];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ry, id * 4u, 0, 0);
+        const __bf16 ob = (__bf16)o;
+        __builtin_amdgcn_raw_buffer_store_b16(*reinterpret_cast<const unsigned short*>(&ob), ryb, id * 2u, 0, 0);
+    }
+}
+
 // the short-K 1x1 problems of the path (LINEAR epilogue, fp32 A rows, bf16 MFMA, <= 192 columns): -1 = not one of them
 inline int try_skinny(const glowtts_conv_args& a, hipStream_t s)
 {
@@ -1692,3 +1831,20 @@ extern "C" int glowtts_conv_chain(const glowtts_conv_args* first, const glowtts_
     if (a.epi == GLOWTTS_EPI_LINEAR && (a.flags & GLOWTTS_F_MASK) && b.epi == GLOWTTS_EPI_DGATE) return launch_chain<GLOWTTS_EPI_LINEAR, GLOWTTS_EPI_DGATE>(a, b, s);
     return GLOWTTS_E_ARG;
 }
+
+extern "C" int glowtts_proj_layernorm(const float* a, int64_t lda, const void* w, int npad, const float* bias, const float* x, const float* gamma,
+                                      const float* beta, const float* rowmask, float* proj_kept, float* s, float* stats, float* y, uint16_t* y_bf16,
+                                      int64_t rows, int C, float eps, float drop_p, uint32_t seed, const uint32_t* seed_ptr, void* stream)
+{
+    if (!a || !w || !bias || !x || !gamma || !beta || !rowmask || !s || !stats || !y || !y_bf16 || rows < 1) return GLOWTTS_E_ARG;
+    if (C != 192 || npad < 192 || lda < C || (lda & 3) || rows * C * 4 >= ((int64_t)1 << 31) || drop_p < 0.f || drop_p >= 1.f) return GLOWTTS_E_ARG;
+    if (drop_p > 0.f && !proj_kept) return GLOWTTS_E_ARG;
+    proj_ln_args p;
+    p.a = a; p.lda = lda; p.w = w; p.npad = npad; p.bias = bias; p.x = x; p.gamma = gamma; p.beta = beta; p.rowmask = rowmask;
+    p.proj = drop_p > 0.f ? proj_kept : nullptr; p.s = s; p.stats = stats; p.y = y; p.yb = y_bf16;
+    p.rows = rows; p.eps = eps; p.drop_p = drop_p; p.seed = seed; p.seed_ptr = seed_ptr;
+    GLOWTTS_NOTE_STATIC("proj_ln<%d>", 192);
+    hipLaunchKernelGGL(proj_ln_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(384), 0, static_cast<hipStream_t>(stream), p);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+

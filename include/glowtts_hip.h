@@ -515,6 +515,13 @@ int glowtts_layernorm_fwd(const float *a, const float *b, float *s_out, const fl
 int glowtts_layernorm_fwd_io(const float *a, const float *b, float *s_out, const float *gamma, const float *beta, const float *rowmask,
                              float *y, float *stats, int64_t rows, int C, float eps, int relu, float drop_p, uint32_t seed,
                              const uint32_t *seed_ptr, uint16_t *y_bf16, void *stream);
+/* Round 4: the attention block's output projection and the LayerNorm behind it in one launch (Modules.py:560-562; replaces glowtts_conv_cl on the
+ * fp32 attention rows + glowtts_layernorm_fwd_io):  proj = Dropout(a W^T + bias) (kept in proj_kept when drop_p > 0: the backward's dropout gate),
+ * s = proj + x, stats = (mean, rstd) of s over C = 192 channels, y = (LayerNorm(s) gamma + beta) rowmask, y_bf16 = y rounded.  w: the packed bf16
+ * image of the [192][192][1] weight (glowtts_pack_weight*, npad columns).  bf16 MFMA operands, fp32 everything else. */
+int glowtts_proj_layernorm(const float *a, int64_t lda, const void *w, int npad, const float *bias, const float *x, const float *gamma,
+                           const float *beta, const float *rowmask, float *proj_kept, float *s, float *stats, float *y, uint16_t *y_bf16,
+                           int64_t rows, int C, float eps, float drop_p, uint32_t seed, const uint32_t *seed_ptr, void *stream);
 int64_t glowtts_layernorm_scratch_floats(int64_t rows, int C);
 /* ds = dL/d(a + b); dgamma_dbeta [2C].  gated != 0: the forward applied relu and/or dropout, y is its output (zero where cut). */
 int glowtts_layernorm_bwd(const float *dy, const float *y, const float *s, const float *stats, const float *gamma, const float *rowmask,

@@ -246,3 +246,82 @@ def test_prosody_conv_stack_matches_conv2d(B, M, T, chans, precision):
             assert err < 2e-5, (name, err)
         else:     # bf16 operands through six layers: direction and scale of every gradient, not its worst element (a flipped ReLU moves one)
             assert cos > (0.98 if name == "dmels" else 0.99) and 0.95 < (a.norm() / b_.norm()).item() < 1.05, (name, err, cos)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_projection_and_layernorm_in_one_launch(drop_p):
+    """Round 4: `glowtts_proj_layernorm` (csrc/gemm_cl.hip proj_ln_kernel; Modules.py:560-562) against the two launches it replaces - the
+    register-staged 1x1 conv with bias + dropout on the fp32 attention rows, then `glowtts_layernorm_fwd_io` with the residual: the same dropout
+    decisions (kept projection: zeros in the same places), s / statistics / y to fp32 rounding of another summation order, the bf16 copy of y within
+    one bf16 step; rows that do not fill the last 32-row fragment; and the block function end to end (outputs and every gradient) with the fusion
+    on and off."""
+    import torch
+    from glow_tts_amd import conv_fn as CF, ops, _lib
+    L = CF._L()
+    torch.manual_seed(5)
+    R, C = 32 * 11 + 7, 192
+    att, x = torch.randn(R, C, device="cuda"), torch.randn(R, C, device="cuda")
+    w, b = torch.randn(C, C, 1, device="cuda") * 0.1, torch.randn(C, device="cuda") * 0.1
+    gamma, beta = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1
+    rowmask = (torch.rand(R, device="cuda") > 0.2).float()
+    pw = ops.pack_weight(w, precision=ops.BF16)
+    seed_t = torch.tensor([12345], dtype=torch.int32, device="cuda")
+    # the two launches
+    proj = torch.empty(R, C, device="cuda")
+    CF._conv_launch(att, pw, C, R, 1, ops.F_BIAS | (ops.F_DROPOUT if drop_p > 0 else 0), C, b, rowmask, proj, drop_p=drop_p, seed=77, seed_t=seed_t, a_bf=False)
+    y0, yb0, s0, st0 = torch.empty(R, C, device="cuda"), torch.empty(R, C, device="cuda", dtype=torch.bfloat16), torch.empty(R, C, device="cuda"), torch.empty(R, 2, device="cuda")
+    _lib.check(L.glowtts_layernorm_fwd_io(proj.data_ptr(), x.data_ptr(), s0.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rowmask.data_ptr(), y0.data_ptr(),
+                                          st0.data_ptr(), R, C, 1e-4, 0, 0.0, 0, None, yb0.data_ptr(), _lib.stream()), "ln")
+    # one launch
+    pk = torch.full((R, C), 3.0, device="cuda")
+    y1, yb1, s1, st1 = torch.empty(R, C, device="cuda"), torch.empty(R, C, device="cuda", dtype=torch.bfloat16), torch.empty(R, C, device="cuda"), torch.empty(R, 2, device="cuda")
+    _lib.check(L.glowtts_proj_layernorm(att.data_ptr(), C, pw.data.data_ptr(), pw.npad, b.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                        rowmask.data_ptr(), pk.data_ptr() if drop_p > 0 else None, s1.data_ptr(), st1.data_ptr(), y1.data_ptr(), yb1.data_ptr(),
+                                        R, C, 1e-4, drop_p, 77, seed_t.data_ptr(), _lib.stream()), "proj_ln")
+    torch.cuda.synchronize()
+    if drop_p > 0:
+        assert torch.equal(pk == 0, proj == 0) and 0.05 < float((proj == 0).float().mean()) < 0.15
+        assert (pk - proj).abs().max().item() <= 1e-5 * proj.abs().max().item()
+    assert (s1 - s0).abs().max().item() <= 1e-5 * s0.abs().max().item()
+    assert (st1 - st0).abs().max().item() <= 1e-4 * st0.abs().max().item()
+    assert (y1 - y0).abs().max().item() <= 2e-5 * y0.abs().max().item()
+    assert (yb1.float() - yb0.float()).abs().max().item() <= 2 ** -7 * y0.abs().max().item()
+    assert bool((y1[rowmask == 0] == 0).all())
+
+
+@pytest.mark.gpu
+def test_attention_block_with_and_without_the_fused_projection():
+    import torch
+    from glow_tts_amd import conv_fn as CF, ops
+    torch.manual_seed(9)
+    B, T, C, H, win = 3, 60, 192, 2, 4
+    Tp = T + 4
+    R = B * Tp
+    rowmask = torch.ones(B, Tp, device="cuda")
+    rowmask[:, :2] = 0; rowmask[:, -2:] = 0; rowmask[1, 40:] = 0
+    rowmask = rowmask.reshape(-1).contiguous()
+    res = []
+    for fuse in (False, True):
+        CF.FUSE["proj_ln"] = fuse
+        try:
+            torch.manual_seed(3)
+            x = (torch.randn(R, C, device="cuda") * rowmask[:, None]).requires_grad_(True)
+            wqkv, bqkv = (torch.randn(3 * C, C, 1, device="cuda") * 0.05).requires_grad_(True), torch.zeros(3 * C, device="cuda", requires_grad=True)
+            relk, relv = (torch.randn(1, 2 * win + 1, C // H, device="cuda") * 0.1).requires_grad_(True), (torch.randn(1, 2 * win + 1, C // H, device="cuda") * 0.1).requires_grad_(True)
+            wp, bp = (torch.randn(C, C, 1, device="cuda") * 0.05).requires_grad_(True), torch.zeros(C, device="cuda", requires_grad=True)
+            gamma, beta = torch.ones(C, device="cuda", requires_grad=True), torch.zeros(C, device="cuda", requires_grad=True)
+            tape = CF.WgradTape()
+            packs = [(ops.pack_weight(w.detach(), precision=ops.BF16), ops.pack_weight(w.detach(), transpose=True, precision=ops.BF16)) for w in (wqkv, wp)]
+            seed_t = torch.tensor([7], dtype=torch.int32, device="cuda")
+            y, yb = CF.AttentionBlock.apply(x, x.detach().to(torch.bfloat16), wqkv, bqkv, relk, relv, wp, bp, gamma, beta, rowmask, B, Tp, H, win, 0.1, (11, 13),
+                                            seed_t, tape, packs[0], packs[1])
+            (y * torch.linspace(-1, 1, C, device="cuda")).sum().backward()
+            tape.flush()
+            torch.cuda.synchronize()
+            # (the weight / LayerNorm-parameter gradients are the tape's deferred launches: same operands either way; compared here: what the chain itself produces)
+            res.append([y.detach().clone(), yb.float()] + [t.grad.clone() for t in (x, relk, relv)])
+        finally:
+            CF.FUSE["proj_ln"] = True
+    for a, b in zip(res[0], res[1]):
+        assert (a - b).abs().max().item() <= 2e-3 * max(1e-6, a.abs().max().item())
