@@ -32,6 +32,7 @@ def _L():
     if not _decl:
         L.glowtts_wgrad_cl.argtypes = [c_p, c_p]
         L.glowtts_layernorm_fwd_io.argtypes = [c_p] * 8 + [c_i64, c_int, c_f, c_int, c_f, c_u32, c_p, c_p, c_p]
+        L.glowtts_layernorm_qkv.argtypes = [c_p] * 10 + [c_int, c_p, c_p, c_i64, c_int, c_f, c_p]
         L.glowtts_proj_layernorm.argtypes = [c_p, c_i64, c_p, c_int] + [c_p] * 10 + [c_i64, c_int, c_f, c_f, c_u32, c_p, c_p]
         L.glowtts_layernorm_scratch_floats.argtypes = [c_i64, c_int]
         L.glowtts_layernorm_scratch_floats.restype = c_i64
@@ -293,7 +294,9 @@ class FFNBlock(torch.autograd.Function):
     parameter gradients are deferred to the tape (grouped launches at the end of the encoder's backward)."""
 
     @staticmethod
-    def forward(ctx, x1, x1b, w0, b0, w1, b1, gamma, beta, rowmask, drop_p, seeds, seed_t, tape, packs0, packs1):
+    def forward(ctx, x1, x1b, w0, b0, w1, b1, gamma, beta, rowmask, drop_p, seeds, seed_t, tape, packs0, packs1, next_qkv=None):
+        """next_qkv = (packed Wqkv, bias) of the NEXT block's fused Q / K / V conv: the closing LayerNorm then also computes that conv's output (one
+        launch, csrc/gemm_cl.hip ln_qkv_kernel) and the call returns it as a third, non-differentiable tensor for `AttentionBlock.forward(qkv_pre=...)`."""
         R, C = x1.shape
         O0, k = w0.shape[0], w0.shape[2]
         dev = x1.device
@@ -304,17 +307,29 @@ class FFNBlock(torch.autograd.Function):
         h1 = torch.empty(R, C, device=dev)
         _conv_launch(h0, packs1[0], O0, R, k, ops.F_BIAS | ops.F_MASK | dflag, C, b1.detach(), rowmask, h1, drop_p=drop_p, seed=seeds[1], seed_t=seed_t)
         y, yb, s_, stats = torch.empty_like(x1), torch.empty(R, C, device=dev, dtype=bf), torch.empty_like(x1), torch.empty(R, 2, device=dev)
-        _lib.check(_L().glowtts_layernorm_fwd_io(h1.data_ptr(), x1.data_ptr(), s_.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rowmask.data_ptr(),
-                                                 y.data_ptr(), stats.data_ptr(), R, C, 1e-4, 0, 0.0, 0, None, yb.data_ptr(), _lib.stream()),
-                   "glowtts_layernorm_fwd_io")
+        qkv = None
+        if next_qkv is not None and C == 192 and next_qkv[0].precision == ops.BF16 and next_qkv[0].npad >= 3 * C and R * 3 * C * 4 < 2 ** 31:
+            qkv = torch.empty(R, 3 * C, device=dev)
+            _lib.check(_L().glowtts_layernorm_qkv(h1.data_ptr(), x1.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rowmask.data_ptr(), s_.data_ptr(),
+                                                  stats.data_ptr(), y.data_ptr(), yb.data_ptr(), next_qkv[0].data.data_ptr(), next_qkv[0].npad,
+                                                  next_qkv[1].detach().data_ptr(), qkv.data_ptr(), R, C, 1e-4, _lib.stream()), "glowtts_layernorm_qkv")
+        else:
+            _lib.check(_L().glowtts_layernorm_fwd_io(h1.data_ptr(), x1.data_ptr(), s_.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rowmask.data_ptr(),
+                                                     y.data_ptr(), stats.data_ptr(), R, C, 1e-4, 0, 0.0, 0, None, yb.data_ptr(), _lib.stream()),
+                       "glowtts_layernorm_fwd_io")
         tape.ln_count += 1
         ctx.save_for_backward(x1b, h0, h1 if drop_p > 0 else None, s_, stats, gamma, rowmask, w0, w1)
         ctx.misc = (tape, packs0[1], packs1[1], float(drop_p))
         ctx.mark_non_differentiable(yb)
-        return y, yb
+        if next_qkv is None:
+            return y, yb
+        if qkv is None:
+            qkv = torch.empty(0, device=dev)                  # (shape contract not met: the next block runs its own conv)
+        ctx.mark_non_differentiable(qkv)
+        return y, yb, qkv
 
     @staticmethod
-    def backward(ctx, dy, _dyb):
+    def backward(ctx, dy, _dyb, _dqkv=None):
         x1b, h0, h1, s_, stats, gamma, rowmask, w0, w1 = ctx.saved_tensors
         tape, pwt0, pwt1, drop_p = ctx.misc
         R, C = s_.shape
@@ -339,7 +354,7 @@ class FFNBlock(torch.autograd.Function):
         dw1, db1 = torch.empty_like(w1), torch.empty(C, device=dev)
         tape.add(dz0, x1b, O0, C, k, ops.BF16, dw0, db0)
         tape.add(dz1, h0, C, O0, k, ops.BF16, dw1, db1)
-        return dx1, None, dw0, db0, dw1, db1, gb[:C], gb[C:], None, None, None, None, None, None, None
+        return dx1, None, dw0, db0, dw1, db1, gb[:C], gb[C:], None, None, None, None, None, None, None, None
 
 
 class AttentionBlock(torch.autograd.Function):
@@ -348,15 +363,18 @@ class AttentionBlock(torch.autograd.Function):
     gradient + the residual branch's gradient in its epilogue."""
 
     @staticmethod
-    def forward(ctx, x, xb, wqkv, bqkv, relk, relv, wp, bp, gamma, beta, rowmask, B, Tp, H, win, drop_p, seeds, seed_t, tape, packs_qkv, packs_p):
+    def forward(ctx, x, xb, wqkv, bqkv, relk, relv, wp, bp, gamma, beta, rowmask, B, Tp, H, win, drop_p, seeds, seed_t, tape, packs_qkv, packs_p, qkv_pre=None):
         R, C = x.shape
         dev = x.device
         bf = torch.bfloat16
         L = _L()
         D = C // H
         dflag = ops.F_DROPOUT if drop_p > 0 else 0
-        qkv = torch.empty(R, 3 * C, device=dev)
-        _conv_launch(xb, packs_qkv[0], C, R, 1, ops.F_BIAS, 3 * C, bqkv.detach(), rowmask, qkv)
+        if qkv_pre is not None and qkv_pre.numel():
+            qkv = qkv_pre                                     # computed by the previous block's closing launch (FFNBlock.forward next_qkv)
+        else:
+            qkv = torch.empty(R, 3 * C, device=dev)
+            _conv_launch(xb, packs_qkv[0], C, R, 1, ops.F_BIAS, 3 * C, bqkv.detach(), rowmask, qkv)
         att = torch.empty(R, C, device=dev)
         P = torch.empty(B, H, Tp, Tp, device=dev)
         rk, rv = relk.detach().contiguous(), relv.detach().contiguous()
@@ -415,7 +433,7 @@ class AttentionBlock(torch.autograd.Function):
         dwp, dbp = torch.empty_like(wp), torch.empty(C, device=dev)
         tape.add(dqkv, xb, 3 * C, C, 1, ops.BF16, dwq, dbq)
         tape.add(dzp.float(), att, C, C, 1, ops.BF16, dwp, dbp)       # (the attention output is fp32 rows: the weight-gradient kernel has no bf16 x fp32 form)
-        return (dx, None, dwq, dbq, drel[0].view(1, nw, D), drel[1].view(1, nw, D), dwp, dbp, gb[:C], gb[C:]) + (None,) * 11
+        return (dx, None, dwq, dbq, drel[0].view(1, nw, D), drel[1].view(1, nw, D), dwp, dbp, gb[:C], gb[C:]) + (None,) * 12
 
 
 class EmbeddingRows(torch.autograd.Function):

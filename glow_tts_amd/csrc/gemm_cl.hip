@@ -1449,6 +1449,133 @@ __global__ __launch_bounds__(384) void proj_ln_kernel(const proj_ln_args p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ln_qkv_kernel (round 4): the LayerNorm that closes a transformer block AND the fused Q / K / V 1x1 conv that opens the next one, in ONE launch
+// (Modules.py:571 -> RPR_MHA.py:82-84):  s = a + b;  y = (LayerNorm_192(s) gamma + beta) rowmask (+ its bf16 copy, the (mean, rstd) pairs);
+// qkv = y_bf16 Wqkv^T + bias.  proj_ln_kernel's shape: one workgroup per 32-row fragment, six waves = the six 32-column fragments of the LayerNorm
+// (row statistics meet in LDS), then the same six waves = three 32-column fragments each of the 576 output columns, A fragments from the bf16 tile
+// the LayerNorm left in LDS, weight chunks asked for at the top of the kernel.
+// ------------------------------------------------------------------------------------------------
+struct ln_qkv_args {
+    const float* a; const float* b;              // LayerNorm input and residual rows, fp32 [rows][192]
+    const float* gamma; const float* beta; const float* rowmask;
+    float* s; float* stats; float* y; unsigned short* yb;
+    const void* w; int npad; const float* bias;  // packed bf16 image of Wqkv [192 -> 576], bias [576]
+    float* qkv;                                  // out: fp32 [rows][576]
+    long rows; float eps;
+};
+
+__global__ __launch_bounds__(384) void ln_qkv_kernel(const ln_qkv_args p)
+{
+    constexpr int KS16 = 12, NW = 6, C = 192, NF = 3, N = 576, LDT = C + 8;
+    __shared__ float part[2][NW][32];
+    __shared__ __attribute__((aligned(16))) unsigned short ytile[32 * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * 32;
+    auto mk = [](const void* ptr, long bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000); };
+    const Rsrc ra = mk(p.a, p.rows * C * 4), rbb = mk(p.b, p.rows * C * 4), rs = mk(p.s, p.rows * C * 4), ry = mk(p.y, p.rows * C * 4);
+    const Rsrc ryb = mk(p.yb, p.rows * C * 2), rst = mk(p.stats, p.rows * 8), rmk = mk(p.rowmask, p.rows * 4), rq = mk(p.qkv, p.rows * N * 4);
+    const int rb = m0 + 4 * lhi, col = wave * 32 + l31;
+    auto rof = [](int reg) { return (reg & 3) + 8 * (reg >> 2); };
+    // the loads up front: the LayerNorm's operands of this lane (element reg: row = rof(reg) + 4 lhi, column = 32 wave + l31) and half of the
+    // 36 weight chunks of this wave's three output fragments
+    float v[16], mk16[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int r = rb + rof(reg);
+        const uint32_t off = (uint32_t)(r * C + col) * 4u;
+        v[reg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, off, 0, 0)) + __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbb, off, 0, 0));
+        mk16[reg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmk, (uint32_t)r * 4u, 0, 0));
+    }
+    const float gm = p.gamma[col], bt = p.beta[col];
+    Chunk16 bfr[KS16][NF];
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w);
+    auto load_w = [&](int k0, int k1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = k0; k < k1; ++k)
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+                bfr[k][f] = *reinterpret_cast<const Chunk16*>(wb + ((size_t)((k >> 1) * p.npad + (wave * NF + f) * 32 + l31) * 64 + (size_t)((2 * (k & 1) + lhi) * 16)));
+    };
+    load_w(0, KS16 / 2);                                        // (the second half behind the LayerNorm: all 36 chunks live across it spilled)
+    float bq[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) bq[f] = p.bias[(wave * NF + f) * 32 + l31];
+    auto half_sum32 = [](float x) __attribute__((always_inline)) -> float {      // valid in lanes 31 / 63 (see proj_ln_kernel)
+        auto dpp = [](float t, auto CTRL, auto RMASK) __attribute__((always_inline)) -> float {
+            return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), decltype(CTRL)::value, decltype(RMASK)::value, 0xF, true));
+        };
+        x += dpp(x, IC<0x111>{}, IC<0xF>{});
+        x += dpp(x, IC<0x112>{}, IC<0xF>{});
+        x += dpp(x, IC<0x114>{}, IC<0xF>{});
+        x += dpp(x, IC<0x118>{}, IC<0xF>{});
+        x += dpp(x, IC<0x142>{}, IC<0xA>{});
+        return x;
+    };
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[reg]), rs, (uint32_t)((rb + rof(reg)) * C + col) * 4u, 0, 0);
+        const float ps = half_sum32(v[reg]);
+        if (l31 == 31) part[0][wave][4 * lhi + rof(reg)] = ps;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int rr = 4 * lhi + rof(reg);
+        float sm = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sm += part[0][w][rr];
+        v[reg] -= sm * (1.f / C);                               // centred from here on (the mean itself is re-summed for the statistics store below)
+        const float pq = half_sum32(v[reg] * v[reg]);
+        if (l31 == 31) part[1][wave][rr] = pq;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int rr = 4 * lhi + rof(reg), r = rb + rof(reg);
+        float sq = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sq += part[1][w][rr];
+        const float rstd = rsqrtf(sq * (1.f / C) + p.eps);
+        if (wave == 0 && l31 < 2) {
+            float sm = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sm += part[0][w][rr];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l31 ? rstd : sm * (1.f / C)), rst, (uint32_t)(2 * r + l31) * 4u, 0, 0);
+        }
+        const uint32_t id = (uint32_t)r * (uint32_t)C + (uint32_t)col;
+        const float o = (v[reg] * rstd * gm + bt) * mk16[reg];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ry, id * 4u, 0, 0);
+        const __bf16 ob = (__bf16)o;
+        const unsigned short ou = *reinterpret_cast<const unsigned short*>(&ob);
+        __builtin_amdgcn_raw_buffer_store_b16(ou, ryb, id * 2u, 0, 0);
+        ytile[rr * LDT + col] = ou;
+    }
+    load_w(KS16 / 2, KS16);
+    __syncthreads();
+    // ---- qkv = y_bf16 Wqkv^T + bias: this wave's output fragments 3 wave .. 3 wave + 2 ----
+    f32x16 acc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KS16; ++k) {
+        const Chunk16 af = *reinterpret_cast<const Chunk16*>(&ytile[l31 * LDT + k * 16 + lhi * 8]);
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&af), *reinterpret_cast<const bf16x8*>(&bfr[k][f]), acc[f], 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int r = rb + rof(reg);
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[f][reg] + bq[f]), rq, (uint32_t)(r * N + (wave * NF + f) * 32 + l31) * 4u, 0, 0);
+    }
+}
+
 // the short-K 1x1 problems of the path (LINEAR epilogue, fp32 A rows, bf16 MFMA, <= 192 columns): -1 = not one of them
 inline int try_skinny(const glowtts_conv_args& a, hipStream_t s)
 {
@@ -1845,6 +1972,20 @@ extern "C" int glowtts_proj_layernorm(const float* a, int64_t lda, const void* w
     p.rows = rows; p.eps = eps; p.drop_p = drop_p; p.seed = seed; p.seed_ptr = seed_ptr;
     GLOWTTS_NOTE_STATIC("proj_ln<%d>", 192);
     hipLaunchKernelGGL(proj_ln_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(384), 0, static_cast<hipStream_t>(stream), p);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
+extern "C" int glowtts_layernorm_qkv(const float* a, const float* b, const float* gamma, const float* beta, const float* rowmask, float* s, float* stats,
+                                     float* y, uint16_t* y_bf16, const void* wqkv, int npad, const float* bias, float* qkv, int64_t rows, int C, float eps,
+                                     void* stream)
+{
+    if (!a || !b || !gamma || !beta || !rowmask || !s || !stats || !y || !y_bf16 || !wqkv || !bias || !qkv || rows < 1) return GLOWTTS_E_ARG;
+    if (C != 192 || npad < 576 || rows * 576 * 4 >= ((int64_t)1 << 31)) return GLOWTTS_E_ARG;
+    ln_qkv_args p;
+    p.a = a; p.b = b; p.gamma = gamma; p.beta = beta; p.rowmask = rowmask; p.s = s; p.stats = stats; p.y = y; p.yb = y_bf16;
+    p.w = wqkv; p.npad = npad; p.bias = bias; p.qkv = qkv; p.rows = rows; p.eps = eps;
+    GLOWTTS_NOTE_STATIC("ln_qkv<%d>", 192);
+    hipLaunchKernelGGL(ln_qkv_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(384), 0, static_cast<hipStream_t>(stream), p);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 

@@ -171,6 +171,8 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
     dr = e.Transformer.Dropout_Rate
     H = e.Transformer.Attention.Heads
     win = e.Transformer.Attention.Window_Size
+    qkv_pre = None
+    from .decoder import TUNE
     for i in range(e.Transformer.Stacks):
         q = f"{prefix}.layer_Dict.Transformer.layer_Dict.ANCRDCN_{i}.layer_Dict"
         a = q + ".Attention"
@@ -180,10 +182,16 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
             x = _with_bf16(*AttentionBlock.apply(x, bf16_of(x), Pc[a + ".QKV.weight"], Pc[a + ".QKV.bias"], P[a + ".weight_K"], P[a + ".weight_V"],
                                                  Pc[a + ".layer_Dict.Projection.weight"], Pc[a + ".layer_Dict.Projection.bias"],
                                                  Pc[q + ".LayerNorm_0.weight"], Pc[q + ".LayerNorm_0.bias"], rmf, B, Tp, H, win, pdr, (nseed(), nseed()), seed_t,
-                                                 tape, packset.get(a + ".QKV"), packset.get(a + ".layer_Dict.Projection")))
-            x = _with_bf16(*FFNBlock.apply(x, bf16_of(x), Pc[q + ".Conv_0.weight"], Pc[q + ".Conv_0.bias"], Pc[q + ".Conv_1.weight"], Pc[q + ".Conv_1.bias"],
-                                           Pc[q + ".LayerNorm_1.weight"], Pc[q + ".LayerNorm_1.bias"], rmf, pdr, (nseed(), nseed()), seed_t, tape,
-                                           packset.get(q + ".Conv_0"), packset.get(q + ".Conv_1")))
+                                                 tape, packset.get(a + ".QKV"), packset.get(a + ".layer_Dict.Projection"), qkv_pre))
+            # the block's closing LayerNorm also computes the NEXT block's fused Q / K / V conv (one launch less on the forward chain per block)
+            nxt = None
+            if i + 1 < e.Transformer.Stacks and TUNE["enc_ln_qkv"]:
+                an = f"{prefix}.layer_Dict.Transformer.layer_Dict.ANCRDCN_{i + 1}.layer_Dict.Attention"
+                nxt = (packset.get(an + ".QKV")[0], Pc[an + ".QKV.bias"])
+            out = FFNBlock.apply(x, bf16_of(x), Pc[q + ".Conv_0.weight"], Pc[q + ".Conv_0.bias"], Pc[q + ".Conv_1.weight"], Pc[q + ".Conv_1.bias"],
+                                 Pc[q + ".LayerNorm_1.weight"], Pc[q + ".LayerNorm_1.bias"], rmf, pdr, (nseed(), nseed()), seed_t, tape,
+                                 packset.get(q + ".Conv_0"), packset.get(q + ".Conv_1"), nxt)
+            x, qkv_pre = _with_bf16(out[0], out[1]), (out[2] if nxt is not None else None)
             continue
         qkv = conv(x, a + ".QKV")                                                                            # RPR_MHA.py:82-84 (one fused 1x1 conv)
         att = RPRAttention.apply(qkv, P[a + ".weight_K"], P[a + ".weight_V"], rmf, B, Tp, H, win,

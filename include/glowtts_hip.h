@@ -522,6 +522,12 @@ int glowtts_layernorm_fwd_io(const float *a, const float *b, float *s_out, const
 int glowtts_proj_layernorm(const float *a, int64_t lda, const void *w, int npad, const float *bias, const float *x, const float *gamma,
                            const float *beta, const float *rowmask, float *proj_kept, float *s, float *stats, float *y, uint16_t *y_bf16,
                            int64_t rows, int C, float eps, float drop_p, uint32_t seed, const uint32_t *seed_ptr, void *stream);
+/* Round 4: the LayerNorm that closes a transformer block and the fused Q / K / V 1x1 conv of the next block in one launch (Modules.py:571 ->
+ * RPR_MHA.py:82-84; replaces glowtts_layernorm_fwd_io + glowtts_conv_cl on the bf16 rows):  s = a + b, stats, y, y_bf16 as glowtts_layernorm_fwd_io
+ * (no relu, no dropout); qkv [rows][576] = y_bf16 Wqkv^T + bias, wqkv the packed bf16 image of the [576][192][1] weight (npad columns). */
+int glowtts_layernorm_qkv(const float *a, const float *b, const float *gamma, const float *beta, const float *rowmask, float *s, float *stats,
+                          float *y, uint16_t *y_bf16, const void *wqkv, int npad, const float *bias, float *qkv, int64_t rows, int C, float eps,
+                          void *stream);
 int64_t glowtts_layernorm_scratch_floats(int64_t rows, int C);
 /* ds = dL/d(a + b); dgamma_dbeta [2C].  gated != 0: the forward applied relu and/or dropout, y is its output (zero where cut). */
 int glowtts_layernorm_bwd(const float *dy, const float *y, const float *s, const float *stats, const float *gamma, const float *rowmask,

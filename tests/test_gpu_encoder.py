@@ -325,3 +325,38 @@ def test_attention_block_with_and_without_the_fused_projection():
             CF.FUSE["proj_ln"] = True
     for a, b in zip(res[0], res[1]):
         assert (a - b).abs().max().item() <= 2e-3 * max(1e-6, a.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_layernorm_and_next_qkv_in_one_launch():
+    """Round 4: `glowtts_layernorm_qkv` (csrc/gemm_cl.hip ln_qkv_kernel; Modules.py:571 -> RPR_MHA.py:82-84) against `glowtts_layernorm_fwd_io`
+    followed by the fused Q / K / V 1x1 conv on its bf16 rows: s / statistics / y to fp32 rounding of another summation order, y_bf16 within one bf16
+    step, qkv within the bf16 operand rounding of the few rows where y_bf16 differs by that step; rows that do not fill the last fragment."""
+    import torch
+    from glow_tts_amd import conv_fn as CF, ops, _lib
+    L = CF._L()
+    torch.manual_seed(21)
+    R, C = 32 * 9 + 5, 192
+    a, b = torch.randn(R, C, device="cuda"), torch.randn(R, C, device="cuda")
+    gamma, beta = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1
+    rowmask = (torch.rand(R, device="cuda") > 0.2).float()
+    wq, bq = torch.randn(3 * C, C, 1, device="cuda") * 0.1, torch.randn(3 * C, device="cuda") * 0.1
+    pw = ops.pack_weight(wq, precision=ops.BF16)
+    y0, yb0, s0, st0 = torch.empty(R, C, device="cuda"), torch.empty(R, C, device="cuda", dtype=torch.bfloat16), torch.empty(R, C, device="cuda"), torch.empty(R, 2, device="cuda")
+    _lib.check(L.glowtts_layernorm_fwd_io(a.data_ptr(), b.data_ptr(), s0.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rowmask.data_ptr(), y0.data_ptr(),
+                                          st0.data_ptr(), R, C, 1e-4, 0, 0.0, 0, None, yb0.data_ptr(), _lib.stream()), "ln")
+    q0 = torch.empty(R, 3 * C, device="cuda")
+    CF._conv_launch(yb0, pw, C, R, 1, ops.F_BIAS, 3 * C, bq, rowmask, q0)
+    y1, yb1, s1, st1, q1 = (torch.empty(R, C, device="cuda"), torch.empty(R, C, device="cuda", dtype=torch.bfloat16), torch.empty(R, C, device="cuda"),
+                            torch.empty(R, 2, device="cuda"), torch.empty(R, 3 * C, device="cuda"))
+    _lib.check(L.glowtts_layernorm_qkv(a.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rowmask.data_ptr(), s1.data_ptr(), st1.data_ptr(),
+                                       y1.data_ptr(), yb1.data_ptr(), pw.data.data_ptr(), pw.npad, bq.data_ptr(), q1.data_ptr(), R, C, 1e-4, _lib.stream()), "ln_qkv")
+    torch.cuda.synchronize()
+    assert torch.equal(s1, s0)
+    assert (st1 - st0).abs().max().item() <= 1e-5 * st0.abs().max().item()
+    assert (y1 - y0).abs().max().item() <= 2e-5 * y0.abs().max().item()
+    assert (yb1.float() - yb0.float()).abs().max().item() <= 2 ** -7 * y0.abs().max().item()
+    # qkv of the fused launch against an fp32 product of ITS OWN bf16 rows (bf16-rounded weights, fp32 accumulation)
+    ref = yb1.float() @ wq[:, :, 0].to(torch.bfloat16).float().t() + bq
+    assert (q1 - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    assert (q1 - q0).abs().max().item() <= 2e-2 * q0.abs().max().item()
