@@ -161,7 +161,10 @@ extern "C" int glowtts_flow_forward(const glowtts_flow_dims* d, const glowtts_fl
     const Ctx c = make_ctx(d, p, a, stream);
     // ActNorm + invertible 1x1                                                 Modules.py:693-694, 738-756
     // (x_a passes through, Modules.py:808: written to xout by the same kernel)
-    CHECK(glowtts_actnorm_inv1x1_pass_bf(a->xin, a->xmid, a->xout, a->xa_bf, p->an_logs, p->an_bias, p->winfo, a->rowmask, c.R, d->C, stream));
+    // (actnorm_done: the previous flow's fused coupling launch has already applied it, glowtts_flow_acts.next_*)
+    if (a->next_xmid && (!p->wn_img || !a->next_an_logs || !a->next_an_bias || !a->next_winfo || !a->next_xout)) return GLOWTTS_E_ARG;
+    if (!a->actnorm_done)
+        CHECK(glowtts_actnorm_inv1x1_pass_bf(a->xin, a->xmid, a->xout, a->xa_bf, p->an_logs, p->an_bias, p->winfo, a->rowmask, c.R, d->C, stream));
     return coupling_net(c, a->xmid, a->xout, false, true);
 }
 

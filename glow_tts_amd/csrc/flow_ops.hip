@@ -6,7 +6,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "../../include/glowtts_hip.h"
+#include "launch_log.h"
 #include "tunable.h"
+#include "actnorm_math.h"
 
 namespace {
 
@@ -141,10 +143,10 @@ __global__ __launch_bounds__(256) void actnorm_inv_kernel(const float* __restric
         const int ch[4] = {2 * g, 2 * g + 1, C2 + 2 * g, C2 + 2 * g + 1};
         float o[4];
         if (!REVERSE) {
+            float e4[4], b4[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (bias[ch[k]] + expf(logs[ch[k]]) * v[k]) * m;       // Modules.py:693
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (w[k * 4 + 0] * v[0] + w[k * 4 + 1] * v[1] + w[k * 4 + 2] * v[2] + w[k * 4 + 3] * v[3]) * m;   // :749-756
+            for (int k = 0; k < 4; ++k) { e4[k] = expf(logs[ch[k]]); b4[k] = bias[ch[k]]; }
+            actnorm_mix4(v, e4, b4, w, m, o);                  // (shared with the fused coupling launch's epilogue: actnorm_math.h)
         } else {
             float u[4];
 #pragma unroll
@@ -593,6 +595,7 @@ extern "C" int glowtts_actnorm_inv1x1_pass_bf(const float* xin, float* xout, flo
                                               const float* rowmask, int64_t rows, int C, void* stream)
 {
     if (!xin || !xout || !logs || !bias || !winfo || !rowmask || rows < 1 || C < 4 || (C & 3)) return GLOWTTS_E_ARG;
+    GLOWTTS_NOTE_STATIC("actnorm_inv1x1_pass%s", "");
     hipLaunchKernelGGL(actnorm_inv_kernel<false>, dim3(grid_for(rows * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream),
                        xin, xout, logs, bias, winfo, rowmask, (long)rows, C, (xpass == xout || !xpass) ? (float*)nullptr : xpass, static_cast<uint32_t*>(xa_bf));
     RET_LAUNCH();

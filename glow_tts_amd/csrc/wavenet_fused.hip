@@ -25,6 +25,7 @@
 #include "tunable.h"
 #include "launch_log.h"
 #include "wavenet_common.h"
+#include "actnorm_math.h"
 
 namespace {
 
@@ -62,6 +63,9 @@ struct wn_fwd_args {
     float* skip; float* outs; int64_t ldo;                              // kept (fp32)
     void* skip_bf;                                                      // kept (bf16 copy of skip, [rows][192]; may be null)
     long long* tl;                                                      // tools builds (ABL & 16): per-workgroup phase stamps [grid][32]
+    // the NEXT flow's ActNorm + invertible 1x1 conv, applied by the coupling epilogue to the rows it produces (nx_xmid null: not asked for)
+    const float* nx_logs; const float* nx_bias; const float* nx_winfo;
+    float* nx_xmid; float* nx_xout; uint32_t* nx_xa_bf;
 };
 
 // DROP / COND: training-mode dropout / conditioning present (compile-time, so that the unrolled gate epilogue is straight-line code)
@@ -618,7 +622,57 @@ __global__ __launch_bounds__(WN_NT) void wn_fwd_kernel(const wn_fwd_args p)
                     const uint32_t vo = ok ? vo0 + (uint32_t)(c * (int)p.ldo * 4) : OOB;
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), ro, vo, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lg), ro, vo + 128u, 0, 0);
+                    xb[h][rt][i] = z;                               // (kept for the next flow's ActNorm + 1x1 below)
                 }
+        }
+    }
+    // ---- the NEXT flow's ActNorm + invertible 1x1 conv on the rows just produced (flow_ops.hip actnorm_inv_kernel's arithmetic and access pattern):
+    // z_b of the window goes through the ring slot no slab occupies any more, then ALL twelve waves take (row, channel group) items: group g mixes
+    // (x_a[2g], x_a[2g+1], z_b[2g], z_b[2g+1]) - float2 loads and stores, contiguous over g.  (Done from the accumulator layout by the six End waves alone -
+    // 4-byte scattered stores, every pair computed twice - the epilogue cost as much as the launch it replaces.) ----
+    if (p.nx_xmid && p.reverse == 0) {
+        float* const Z = reinterpret_cast<float*>(wn_smem + OFF_RING + (snext & (WN_NS - 1)) * WN_SLAB);      // [64 window rows][ZLD]
+        constexpr int ZLD = 96;
+        if (wave < 6) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int je = je0 + 16 * h;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Z[(rbe + 16 * rt + i) * ZLD + je] = xb[h][rt][i];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int Cn = 2 * p.C2, G = p.C2 >> 1;
+        const Rsrc rnm = mk_rsrc(p.nx_xmid, (long)p.rows * Cn * 4), rno = mk_rsrc(p.nx_xout, (long)p.rows * Cn * 4);
+        const Rsrc rnb = mk_rsrc(p.nx_xa_bf, p.nx_xa_bf ? (long)p.rows * p.C2 * 2 : 0);
+        float w[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w[q] = p.nx_winfo[q];
+        const int nitems = lim * G;
+        for (int it = tid; it < nitems; it += WN_NT) {
+            const int r = it / G, g = it - r * G;                // owned row r = window row halo + r = global row v0 + r
+            const int grow = v0 + r;
+            const float m = MK[halo + r + WN_PAD];
+            const uint32_t vsrc = (uint32_t)(grow * (int)p.ldx + 2 * g) * 4u;
+            float x[4], e[4], bsn[4], o[4];
+            x[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vsrc, 0, 0));
+            x[1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vsrc, 4, 0));
+            x[2] = Z[(halo + r) * ZLD + 2 * g];
+            x[3] = Z[(halo + r) * ZLD + 2 * g + 1];
+            const int ch[4] = {2 * g, 2 * g + 1, p.C2 + 2 * g, p.C2 + 2 * g + 1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { e[k] = expf(p.nx_logs[ch[k]]); bsn[k] = p.nx_bias[ch[k]]; }
+            actnorm_mix4(x, e, bsn, w, m, o);
+            const uint32_t vn = (uint32_t)(grow * Cn + 2 * g) * 4u;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[0]), rnm, vn, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[1]), rnm, vn, 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[2]), rnm, vn + (uint32_t)p.C2 * 4u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[3]), rnm, vn + (uint32_t)p.C2 * 4u, 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[0]), rno, vn, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[1]), rno, vn, 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(pack_bf16x2(o[0], o[1]), rnb, (uint32_t)(grow * p.C2 + 2 * g) * 2u, 0, 0);
         }
     }
     TLS();
@@ -712,6 +766,11 @@ extern "C" int glowtts_wavenet_fwd(const glowtts_flow_dims* d, const glowtts_flo
     memset(&k, 0, sizeof(k));
     k.rows = (int)R; k.rows_per_utt = Tp; k.L = d->L; k.C2 = C2; k.reverse = reverse; k.keep = keep;
     k.xsrc = xsrc; k.ldx = d->C; k.xdst = xdst; k.ldxd = d->C; k.rowmask = a->rowmask;
+    if (a->next_xmid && !reverse) {                           // the next flow's ActNorm + 1x1 in this launch's coupling epilogue (glowtts_flow_acts.next_*)
+        if (!a->next_an_logs || !a->next_an_bias || !a->next_winfo || !a->next_xout) return GLOWTTS_E_ARG;
+        k.nx_logs = a->next_an_logs; k.nx_bias = a->next_an_bias; k.nx_winfo = a->next_winfo;
+        k.nx_xmid = a->next_xmid; k.nx_xout = a->next_xout; k.nx_xa_bf = static_cast<uint32_t*>(a->next_xa_bf);
+    }
     k.wimg = static_cast<const unsigned char*>(p->wn_img);
     k.b_start = p->b_start; k.b_end = p->b_end;
     for (int l = 0; l < d->L; ++l) { k.b_in[l] = p->b_in[l]; k.b_rs[l] = p->b_rs[l]; }

@@ -40,7 +40,9 @@ class FlowParams(ctypes.Structure):
 class FlowActs(ctypes.Structure):
     _fields_ = [("xin", c_void_p), ("xmid", c_void_p), ("xout", c_void_p),
                 ("hs", c_void_p * MAXL), ("gates", c_void_p * MAXL), ("skip", c_void_p), ("outs", c_void_p),
-                ("rowmask", c_void_p), ("acts", c_void_p * MAXL), ("skip_bf", c_void_p), ("xa_bf", c_void_p)]
+                ("rowmask", c_void_p), ("acts", c_void_p * MAXL), ("skip_bf", c_void_p), ("xa_bf", c_void_p),
+                ("next_an_logs", c_void_p), ("next_an_bias", c_void_p), ("next_winfo", c_void_p),
+                ("next_xmid", c_void_p), ("next_xout", c_void_p), ("next_xa_bf", c_void_p), ("actnorm_done", c_int)]
 
 
 class FlowGrads(ctypes.Structure):
@@ -168,7 +170,7 @@ TAIL = {"defer": False, "pending": []}
 #       memory system at the head of the step and the decoder's forward ends 45 us later: 5.24-5.30 against 5.20-5.23 ms/step (three alternating pairs)
 #   prep_fused: training on the fused bf16 path forms w = g v / ||v|| and every weight image in ONE launch (csrc/prep_ops.hip) instead of 4 weight-norm +
 #       ~22 packing launches (0.42 -> ~0.1 ms at the head of the step, round 4)
-TUNE = {"enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0}
+TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
@@ -653,6 +655,7 @@ def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
     _, rowmask, T = squeeze_rows(cfg, mels, lengths, out=buf.x[0])
     prow = pitch_rows(cfg, pitch[0], rowmask, B, T) if pitch is not None else None
     stamp("dec_fwd_begin")
+    chained = False
     for f in range(cfg.F):
         if pitch is not None:
             cr = _cond_rows(cfg, prep, f, prow, pitch[1], pitch[2], T + 2 * ROW_PAD)
@@ -660,6 +663,14 @@ def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
         if getattr(prep, "fwd_side_from", None) == f:
             torch.cuda.current_stream(mels.device).wait_stream(prep.bwd_side)
         acts = buf.acts(f, cfg.L, rowmask)
+        acts.actnorm_done = int(chained)
+        # a flow on the fused coupling launch also applies the NEXT flow's ActNorm + 1x1 conv in that launch's epilogue (one launch less per flow on the
+        # decoder's forward chain; csrc/wavenet_fused.hip)
+        chained = bool(TUNE["chain_actnorm"]) and f + 1 < cfg.F and bool(prep.params[f].wn_img) and pitch is None
+        if chained:
+            nxt, pn = buf.acts(f + 1, cfg.L, rowmask), prep.params[f + 1]
+            acts.next_an_logs, acts.next_an_bias, acts.next_winfo = pn.an_logs, pn.an_bias, pn.winfo
+            acts.next_xmid, acts.next_xout, acts.next_xa_bf = nxt.xmid, nxt.xout, nxt.xa_bf
         dims = _dims(cfg, B, T, drop_p, seed, f)
         _lib.check(L.glowtts_flow_forward(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(acts), _lib.stream()),
                    "glowtts_flow_forward")

@@ -20,7 +20,7 @@ extern "C" {
 #define GLOWTTS_OK            0
 #define GLOWTTS_E_ARG        -1   /* bad argument / unsupported size */
 #define GLOWTTS_E_LAUNCH     -2   /* hip launch error */
-#define GLOWTTS_ABI_VERSION    3
+#define GLOWTTS_ABI_VERSION    4
 
 /* Library / device identification.  Returns the ABI version (currently 3: round 4 added glowtts_prep_job / glowtts_prep_launch / glowtts_wavenet_prep_jobs; 2: glowtts_flow_params grew wn_img / wn_img_t; round 2's additions to
  * glowtts_mle_loss_bwd, glowtts_flow_params.cond_rows and glowtts_flow_grads.pitch_rows belong to version 2 as well). */
@@ -399,6 +399,14 @@ typedef struct glowtts_flow_acts {        /* rows tensors, R = B*(T+2*PAD) rows 
     float *skip_bf;                       /* act_bf16 only (else NULL): [R][H] bf16 copy of `skip` (End conv / its weight gradient) (kept) */
     void *xa_bf;                          /* optional (ABI 3): [R][C/2] bf16 copy of xmid[:, :C/2] = x_a, written by the flow's ActNorm + 1x1 pass: the X operand
                                            * of the Start conv's weight gradient at half the bytes (kept) */
+    /* ABI 4, glowtts_flow_forward on the fused coupling network only (params->wn_img set): when next_xmid is given, the launch's coupling epilogue also
+     * applies the NEXT flow's ActNorm + invertible 1x1 conv (Modules.py:693-694, 738-756; parameters next_an_logs / next_an_bias [C], next_winfo) to the
+     * rows it has just produced and writes what that flow's own pass would have written: next_xmid [R][C], the x_a half of next_xout [R][C],
+     * next_xa_bf (may be NULL).  The next flow is then called with actnorm_done != 0 and skips its pass. */
+    const float *next_an_logs, *next_an_bias, *next_winfo;
+    float *next_xmid, *next_xout;
+    void *next_xa_bf;
+    int actnorm_done;
 } glowtts_flow_acts;
 
 typedef struct glowtts_flow_grads {       /* backward outputs; weight grads are ADDED (zero them first) */

@@ -80,3 +80,37 @@ def test_decoder_function_gv_form_is_bit_identical(drop):
     assert res[0][2].keys() == res[1][2].keys() and len(res[0][2]) == 96
     for k in res[0][2]:
         assert torch.equal(res[0][2][k], res[1][2][k]), k
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_next_flows_actnorm_in_the_coupling_epilogue_is_bit_identical(drop):
+    """Round 4 (ABI 4, glowtts_flow_acts.next_*): a flow on the fused coupling launch applies the NEXT flow's ActNorm + invertible 1x1 conv in that
+    launch's epilogue (Modules.py:693-694, 738-756) instead of a launch of its own: z, log-determinants and every gradient - i.e. every kept
+    activation the backward reads (xmid, the x_a half of each flow's output, the bf16 x_a rows) - equal the separate pass bit for bit, ragged lengths
+    and a two-frame utterance included."""
+    D, dc, st, P, g = _stacks(4, 23)
+    mels = torch.randn(4, 80, 200, generator=g).cuda()
+    ml = torch.tensor([200, 164, 96, 2]).cuda()
+    wz = torch.randn(4, 80, 200, generator=g).cuda()
+    res, counts = [], []
+    old = D.TUNE["chain_actnorm"]
+    try:
+        for chain in (False, True):
+            D.TUNE["chain_actnorm"] = chain
+            for p in P.values():
+                p.grad = None
+            torch.manual_seed(3)
+            launch_reset()
+            z, ld, _ = D.DecoderFunction.apply(dc, mels, ml, None, drop, None, None, None, *st.weights(gv=True))
+            ((z * wz).sum() + ld.sum()).backward()
+            torch.cuda.synchronize()
+            counts.append(launch_counts())
+            res.append((z.detach().clone(), ld.detach().clone(), {k: p.grad.clone() for k, p in P.items() if p.grad is not None}))
+    finally:
+        D.TUNE["chain_actnorm"] = old
+    n_an = lambda lc: sum(n for k, n in lc.items() if k.startswith("actnorm_inv1x1") and "bwd" not in k)
+    assert n_an(counts[0]) > n_an(counts[1]) >= 1, (counts[0], counts[1])
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert res[0][2].keys() == res[1][2].keys()
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
