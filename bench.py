@@ -565,8 +565,7 @@ def main():
 
     def barrier():
         if dp:
-            import torch.distributed as dist
-            dist.barrier()
+            _gd.barrier()                                       # on the process group's own stream (glow_tts_amd.distributed: collectives and capture)
         torch.cuda.synchronize()
 
     # A step = forward + losses + backward as ONE captured hipGraph (static shapes; the dropout seed is re-drawn on the
@@ -623,6 +622,8 @@ def main():
                         opt[1].step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            if dp:
+                _gd.before_capture()                            # the watchdog holds no Work when the captures begin (glow_tts_amd.distributed)
             graph = torch.cuda.CUDAGraph()
             with _lib.pinned_sink(keep):
                 if dp and not args.no_overlap:
@@ -716,7 +717,7 @@ def main():
         if dp:
             import torch.distributed as dist
             t = torch.tensor([el], device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            _gd._collective(dist.all_reduce, t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, out
 
@@ -748,15 +749,15 @@ def main():
         import torch.distributed as dist
         cs = torch.stack([p.grad.double().sum() for p in model.parameters() if p.grad is not None])
         lo, hi = cs.clone(), cs.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        _gd._collective(dist.all_reduce, lo, op=dist.ReduceOp.MIN)
+        _gd._collective(dist.all_reduce, hi, op=dist.ReduceOp.MAX)
         if not torch.equal(lo, hi):
             raise SystemExit(f"[bench] rank {rank}: {int((lo != hi).sum())} gradient tensors differ between ranks after the all-reduce")
         if opt is not None:                                     # ... and the replicas must still hold the same weights after all those updates
             ps = torch.stack([p.detach().double().sum() for p in model.parameters()])
             lo, hi = ps.clone(), ps.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            _gd._collective(dist.all_reduce, lo, op=dist.ReduceOp.MIN)
+            _gd._collective(dist.all_reduce, hi, op=dist.ReduceOp.MAX)
             if not torch.equal(lo, hi):
                 names = [k for (k, _), bad in zip(model.named_parameters(), (lo != hi).tolist()) if bad]
                 raise SystemExit(f"[bench] rank {rank}: {len(names)} parameter tensors differ between ranks after the optimizer steps, e.g. {names[:4]} .. {names[-2:]}; "
@@ -794,7 +795,7 @@ def main():
     if dp:
         import torch.distributed as dist
         ft = torch.tensor([frames], device=dev, dtype=torch.float64)
-        dist.all_reduce(ft)
+        _gd._collective(dist.all_reduce, ft)
         frames = int(ft.item())
     inv = inverse_flow_leg(model, hp, dev, B, 99 + rank) if (args.config == 5 and rank == 0) else None
     if rank == 0:
@@ -839,7 +840,7 @@ def main():
     sys.stdout.flush()
     if dp:
         import torch.distributed as dist
-        dist.barrier()
+        _gd.barrier()
         dist.destroy_process_group()
         try:
             ctypes.CDLL(None).fflush(None)

@@ -31,7 +31,7 @@ __device__ __forceinline__ float prep_wave_sum(float v) {
 
 __device__ __forceinline__ unsigned short bf16_bits_prep(float v) { const __bf16 b = (__bf16)v; return *reinterpret_cast<const unsigned short*>(&b); }
 
-// The job table travels in the kernel's ARGUMENT segment (<= PREP_MAXJOBS x 96 bytes): inside a captured training step a device-side table would
+// The job table travels in the kernel's ARGUMENT segment (<= PREP_MAXJOBS x sizeof(glowtts_prep_job) = 24 x 120 bytes): inside a captured training step a device-side table would
 // need a host-to-device copy node in front of the launch, re-executed at every replay, on the critical path of the decoder's stream.
 constexpr int PREP_MAXJOBS = GLOWTTS_PREP_MAX_JOBS;
 struct prep_table { glowtts_prep_job jobs[PREP_MAXJOBS]; };

@@ -853,6 +853,8 @@ class DecoderFunction(torch.autograd.Function):
         # class a gap-free view: the leaves' .grad are views of them (LeafStack), so a data-parallel step exchanges the decoder's gradients with ONE
         # collective per arena instead of one per class (distributed.FlatGradReducer reduces storages that its gradients tile; a collective costs
         # ~25 us of launch and stream hand-over whatever its size).  Weight-normalised classes return (d g, d v); their d w is an intermediate.
+        from .distributed import register_arena
+
         def arenas(shapes):
             out = {}
             for tail in (False, True):
@@ -864,6 +866,8 @@ class DecoderFunction(torch.autograd.Function):
                 for k, n, npad in zip(ks, sizes, padded):
                     out[k] = flat[off:off + n].view(shapes[k])
                     off += npad
+                if ks:
+                    register_arena(out[ks[0]])                               # (its pads are private and zero: the reducer may sum the whole span)
             return out
         ret_shapes = {}
         for k in (WEIGHT_KEYS_GV if GV is not None else WEIGHT_KEYS):

@@ -6,6 +6,8 @@ sharded step must keep consistent:
     so ranks are weighted by their frame counts, not averaged);
   * ActNorm data-dependent init (Modules.py:698-711): the [2C+1] batch statistics are summed over ranks.
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -17,6 +19,65 @@ def is_dist():
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or SINGLE_RANK_IS_DIST)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Collectives and hipGraph capture in one process.
+#
+# ProcessGroupNCCL hands every eager collective's Work to its watchdog thread, which polls `hipEventQuery(work.ncclEndEvent_)` every 100 ms
+# until the work has completed.  HIP (ROCm 7) answers such a query with hipErrorCapturedEvent - and the watchdog then aborts the process -
+# when the STREAM THE EVENT WAS LAST RECORDED ON is capturing at that moment, whether or not the record itself was captured.  torch >= 2.7
+# runs `async_op=False` collectives on the CALLER'S CURRENT stream and records the end event there; a step captured within the next 100 ms on
+# that stream (or on a stream the captured autograd pass hops to: the AccumulateGrad nodes stay on the stream of the warm-up passes) then
+# kills the process from the watchdog thread (round 4: `bench.py --force-dist` on a fresh box, the ActNorm-init all-reduces of the warm-up
+# step followed by the capture).  Two rules, both enforced here:
+#   1. every eager collective of this package is issued with `async_op=True` + `wait()`: it runs on the process group's OWN stream, which no
+#      capture ever joins (no collective is issued under capture: `_check_not_capturing`), so the watchdog only ever holds events of that stream;
+#   2. before any capture `before_capture()` drains the watchdog's list (`ProcessGroup._wait_for_pending_works`), so that it holds nothing at all.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _check_not_capturing(what):
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError(f"glow_tts_amd.distributed.{what} was called while the current stream is capturing a hipGraph: collectives stay outside "
+                           "the captured step (compute their results before the capture and pass them in)")
+
+
+def _collective(fn, tensor, *args, **kwargs):
+    """One eager collective (fn = dist.all_reduce / dist.broadcast ...) on the process group's own stream; returns when the caller's current
+    stream is ordered behind it."""
+    _check_not_capturing(fn.__name__)
+    work = fn(tensor, *args, async_op=True, **kwargs)
+    if work is not None:
+        work.wait()
+    return tensor
+
+
+def before_capture():
+    """Call in front of every hipGraph capture of a process that has a process group: waits for the device, then until the backend's watchdog
+    has retired every Work it holds (a no-op without a process group / for backends without a watchdog)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    pg = dist.distributed_c10d._get_default_group()
+    wait = getattr(pg, "_wait_for_pending_works", None)
+    if wait is not None:
+        try:
+            wait()
+        except (RuntimeError, NotImplementedError):
+            pass
+
+
+def barrier():
+    """dist.barrier() on the process group's stream + a device synchronise (bench.py's window brackets)."""
+    if dist.is_available() and dist.is_initialized():
+        _check_not_capturing("barrier")
+        if torch.cuda.is_available() and dist.get_backend() == "nccl":
+            t = torch.zeros(1, device=torch.device("cuda", torch.cuda.current_device()))
+            _collective(dist.all_reduce, t)
+        else:
+            dist.barrier()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
 def broadcast_parameters(model, src=0):
     """Identical replicas at start: rank `src`'s parameters and buffers to every rank (tensors made contiguous first: RCCL rejects
     strided ones, e.g. a loaded checkpoint's column-major 4x4 flow weights)."""
@@ -26,12 +87,12 @@ def broadcast_parameters(model, src=0):
         for t in list(model.parameters()) + list(model.buffers()):
             if not t.data.is_contiguous():
                 t.data = t.data.contiguous()
-            dist.broadcast(t.data, src)
+            _collective(dist.broadcast, t.data, src)
 
 
 def actnorm_stats_allreduce(stats):
     if is_dist():
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        _collective(dist.all_reduce, stats, op=dist.ReduceOp.SUM)
 
 
 def global_frame_weight(local_frames):
@@ -40,7 +101,7 @@ def global_frame_weight(local_frames):
     if not is_dist():
         return torch.ones((), device=local_frames.device)
     tot = local_frames.detach().clone().to(torch.float32)
-    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    _collective(dist.all_reduce, tot, op=dist.ReduceOp.SUM)
     return local_frames.to(torch.float32) / tot
 
 
@@ -50,8 +111,21 @@ def global_token_extent(local_max):
     if not is_dist():
         return local_max
     t = local_max.detach().clone().to(torch.float32)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    _collective(dist.all_reduce, t, op=dist.ReduceOp.MAX)
     return t
+
+
+def global_step_scalars(local_frames, local_max_tokens):
+    """Both per-step scalars of a sharded `Train_Step` with ONE collective (a SUM all-reduce of 1 + world floats: the frame count, and every
+    rank's longest text in its own slot): -> (global_frame_weight(local_frames), global_token_extent(local_max_tokens)), 0-d device tensors."""
+    if not is_dist():
+        return torch.ones((), device=local_frames.device), local_max_tokens
+    frames = local_frames.detach().to(torch.float32)
+    v = torch.zeros(1 + dist.get_world_size(), dtype=torch.float32, device=frames.device)
+    v[0] = frames
+    v[1 + dist.get_rank()] = local_max_tokens.detach().to(torch.float32)
+    _collective(dist.all_reduce, v, op=dist.ReduceOp.SUM)
+    return frames / v[0], v[1:].max()
 
 
 def global_batch_weight(local_utterances, device=None):
@@ -60,8 +134,27 @@ def global_batch_weight(local_utterances, device=None):
     if not is_dist():
         return 1.0
     t = torch.tensor([float(local_utterances)], device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    _collective(dist.all_reduce, t, op=dist.ReduceOp.SUM)
     return float(local_utterances) / float(t.item())
+
+
+# Gradient ARENAS: storages whose gradient views are separated by private, zeroed alignment pads (decoder.DecoderFunction.backward packs each weight
+# class at a 16-byte boundary).  Only for these may FlatGradReducer reduce the whole span, pads included, in place; between gradient views of any
+# other storage a gap may hold somebody else's data.  storage data_ptr -> weak reference to one of the arena's views (alive <=> the storage is).
+_ARENAS = {}
+
+
+def register_arena(view):
+    _ARENAS[view.untyped_storage().data_ptr()] = weakref.ref(view)
+
+
+def _is_arena(storage_ptr):
+    ref = _ARENAS.get(storage_ptr)
+    t = ref() if ref is not None else None
+    if t is None or t.untyped_storage().data_ptr() != storage_ptr:
+        _ARENAS.pop(storage_ptr, None)
+        return False
+    return True
 
 
 class FlatGradReducer:
@@ -77,7 +170,10 @@ class FlatGradReducer:
         flat buckets are built on the first call and kept - no per-step Python over hundreds of parameters, no allocation."""
         self.params = [p for p in params if p.requires_grad]
         self.bucket_bytes, self.direct_bytes, self.static = bucket_bytes, direct_bytes, static
-        self._kept = None
+        self._kept = self._kept_sig = None
+
+    def _signature(self):
+        return tuple(g.data_ptr() if (g := p.grad) is not None else 0 for p in self.params)
 
     def _plan(self):
         """-> (direct: list of flat tensors aliasing gradient storages, buckets: list of lists of gradient tensors)."""
@@ -88,11 +184,12 @@ class FlatGradReducer:
                 g = p.grad = torch.zeros_like(p)
             groups.setdefault(g.untyped_storage().data_ptr(), []).append(g)
         direct, small = [], []
-        for gs in groups.values():
+        for sptr, gs in groups.items():
             gs = sorted(gs, key=lambda t: t.storage_offset())
-            # the gradients tile one span of the storage (alignment gaps of a few elements allowed: decoder.DecoderFunction's arenas pad classes to
-            # 16 bytes and zero the pad)
-            covered = all(t.is_contiguous() for t in gs) and all(0 <= b.storage_offset() - (a.storage_offset() + a.numel()) < 4 for a, b in zip(gs, gs[1:]))
+            # the gradients tile one span of the storage exactly; alignment gaps of a few elements only inside a registered arena (its pads are
+            # private and zero: `register_arena`)
+            slack = 4 if _is_arena(sptr) else 1
+            covered = all(t.is_contiguous() for t in gs) and all(0 <= b.storage_offset() - (a.storage_offset() + a.numel()) < slack for a, b in zip(gs, gs[1:]))
             total = gs[-1].storage_offset() + gs[-1].numel() - gs[0].storage_offset()
             if covered and len({t.dtype for t in gs}) == 1 and total * gs[0].element_size() >= self.direct_bytes:
                 direct.append(torch.empty(0, dtype=gs[0].dtype, device=gs[0].device).set_(gs[0].untyped_storage(), gs[0].storage_offset(), (total,)))
@@ -117,6 +214,9 @@ class FlatGradReducer:
         not touch these gradients may be launched in between: it overlaps the exchange."""
         if not is_dist():
             return None
+        _check_not_capturing("FlatGradReducer.begin")
+        if self.static and self._kept is not None and self._signature() != self._kept_sig:
+            self._kept = None                                  # a gradient appeared, vanished or moved since the plan was made: plan again
         if self.static and self._kept is not None:
             direct, buckets, flats, views = self._kept
             for b, v in zip(buckets, views):
@@ -126,7 +226,7 @@ class FlatGradReducer:
             flats = [torch.cat([g.reshape(-1) for g in b]) for b in buckets]
             views = [self._views(f, b) for f, b in zip(flats, buckets)]
             if self.static:
-                self._kept = (direct, buckets, flats, views)
+                self._kept, self._kept_sig = (direct, buckets, flats, views), self._signature()
         works = [dist.all_reduce(f, op=dist.ReduceOp.SUM, async_op=True) for f in direct + flats]
         return direct, buckets, flats, views, works
 

@@ -40,10 +40,13 @@ class _PackSets:
         self.sets, self.sig = sets, sig
 
     def get(self, key):
+        fwd = None
         for st in self.sets:
             if (key, False) in st.packed:
                 fwd = st.packed[(key, False)]
                 break
+        if fwd is None:
+            raise KeyError(f"no packed weight image for {key!r}")
         tr = None
         for st in self.sets:
             if (key, True) in st.packed:
@@ -126,10 +129,10 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
                  for tr in ((False, True) if torch.is_grad_enabled() else (False,))]
         head = [it for it in items if ".Prenet." in it[0] and not it[2]]
         rest = [it for it in items if not (".Prenet." in it[0] and not it[2])]
-        slot = ("packset", precision, torch.is_grad_enabled())
+        from .decoder import TUNE
+        slot = ("packset", precision, torch.is_grad_enabled(), bool(TUNE["enc_pack_split"]))
         packset = cache.get(slot)
         if packset is None or packset.sig != ops.PackSet.signature(items):
-            from .decoder import TUNE
             parts = (head, rest) if TUNE["enc_pack_split"] else (items,)
             packset = cache[slot] = _PackSets([ops.PackSet(part, precision) for part in parts if part], ops.PackSet.signature(items))
         pack_join = packset.run(pack_stream)

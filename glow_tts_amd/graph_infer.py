@@ -41,8 +41,13 @@ class GraphedInference:
                 fn()
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
+        import torch.distributed as dist
+        grouped = dist.is_available() and dist.is_initialized()
+        if grouped:                                            # a data-parallel trainer's evaluation: see distributed.py "collectives and capture"
+            from .distributed import before_capture
+            before_capture()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local" if grouped else "global"):
             out = fn()
         return g, out
 

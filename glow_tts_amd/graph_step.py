@@ -95,10 +95,13 @@ class GraphedTrainStep:
                 self.steps_taken += 1
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
+        if dp:
+            from .distributed import before_capture
+            before_capture()                                   # the process group's watchdog holds no Work when the captures begin
         _lib.refill_spares()                                   # pinned job tables for this capture (earlier captures kept theirs)
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()         # one pool for every shape: a capture reuses what earlier ones have freed
-        mode = "thread_local" if dp else "global"              # (RCCL's watchdog thread makes its own runtime calls)
+        mode = "thread_local" if dp else "global"              # (RCCL's proxy / watchdog threads make their own runtime calls; see distributed.py)
         keep = []                                              # pinned job tables this entry's copy nodes read
         entry = {"in": static_in, "keep": keep, "tail": None, "opt": None, "early": None, "late": None}
         g = torch.cuda.CUDAGraph()

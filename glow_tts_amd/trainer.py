@@ -62,6 +62,8 @@ class Trainer:
         torch.cuda.set_device(self.device)
         if self.world > 1 and not torch.distributed.is_initialized():
             torch.distributed.init_process_group("nccl")                       # RCCL
+        from . import distributed as gd
+        self.dp = gd.is_dist()                                                 # (also a one-rank group under distributed.SINGLE_RANK_IS_DIST: the RCCL path on one GPU)
         self.Datset_Generate()
         self.Model_Generate()
         self.scalar_Dict = {"Train": defaultdict(float), "Evaluation": defaultdict(float)}
@@ -82,12 +84,15 @@ class Trainer:
         ge = hp.Speaker_Embedding.GE2E.Inference
         ge2e = (ge.Samples, ge.Slice_Length, ge.Overlap_Length) if (hp.Mode.upper() in ("SE", "GR") and hp.Speaker_Embedding.Type.upper() == "GE2E") else None
         buckets = getattr(hp, "HIP_Buckets", None)          # optional extra yaml key: {Mel: [...], Token: [...]} padded shapes (one hipGraph each)
-        mel_b = list(buckets.Mel) if buckets is not None else default_buckets(hp.Train.Train_Pattern.Mel_Length.Max, mel_bucket_step(hp), int(hp.Decoder.Num_Squeeze),
+        # (the Dev loader shares the collater: the top bucket covers the longer of the two filters' maxima - ADVICE r4)
+        mel_max = max(int(hp.Train.Train_Pattern.Mel_Length.Max), int(hp.Train.Eval_Pattern.Mel_Length.Max))
+        txt_max = max(int(hp.Train.Train_Pattern.Text_Length.Max), int(hp.Train.Eval_Pattern.Text_Length.Max))
+        mel_b = list(buckets.Mel) if buckets is not None else default_buckets(mel_max, mel_bucket_step(hp), int(hp.Decoder.Num_Squeeze),
                                                                               offset=-2 * encoder.ROW_PAD * int(hp.Decoder.Num_Squeeze))
         # token buckets: the encoder's rows carry 2 x GLOWTTS_ROW_PAD zero rows per utterance and its attention kernels work on 32-row tiles, the one-workgroup
         # MFMA kernels up to 128 rows: buckets of 32 k - 4 tokens fill whole tiles, and 124 tokens (not 128) is the longest text on the fast kernels -
         # a 128-token bucket ran the step at 6.1 instead of 5.2 ms (attention forward 25 -> 63 us, backward 41 -> 166 us, x 6 blocks)
-        tok_b = list(buckets.Token) if buckets is not None else default_buckets(hp.Train.Train_Pattern.Text_Length.Max + 2, 32, offset=-2 * encoder.ROW_PAD)
+        tok_b = list(buckets.Token) if buckets is not None else default_buckets(txt_max + 2, 32, offset=-2 * encoder.ROW_PAD)
         # Collation (unpickling, padding to the shape bucket): in worker processes like the reference's DataLoader(num_workers = hp.Train.Num_Workers,
         # pin_memory = True) (Train.py:100-107) - at ~6 ms per B = 32 step one Python thread cannot unpickle and pad 5 300 utterances per second.
         # Workers return plain CPU tensors, the loader's pin thread stages them in pinned memory, `_batch_to_device` issues the async copy.
@@ -124,7 +129,7 @@ class Trainer:
                                eps=hp.Train.ADAM.Epsilon, weight_decay=hp.Train.Weight_Decay)
         self.scheduler = Modified_Noam_Scheduler(self.optimizer, base=hp.Train.Learning_Rate.Base)
         self.reducer = None
-        if self.world > 1:
+        if self.dp:
             from .distributed import FlatGradReducer, actnorm_stats_allreduce, broadcast_parameters
             broadcast_parameters(model)
             model.actnorm_allreduce = actnorm_stats_allreduce
@@ -140,9 +145,11 @@ class Trainer:
         # the duration loss (and, GR, the speaker classifier's) on the encoder's stream, beside the MLE reduction: neither they nor their backward
         # sit in front of the flow decoder's backward on this stream
         from .modules import Beside
-        if self.world > 1 and token_extent is None:
-            from .distributed import global_token_extent
-            token_extent = global_token_extent(token_lengths.max())
+        if self.dp and (token_extent is None or frame_weight is None):
+            from .distributed import global_step_scalars
+            fw, te = global_step_scalars(mel_lengths.sum(), token_lengths.max())
+            frame_weight = fw if frame_weight is None else frame_weight
+            token_extent = te if token_extent is None else token_extent
         with Beside(model) as beside:
             beside.uses(log_Durations, log_Duration_Targets, token_lengths, token_extent, classified, speakers)
             length = duration_loss(log_Durations, log_Duration_Targets, token_lengths, token_extent)
@@ -151,10 +158,7 @@ class Trainer:
         mle = self.criterion_Dict["MLE"](z=z, mean=mel_Mean, std=mel_Log_Std, log_dets=log_Dets, lengths=mel_lengths)
         beside.join(length, ce, rest)
         total = mle + length
-        if self.world > 1:
-            if frame_weight is None:
-                from .distributed import global_frame_weight
-                frame_weight = global_frame_weight(mel_lengths.sum())
+        if self.dp:
             loss = mle * frame_weight + rest / self.world
         else:
             loss = mle + rest
@@ -185,9 +189,9 @@ class Trainer:
             loss, comp = self._losses(m, *inp)
             self._comp.copy_(comp)
             return loss
-        if self.world > 1:                                     # two tiny all-reduces per step, outside the captured graphs
-            from .distributed import global_frame_weight, global_token_extent
-            inputs = tuple(inputs) + (global_frame_weight(inputs[3].sum()), global_token_extent(inputs[1].max()))
+        if self.dp:                                            # one tiny all-gather per step, outside the captured graphs
+            from .distributed import global_step_scalars
+            inputs = tuple(inputs) + global_step_scalars(inputs[3].sum(), inputs[1].max())
         if self.use_graph:
             # one process or data parallel: the same captured step (data parallel: three graphs around the gradient exchange, graph_step.py)
             if self._graphed is None:
@@ -268,6 +272,12 @@ class Trainer:
         mv = lambda t: t.to(dev) if torch.is_tensor(t) else t
         mode = self.hp.Mode.upper()
         lut = "LUT" in self.model_Dict["GlowTTS"].layer_Dict
+        if mode in ("SE", "GR") and not lut:
+            # GE2E: the loader hands over the raw slice stack [B * Samples, Mel, Slice]; the model takes d-vectors [B, Embedding_Size] - the same
+            # conversion `_batch_to_device` applies to training batches (Modules.py:154-156 runs the GE2E network inside `inference`)
+            if self.speaker_encoder is None:
+                raise RuntimeError("GE2E mode: pass Trainer(speaker_encoder=...) producing d-vectors (the GE2E network is not part of this package)")
+            mels_for_ge2e = self.speaker_encoder(mv(mels_for_ge2e)).detach()
         mels, mel_Lengths, attentions = self.model_Dict["GlowTTS"].inference(
             mv(tokens), mv(token_lengths), mels_for_prosody=mv(mels_for_prosody) if mode in ("PE", "GR") else None,
             mel_lengths_for_prosody=mv(mel_lengths_for_prosody) if mode in ("PE", "GR") else None,

@@ -22,7 +22,9 @@ extern "C" {
 #define GLOWTTS_E_LAUNCH     -2   /* hip launch error */
 #define GLOWTTS_ABI_VERSION    4
 
-/* Library / device identification.  Returns the ABI version (currently 3: round 4 added glowtts_prep_job / glowtts_prep_launch / glowtts_wavenet_prep_jobs; 2: glowtts_flow_params grew wn_img / wn_img_t; round 2's additions to
+/* Library / device identification.  Returns the ABI version (currently 4: glowtts_flow_acts grew next_* / actnorm_done - the next flow's ActNorm + 1x1 conv in the
+ * fused coupling launch's epilogue - and glowtts_proj_layernorm / glowtts_layernorm_qkv were added; 3: glowtts_prep_job / glowtts_prep_launch / glowtts_wavenet_prep_jobs,
+ * glowtts_actnorm_inv1x1_pass_bf, glowtts_flow_acts.xa_bf, glowtts_flow_grads.dh0_bf16, GLOWTTS_WIO_DMA; 2: glowtts_flow_params grew wn_img / wn_img_t; round 2's additions to
  * glowtts_mle_loss_bwd, glowtts_flow_params.cond_rows and glowtts_flow_grads.pitch_rows belong to version 2 as well). */
 int glowtts_abi_version(void);
 /* Writes the gfx arch string of device 0 into buf (host pointer).  0 on success. */
@@ -326,8 +328,10 @@ typedef struct glowtts_wgrad_args {
 #define GLOWTTS_WIO_X_BF16  2
 #define GLOWTTS_WIO_WIDE    4   /* bf16 precision, no prologue, both operands stored alike (both bf16 or both fp32): the caller promises m, ca, lddy,
                                   ldx multiples of 8 and 16-byte aligned dy / x for EVERY job: operands are then staged 8 channels per item */
-#define GLOWTTS_WIO_DMA     8   /* glowtts_wgrad_grouped_io only (ABI 3): the LDS-DMA / 16x16x32 kernel; on top of WIDE with both operands bf16 the caller promises that every
-                                 * job's m is a multiple of 128 and ca a multiple of 64, operands below 2 GiB, splits = 1, no accumulation */
+#define GLOWTTS_WIO_DMA     8   /* glowtts_wgrad_grouped_io only (ABI 3): the LDS-DMA kernel (192 (o) x 64 (c) x taps tiles; 192 x 192 at one tap; edge tiles are
+                                 * masked on store); on top of WIDE with both operands bf16 (GLOWTTS_WIO_DY_BF16 | GLOWTTS_WIO_X_BF16) the caller promises for EVERY job: m, ca, lddy, ldx
+                                 * multiples of 8, dy / x 16-byte aligned, each operand below 2 GiB, and (mt, nt) / tile0 / total_tiles counted in THAT tiling - mt = ceil(m / 192),
+                                 * nt = ceil(ca / 64) (ceil(ca / 192) at one tap); precision bf16, no prologue, pad = (taps - 1) / 2, splits = 1, no accumulation (else GLOWTTS_E_ARG) */
 int glowtts_wgrad_cl(const glowtts_wgrad_args *args /* host pointer */, void *stream);
 
 /* Grouped form: many weight-gradient problems that share (rows, taps, pad, precision) in ONE launch, so that the

@@ -8,7 +8,7 @@ import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.late(2)]
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAST = ["--steps", "3", "--warmup", "2", "--windows", "0", "--no-cpu-baseline"]
 

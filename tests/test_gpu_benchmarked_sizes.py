@@ -264,6 +264,7 @@ def test_run_to_run_reproducibility(mode):
     print(f"{mode}: {len(a['grads']) - len(noisy)} of {len(a['grads'])} gradients bit-identical across two runs; the others: {sorted(noisy, key=lambda t: -t[1])[:3]}")
 
 
+@pytest.mark.late(1)
 def test_long_form_inverse_at_full_width():
     here = os.path.dirname(os.path.abspath(__file__))
     out = subprocess.run([sys.executable, os.path.join(here, "longform_check.py")], capture_output=True, text=True, timeout=1200, cwd=os.path.dirname(here))

@@ -11,7 +11,7 @@ import torch
 
 from helpers import tiny_hp_dict
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.late(1)]
 
 TEXTS = ["HELLO WORLD.", "GLOW T T S ON M I THREE FIFTY FIVE X!", "A FLOW IS A BIJECTION, IS IT NOT?", "SHORT ONE.", "MONOTONIC ALIGNMENT SEARCH.",
          "WAVE NET COUPLING LAYERS.", "THE QUICK BROWN FOX.", "JUMPS OVER THE LAZY DOG?"]

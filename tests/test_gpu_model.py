@@ -244,6 +244,7 @@ def test_deferred_tail_weight_gradients_equal_plain_backward():
             assert torch.equal(p.grad, want[k]), k
 
 
+@pytest.mark.late(1)
 def test_graphed_train_step_matches_eager():
     """glow_tts_amd.graph_step.GraphedTrainStep: the replayed hipGraph gives the eager step's loss and gradients (f32), also for a
     second batch copied into the static buffers.  Runs in a child process: a failed stream capture takes the process down on
@@ -254,6 +255,7 @@ def test_graphed_train_step_matches_eager():
     assert out.returncode == 0 and "GRAPH STEP OK" in out.stdout, (out.returncode, out.stdout[-2000:], out.stderr[-2000:])
 
 
+@pytest.mark.late(1)
 def test_graphed_inference_matches_eager():
     """glow_tts_amd.graph_infer.GraphedInference: encoder graph + one length read + bucketed inverse-flow graph reproduce
     GlowTTS.inference (same injected noise) for several length scales, Vanilla and speaker-conditioned.  Child process, see above."""
@@ -263,6 +265,7 @@ def test_graphed_inference_matches_eager():
     assert out.returncode == 0 and "GRAPH INFER OK" in out.stdout, (out.returncode, out.stdout[-2000:], out.stderr[-2000:])
 
 
+@pytest.mark.late(2)
 def test_two_ranks_on_one_gpu(tmp_path):
     """Data parallel with the real model on hardware: two ranks share the one GPU of the test box - RCCL if it
     accepts that (probed in a child with a time-out: it usually refuses a duplicate device), else gloo over the same FlatGradReducer /

@@ -36,7 +36,7 @@ def _dp_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from glow_tts_amd.distributed import global_token_extent
+    from glow_tts_amd.distributed import before_capture, global_frame_weight, global_step_scalars, global_token_extent
     g = torch.Generator().manual_seed(0)
     lengths = torch.tensor([17, 9, 23, 4])                           # global batch; rank 0 holds the SHORT texts
     tmax = int(lengths.max())
@@ -46,6 +46,11 @@ def _dp_worker(rank, world, port, q):
     want = torch.nn.MSELoss()(d, t)                                  # Train.py:210 on the global batch
     own = [1, 3] if rank == 0 else [0, 2]
     ext = global_token_extent(lengths[own].max())
+    # the Trainer's per-step form: both scalars from ONE collective
+    frames = torch.tensor(100.0 * (rank + 1))
+    fw2, ext2 = global_step_scalars(frames, lengths[own].max())
+    assert float(ext2) == float(ext) and abs(float(fw2) - float(global_frame_weight(frames))) < 1e-7 and abs(float(fw2) - (rank + 1) / 3.0) < 1e-6
+    before_capture()                                                 # (a backend without a watchdog: returns at once)
     got = duration_loss(d[own][:, :, :32], t[own][:, :, :32], lengths[own], ext) / world
     tot = got.clone()
     dist.all_reduce(tot)
