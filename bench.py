@@ -209,8 +209,48 @@ def fused_forward_case(B, T):
                 kernel="wn_fwd_kernel<drop> (fused coupling network of one flow: Start + 4 x [In_l k=5 + gate + Res_Skip_l] + End + coupling)")
 
 
-# launches per training step of config 2 (12 flows x 4 layers; the fused forward replaced the In_l forward launches)
-CALLS_PER_STEP = {"wn_fwd": 12, "in_dgrad": 48, "in_fwd": 0}
+# Launches per training step of the roofline's kernels.  Filled from the library's own launch log (glowtts_launch_count) around the capture pass of
+# the timed step - `step_launch_counts()` -; the constants are only what an eager (--no-graph) run reports (12 flows x 4 layers).
+CALLS_PER_STEP = {"wn_fwd": 12, "wn_bwd": 0, "in_dgrad": 48, "in_fwd": 0}
+CALLS_SOURCE = ["constants (eager run)"]
+
+
+def launch_log_reset():
+    from glow_tts_amd import _lib
+    _lib.lib().glowtts_launch_log_reset()
+
+
+def step_launch_counts(n_flows=12, n_layers=4):
+    """Reads the launch log after the step's capture pass (exactly one pass of every captured graph was issued since launch_log_reset())."""
+    import ctypes
+    from glow_tts_amd import _lib
+    L = _lib.lib()
+    L.glowtts_launch_count.restype = ctypes.c_int64
+    L.glowtts_launch_count.argtypes = [ctypes.c_char_p]
+    n = lambda cls: int(L.glowtts_launch_count(cls.encode()))
+    wn_bwd = n("wn_bwd<")
+    CALLS_PER_STEP.update({"wn_fwd": n("wn_fwd<"), "wn_bwd": wn_bwd, "in_fwd": n("conv_dma<GATE,5>"),
+                           "in_dgrad": n_layers * (n_flows - wn_bwd)})          # (the decoder flows that are not on the fused backward: one per layer)
+    CALLS_SOURCE[0] = "glowtts_launch_count over the capture pass of the timed step"
+
+
+def in_step_durations():
+    """Average launch durations INSIDE the replayed step from the newest committed per-step kernel statistics (profiles/r*_step_kernel_stats.csv, a
+    rocprofv3 --kernel-trace of `bench.py --profile-run`): evidence read from a file, named as such - not measured by this run."""
+    import csv
+    pdir = os.path.join(REPO, "profiles")
+    cands = sorted(f for f in os.listdir(pdir) if f.endswith("_step_kernel_stats.csv") and f.startswith("r")) if os.path.isdir(pdir) else []
+    if not cands:
+        return {}, None
+    out = {}
+    with open(os.path.join(pdir, cands[-1])) as f:
+        for row in csv.DictReader(f):
+            nm = row.get("Name", "")
+            for key, pat in (("wn_fwd", "wn_fwd_kernel<true, false, true"), ("wn_bwd", "wn_bwd_kernel<true, false"), ("in_dgrad", "conv_dma_kernel<0, 5, 2"),
+                             ("in_fwd", "conv_dma_kernel<1, 5, 2")):
+                if pat in nm and key not in out:
+                    out[key] = (float(row["AverageNs"]) * 1e-3, float(row["CallsPerStep"]))
+    return out, "profiles/" + cands[-1]
 
 
 def time_kernel(run, iters=30):
@@ -269,15 +309,24 @@ def roofline(precision, B, T, step_tflops):
         tr = pmc.get(name, {}).get("traffic") if (pmc and pmc.get("shape") == [B, T] and pmc.get("precision") == precision) else None
         rows[name] = {"kernel": c["kernel"], "achieved": round(ach, 1), "frac": round(ach / peak, 4), "us_per_launch": round(sec * 1e6, 2),
                       "algorithmic_bytes": int(c["alg_bytes"]), "traffic": tr}
+    instep, instep_src = in_step_durations()
     for name, r in rows.items():
         r["launches_per_step"] = CALLS_PER_STEP.get(name, 0)
         r["us_per_step"] = round(r["us_per_launch"] * r["launches_per_step"], 1)
-    top = max(rows.values(), key=lambda r: r["us_per_step"])          # the dominant kernel BY TIME IN THE STEP
+        if name in instep and B == 32 and precision == "bf16":
+            r["in_step_us_per_launch"] = round(instep[name][0], 2)
+            r["frac_in_step"] = round(cases[name]["flops"] / (instep[name][0] * 1e-6) / 1e12 / peak, 4)
+    top_name = max(rows, key=lambda k: rows[k]["us_per_step"])        # the dominant kernel BY TIME IN THE STEP
+    top = rows[top_name]
     out = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": top["frac"],
            "us_per_launch": top["us_per_launch"], "traffic": top["traffic"], "algorithmic_bytes": top["algorithmic_bytes"],
            "traffic_source": src if top["traffic"] is not None else None,
            "timing": "HIP events on the launch stream, 30 back-to-back launches of the kernel alone",
+           "launches_per_step_source": CALLS_SOURCE[0],
            "step_frac": round(step_tflops / peak, 4), "kernels": rows}
+    if "frac_in_step" in top:
+        # the same kernel's average duration inside the replayed step (both streams busy, lower clock): the smaller, stricter fraction
+        out.update(frac_in_step=top["frac_in_step"], in_step_us_per_launch=top["in_step_us_per_launch"], in_step_source=instep_src)
     if precision == "bf16":
         # context, not the graded fraction: the clock (and with it the matrix rate) the chip actually sustains under MFMA load
         ghz, sus = sustained_mfma_clock()
@@ -624,6 +673,7 @@ def main():
             torch.cuda.synchronize()
             if dp:
                 _gd.before_capture()                            # the watchdog holds no Work when the captures begin (glow_tts_amd.distributed)
+            launch_log_reset()
             graph = torch.cuda.CUDAGraph()
             with _lib.pinned_sink(keep):
                 if dp and not args.no_overlap:
@@ -658,6 +708,8 @@ def main():
                     with torch.cuda.graph(opt_graph, pool=graph.pool(), capture_error_mode="thread_local"):
                         clip_and_update()
                     uncount_capture_pass()
+            if not extra_graphs:
+                step_launch_counts()                            # one pass of every graph of the step has been issued since the reset
             if opt is not None and not dp:
                 opt[0].advance_host()
             graph.replay()

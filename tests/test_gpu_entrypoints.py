@@ -114,6 +114,40 @@ def test_train_resume_and_inference(mode, tmp_path):
         assert mel.ndim == 2 and mel.shape[1] == 12 and mel.shape[0] >= 2 and np.isfinite(mel).all()
 
 
+def test_ge2e_mode_trains_and_runs_its_inference_epoch(tmp_path):
+    """SE mode with GE2E d-vectors (config 4's conditioning): the loaders hand over the raw slice stack [B * Samples, Mel, Slice] and BOTH the
+    training batches and the prompts of `Inference_Epoch` must go through `Trainer(speaker_encoder=...)` before the model sees them as d-vectors
+    [B, Embedding_Size] (Modules.py:75-77, 154-156 run the GE2E network inside the model; here it is a caller-supplied callable)."""
+    from glow_tts_amd.hparams import Recursive_Parse
+    from glow_tts_amd.trainer import Trainer
+    d = _make_dataset(str(tmp_path), "SE")
+    d["Speaker_Embedding"]["Type"] = "GE2E"
+    d["Speaker_Embedding"]["GE2E"]["Inference"] = {"Samples": 3, "Slice_Length": 16, "Overlap_Length": 8}
+    d["Train"].update(Max_Step=6, Inference_Interval=5, Checkpoint_Save_Interval=100)
+    hp = Recursive_Parse(d)
+    seen = []
+
+    def speaker_encoder(stack):                                  # a stand-in for the un-vendored GE2E network: [B * 3, 12, 16] -> unit d-vectors [B, 16]
+        assert stack.dim() == 3 and stack.shape[0] % 3 == 0 and tuple(stack.shape[1:]) == (12, 16), tuple(stack.shape)
+        seen.append(stack.shape[0] // 3)
+        v = stack.reshape(-1, 3, 12 * 16).mean(1)[:, :16]
+        return torch.nn.functional.normalize(v, dim=1)
+    torch.manual_seed(0)
+    tr = Trainer(steps=0, hp=hp, speaker_encoder=speaker_encoder)
+    assert "LUT" not in tr.model_Dict["GlowTTS"].layer_Dict
+    tr.Train()
+    assert tr.steps >= 6
+    got = sorted(os.listdir(os.path.join(hp.Inference_Path, "Step-5", "NPY")))
+    assert got == [f"P{i}.npy" for i in range(4)], got
+    for f in got:
+        m = np.load(os.path.join(hp.Inference_Path, "Step-5", "NPY", f))
+        assert m.ndim == 2 and m.shape[1] == 12 and np.isfinite(m).all()
+    assert 3 in seen and 1 in seen                               # the prompts' batches (Inference_Batch_Size = 3: 3 + 1) went through the encoder too
+    with pytest.raises(RuntimeError, match="GE2E"):
+        tr.speaker_encoder = None
+        tr.Inference_Epoch()
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
 def test_graphed_training_reduces_the_loss(precision):
     """120 replayed Train_Steps (forward, MLE + duration loss, backward, clip, RAdam, Noam schedule - all inside the captured hipGraph) on one
