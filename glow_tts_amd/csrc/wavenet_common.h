@@ -20,6 +20,11 @@ constexpr int WN_SROWS = 96;                      // rows of the Start conv's op
 typedef __amdgpu_buffer_rsrc_t Rsrc;
 template <int V> struct IC { static constexpr int value = V; };
 constexpr uint32_t OOB = 0x80000000u;
+// f(IC<0>{}), f(IC<1>{}), ... f(IC<N - 1>{}): straight-line code over compile-time step numbers
+template <int N> struct StaticForN {
+    template <class F> __device__ __forceinline__ static void run(F&& f) { StaticForN<N - 1>::run(f); f(IC<N - 1>{}); }
+};
+template <> struct StaticForN<0> { template <class F> __device__ __forceinline__ static void run(F&&) {} };
 
 __device__ __forceinline__ Rsrc mk_rsrc(const void* ptr, long bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000); }
 __device__ __forceinline__ int frag_row(int reg) { return (reg & 3) + 8 * (reg >> 2); }       // + 4 * (lane >> 5): row of accumulator element `reg`

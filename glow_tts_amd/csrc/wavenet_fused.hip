@@ -44,10 +44,6 @@ constexpr int WN_LDS = OFF_UT + WN_XR * 4;
 static_assert(WN_LDS <= 160 * 1024, "LDS budget");
 static_assert(SZ_AT >= 3 * WN_SROWS * 64, "the Start operand tile aliases the acts tile");
 
-template <int N> struct StaticForN {
-    template <class F> __device__ __forceinline__ static void run(F&& f) { StaticForN<N - 1>::run(f); f(IC<N - 1>{}); }
-};
-template <> struct StaticForN<0> { template <class F> __device__ __forceinline__ static void run(F&&) {} };
 typedef StaticForN<WN_TAPS * WN_KCH> StaticFor30;
 
 struct wn_fwd_args {

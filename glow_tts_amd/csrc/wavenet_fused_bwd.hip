@@ -41,7 +41,8 @@ constexpr int BOFF_DT = BOFF_DS + BSZ_T;                        // da or ds of t
 constexpr int BOFF_RING = BOFF_DT + BSZ_T;
 constexpr int BOFF_MK = BOFF_RING + BW_NS * WN_SLAB;
 constexpr int BOFF_UT = BOFF_MK + WN_XR * 4;                    // utterance of the 68 tile rows (conditioned models)
-constexpr int BW_LDS = BOFF_UT + WN_XR * 4;
+constexpr int BOFF_P3 = BOFF_UT + WN_XR * 4;                    // sigmoid-side gate gradients of tile rows 64..67 (last layer), parked until the second pass: [6][4][64 B]
+constexpr int BW_LDS = BOFF_P3 + WN_KCH * 4 * 64;
 static_assert(BW_LDS <= 160 * 1024, "LDS budget");
 static_assert(BSZ_T >= WN_NW * 8 * 256, "the partial-sum exchange (8 registers per wave and round) reuses the gate-gradient tile");
 
@@ -64,7 +65,16 @@ struct wn_bwd_args {
 // utterance's rows of (da, ds) BEFORE the keep mask, which only exists here in registers.  Every workgroup adds the sums of its OWNED rows to
 // dcond with atomic adds, one run per utterance (as the per-conv DGATE epilogue does: order-dependent in the last bits).
 // ABL (tools builds only, tools/bench_wn.py): timing ablations - 1: no weight DMAs after the prologue, 2: no MFMAs, 4: no global stores (copy-outs, d x_0, d x_a),
-// 8: no gate loads, 16: no partial-sum exchange, 32: no fragment reads in the In_l^T loop.  Wrong results by design.
+// 8: no gate loads, 16: no partial-sum exchange.  Wrong results by design.
+//
+// Round 5: rebuilt on the forward kernel's footing (wavenet_fused.hip, round 4).  Every product runs on v_mfma_f32_16x16x32_bf16 - between
+// back-to-back 8-pass 32x32x16 MFMAs a SIMD issues no vector-memory instruction, so weight DMAs and matrix work added up instead of overlapping -
+// on `swz16` tiles (conflict-free ds_read_b128 at every tap shift) with the source-side DMA swizzle that goes with them; the 30 slab steps of
+// In_l^T are straight-line code whose fragment reads are inline asm with hand-counted lgkmcnt waits (slab j's reads fly under slab j - 1's MFMAs;
+// the compiler's own waits fall back to lgkmcnt(0) at every block boundary), `last` is a compile-time parameter of the layer body for the same reason;
+// the wave pairs swap their partial sums in ONE round (two barriers instead of four: 8 registers through the gate-gradient tile, 8 through the ring
+// slot the layer's last slab has just left).  Accumulator element i of fragment (rt, ct) of a wave: row 16 rt + 4 (lane >> 4) + i, column
+// 16 ct + (lane & 15).
 template <bool DROP, bool COND, int ABL = 0>
 __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
 {
@@ -77,21 +87,21 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const int rf = wave >= 6 ? 1 : 0, cf = wave - rf * 6;      // this wave's 32 x 32 output fragment: row fragment, 32-channel block
-    const int cp = cf >> 1, kh = cf & 1;                       // In^T: column pair of the wave pair / K chunk of this wave
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int rf = wave >= 6 ? 1 : 0, cf = wave - rf * 6;      // one-fragment GEMMs: this wave's 32 rows x 32 columns (row half rf, 32-channel block cf)
+    const int cp = cf >> 1, kh = cf & 1;                       // In^T: 64-column block of the wave pair / K chunk of this wave
     const int L = p.L;
     const int halo = WN_PAD * (L - 1);
     const int nvalid = WN_WIN - 2 * halo;
     const int v0 = blockIdx.x * nvalid;                        // first owned row
     const int t0 = v0 - halo;                                  // global row of window row 0
     const int xr0 = t0 - WN_PAD;                               // global row of tile row 0
-    const int nslabs = 36 * L + 2;
     const int lim = (p.rows - v0) < nvalid ? (p.rows - v0) : nvalid;
-    const int jch = cf * 32 + l31;                             // channel of this lane in 192-wide tensors
+    const int jch0 = cf * 32 + l15;                            // this lane's channels in 192-wide tensors: jch0 and jch0 + 16
 
-    // ---- weight stream (see wavenet_fused.hip): slab s -> ring slot s % 3, this wave's two 1-KiB units are rows [32 wave, 32 wave + 32) ----
-    const int lrow = lane >> 2, qa = (lane & 3) ^ ((lane >> 4) & 3);
+    // ---- weight stream (see wavenet_fused.hip): slab s -> ring slot s % 3; this wave's two 1-KiB units are rows [32 wave, 32 wave + 32) of the slab;
+    // lane i of a unit lands in LDS row i >> 2, slot i & 3, and fetches the global slot (i & 3) ^ swizzle(row) ----
+    const int lrow = lane >> 2, qa = (lane & 3) ^ (((lane >> 4) & 1) << 1);
     const unsigned char* const wsrc = p.wimg + (uint32_t)((wave * 32 + lrow) * 64 + qa * 16);
     auto issue = [&](int s) __attribute__((always_inline)) {
         const unsigned char* src = wsrc + (size_t)s * WN_SLAB;
@@ -100,22 +110,18 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + 1024), (void __attribute__((address_space(3)))*)(dst + 1024), 16, 0, 0);
     };
     int snext = 0;
-    // slab `snext` has landed (one younger slab may fly), everyone is done with slab snext - 1 -> its slot; the last slab drains the ring.
-    // (Conservative count: the wave also waits for its own earlier stores; the forward measured no gain from exact counts.)
+    // slab `snext` has landed (one younger slab may fly), everyone is done with slab snext - 1 -> its slot.  Conservative count: whatever else the wave
+    // has issued since (copy-outs, gate loads) is waited for as well (counted waits as in the forward measured nothing here: DESIGN.md section 5).
+    // The last two slabs (Start^T) drain the ring: `drain_step`.
     auto begin_step = [&]() __attribute__((always_inline)) -> const unsigned char* {
-        if (snext + 1 < nslabs) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         return wb_smem + BOFF_RING + (snext % BW_NS) * WN_SLAB;
     };
     auto end_step = [&]() __attribute__((always_inline)) {
-        if (!(ABL & 1) && snext + BW_NS - 1 < nslabs) issue(snext + BW_NS - 1);
+        if (!(ABL & 1)) issue(snext + BW_NS - 1);
         ++snext;
     };
     auto plain_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    auto mfma_bf16 = [](const Chunk16& a, const Chunk16& b, const f32x16& c) __attribute__((always_inline)) -> f32x16 {
-        if constexpr ((ABL & 2) != 0) { f32x16 r = c; asm volatile("" : "+v"(r) : "v"(a), "v"(b)); return r; }
-        else return ::mfma_bf16(a, b, c);
-    };
 
     // ---- prologue: d(m, logs) rows of the tile -> DT (A operand of End^T), row masks ----
     issue(0); issue(1);
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
                 int g = xr0 + i;
                 g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
                 const Chunk16 v = *reinterpret_cast<const Chunk16*>(static_cast<const unsigned char*>(p.douts_bf) + ((int64_t)g * p.ldo) * 2 + pc * 16);
-                *reinterpret_cast<Chunk16*>(DT + (pc >> 2) * (WN_XR * 64) + swz(i, pc & 3)) = v;
+                *reinterpret_cast<Chunk16*>(DT + (pc >> 2) * (WN_XR * 64) + swz16(i, pc & 3)) = v;
             }
         }
         if (tid < WN_XR) {
@@ -139,10 +145,16 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
             if (COND) UT[tid] = g / p.rows_per_utt;
         }
     }
-    int bl[2];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) bl[s2] = swz(l31, 2 * s2 + lhi);
-    const int offA = rf * 2048;
+    const int bl = swz16(l15, lq);                             // per-lane fragment offset: row l15 of a 16-row block (+1024 B per block), slot lq
+    const int offA = rf * 2048;                                // this wave's 32-row half of a tile chunk
+    const int rbw = rf * 32 + 4 * lq;                          // first tile / window row of this lane's accumulator rows (rt = 0, i = 0)
+    // byte offset inside a 64-byte tile row of channel 16 h + l15 of a 32-channel chunk, for a row whose (row >> 2) parity is (lq + cy) & 1
+    auto tile_off_of = [](int l15x, int lqx, int h, int cy) __attribute__((always_inline)) -> int {
+        return ((((2 * h + (l15x >> 3)) ^ (((lqx + cy) & 1) << 1)) & 3) << 4) + (l15x & 7) * 2;
+    };
+    // Every phase derives its per-lane addresses from an OPAQUE copy of the lane id: all of them are invariant over the layers, and left alone the
+    // compiler hoists them out of the layer loop and keeps dozens of registers live across the GEMM loops (the first build of this kernel spilled).
+    auto fresh_lane = [&]() __attribute__((always_inline)) -> int { int a = lane; asm volatile("" : "+v"(a)); return a; };
 
     // copy of the owned rows of an LDS tile [6 chunks][trows][64 B] to global rows: piece (chunk kc, slot q) of row r goes to
     // dst + r * row_bytes + off + kc * chunk_bytes + 16 q
@@ -156,69 +168,81 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
             const int idx = tid_ + k * WN_NT;
             const int r = idx / 24, pc = idx - r * 24;
             const bool ok = r < lim;
-            const Chunk16 v = lds16(tile + (pc >> 2) * (trows * 64) + swz(row_off + (ok ? r : 0), pc & 3));
+            const Chunk16 v = lds16(tile + (pc >> 2) * (trows * 64) + swz16(row_off + (ok ? r : 0), pc & 3));
             __builtin_amdgcn_raw_buffer_store_b128(v, rd, ok ? (uint32_t)((v0 + r) * row_bytes + off + (pc >> 2) * chunk_bytes + (pc & 3) * 16) : OOB, 0, 0);
         }
     };
-    auto tile_bases = [&](int rb, int (&tb)[2][2]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int og = 0; og < 2; ++og)
-#pragma unroll
-            for (int cy = 0; cy < 2; ++cy) tb[og][cy] = rb * 64 + ((((l31 >> 3) ^ (lhi + 2 * og + cy)) & 3) << 4) + (l31 & 7) * 2;
-    };
-#define WN_TOFF(tb, reg, extra) ((tb)[((reg) >> 2) & 1][(((reg) & 3) + (extra)) >> 2] + (frag_row(reg) + (extra)) * 64)
 
-    f32x16 acc0, acc1;
-    auto zero = [](f32x16& a) __attribute__((always_inline)) {
+    f32x4 acc[2][4];                                           // [16-row fragment rt][16-column fragment ct]
+    f32x4 a3[2];                                               // third row fragment (tile rows 64..79, of which 64..67 exist) of the waves rf = 0: [ct]
+    auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = 0.f;
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        a3[0] = a3[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    // one-fragment GEMM step over a slab of two K chunks x 192 columns: A tiles a0 / a1 (already offset to the wave's rows), third row
-    // fragment (rows 64..95 of the same tiles) into acc1 when `third`
-    auto mma192 = [&](const unsigned char* slot, const unsigned char* a0, const unsigned char* a1, bool third) __attribute__((always_inline)) {
-        Chunk16 fa[2][2], fb[2][2], f3[2][2];
+    // one-fragment GEMM step over a slab of two K chunks x 192 columns: A chunk tiles a0 / a1 ([rows][64 B]), this wave's rows start at tile row
+    // 32 rf + shift (shift 0: one lane offset serves both fragments); `third`: rows 64..79 of the same tiles into a3 (waves rf = 0)
+    auto mma192 = [&](const unsigned char* slot, const unsigned char* a0, const unsigned char* a1, bool third, int shift) __attribute__((always_inline)) {
+        Chunk16 fa[2][2], fb[2][2], f3[2];
+        int ar0 = offA + bl, ar1 = offA + 1024 + bl;
+        if (shift) {
+            const int ln = fresh_lane();
+            ar0 = swz16(rf * 32 + (ln & 15) + shift, ln >> 4);
+            ar1 = swz16(rf * 32 + 16 + (ln & 15) + shift, ln >> 4);
+        }
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c) {
+            const unsigned char* At = c ? a1 : a0;
+            fa[c][0] = lds16(At + ar0);
+            fa[c][1] = lds16(At + ar1);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                fa[c][s2] = lds16((c ? a1 : a0) + bl[s2]);
-                fb[c][s2] = lds16(slot + c * 12288 + cf * 2048 + bl[s2]);
-                if (third) f3[c][s2] = lds16((c ? a1 : a0) + (2 - rf) * 2048 + bl[s2]);
-            }
+            for (int ct = 0; ct < 2; ++ct) fb[c][ct] = lds16(slot + c * 12288 + cf * 2048 + ct * 1024 + bl);
+            if (third) f3[c] = lds16(At + 4096 + bl);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                acc0 = mfma_bf16(fa[c][s2], fb[c][s2], acc0);
-                if (third) acc1 = mfma_bf16(f3[c][s2], fb[c][s2], acc1);
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma16_bf16<!(ABL & 2)>(fa[c][rt], fb[c][ct], acc[rt][ct]);
+            if (third) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) a3[ct] = mfma16_bf16<!(ABL & 2)>(f3[c], fb[c][ct], a3[ct]);
             }
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
-    const bool w3 = wave < 6;                                   // waves 0..5 (rf = 0) also carry the third row fragment (tile rows 64..67) where 68 rows are needed
+    const bool w3 = wave < 6;                                   // waves rf = 0 also carry the third row fragment where 68 rows are needed
 
     // ================= End^T: d skip = (d(m, logs) W_end^T) * mask on the 68 tile rows =================
-    zero(acc0); zero(acc1);
+    zero_acc();
 #pragma unroll 1
     for (int j = 0; j < 3; ++j) {
         const unsigned char* slot = begin_step();
-        mma192(slot, DT + (2 * j) * (WN_XR * 64) + offA, DT + (2 * j + 1) * (WN_XR * 64) + offA, w3);
+        mma192(slot, DT + (2 * j) * (WN_XR * 64), DT + (2 * j + 1) * (WN_XR * 64), w3, 0);
         end_step();
     }
     {
-        int rb = rf * 32 + 4 * lhi;
-        asm volatile("" : "+v"(rb));
-        int tb[2][2];
-        tile_bases(rb, tb);
+        const int ln = fresh_lane(), l15x = ln & 15, lqx = ln >> 4;
+        const int rb = rf * 32 + 4 * lqx;
         unsigned char* const dc = DS + cf * (WN_XR * 64);
-        const float* const mk = MK + rb;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-            *reinterpret_cast<unsigned short*>(dc + WN_TOFF(tb, reg, 0)) = bf16_bits(acc0[reg] * mk[frag_row(reg)]);
-        if (w3 && lhi == 0) {
+        for (int h = 0; h < 2; ++h) {
+            const int to = tile_off_of(l15x, lqx, h, 0);
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-                *reinterpret_cast<unsigned short*>(dc + 64 * 64 + WN_TOFF(tb, reg, 0)) = bf16_bits(acc1[reg] * mk[64 + reg]);
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = rb + 16 * rt + i;
+                    *reinterpret_cast<unsigned short*>(dc + row * 64 + to) = bf16_bits(acc[rt][h][i] * MK[row]);
+                }
+            if (w3 && lqx == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<unsigned short*>(dc + (64 + i) * 64 + to) = bf16_bits(a3[h][i] * MK[64 + i]);
+            }
         }
     }
 
@@ -226,281 +250,342 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
     const float ik = drop_inv_keep(thr);
     uint32_t seed0 = p.seed;
     if (DROP && p.seed_ptr) seed0 += *p.seed_ptr;
-    const uint32_t jkey = drop_colkey((uint32_t)jch);
+    const uint32_t lds0 = lds_addr(wb_smem);
 
-    // ================= layers, last to first =================
-#pragma unroll 1
-    for (int l = L - 1; l >= 0; --l) {
-        const bool last = l == L - 1;
+    // ================= one layer (LAST: the last layer of the network, the first one here) =================
+    auto layer = [&](auto LAST_, const int l) __attribute__((always_inline)) {
+        constexpr bool last = decltype(LAST_)::value;
         // ---- RS_l^T: d acts = [d x_{l+1} | d skip] W^T.  Last layer: d skip only, on all 68 tile rows; else on the 64 window rows ----
-        zero(acc0); zero(acc1);
-        if (last) {
+        zero_acc();
+        if constexpr (last) {
 #pragma unroll 1
             for (int j = 0; j < 3; ++j) {
                 const unsigned char* slot = begin_step();
                 if (j == 0) copy_out(DS, WN_XR, halo + WN_PAD, p.dskip, WN_H * 2, 64, 0);            // d skip (kept: DY of the Res_Skip weight gradients)
-                mma192(slot, DS + (2 * j) * (WN_XR * 64) + offA, DS + (2 * j + 1) * (WN_XR * 64) + offA, w3);
+                mma192(slot, DS + (2 * j) * (WN_XR * 64), DS + (2 * j + 1) * (WN_XR * 64), w3, 0);
                 end_step();
             }
         } else {
 #pragma unroll 1
-            for (int j = 0; j < 6; ++j) {
+            for (int j = 0; j < 3; ++j) {                       // K chunks 0..5: d x_{l+1} (window rows)
                 const unsigned char* slot = begin_step();
                 if (j == 0) copy_out(DX, WN_WIN, halo, pick4(p.dh, l + 1), WN_H * 2, 64, 0);           // d x_{l+1} (kept: DY of the Res_Skip weight gradient)
-                // K chunks 0..5: d x_{l+1} (window rows), 6..11: d skip (window row r = tile row r + 2)
-                const unsigned char* a0 = j < 3 ? DX + (2 * j) * (WN_WIN * 64) + offA : DS + (2 * j - 6) * (WN_XR * 64) + offA;
-                const unsigned char* a1 = j < 3 ? DX + (2 * j + 1) * (WN_WIN * 64) + offA : DS + (2 * j - 5) * (WN_XR * 64) + offA;
-                if (j < 3) mma192(slot, a0, a1, false);
-                else {                                          // rows shifted by two: the swizzle phase changes, compute the offsets for row + 2
-                    Chunk16 fa[2][2], fb[2][2];
-#pragma unroll
-                    for (int c = 0; c < 2; ++c)
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            fa[c][s2] = lds16((c ? a1 : a0) - offA + swz(rf * 32 + l31 + WN_PAD, 2 * s2 + lhi));
-                            fb[c][s2] = lds16(slot + c * 12288 + cf * 2048 + bl[s2]);
-                        }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int c = 0; c < 2; ++c)
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) acc0 = mfma_bf16(fa[c][s2], fb[c][s2], acc0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                mma192(slot, DX + (2 * j) * (WN_WIN * 64), DX + (2 * j + 1) * (WN_WIN * 64), false, 0);
+                end_step();
+            }
+#pragma unroll 1
+            for (int j = 0; j < 3; ++j) {                       // K chunks 6..11: d skip (window row r = tile row r + 2)
+                const unsigned char* slot = begin_step();
+                mma192(slot, DS + (2 * j) * (WN_XR * 64), DS + (2 * j + 1) * (WN_XR * 64), false, WN_PAD);
                 end_step();
             }
         }
         // ---- gate derivative (autograd of Modules.py:885-887 and of the dropout at :862): (da, ds) kept packed as bf16 pairs ----
-        const int roff = last ? 0 : WN_PAD;                     // tile row of accumulator row 0
-        uint32_t pk[16], pk3[4];
+        constexpr int roff = last ? 0 : WN_PAD;                 // tile row of accumulator row 0
+        // The tanh-side gradients da go straight into the tile DT (tile rows roff ..: its last readers - End^T / the previous layer's exchange - are at least
+        // three slab barriers back), the sigmoid-side ds wait in registers as bf16 pairs (rows i, i + 1) until the second K pass rewrites the tile.
+        uint32_t pkd[2][2][2];                                  // [rt][h][i >> 1]
         {
-            int rb = rf * 32 + 4 * lhi;
-            asm volatile("" : "+v"(rb));
+            const int ln = fresh_lane(), l15x = ln & 15, lqx = ln >> 4;
+            const int rb = rf * 32 + 4 * lqx;
+            const int jch0 = cf * 32 + l15x;                    // (shadows the kernel-wide one)
             const Rsrc rg = mk_rsrc(pick4(p.gates, l), (long)p.rows * (2 * WN_H * 2));
-            const int g0 = xr0 + roff + rb;                     // global row of register 0
-            const uint32_t rk0 = (uint32_t)g0 * 0x9E3779B1u + seed0 + (uint32_t)l;
-            // conditioning gradient: running sums of the current utterance's owned rows (this lane's column pair)
-            float sa = 0.f, ss = 0.f;
-            int cur_u = -1;
-            float* const dcl = COND ? p.dcond + (long)l * (2 * WN_H) + jch : nullptr;
-            // flush: called by ALL lanes (it shuffles).  Lanes l and l + 32 hold the same column, rows 4 apart: when both close a run of the
-            // same utterance the upper half hands its sums to the lower one, which alone issues the atomics.
-            auto flush = [&](const bool need) __attribute__((always_inline)) {
-                const int other_u = __shfl_xor(need ? cur_u : -2, 32, 64);
-                const bool pair = need && other_u == cur_u;
-                const float oa = __shfl_xor(sa, 32, 64), os = __shfl_xor(ss, 32, 64);
-                if (pair) { sa += oa; ss += os; }
-                if (need && cur_u >= 0 && !(pair && lhi)) {
-                    float* dst = dcl + (long)cur_u * p.ldcond;
-                    unsafeAtomicAdd(dst, sa); unsafeAtomicAdd(dst + WN_H, ss);
+            const int g0 = xr0 + roff + rb;                     // global row of accumulator row 0
+            uint32_t gw[2][2][4], gw3[2][4];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {                   // (rows outside the tensor: clamped garbage is fine, those rows are never stored or valid)
+                    int g = g0 + 16 * rt + i;
+                    g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        gw[rt][h][i] = (ABL & 8) ? 0x3f003e80u + (uint32_t)i : __builtin_amdgcn_raw_buffer_load_b32(rg, (uint32_t)(g * (2 * WN_H * 2) + (jch0 + 16 * h) * 4), 0, 0);
                 }
-                if (need) sa = ss = 0.f;
-            };
-            // (wave-uniform) all owned rows of this workgroup in one utterance - the rule, an utterance is hundreds of rows: no run logic
-            const int own_lo = halo + WN_PAD, own_hi = own_lo + lim;                     // owned TILE rows [own_lo, own_hi)
-            const bool one_utt = COND && lim > 0 && UT[halo + WN_PAD] == UT[halo + WN_PAD + lim - 1];
-            auto gate = [&](float d, uint32_t w, int c) __attribute__((always_inline)) -> uint32_t {
-                const float t = __uint_as_float(w << 16), sg = __uint_as_float(w & 0xFFFF0000u);
-                const float dsg = d * sg;
-                float da = dsg * (1.f - t * t), ds = dsg * t * (1.f - sg);
-                if constexpr (COND) {
-                    const int tr = roff + rb + c;                                  // tile row of this accumulator row
-                    const bool own = tr >= own_lo && tr < own_hi;
-                    if (one_utt) { sa += own ? da : 0.f; ss += own ? ds : 0.f; }
-                    else {
-                        const int u = own ? UT[tr < WN_XR ? tr : WN_XR - 1] : cur_u;
-                        const bool need = own && u != cur_u;
-                        if (__any(need)) flush(need);
-                        if (need) cur_u = u;
-                        sa += own ? da : 0.f; ss += own ? ds : 0.f;
+            if constexpr (last) {
+                if (w3) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int g = g0 + 64 + i;                    // (waves rf = 0: tile row 64 + i + 4 lq; lanes lq > 0: rows 68..79 do not exist in the tile, their results are never used)
+                        g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            gw3[h][i] = (ABL & 8) ? 0x3f003e80u : __builtin_amdgcn_raw_buffer_load_b32(rg, (uint32_t)(g * (2 * WN_H * 2) + (jch0 + 16 * h) * 4), 0, 0);
                     }
                 }
-                if constexpr (DROP) {
-                    uint32_t x = rk0 + (uint32_t)c * 0x9E3779B1u; x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13;
-                    const uint32_t dd = drop_draw(x, jkey);
-                    da *= drop_keep_lo(dd, thr, ik); ds *= drop_keep_hi(dd, thr, ik);
-                }
-                return pack_bf16x2(da, ds);
+            }
+            const uint32_t rk0 = (uint32_t)g0 * 0x9E3779B1u + seed0 + (uint32_t)l;      // drop_rowkey(seed + l, row) = mix(row * M + seed + l)
+            auto rowkey = [&](int c) __attribute__((always_inline)) -> uint32_t {
+                uint32_t x = rk0 + (uint32_t)c * 0x9E3779B1u; x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13;
+                return x;
             };
-            uint32_t gw[16];
+            // owned TILE rows [own_lo, own_hi): the conditioning gradient sums them per utterance
+            const int own_lo = halo + WN_PAD, own_hi = own_lo + lim;
+            const bool one_utt = COND && lim > 0 && UT[own_lo] == UT[own_lo + lim - 1];       // (wave-uniform) the rule: an utterance is hundreds of rows
+            float* const dcl = COND ? p.dcond + (long)l * (2 * WN_H) + jch0 : nullptr;
+            unsigned char* const dc = DT + cf * (WN_XR * 64) + (rb + roff) * 64;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {                // (rows outside the tensor: clamped garbage is fine, those rows are never stored or valid)
-                int g = g0 + frag_row(reg);
-                g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
-                gw[reg] = (ABL & 8) ? 0x3f003e80u + (uint32_t)reg : __builtin_amdgcn_raw_buffer_load_b32(rg, (uint32_t)(g * (2 * WN_H * 2) + jch * 4), 0, 0);
-            }
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t jkey = drop_colkey((uint32_t)(jch0 + 16 * h));
+                const int to0 = tile_off_of(l15x, lqx, h, 0), to1 = tile_off_of(l15x, lqx, h, 1);
+                float sa = 0.f, ss = 0.f;
+                int cur_u = -1;
+                // c: accumulator row (tile row roff + rb + c) -> da (returned), ds
+                auto gate = [&](float d, uint32_t w, int c, float& ds) __attribute__((always_inline)) -> float {
+                    const float t = __uint_as_float(w << 16), sg = __uint_as_float(w & 0xFFFF0000u);
+                    const float dsg = d * sg;
+                    float da = dsg * (1.f - t * t);
+                    ds = dsg * t * (1.f - sg);
+                    if constexpr (COND) {
+                        const int tr = roff + rb + c;
+                        const bool own = tr >= own_lo && tr < own_hi;
+                        if (one_utt) { sa += own ? da : 0.f; ss += own ? ds : 0.f; }
+                        else if (own) {                         // windows that straddle utterances: this lane's own runs, one pair of atomics per run
+                            const int u = UT[tr];
+                            if (u != cur_u) {
+                                if (cur_u >= 0) { float* dst = dcl + 16 * h + (long)cur_u * p.ldcond; unsafeAtomicAdd(dst, sa); unsafeAtomicAdd(dst + WN_H, ss); }
+                                sa = ss = 0.f;
+                                cur_u = u;
+                            }
+                            sa += da; ss += ds;
+                        }
+                    }
+                    if constexpr (DROP) {
+                        const uint32_t dd = drop_draw(rowkey(c), jkey);
+                        da *= drop_keep_lo(dd, thr, ik); ds *= drop_keep_hi(dd, thr, ik);
+                    }
+                    return da;
+                };
+                if constexpr (last) {
+                    if (w3) {                                   // tile rows 64..67 (lanes lq = 0; the other lanes' values are never stored): da -> the tile,
+#pragma unroll                                                  // ds -> parked in P3 until the second pass
+                        for (int i = 0; i < 4; ++i) {
+                            float ds;
+                            const float da = gate(a3[h][i], gw3[h][i], lqx == 0 ? 64 + i - rb : 1 << 20, ds);
+                            if (lqx == 0) {
+                                *reinterpret_cast<unsigned short*>(DT + cf * (WN_XR * 64) + (64 + i) * 64 + to0) = bf16_bits(da);
+                                *reinterpret_cast<unsigned short*>(wb_smem + BOFF_P3 + cf * 256 + i * 64 + to0) = bf16_bits(ds);
+                            }
+                        }
+                    }
+                }
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) pk[reg] = gate(acc0[reg], gw[reg], frag_row(reg));
-            if constexpr (COND) {
-                if (one_utt) cur_u = UT[halo + WN_PAD];
-                flush(true);
-                cur_u = -1;                                     // (the third row fragment below holds tile rows 64..67: never owned)
-            }
-            if (last && w3) {
+                for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    int g = g0 + 64 + reg;
-                    g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
-                    const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(rg, (uint32_t)(g * (2 * WN_H * 2) + jch * 4), 0, 0);
-                    pk3[reg] = gate(acc1[reg], w, 64 + reg);
+                    for (int i2 = 0; i2 < 2; ++i2) {
+                        float ds0, ds1;
+                        const float da0 = gate(acc[rt][h][2 * i2], gw[rt][h][2 * i2], 16 * rt + 2 * i2, ds0);
+                        const float da1 = gate(acc[rt][h][2 * i2 + 1], gw[rt][h][2 * i2 + 1], 16 * rt + 2 * i2 + 1, ds1);
+                        // rows i = 2 i2, 2 i2 + 1 of this 4-row group: the swizzle parity flips where (i + roff) crosses 4 (roff = 2: for i2 = 1)
+                        const int to = ((2 * i2 + roff) >> 2) ? to1 : to0;
+                        *reinterpret_cast<unsigned short*>(dc + (16 * rt + 2 * i2) * 64 + to) = bf16_bits(da0);
+                        *reinterpret_cast<unsigned short*>(dc + (16 * rt + 2 * i2 + 1) * 64 + to) = bf16_bits(da1);
+                        pkd[rt][h][i2] = pack_bf16x2(ds0, ds1);
+                    }
+                if constexpr (COND) {
+                    if (one_utt) {                              // the four lanes (lq) of a column hold rows 4 apart: one sum, one pair of atomics
+                        sa += __shfl_xor(sa, 16, 64); ss += __shfl_xor(ss, 16, 64);
+                        sa += __shfl_xor(sa, 32, 64); ss += __shfl_xor(ss, 32, 64);
+                        if (lqx == 0) { float* dst = dcl + 16 * h + (long)UT[own_lo] * p.ldcond; unsafeAtomicAdd(dst, sa); unsafeAtomicAdd(dst + WN_H, ss); }
+                    } else if (cur_u >= 0) {
+                        float* dst = dcl + 16 * h + (long)cur_u * p.ldcond;
+                        unsafeAtomicAdd(dst, sa); unsafeAtomicAdd(dst + WN_H, ss);
+                    }
                 }
             }
         }
-        // the tanh-side half -> DT (rows roff ..), then In^T pass 0; the sigmoid-side half is written at the pass boundary
-        auto write_half = [&](int h) __attribute__((always_inline)) {
-            int rb = rf * 32 + 4 * lhi;
-            asm volatile("" : "+v"(rb));
-            int tb[2][2];
-            tile_bases(rb, tb);
-            unsigned char* const dc = DT + cf * (WN_XR * 64);
+        // the sigmoid-side half -> DT at the pass boundary
+        auto write_ds_half = [&]() __attribute__((always_inline)) {
+            const int ln = fresh_lane(), l15x = ln & 15, lqx = ln >> 4;
+            const int rb = rf * 32 + 4 * lqx;
+            unsigned char* const dc = DT + cf * (WN_XR * 64) + (rb + roff) * 64;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const unsigned short v = (unsigned short)(h ? pk[reg] >> 16 : pk[reg] & 0xFFFFu);
-                if (last) *reinterpret_cast<unsigned short*>(dc + WN_TOFF(tb, reg, 0)) = v;
-                else      *reinterpret_cast<unsigned short*>(dc + WN_TOFF(tb, reg, WN_PAD)) = v;
-            }
-            if (last && w3 && lhi == 0) {
+            for (int h = 0; h < 2; ++h) {
+                const int to0 = tile_off_of(l15x, lqx, h, 0), to1 = tile_off_of(l15x, lqx, h, 1);
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                    *reinterpret_cast<unsigned short*>(dc + 64 * 64 + WN_TOFF(tb, reg, 0)) = (unsigned short)(h ? pk3[reg] >> 16 : pk3[reg] & 0xFFFFu);
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; ++i2) {
+                        const uint32_t w = pkd[rt][h][i2];
+                        const int to = ((2 * i2 + roff) >> 2) ? to1 : to0;
+                        *reinterpret_cast<unsigned short*>(dc + (16 * rt + 2 * i2) * 64 + to) = (unsigned short)(w & 0xFFFFu);
+                        *reinterpret_cast<unsigned short*>(dc + (16 * rt + 2 * i2 + 1) * 64 + to) = (unsigned short)(w >> 16);
+                    }
+                if constexpr (last) {
+                    if (w3 && lqx == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            *reinterpret_cast<unsigned short*>(DT + cf * (WN_XR * 64) + (64 + i) * 64 + to0) = *reinterpret_cast<const unsigned short*>(wb_smem + BOFF_P3 + cf * 256 + i * 64 + to0);
+                    }
+                }
             }
         };
-        plain_barrier();                                        // every wave is done reading DT (End^T operand / the previous layer's exchange)
-        write_half(0);
 
-        // ---- In_l^T: two K passes (da, ds) x 5 taps x 3 slabs; wave (rf, cp, kh) multiplies chunk kh of every slab; reads one step ahead ----
-        zero(acc0); zero(acc1);
+        // ---- In_l^T: two K passes (da, ds) x 5 taps x 3 slabs; wave (rf, cp, kh) multiplies chunk kh of every slab over 32 rows x 64 columns.
+        // Software pipeline as in the forward: step n reads slab n's fragments into register set n & 1 and multiplies slab n - 1 from the other set ----
+        zero_acc();
         {
-            Chunk16 fa[2][2] = {}, fb[2][2][2] = {};
+            Chunk16 fa[2][2], fb[2][4];                        // [set][rt], [set][ct]
             auto mma = [&](auto SET_) __attribute__((always_inline)) {
                 constexpr int st = decltype(SET_)::value;
-                acc0 = mfma_bf16(fa[st][0], fb[st][0][0], acc0);
-                acc1 = mfma_bf16(fa[st][0], fb[st][0][1], acc1);
-                acc0 = mfma_bf16(fa[st][1], fb[st][1][0], acc0);
-                acc1 = mfma_bf16(fa[st][1], fb[st][1][1], acc1);
-            };
-            auto reads = [&](auto SET_, const unsigned char* slot, int n) __attribute__((always_inline)) {
-                constexpr int st = decltype(SET_)::value;
-                if constexpr ((ABL & 32) != 0) { asm volatile("" : "+v"(fa[st][0]), "+v"(fa[st][1]), "+v"(fb[st][0][0]), "+v"(fb[st][0][1]), "+v"(fb[st][1][0]), "+v"(fb[st][1][1])); return; }
-                const int m = n >= 15 ? n - 15 : n, t = m / 3, jj = m - 3 * t;
-                const unsigned char* At = DT + (2 * jj + kh) * (WN_XR * 64);
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    fa[st][s2] = lds16(At + swz(rf * 32 + l31 + t, 2 * s2 + lhi));
-                    fb[st][s2][0] = lds16(slot + kh * 12288 + cp * 4096 + bl[s2]);
-                    fb[st][s2][1] = lds16(slot + kh * 12288 + cp * 4096 + 2048 + bl[s2]);
-                }
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma16_bf16<!(ABL & 2)>(fa[st][rt], fb[st][ct], acc[rt][ct]);
             };
-#pragma unroll 1
-            for (int n2 = 0; n2 < 15; ++n2) {
-                {   // even step n = 2 n2
-                    const unsigned char* slot = begin_step();
-                    if (n2 == 0) copy_out(DT, WN_XR, halo + WN_PAD, pick4(p.dins, l), (int)p.ldin * 2, 128, 0);       // da half of dins_l
-                    reads(IC<0>{}, slot, 2 * n2);
-                    if (n2 > 0) mma(IC<1>{});
-                    end_step();
+            const int lnI = fresh_lane(), l15i = lnI & 15, lqi = lnI >> 4;
+            const uint32_t dtk = lds0 + (uint32_t)(BOFF_DT + kh * (WN_XR * 64));       // this wave's K chunk of a slab's two: tile chunk 2 jj + kh
+            const uint32_t sbk = (uint32_t)(kh * 12288 + cp * 4096 + swz16(l15i, lqi));
+            uint32_t ao0 = 0, ao1 = 0;
+            auto step = [&](auto N_) __attribute__((always_inline)) {
+                constexpr int n = decltype(N_)::value;
+                constexpr int m = n >= 15 ? n - 15 : n, t = m / 3, jj = m - 3 * t, st = n & 1;
+                const unsigned char* slot = begin_step();
+                if constexpr (n == 0) copy_out(DT, WN_XR, halo + WN_PAD, pick4(p.dins, l), (int)p.ldin * 2, 128, 0);        // da half of dins_l
+                if constexpr (n == 15) {                        // second pass: the tile is rewritten with the sigmoid-side half (every read of it has landed: lgkmcnt(0) + barrier above)
+                    write_ds_half();
+                    plain_barrier();
+                    copy_out(DT, WN_XR, halo + WN_PAD, pick4(p.dins, l), (int)p.ldin * 2, 128, 64);                         // ds half
                 }
-                {   // odd step n = 2 n2 + 1; n = 15 opens the second pass: rewrite the tile with the sigmoid-side half
-                    const unsigned char* slot = begin_step();
-                    if (n2 == 7) {
-                        write_half(1);
-                        plain_barrier();
-                        copy_out(DT, WN_XR, halo + WN_PAD, pick4(p.dins, l), (int)p.ldin * 2, 128, 64);              // ds half
-                    }
-                    reads(IC<1>{}, slot, 2 * n2 + 1);
-                    mma(IC<0>{});
-                    end_step();
+                if constexpr (jj == 0) {                        // this tap's rows of the tile: row + t, swizzled
+                    ao0 = dtk + (uint32_t)swz16(rf * 32 + l15i + t, lqi);
+                    ao1 = dtk + (uint32_t)swz16(rf * 32 + 16 + l15i + t, lqi);
                 }
-            }
+                const uint32_t sa = lds_addr(slot) + sbk;
+                fa[st][0] = lds16_asm<2 * jj * (WN_XR * 64)>(ao0);
+                fa[st][1] = lds16_asm<2 * jj * (WN_XR * 64)>(ao1);
+                fb[st][0] = lds16_asm<0>(sa); fb[st][1] = lds16_asm<1024>(sa); fb[st][2] = lds16_asm<2048>(sa); fb[st][3] = lds16_asm<3072>(sa);
+                if constexpr (n > 0) { lgkm_wait<6>(fa[st ^ 1], fb[st ^ 1]); mma(IC<st ^ 1>{}); }
+                __builtin_amdgcn_sched_barrier(0);
+                end_step();
+            };
+            StaticForN<30>::run([&](auto J_) __attribute__((always_inline)) { step(J_); });
+            lgkm_wait<0>(fa[1], fb[1]);
             mma(IC<1>{});                                       // slab 29
         }
-        // ---- partners swap halves of their partial sums (two rounds of 8 registers through the tile) ----
+        // ---- partners swap halves of their partial sums: the wave keeps fragments ct = 2 kh, 2 kh + 1 (columns 64 cp + 32 kh ..: its cf-th
+        // 32-channel block) and hands the other two to wave ^ 1.  One round: 8 registers through the tile, 8 through the ring slot of the slab just used ----
+        f32x4 fin[2][2];                                        // [rt][h]: rows 32 rf + 16 rt + 4 lq + i, channel 32 cf + 16 h + l15
         {
-            float* const xs = reinterpret_cast<float*>(DT);
+            const int lane = fresh_lane();                      // (shadows the kernel-wide one)
+            float* const xs0 = reinterpret_cast<float*>(DT);
+            float* const xs1 = reinterpret_cast<float*>(wb_smem + BOFF_RING + ((snext + BW_NS - 1) % BW_NS) * WN_SLAB);      // slot of slab snext - 1
+            if constexpr (!(ABL & 16)) {
+                plain_barrier();                                // every wave is done reading the tile and the last slab
 #pragma unroll
-            for (int rd = 0; rd < ((ABL & 16) ? 0 : 2); ++rd) {
-                plain_barrier();                                // (round 0: every wave is done reading the tile; round 1: done reading round 0)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) xs[(wave * 8 + i) * 64 + lane] = kh ? acc0[rd * 8 + i] : acc1[rd * 8 + i];
+                    for (int i = 0; i < 4; ++i) {
+                        xs0[(wave * 8 + h * 4 + i) * 64 + lane] = kh ? acc[0][h][i] : acc[0][2 + h][i];
+                        xs1[(wave * 8 + h * 4 + i) * 64 + lane] = kh ? acc[1][h][i] : acc[1][2 + h][i];
+                    }
                 plain_barrier();
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float o = xs[((wave ^ 1) * 8 + i) * 64 + lane];
-                    if (kh) acc1[rd * 8 + i] += o; else acc0[rd * 8 + i] += o;
-                }
             }
-            if (kh) acc0 = acc1;                                // this wave's fragment (rf, cf = 2 cp + kh)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float o0 = (ABL & 16) ? 0.f : xs0[((wave ^ 1) * 8 + h * 4 + i) * 64 + lane];
+                    const float o1 = (ABL & 16) ? 0.f : xs1[((wave ^ 1) * 8 + h * 4 + i) * 64 + lane];
+                    fin[0][h][i] = (kh ? acc[0][2 + h][i] : acc[0][h][i]) + o0;
+                    fin[1][h][i] = (kh ? acc[1][2 + h][i] : acc[1][h][i]) + o1;
+                }
         }
         // ---- d x_l = (conv^T + d x_{l+1}) * mask -> DX (bf16, in place); l = 0: fp32 rows for the Start conv's weight gradient ----
         {
-            int rb = rf * 32 + 4 * lhi;
-            asm volatile("" : "+v"(rb));
-            int tb[2][2];
-            tile_bases(rb, tb);
-            unsigned char* const xc = DX + cf * (WN_WIN * 64);
+            const int ln = fresh_lane(), l15x = ln & 15, lqx = ln >> 4;
+            const int rb = rf * 32 + 4 * lqx;
+            const int jch0 = cf * 32 + l15x;
+            unsigned char* const xc = DX + cf * (WN_WIN * 64) + rb * 64;
             const float* const mk = MK + rb + WN_PAD;
             const Rsrc r0 = mk_rsrc(p.dh[0], (l == 0 && !p.dh0_bf16) ? (long)p.rows * (WN_H * 4) : 0);
-            const uint32_t v00 = (uint32_t)((t0 + rb) * (WN_H * 4) + jch * 4);
             const uint32_t own0 = (uint32_t)(rb - halo);
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int c = frag_row(reg);
-                unsigned short* xp = reinterpret_cast<unsigned short*>(xc + WN_TOFF(tb, reg, 0));
-                const float xin = last ? 0.f : __uint_as_float((uint32_t)*xp << 16);
-                const float v = (acc0[reg] + xin) * mk[c];
-                *xp = bf16_bits(v);
-                const bool ok = own0 + (uint32_t)c < (uint32_t)lim;
-                if constexpr (!(ABL & 4)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r0, ok ? v00 + (uint32_t)(c * (WN_H * 4)) : OOB, 0, 0);
+            for (int h = 0; h < 2; ++h) {
+                const int to = tile_off_of(l15x, lqx, h, 0);
+                const uint32_t v00 = (uint32_t)((t0 + rb) * (WN_H * 4) + (jch0 + 16 * h) * 4);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = 16 * rt + i;
+                        unsigned short* xp = reinterpret_cast<unsigned short*>(xc + c * 64 + to);
+                        const float xin = last ? 0.f : __uint_as_float((uint32_t)*xp << 16);
+                        const float v = (fin[rt][h][i] + xin) * mk[c];
+                        *xp = bf16_bits(v);
+                        const bool ok = own0 + (uint32_t)c < (uint32_t)lim;
+                        if constexpr (!(ABL & 4)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r0, ok ? v00 + (uint32_t)(c * (WN_H * 4)) : OOB, 0, 0);
+                    }
             }
         }
+    };
+#pragma unroll 1
+    for (int l = L - 1; l >= 0; --l) {
+        if (l == L - 1) layer(IC<1>{}, l); else layer(IC<0>{}, l);
     }
 
-    // ================= Start^T: d x_a += d x_0 W_start^T (K = 192, 96 columns of a 128-column image: 2 slabs of 3 chunks) =================
-    zero(acc0);
-#pragma unroll 1
+    // ================= Start^T: d x_a += d x_0 W_start^T (K = 192, 96 columns of a 128-column image: 2 slabs of 3 chunks); the ring drains =================
+    zero_acc();
+#pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const unsigned char* slot = begin_step();
+        if (j == 0) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const unsigned char* slot = wb_smem + BOFF_RING + (snext % BW_NS) * WN_SLAB;
+        ++snext;
         // d x_0 as bf16 rows (DY of the Start conv's weight gradient): the finished tile, 16 bytes per store, behind the step's barrier
+        // (j = 1's vmcnt(0) also waits for these two stores: the last step)
         if (j == 0 && p.dh0_bf16) copy_out(DX, WN_WIN, halo, p.dh[0], WN_H * 2, 64, 0);
         if (cf < 3) {
             Chunk16 fa[3][2], fb[3][2];
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < 3; ++c) {
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    fa[c][s2] = lds16(DX + (3 * j + c) * (WN_WIN * 64) + offA + bl[s2]);
-                    fb[c][s2] = lds16(slot + c * 8192 + cf * 2048 + bl[s2]);
-                }
+                for (int rt = 0; rt < 2; ++rt) fa[c][rt] = lds16(DX + (3 * j + c) * (WN_WIN * 64) + offA + rt * 1024 + bl);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) fb[c][ct] = lds16(slot + c * 8192 + cf * 2048 + ct * 1024 + bl);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) acc0 = mfma_bf16(fa[c][s2], fb[c][s2], acc0);
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma16_bf16<!(ABL & 2)>(fa[c][rt], fb[c][ct], acc[rt][ct]);
         }
-        end_step();
     }
     if (cf < 3) {
-        int rb = rf * 32 + 4 * lhi;
+        int rb = rbw;
         asm volatile("" : "+v"(rb));
         const Rsrc rx = mk_rsrc(p.dx, (long)p.rows * p.lddx * 4);
-        const bool cok = jch < p.C2;
-        const uint32_t vx0 = (uint32_t)((t0 + rb) * (int)p.lddx + jch) * 4u;
         const uint32_t own0 = (uint32_t)(rb - halo);
-        float old[16];
+        float old[2][2][4];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int c = frag_row(reg);
-            const bool ok = cok && own0 + (uint32_t)c < (uint32_t)lim;
-            old[reg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, ok ? vx0 + (uint32_t)(c * (int)p.lddx * 4) : OOB, 0, 0));
+        for (int h = 0; h < 2; ++h) {
+            const bool cok = jch0 + 16 * h < p.C2;
+            const uint32_t vx0 = (uint32_t)((t0 + rb) * (int)p.lddx + jch0 + 16 * h) * 4u;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 16 * rt + i;
+                    const bool ok = cok && own0 + (uint32_t)c < (uint32_t)lim;
+                    old[h][rt][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, ok ? vx0 + (uint32_t)(c * (int)p.lddx * 4) : OOB, 0, 0));
+                }
         }
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int c = frag_row(reg);
-            const bool ok = cok && own0 + (uint32_t)c < (uint32_t)lim;
-            if constexpr (!(ABL & 4)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(old[reg] + acc0[reg]), rx, ok ? vx0 + (uint32_t)(c * (int)p.lddx * 4) : OOB, 0, 0);
+        for (int h = 0; h < 2; ++h) {
+            const bool cok = jch0 + 16 * h < p.C2;
+            const uint32_t vx0 = (uint32_t)((t0 + rb) * (int)p.lddx + jch0 + 16 * h) * 4u;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 16 * rt + i;
+                    const bool ok = cok && own0 + (uint32_t)c < (uint32_t)lim;
+                    if constexpr (!(ABL & 4)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(old[h][rt][i] + acc[rt][h][i]), rx, ok ? vx0 + (uint32_t)(c * (int)p.lddx * 4) : OOB, 0, 0);
+                }
         }
     }
-#undef WN_TOFF
 }
 
 template <bool DROP, bool COND, int ABL = 0>
@@ -518,9 +603,8 @@ int launch_wn_bwd(const wn_bwd_args& k, dim3 grid, hipStream_t s)
             case 13: return launch_wn_bwd<DROP, COND, 13>(k, grid, s);
             case 14: return launch_wn_bwd<DROP, COND, 14>(k, grid, s);
             case 16: return launch_wn_bwd<DROP, COND, 16>(k, grid, s);
-            case 32: return launch_wn_bwd<DROP, COND, 32>(k, grid, s);
-            case 46: return launch_wn_bwd<DROP, COND, 46>(k, grid, s);
-            case 47: return launch_wn_bwd<DROP, COND, 47>(k, grid, s);
+            case 29: return launch_wn_bwd<DROP, COND, 29>(k, grid, s);
+            case 31: return launch_wn_bwd<DROP, COND, 31>(k, grid, s);
             default: break;
         }
     }
