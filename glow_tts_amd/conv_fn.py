@@ -320,6 +320,9 @@ class FFNBlock(torch.autograd.Function):
         tape.ln_count += 1
         ctx.save_for_backward(x1b, h0, h1 if drop_p > 0 else None, s_, stats, gamma, rowmask, w0, w1)
         ctx.misc = (tape, packs0[1], packs1[1], float(drop_p))
+        # the non-differentiable outputs' "gradients" stay None: materialised, each is a zero-fill launch of [R, C] / [R, 3C] on the encoder's backward chain
+        # (two to three 5-us launches per block, twelve blocks: profiles/r04_step_order.txt)
+        ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(yb)
         if next_qkv is None:
             return y, yb
@@ -399,6 +402,7 @@ class AttentionBlock(torch.autograd.Function):
         tape.ln_count += 1
         ctx.save_for_backward(xb, qkv, rk, rv, P, att, proj if drop_p > 0 else None, s_, stats, gamma, rowmask, wqkv, wp, seed_t)
         ctx.misc = (tape, packs_qkv[1], packs_p[1], float(drop_p), B, Tp, H, win, int(seeds[0]) & 0xFFFFFFFF)
+        ctx.set_materialize_grads(False)                      # (see FFNBlock.forward)
         ctx.mark_non_differentiable(yb)
         return y, yb
 
@@ -432,7 +436,7 @@ class AttentionBlock(torch.autograd.Function):
         dwq, dbq = torch.empty_like(wqkv), torch.empty(3 * C, device=dev)
         dwp, dbp = torch.empty_like(wp), torch.empty(C, device=dev)
         tape.add(dqkv, xb, 3 * C, C, 1, ops.BF16, dwq, dbq)
-        tape.add(dzp.float(), att, C, C, 1, ops.BF16, dwp, dbp)       # (the attention output is fp32 rows: the weight-gradient kernel has no bf16 x fp32 form)
+        tape.add(dzp, att, C, C, 1, ops.BF16, dwp, dbp)               # (bf16-stored DY x fp32-stored X: the staged weight-gradient kernel converts X in its loop)
         return (dx, None, dwq, dbq, drel[0].view(1, nw, D), drel[1].view(1, nw, D), dwp, dbp, gb[:C], gb[C:]) + (None,) * 12
 
 

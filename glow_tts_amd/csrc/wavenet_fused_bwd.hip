@@ -59,13 +59,14 @@ struct wn_bwd_args {
     int dh0_bf16;
     float* dx; int64_t lddx;                      // in / out: [rows][lddx] fp32, channels [0, C2) += d x_a
     float* dcond; int64_t ldcond;                 // COND: d conditioning [utterances][ldcond], layer l at + l * 2 H; ACCUMULATED (atomic adds)
+    long long* tl;                                // tools builds (ABL & 64): per-workgroup phase stamps [grid][64]
 };
 
 // COND: the per-utterance conditioning joins the gate pre-activation AFTER the dropout (Modules.py:861-866): its gradient is the sum over an
 // utterance's rows of (da, ds) BEFORE the keep mask, which only exists here in registers.  Every workgroup adds the sums of its OWNED rows to
 // dcond with atomic adds, one run per utterance (as the per-conv DGATE epilogue does: order-dependent in the last bits).
 // ABL (tools builds only, tools/bench_wn.py): timing ablations - 1: no weight DMAs after the prologue, 2: no MFMAs, 4: no global stores (copy-outs, d x_0, d x_a),
-// 8: no gate loads, 16: no partial-sum exchange.  Wrong results by design.
+// 8: no gate loads, 16: no partial-sum exchange, 64: per-workgroup phase stamps (s_memtime of thread 0; results stay right).  1..16: wrong results by design.
 //
 // Round 5: rebuilt on the forward kernel's footing (wavenet_fused.hip, round 4).  Every product runs on v_mfma_f32_16x16x32_bf16 - between
 // back-to-back 8-pass 32x32x16 MFMAs a SIMD issues no vector-memory instruction, so weight DMAs and matrix work added up instead of overlapping -
@@ -110,13 +111,22 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + 1024), (void __attribute__((address_space(3)))*)(dst + 1024), 16, 0, 0);
     };
     int snext = 0;
-    // slab `snext` has landed (one younger slab may fly), everyone is done with slab snext - 1 -> its slot.  Conservative count: whatever else the wave
-    // has issued since (copy-outs, gate loads) is waited for as well (counted waits as in the forward measured nothing here: DESIGN.md section 5).
-    // The last two slabs (Start^T) drain the ring: `drain_step`.
-    auto begin_step = [&]() __attribute__((always_inline)) -> const unsigned char* {
-        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int tli = 0;
+    auto TLS = [&]() __attribute__((always_inline)) { if constexpr ((ABL & 64) != 0) { if (tid == 0) p.tl[blockIdx.x * 64 + tli] = (long long)__builtin_readcyclecounter(); ++tli; } };
+    TLS();
+    // A slab step: begin_step(IC<X>) = this wave's DMAs of slab `snext` have landed, barrier (everyone's have, everyone is done with slab snext - 1) ->
+    // its slot.  X = vector-memory operations this wave has issued BEHIND the DMAs of slab snext besides the two DMAs of slab snext + 1 (memory
+    // operations retire in order on vmcnt, loads and stores alike on gfx9): the prefetched gate loads and the copy-outs' stores.  vmcnt(2 + X) waits
+    // for exactly slab snext; a smaller count would also wait for the wave's own stores to be acknowledged / its gate loads to return.  X must never
+    // exceed the real count: every counted operation is an unconditional buffer instruction.  The conditioned variants (their atomics make the
+    // count data-dependent) run the conservative vmcnt(2) everywhere.  The last two slabs (Start^T) drain the ring with conservative counts.
+    constexpr bool EXACT = !COND;
+    auto begin_step = [&](auto X_) __attribute__((always_inline)) -> const unsigned char* {
+        constexpr int X = EXACT ? decltype(X_)::value : 0;
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(2 + X) : "memory");
         return wb_smem + BOFF_RING + (snext % BW_NS) * WN_SLAB;
     };
+    constexpr int XC = 2;                                      // stores of a copy_out
     auto end_step = [&]() __attribute__((always_inline)) {
         if (!(ABL & 1)) issue(snext + BW_NS - 1);
         ++snext;
@@ -218,13 +228,15 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
     const bool w3 = wave < 6;                                   // waves rf = 0 also carry the third row fragment where 68 rows are needed
 
     // ================= End^T: d skip = (d(m, logs) W_end^T) * mask on the 68 tile rows =================
+    TLS();
     zero_acc();
 #pragma unroll 1
     for (int j = 0; j < 3; ++j) {
-        const unsigned char* slot = begin_step();
+        const unsigned char* slot = begin_step(IC<0>{});
         mma192(slot, DT + (2 * j) * (WN_XR * 64), DT + (2 * j + 1) * (WN_XR * 64), w3, 0);
         end_step();
     }
+    TLS();
     {
         const int ln = fresh_lane(), l15x = ln & 15, lqx = ln >> 4;
         const int rb = rf * 32 + 4 * lqx;
@@ -255,43 +267,17 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
     // ================= one layer (LAST: the last layer of the network, the first one here) =================
     auto layer = [&](auto LAST_, const int l) __attribute__((always_inline)) {
         constexpr bool last = decltype(LAST_)::value;
-        // ---- RS_l^T: d acts = [d x_{l+1} | d skip] W^T.  Last layer: d skip only, on all 68 tile rows; else on the 64 window rows ----
-        zero_acc();
-        if constexpr (last) {
-#pragma unroll 1
-            for (int j = 0; j < 3; ++j) {
-                const unsigned char* slot = begin_step();
-                if (j == 0) copy_out(DS, WN_XR, halo + WN_PAD, p.dskip, WN_H * 2, 64, 0);            // d skip (kept: DY of the Res_Skip weight gradients)
-                mma192(slot, DS + (2 * j) * (WN_XR * 64), DS + (2 * j + 1) * (WN_XR * 64), w3, 0);
-                end_step();
-            }
-        } else {
-#pragma unroll 1
-            for (int j = 0; j < 3; ++j) {                       // K chunks 0..5: d x_{l+1} (window rows)
-                const unsigned char* slot = begin_step();
-                if (j == 0) copy_out(DX, WN_WIN, halo, pick4(p.dh, l + 1), WN_H * 2, 64, 0);           // d x_{l+1} (kept: DY of the Res_Skip weight gradient)
-                mma192(slot, DX + (2 * j) * (WN_WIN * 64), DX + (2 * j + 1) * (WN_WIN * 64), false, 0);
-                end_step();
-            }
-#pragma unroll 1
-            for (int j = 0; j < 3; ++j) {                       // K chunks 6..11: d skip (window row r = tile row r + 2)
-                const unsigned char* slot = begin_step();
-                mma192(slot, DS + (2 * j) * (WN_XR * 64), DS + (2 * j + 1) * (WN_XR * 64), false, WN_PAD);
-                end_step();
-            }
-        }
-        // ---- gate derivative (autograd of Modules.py:885-887 and of the dropout at :862): (da, ds) kept packed as bf16 pairs ----
+        TLS();
+        // ---- the layer's kept gates (t, s), prefetched: 16 (+ 8: tile rows 64..67 of the last layer; every wave issues them, the count below is uniform)
+        // loads per lane that return under the RS^T GEMM instead of in front of the gate derivative ----
         constexpr int roff = last ? 0 : WN_PAD;                 // tile row of accumulator row 0
-        // The tanh-side gradients da go straight into the tile DT (tile rows roff ..: its last readers - End^T / the previous layer's exchange - are at least
-        // three slab barriers back), the sigmoid-side ds wait in registers as bf16 pairs (rows i, i + 1) until the second K pass rewrites the tile.
-        uint32_t pkd[2][2][2];                                  // [rt][h][i >> 1]
+        constexpr int NG = last ? 24 : 16;
+        uint32_t gw[2][2][4], gw3[2][4];
         {
             const int ln = fresh_lane(), l15x = ln & 15, lqx = ln >> 4;
-            const int rb = rf * 32 + 4 * lqx;
-            const int jch0 = cf * 32 + l15x;                    // (shadows the kernel-wide one)
             const Rsrc rg = mk_rsrc(pick4(p.gates, l), (long)p.rows * (2 * WN_H * 2));
-            const int g0 = xr0 + roff + rb;                     // global row of accumulator row 0
-            uint32_t gw[2][2][4], gw3[2][4];
+            const int g0 = xr0 + roff + rf * 32 + 4 * lqx;      // global row of accumulator row 0
+            const uint32_t cb = (uint32_t)(cf * 32 + l15x) * 4u;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -300,20 +286,56 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
                     g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
-                        gw[rt][h][i] = (ABL & 8) ? 0x3f003e80u + (uint32_t)i : __builtin_amdgcn_raw_buffer_load_b32(rg, (uint32_t)(g * (2 * WN_H * 2) + (jch0 + 16 * h) * 4), 0, 0);
+                        gw[rt][h][i] = (ABL & 8) ? 0x3f003e80u + (uint32_t)i : __builtin_amdgcn_raw_buffer_load_b32(rg, (uint32_t)(g * (2 * WN_H * 2)) + cb + 64u * h, 0, 0);
                 }
             if constexpr (last) {
-                if (w3) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        int g = g0 + 64 + i;                    // (waves rf = 0: tile row 64 + i + 4 lq; lanes lq > 0: rows 68..79 do not exist in the tile, their results are never used)
-                        g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
+                for (int i = 0; i < 4; ++i) {
+                    int g = g0 + 64 + i;                        // (waves rf = 0: tile row 64 + i + 4 lq; lanes lq > 0 and waves rf = 1: rows that do not exist in the tile, never used)
+                    g = g < 0 ? 0 : (g >= p.rows ? p.rows - 1 : g);
 #pragma unroll
-                        for (int h = 0; h < 2; ++h)
-                            gw3[h][i] = (ABL & 8) ? 0x3f003e80u : __builtin_amdgcn_raw_buffer_load_b32(rg, (uint32_t)(g * (2 * WN_H * 2) + (jch0 + 16 * h) * 4), 0, 0);
-                    }
+                    for (int h = 0; h < 2; ++h)
+                        gw3[h][i] = (ABL & 8) ? 0x3f003e80u : __builtin_amdgcn_raw_buffer_load_b32(rg, (uint32_t)(g * (2 * WN_H * 2)) + cb + 64u * h, 0, 0);
                 }
             }
+        }
+        constexpr int NGX = (ABL & 8) ? 0 : NG;
+        // ---- RS_l^T: d acts = [d x_{l+1} | d skip] W^T.  Last layer: d skip only, on all 68 tile rows; else on the 64 window rows.
+        // Behind slab 0's DMAs: the NG gate loads; behind slab 1's: those and the copy-out's stores; from slab 2 on all of them are older ----
+        zero_acc();
+        if constexpr (last) {
+            StaticForN<3>::run([&](auto J_) __attribute__((always_inline)) {
+                constexpr int j = decltype(J_)::value;
+                const unsigned char* slot = begin_step(IC<(j == 0 ? NGX : (j == 1 ? NGX + ((ABL & 4) ? 0 : XC) : 0))>{});
+                if constexpr (j == 0) copy_out(DS, WN_XR, halo + WN_PAD, p.dskip, WN_H * 2, 64, 0);            // d skip (kept: DY of the Res_Skip weight gradients)
+                mma192(slot, DS + (2 * j) * (WN_XR * 64), DS + (2 * j + 1) * (WN_XR * 64), w3, 0);
+                end_step();
+            });
+        } else {
+            StaticForN<3>::run([&](auto J_) __attribute__((always_inline)) {      // K chunks 0..5: d x_{l+1} (window rows)
+                constexpr int j = decltype(J_)::value;
+                const unsigned char* slot = begin_step(IC<(j == 0 ? NGX : (j == 1 ? NGX + ((ABL & 4) ? 0 : XC) : 0))>{});
+                if constexpr (j == 0) copy_out(DX, WN_WIN, halo, pick4(p.dh, l + 1), WN_H * 2, 64, 0);           // d x_{l+1} (kept: DY of the Res_Skip weight gradient)
+                mma192(slot, DX + (2 * j) * (WN_WIN * 64), DX + (2 * j + 1) * (WN_WIN * 64), false, 0);
+                end_step();
+            });
+#pragma unroll 1
+            for (int j = 0; j < 3; ++j) {                       // K chunks 6..11: d skip (window row r = tile row r + 2)
+                const unsigned char* slot = begin_step(IC<0>{});
+                mma192(slot, DS + (2 * j) * (WN_XR * 64), DS + (2 * j + 1) * (WN_XR * 64), false, WN_PAD);
+                end_step();
+            }
+        }
+        // ---- gate derivative (autograd of Modules.py:885-887 and of the dropout at :862): (da, ds) kept packed as bf16 pairs ----
+        TLS();
+        // The tanh-side gradients da go straight into the tile DT (tile rows roff ..: its last readers - End^T / the previous layer's exchange - are at least
+        // three slab barriers back), the sigmoid-side ds wait in registers as bf16 pairs (rows i, i + 1) until the second K pass rewrites the tile.
+        uint32_t pkd[2][2][2];                                  // [rt][h][i >> 1]
+        {
+            const int ln = fresh_lane(), l15x = ln & 15, lqx = ln >> 4;
+            const int rb = rf * 32 + 4 * lqx;
+            const int jch0 = cf * 32 + l15x;                    // (shadows the kernel-wide one)
+            const int g0 = xr0 + roff + rb;                     // global row of accumulator row 0
             const uint32_t rk0 = (uint32_t)g0 * 0x9E3779B1u + seed0 + (uint32_t)l;      // drop_rowkey(seed + l, row) = mix(row * M + seed + l)
             auto rowkey = [&](int c) __attribute__((always_inline)) -> uint32_t {
                 uint32_t x = rk0 + (uint32_t)c * 0x9E3779B1u; x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13;
@@ -394,6 +416,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
                 }
             }
         }
+        TLS();
         // the sigmoid-side half -> DT at the pass boundary
         auto write_ds_half = [&]() __attribute__((always_inline)) {
             const int ln = fresh_lane(), l15x = ln & 15, lqx = ln >> 4;
@@ -440,8 +463,9 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
             auto step = [&](auto N_) __attribute__((always_inline)) {
                 constexpr int n = decltype(N_)::value;
                 constexpr int m = n >= 15 ? n - 15 : n, t = m / 3, jj = m - 3 * t, st = n & 1;
-                const unsigned char* slot = begin_step();
+                const unsigned char* slot = begin_step(IC<((n == 1 || n == 16) && !(ABL & 4) ? XC : 0)>{});
                 if constexpr (n == 0) copy_out(DT, WN_XR, halo + WN_PAD, pick4(p.dins, l), (int)p.ldin * 2, 128, 0);        // da half of dins_l
+                if constexpr (n == 15) TLS();
                 if constexpr (n == 15) {                        // second pass: the tile is rewritten with the sigmoid-side half (every read of it has landed: lgkmcnt(0) + barrier above)
                     write_ds_half();
                     plain_barrier();
@@ -465,6 +489,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
         }
         // ---- partners swap halves of their partial sums: the wave keeps fragments ct = 2 kh, 2 kh + 1 (columns 64 cp + 32 kh ..: its cf-th
         // 32-channel block) and hands the other two to wave ^ 1.  One round: 8 registers through the tile, 8 through the ring slot of the slab just used ----
+        TLS();
         f32x4 fin[2][2];                                        // [rt][h]: rows 32 rf + 16 rt + 4 lq + i, channel 32 cf + 16 h + l15
         {
             const int lane = fresh_lane();                      // (shadows the kernel-wide one)
@@ -491,6 +516,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
                     fin[1][h][i] = (kh ? acc[1][2 + h][i] : acc[1][h][i]) + o1;
                 }
         }
+        TLS();
         // ---- d x_l = (conv^T + d x_{l+1}) * mask -> DX (bf16, in place); l = 0: fp32 rows for the Start conv's weight gradient ----
         {
             const int ln = fresh_lane(), l15x = ln & 15, lqx = ln >> 4;
@@ -498,7 +524,8 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
             const int jch0 = cf * 32 + l15x;
             unsigned char* const xc = DX + cf * (WN_WIN * 64) + rb * 64;
             const float* const mk = MK + rb + WN_PAD;
-            const Rsrc r0 = mk_rsrc(p.dh[0], (l == 0 && !p.dh0_bf16) ? (long)p.rows * (WN_H * 4) : 0);
+            const bool fp32_rows = l == 0 && !p.dh0_bf16;      // (wave-uniform)
+            const Rsrc r0 = mk_rsrc(p.dh[0], fp32_rows ? (long)p.rows * (WN_H * 4) : 0);
             const uint32_t own0 = (uint32_t)(rb - halo);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -514,7 +541,8 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
                         const float v = (fin[rt][h][i] + xin) * mk[c];
                         *xp = bf16_bits(v);
                         const bool ok = own0 + (uint32_t)c < (uint32_t)lim;
-                        if constexpr (!(ABL & 4)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r0, ok ? v00 + (uint32_t)(c * (WN_H * 4)) : OOB, 0, 0);
+                        // (l = 0 is followed by Start^T, whose steps wait conservatively: these stores are in no exact count)
+                        if constexpr (!(ABL & 4)) { if (fp32_rows) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r0, ok ? v00 + (uint32_t)(c * (WN_H * 4)) : OOB, 0, 0); }
                     }
             }
         }
@@ -524,6 +552,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
         if (l == L - 1) layer(IC<1>{}, l); else layer(IC<0>{}, l);
     }
 
+    TLS();
     // ================= Start^T: d x_a += d x_0 W_start^T (K = 192, 96 columns of a 128-column image: 2 slabs of 3 chunks); the ring drains =================
     zero_acc();
 #pragma unroll
@@ -553,6 +582,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
                     for (int rt = 0; rt < 2; ++rt) acc[rt][ct] = mfma16_bf16<!(ABL & 2)>(fa[c][rt], fb[c][ct], acc[rt][ct]);
         }
     }
+    TLS();
     if (cf < 3) {
         int rb = rbw;
         asm volatile("" : "+v"(rb));
@@ -586,6 +616,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
                 }
         }
     }
+    TLS();
 }
 
 template <bool DROP, bool COND, int ABL = 0>
@@ -603,6 +634,7 @@ int launch_wn_bwd(const wn_bwd_args& k, dim3 grid, hipStream_t s)
             case 13: return launch_wn_bwd<DROP, COND, 13>(k, grid, s);
             case 14: return launch_wn_bwd<DROP, COND, 14>(k, grid, s);
             case 16: return launch_wn_bwd<DROP, COND, 16>(k, grid, s);
+            case 64: return launch_wn_bwd<DROP, COND, 64>(k, grid, s);
             case 29: return launch_wn_bwd<DROP, COND, 29>(k, grid, s);
             case 31: return launch_wn_bwd<DROP, COND, 31>(k, grid, s);
             default: break;
@@ -671,6 +703,9 @@ extern "C" int glowtts_wavenet_bwd(const glowtts_flow_dims* d, const glowtts_flo
     const dim3 grid((unsigned)((R + nvalid - 1) / nvalid));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (cnd) { k.dcond = g->dcond; k.ldcond = p->ldcond; }
+#ifdef GLOWTTS_TOOLS
+    if (!cnd && (GLOWTTS_TUNABLE("GLOWTTS_WN_BWD_ABL", 0) & 64)) k.tl = reinterpret_cast<long long*>(g->dcond);      // tools/bench_wn.py passes the stamp buffer here
+#endif
     if (d->drop_p > 0.f) return cnd ? launch_wn_bwd<true, true>(k, grid, s) : launch_wn_bwd<true, false>(k, grid, s);
     return cnd ? launch_wn_bwd<false, true>(k, grid, s) : launch_wn_bwd<false, false>(k, grid, s);
 }

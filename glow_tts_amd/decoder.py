@@ -832,6 +832,7 @@ class DecoderFunction(torch.autograd.Function):
         # i.e. already "frames x channels" for the log-prior GEMM (alignment.log_prior_t(z_rows=...) reads it instead of transposing z)
         z_rows = buf.x[cfg.F]
         ctx.mark_non_differentiable(z_rows)
+        ctx.set_materialize_grads(False)                     # (its "gradient" stays None instead of an 8-MB zero fill in front of the decoder's backward)
         return z, logdet, z_rows
 
     @staticmethod
@@ -840,6 +841,8 @@ class DecoderFunction(torch.autograd.Function):
         cfg, prep, buf, rowmask, T = ctx.cfg, ctx.prep, ctx.buf, ctx.rowmask, ctx.T
         W = prep.keep
         B, Cm, Tm = ctx.mel_shape
+        if dz is None:                                       # (only the log-determinant was differentiated: tests)
+            dz = torch.zeros(ctx.mel_shape, device=dlogdet.device)
         dev = dz.device
         if getattr(prep, "bwd_side", None) is not None:
             torch.cuda.current_stream(dev).wait_stream(prep.bwd_side)

@@ -66,6 +66,9 @@ for fused in (True, False):
         scratch = torch.empty(L.glowtts_actnorm_stats_scratch_floats(R, C), device="cuda"); dld = torch.zeros(B, device="cuda")
         gb.dx, gb.dlogdet, gb.douts, gb.dskip, gb.douts_bf = dx.data_ptr(), dld.data_ptr(), douts.data_ptr(), dskip.data_ptr(), douts_bf.data_ptr()
         gb.scratch, gb.defer_wgrad = scratch.data_ptr(), 1
+        tlb = torch.zeros(512 * 64, dtype=torch.int64, device="cuda")
+        if fused and int(os.environ.get("GLOWTTS_WN_BWD_ABL", "0")) & 64:
+            gb.dcond = tlb.data_ptr()
         for l in range(dc.L):
             gb.dh[l] = dh0.data_ptr() if l == 0 else dhn[l].data_ptr()
             gb.dins[l] = dins[l].data_ptr()
@@ -84,6 +87,8 @@ for fused in (True, False):
             e1.record(st)
         torch.cuda.synchronize()
         res[("fused" if fused else "per-conv") + " bwd"] = e0.elapsed_time(e1) * 1e3 / n
+        if fused:
+            tlb_fused = tlb
         if os.environ.get("COLD") == "1":
             # the same with the caches flushed between launches (in the training step a flow's kept activations were written milliseconds
             # and > 1 GB of traffic earlier: they come from HBM, not from the 256 MB MALL that a back-to-back loop over ONE flow enjoys)
@@ -117,6 +122,17 @@ if os.environ.get("GLOWTTS_WN_ABL") in ("32", "96", "160", "288"):
         print(f"  wave {w:2d}: barrier -> before wait (issue) {iss:6.0f} | waitcnt {wait:6.0f} | barrier {bar:6.0f} | step {step:6.0f}")
     arrive = t[:, :, :, 1]                                           # when each wave reaches the barrier
     print("  barrier arrival spread over the 12 waves (max - min), median:", (arrive.max(dim=1).values - arrive.min(dim=1).values).median().item())
+if int(os.environ.get("GLOWTTS_WN_BWD_ABL", "0")) & 64:
+    nwg = (R + 51) // 52
+    t = tlb_fused.view(512, 64)[:nwg].cpu()
+    n = int((t[0] != 0).sum())
+    d = (t[:, 1:n] - t[:, : n - 1]).float()
+    names = ["prologue", "end^T gemm", "end^T epi"] + sum([[f"L{l} gate loads", f"L{l} rs^T gemm", f"L{l} gate deriv", f"L{l} in^T pass 0", f"L{l} in^T pass 1", f"L{l} exchange", f"L{l} dx update"]
+                                                            for l in range(dc.L - 1, -1, -1)], []) + ["start^T gemm", "dx_a rmw"]
+    print("backward phase: median clocks over workgroups (min .. max)")
+    for i in range(n - 1):
+        print(f"  {names[i] if i < len(names) else i:18s} {d[:, i].median().item():9.0f} ({d[:, i].min().item():.0f} .. {d[:, i].max().item():.0f})")
+    print(f"  total              {(t[:, n - 1] - t[:, 0]).float().median().item():9.0f}; first start .. last end {(t[:, n - 1].max() - t[:, 0].min()).item()}")
 if os.environ.get("GLOWTTS_WN_ABL") == "16":
     tl = tl_fused
     t = tl.view(512 * 12, 32)[:512][: (R + 51) // 52].cpu()
