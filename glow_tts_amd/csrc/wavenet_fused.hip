@@ -59,6 +59,7 @@ struct wn_fwd_args {
     float* skip; float* outs; int64_t ldo;                              // kept (fp32)
     void* skip_bf;                                                      // kept (bf16 copy of skip, [rows][192]; may be null)
     long long* tl;                                                      // tools builds (ABL & 16): per-workgroup phase stamps [grid][32]
+    int stagger;                                                        // experiment (tools builds): start delay of workgroup b = ((b >> 3) & 7) * stagger * 512 clocks
     // the NEXT flow's ActNorm + invertible 1x1 conv, applied by the coupling epilogue to the rows it produces (nx_xmid null: not asked for)
     const float* nx_logs; const float* nx_bias; const float* nx_winfo;
     float* nx_xmid; float* nx_xout; uint32_t* nx_xa_bf;
@@ -171,6 +172,9 @@ __global__ __launch_bounds__(WN_NT) void wn_fwd_kernel(const wn_fwd_args p)
             UT[tid] = p.cond_rows ? g : g / p.rows_per_utt;
         }
         issue(0); issue(1); issue(2);
+#ifdef GLOWTTS_TOOLS
+        for (int k = 0; k < (int)((blockIdx.x >> 3) & 7) * p.stagger; ++k) __builtin_amdgcn_s_sleep(8);
+#endif
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (xi[k] < 0) continue;
@@ -775,6 +779,7 @@ extern "C" int glowtts_wavenet_fwd(const glowtts_flow_dims* d, const glowtts_flo
     k.safe_waits = g_wn_safe_waits;
 #ifdef GLOWTTS_TOOLS
     if (GLOWTTS_TUNABLE("GLOWTTS_WN_ABL", 0) & 16) k.tl = reinterpret_cast<long long*>(a->skip_bf);      // tools/bench_wn.py passes the stamp buffer here
+    k.stagger = GLOWTTS_TUNABLE("GLOWTTS_WN_STAGGER", 0);
 #endif
     if (keep) {
         if (!a->skip || !a->outs) return GLOWTTS_E_ARG;

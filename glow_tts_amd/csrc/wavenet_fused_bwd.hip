@@ -60,6 +60,7 @@ struct wn_bwd_args {
     float* dx; int64_t lddx;                      // in / out: [rows][lddx] fp32, channels [0, C2) += d x_a
     float* dcond; int64_t ldcond;                 // COND: d conditioning [utterances][ldcond], layer l at + l * 2 H; ACCUMULATED (atomic adds)
     long long* tl;                                // tools builds (ABL & 64): per-workgroup phase stamps [grid][64]
+    int stagger;                                  // experiment (tools builds): start delay of workgroup b = ((b >> 3) & 7) * stagger * 512 clocks
 };
 
 // COND: the per-utterance conditioning joins the gate pre-activation AFTER the dropout (Modules.py:861-866): its gradient is the sum over an
@@ -135,6 +136,9 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
 
     // ---- prologue: d(m, logs) rows of the tile -> DT (A operand of End^T), row masks ----
     issue(0); issue(1);
+#ifdef GLOWTTS_TOOLS
+    for (int k = 0; k < (int)((blockIdx.x >> 3) & 7) * p.stagger; ++k) __builtin_amdgcn_s_sleep(8);
+#endif
     {
         const int per_row = (WN_H * 2) / 16;                   // 24 16-byte pieces per row (ldo = 192)
 #pragma unroll
@@ -704,6 +708,7 @@ extern "C" int glowtts_wavenet_bwd(const glowtts_flow_dims* d, const glowtts_flo
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (cnd) { k.dcond = g->dcond; k.ldcond = p->ldcond; }
 #ifdef GLOWTTS_TOOLS
+    k.stagger = GLOWTTS_TUNABLE("GLOWTTS_WN_STAGGER", 0);
     if (!cnd && (GLOWTTS_TUNABLE("GLOWTTS_WN_BWD_ABL", 0) & 64)) k.tl = reinterpret_cast<long long*>(g->dcond);      // tools/bench_wn.py passes the stamp buffer here
 #endif
     if (d->drop_p > 0.f) return cnd ? launch_wn_bwd<true, true>(k, grid, s) : launch_wn_bwd<true, false>(k, grid, s);

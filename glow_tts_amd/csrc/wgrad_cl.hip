@@ -645,7 +645,7 @@ int launch_x(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const
 }
 // all jobs of one launch share the X prologue (`xpro`) and the storage types (`io`): grouped launches are formed per class.
 // bf16 storage combinations the Glow-TTS path uses: (DY, X) both bf16 with no prologue (In conv: gate gradients x WaveNet state)
-// and X alone, with PAIRMUL (Res_Skip conv: fp32 gradients x gates) or without (x stored tanh * sigmoid).
+// and X alone, with PAIRMUL (Res_Skip conv: fp32 gradients x gates) or without (x stored tanh * sigmoid); DY alone without a prologue.
 template <typename CT>
 int launch_w(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const WCommon& cm, int taps, int xpro, int io, dim3 grid, hipStream_t s)
 {
@@ -657,6 +657,8 @@ int launch_w(const glowtts_wgrad_job& one, const glowtts_wgrad_job* table, const
         if (io == (GLOWTTS_WIO_DY_BF16 | GLOWTTS_WIO_X_BF16) && xpro == GLOWTTS_APRO_NONE) return launch_x<CT, GLOWTTS_APRO_NONE, true, true>(one, table, cm, taps, grid, s);
         if (io == GLOWTTS_WIO_X_BF16 && xpro == GLOWTTS_APRO_PAIRMUL) return launch_x<CT, GLOWTTS_APRO_PAIRMUL, false, true>(one, table, cm, taps, grid, s);
         if (io == GLOWTTS_WIO_X_BF16 && xpro == GLOWTTS_APRO_NONE) return launch_x<CT, GLOWTTS_APRO_NONE, false, true>(one, table, cm, taps, grid, s);
+        // DY alone (round 5): the encoder's projection conv - bf16 gate gradients x the attention core's fp32 output rows
+        if (io == GLOWTTS_WIO_DY_BF16 && xpro == GLOWTTS_APRO_NONE) return launch_x<CT, GLOWTTS_APRO_NONE, true, false>(one, table, cm, taps, grid, s);
     }
     if (io) return GLOWTTS_E_ARG;
     if (xpro == GLOWTTS_APRO_PAIRMUL) return launch_x<CT, GLOWTTS_APRO_PAIRMUL, false, false>(one, table, cm, taps, grid, s);
