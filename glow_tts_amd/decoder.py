@@ -90,6 +90,10 @@ def _L():
         L.glowtts_prep_job_init.argtypes = [c_void_p] * 4 + [c_int] * 8 + [c_void_p] + [c_i64] * 4 + [c_int, ctypes.POINTER(c_int)]
         L.glowtts_prep_launch.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
         L.glowtts_wavenet_prep_jobs.argtypes = [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)] + [c_void_p] * 13 + [c_int] * 3 + [c_void_p, c_int, c_void_p]
+        L.glowtts_cond_linear_fwd.argtypes = [c_void_p] * 6 + [c_int] * 4 + [c_void_p]
+        L.glowtts_cond_linear_bwd.argtypes = [c_void_p, c_i64] + [c_void_p] * 9 + [c_int] * 3 + [c_void_p]
+        L.glowtts_cond_linear_bwd_scratch_floats.argtypes = [c_int] * 3
+        L.glowtts_cond_linear_bwd_scratch_floats.restype = c_i64
         _declared = True
     return L
 
@@ -170,7 +174,7 @@ TAIL = {"defer": False, "pending": []}
 #       memory system at the head of the step and the decoder's forward ends 45 us later: 5.24-5.30 against 5.20-5.23 ms/step (three alternating pairs)
 #   prep_fused: training on the fused bf16 path forms w = g v / ||v|| and every weight image in ONE launch (csrc/prep_ops.hip) instead of 4 weight-norm +
 #       ~22 packing launches (0.42 -> ~0.1 ms at the head of the step, round 4)
-TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0}
+TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0, "dec_chunks": 1, "cond_hip": True}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
@@ -570,9 +574,10 @@ class _Prepared:
         p.cond, p.ldcond, p.cond_rows = rows.data_ptr(), self._Lw * 2 * self._H, 1
 
 
-def _dims(cfg, B, T, drop_p=0.0, seed=None, flow=0):
-    """seed: None or a device int32/uint32 tensor with one element (re-drawn on device every step, hipGraph-safe)."""
-    return FlowDims(B, T, cfg.C, cfg.H, cfg.L, cfg.k, cfg.precision, float(drop_p), (1000003 * flow) & 0xFFFFFFFF,
+def _dims(cfg, B, T, drop_p=0.0, seed=None, flow=0, chunk=0):
+    """seed: None or a device int32/uint32 tensor with one element (re-drawn on device every step, hipGraph-safe).
+    chunk: index of the utterance chunk this launch serves (TUNE["dec_chunks"]; its rows are numbered from 0: the dropout hash gets its own key)."""
+    return FlowDims(B, T, cfg.C, cfg.H, cfg.L, cfg.k, cfg.precision, float(drop_p), (1000003 * flow + 7368787 * chunk) & 0xFFFFFFFF,
                     seed.data_ptr() if seed is not None else None, int(cfg.act_bf16))
 
 
@@ -613,19 +618,21 @@ class _Buffers:
         # bf16 copy of x_a = xmid[:, :C/2] (written by the flow's ActNorm + 1x1 pass): X of the Start conv's weight gradient
         self.xa_bf = torch.empty(F_, R, C // 2, device=dev, dtype=torch.bfloat16) if (cfg.act_bf16 and (C // 2) % 8 == 0) else None
 
-    def acts(self, f, L, rowmask):
+    def acts(self, f, L, rowmask, row0=0):
+        """row0: first row of the utterance chunk the launch serves (every kept tensor is rows-major: a chunk is a row range of each)."""
+        at = lambda t: t.data_ptr() + row0 * t.stride(-2) * t.element_size()
         a = FlowActs()
-        a.xin, a.xmid, a.xout = self.x[f].data_ptr(), self.xmid[f].data_ptr(), self.x[f + 1].data_ptr()
+        a.xin, a.xmid, a.xout = at(self.x[f]), at(self.xmid[f]), at(self.x[f + 1])
         for l in range(L):
-            a.hs[l] = self.hs[f, l].data_ptr()
-            a.gates[l] = self.gates[f, l].data_ptr()
+            a.hs[l] = at(self.hs[f, l])
+            a.gates[l] = at(self.gates[f, l])
             if self.actp is not None:
-                a.acts[l] = self.actp[f, l].data_ptr()
+                a.acts[l] = at(self.actp[f, l])
         if self.skipb is not None:
-            a.skip_bf = self.skipb[f].data_ptr()
+            a.skip_bf = at(self.skipb[f])
         if self.xa_bf is not None:
-            a.xa_bf = self.xa_bf[f].data_ptr()
-        a.skip, a.outs, a.rowmask = self.skip[f].data_ptr(), self.outs[f].data_ptr(), rowmask.data_ptr()
+            a.xa_bf = at(self.xa_bf[f])
+        a.skip, a.outs, a.rowmask = at(self.skip[f]), at(self.outs[f]), rowmask.data_ptr() + 4 * row0
         return a
 
 
@@ -646,6 +653,49 @@ def _cond_rows(cfg, prep, f, prow, pitch_w, pitch_b, Tp):
     return cr.contiguous()
 
 
+# Utterance chunks (TUNE["dec_chunks"] = n > 1): the flows' launches are row-local per utterance, so the batch can run as n independent chains - utterances
+# [b0, b0 + B / n) each - on n streams forked from the caller's and joined behind the last flow.  A fused coupling workgroup owns its CU for ~100 us and the
+# whole batch's launch fills the chip: the text encoder's short dependent launches on the other stream then advance ONE launch per decoder kernel boundary.
+# n chains of a quarter-chip launch each drift apart and give the encoder a boundary every ~25 us instead of every ~110.
+_CHUNK_STREAMS = {}
+
+
+def _chunks(B, prep, pitch):
+    """[(index, first utterance, utterances)] of the decoder's utterance chunks for this batch."""
+    n = int(TUNE["dec_chunks"])
+    if n <= 1 or pitch is not None or B % n or B // n < 1:
+        return [(0, 0, B)]
+    return [(i, i * (B // n), B // n) for i in range(n)]
+
+
+def _params_at(prep, f, b0):
+    """Flow f's parameter struct as utterance b0's chunk sees it: the per-utterance conditioning rows start at b0."""
+    p = prep.params[f]
+    if b0 == 0 or not p.cond:
+        return p
+    q = FlowParams.from_buffer_copy(p)
+    q.cond = p.cond + 4 * b0 * p.ldcond
+    return q
+
+
+def _run_chunks(chunks, chain, device):
+    if len(chunks) == 1:
+        chain(*chunks[0])
+        return
+    main = torch.cuda.current_stream(device)
+    key = (str(device), len(chunks))
+    if key not in _CHUNK_STREAMS:
+        _CHUNK_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in chunks[1:]]
+    # chunk 0 stays on the caller's stream: one branch less for the graph executor
+    for c, st in zip(chunks[1:], _CHUNK_STREAMS[key]):
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            chain(*c)
+    chain(*chunks[0])
+    for st in _CHUNK_STREAMS[key]:
+        main.wait_stream(st)
+
+
 def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
     """pitch: None or (pitches [B, Tm], pitch_w [F, L, 2H, ns], pitch_b [F, L, 2H]) - GR mode."""
     L = _L()
@@ -655,25 +705,31 @@ def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
     _, rowmask, T = squeeze_rows(cfg, mels, lengths, out=buf.x[0])
     prow = pitch_rows(cfg, pitch[0], rowmask, B, T) if pitch is not None else None
     stamp("dec_fwd_begin")
-    chained = False
-    for f in range(cfg.F):
-        if pitch is not None:
-            cr = _cond_rows(cfg, prep, f, prow, pitch[1], pitch[2], T + 2 * ROW_PAD)
-            prep.set_cond_rows(f, cr)
-        if getattr(prep, "fwd_side_from", None) == f:
-            torch.cuda.current_stream(mels.device).wait_stream(prep.bwd_side)
-        acts = buf.acts(f, cfg.L, rowmask)
-        acts.actnorm_done = int(chained)
-        # a flow on the fused coupling launch also applies the NEXT flow's ActNorm + 1x1 conv in that launch's epilogue (one launch less per flow on the
-        # decoder's forward chain; csrc/wavenet_fused.hip)
-        chained = bool(TUNE["chain_actnorm"]) and f + 1 < cfg.F and bool(prep.params[f].wn_img) and pitch is None
-        if chained:
-            nxt, pn = buf.acts(f + 1, cfg.L, rowmask), prep.params[f + 1]
-            acts.next_an_logs, acts.next_an_bias, acts.next_winfo = pn.an_logs, pn.an_bias, pn.winfo
-            acts.next_xmid, acts.next_xout, acts.next_xa_bf = nxt.xmid, nxt.xout, nxt.xa_bf
-        dims = _dims(cfg, B, T, drop_p, seed, f)
-        _lib.check(L.glowtts_flow_forward(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(acts), _lib.stream()),
-                   "glowtts_flow_forward")
+    Tp = T + 2 * ROW_PAD
+    chunks = _chunks(B, prep, pitch)
+
+    def chain(ci, b0, nb):
+        """All flows of utterances [b0, b0 + nb) on the current stream."""
+        chained = False
+        for f in range(cfg.F):
+            if pitch is not None:
+                cr = _cond_rows(cfg, prep, f, prow, pitch[1], pitch[2], Tp)
+                prep.set_cond_rows(f, cr)
+            if getattr(prep, "fwd_side_from", None) == f:
+                torch.cuda.current_stream(mels.device).wait_stream(prep.bwd_side)
+            acts = buf.acts(f, cfg.L, rowmask, b0 * Tp)
+            acts.actnorm_done = int(chained)
+            # a flow on the fused coupling launch also applies the NEXT flow's ActNorm + 1x1 conv in that launch's epilogue (one launch less per flow on the
+            # decoder's forward chain; csrc/wavenet_fused.hip)
+            chained = bool(TUNE["chain_actnorm"]) and f + 1 < cfg.F and bool(prep.params[f].wn_img) and pitch is None
+            if chained:
+                nxt, pn = buf.acts(f + 1, cfg.L, rowmask, b0 * Tp), prep.params[f + 1]
+                acts.next_an_logs, acts.next_an_bias, acts.next_winfo = pn.an_logs, pn.an_bias, pn.winfo
+                acts.next_xmid, acts.next_xout, acts.next_xa_bf = nxt.xmid, nxt.xout, nxt.xa_bf
+            dims = _dims(cfg, nb, T, drop_p, seed, f, ci)
+            _lib.check(L.glowtts_flow_forward(ctypes.byref(dims), ctypes.byref(_params_at(prep, f, b0)), ctypes.byref(acts), _lib.stream()),
+                       "glowtts_flow_forward")
+    _run_chunks(chunks, chain, mels.device)
     stamp("dec_fwd_end")
     z = unsqueeze_rows(cfg, buf.x[cfg.F], lengths, B, Tm)
     part = torch.empty(cfg.F * B, device=mels.device)
@@ -949,36 +1005,53 @@ class DecoderFunction(torch.autograd.Function):
         main = torch.cuda.current_stream()
         side = _wgrad_stream(dev)
         stamp("dec_bwd_begin")
-        for f in order:
-            g = FlowGrads()
-            g.dx, g.dlogdet, g.douts, g.dskip = dx.data_ptr(), dld.data_ptr(), douts[f].data_ptr(), dskip[f].data_ptr()
-            g.douts_bf = douts_bf[f].data_ptr() if douts_bf is not None else None
-            g.dh0_bf16 = int(h0bf)
-            # the last kernel of this flow's backward also applies the coupling backward of the flow that runs next (f - 1)
-            g.coupling_done = int(fuse and f != order[0])
-            if fuse and f > 0:
-                g.prev_xmid, g.prev_outs, g.prev_douts = buf.xmid[f - 1].data_ptr(), buf.outs[f - 1].data_ptr(), douts[f - 1].data_ptr()
-                g.prev_douts_bf = douts_bf[f - 1].data_ptr() if douts_bf is not None else None
-            g.scratch, g.d_an, g.defer_wgrad = scratch[f].data_ptr(), None, 1
-            for l in range(Lw):
-                g.dh[l], g.dins[l] = dh_ptr(f, l), dins[f, l].data_ptr()
-            if dcond is not None:
-                g.dcond = dcond.data_ptr() + 4 * f * Lw * 2 * H
-                if npit:
-                    g.pitch_rows, g.pitch_ns = ctx.prow.data_ptr(), npit
-            acts = buf.acts(f, Lw, rowmask)
-            dims = _dims(cfg, B, T, ctx.drop[0], ctx.drop[1], f)
-            _lib.check(L.glowtts_flow_backward(ctypes.byref(dims), ctypes.byref(prep.params[f]), ctypes.byref(acts), ctypes.byref(g),
-                                               _lib.stream()), "glowtts_flow_backward")
-            stamp(f"dec_bwd_flow{f}")
-            if halves > 1:
-                per = -(-len(order) // halves)
-                pos = order.index(f) + 1
-                if pos % per == 0 and pos < len(order):
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
-                        for grp in (gk, gp, g1):
-                            grp.launch_segment(pos // per - 1)
+        Tp = T + 2 * ROW_PAD
+        chunks = _chunks(B, prep, None if ctx.prow is None else ctx.prow)
+        if halves > 1:
+            chunks = [(0, 0, B)]
+        # the ActNorm / 1x1 backward leaves one row of partial sums per block of its launch: a chunk's blocks follow the previous chunk's
+        blk_off, nblk_all = [], 0
+        for _, _, nb in chunks:
+            blk_off.append(nblk_all)
+            nblk_all += L.glowtts_actnorm_bwd_blocks(nb * Tp)
+        assert nblk_all * (2 * C + 16) <= nscr
+        at = lambda t, row0: t.data_ptr() + row0 * t.stride(-2) * t.element_size()
+
+        def chain(ci, b0, nb):
+            r0 = b0 * Tp
+            for f in order:
+                g = FlowGrads()
+                g.dx, g.dlogdet, g.douts, g.dskip = at(dx, r0), dld.data_ptr() + 4 * b0, at(douts[f], r0), at(dskip[f], r0)
+                g.douts_bf = at(douts_bf[f], r0) if douts_bf is not None else None
+                g.dh0_bf16 = int(h0bf)
+                # the last kernel of this flow's backward also applies the coupling backward of the flow that runs next (f - 1)
+                g.coupling_done = int(fuse and f != order[0])
+                if fuse and f > 0:
+                    g.prev_xmid, g.prev_outs, g.prev_douts = at(buf.xmid[f - 1], r0), at(buf.outs[f - 1], r0), at(douts[f - 1], r0)
+                    g.prev_douts_bf = at(douts_bf[f - 1], r0) if douts_bf is not None else None
+                g.scratch, g.d_an, g.defer_wgrad = scratch[f].data_ptr() + 4 * blk_off[ci] * (2 * C + 16), None, 1
+                for l in range(Lw):
+                    g.dh[l] = at(dh0[f], r0) if l == 0 else at(dhn[f, l - 1], r0)
+                    g.dins[l] = at(dins[f, l], r0)
+                if dcond is not None:
+                    g.dcond = dcond.data_ptr() + 4 * f * Lw * 2 * H + 4 * b0 * dcond.stride(0)
+                    if npit:
+                        g.pitch_rows, g.pitch_ns = ctx.prow.data_ptr(), npit
+                acts = buf.acts(f, Lw, rowmask, r0)
+                dims = _dims(cfg, nb, T, ctx.drop[0], ctx.drop[1], f, ci)
+                _lib.check(L.glowtts_flow_backward(ctypes.byref(dims), ctypes.byref(_params_at(prep, f, b0)), ctypes.byref(acts), ctypes.byref(g),
+                                                   _lib.stream()), "glowtts_flow_backward")
+                if ci == 0:
+                    stamp(f"dec_bwd_flow{f}")
+                if halves > 1:
+                    per = -(-len(order) // halves)
+                    pos = order.index(f) + 1
+                    if pos % per == 0 and pos < len(order):
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            for grp in (gk, gp, g1):
+                                grp.launch_segment(pos // per - 1)
+        _run_chunks(chunks, chain, dev)
         if halves > 1:
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -1015,7 +1088,7 @@ class DecoderFunction(torch.autograd.Function):
                 else:
                     run()
         stamp("dec_wgrads_done")
-        _lib.check(L.glowtts_colsum_batched(scratch.data_ptr(), d_an.data_ptr(), L.glowtts_actnorm_bwd_blocks(R), 2 * C + 16, F_, nscr, 2 * C + 16, _lib.stream()),
+        _lib.check(L.glowtts_colsum_batched(scratch.data_ptr(), d_an.data_ptr(), nblk_all, 2 * C + 16, F_, nscr, 2 * C + 16, _lib.stream()),
                    "glowtts_colsum_batched")
         # + the log-determinant terms of the parameters (Modules.py:694, 747): logdet_b += (sum logs + logdet(W) C/4) * len_b
         _lib.check(L.glowtts_decoder_param_grads(d_an.data_ptr(), dld.data_ptr(), rowmask.data_ptr(), prep.winfo.data_ptr(), G["an_logs"].data_ptr(),
@@ -1155,6 +1228,54 @@ class WeightNorm(torch.autograd.Function):
         return dg, dv, None
 
 
+class CondLinear(torch.autograd.Function):
+    """cond [B, N] = sum over kinds of  vec_k [B, D_k] @ (g_k v_k / ||v_k||)^T + bias_k   for the N = F * L * 2H weight-normalised 1x1 conditioning
+    convs of the decoder (Modules.py:832-845, 863-866).  apply(g_0, v_0, bias_0, vec_0, g_1, ...): one forward launch per kind (the second accumulates),
+    one backward launch per kind producing d g, d v, d bias and - when the vectors are differentiable (LUT / prosody encoder) - their gradient by a
+    deterministic two-stage sum."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        L = _L()
+        kinds = [args[i:i + 4] for i in range(0, len(args), 4)]
+        B = kinds[0][3].shape[0]
+        N = kinds[0][1].numel() // kinds[0][1].shape[-2]
+        dev = kinds[0][3].device
+        out = torch.empty(B, N, device=dev)
+        keep = []
+        for i, (g, v, b, vec) in enumerate(kinds):
+            g, v, b, vec = g.detach().contiguous(), v.detach().contiguous(), b.detach().contiguous(), vec.detach().contiguous()
+            D = v.shape[-2]
+            assert v.shape[-1] == 1 and v.numel() == N * D and g.numel() == N and b.numel() == N and tuple(vec.shape) == (B, D)
+            inv = torch.empty(N, device=dev)
+            _lib.check(L.glowtts_cond_linear_fwd(v.data_ptr(), g.data_ptr(), b.data_ptr(), vec.data_ptr(), out.data_ptr(), inv.data_ptr(), N, D, B, int(i > 0),
+                                                 _lib.stream()), "glowtts_cond_linear_fwd")
+            keep += [g, v, vec, inv]
+        ctx.save_for_backward(*keep)
+        ctx.shapes = [(tuple(k[0].shape), tuple(k[1].shape), tuple(k[2].shape)) for k in kinds]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _L()
+        keep = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, N = dout.shape
+        grads = []
+        for i, (gs, vs, bs) in enumerate(ctx.shapes):
+            g, v, vec, inv = keep[4 * i:4 * i + 4]
+            D = vec.shape[1]
+            dv, dg, db = torch.empty_like(v), torch.empty_like(g), torch.empty(N, device=dout.device)
+            want_vec = ctx.needs_input_grad[4 * i + 3]
+            dvec = torch.empty_like(vec) if want_vec else None
+            scratch = torch.empty(L.glowtts_cond_linear_bwd_scratch_floats(N, D, B), device=dout.device)
+            _lib.check(L.glowtts_cond_linear_bwd(dout.data_ptr(), N, v.data_ptr(), g.data_ptr(), inv.data_ptr(), vec.data_ptr(), dv.data_ptr(), dg.data_ptr(),
+                                                 db.data_ptr(), dvec.data_ptr() if want_vec else None, scratch.data_ptr(), N, D, B, _lib.stream()),
+                       "glowtts_cond_linear_bwd")
+            grads += [dg.view(gs), dv.view(vs), db.view(bs), dvec]
+        return tuple(grads)
+
+
 class DecoderStacks:
     """Leaf stacks of the decoder's parameters, built once per model from the reference-named parameter dict."""
 
@@ -1218,11 +1339,20 @@ class DecoderStacks:
         return w.view(cfg.F, cfg.L, 2 * cfg.H, -1), self.S["Pitch_b"].tensor().view(cfg.F, cfg.L, 2 * cfg.H)
 
     def conditioning(self, speakers=None, prosodies=None):
-        """cond[b, f, l, :] = Speaker_l(spk_b) + Prosody_l(pro_b)  (Modules.py:863-866), one batched matmul each."""
+        """cond[b, f, l, :] = Speaker_l(spk_b) + Prosody_l(pro_b)  (Modules.py:863-866): one launch per kind straight from the weight-norm pairs
+        (CondLinear; csrc/cond_ops.hip), or - shapes that kernel does not take - weight norm + one batched matmul each."""
+        kinds = [(kind, vec) for kind, vec in (("Speaker", speakers), ("Prosody", prosodies)) if vec is not None]
+        if not kinds:
+            return None
+        if TUNE["cond_hip"] and all(vec.is_cuda and vec.dtype == torch.float32 and vec.dim() == 2 and vec.shape[0] <= 64 and vec.shape[1] in (128, 256, 384, 512)
+                                    and vec.shape[1] == self.S[kind + "_v"].tensor().shape[-2] for kind, vec in kinds):
+            args = []
+            for kind, vec in kinds:
+                args += [self.S[kind + "_g"].tensor(), self.S[kind + "_v"].tensor(), self.S[kind + "_b"].tensor(), vec]
+            cond = CondLinear.apply(*args)
+            return cond.view(cond.shape[0], self.cfg.F, self.cfg.L, 2 * self.cfg.H)
         cond = None
-        for kind, vec in (("Speaker", speakers), ("Prosody", prosodies)):
-            if vec is None:
-                continue
+        for kind, vec in kinds:
             w = WeightNorm.apply(self.S[kind + "_g"].tensor(), self.S[kind + "_v"].tensor()).squeeze(-1)
             c = torch.einsum("nod,bd->bno", w, vec) + self.S[kind + "_b"].tensor()
             cond = c if cond is None else cond + c

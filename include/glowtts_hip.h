@@ -499,6 +499,20 @@ int glowtts_utt_colsum(const float *x, int64_t ldx, float *out, int64_t ldout, i
                        int perm, int perm_h, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Per-utterance conditioning of the WaveNet gates (Modules.py:832-845: Speaker_l / Prosody_l, weight-normalised Conv1d(D -> 2H, k = 1), and :863-866 where
+ * their outputs join the gate pre-activation; round 5, csrc/cond_ops.hip).  All N = F * L * 2H output channels of one kind in one launch, straight from
+ * the (weight_g, weight_v) pairs:   out[b][n] = (accumulate ? out[b][n] : 0) + bias[n] + g[n] / ||v[n]|| <v[n], vec[b]>
+ *   v [N][D] (D <= 512), g [N], bias [N] (may be NULL), vec [B][D] (B <= 64), out [B][N]; inv_out [N] (may be NULL) receives 1 / ||v[n]|| for the backward.
+ * _bwd: from dcond [B][ldd] (this kind's channel n at column n, ldd >= N): dv [N][D], dg [N], dbias [N] (may be NULL) - the weight-norm backward applied in
+ * place - and, when dvec [B][D] is given, the vectors' gradient as a deterministic two-stage sum through `scratch`
+ * (glowtts_cond_linear_bwd_scratch_floats(N, D, B) floats; always required). */
+int glowtts_cond_linear_fwd(const float *v, const float *g, const float *bias, const float *vec, float *out, float *inv_out,
+                            int N, int D, int B, int accumulate, void *stream);
+int64_t glowtts_cond_linear_bwd_scratch_floats(int N, int D, int B);
+int glowtts_cond_linear_bwd(const float *dcond, int64_t ldd, const float *v, const float *g, const float *inv, const float *vec,
+                            float *dv, float *dg, float *dbias, float *dvec, float *scratch, int N, int D, int B, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * GRU recurrence of the GST prosody encoder (Modules.py:338-343, 371: torch.nn.GRU, one layer, batch_first, h0 = 0), one launch per
  * direction instead of MIOpen's ~30 launches per time step.  The caller does the GEMMs around it: gi = x W_ih^T + b_ih before,
  * dx = dgi W_ih, dW_ih = dgi^T x, dW_hh = dgh^T h_prev, db = column sums after.   3H <= 1024.

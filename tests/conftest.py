@@ -10,6 +10,12 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
 def pytest_configure(config):
+    # the oracle's CPU passes at full size dominate the GPU suite's wall time, and torch's default of one intra-op thread per core is the slowest setting
+    # on the GPU boxes (128 cores: 5.1 s per oracle step against 0.20 s at 16 threads, bench.py's cpu_baseline sweep)
+    import torch
+    n = int(os.environ.get("GLOWTTS_TEST_THREADS", "16"))          # (0: torch's default)
+    if n > 0:
+        torch.set_num_threads(min(n, os.cpu_count() or 1))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "late(tier): run after the in-process oracle-parity tests - tier 1 = child-process / entry-point / loader "
                             "integration tests, tier 2 = process-group (RCCL / gloo) tests")

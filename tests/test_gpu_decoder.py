@@ -267,3 +267,36 @@ def test_gr_pitch_weight_gradient_is_exact_under_dropout(precision):
         numeric = (4 * central(2e-3) - central(4e-3)) / 3 if precision == 0 else central(2e-2)
         tol = (2e-2 if precision == 0 else 0.15) * max(1.0, abs(analytic))
         assert abs(numeric - analytic) <= tol, (trial, numeric, analytic)
+
+
+@pytest.mark.parametrize("B,kinds", [(32, 1), (5, 2), (64, 2), (17, 1)])
+def test_conditioning_linear_kernel_matches_torch(B, kinds):
+    """csrc/cond_ops.hip (`decoder.CondLinear`): the F * L * 2H weight-normalised 1x1 conditioning convs of the decoder (Modules.py:832-845, 863-866)
+    as one launch per kind straight from (weight_g, weight_v) - against torch's weight norm + matmul in float64, values and every gradient
+    (d g, d v, d bias, d vector).  fp32 sums in a different order than torch: 2e-5 of the tensor's largest entry."""
+    from glow_tts_amd.decoder import CondLinear
+    g_ = torch.Generator().manual_seed(B * 10 + kinds)
+    N, Ds = 12 * 4 * 384, [256, 128][:kinds]
+    args, ref = [], []
+    for D in Ds:
+        v = torch.randn(48, 384, D, 1, generator=g_) * 0.1
+        gg = torch.rand(48, 384, 1, 1, generator=g_) + 0.5
+        b = torch.randn(48, 384, generator=g_) * 0.1
+        vec = torch.randn(B, D, generator=g_)
+        cu = [t.cuda().requires_grad_(True) for t in (gg, v, b, vec)]
+        args += cu
+        ref.append([t.double().requires_grad_(True) for t in (gg, v, b, vec)])
+    out = CondLinear.apply(*args)
+    want = 0
+    for gg, v, b, vec in ref:
+        w = (gg * v / v.flatten(-2).norm(dim=-1).unsqueeze(-1).unsqueeze(-1)).reshape(N, -1)
+        want = want + vec @ w.t() + b.reshape(1, N)
+    assert tuple(out.shape) == (B, N)
+    assert (out.detach().cpu().double() - want.detach()).abs().max() <= 2e-5 * want.detach().abs().max()
+    dout = torch.randn(B, N, generator=g_)
+    out.backward(dout.cuda())
+    want.backward(dout.double())
+    torch.cuda.synchronize()
+    for got_k, want_k in zip(args, [t for k in ref for t in k]):
+        err = (got_k.grad.cpu().double() - want_k.grad).abs().max() / want_k.grad.abs().max()
+        assert err <= 2e-5, (tuple(got_k.shape), float(err))
