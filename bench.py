@@ -587,9 +587,11 @@ def main():
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from glow_tts_amd import _lib, decoder as _dec
-    for kv in args.tune:
+    from glow_tts_amd import conv_fn as _cf, ops as _ops
+    for kv in args.tune:                                      # decoder.TUNE, or the encoder's block-function / packing switches (conv_fn.FUSE, ops.FAST_PACK)
         k, v = kv.split("=")
-        _dec.TUNE[k] = type(_dec.TUNE[k])(int(v))
+        d = _dec.TUNE if k in _dec.TUNE else _cf.FUSE if k in _cf.FUSE else _ops.FAST_PACK
+        d[k] = type(d[k])(int(v))
     if args.timeline:
         _dec.STAMPS["buf"] = torch.zeros(4096, dtype=torch.int64, device=dev)
     from glow_tts_amd.distributed import FlatGradReducer, actnorm_stats_allreduce

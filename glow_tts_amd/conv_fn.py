@@ -45,6 +45,8 @@ def _L():
         L.glowtts_rpr_attention_scratch_floats.argtypes = [c_int] * 5
         L.glowtts_rpr_attention_scratch_floats.restype = c_i64
         L.glowtts_rpr_attention_bwd_prec.argtypes = [c_p] * 11 + [c_int] * 5 + [c_f, c_u32, c_p, c_int, c_p]
+        L.glowtts_rpr_attention_bwd_partial_rows.argtypes = [c_int] * 5
+        L.glowtts_rpr_attention_bwd_partial_rows.restype = c_i64
         _decl = True
     return L
 
@@ -77,6 +79,7 @@ class WgradTape:
     def __init__(self):
         self.jobs = []
         self.ln_count, self.ln = 0, None           # LayerNorms of the block functions: their gamma / beta partials are reduced by ONE launch
+        self.att_count, self.att = 0, None         # attention cores of the block functions: their relative-position gradients likewise
 
     def ln_slot(self, R, C, device):
         """-> (scratch [nfloats], gb [2C]) of the next LayerNorm backward: slices of two buffers that `flush` reduces with one
@@ -90,6 +93,21 @@ class WgradTape:
         i = st["used"]
         st["used"] += 1
         return st["scratch"][i], st["gb"][i]
+
+    def att_slot(self, B, Tp, H, D, win, device):
+        """-> (scratch, drel [2][2 win + 1][D]) of the next attention backward: the kernel leaves its per-workgroup partial sums of (d relK | d relV) in
+        `scratch`, `flush` reduces every layer's with one launch - the reduction is not on the chain to the next layer's gradient."""
+        L = _L()
+        if self.att is None:
+            nf = L.glowtts_rpr_attention_scratch_floats(B, Tp, H, D, win)
+            cols = 2 * (2 * win + 1) * D
+            self.att = {"scratch": torch.empty(self.att_count, nf, device=device), "out": torch.empty(self.att_count, cols, device=device), "used": 0,
+                        "rows": L.glowtts_rpr_attention_bwd_partial_rows(B, Tp, H, D, win), "cols": cols, "key": (B, Tp, H, D, win)}
+        st = self.att
+        assert st["used"] < self.att_count and st["key"] == (B, Tp, H, D, win)
+        i = st["used"]
+        st["used"] += 1
+        return st["scratch"][i], st["out"][i].view(2, 2 * win + 1, D)
 
     def add(self, dz, x, O, ca, taps, precision, dw, db):
         self.jobs.append((dz, x, O, ca, taps, precision, dw, db))
@@ -117,6 +135,12 @@ class WgradTape:
             _lib.check(_L().glowtts_colsum_batched(st["scratch"].data_ptr(), st["gb"].data_ptr(), st["nblk"], 2 * st["C"], st["used"],
                                                    st["scratch"].shape[1], 2 * st["C"], _lib.stream()), "glowtts_colsum_batched")
             self.ln = None
+        if self.att is not None:
+            st = self.att
+            assert st["used"] == self.att_count, "an attention core of the block functions did not run its backward"
+            _lib.check(_L().glowtts_colsum_batched(st["scratch"].data_ptr(), st["out"].data_ptr(), st["rows"], st["cols"], st["used"],
+                                                   st["scratch"].shape[1], st["cols"], _lib.stream()), "glowtts_colsum_batched")
+            self.att = None
 
 
 class ParamGate(torch.autograd.Function):
@@ -276,13 +300,16 @@ def layernorm_rows(a, b, gamma, beta, rowmask, relu=False, drop_p=0.0, seed=0, s
 
 
 def _conv_launch(a, pw, ci, R, k, flags, n, bias, rowmask, out, in0=None, drop_p=0.0, seed=0, seed_t=None, a_bf=True):
-    io = (ops.IO_A_BF16 if a_bf else 0) | (ops.IO_OUT0_BF16 if out.dtype == torch.bfloat16 else 0)
-    ops.conv_cl(a, pw, ci, R, lda=ci, pad=(k - 1) // 2, epi=ops.EPI_LINEAR, flags=flags | (ops.F_ADD_IN0 if in0 is not None else 0), n=n,
+    """in0: added to the result (residual) - or, with ops.F_GATE_IN0 in `flags`, the kept output of the relu / dropout layer that gates it."""
+    io = (ops.IO_A_BF16 if a_bf else 0) | (ops.IO_OUT0_BF16 if out.dtype == torch.bfloat16 else 0) | \
+        (ops.IO_IN0_BF16 if (in0 is not None and in0.dtype == torch.bfloat16) else 0)
+    ops.conv_cl(a, pw, ci, R, lda=ci, pad=(k - 1) // 2, epi=ops.EPI_LINEAR,
+                flags=flags | (ops.F_ADD_IN0 if (in0 is not None and not flags & ops.F_GATE_IN0) else 0), n=n,
                 bias=bias, rowmask=rowmask, in0=in0, ldi0=n, out0=out, ld0=n, drop_p=drop_p, seed=seed, seed_t=seed_t, io_flags=io)
 
 
 # measured design switches of the block functions (tests flip them; never read from the environment)
-FUSE = {"proj_ln": True}
+FUSE = {"proj_ln": True, "gate_in_dgrad": True, "defer_rel_sum": True}
 
 
 class FFNBlock(torch.autograd.Function):
@@ -347,10 +374,14 @@ class FFNBlock(torch.autograd.Function):
         # LayerNorm_1 backward; dz1 = d(Conv_1 pre-activation): through the conv's dropout gate when there is one, else ds * mask = ds
         _lib.check(L.glowtts_layernorm_bwd_io(dy.data_ptr(), None, s_.data_ptr(), stats.data_ptr(), gamma.data_ptr(), rowmask.data_ptr(), ds.data_ptr(),
                                               None, scratch.data_ptr(), R, C, 0, 0.0, dz1.data_ptr(), _sp(h1), scale, _lib.stream()), "glowtts_layernorm_bwd_io")
-        dh = torch.empty(R, O0, device=dev, dtype=bf)
-        _conv_launch(dz1, pwt1, C, R, k, 0, O0, None, None, dh)                                     # Conv_1 data gradient
         dz0 = torch.empty(R, O0, device=dev, dtype=bf)
-        _lib.check(L.glowtts_gate_bwd_io(dh.data_ptr(), h0.data_ptr(), rowmask.data_ptr(), dz0.data_ptr(), R, O0, scale, 7, _lib.stream()), "glowtts_gate_bwd_io")
+        if FUSE["gate_in_dgrad"]:
+            # Conv_1 data gradient with the relu / dropout gate of Conv_0's output in its epilogue (h0 == 0 on cut elements and on masked rows)
+            _conv_launch(dz1, pwt1, C, R, k, ops.F_GATE_IN0, O0, None, None, dz0, in0=h0, drop_p=drop_p)
+        else:
+            dh = torch.empty(R, O0, device=dev, dtype=bf)
+            _conv_launch(dz1, pwt1, C, R, k, 0, O0, None, None, dh)                                 # Conv_1 data gradient
+            _lib.check(L.glowtts_gate_bwd_io(dh.data_ptr(), h0.data_ptr(), rowmask.data_ptr(), dz0.data_ptr(), R, O0, scale, 7, _lib.stream()), "glowtts_gate_bwd_io")
         dx1 = torch.empty(R, C, device=dev)
         _conv_launch(dz0, pwt0, O0, R, k, 0, C, None, None, dx1, in0=ds)                            # Conv_0 data gradient + the residual branch (ds)
         dw0, db0 = torch.empty_like(w0), torch.empty(O0, device=dev)
@@ -366,7 +397,9 @@ class AttentionBlock(torch.autograd.Function):
     gradient + the residual branch's gradient in its epilogue."""
 
     @staticmethod
-    def forward(ctx, x, xb, wqkv, bqkv, relk, relv, wp, bp, gamma, beta, rowmask, B, Tp, H, win, drop_p, seeds, seed_t, tape, packs_qkv, packs_p, qkv_pre=None):
+    def forward(ctx, x, xb, wqkv, bqkv, relk, relv, wp, bp, gamma, beta, rowmask, B, Tp, H, win, drop_p, seeds, seed_t, tape, packs_qkv, packs_p, qkv_pre=None,
+                rel_gated=False):
+        """rel_gated: relk / relv reached this call through the tape's ParamGate - their gradients may then be filled by the tape's flush."""
         R, C = x.shape
         dev = x.device
         bf = torch.bfloat16
@@ -400,8 +433,11 @@ class AttentionBlock(torch.autograd.Function):
             _lib.check(L.glowtts_layernorm_fwd_io(proj.data_ptr(), x.data_ptr(), s_.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rowmask.data_ptr(),
                                                   y.data_ptr(), stats.data_ptr(), R, C, 1e-4, 0, 0.0, 0, None, yb.data_ptr(), _lib.stream()), "glowtts_layernorm_fwd_io")
         tape.ln_count += 1
+        defer_rel = bool(FUSE["defer_rel_sum"] and rel_gated)
+        if defer_rel:
+            tape.att_count += 1
         ctx.save_for_backward(xb, qkv, rk, rv, P, att, proj if drop_p > 0 else None, s_, stats, gamma, rowmask, wqkv, wp, seed_t)
-        ctx.misc = (tape, packs_qkv[1], packs_p[1], float(drop_p), B, Tp, H, win, int(seeds[0]) & 0xFFFFFFFF)
+        ctx.misc = (tape, packs_qkv[1], packs_p[1], float(drop_p), B, Tp, H, win, int(seeds[0]) & 0xFFFFFFFF, defer_rel)
         ctx.set_materialize_grads(False)                      # (see FFNBlock.forward)
         ctx.mark_non_differentiable(yb)
         return y, yb
@@ -409,7 +445,7 @@ class AttentionBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dyb):
         xb, qkv, rk, rv, P, att, proj, s_, stats, gamma, rowmask, wqkv, wp, seed_t = ctx.saved_tensors
-        tape, pwt_qkv, pwt_p, drop_p, B, Tp, H, win, aseed = ctx.misc
+        tape, pwt_qkv, pwt_p, drop_p, B, Tp, H, win, aseed, defer_rel = ctx.misc
         R, C = s_.shape
         D = C // H
         dev = s_.device
@@ -426,10 +462,14 @@ class AttentionBlock(torch.autograd.Function):
         nw = 2 * win + 1
         dS = torch.empty(B, H, Tp, Tp, device=dev)
         dqkv = torch.empty_like(qkv)
-        drel = torch.empty(2, nw, D, device=dev)
-        ascr = torch.empty(L.glowtts_rpr_attention_scratch_floats(B, Tp, H, D, win) + 2 * nw * D, device=dev)
+        if defer_rel:
+            ascr, drel = tape.att_slot(B, Tp, H, D, win, dev)          # (d relK | d relV): summed by the tape's flush, off this chain
+        else:
+            drel = torch.empty(2, nw, D, device=dev)
+            ascr = torch.empty(L.glowtts_rpr_attention_scratch_floats(B, Tp, H, D, win) + 2 * nw * D, device=dev)
         _lib.check(L.glowtts_rpr_attention_bwd_prec(qkv.data_ptr(), rk.data_ptr(), rv.data_ptr(), rowmask.data_ptr(), P.data_ptr(), datt.data_ptr(),
-                                                    dS.data_ptr(), dqkv.data_ptr(), drel[0].data_ptr(), drel[1].data_ptr(), ascr.data_ptr(), B, Tp, H, D, win,
+                                                    dS.data_ptr(), dqkv.data_ptr(), None if defer_rel else drel[0].data_ptr(),
+                                                    None if defer_rel else drel[1].data_ptr(), ascr.data_ptr(), B, Tp, H, D, win,
                                                     drop_p, aseed, _sp(seed_t), ops.BF16, _lib.stream()), "glowtts_rpr_attention_bwd_prec")
         dx = torch.empty(R, C, device=dev)
         _conv_launch(dqkv, pwt_qkv, 3 * C, R, 1, 0, C, None, None, dx, in0=ds, a_bf=False)            # QKV data gradient + the residual branch (ds)
@@ -437,7 +477,7 @@ class AttentionBlock(torch.autograd.Function):
         dwp, dbp = torch.empty_like(wp), torch.empty(C, device=dev)
         tape.add(dqkv, xb, 3 * C, C, 1, ops.BF16, dwq, dbq)
         tape.add(dzp, att, C, C, 1, ops.BF16, dwp, dbp)               # (bf16-stored DY x fp32-stored X: the staged weight-gradient kernel converts X in its loop)
-        return (dx, None, dwq, dbq, drel[0].view(1, nw, D), drel[1].view(1, nw, D), dwp, dbp, gb[:C], gb[C:]) + (None,) * 12
+        return (dx, None, dwq, dbq, drel[0].view(1, nw, D), drel[1].view(1, nw, D), dwp, dbp, gb[:C], gb[C:]) + (None,) * 13
 
 
 class EmbeddingRows(torch.autograd.Function):

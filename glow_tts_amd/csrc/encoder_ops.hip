@@ -1507,11 +1507,20 @@ extern "C" int glowtts_rpr_attention_fwd(const float* qkv, const float* relk, co
 
 extern "C" int64_t glowtts_rpr_attention_scratch_floats(int B, int Tp, int H, int D, int win) { return (int64_t)B * H * 8 * 2 * (2 * win + 1) * D; }
 
+extern "C" int64_t glowtts_rpr_attention_bwd_partial_rows(int B, int Tp, int H, int D, int win)
+{
+    if (attn_mfma_ok(Tp, D, win)) return (int64_t)B * H * 4;
+    if (attn_long_ok(Tp, D, win)) return (int64_t)B * H * ((Tp + 63) / 64) * 2;
+    return (int64_t)B * H;
+}
+
 extern "C" int glowtts_rpr_attention_bwd_prec(const float* qkv, const float* relk, const float* relv, const float* rowmask, const float* P, const float* dout,
                                               float* dS /* [B][H][Tp][Tp] scratch */, float* dqkv, float* drelk, float* drelv, float* scratch,
                                               int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t* seed_ptr, int precision, void* stream)
 {
-    if (!qkv || !relk || !relv || !rowmask || !P || !dout || !dS || !dqkv || !drelk || !drelv || !scratch || Tp > 256) return GLOWTTS_E_ARG;
+    // drelk == drelv == NULL (round 5): the partial rows stay in `scratch` ([glowtts_rpr_attention_bwd_partial_rows][2 nw D]) for the caller's own reduction
+    // (one glowtts_colsum_batched over all layers, off the encoder's backward chain)
+    if (!qkv || !relk || !relv || !rowmask || !P || !dout || !dS || !dqkv || (!drelk != !drelv) || !scratch || Tp > 256) return GLOWTTS_E_ARG;
     if (precision != GLOWTTS_F32 && precision != GLOWTTS_BF16) return GLOWTTS_E_ARG;
     const bool bf = precision == GLOWTTS_BF16;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1554,6 +1563,7 @@ extern "C" int glowtts_rpr_attention_bwd_prec(const float* qkv, const float* rel
         hipLaunchKernelGGL(attn_bwd_rel_kernel, dim3(nw, B * H), dim3(128), 0, st, qkv, P, dS, dout, scratch, B, Tp, H, D, win);
         prow = B * H;
     }
+    if (!drelk) { RET_LAUNCH(); }
     const bool adjacent = (drelv == drelk + (size_t)nw * D);
     float* both = adjacent ? drelk : scratch + glowtts_rpr_attention_scratch_floats(B, Tp, H, D, win);   // else the caller's scratch has 2*nw*D more floats
     hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * nw * D + 3) / 4), dim3(256), 0, st, scratch, both, prow, 2 * nw * D);

@@ -193,7 +193,7 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
 #pragma unroll
                     for (int q = 0; q < 8; ++q) mk8[q] = ldf(rmk, (uint32_t)rb * 4u, roff(mi, hb * 8 + q) * 4);
                 }
-                if (fl & GLOWTTS_F_ADD_IN0) {
+                if (fl & (GLOWTTS_F_ADD_IN0 | GLOWTTS_F_GATE_IN0)) {
                     if (in0_bf) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q)
@@ -222,6 +222,12 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni)
                             v[q][ni] *= drop_scale(seed, idn[ni] + (uint32_t)roff(mi, hb * 8 + q) * (uint32_t)p.n, p.drop_p, ikl);
+                }
+                if (fl & GLOWTTS_F_GATE_IN0) {           // in0 = the kept output of the relu / dropout layer whose backward this is
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) { v[q][ni] *= xin[q][ni] != 0.f ? ikl : 0.f; xin[q][ni] = 0.f; }
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
@@ -1580,7 +1586,7 @@ __global__ __launch_bounds__(384) void ln_qkv_kernel(const ln_qkv_args p)
 inline int try_skinny(const glowtts_conv_args& a, hipStream_t s)
 {
     if (!(GLOWTTS_TUNABLE("GLOWTTS_SKINNY", 1) && a.precision == GLOWTTS_BF16 && a.taps == 1 && a.epi == GLOWTTS_EPI_LINEAR && a.apro == GLOWTTS_APRO_NONE &&
-          !(a.io_flags & GLOWTTS_IO_IN0_BF16) && !a.a2 && a.batch <= 1 && !(a.flags & (GLOWTTS_F_COLMASK | GLOWTTS_F_DROPOUT)) &&
+          !(a.io_flags & GLOWTTS_IO_IN0_BF16) && !a.a2 && a.batch <= 1 && !(a.flags & (GLOWTTS_F_COLMASK | GLOWTTS_F_DROPOUT | GLOWTTS_F_GATE_IN0)) &&
           (a.ca % 16) == 0 && a.lda >= a.ca && (a.lda & 3) == 0 && a.kchunks * 32 >= a.ca && a.rows >= 32)) return -1;
     const int ni = (a.n + 31) / 32;
     if (ni * 32 > a.npad) return -1;
@@ -1915,6 +1921,7 @@ extern "C" int glowtts_conv_cl(const glowtts_conv_args* args, void* stream)
     if (!a.a2 && a.apro != GLOWTTS_APRO_SQNEG) a.ca1 = a.ca;
     if (a.apro == GLOWTTS_APRO_SQNEG && ((a.ca1 % (a.precision == GLOWTTS_BF16 ? 8 : 4)) || a.ca != 2 * a.ca1)) return GLOWTTS_E_ARG;
     if ((a.flags & GLOWTTS_F_COLMASK) && !a.ncols_valid) return GLOWTTS_E_ARG;
+    if ((a.flags & GLOWTTS_F_GATE_IN0) && (a.epi != GLOWTTS_EPI_LINEAR || !a.in0 || (a.flags & (GLOWTTS_F_ADD_IN0 | GLOWTTS_F_DROPOUT)) || a.drop_p < 0.f || a.drop_p >= 1.f)) return GLOWTTS_E_ARG;
     {   // loads are unconditional 16-byte vectors covering one LDS slot (E = 8 bf16 / 4 f32 channels): every row must be wide enough
         // to contain the last, possibly partial, slot:  lda >= round_up(channels read from it, E)   (lda in A elements)
         const int E = a.precision == GLOWTTS_BF16 ? 8 : 4;

@@ -125,7 +125,17 @@ __global__ __launch_bounds__(256) void multi_sqnorm_kernel(const glowtts_opt_job
     const glowtts_opt_job& j = find_job(jobs, njobs, blockIdx.x, first);
     const long end = min(first + OPT_CHUNK, (long)j.n);
     float s = 0.f;
-    for (long i = first + threadIdx.x; i < end; i += 256) { const float g = j.g[i]; s += g * g; }
+    if (end - first == OPT_CHUNK && (reinterpret_cast<uintptr_t>(j.g + first) & 15) == 0) {
+        // a full chunk on a 16-byte boundary: the four 16-byte loads of a thread issued together (the scalar loop ran at 2.7 TB/s)
+        const float4* g4 = reinterpret_cast<const float4*>(j.g + first);
+        float4 x[OPT_CHUNK / 1024];
+#pragma unroll
+        for (int k = 0; k < OPT_CHUNK / 1024; ++k) x[k] = g4[threadIdx.x + 256 * k];
+#pragma unroll
+        for (int k = 0; k < OPT_CHUNK / 1024; ++k) s += (x[k].x * x[k].x + x[k].y * x[k].y) + (x[k].z * x[k].z + x[k].w * x[k].w);
+    } else {
+        for (long i = first + threadIdx.x; i < end; i += 256) { const float g = j.g[i]; s += g * g; }
+    }
     s = wave_sum(s);
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -168,6 +178,43 @@ __global__ __launch_bounds__(256) void radam_kernel(const glowtts_opt_job* __res
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], step_size = hyper[5];
     const bool rect = hyper[6] != 0.f;
     const float gs = gscale ? gscale[0] : 1.f;
+    if (end - first == OPT_CHUNK && ((reinterpret_cast<uintptr_t>(j.g + first) | reinterpret_cast<uintptr_t>(j.p + first) |
+                                      reinterpret_cast<uintptr_t>(j.v + first) | reinterpret_cast<uintptr_t>(j.m + first)) & 15) == 0) {
+        // full, 16-byte aligned chunk: float4 accesses, every load of a pass in flight before the arithmetic (same per-element formulas as below)
+        const float4* g4 = reinterpret_cast<const float4*>(j.g + first);
+        float4* p4 = reinterpret_cast<float4*>(j.p + first);
+        float4* v4 = reinterpret_cast<float4*>(j.v + first);
+        float4* m4 = reinterpret_cast<float4*>(j.m + first);
+#pragma unroll
+        for (int h = 0; h < OPT_CHUNK / 2048; ++h) {
+            float4 G[2], Pp[2], V[2], M[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int q = threadIdx.x + 256 * (2 * h + k);
+                G[k] = g4[q]; Pp[k] = p4[q]; V[k] = v4[q]; M[k] = m4[q];
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int q = threadIdx.x + 256 * (2 * h + k);
+                float* gp = reinterpret_cast<float*>(&G[k]); float* pp = reinterpret_cast<float*>(&Pp[k]);
+                float* vp = reinterpret_cast<float*>(&V[k]); float* mp = reinterpret_cast<float*>(&M[k]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = gp[e] * gs;
+                    float p = pp[e];
+                    const float v = vp[e] * b2 + (1.f - b2) * g * g;
+                    const float m = mp[e] * b1 + (1.f - b1) * g;
+                    vp[e] = v; mp[e] = m;
+                    if (wd != 0.f) p += -wd * lr * p;
+                    if (rect) p += -step_size * lr * m / (sqrtf(v) + eps);
+                    else      p += -step_size * lr * m;
+                    pp[e] = p;
+                }
+                v4[q] = V[k]; m4[q] = M[k]; p4[q] = Pp[k];
+            }
+        }
+        return;
+    }
     for (long i = first + threadIdx.x; i < end; i += 256) {
         const float g = j.g[i] * gs;
         float p = j.p[i];

@@ -36,15 +36,10 @@ __device__ __forceinline__ unsigned short bf16_bits_prep(float v) { const __bf16
 constexpr int PREP_MAXJOBS = GLOWTTS_PREP_MAX_JOBS;
 struct prep_table { glowtts_prep_job jobs[PREP_MAXJOBS]; };
 
-__global__ __launch_bounds__(PREP_NT) void prep_kernel(const prep_table tab, int njobs)
+__device__ __forceinline__ void prep_body(const glowtts_prep_job& j, const int rel)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char prep_smem[];
     unsigned short* const tile = reinterpret_cast<unsigned short*>(prep_smem);
-    int lo = 0;
-#pragma unroll 1
-    for (int i = 1; i < njobs; ++i) lo = tab.jobs[i].block0 <= (int)blockIdx.x ? i : lo;
-    const glowtts_prep_job& j = tab.jobs[lo];
-    const int rel = blockIdx.x - j.block0;
     const int b = rel / j.tiles, tl = rel - b * j.tiles;             // conv of the batch, tile of PREP_TR packed O indices
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cols = j.I * j.taps;                                   // floats per source row
@@ -53,6 +48,30 @@ __global__ __launch_bounds__(PREP_NT) void prep_kernel(const prep_table tab, int
     // ---- 1 + 2: rows -> norm -> scaled bf16 tile (PREP_RP rows per pass: PREP_RP x nk loads in flight, unconditional - a predicated load makes hipcc
     // branch around it and wait for it before the next one is issued) ----
     const int nk = (cols + 63) >> 6;
+    if (!j.g) {
+        // a plain weight (no norm to reduce): rows straight into the tile, any row length the tile holds (the text encoder's 768-channel k = 3 conv: 2 304
+        // floats per row), four loads in flight per lane
+#pragma unroll 1
+        for (int rr = 0; rr < PREP_TR / 4; ++rr) {
+            const int r = wave * (PREP_TR / 4) + rr, oi = tl * PREP_TR + r;
+            bool ok = oi < j.o_ext;
+            int o = oi;
+            if (j.perm == GLOWTTS_PERM_PAIR) {
+                const int p = oi >> 6, hsel = (oi >> 5) & 1, jj = (p << 5) + (oi & 31);
+                ok = ok && jj < j.perm_h;
+                o = hsel * j.perm_h + jj;
+            }
+            ok = ok && o < j.O;
+            const float* vr = vb + (int64_t)(ok ? o : 0) * cols;
+            for (int c0 = 0; c0 < cols; c0 += 256) {
+                float x[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int c = c0 + lane + 64 * k; x[k] = vr[c < cols ? c : cols - 1]; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int c = c0 + lane + 64 * k; if (c < cols) tile[r * pitch + c] = ok ? bf16_bits_prep(x[k]) : (unsigned short)0; }
+            }
+        }
+    } else
 #pragma unroll 1
     for (int rr = 0; rr < PREP_TR / 4; rr += PREP_RP) {
         float x[PREP_RP][PREP_MAXPL];
@@ -146,6 +165,26 @@ __global__ __launch_bounds__(PREP_NT) void prep_kernel(const prep_table tab, int
     }
 }
 
+__global__ __launch_bounds__(PREP_NT) void prep_kernel(const prep_table tab, int njobs)
+{
+    int lo = 0;
+#pragma unroll 1
+    for (int i = 1; i < njobs; ++i) lo = tab.jobs[i].block0 <= (int)blockIdx.x ? i : lo;
+    const glowtts_prep_job& j = tab.jobs[lo];
+    prep_body(j, blockIdx.x - j.block0);
+}
+
+// the same with the job table in device memory (a table that does not change between steps - the text encoder's ~60 images: built and uploaded once)
+__global__ __launch_bounds__(PREP_NT) void prep_dev_kernel(const glowtts_prep_job* __restrict__ jobs, int njobs)
+{
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const glowtts_prep_job j = jobs[lo];
+    prep_body(j, blockIdx.x - j.block0);
+}
+
+constexpr int PREP_MAX_COLS = 4096;              // plain-weight rows: a 16-row bf16 tile of 128 KiB
+
 inline int prep_pad_to(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
@@ -154,7 +193,7 @@ extern "C" int glowtts_prep_job_init(glowtts_prep_job* job, const float* v, cons
                                      int transpose, int perm, int perm_h, void* packed, int64_t outer_stride, int64_t inner_stride, int64_t w_stride,
                                      int64_t g_stride, int block0, int* blocks_out)
 {
-    if (!job || batch < 1 || inner < 1 || O < 1 || I < 1 || taps < 1 || taps > 5 || I * taps > 64 * PREP_MAXPL) return GLOWTTS_E_ARG;
+    if (!job || batch < 1 || inner < 1 || O < 1 || I < 1 || taps < 1 || taps > 5 || I * taps > (g ? 64 * PREP_MAXPL : PREP_MAX_COLS)) return GLOWTTS_E_ARG;
     if (perm == GLOWTTS_PERM_PAIR && (perm_h < 1 || 2 * perm_h != O)) return GLOWTTS_E_ARG;
     if ((outer_stride & 15) || (inner_stride & 15) || w_stride < 0 || g_stride < 0) return GLOWTTS_E_ARG;
     const int o_ext = (perm == GLOWTTS_PERM_PAIR) ? prep_pad_to(perm_h, 32) * 2 : O;
@@ -173,16 +212,30 @@ extern "C" int glowtts_prep_job_init(glowtts_prep_job* job, const float* v, cons
     return GLOWTTS_OK;
 }
 
+extern "C" int glowtts_prep_launch_dev(const glowtts_prep_job* dev_jobs, int njobs, int total_blocks, int max_cols, void* stream)
+{
+    if (!dev_jobs || njobs < 1 || total_blocks < 1 || max_cols < 1 || max_cols > PREP_MAX_COLS) return GLOWTTS_E_ARG;
+    const int lds = PREP_TR * (max_cols + 2) * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_dev_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PREP_TR * (PREP_MAX_COLS + 2) * 2) != hipSuccess) return GLOWTTS_E_LAUNCH;
+        attr_done = true;
+    }
+    GLOWTTS_NOTE_STATIC("prep_weights_dev");
+    hipLaunchKernelGGL(prep_dev_kernel, dim3(total_blocks), dim3(PREP_NT), lds, static_cast<hipStream_t>(stream), dev_jobs, njobs);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
 extern "C" int glowtts_prep_launch(const glowtts_prep_job* host_jobs, int njobs, int total_blocks, int max_cols, void* stream)
 {
-    if (!host_jobs || njobs < 1 || njobs > PREP_MAXJOBS || total_blocks < 1 || max_cols < 1 || max_cols > 64 * PREP_MAXPL) return GLOWTTS_E_ARG;
+    if (!host_jobs || njobs < 1 || njobs > PREP_MAXJOBS || total_blocks < 1 || max_cols < 1 || max_cols > PREP_MAX_COLS) return GLOWTTS_E_ARG;
     prep_table tab;
     memset(&tab, 0, sizeof(tab));
     memcpy(tab.jobs, host_jobs, (size_t)njobs * sizeof(glowtts_prep_job));
     const int lds = PREP_TR * (max_cols + 2) * 2;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PREP_TR * (64 * PREP_MAXPL + 2) * 2) != hipSuccess) return GLOWTTS_E_LAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PREP_TR * (PREP_MAX_COLS + 2) * 2) != hipSuccess) return GLOWTTS_E_LAUNCH;
         attr_done = true;
     }
     GLOWTTS_NOTE_STATIC("prep_weights");

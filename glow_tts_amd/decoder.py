@@ -174,7 +174,7 @@ TAIL = {"defer": False, "pending": []}
 #       memory system at the head of the step and the decoder's forward ends 45 us later: 5.24-5.30 against 5.20-5.23 ms/step (three alternating pairs)
 #   prep_fused: training on the fused bf16 path forms w = g v / ||v|| and every weight image in ONE launch (csrc/prep_ops.hip) instead of 4 weight-norm +
 #       ~22 packing launches (0.42 -> ~0.1 ms at the head of the step, round 4)
-TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0, "dec_chunks": 1, "cond_hip": True}
+TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0, "dec_chunks": 1, "cond_hip": True, "fwd_tail_aside": False}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
@@ -482,7 +482,9 @@ class _Prepared:
             # 6 / 7 / 8 / 9 / 10 / 12 fused flows measure 5.61 / 5.54-5.59 / 5.54-5.61 / 5.59-5.73 / 5.88 / 6.08 ms/step against 5.58-5.66 for 5.)
             nwg = -(-rows // (64 - 4 * (Lw - 1))) if rows else None
             cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
-            nfb = F_ if (nwg is not None and 4 * nwg <= 3 * cus) else max(1, (7 * F_) // 12)
+            # (round 5: 8 of 12 - the encoder's backward chain lost its gate passes, the relative-position sums and ~100 us of weight packing at its head:
+            # 5.02 vs 5.07 ms/step for 7, three alternating pairs on one box; 9: 5.23)
+            nfb = F_ if (nwg is not None and 4 * nwg <= 3 * cus) else max(1, (2 * F_) // 3)
         else:
             nfb = min(int(nfb), F_)                             # flows 0 .. nfb-1 take the fused kernel
         f0 = min(max(int(TUNE["fused_wn_bwd_from"]), 0), F_ - nfb)               # (experiments: the fused flows are f0 .. f0 + nfb - 1)
@@ -731,12 +733,25 @@ def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
                        "glowtts_flow_forward")
     _run_chunks(chunks, chain, mels.device)
     stamp("dec_fwd_end")
+    # z in the reference's [B, C, T] layout and the log-determinants are read by the losses only - the log-prior / MAS side of the step reads the rows
+    # tensor: with a side stream given (AUX["stream"], the text encoder's, which the caller joins before it returns) the two passes (14 + 35 us) leave
+    # the chain  decoder forward -> log-prior -> MAS -> losses -> decoder backward.  MEASURED AND OFF (TUNE["fwd_tail_aside"]): 5.07 against 5.01 ms/step, three
+    # alternating pairs - the extra cross-stream edges cost the replayed graph more (dec_fwd_end -> dec_bwd_begin 330 us against 219) than the two passes take
+    main, aux = torch.cuda.current_stream(mels.device), AUX["stream"]
+    if aux is not None and TUNE["fwd_tail_aside"]:
+        aux.wait_stream(main)
+        torch.cuda.set_stream(aux)
+    an_logs = prep.keep["an_logs"].contiguous()
     z = unsqueeze_rows(cfg, buf.x[cfg.F], lengths, B, Tm)
     part = torch.empty(cfg.F * B, device=mels.device)
     logdet = torch.empty(B, device=mels.device)
-    _lib.check(L.glowtts_decoder_logdet(_lib.ptr(buf.outs), R * prep.ldo, _lib.ptr(prep.keep["an_logs"].contiguous()), _lib.ptr(prep.winfo),
+    _lib.check(L.glowtts_decoder_logdet(_lib.ptr(buf.outs), R * prep.ldo, _lib.ptr(an_logs), _lib.ptr(prep.winfo),
                                         _lib.ptr(rowmask), _lib.ptr(part), _lib.ptr(logdet), cfg.F, B, T + 2 * ROW_PAD, cfg.C, prep.ldo,
                                         _lib.stream()), "glowtts_decoder_logdet")
+    if aux is not None and TUNE["fwd_tail_aside"]:
+        torch.cuda.set_stream(main)
+        for t_ in (z, logdet, part, an_logs):
+            t_.record_stream(main)
     if pitch is not None:
         prep.set_cond(prep.cond)            # the backward addresses the conditioning gradient per utterance
     return z, logdet, buf, rowmask, T, prow
@@ -830,6 +845,8 @@ def actnorm_data_init(cfg, W, mels, lengths, cond=None, allreduce=None, pitch=No
 # replayed hipGraph the decoder's branch otherwise starts ~180 us after the encoder's (measured with in-graph stamps: the runtime reaches the nodes of
 # the second branch late), and the 80-us preparation launch sat behind that.  `early_prepare` builds the _Prepared; DecoderFunction.forward picks it up.
 EARLY = {"prep": None, "key": None}
+# A stream the caller joins with its own before it consumes z / the log-determinants (modules.GlowTTS.forward: the text encoder's stream), or None
+AUX = {"stream": None}
 
 
 def _split_gv(weights):

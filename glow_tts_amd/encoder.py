@@ -100,6 +100,7 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
             Pc[a + ".QKV.weight"] = torch.cat([P[n + ".weight"] for n in names], 0)
             Pc[a + ".QKV.bias"] = torch.cat([P[n + ".bias"] for n in names], 0)
     tape = None
+    rel_gated = False
     if torch.is_grad_enabled():
         fused = (".Query.weight", ".Key.weight", ".Value.weight")                # consumed through the fused QKV tensor only
         gated = [k for k, v in Pc.items() if k.startswith(prefix) and k.endswith(".weight") and v.dim() == 3 and v.requires_grad
@@ -112,6 +113,10 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
                 for j in (0, 1):
                     q = f"{prefix}.layer_Dict.Transformer.layer_Dict.ANCRDCN_{i}.layer_Dict.LayerNorm_{j}"
                     gated += [q + ".weight", q + ".bias"]
+                # ... and the attention cores' relative-position embeddings (their gradients are summed by the tape's flush too)
+                a_ = f"{prefix}.layer_Dict.Transformer.layer_Dict.ANCRDCN_{i}.layer_Dict.Attention"
+                gated += [a_ + ".weight_K", a_ + ".weight_V"]
+            rel_gated = True
         if gated:
             tape = WgradTape()
             for k, v in zip(gated, ParamGate.apply(tape, *[Pc[k] for k in gated])):
@@ -182,10 +187,10 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
         if blocks:
             # bf16-stored rows, training: two autograd nodes per layer whose backward chains are hand-ordered (conv_fn.AttentionBlock / FFNBlock)
             pdr = float(dr) if training else 0.0
-            x = _with_bf16(*AttentionBlock.apply(x, bf16_of(x), Pc[a + ".QKV.weight"], Pc[a + ".QKV.bias"], P[a + ".weight_K"], P[a + ".weight_V"],
+            x = _with_bf16(*AttentionBlock.apply(x, bf16_of(x), Pc[a + ".QKV.weight"], Pc[a + ".QKV.bias"], Pc[a + ".weight_K"], Pc[a + ".weight_V"],
                                                  Pc[a + ".layer_Dict.Projection.weight"], Pc[a + ".layer_Dict.Projection.bias"],
                                                  Pc[q + ".LayerNorm_0.weight"], Pc[q + ".LayerNorm_0.bias"], rmf, B, Tp, H, win, pdr, (nseed(), nseed()), seed_t,
-                                                 tape, packset.get(a + ".QKV"), packset.get(a + ".layer_Dict.Projection"), qkv_pre))
+                                                 tape, packset.get(a + ".QKV"), packset.get(a + ".layer_Dict.Projection"), qkv_pre, rel_gated))
             # the block's closing LayerNorm also computes the NEXT block's fused Q / K / V conv (one launch less on the forward chain per block)
             nxt = None
             if i + 1 < e.Transformer.Stacks and TUNE["enc_ln_qkv"]:

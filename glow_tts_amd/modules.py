@@ -349,8 +349,12 @@ class GlowTTS(torch.nn.Module):
         self._maybe_init_actnorm(P, mels, mel_lengths, cond, None if pitches is None else (pitches, pitch_w.detach(), pitch_b.detach()))
         # (training on the fused bf16 path: W holds the weight-norm pairs themselves - every weight image was prepared by one launch above)
         drop_p = float(hp.Decoder.Affine_Coupling.WaveNet.Dropout_Rate) if self.training else 0.0      # Modules.py:854-862
-        z, log_dets, z_rows = decoder.DecoderFunction.apply(self.dec_cfg, mels, mel_lengths, cond, drop_p, pitches, pitch_w if pitches is not None else None,
-                                                            pitch_b if pitches is not None else None, *W)
+        decoder.AUX["stream"] = side if side is not main else None          # (z / log-determinant passes: off the chain to the log-prior, joined below)
+        try:
+            z, log_dets, z_rows = decoder.DecoderFunction.apply(self.dec_cfg, mels, mel_lengths, cond, drop_p, pitches, pitch_w if pitches is not None else None,
+                                                                pitch_b if pitches is not None else None, *W)
+        finally:
+            decoder.AUX["stream"] = None
         if side is not main:
             # the log-prior needs mean / log_std only: the duration predictor still runs on the encoder's stream (joined below, before the
             # losses read log_dur) - the encoder's forward is what this point of the step waits for (timeline)

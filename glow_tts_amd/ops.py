@@ -14,6 +14,7 @@ EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_DGATE = 0, 1, 2, 3, 4
 IO_A_BF16, IO_IN0_BF16, IO_OUT0_BF16 = 1, 2, 4      # glowtts_conv_args.io_flags
 WIO_DY_BF16, WIO_X_BF16, WIO_WIDE, WIO_DMA = 1, 2, 4, 8           # glowtts_wgrad_args.io_flags (DMA: grouped launches only)
 F_BIAS, F_RELU, F_ADD_IN0, F_MASK, F_ACCUM, F_FIRST, F_LAST, F_REVERSE, F_COLMASK, F_DROPOUT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+F_GATE_IN0 = 2048
 
 
 class ConvArgs(ctypes.Structure):
@@ -76,6 +77,9 @@ class PackJob(ctypes.Structure):
                 ("O", "I", "taps", "transpose", "perm", "perm_h", "N", "K", "npad", "kchunks", "block0", "reserved")]
 
 
+FAST_PACK = {"on": True}        # tests flip it to compare the two packing kernels' bytes
+
+
 class PackSet:
     """Conv weights of different shapes packed by ONE launch (glowtts_pack_weight_multi) into one buffer.
     items: [(key, fp32 weight [O, I, taps], transpose)].  The device job table is built once; `run()` re-packs the current values
@@ -111,12 +115,32 @@ class PackSet:
         self.table = torch.frombuffer(bytearray(jobs), dtype=torch.uint8).to(dev)
         self.njobs, self.blocks, self.precision = n, b0, precision
         self.sig = self.signature(items)
+        # bf16 images: the same bytes by the tile kernel of the decoder's weight preparation (csrc/prep_ops.hip: coalesced row reads, 16-byte image stores)
+        # over a device job table built here, once
+        self.prep = None
+        if precision == BF16 and FAST_PACK["on"] and all(w.shape[1] * w.shape[2] <= 4096 for _, w, _ in items):
+            from .decoder import PrepJob, _L as _dec_L
+            Ld = _dec_L()
+            Ld.glowtts_prep_launch_dev.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
+            pj = (PrepJob * n)()
+            nb, pb0 = c_int(0), 0
+            for i, (key, w, tr) in enumerate(items):
+                O, I, k = w.shape
+                _lib.check(Ld.glowtts_prep_job_init(ctypes.byref(pj[i]), w.data_ptr(), None, None, 1, 1, O, I, k, int(tr), PERM_NONE, 0,
+                                                    self.data.data_ptr() + offs[i], 0, 0, 0, 0, pb0, ctypes.byref(nb)), "glowtts_prep_job_init")
+                assert (pj[i].npad, pj[i].kchunks) == (jobs[i].npad, jobs[i].kchunks)
+                pb0 += nb.value
+            self.prep = (torch.frombuffer(bytearray(pj), dtype=torch.uint8).to(dev), pb0, max(w.shape[1] * w.shape[2] for _, w, _ in items))
 
     @staticmethod
     def signature(items):
         return tuple((k, w.data_ptr(), tuple(w.shape), bool(tr)) for k, w, tr in items)
 
     def run(self):
+        if self.prep is not None:
+            _lib.check(_lib.lib().glowtts_prep_launch_dev(self.prep[0].data_ptr(), self.njobs, self.prep[1], self.prep[2], _lib.stream()),
+                       "glowtts_prep_launch_dev")
+            return
         _lib.check(_lib.lib().glowtts_pack_weight_multi(self.table.data_ptr(), self.njobs, self.blocks, self.precision, _lib.stream()),
                    "glowtts_pack_weight_multi")
 

@@ -148,7 +148,7 @@ int glowtts_pack_weight_strided(const float *w, int batch, int inner, int O, int
  * weight-norm pair (v [batch][O][I][taps], g [batch][O]) instead of w: w = g * v / ||v|| (norm over (I, taps) per output channel, old-style
  * torch weight_norm) is formed on the fly in fp32, rounded to bf16 exactly as the two-step path rounds it, and never written.  g == NULL: v is a
  * plain weight.  inv_out (optional) [batch][O] receives 1 / ||v|| for glowtts_weightnorm_bwd.  g_stride: elements between consecutive convs'
- * g / inv_out rows (0 = O; larger when a job covers the leading [O] slice of a bigger conv).  bf16 images only.  I * taps <= 1024.
+ * g / inv_out rows (0 = O; larger when a job covers the leading [O] slice of a bigger conv).  bf16 images only.  I * taps <= 1024 (plain weights: 4096).
  * Jobs are a HOST array (fill with glowtts_prep_job_init, block0 = running sum of *blocks_out; at most GLOWTTS_PREP_MAX_JOBS per launch): the launch
  * carries the table in its argument segment, so a captured step needs no copy node for it. */
 #define GLOWTTS_PREP_MAX_JOBS 24
@@ -164,6 +164,9 @@ int glowtts_prep_job_init(glowtts_prep_job *job /* host */, const float *v, cons
                           int64_t g_stride, int block0, int *blocks_out /* host */);
 /* max_cols = the largest I * taps among the jobs (sizes the LDS tile) */
 int glowtts_prep_launch(const glowtts_prep_job *host_jobs, int njobs, int total_blocks, int max_cols, void *stream);
+/* Round 5: the same kernel over a job table in DEVICE memory, any number of jobs - for tables that do not change between steps (the text encoder's ~60
+ * images of plain conv weights: built and uploaded once; replaces glowtts_pack_weight_multi's element-wise gather, 70 -> ~15 us per step). */
+int glowtts_prep_launch_dev(const glowtts_prep_job *dev_jobs, int njobs, int total_blocks, int max_cols, void *stream);
 
 #define GLOWTTS_APRO_NONE    0
 #define GLOWTTS_APRO_PAIRMUL 1  /* a[r][c] = A[r][2c] * A[r][2c+1]   (tanh*sigmoid gates, Modules.py:885-887) */
@@ -188,6 +191,9 @@ int glowtts_prep_launch(const glowtts_prep_job *host_jobs, int njobs, int total_
 #define GLOWTTS_IO_OUT0_BF16 4
 #define GLOWTTS_F_DROPOUT 512  /* LINEAR: dropout(p = drop_p, seed) after the optional ReLU, before residual / mask */
 #define GLOWTTS_F_COLMASK 256  /* LINEAR: zero columns n >= ncols_valid[batch]  (attention mask, Modules.py:102) */
+#define GLOWTTS_F_GATE_IN0 2048 /* LINEAR (round 5): in0 is the KEPT OUTPUT of a relu / dropout layer and gates the result instead of being added:
+                                  * out = value * (in0 != 0 ? 1 / (1 - drop_p) : 0) - the backward of relu and dropout (Modules.py:566-567) in the epilogue of
+                                  * the data-gradient conv that feeds it (was a pass of its own: glowtts_gate_bwd).  Not with GLOWTTS_F_ADD_IN0 / _DROPOUT. */
 #define GLOWTTS_F_COND_ROWS 1024 /* GATE: `cond` holds one row per ACTIVATION row, [rows][ldcond] (per-frame conditioning: the GR-mode
                                   * pitch term, Modules.py:867-869, summed with the per-utterance speaker / prosody terms by the caller) */
 
@@ -589,6 +595,9 @@ int glowtts_rpr_attention_bwd(const float *qkv, const float *relk, const float *
  * bf16 MFMAs - operands rounded to bf16 in registers, fp32 accumulate, fp32 softmax - the other paths are fp32 in either mode). */
 int glowtts_rpr_attention_fwd_prec(const float *qkv, const float *relk, const float *relv, const float *rowmask, float *out, float *P,
                                    int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t *seed_ptr, int precision, void *stream);
+/* rows of per-workgroup partial sums of (d relK | d relV) [rows][2 (2 win + 1) D] that glowtts_rpr_attention_bwd* leaves at the head of `scratch`; with
+ * drelk == drelv == NULL (round 5) the call stops there and the caller sums them itself (glowtts_colsum_batched over several layers at once). */
+int64_t glowtts_rpr_attention_bwd_partial_rows(int B, int Tp, int H, int D, int win);
 int glowtts_rpr_attention_bwd_prec(const float *qkv, const float *relk, const float *relv, const float *rowmask, const float *P, const float *dout,
                                    float *dS, float *dqkv, float *drelk, float *drelv, float *scratch,
                                    int B, int Tp, int H, int D, int win, float drop_p, uint32_t seed, const uint32_t *seed_ptr, int precision, void *stream);

@@ -215,6 +215,7 @@ def test_pack_set_equals_single_packs(precision):
           "d": torch.randn(40, 20, 5, device="cuda")}
     items = [(k, w, tr) for k, w in ws.items() for tr in (False, True)]
     ps = ops.PackSet(items, precision)
+    assert (ps.prep is not None) == (precision == ops.BF16)          # bf16 images: the tile kernel over a device job table (glowtts_prep_launch_dev)
     ps.run()
     for k, w in ws.items():
         fwd, tr = ps.get(k)
