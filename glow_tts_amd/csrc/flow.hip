@@ -156,7 +156,8 @@ extern "C" int glowtts_utt_colsum(const float* x, int64_t ldx, float* out, int64
 extern "C" int glowtts_flow_forward(const glowtts_flow_dims* d, const glowtts_flow_params* p, const glowtts_flow_acts* a, void* stream)
 {
     CHECK(check_dims(d));
-    if (!p || !a || !a->xin || !a->xmid || !a->xout || !a->rowmask || !a->skip || !a->outs) return GLOWTTS_E_ARG;
+    if (!p || !a || !a->xin || !a->xmid || !a->xout || !a->rowmask || !a->outs) return GLOWTTS_E_ARG;
+    if (!a->skip && !(p->wn_img && a->skip_bf)) return GLOWTTS_E_ARG;      // (the fused launch may keep the bf16 copy of the skip sum only)
     if (d->act_bf16) for (int l = 0; l < d->L; ++l) if (!a->acts[l]) return GLOWTTS_E_ARG;
     const Ctx c = make_ctx(d, p, a, stream);
     // ActNorm + invertible 1x1                                                 Modules.py:693-694, 738-756

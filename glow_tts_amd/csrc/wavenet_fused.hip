@@ -511,7 +511,7 @@ __global__ __launch_bounds__(WN_NT) void wn_fwd_kernel(const wn_fwd_args p)
             // output = (sum of skips + b) * mask (Modules.py:880-883): fp32 rows kept for the End conv's weight gradient, bf16 tile for the End conv
             int rb = rbw;
             asm volatile("" : "+v"(rb));
-            const Rsrc rs = mk_rsrc(p.skip, keep ? (long)p.rows * (WN_H * 4) : 0);
+            const Rsrc rs = mk_rsrc(p.skip, (keep && p.skip) ? (long)p.rows * (WN_H * 4) : 0);
             const uint32_t own0 = (uint32_t)(rb - halo);
             unsigned char* const sc = XT + pi * (WN_WIN * 64) + rb * 64;
             const float* const mk = MK + rb + WN_PAD;
@@ -782,7 +782,9 @@ extern "C" int glowtts_wavenet_fwd(const glowtts_flow_dims* d, const glowtts_flo
     k.stagger = GLOWTTS_TUNABLE("GLOWTTS_WN_STAGGER", 0);
 #endif
     if (keep) {
-        if (!a->skip || !a->outs) return GLOWTTS_E_ARG;
+        // (a->skip == NULL, round 5: the fp32 skip rows are not kept - the caller's backward reads the bf16 copy skip_bf only; the epilogue's 16 stores then
+        // fall outside a zero-sized buffer range and are dropped by the bounds check, 9.9 MB per launch at B = 32)
+        if ((!a->skip && !a->skip_bf) || !a->outs) return GLOWTTS_E_ARG;
         for (int l = 0; l < d->L; ++l) {
             if (!a->hs[l] || !a->gates[l] || !a->acts[l]) return GLOWTTS_E_ARG;
             k.hs[l] = a->hs[l]; k.gates[l] = a->gates[l]; k.acts[l] = a->acts[l];

@@ -174,7 +174,7 @@ TAIL = {"defer": False, "pending": []}
 #       memory system at the head of the step and the decoder's forward ends 45 us later: 5.24-5.30 against 5.20-5.23 ms/step (three alternating pairs)
 #   prep_fused: training on the fused bf16 path forms w = g v / ||v|| and every weight image in ONE launch (csrc/prep_ops.hip) instead of 4 weight-norm +
 #       ~22 packing launches (0.42 -> ~0.1 ms at the head of the step, round 4)
-TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0, "dec_chunks": 1, "cond_hip": True, "fwd_tail_aside": False}
+TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0, "dec_chunks": 1, "cond_hip": True, "fwd_tail_aside": False, "drop_skip32": True}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
@@ -619,6 +619,10 @@ class _Buffers:
         self.outs = torch.empty(F_, R, prep.ldo, device=dev)
         # bf16 copy of x_a = xmid[:, :C/2] (written by the flow's ActNorm + 1x1 pass): X of the Start conv's weight gradient
         self.xa_bf = torch.empty(F_, R, C // 2, device=dev, dtype=torch.bfloat16) if (cfg.act_bf16 and (C // 2) % 8 == 0) else None
+        # the fp32 skip sum: scratch of the per-conv forward launches and X of the End conv's weight gradient where that reads fp32 operands.  A flow on the
+        # fused forward launch whose backward takes the bf16 copy needs neither: its launch is told not to keep it (a->skip = NULL: 768 of 8 064 kept bytes per row)
+        bf_tail = self.skipb is not None and self.xa_bf is not None
+        self.keep_skip32 = [not (bf_tail and TUNE["drop_skip32"] and bool(prep.params[f].wn_img)) for f in range(F_)]
 
     def acts(self, f, L, rowmask, row0=0):
         """row0: first row of the utterance chunk the launch serves (every kept tensor is rows-major: a chunk is a row range of each)."""
@@ -634,7 +638,7 @@ class _Buffers:
             a.skip_bf = at(self.skipb[f])
         if self.xa_bf is not None:
             a.xa_bf = at(self.xa_bf[f])
-        a.skip, a.outs, a.rowmask = at(self.skip[f]), at(self.outs[f]), rowmask.data_ptr() + 4 * row0
+        a.skip, a.outs, a.rowmask = (at(self.skip[f]) if self.keep_skip32[f] else None), at(self.outs[f]), rowmask.data_ptr() + 4 * row0
         return a
 
 
