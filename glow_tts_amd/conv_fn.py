@@ -46,6 +46,7 @@ def _L():
         L.glowtts_rpr_attention_scratch_floats.restype = c_i64
         L.glowtts_rpr_attention_bwd_prec.argtypes = [c_p] * 11 + [c_int] * 5 + [c_f, c_u32, c_p, c_int, c_p]
         L.glowtts_rpr_attention_bwd_partial_rows.argtypes = [c_int] * 5
+        L.glowtts_sum_slices.argtypes = [c_p, c_p, c_int, c_i64, c_p]
         L.glowtts_rpr_attention_bwd_partial_rows.restype = c_i64
         _decl = True
     return L
@@ -80,6 +81,26 @@ class WgradTape:
         self.jobs = []
         self.ln_count, self.ln = 0, None           # LayerNorms of the block functions: their gamma / beta partials are reduced by ONE launch
         self.att_count, self.att = 0, None         # attention cores of the block functions: their relative-position gradients likewise
+        # Row splits (round 5).  A weight gradient reduces over the rows, and the text encoder has few of them (B x (T + 4) = 3 968 at 32 x 120 tokens): a
+        # launch of the grouped kernels is ~150 tiles, each a serial walk over all rows - 50-115 us per launch, six launches at the very end of the
+        # encoder's backward, behind which the optimizer waits.  With `splits` = S > 1 every problem is issued S times over B / S utterances each (the
+        # rows just outside a split are the neighbouring utterances' zero pad rows: exact) into S partial images; one more launch sums them, in a
+        # fixed order, into the gradients - which for that purpose live in ONE arena (`out`), sized at forward time (`capacity`).
+        self.splits, self.rows_per_utt, self.capacity = 1, 0, 0
+        self.arena, self.used = None, 0
+
+    def out(self, shape, device):
+        """A gradient tensor of the taped convs: a 16-byte aligned slice of the tape's arena (or a tensor of its own when the tape keeps none)."""
+        n = 1
+        for d_ in shape:
+            n *= int(d_)
+        if self.capacity <= 0 or self.used + n > self.capacity:
+            return torch.empty(shape, device=device)
+        if self.arena is None:
+            self.arena = torch.empty(self.capacity, device=device)
+        t = self.arena[self.used:self.used + n].view(shape)
+        self.used += (n + 3) & ~3
+        return t
 
     def ln_slot(self, R, C, device):
         """-> (scratch [nfloats], gb [2C]) of the next LayerNorm backward: slices of two buffers that `flush` reduces with one
@@ -115,12 +136,26 @@ class WgradTape:
     def flush(self):
         from .decoder import WgradGroup
         groups = {}
+        S, part, base = 1, None, 0
+        if self.splits > 1 and self.arena is not None and self.rows_per_utt > 0 and self.jobs:
+            lo, hi = self.arena.data_ptr(), self.arena.data_ptr() + 4 * self.used
+            R0 = self.jobs[0][0].shape[0]
+            inside = all(lo <= dw.data_ptr() < hi and (db is None or lo <= db.data_ptr() < hi) and dz.shape[0] == R0 for dz, _, _, _, _, _, dw, db in self.jobs)
+            nutt = R0 // self.rows_per_utt
+            if inside and R0 == nutt * self.rows_per_utt and nutt % self.splits == 0:
+                S, base = self.splits, lo
+                part = torch.empty(S, self.used, device=self.arena.device)
         for dz, x, O, ca, taps, precision, dw, db in self.jobs:
             io = (ops.WIO_DY_BF16 if dz.dtype == torch.bfloat16 else 0) | (ops.WIO_X_BF16 if x.dtype == torch.bfloat16 else 0)
-            key = (dz.shape[0], taps, precision, io)
+            rows = dz.shape[0] // S
+            key = (rows, taps, precision, io)
             if key not in groups:
-                groups[key] = WgradGroup(dz.shape[0], taps, precision, io_flags=io, tag="enc")
-            groups[key].add(dz.data_ptr(), dz.shape[1], O, x.data_ptr(), x.shape[1], ca, dw.data_ptr(), _sp(db))
+                groups[key] = WgradGroup(rows, taps, precision, io_flags=io, tag="enc")
+            for s_ in range(S):
+                shift = 0 if part is None else part[s_].data_ptr() - base          # this split's image of the arena
+                groups[key].add(dz.data_ptr() + s_ * rows * dz.shape[1] * dz.element_size(), dz.shape[1], O,
+                                x.data_ptr() + s_ * rows * x.shape[1] * x.element_size(), x.shape[1], ca, dw.data_ptr() + shift,
+                                (db.data_ptr() + shift) if db is not None else None)
         # one host-to-device copy for the job tables of all groups, then the launches back to back (a copy in front of every launch was a memcpy
         # node + two dependency hops, ~13 us each, six times at the very end of the encoder's chain)
         for g in groups.values():
@@ -128,7 +163,10 @@ class WgradTape:
         WgradGroup.upload_all(list(groups.values()), self.jobs[0][0].device)
         for g in groups.values():
             g.launch_segment(0)
+        if part is not None:                                   # gradients = sum of the splits' partial images (one launch, fixed order)
+            _lib.check(_L().glowtts_sum_slices(part.data_ptr(), self.arena.data_ptr(), S, self.used, _lib.stream()), "glowtts_sum_slices")
         self.jobs = []        # (dz / x stay referenced by the launched work's stream ordering: same stream, freed after)
+        self.arena, self.used = None, 0
         if self.ln is not None:
             st = self.ln
             assert st["used"] == self.ln_count, "a LayerNorm of the block functions did not run its backward"
@@ -150,6 +188,7 @@ class ParamGate(torch.autograd.Function):
     def forward(ctx, tape, *params):
         ctx.tape = tape
         ctx.set_materialize_grads(False)      # gradients of gated tensors nobody used stay None (no zero tensors to add downstream)
+        tape.capacity = sum((p.numel() + 3) & ~3 for p in params) if tape.splits > 1 else 0
         return tuple(p.detach() for p in params)
 
     @staticmethod
@@ -238,8 +277,8 @@ class ConvRows(torch.autograd.Function):
         dw = db = None
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             if ctx.tape is not None:                           # deferred: filled by ParamGate.backward (one grouped launch)
-                dw = torch.empty(O, Ci2, k, device=x.device)
-                db = torch.empty(O, device=x.device) if has_b else None
+                dw = ctx.tape.out((O, Ci2, k), x.device)
+                db = ctx.tape.out((O,), x.device) if has_b else None
                 ctx.tape.add(dz, x, O, Ci2, k, precision, dw, db)
             else:
                 # split-K slices: few for the text encoder's short row counts; 0 = the library's own choice (about two workgroups per CU) for
@@ -309,7 +348,7 @@ def _conv_launch(a, pw, ci, R, k, flags, n, bias, rowmask, out, in0=None, drop_p
 
 
 # measured design switches of the block functions (tests flip them; never read from the environment)
-FUSE = {"proj_ln": True, "gate_in_dgrad": True, "defer_rel_sum": True}
+FUSE = {"proj_ln": True, "gate_in_dgrad": True, "defer_rel_sum": True, "wgrad_splits": 2}
 
 
 class FFNBlock(torch.autograd.Function):
@@ -384,8 +423,8 @@ class FFNBlock(torch.autograd.Function):
             _lib.check(L.glowtts_gate_bwd_io(dh.data_ptr(), h0.data_ptr(), rowmask.data_ptr(), dz0.data_ptr(), R, O0, scale, 7, _lib.stream()), "glowtts_gate_bwd_io")
         dx1 = torch.empty(R, C, device=dev)
         _conv_launch(dz0, pwt0, O0, R, k, 0, C, None, None, dx1, in0=ds)                            # Conv_0 data gradient + the residual branch (ds)
-        dw0, db0 = torch.empty_like(w0), torch.empty(O0, device=dev)
-        dw1, db1 = torch.empty_like(w1), torch.empty(C, device=dev)
+        dw0, db0 = tape.out(w0.shape, dev), tape.out((O0,), dev)
+        dw1, db1 = tape.out(w1.shape, dev), tape.out((C,), dev)
         tape.add(dz0, x1b, O0, C, k, ops.BF16, dw0, db0)
         tape.add(dz1, h0, C, O0, k, ops.BF16, dw1, db1)
         return dx1, None, dw0, db0, dw1, db1, gb[:C], gb[C:], None, None, None, None, None, None, None, None
@@ -473,8 +512,8 @@ class AttentionBlock(torch.autograd.Function):
                                                     drop_p, aseed, _sp(seed_t), ops.BF16, _lib.stream()), "glowtts_rpr_attention_bwd_prec")
         dx = torch.empty(R, C, device=dev)
         _conv_launch(dqkv, pwt_qkv, 3 * C, R, 1, 0, C, None, None, dx, in0=ds, a_bf=False)            # QKV data gradient + the residual branch (ds)
-        dwq, dbq = torch.empty_like(wqkv), torch.empty(3 * C, device=dev)
-        dwp, dbp = torch.empty_like(wp), torch.empty(C, device=dev)
+        dwq, dbq = tape.out(wqkv.shape, dev), tape.out((3 * C,), dev)
+        dwp, dbp = tape.out(wp.shape, dev), tape.out((C,), dev)
         tape.add(dqkv, xb, 3 * C, C, 1, ops.BF16, dwq, dbq)
         tape.add(dzp, att, C, C, 1, ops.BF16, dwp, dbp)               # (bf16-stored DY x fp32-stored X: the staged weight-gradient kernel converts X in its loop)
         return (dx, None, dwq, dbq, drel[0].view(1, nw, D), drel[1].view(1, nw, D), dwp, dbp, gb[:C], gb[C:]) + (None,) * 13

@@ -256,3 +256,24 @@ extern "C" int glowtts_radam_step(const glowtts_opt_job* dev_jobs, int njobs, in
 }
 
 extern "C" int glowtts_opt_chunk(void) { return OPT_CHUNK; }
+
+// out[i] = partial[0][i] + partial[1][i] + ... + partial[S - 1][i]  (fixed order; n % 4 == 0, 16-byte aligned): the row splits of the text encoder's
+// weight gradients (conv_fn.WgradTape) summed into the gradients' arena
+namespace {
+__global__ __launch_bounds__(256) void sum_slices_kernel(const float4* __restrict__ partial, float4* __restrict__ out, int S, long n4)
+{
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = partial[i];
+    for (int s = 1; s < S; ++s) { const float4 b = partial[(long)s * n4 + i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    out[i] = a;
+}
+}
+extern "C" int glowtts_sum_slices(const float* partial, float* out, int S, int64_t n, void* stream)
+{
+    if (!partial || !out || S < 1 || n < 4 || (n & 3) || ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(out)) & 15)) return GLOWTTS_E_ARG;
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(out), S, n4);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}

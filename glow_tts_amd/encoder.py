@@ -119,6 +119,9 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
             rel_gated = True
         if gated:
             tape = WgradTape()
+            from .conv_fn import FUSE
+            if precision == ops.BF16 and B % max(int(FUSE["wgrad_splits"]), 1) == 0:
+                tape.splits, tape.rows_per_utt = max(int(FUSE["wgrad_splits"]), 1), Tp
             for k, v in zip(gated, ParamGate.apply(tape, *[Pc[k] for k in gated])):
                 Pc[k] = v
 

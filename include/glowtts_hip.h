@@ -654,6 +654,9 @@ typedef struct glowtts_opt_job {
 int glowtts_opt_chunk(void);
 int glowtts_multi_grad_norm(const glowtts_opt_job *dev_jobs, int njobs, int total_blocks, float max_norm, float *partial,
                             float *norm_and_coef, void *stream);
+/* out[i] = sum over s < S of partial[s][i], i < n, in a fixed order (round 5; n % 4 == 0, both pointers 16-byte aligned): the row splits of the text
+ * encoder's weight gradients summed into the gradients (no reference counterpart: autograd of Modules.py:438-573 accumulates in one pass). */
+int glowtts_sum_slices(const float *partial, float *out, int S, int64_t n, void *stream);
 int glowtts_multi_grad_scale(const glowtts_opt_job *dev_jobs, int njobs, int total_blocks, const float *coef, void *stream);
 int glowtts_radam_step(const glowtts_opt_job *dev_jobs, int njobs, int total_blocks, const float *hyper, const float *grad_scale, void *stream);
 
