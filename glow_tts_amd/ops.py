@@ -77,7 +77,9 @@ class PackJob(ctypes.Structure):
                 ("O", "I", "taps", "transpose", "perm", "perm_h", "N", "K", "npad", "kchunks", "block0", "reserved")]
 
 
-FAST_PACK = {"on": True}        # tests flip it to compare the two packing kernels' bytes
+# Measured and OFF: the tile kernel of the decoder's weight preparation over the encoder's 60 images (glowtts_prep_launch_dev) - alone 47 us per launch against 33
+# for the element-wise gather (tools/bench_pack.py; 74 KB of LDS per workgroup for the 2 304-float rows of the 768-channel convs), in the step 100 against 70
+FAST_PACK = {"on": False}
 
 
 class PackSet:
