@@ -172,8 +172,8 @@ def fused_forward_case(B, T):
     """The fused coupling-network forward (csrc/wavenet_fused.hip: Start .. End + affine coupling of ONE flow, kept activations written),
     launched alone through the C ABI.  Algorithmic FLOPs per valid row: 2 x (80 x 192 + 4 x 192 x 384 x 5 + 3 x 192 x 384 + 192 x 192 +
     192 x 160) = 3 557 376 (the halo rows the kernel recomputes are NOT counted); algorithmic bytes per valid row: 640 read (flow input)
-    + 320 (x_b') + 4 x (384 + 768 + 384) (kept x_l, gate pairs, tanh * sigmoid, bf16) + 768 (skip) + 640 (m, logs) written, + the 3.6 MB
-    weight image once."""
+    + 320 (x_b') + 4 x (384 + 768 + 384) (kept x_l, gate pairs, tanh * sigmoid, bf16) + 384 (skip sum, bf16 - round 5: its fp32 rows are no
+    longer kept, 768 before) + 640 (m, logs) written, + the 3.6 MB weight image once."""
     import ctypes
     from glow_tts_amd import _lib, decoder as D, ops
     dev = "cuda"
@@ -205,7 +205,7 @@ def fused_forward_case(B, T):
         _lib.check(Lb.glowtts_wavenet_fwd(ctypes.byref(dims), ctypes.byref(prep.params[0]), ctypes.byref(acts), buf.xmid[0].data_ptr(),
                                           buf.x[1].data_ptr(), 0, 1, _lib.stream()), "glowtts_wavenet_fwd")
     per_row = 2.0 * (80 * H + Lw * H * 2 * H * k + (Lw - 1) * H * 2 * H + H * H + H * C)
-    return dict(run=run, flops=B * T * per_row, alg_bytes=B * T * (640 + 320 + Lw * (384 + 768 + 384) + 768 + 640) + (36 * Lw + 2) * 24576,
+    return dict(run=run, flops=B * T * per_row, alg_bytes=B * T * (640 + 320 + Lw * (384 + 768 + 384) + 384 + 640) + (36 * Lw + 2) * 24576,
                 kernel="wn_fwd_kernel<drop> (fused coupling network of one flow: Start + 4 x [In_l k=5 + gate + Res_Skip_l] + End + coupling)")
 
 
