@@ -422,6 +422,7 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
         // conditioning joins the pre-activation AFTER the dropout (Modules.py:861-866), so its gradient is the per-utterance sum of the
         // gate gradients BEFORE the keep mask is applied - which only exists here, in registers.
         float* dcnd = p.out1;
+        const bool fx = (fl & GLOWTTS_F_COND_FX) != 0;             // out1 holds 64-bit fixed-point accumulators (device_common.h fx_atomic_add)
         const int Tp = p.rows_per_utt > 0 ? p.rows_per_utt : 1;
         int dcol[NI];
 #pragma unroll
@@ -462,8 +463,13 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
                     if (dcol[ni] >= 0) {
-                        float* dst = dcnd + (long)cur_u * p.ld1 + dcol[ni];
-                        unsafeAtomicAdd(dst, sa[ni]); unsafeAtomicAdd(dst + p.n, ss[ni]);
+                        if (fx) {
+                            long long* dst = reinterpret_cast<long long*>(dcnd) + (long)cur_u * p.ld1 + dcol[ni];
+                            fx_atomic_add(dst, sa[ni]); fx_atomic_add(dst + p.n, ss[ni]);
+                        } else {
+                            float* dst = dcnd + (long)cur_u * p.ld1 + dcol[ni];
+                            unsafeAtomicAdd(dst, sa[ni]); unsafeAtomicAdd(dst + p.n, ss[ni]);
+                        }
                     }
             }
             if (need) {
@@ -561,8 +567,13 @@ __device__ __forceinline__ void conv_epilogue(const glowtts_conv_args& p, f32x16
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
                     if (dcol[ni] >= 0) {
-                        float* dst = dcnd + (long)(nutt + j) * p.ld1 + dcol[ni];
-                        unsafeAtomicAdd(dst, pa[j][ni]); unsafeAtomicAdd(dst + p.n, ps[j][ni]);
+                        if (fx) {
+                            long long* dst = reinterpret_cast<long long*>(dcnd) + (long)(nutt + j) * p.ld1 + dcol[ni];
+                            fx_atomic_add(dst, pa[j][ni]); fx_atomic_add(dst + p.n, ps[j][ni]);
+                        } else {
+                            float* dst = dcnd + (long)(nutt + j) * p.ld1 + dcol[ni];
+                            unsafeAtomicAdd(dst, pa[j][ni]); unsafeAtomicAdd(dst + p.n, ps[j][ni]);
+                        }
                     }
         }
     } else {

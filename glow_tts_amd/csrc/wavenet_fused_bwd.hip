@@ -58,14 +58,14 @@ struct wn_bwd_args {
     void* dh[WN_MAXL];                            // out: d x_l, l >= 1 bf16 [rows][H]; l = 0 fp32 [rows][H] (bf16 like the others when dh0_bf16)
     int dh0_bf16;
     float* dx; int64_t lddx;                      // in / out: [rows][lddx] fp32, channels [0, C2) += d x_a
-    float* dcond; int64_t ldcond;                 // COND: d conditioning [utterances][ldcond], layer l at + l * 2 H; ACCUMULATED (atomic adds)
+    float* dcond; int64_t ldcond;                 // COND: d conditioning [utterances][ldcond] as 64-bit FIXED-POINT accumulators (2^-40 units; the pointer's type is nominal), layer l at + l * 2 H; ACCUMULATED (integer atomic adds: order-independent)
     long long* tl;                                // tools builds (ABL & 64): per-workgroup phase stamps [grid][64]
     int stagger;                                  // experiment (tools builds): start delay of workgroup b = ((b >> 3) & 7) * stagger * 512 clocks
 };
 
 // COND: the per-utterance conditioning joins the gate pre-activation AFTER the dropout (Modules.py:861-866): its gradient is the sum over an
 // utterance's rows of (da, ds) BEFORE the keep mask, which only exists here in registers.  Every workgroup adds the sums of its OWNED rows to
-// dcond with atomic adds, one run per utterance (as the per-conv DGATE epilogue does: order-dependent in the last bits).
+// dcond with 64-bit fixed-point atomic adds, one run per utterance (as the per-conv DGATE epilogue does; integer adds: bit-reproducible).
 // ABL (tools builds only, tools/bench_wn.py): timing ablations - 1: no weight DMAs after the prologue, 2: no MFMAs, 4: no global stores (copy-outs, d x_0, d x_a),
 // 8: no gate loads, 16: no partial-sum exchange, 64: per-workgroup phase stamps (s_memtime of thread 0; results stay right).  1..16: wrong results by design.
 //
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
             // owned TILE rows [own_lo, own_hi): the conditioning gradient sums them per utterance
             const int own_lo = halo + WN_PAD, own_hi = own_lo + lim;
             const bool one_utt = COND && lim > 0 && UT[own_lo] == UT[own_lo + lim - 1];       // (wave-uniform) the rule: an utterance is hundreds of rows
-            float* const dcl = COND ? p.dcond + (long)l * (2 * WN_H) + jch0 : nullptr;
+            long long* const dcl = COND ? reinterpret_cast<long long*>(p.dcond) + (long)l * (2 * WN_H) + jch0 : nullptr;     // (fixed-point accumulators: device_common.h)
             unsigned char* const dc = DT + cf * (WN_XR * 64) + (rb + roff) * 64;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
                         else if (own) {                         // windows that straddle utterances: this lane's own runs, one pair of atomics per run
                             const int u = UT[tr];
                             if (u != cur_u) {
-                                if (cur_u >= 0) { float* dst = dcl + 16 * h + (long)cur_u * p.ldcond; unsafeAtomicAdd(dst, sa); unsafeAtomicAdd(dst + WN_H, ss); }
+                                if (cur_u >= 0) { long long* dst = dcl + 16 * h + (long)cur_u * p.ldcond; fx_atomic_add(dst, sa); fx_atomic_add(dst + WN_H, ss); }
                                 sa = ss = 0.f;
                                 cur_u = u;
                             }
@@ -412,10 +412,10 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
                     if (one_utt) {                              // the four lanes (lq) of a column hold rows 4 apart: one sum, one pair of atomics
                         sa += __shfl_xor(sa, 16, 64); ss += __shfl_xor(ss, 16, 64);
                         sa += __shfl_xor(sa, 32, 64); ss += __shfl_xor(ss, 32, 64);
-                        if (lqx == 0) { float* dst = dcl + 16 * h + (long)UT[own_lo] * p.ldcond; unsafeAtomicAdd(dst, sa); unsafeAtomicAdd(dst + WN_H, ss); }
+                        if (lqx == 0) { long long* dst = dcl + 16 * h + (long)UT[own_lo] * p.ldcond; fx_atomic_add(dst, sa); fx_atomic_add(dst + WN_H, ss); }
                     } else if (cur_u >= 0) {
-                        float* dst = dcl + 16 * h + (long)cur_u * p.ldcond;
-                        unsafeAtomicAdd(dst, sa); unsafeAtomicAdd(dst + WN_H, ss);
+                        long long* dst = dcl + 16 * h + (long)cur_u * p.ldcond;
+                        fx_atomic_add(dst, sa); fx_atomic_add(dst + WN_H, ss);
                     }
                 }
             }

@@ -978,7 +978,8 @@ class DecoderFunction(torch.autograd.Function):
         scratch = torch.empty(F_, nscr, device=dev)          # per-flow partials of the ActNorm / 1x1 parameter gradients, reduced once below
         # conditioning gradient [B, F*L*2H], accumulated by the gate-derivative epilogues; GR mode: + ns rows that collect the Pitch_l weight gradients
         npit = ctx.prow.shape[1] if ctx.prow is not None else 0
-        dcond = torch.zeros((B + npit,) + tuple(prep.cond.shape[1:]), device=dev) if prep.cond is not None else None
+        # (int64: 2^-40 fixed-point accumulators of the kernels' integer atomic adds - the sums do not depend on the order the workgroups arrive in)
+        dcond = torch.zeros((B + npit,) + tuple(prep.cond.shape[1:]), device=dev, dtype=torch.int64) if prep.cond is not None else None
         bf = cfg.act_bf16
         gk = WgradGroup(R, cfg.k, cfg.precision, io_flags=(ops.WIO_DY_BF16 | ops.WIO_X_BF16) if bf else 0)     # In_l (k taps)
         g1 = WgradGroup(R, 1, cfg.precision)                            # Start / End (1x1)
@@ -1055,7 +1056,7 @@ class DecoderFunction(torch.autograd.Function):
                     g.dh[l] = at(dh0[f], r0) if l == 0 else at(dhn[f, l - 1], r0)
                     g.dins[l] = at(dins[f, l], r0)
                 if dcond is not None:
-                    g.dcond = dcond.data_ptr() + 4 * f * Lw * 2 * H + 4 * b0 * dcond.stride(0)
+                    g.dcond = dcond.data_ptr() + 8 * f * Lw * 2 * H + 8 * b0 * dcond.stride(0)
                     if npit:
                         g.pitch_rows, g.pitch_ns = ctx.prow.data_ptr(), npit
                 acts = buf.acts(f, Lw, rowmask, r0)
@@ -1116,6 +1117,8 @@ class DecoderFunction(torch.autograd.Function):
                                                  G["an_bias"].data_ptr(), G["inv_w"].data_ptr(), F_, B, T + 2 * ROW_PAD, C, _lib.stream()),
                    "glowtts_decoder_param_grads")
         dmel = unsqueeze_rows(cfg, dx, ctx.lengths, B, Tm) if ctx.want_dmel else None
+        if dcond is not None:
+            dcond = (dcond.to(torch.float64) * 2.0 ** -40).to(torch.float32)
         dpw = dpb = None
         if ctx.prow is not None:
             # Pitch_l conv (Modules.py:846-852, 867-869): bias gradient = the conditioning gradient summed over utterances; weight gradient =

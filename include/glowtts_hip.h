@@ -194,6 +194,8 @@ int glowtts_prep_launch_dev(const glowtts_prep_job *dev_jobs, int njobs, int tot
 #define GLOWTTS_IO_OUT0_BF16 4
 #define GLOWTTS_F_DROPOUT 512  /* LINEAR: dropout(p = drop_p, seed) after the optional ReLU, before residual / mask */
 #define GLOWTTS_F_COLMASK 256  /* LINEAR: zero columns n >= ncols_valid[batch]  (attention mask, Modules.py:102) */
+#define GLOWTTS_F_COND_FX 4096  /* DGATE (round 5): out1 is an array of int64 FIXED-POINT accumulators (units of 2^-40, same shape and ld1 in elements) instead of
+                                  * floats; the per-utterance sums are added with 64-bit integer atomics - order-independent, bit-reproducible.  value = (double)acc * 2^-40 */
 #define GLOWTTS_F_GATE_IN0 2048 /* LINEAR (round 5): in0 is the KEPT OUTPUT of a relu / dropout layer and gates the result instead of being added:
                                   * out = value * (in0 != 0 ? 1 / (1 - drop_p) : 0) - the backward of relu and dropout (Modules.py:566-567) in the epilogue of
                                   * the data-gradient conv that feeds it (was a pass of its own: glowtts_gate_bwd).  Not with GLOWTTS_F_ADD_IN0 / _DROPOUT. */
@@ -439,7 +441,8 @@ typedef struct glowtts_flow_grads {       /* backward outputs; weight grads are 
     float *dw_in[GLOWTTS_MAX_WN_LAYERS], *db_in[GLOWTTS_MAX_WN_LAYERS];   /* [2H][H][k], [2H] */
     float *dw_rs[GLOWTTS_MAX_WN_LAYERS], *db_rs[GLOWTTS_MAX_WN_LAYERS];   /* [2H|H][H][1], [2H|H] */
     float *dw_end, *db_end;               /* [C][H][1], [C] */
-    float *dcond;                         /* [B][ldcond] or NULL: grad of the conditioning, ACCUMULATED (zero it first) */
+    float *dcond;                         /* [B][ldcond] or NULL: grad of the conditioning, ACCUMULATED (zero it first).  ABI 5: the ELEMENTS are int64 fixed-point
+                                           * accumulators in units of 2^-40 (the pointer type is nominal; value = (double)acc * 2^-40): integer atomics, reproducible sums */
     float *douts_bf;                      /* act_bf16 only (else NULL): [R][ldo] bf16 copy of douts, scratch (End data gradient operand) */
     /* fusion across flows (backward runs flow F-1 .. 0): */
     int coupling_done;                    /* 1: the previous call already applied THIS flow's coupling backward (dx, douts, douts_bf are ready) */

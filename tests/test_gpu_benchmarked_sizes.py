@@ -244,24 +244,17 @@ def test_full_size_conditioned_models(mode):
 
 @pytest.mark.parametrize("mode", ["Vanilla", "SE"])
 def test_run_to_run_reproducibility(mode):
-    """The same batch twice through the training step (eval mode: no dropout draw).  Vanilla: every output and every gradient bit for bit -
-    nothing on that path accumulates in an order that depends on the run.  SE: the per-utterance conditioning gradient is accumulated with
-    fp32 atomic adds from the gate-derivative epilogues (one add per utterance run of a workgroup's rows), so the
-    gradients that flow through it - the speaker conv weights / biases of the coupling networks and the embedding table - may differ in the
-    last bits between runs: bounded here at 1e-5 of the tensor's largest entry (observed <= 3e-7 on 145 of 660 tensors); everything else stays bit-identical."""
+    """The same batch twice through the training step (eval mode: no dropout draw): every output and every gradient bit for bit, in both modes - nothing
+    on the path accumulates in an order that depends on the run.  (Until round 5 the per-utterance conditioning gradient of the SE mode was accumulated
+    with fp32 atomic adds and the speaker convs' / embedding table's gradients differed in the last bits between runs; the accumulators are 64-bit fixed
+    point now - integer atomic adds commute - and the vectors' gradient is a two-stage sum: csrc/device_common.h fx_atomic_add, csrc/cond_ops.hip.)"""
     case = make_case(mode, [120, 104, 75, 31], [800, 702, 500, 210], 7)
     a, b = run_hip(case, "bf16"), run_hip(case, "bf16")
     assert torch.equal(a["z"], b["z"]) and torch.equal(a["attn"], b["attn"]) and torch.equal(a["log_dets"], b["log_dets"]) and a["mle"] == b["mle"]
-    noisy = []
     for k, ga in a["grads"].items():
-        gb = b["grads"][k]
-        if torch.equal(ga, gb):
-            continue
-        rel = (ga - gb).abs().max().item() / (ga.abs().max().item() + 1e-30)
-        noisy.append((k, rel))
-        assert mode == "SE" and ("Speaker" in k or "LUT" in k), (k, rel)
-        assert rel <= 1e-5, (k, rel)
-    print(f"{mode}: {len(a['grads']) - len(noisy)} of {len(a['grads'])} gradients bit-identical across two runs; the others: {sorted(noisy, key=lambda t: -t[1])[:3]}")
+        assert torch.equal(ga, b["grads"][k]), (k, (ga - b["grads"][k]).abs().max().item() / (ga.abs().max().item() + 1e-30))
+    if mode == "SE":
+        assert any("Speaker" in k for k in a["grads"]) and any("LUT" in k for k in a["grads"])
 
 
 @pytest.mark.late(1)
