@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ord_$TAG
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ord_$TAG -o run -- python $REPO/bench.py --steps 3 --warmup 2 --windows 0 --no-cpu-baseline --no-f32-key > /tmp/ord_$TAG.json 2> /tmp/ord_$TAG.err
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ord_$TAG -o run -- python $REPO/bench.py --steps 3 --warmup 2 --windows 0 --no-cpu-baseline --no-f32-key $ORDER_ARGS > /tmp/ord_$TAG.json 2> /tmp/ord_$TAG.err
 python - "$TAG" "$REPO" <<'PY'
 import csv, glob, sys, re
 tag, repo = sys.argv[1], sys.argv[2]
