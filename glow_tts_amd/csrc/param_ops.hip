@@ -277,3 +277,38 @@ extern "C" int glowtts_sum_slices(const float* partial, float* out, int S, int64
                        reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(out), S, n4);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
+
+// The same for a partial image that is cut into up to GLOWTTS_SUM_MAX_SEGS destination tensors (the decoder's one-tap weight gradients: several classes, some of them
+// views of the returned gradient arena): element i of [off_k, off_k + n_k) goes to dst_k[i - off_k].  The table travels in the argument segment.
+namespace {
+struct sum_seg_table { glowtts_sum_seg seg[GLOWTTS_SUM_MAX_SEGS]; };
+__global__ __launch_bounds__(256) void sum_slices_seg_kernel(const float4* __restrict__ partial, int S, long stride4, long n4, const sum_seg_table tab, int nseg)
+{
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = partial[i];
+    for (int s = 1; s < S; ++s) { const float4 b = partial[(long)s * stride4 + i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < GLOWTTS_SUM_MAX_SEGS; ++j) k = (j < nseg && tab.seg[j].off <= 4 * i) ? j : k;
+    reinterpret_cast<float4*>(tab.seg[k].dst)[(4 * i - tab.seg[k].off) >> 2] = a;
+}
+}
+extern "C" int glowtts_sum_slices_seg(const float* partial, int S, int64_t stride, const glowtts_sum_seg* segs, int nseg, void* stream)
+{
+    if (!partial || S < 1 || !segs || nseg < 1 || nseg > GLOWTTS_SUM_MAX_SEGS || (stride & 3) || (reinterpret_cast<uintptr_t>(partial) & 15)) return GLOWTTS_E_ARG;
+    sum_seg_table tab;
+    int64_t end = 0;
+    for (int k = 0; k < nseg; ++k) {                           // segments tile [0, n) in ascending order
+        if (!segs[k].dst || segs[k].off != end || segs[k].n < 4 || (segs[k].n & 3) || (reinterpret_cast<uintptr_t>(segs[k].dst) & 15)) return GLOWTTS_E_ARG;
+        tab.seg[k] = segs[k];
+        end += segs[k].n;
+    }
+    for (int k = nseg; k < GLOWTTS_SUM_MAX_SEGS; ++k) tab.seg[k] = segs[0];
+    if (end > stride) return GLOWTTS_E_ARG;
+    const long n4 = end / 4;
+    hipLaunchKernelGGL(sum_slices_seg_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(partial), S, (long)(stride / 4), n4, tab, nseg);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+

@@ -91,11 +91,17 @@ def _L():
         L.glowtts_prep_launch.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
         L.glowtts_wavenet_prep_jobs.argtypes = [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)] + [c_void_p] * 13 + [c_int] * 3 + [c_void_p, c_int, c_void_p]
         L.glowtts_cond_linear_fwd.argtypes = [c_void_p] * 6 + [c_int] * 4 + [c_void_p]
+        L.glowtts_sum_slices_seg.argtypes = [c_void_p, c_int, c_i64, c_void_p, c_int, c_void_p]
         L.glowtts_cond_linear_bwd.argtypes = [c_void_p, c_i64] + [c_void_p] * 9 + [c_int] * 3 + [c_void_p]
         L.glowtts_cond_linear_bwd_scratch_floats.argtypes = [c_int] * 3
         L.glowtts_cond_linear_bwd_scratch_floats.restype = c_i64
         _declared = True
     return L
+
+
+class SumSeg(ctypes.Structure):
+    """Mirror of `glowtts_sum_seg`."""
+    _fields_ = [("dst", c_void_p), ("off", c_i64), ("n", c_i64)]
 
 
 class WgradJob(ctypes.Structure):
@@ -174,7 +180,7 @@ TAIL = {"defer": False, "pending": []}
 #       memory system at the head of the step and the decoder's forward ends 45 us later: 5.24-5.30 against 5.20-5.23 ms/step (three alternating pairs)
 #   prep_fused: training on the fused bf16 path forms w = g v / ||v|| and every weight image in ONE launch (csrc/prep_ops.hip) instead of 4 weight-norm +
 #       ~22 packing launches (0.42 -> ~0.1 ms at the head of the step, round 4)
-TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0, "dec_chunks": 1, "cond_hip": True, "fwd_tail_aside": False, "drop_skip32": True}
+TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0, "dec_chunks": 1, "cond_hip": True, "fwd_tail_aside": False, "drop_skip32": True, "wgrad_tail_splits": 2}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
@@ -227,14 +233,14 @@ class WgradGroup:
     """Weight-gradient problems sharing (rows, taps, X prologue).  Problems are added in *segments* (one per flow); the whole
     job table is uploaded once and every segment is one glowtts_wgrad_grouped launch (tile indices restart per segment)."""
 
-    def __init__(self, rows, taps, precision, xpro=ops.APRO_NONE, io_flags=0, tag="dec"):
+    def __init__(self, rows, taps, precision, xpro=ops.APRO_NONE, io_flags=0, tag="dec", dma_k1=None):
         self.rows, self.taps, self.precision, self.xpro, self.io_flags, self.tag = rows, taps, precision, xpro, io_flags, tag
         self.jobs, self.segments, self._tiles, self._start = [], [], 0, 0
         self.table = None
         # 16-byte staging items (glowtts_wgrad WIO_WIDE): both operands bf16, no prologue, and every job 8-channel / 16-byte aligned
         self._wide = io_flags in (0, ops.WIO_DY_BF16 | ops.WIO_X_BF16) and xpro == ops.APRO_NONE and precision == ops.BF16 and TUNE["wgrad_wide"]
         # the LDS-DMA / 16x16x32 kernel (csrc/wgrad_cl.hip wgrad_dma_kernel): both operands bf16 rows
-        self._dma = self._wide and io_flags == (ops.WIO_DY_BF16 | ops.WIO_X_BF16) and bool(TUNE["wgrad_dma"]) and (taps > 1 or bool(TUNE["wgrad_dma_k1"]))
+        self._dma = self._wide and io_flags == (ops.WIO_DY_BF16 | ops.WIO_X_BF16) and bool(TUNE["wgrad_dma"]) and (taps > 1 or bool(TUNE["wgrad_dma_k1"] if dma_k1 is None else dma_k1))
 
     def add(self, dy, lddy, m, x, ldx, ca, dw, dbias, perm=ops.PERM_NONE, perm_h=0):
         j = WgradJob()
@@ -984,7 +990,36 @@ class DecoderFunction(torch.autograd.Function):
         gk = WgradGroup(R, cfg.k, cfg.precision, io_flags=(ops.WIO_DY_BF16 | ops.WIO_X_BF16) if bf else 0)     # In_l (k taps)
         g1 = WgradGroup(R, 1, cfg.precision)                            # Start / End (1x1)
         # Res_Skip_l (1x1 on tanh*sigmoid): the stored bf16 product, or the fp32 (tanh, sigmoid) pairs through the PAIRMUL prologue
-        gp = WgradGroup(R, 1, cfg.precision, ops.APRO_NONE if bf else ops.APRO_PAIRMUL, io_flags=(ops.WIO_DY_BF16 | ops.WIO_X_BF16) if bf else 0)
+        # Row splits of the one-tap group (round 5, TUNE["wgrad_tail_splits"] = S): its 108 problems move 1.07 GB of unique operands and are bound by how many
+        # bytes a workgroup keeps in flight; S x the workgroups over B / S utterances each (one tap: no halo, any row cut is exact) into S partial images,
+        # summed in a fixed order into the gradient tensors by ONE launch (glowtts_sum_slices_seg)
+        S_t = int(TUNE["wgrad_tail_splits"])
+        tail_seg = None
+        if S_t > 1 and h0bf and B % S_t == 0 and int(TUNE["wgrad_split"]) == 1:
+            names = ["w_end", "b_end", "w_rs_last", "b_rs_last", "w_start", "b_start"] + (["w_rs", "b_rs"] if Lw > 1 else [])
+            if all(G[k].is_contiguous() and G[k].numel() % 4 == 0 and G[k].data_ptr() % 16 == 0 for k in names):
+                tot, tail_seg = 0, []
+                for k in names:
+                    tail_seg.append((G[k].data_ptr(), G[k].numel(), tot))
+                    tot += G[k].numel()
+                tail_part = torch.empty(S_t, tot, device=dev)
+        R_t = R // S_t if tail_seg is not None else R
+        # (in row splits the group takes the LDS-DMA kernel's 192 x 192 one-tap tiles: 108 x S workgroups that read every operand byte once - 4.84 against 4.96
+        # ms/step for S = 2, two alternating runs on one box; unsplit that kernel is 108 workgroups on 256 CUs and loses to the staged one: 4.99)
+        gp = WgradGroup(R_t, 1, cfg.precision, ops.APRO_NONE if bf else ops.APRO_PAIRMUL, io_flags=(ops.WIO_DY_BF16 | ops.WIO_X_BF16) if bf else 0,
+                        dma_k1=True if tail_seg is not None else None)
+        if tail_seg is not None:
+            _gp_add = gp.add
+
+            def _split_add(dy, lddy, m, x, ldx, ca, dw, dbias, **kw):          # (bf16 operands: 2 bytes per element)
+                def image(ptr, s_):
+                    for p0, n, off in tail_seg:
+                        if p0 <= ptr < p0 + 4 * n:
+                            return tail_part.data_ptr() + 4 * (s_ * tail_part.shape[1] + off) + (ptr - p0)
+                    raise AssertionError("one-tap weight gradient outside the split's segments")
+                for s_ in range(S_t):
+                    _gp_add(dy + 2 * s_ * R_t * lddy, lddy, m, x + 2 * s_ * R_t * ldx, ldx, ca, image(dw, s_), image(dbias, s_), **kw)
+            gp.add = _split_add
         C2 = C // 2
         order = list(range(F_ - 1, -1, -1))
         for f in order:       # weight-gradient problems of every flow (autograd of Modules.py:791,861,871,793): all pointers are known up front
@@ -1024,6 +1059,11 @@ class DecoderFunction(torch.autograd.Function):
             grp.end_segment()
         WgradGroup.upload_all((gk, g1, gp), dev)
         halves = len(gk.segments)
+
+        def sum_tail():
+            if tail_seg is not None:                       # the one-tap group's partial images -> the gradient tensors
+                segs = (SumSeg * len(tail_seg))(*[SumSeg(p0, off, n) for p0, n, off in tail_seg])
+                _lib.check(L.glowtts_sum_slices_seg(tail_part.data_ptr(), S_t, tail_part.shape[1], segs, len(tail_seg), _lib.stream()), "glowtts_sum_slices_seg")
         main = torch.cuda.current_stream()
         side = _wgrad_stream(dev)
         stamp("dec_bwd_begin")
@@ -1085,10 +1125,11 @@ class DecoderFunction(torch.autograd.Function):
             # the queued launches read the kept activations and this backward's gradient buffers through raw pointers: the closure
             # keeps them alive (also across replays when the flush is captured as its own hipGraph)
             keep = (buf, dins, dskip, dh0, dhn, douts, G)
-            TAIL["pending"].append(lambda keep=keep: (gp.launch_segment(0), g1.launch_segment(0)))
+            TAIL["pending"].append(lambda keep=keep: (gp.launch_segment(0), g1.launch_segment(0), sum_tail()))
         else:
             for grp in (gk, gp, g1):
                 grp.launch_segment(0)
+            sum_tail()
         # weight-norm backward of the (g, v) form (Modules.py:766, 818, 825): d g, d v from d w; the classes whose d w comes from the deferrable
         # 1x1 groups are queued behind them
         GVgrad = {}

@@ -663,6 +663,11 @@ int glowtts_multi_grad_norm(const glowtts_opt_job *dev_jobs, int njobs, int tota
 /* out[i] = sum over s < S of partial[s][i], i < n, in a fixed order (round 5; n % 4 == 0, both pointers 16-byte aligned): the row splits of the text
  * encoder's weight gradients summed into the gradients (no reference counterpart: autograd of Modules.py:438-573 accumulates in one pass). */
 int glowtts_sum_slices(const float *partial, float *out, int S, int64_t n, void *stream);
+/* ... into up to GLOWTTS_SUM_MAX_SEGS destination tensors: partial [S][stride]; segment k = elements [off, off + n) of a slice -> dst[0 .. n); the segments tile
+ * [0, sum n) in ascending order, every n a multiple of 4, every dst 16-byte aligned (the decoder's one-tap weight gradients in row splits). */
+#define GLOWTTS_SUM_MAX_SEGS 12
+typedef struct glowtts_sum_seg { float *dst; int64_t off, n; } glowtts_sum_seg;
+int glowtts_sum_slices_seg(const float *partial, int S, int64_t stride, const glowtts_sum_seg *segs /* host */, int nseg, void *stream);
 int glowtts_multi_grad_scale(const glowtts_opt_job *dev_jobs, int njobs, int total_blocks, const float *coef, void *stream);
 int glowtts_radam_step(const glowtts_opt_job *dev_jobs, int njobs, int total_blocks, const float *hyper, const float *grad_scale, void *stream);
 
