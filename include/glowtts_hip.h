@@ -23,8 +23,8 @@ extern "C" {
 #define GLOWTTS_ABI_VERSION    5
 
 /* Library / device identification.  Returns the ABI version (currently 5: additions only - glowtts_cond_linear_fwd / _bwd, glowtts_prep_launch_dev,
- * glowtts_rpr_attention_bwd_partial_rows (and NULL drelk / drelv), glowtts_sum_slices, GLOWTTS_F_GATE_IN0, glowtts_flow_acts.skip may be NULL on the fused
- * forward launch; 4: glowtts_flow_acts grew next_* / actnorm_done - the next flow's ActNorm + 1x1 conv in the
+ * glowtts_rpr_attention_bwd_partial_rows (and NULL drelk / drelv), glowtts_sum_slices / _seg, GLOWTTS_F_GATE_IN0, GLOWTTS_F_COND_FX, glowtts_flow_acts.skip may be NULL on
+ * the fused forward launch, glowtts_flow_grads.dcond holds 64-bit fixed-point accumulators; 4: glowtts_flow_acts grew next_* / actnorm_done - the next flow's ActNorm + 1x1 conv in the
  * fused coupling launch's epilogue - and glowtts_proj_layernorm / glowtts_layernorm_qkv were added; 3: glowtts_prep_job / glowtts_prep_launch / glowtts_wavenet_prep_jobs,
  * glowtts_actnorm_inv1x1_pass_bf, glowtts_flow_acts.xa_bf, glowtts_flow_grads.dh0_bf16, GLOWTTS_WIO_DMA; 2: glowtts_flow_params grew wn_img / wn_img_t; round 2's additions to
  * glowtts_mle_loss_bwd, glowtts_flow_params.cond_rows and glowtts_flow_grads.pitch_rows belong to version 2 as well). */
