@@ -28,3 +28,7 @@ if os.environ.get("PMC_PROBE"):                      # calibration of the MFMA-b
         _lib.check(L.glowtts_mfma_clock_probe(out.data_ptr(), ncu, 20000, None, _lib.stream()), "probe")
 torch.cuda.synchronize()
 print("ran", list(cases), "x", iters)
+if os.environ.get("PMC_WN_BWD"):                    # + one flow's fused data-gradient launch (wn_bwd_kernel) at the same shape: tools/bench_wn.py's set-up
+    import runpy
+    os.environ.setdefault("ITERS", "6")
+    runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_wn.py"), run_name="__main__")

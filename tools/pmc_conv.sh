@@ -10,7 +10,7 @@ case "$OUT" in /*) ;; *) OUT="$PWD/$OUT";; esac
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  ITERS=6 timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o run -- python $REPO/tools/pmc_conv.py > /tmp/pmc_$c.log 2>&1 || { echo "rocprofv3 $c failed"; tail -5 /tmp/pmc_$c.log; }
+  PMC_WN_BWD=1 ITERS=6 timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o run -- python $REPO/tools/pmc_conv.py > /tmp/pmc_$c.log 2>&1 || { echo "rocprofv3 $c failed"; tail -5 /tmp/pmc_$c.log; }
 done
 python - "$OUT" <<'PY'
 import collections, csv, glob, json, sys
@@ -40,9 +40,9 @@ out = {"shape": [32, 400], "precision": "bf16", "units": "bytes per launch",
                  "requests tallied at 64 B, MI355X_MICROARCH.md); WRITE_SIZE x 1024 x the factor that makes a 1 GiB fill read 1 GiB",
        "calibration": {"fill_1GiB_WRITE_SIZE_KiB": fill_w, "write_factor": wcal, "mul_1GiB_FETCH_SIZE_KiB": mul_r,
                        "mul_fetch_bytes_after_x2_over_1GiB": (mul_r * 2048 / GiB) if mul_r else None, "mul_1GiB_WRITE_SIZE_KiB": mul_w}}
-for name, subs in (("in_fwd", ("conv_dma_kernel", "Li1ELi5E")), ("in_dgrad", ("conv_dma_kernel", "Li0ELi5E")), ("wn_fwd", ("wn_fwd_kernel",))):
+for name, subs in (("in_fwd", ("conv_dma_kernel", "Li1ELi5E")), ("in_dgrad", ("conv_dma_kernel", "Li0ELi5E")), ("wn_fwd", ("wn_fwd_kernel",)), ("wn_bwd", ("wn_bwd_kernel",))):
     f, w = pick(fetch, *subs), pick(write, *subs)
-    if f is None and name != "wn_fwd":      # demangled names
+    if f is None and not name.startswith("wn_"):      # demangled names
         subs2 = ("conv_dma_kernel<1, 5", ) if name == "in_fwd" else ("conv_dma_kernel<0, 5", )
         f, w = pick(fetch, *subs2), pick(write, *subs2)
     if f is not None and w is not None:

@@ -8,7 +8,7 @@ OUT=${1:-$REPO/gpurun_out/conv_mfma_pmc.json}
 case "$OUT" in /*) ;; *) OUT="$PWD/$OUT";; esac
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_mfma
-PMC_PROBE=1 ITERS=6 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -o run -- python $REPO/tools/pmc_conv.py > /tmp/pmc_mfma.log 2>&1 || { echo "rocprofv3 failed"; tail -5 /tmp/pmc_mfma.log; }
+PMC_PROBE=1 PMC_WN_BWD=1 ITERS=6 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -o run -- python $REPO/tools/pmc_conv.py > /tmp/pmc_mfma.log 2>&1 || { echo "rocprofv3 failed"; tail -5 /tmp/pmc_mfma.log; }
 python - "$OUT" <<'PY'
 import collections, csv, glob, json, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -25,7 +25,7 @@ probe = ratio("mfma_clock_probe")
 out = {"method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (tools/pmc_mfma.sh), mean of the last 4 launches; utilisation relative to "
                  "glowtts_mfma_clock_probe (back-to-back bf16 MFMAs, one wave per SIMD on every CU = 100 %) measured in the same pass",
        "probe": {"mfma_busy_cycles": probe[0], "gui_active": probe[1]} if probe else None}
-for name, sub in (("in_fwd", "conv_dma_kernel<1, 5"), ("in_dgrad", "conv_dma_kernel<0, 5"), ("wn_fwd", "wn_fwd_kernel")):
+for name, sub in (("in_fwd", "conv_dma_kernel<1, 5"), ("in_dgrad", "conv_dma_kernel<0, 5"), ("wn_fwd", "wn_fwd_kernel"), ("wn_bwd", "wn_bwd_kernel")):
     r = ratio(sub) or ratio(sub.replace("<1, 5", "ILi1ELi5E").replace("<0, 5", "ILi0ELi5E"))
     if r and probe:
         out[name] = {"mfma_busy_cycles": r[0], "gui_active": r[1], "mfma_util": (r[0] / r[1]) / (probe[0] / probe[1])}
