@@ -652,6 +652,27 @@ extern "C" int glowtts_gate_bwd(const float* dy, const float* out, const float* 
     return glowtts_gate_bwd_io(dy, out, rowmask, dz, rows, C, scale, 0, stream);
 }
 
+// token masks of a batch in one launch (Modules.py:206-211 Mask_Generate + the rows layout's padded row mask): mask [B][T] = t < len_b,
+// rowmask [B][T + 2 PAD] = the same with GLOWTTS_ROW_PAD zero rows on either side (was arange, compare, cast, pad = 5 launches at the head of the encoder's chain)
+__global__ __launch_bounds__(256) void token_masks_kernel(const int64_t* __restrict__ len, float* __restrict__ mask, float* __restrict__ rowmask, int B, int T)
+{
+    const int Tp = T + 2 * GLOWTTS_ROW_PAD;
+    const long total = (long)B * Tp;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / Tp), t = (int)(i - (long)b * Tp) - GLOWTTS_ROW_PAD;
+        const float v = (t >= 0 && t < T && t < len[b]) ? 1.f : 0.f;
+        rowmask[i] = v;
+        if (t >= 0 && t < T) mask[(long)b * T + t] = v;
+    }
+}
+extern "C" int glowtts_token_masks(const int64_t* lengths, float* mask, float* rowmask, int B, int T, void* stream)
+{
+    if (!lengths || !mask || !rowmask || B < 1 || T < 1) return GLOWTTS_E_ARG;
+    const long total = (long)B * (T + 2 * GLOWTTS_ROW_PAD);
+    hipLaunchKernelGGL(token_masks_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), lengths, mask, rowmask, B, T);
+    RET_LAUNCH();
+}
+
 extern "C" int glowtts_embedding_fwd(const int64_t* tokens, const float* table, const float* rowmask, float* rows, int B, int T, int C, float scale, void* stream)
 {
     if (!tokens || !table || !rowmask || !rows || B < 1 || T < 1 || C < 1) return GLOWTTS_E_ARG;

@@ -180,7 +180,7 @@ TAIL = {"defer": False, "pending": []}
 #       memory system at the head of the step and the decoder's forward ends 45 us later: 5.24-5.30 against 5.20-5.23 ms/step (three alternating pairs)
 #   prep_fused: training on the fused bf16 path forms w = g v / ||v|| and every weight image in ONE launch (csrc/prep_ops.hip) instead of 4 weight-norm +
 #       ~22 packing launches (0.42 -> ~0.1 ms at the head of the step, round 4)
-TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0, "dec_chunks": 1, "cond_hip": True, "fwd_tail_aside": False, "drop_skip32": True, "wgrad_tail_splits": 2}
+TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0, "dec_chunks": 1, "cond_hip": True, "fwd_tail_aside": False, "drop_skip32": True, "wgrad_tail_splits": 2, "prep_bwd_late": True}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
@@ -388,6 +388,11 @@ class _Prepared:
         self.winfo = torch.empty(F_, 36, device=dev)
         _lib.check(L.glowtts_inv1x1_prepare(_lib.ptr(W["inv_w"].contiguous()), _lib.ptr(self.winfo), F_, _lib.stream()), "inv1x1_prepare")
         jobs = PrepJobs() if GV is not None else None
+        # (round 5) the images only the BACKWARD reads - the fused data-gradient image, the per-conv transposed images - are a second launch that the caller
+        # may issue later, off the decoder's chain (`launch_bwd_images`: modules.GlowTTS.forward queues it on the encoder's stream behind the encoder's forward,
+        # where it runs under the log-prior / MAS section of the step; DecoderFunction.backward issues it itself if nobody has)
+        jobs_b = PrepJobs() if (jobs is not None and need_bwd and TUNE["prep_bwd_late"]) else None
+        cur = [jobs]
         self.inv = None
         if GV is not None:
             assert fused_wn_supported(cfg) and P == ops.BF16, "weight preparation from (g, v) serves the fused bf16 path"
@@ -402,7 +407,7 @@ class _Prepared:
 
         def batch(key, sl, shape, transpose, perm, perm_h):
             w, g = src(key, sl)
-            return PackedBatch(w.reshape(shape), transpose, perm, perm_h, P, g=g, jobs=jobs)
+            return PackedBatch(w.reshape(shape), transpose, perm, perm_h, P, g=g, jobs=cur[0])
 
         def images(sl, nflows, img_fwd, nbwd, img_bwd, with_inv):
             """the fused kernels' weight images of flows `sl` (forward: nflows of them; transposed: the first nbwd)"""
@@ -419,9 +424,10 @@ class _Prepared:
                     a += [None, None, None]
                 else:
                     a += [v[sl].data_ptr(), g[sl].data_ptr(), inv[sl].data_ptr() if inv is not None else None]
-            _lib.check(L.glowtts_wavenet_prep_jobs(ctypes.cast(jobs.jobs, c_void_p), PrepJobs.CAP, ctypes.byref(jobs.n), ctypes.byref(jobs.blocks), *a,
+            jb = cur[0]
+            _lib.check(L.glowtts_wavenet_prep_jobs(ctypes.cast(jb.jobs, c_void_p), PrepJobs.CAP, ctypes.byref(jb.n), ctypes.byref(jb.blocks), *a,
                                                    W["w_end"][sl].data_ptr(), nflows, Lw, C // 2, _lib.ptr(img_fwd), nbwd, _lib.ptr(img_bwd)), "wavenet_prep_jobs")
-            jobs.max_cols = max(jobs.max_cols, H * cfg.k)
+            jb.max_cols = max(jb.max_cols, H * cfg.k)
 
         self.wn_img = None
         ksplit = 0
@@ -505,6 +511,8 @@ class _Prepared:
             if ksplit:
                 self.fwd_side_from = ksplit
                 images(slice(ksplit, None), F_ - ksplit, self.wn_img[ksplit:], 0, None, False)
+        if jobs_b is not None:
+            cur[0] = jobs_b                                                    # everything from here on is read by the backward only
         if need_bwd and self.wn_img is not None and fused_bwd_ok and nfb > 0:
             self.wn_img_t = torch.empty_like(self.wn_img[:nfb])                # (the fused flows only)
             images(slice(f0, None), nfb, None, nfb, self.wn_img_t, False)
@@ -531,6 +539,7 @@ class _Prepared:
             jobs.launch(dev)
             stamp("dec_prep_end")
             self.prep_jobs = jobs                                              # (keeps the job table and the tensors it points into)
+        self.bwd_pending = jobs_b if (jobs_b is not None and jobs_b.n.value > 0) else None
         self.ldo = self.pk["end"].npad
         self.ldin = self.pk["in"].npad
         self.cond, self._H, self._Lw = cond, H, Lw
@@ -566,6 +575,20 @@ class _Prepared:
                     p.rs_t[l] = self.pk["rs_t"].at(fc * (Lw - 1) + l) if l < Lw - 1 else self.pk["rs_last_t"].at(fc)
             self.params.append(p)
         self.set_cond(cond)
+
+    def launch_bwd_images(self):
+        """Issues, on the CURRENT stream, the weight-preparation launch of the images only the backward reads, if it is still pending."""
+        jb = getattr(self, "bwd_pending", None)
+        if jb is None:
+            return
+        self.bwd_pending = None
+        dev = self.winfo.device
+        jb.launch(dev)
+        self.prep_jobs_b = jb
+        cs = torch.cuda.current_stream(dev)
+        for t in [self.wn_img_t] + [self.pk[k].data for k in ("start_t", "in_t", "rs_last_t", "end_t", "rs_t") if k in self.pk]:
+            if t is not None:
+                t.record_stream(cs)
 
     def set_cond(self, cond):
         """Attach the per-call conditioning [B, F, L, 2H] (None: unconditioned) to the per-flow parameter structs."""
@@ -929,6 +952,7 @@ class DecoderFunction(torch.autograd.Function):
         dev = dz.device
         if getattr(prep, "bwd_side", None) is not None:
             torch.cuda.current_stream(dev).wait_stream(prep.bwd_side)
+        prep.launch_bwd_images()                                 # (nobody has issued the backward-only images yet: here, on this stream)
         F_, Lw, H, C = cfg.F, cfg.L, cfg.H, cfg.C
         dx, _, _ = squeeze_rows(cfg, dz.contiguous(), ctx.lengths, want_mask=False)
         R = dx.shape[0]

@@ -68,15 +68,30 @@ class _PackSets:
         return lambda: cur.wait_stream(aux)
 
 
+def token_masks(token_lengths, T):
+    """-> (mask [B, 1, T] float, rowmask [B * (T + 4)]) of a token batch, one launch (glowtts_token_masks)."""
+    import ctypes
+    from . import _lib
+    L = _lib.lib()
+    L.glowtts_token_masks.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 2 + [ctypes.c_void_p]
+    B = token_lengths.shape[0]
+    tl = token_lengths.to(torch.int64).contiguous()
+    mask = torch.empty(B, 1, T, device=tl.device)
+    rowmask = torch.empty(B * (T + 2 * ROW_PAD), device=tl.device)
+    _lib.check(L.glowtts_token_masks(tl.data_ptr(), mask.data_ptr(), rowmask.data_ptr(), B, T, _lib.stream()), "glowtts_token_masks")
+    return mask, rowmask
+
+
 def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training=False, prefix="layer_Dict.Encoder",
-                    precision=1, cache=None, on_prior_ready=None, pack_stream=None):
+                    precision=1, cache=None, on_prior_ready=None, pack_stream=None, rowmask=None):
     """Modules.py:262-284 -> mean [B,mel,T], log_std [B,mel,T], log_durations [B,1,T] (channel-first, like the reference).
     pack_stream: a stream forked from the step's origin stream for the second weight-packing launch (see `_PackSets.run`)."""
     e = hp.Encoder
     C = e.Channels
     B, T = tokens.shape
     Tp = T + 2 * ROW_PAD
-    rmf = F.pad(mask.squeeze(1), (ROW_PAD, ROW_PAD)).reshape(-1).contiguous()            # [B*Tp] row mask (0 on pad rows)
+    # [B*Tp] row mask (0 on pad rows); `rowmask`: already built with the mask (token_masks)
+    rmf = rowmask if rowmask is not None else F.pad(mask.squeeze(1), (ROW_PAD, ROW_PAD)).reshape(-1).contiguous()
     dev = tokens.device
     seed_t = torch.randint(0, 2 ** 31 - 1, (1,), device=dev, dtype=torch.int32) if training else None
     counter = [0]

@@ -334,11 +334,15 @@ class GlowTTS(torch.nn.Module):
         with torch.cuda.stream(side):
             decoder.stamp("enc_branch_first_node")
             # (the token mask is the encoder's: built on its stream, so that the decoder's chain starts with its own weight preparation)
-            token_mask = self.Mask_Generate(token_lengths, tokens.shape[1])
+            token_mask, token_rowmask = encoder.token_masks(token_lengths, tokens.shape[1])
             mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, self.training, precision=self.dec_cfg.precision,
-                                                             cache=self._enc_cache,
+                                                             cache=self._enc_cache, rowmask=token_rowmask,
                                                              on_prior_ready=(lambda: prior_ready.record(side)) if prior_ready is not None else None,
                                                              pack_stream=pack_aux)
+            # the decoder's backward-only weight images: behind the encoder's forward on ITS stream - they need nothing but the weights, run under the
+            # log-prior / MAS section of the step and are joined with everything else of this stream before the call returns
+            if side is not main and decoder.EARLY["prep"] is not None:
+                decoder.EARLY["prep"].launch_bwd_images()
         decoder.stamp("main_after_enc_launch")
         cond = stacks.conditioning(spk, pro)
         pitch_w, pitch_b = stacks.pitch_weights()

@@ -582,6 +582,8 @@ int glowtts_gate_bwd(const float *dy, const float *out, const float *rowmask, fl
 /* io_flags: 1 = dy, 2 = out, 4 = dz stored as bf16 instead of fp32 (C a multiple of 4) */
 int glowtts_gate_bwd_io(const void *dy, const void *out, const float *rowmask, void *dz, int64_t rows, int C, float scale, int io_flags, void *stream);
 /* rows[b][PAD+t][:] = table[tokens[b][t]][:] * scale * mask (Modules.py:267), and its gradient (deterministic) */
+/* mask [B][T] = (t < lengths[b]) and the rows layout's row mask [B][T + 2 GLOWTTS_ROW_PAD] (zero pad rows) in one launch (Modules.py:206-211; round 5) */
+int glowtts_token_masks(const int64_t *lengths, float *mask, float *rowmask, int B, int T, void *stream);
 int glowtts_embedding_fwd(const int64_t *tokens, const float *table, const float *rowmask, float *rows, int B, int T, int C, float scale, void *stream);
 int glowtts_embedding_bwd(const int64_t *tokens, const float *drows, const float *rowmask, float *dtable, int V, int B, int T, int C, float scale, void *stream);
 /* Relative-position multi-head self-attention core (RPR_MHA.py:95-128; window `win`, embeddings shared over heads).

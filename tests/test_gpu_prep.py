@@ -32,8 +32,12 @@ def test_prep_images_byte_identical(nskip, nfb):
             launch_reset()
             got = D._Prepared(dc, A, need_bwd=True, rows=4 * 404, GV=GV)
             torch.cuda.synchronize()
+            assert launch_counts().get("prep_weights", 0) == 1          # what the forward reads ...
+            got.launch_bwd_images()                                     # ... and (round 5: a second launch, issued off the decoder's chain) what only the backward reads
+            got.launch_bwd_images()                                     # (idempotent)
+            torch.cuda.synchronize()
             lc = launch_counts()
-        assert lc.get("prep_weights", 0) == 1 and not any(k.startswith("pack") or k.startswith("weightnorm") for k in lc), lc
+        assert lc.get("prep_weights", 0) == 2 and not any(k.startswith("pack") or k.startswith("weightnorm") for k in lc), lc
         # (the Start conv's three K chunks fill 1.5 of its two slabs; the other half slab is never written nor read)
         hole = slice(36864, 49152)
         a, b = got.wn_img.clone(), ref.wn_img.clone()
