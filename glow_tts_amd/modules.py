@@ -331,18 +331,23 @@ class GlowTTS(torch.nn.Module):
         # (behind the fork: the encoder's stream does not wait for it)
         if use_gv and decoder.TUNE["prep_early"] and all(f.layers[0].initialized for f in self._flows()):
             decoder.early_prepare(self.dec_cfg, W, mels.shape, fused_bwd_ok=(pitches is None or "Pitch_v" not in stacks.S))
+        early_prep = decoder.EARLY["prep"]
+
+        def prior_done():
+            prior_ready.record(side)
+            # the decoder's backward-only weight images: on the encoder's stream right behind its projection (they need nothing but the weights) - under the
+            # decoder's z / log-determinant passes and in front of the duration predictor, whose result only the losses read.  (Behind the duration
+            # predictor they ran under the alignment search, a single-wave latency chain: mas_dp2 36 -> 52 us.)  Joined with this stream before the call returns.
+            if early_prep is not None:
+                early_prep.launch_bwd_images()
         with torch.cuda.stream(side):
             decoder.stamp("enc_branch_first_node")
             # (the token mask is the encoder's: built on its stream, so that the decoder's chain starts with its own weight preparation)
             token_mask, token_rowmask = encoder.token_masks(token_lengths, tokens.shape[1])
             mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, self.training, precision=self.dec_cfg.precision,
                                                              cache=self._enc_cache, rowmask=token_rowmask,
-                                                             on_prior_ready=(lambda: prior_ready.record(side)) if prior_ready is not None else None,
+                                                             on_prior_ready=prior_done if prior_ready is not None else None,
                                                              pack_stream=pack_aux)
-            # the decoder's backward-only weight images: behind the encoder's forward on ITS stream - they need nothing but the weights, run under the
-            # log-prior / MAS section of the step and are joined with everything else of this stream before the call returns
-            if side is not main and decoder.EARLY["prep"] is not None:
-                decoder.EARLY["prep"].launch_bwd_images()
         decoder.stamp("main_after_enc_launch")
         cond = stacks.conditioning(spk, pro)
         pitch_w, pitch_b = stacks.pitch_weights()
