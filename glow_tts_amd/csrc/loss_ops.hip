@@ -168,16 +168,32 @@ __global__ __launch_bounds__(256) void logprior_prep_tile_kernel(const float* __
     const int x = n0 + lane;
     float* part = lp_tile + 2 * Cm * 65;
     float acc = 0.f;
-    for (int c = grp; c < Cm; c += 4) {                 // wave `grp` takes channels grp, grp + 4, ...: loads coalesced over the 64 tokens
-        float r = 0.f, mr = 0.f;
-        if (x < Tx) {
-            const long src = ((long)b * Cm + c) * Tx + x;
-            const float l = ls[src], m = mean[src];
-            r = expf(-2.f * l); mr = m * r;
-            acc += -0.9189385332046727f - l - 0.5f * m * mr;
+    // wave `grp` takes channels grp, grp + 4, ...: loads coalesced over the 64 tokens.  Round 5: every load of a block of LP_CH channels is issued before the
+    // first use, unconditionally (clamped addresses) - the predicated one-channel-at-a-time loop was a chain of Cm / 4 dependent round trips to memory (15 us
+    // alone, 45 us with another stream's HBM traffic beside it, on the chain between the decoder's forward and the alignment search)
+    constexpr int LP_CH = 8;
+    const int xs = x < Tx ? x : Tx - 1;
+    for (int c0 = grp; c0 < Cm; c0 += 4 * LP_CH) {
+        float lv[LP_CH], mv[LP_CH];
+#pragma unroll
+        for (int i = 0; i < LP_CH; ++i) {
+            const int c = c0 + 4 * i;
+            const long src = ((long)b * Cm + (c < Cm ? c : Cm - 1)) * Tx + xs;
+            lv[i] = ls[src]; mv[i] = mean[src];
         }
-        lp_tile[c * 65 + lane] = r;
-        lp_tile[(Cm + c) * 65 + lane] = mr;
+#pragma unroll
+        for (int i = 0; i < LP_CH; ++i) {
+            const int c = c0 + 4 * i;
+            if (c < Cm) {
+                float r = 0.f, mr = 0.f;
+                if (x < Tx) {
+                    r = expf(-2.f * lv[i]); mr = mv[i] * r;
+                    acc += -0.9189385332046727f - lv[i] - 0.5f * mv[i] * mr;
+                }
+                lp_tile[c * 65 + lane] = r;
+                lp_tile[(Cm + c) * 65 + lane] = mr;
+            }
+        }
     }
     part[grp * 64 + lane] = acc;
     __syncthreads();

@@ -180,7 +180,7 @@ TAIL = {"defer": False, "pending": []}
 #       memory system at the head of the step and the decoder's forward ends 45 us later: 5.24-5.30 against 5.20-5.23 ms/step (three alternating pairs)
 #   prep_fused: training on the fused bf16 path forms w = g v / ||v|| and every weight image in ONE launch (csrc/prep_ops.hip) instead of 4 weight-norm +
 #       ~22 packing launches (0.42 -> ~0.1 ms at the head of the step, round 4)
-TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0, "dec_chunks": 1, "cond_hip": True, "fwd_tail_aside": False, "drop_skip32": True, "wgrad_tail_splits": 2, "prep_bwd_late": True}
+TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0, "dec_chunks": 1, "cond_hip": True, "fwd_tail_aside": False, "drop_skip32": True, "wgrad_tail_splits": 2, "prep_bwd_late": True, "prep_bwd_gentle": True}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
@@ -576,13 +576,17 @@ class _Prepared:
             self.params.append(p)
         self.set_cond(cond)
 
-    def launch_bwd_images(self):
+    def launch_bwd_images(self, gentle=False):
         """Issues, on the CURRENT stream, the weight-preparation launch of the images only the backward reads, if it is still pending."""
         jb = getattr(self, "bwd_pending", None)
         if jb is None:
             return
         self.bwd_pending = None
         dev = self.winfo.device
+        if gentle:
+            # beside another stream's latency-critical kernels: one workgroup per CU (an 83-KB LDS request instead of 31 KB x 5 workgroups, which leave no CU
+            # with LDS for anybody else - the log-prior's 42-KB operand pass waited for them: 15 -> 45 us); this launch has ~150 us of slack
+            jb.max_cols = max(jb.max_cols, 2600)
         jb.launch(dev)
         self.prep_jobs_b = jb
         cs = torch.cuda.current_stream(dev)

@@ -339,7 +339,7 @@ class GlowTTS(torch.nn.Module):
             # decoder's z / log-determinant passes and in front of the duration predictor, whose result only the losses read.  (Behind the duration
             # predictor they ran under the alignment search, a single-wave latency chain: mas_dp2 36 -> 52 us.)  Joined with this stream before the call returns.
             if early_prep is not None:
-                early_prep.launch_bwd_images()
+                early_prep.launch_bwd_images(gentle=bool(decoder.TUNE["prep_bwd_gentle"]))
         with torch.cuda.stream(side):
             decoder.stamp("enc_branch_first_node")
             # (the token mask is the encoder's: built on its stream, so that the decoder's chain starts with its own weight preparation)
