@@ -466,6 +466,46 @@ def cpu_baseline():
                                "python_loop": round(py_utt * 1e6, 1)}}
 
 
+def parity_sample(model, cfg, batch, cond, n=4):
+    """Part of the cpu_baseline leg (the only place bench.py touches the oracle; the checker, never the thing measured): the benchmarked model - its
+    CURRENT weights, eval mode (no dropout draw), the arithmetic mode of the timed step - on the first `n` utterances of the timed batch against
+    oracle/glowtts_ref.py on the same state dict: the fraction of valid frames whose aligned token differs from the fp32 oracle's path, max |z - oracle|
+    over valid frames, |NLL - oracle|.  In `HIP_Precision: f32` the alignment is bit-exact (tests/test_gpu_benchmarked_sizes.py); in bf16 - the mode
+    BASELINE config 2 names - near-tied paths of a barely trained model move a few percent of the frames."""
+    from oracle import glowtts_ref as O
+    from glow_tts_amd.modules import MLE_Loss
+    tokens, tl, mels, ml = (t[:n] for t in batch)
+    spk = cond[0][:n] if cond[0] is not None else (cond[1][:n] if cond[1] is not None else None)
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            z, mm, ms, ld, _, _, attn, _ = model(tokens, tl, mels, ml, None if cond[0] is None else cond[0][:n], None if cond[1] is None else cond[1][:n], None)
+            nll = MLE_Loss(model.hp)(z=z, mean=mm, std=ms, log_dets=ld, lengths=ml)
+        torch.cuda.synchronize()
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    finally:
+        model.train(was_training)
+    hpd = {"Mode": model.hp.Mode, "Speaker_Embedding": {"Type": model.hp.Speaker_Embedding.Type}}
+    import yaml
+    with open(os.path.join(REPO, "glow_tts_amd", "Hyper_Parameters.default.yaml")) as f:
+        full = yaml.safe_load(f)
+    full["Mode"] = hpd["Mode"]
+    full["Speaker_Embedding"]["Type"] = hpd["Speaker_Embedding"]["Type"]
+    ocfg = O.Cfg.from_yaml_dict(full)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        o = O.forward_train(sd, ocfg, tokens.cpu(), tl.cpu(), mels.cpu(), ml.cpu(), None if spk is None else spk.cpu())
+        onll, _ = O.train_losses(o, ml.cpu(), ocfg)
+    mmask = O.mask_from_lengths(ml.cpu(), mels.shape[2])
+    a, oa = attn.cpu(), o["attn"]
+    differ = ((a[:, :, :oa.shape[2]] != oa).any(1).float() * mmask[:, 0, :oa.shape[2]]).sum().item() / max(1.0, mmask.sum().item())
+    return {"utterances": int(n), "frames_aligned_differently": round(differ, 5),
+            "z_max_err": round(float(((z.cpu() - o["z"]) * mmask).abs().max()), 6), "nll_abs_err": round(abs(float(nll) - float(onll)), 7),
+            "note": "benchmarked model (current weights, eval mode, this run's arithmetic mode) vs oracle/glowtts_ref.py (fp32 CPU) on the first utterances "
+                    "of the timed batch; alignment bit-exactness is a property of the MAS operator on identical fp32 scores and of the f32 mode"}
+
+
 def f32_key(args):
     """north_star states its tolerance in fp32: the same step in `HIP_Precision: f32` (exact fp32 MFMA, v_mfma_f32_32x32x2_f32, the arithmetic the
     1e-3 / 1e-4 parity tests run in), timed by a child process so that its model and graph do not share this one's memory."""
@@ -889,6 +929,10 @@ def main():
             out["inverse_flow"] = inv
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["parity_sample"] = parity_sample(model, cfg, batch, cond)
+            except Exception as exc:                            # noqa: BLE001 - a reported extra, never fatal for the timing line
+                out["parity_sample"] = {"error": f"{type(exc).__name__}: {exc}"}
         if args.precision == "bf16" and not dp and not args.no_f32_key and args.config == 2 and opt is not None:
             out["f32"] = f32_key(args)
     # The JSON line must be the LAST line of the job's stdout.  RCCL writes a banner ("Librccl path : ...") through C stdio, which a pipe

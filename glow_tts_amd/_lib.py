@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libglowtts_hip.so")
 if os.environ.get("GLOWTTS_LIB_PATH"):
     LIB_PATH = os.environ["GLOWTTS_LIB_PATH"]
 _lib = None
-ABI_VERSION = 5                          # GLOWTTS_ABI_VERSION of include/glowtts_hip.h
+ABI_VERSION = 6                          # GLOWTTS_ABI_VERSION of include/glowtts_hip.h
 
 c_int, c_float, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 

@@ -197,6 +197,21 @@ __global__ __launch_bounds__(1024) void cond_dvec_kernel(const float* __restrict
 
 }  // namespace
 
+// LDS bytes of the two kernels for (D, B): the shapes the launches below accept are exactly those whose tiles fit 160 KiB
+static size_t cond_fwd_lds(int D, int B) { const int NJ = (B + 7) / 8; return ((size_t)(CT_ROWS + 8 * NJ) * (D + 4) + CT_ROWS) * sizeof(float); }
+static size_t cond_bwd_lds(int D, int B)
+{
+    const int BP = (B + 7) / 8 * 8;
+    return ((size_t)(CT_ROWS + BP) * (D + 4) + CT_ROWS + (size_t)BP * (CT_ROWS + 1) + 8 * CT_ROWS) * sizeof(float);
+}
+
+extern "C" int glowtts_cond_linear_supported(int N, int D, int B)
+{
+    if (N < 1 || B < 1 || B > CO_MAXB) return 0;
+    if (D != 128 && D != 256 && D != 384 && D != 512) return 0;
+    return cond_fwd_lds(D, B) <= 160 * 1024 && cond_bwd_lds(D, B) <= 160 * 1024;
+}
+
 extern "C" int glowtts_cond_linear_fwd(const float* v, const float* g, const float* bias, const float* vec, float* out, float* inv_out,
                                        int N, int D, int B, int accumulate, void* stream)
 {
@@ -205,7 +220,7 @@ extern "C" int glowtts_cond_linear_fwd(const float* v, const float* g, const flo
     const dim3 grid((N + CT_ROWS - 1) / CT_ROWS);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int NJ = (B + 7) / 8;
-    const size_t lds = ((size_t)(CT_ROWS + 8 * NJ) * (D + 4) + CT_ROWS) * sizeof(float);
+    const size_t lds = cond_fwd_lds(D, B);
     if (lds > 160 * 1024) return GLOWTTS_E_ARG;
 #define CF_LAUNCH(J) do { static bool done = false; if (!done) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_fwd_kernel<J>), \
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GLOWTTS_E_LAUNCH; done = true; } \
@@ -226,7 +241,7 @@ extern "C" int glowtts_cond_linear_bwd(const float* dcond, int64_t ldd, const fl
     if (!dcond || !v || !g || !inv || !vec || !dv || !dg || !scratch || N < 1 || B < 1 || B > CO_MAXB || ldd < N) return GLOWTTS_E_ARG;
     if (D != 128 && D != 256 && D != 384 && D != 512) return GLOWTTS_E_ARG;         // (phase 2 tiles the columns in groups of 128)
     const int BP = (B + 7) / 8 * 8;
-    const size_t lds = ((size_t)(CT_ROWS + BP) * (D + 4) + CT_ROWS + (size_t)BP * (CT_ROWS + 1) + 8 * CT_ROWS) * sizeof(float);
+    const size_t lds = cond_bwd_lds(D, B);
     if (lds > 160 * 1024) return GLOWTTS_E_ARG;
     const int nwg = (N + CT_ROWS - 1) / CT_ROWS;
     hipStream_t s = static_cast<hipStream_t>(stream);

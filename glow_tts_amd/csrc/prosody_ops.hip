@@ -216,79 +216,3 @@ extern "C" int glowtts_gru_bwd(const float* dhs, const float* hs, const float* k
     hipLaunchKernelGGL(gru_bwd_kernel, dim3(B), dim3(3 * H), 7 * H * sizeof(float), static_cast<hipStream_t>(stream), dhs, hs, keep, w_hh, dgi, dgh, T, H);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
-
-// ------------------------------------------------------------------------------------------------
-// Reference encoder of the GST prosody encoder (Modules.py:320-333): six Conv2d(3x3, stride 2, padding 1, no bias) + ReLU over the mel
-// "image" [B][1][Mel][T].  Here every layer is a GEMM on the MFMA conv kernel (glowtts_conv_cl, 1x1 mode, ReLU epilogue) over an explicit
-// patch matrix: activations are channels-last [B][H][W][C], patch row (b, ho, wo) holds the 3 x 3 x C window (tap-major, channel-minor, zero
-// outside the image, zero columns up to ldc).  Both kernels are pure gathers - coalesced along channels / columns, no atomics: the backward
-// sums, for an input pixel, the <= 4 patch entries that read it.
-// ------------------------------------------------------------------------------------------------
-namespace {
-__global__ __launch_bounds__(256) void im2col_s2_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int H, int W, int C, int Ho, int Wo, int ldc)
-{
-    const long total = (long)B * Ho * Wo * ldc;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(i % ldc);
-        const long row = i / ldc;
-        float v = 0.f;
-        if (k < 9 * C) {
-            const int tap = k / C, c = k - tap * C, kh = tap / 3, kw = tap - kh * 3;
-            const int wo = (int)(row % Wo), ho = (int)((row / Wo) % Ho), b = (int)(row / ((long)Wo * Ho));
-            const int h = 2 * ho + kh - 1, w = 2 * wo + kw - 1;
-            if (h >= 0 && h < H && w >= 0 && w < W) v = x[(((long)b * H + h) * W + w) * C + c];
-        }
-        col[i] = v;
-    }
-}
-
-__global__ __launch_bounds__(256) void col2im_s2_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo, int ldc)
-{
-    const long total = (long)B * H * W * C;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long pix = i / C;
-        const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
-        float s = 0.f;
-        // h = 2 ho + kh - 1  <=>  kh = h + 1 - 2 ho in {0, 1, 2}
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int hh = h + 1 - kh;
-            if (hh < 0 || (hh & 1)) continue;
-            const int ho = hh >> 1;
-            if (ho >= Ho) continue;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ww = w + 1 - kw;
-                if (ww < 0 || (ww & 1)) continue;
-                const int wo = ww >> 1;
-                if (wo >= Wo) continue;
-                s += dcol[(((long)b * Ho + ho) * Wo + wo) * ldc + (kh * 3 + kw) * C + c];
-            }
-        }
-        dx[i] = s;
-    }
-}
-}  // namespace
-
-extern "C" int glowtts_im2col3x3s2(const float* x, float* col, int B, int H, int W, int C, int ldc, void* stream)
-{
-    if (!x || !col || B < 1 || H < 1 || W < 1 || C < 1 || ldc < 9 * C) return GLOWTTS_E_ARG;
-    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    const long total = (long)B * Ho * Wo * ldc;
-    const int blocks = (int)std::min<long>((total + 255) / 256, 256L * 64);
-    GLOWTTS_NOTE_STATIC("im2col3x3s2");
-    hipLaunchKernelGGL(im2col_s2_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, col, B, H, W, C, Ho, Wo, ldc);
-    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
-}
-
-extern "C" int glowtts_col2im3x3s2(const float* dcol, float* dx, int B, int H, int W, int C, int ldc, void* stream)
-{
-    if (!dcol || !dx || B < 1 || H < 1 || W < 1 || C < 1 || ldc < 9 * C) return GLOWTTS_E_ARG;
-    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    const long total = (long)B * H * W * C;
-    const int blocks = (int)std::min<long>((total + 255) / 256, 256L * 64);
-    GLOWTTS_NOTE_STATIC("col2im3x3s2");
-    hipLaunchKernelGGL(col2im_s2_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dcol, dx, B, H, W, C, Ho, Wo, ldc);
-    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
-}

@@ -1437,8 +1437,11 @@ class DecoderStacks:
         kinds = [(kind, vec) for kind, vec in (("Speaker", speakers), ("Prosody", prosodies)) if vec is not None]
         if not kinds:
             return None
-        if TUNE["cond_hip"] and all(vec.is_cuda and vec.dtype == torch.float32 and vec.dim() == 2 and vec.shape[0] <= 64 and vec.shape[1] in (128, 256, 384, 512)
-                                    and vec.shape[1] == self.S[kind + "_v"].tensor().shape[-2] for kind, vec in kinds):
+        # (the kernels' own bound - D in {128, 256, 384, 512}, B <= 64 AND their LDS tiles within 160 KiB: D = 512 stops at B = 40 - asked of the library,
+        #  so that a shape it rejects takes the matmul path below instead of raising in the forward: ADVICE r5)
+        n_out = self.cfg.F * self.cfg.L * 2 * self.cfg.H
+        if TUNE["cond_hip"] and all(vec.is_cuda and vec.dtype == torch.float32 and vec.dim() == 2 and vec.shape[1] == self.S[kind + "_v"].tensor().shape[-2]
+                                    and _lib.lib().glowtts_cond_linear_supported(n_out, int(vec.shape[1]), int(vec.shape[0])) for kind, vec in kinds):
             args = []
             for kind, vec in kinds:
                 args += [self.S[kind + "_g"].tensor(), self.S[kind + "_v"].tensor(), self.S[kind + "_b"].tensor(), vec]

@@ -3,6 +3,7 @@ per-utterance tensor, < 1 % of the FLOPs): the GST `Prosody_Encoder` (Modules.py
 gradient-reversal layer (Modules.py:407-435, Gradient_Reversal_Layer.py:6-35) and the `Pitch_Interpolater` (Modules.py:387-405).  Plain
 PyTorch-ROCm modules with the reference's parameter names, so PE- and GR-mode checkpoints load strictly; they feed the HIP decoder / encoder
 as conditioning vectors.  Parity: tests/test_gpu_modes.py against the golden vectors of the reference (tiny_pe.npz, tiny_gr.npz)."""
+import ctypes
 import math
 
 import torch
@@ -44,51 +45,179 @@ class _GRUFunction(torch.autograd.Function):
         return dx, dgi2.t() @ x.reshape(B * T, -1), dgh2.t() @ hprev, dgi2.sum(0), dgh2.sum(0)
 
 
-class _Im2ColS2(torch.autograd.Function):
-    """Patch matrix of Conv2d(3x3, stride 2, padding 1) over channels-last activations [B, H, W, C] -> [B*Ho*Wo, ldc] (glowtts_im2col3x3s2);
-    the backward is the gather-sum adjoint (glowtts_col2im3x3s2)."""
+class _PackJob(ctypes.Structure):
+    """glowtts_c2d_pack_job (include/glowtts_hip.h)"""
+    _fields_ = [("w", ctypes.c_void_p), ("img", ctypes.c_void_p)] + [(k, ctypes.c_int) for k in ("Ci", "Co", "cls", "N", "K", "npad", "kchunks", "block0")]
+
+
+class _ReduceJob(ctypes.Structure):
+    """glowtts_c2d_reduce_job"""
+    _fields_ = [("partial", ctypes.c_void_p), ("dw", ctypes.c_void_p)] + [(k, ctypes.c_int) for k in ("splits", "Ci", "Co", "block0")]
+
+
+_C2D_DECLARED = []
+
+
+def _c2d():
+    from . import _lib
+    L = _lib.lib()
+    if not _C2D_DECLARED:
+        vp, ci, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        L.glowtts_conv3x3s2_supported.argtypes = [ci] * 5
+        L.glowtts_conv3x3s2_image_bytes.argtypes = [ci, ci, ci, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+        L.glowtts_conv3x3s2_pack_job_init.argtypes = [ctypes.POINTER(_PackJob), vp, ci, ci, ci, ci, vp, ci, ctypes.POINTER(ci)]
+        L.glowtts_conv3x3s2_pack.argtypes = [vp, ci, ci, ci, vp]
+        L.glowtts_conv3x3s2_fwd.argtypes = [vp, vp, vp, vp] + [ci] * 7 + [vp]
+        L.glowtts_conv3x3s2_dgrad.argtypes = [vp, ctypes.POINTER(vp), vp, vp] + [ci] * 6 + [vp]
+        L.glowtts_conv3x3s2_wgrad_scratch_floats.argtypes = [ci] * 5
+        L.glowtts_conv3x3s2_wgrad_scratch_floats.restype = i64
+        L.glowtts_conv3x3s2_wgrad.argtypes = [vp, vp, vp] + [ci] * 5 + [ctypes.POINTER(ci), vp]
+        L.glowtts_conv3x3s2_wgrad_reduce.argtypes = [ctypes.POINTER(_ReduceJob), ci, vp]
+        _C2D_DECLARED.append(True)
+    return L
+
+
+class _ConvImages:
+    """Weight images of a conv stack (forward image per layer with Ci > 1, four data-gradient class images when gradients are needed) in one
+    buffer, plus the device job table of the ONE launch that rewrites them from the current weights (static while the parameters stay in place)."""
+
+    def __init__(self, weights, precision, need_bwd):
+        from . import _lib
+        L = _c2d()
+        self.key = (tuple(w.data_ptr() for w in weights), int(precision), bool(need_bwd))
+        dev = weights[0].device
+        sizes = []
+        for w in weights:
+            Co, Ci = int(w.shape[0]), int(w.shape[1])
+            fwd, dg = ctypes.c_int64(0), (ctypes.c_int64 * 4)()
+            _lib.check(L.glowtts_conv3x3s2_image_bytes(Ci, Co, precision, ctypes.byref(fwd), dg), "glowtts_conv3x3s2_image_bytes")
+            sizes.append((int(fwd.value) if Ci > 1 else 0, [int(v) if (need_bwd and Ci > 1) else 0 for v in dg]))
+        total = sum(f + sum(d) for f, d in sizes)
+        self.buf = torch.empty(max(total, 16), dtype=torch.uint8, device=dev)
+        base, off = self.buf.data_ptr(), 0
+        self.fwd, self.dgrad, jobs, block = [], [], [], 0
+        for w, (f, d) in zip(weights, sizes):
+            Co, Ci = int(w.shape[0]), int(w.shape[1])
+            fp, dps = None, None
+            todo = []
+            if f:
+                fp = base + off
+                off += f
+                todo.append((-1, fp))
+            if any(d):
+                dps = []
+                for cls in range(4):
+                    dps.append(base + off)
+                    todo.append((cls, base + off))
+                    off += d[cls]
+            for cls, img in todo:
+                job, nb = _PackJob(), ctypes.c_int(0)
+                _lib.check(L.glowtts_conv3x3s2_pack_job_init(ctypes.byref(job), w.data_ptr(), Ci, Co, cls, precision, img, block, ctypes.byref(nb)),
+                           "glowtts_conv3x3s2_pack_job_init")
+                block += nb.value
+                jobs.append(job)
+            self.fwd.append(fp)
+            self.dgrad.append(dps)
+        self.njobs, self.blocks = len(jobs), block
+        self.table = None
+        if jobs:
+            raw = b"".join(bytes(j) for j in jobs)
+            self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.precision = precision
+
+    def pack(self):
+        from . import _lib
+        if self.table is not None:
+            _lib.check(_c2d().glowtts_conv3x3s2_pack(self.table.data_ptr(), self.njobs, self.blocks, self.precision, _lib.stream()), "glowtts_conv3x3s2_pack")
+
+
+class _ConvStack(torch.autograd.Function):
+    """The reference encoder's Conv2d(3x3, stride 2, padding 1, no bias) + ReLU stack (Modules.py:320-333, 366-368) as direct HIP kernels on
+    channels-last activations (csrc/conv2d_ops.hip): 1 weight-image launch + one launch per layer forward; backward one data-gradient launch
+    (four parity classes, the producing layer's ReLU in its epilogue) and one weight-gradient launch per layer + ONE deterministic reduction for all
+    layers.  apply(mels [B, Mel, T], images, precision, *weights [Co, Ci, 3, 3]) -> [B, Mel', T', C] (channels-last)."""
 
     @staticmethod
-    def forward(ctx, x, ldc):
-        import ctypes
+    def forward(ctx, mels, images, precision, *weights):
         from . import _lib
-        L = _lib.lib()
-        L.glowtts_im2col3x3s2.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
-        x = x.contiguous()
-        B, H, W, C = x.shape
-        col = torch.empty(B * ((H + 1) // 2) * ((W + 1) // 2), ldc, device=x.device)
-        _lib.check(L.glowtts_im2col3x3s2(_lib.ptr(x), _lib.ptr(col), B, H, W, C, ldc, _lib.stream()), "glowtts_im2col3x3s2")
-        ctx.cfg = (B, H, W, C, ldc)
-        return col
+        L = _c2d()
+        x = mels.contiguous()                                  # [B][H = Mel][W = T] == channels-last with C = 1
+        B, H, W = x.shape
+        images.pack()
+        acts, shapes = [x], []
+        s = _lib.stream()
+        for l, w in enumerate(weights):
+            Co, Ci = int(w.shape[0]), int(w.shape[1])
+            Ho, Wo = (H + 1) // 2, (W + 1) // 2
+            y = torch.empty(B, Ho, Wo, Co, device=x.device)
+            _lib.check(L.glowtts_conv3x3s2_fwd(acts[-1].data_ptr(), w.data_ptr(), images.fwd[l], y.data_ptr(), B, H, W, Ci, Co, 1, precision, s),
+                       "glowtts_conv3x3s2_fwd")
+            shapes.append((H, W, Ci, Co))
+            acts.append(y)
+            H, W = Ho, Wo
+        ctx.save_for_backward(*acts, *weights)
+        ctx.cfg = (images, precision, shapes, B)
+        return acts[-1]
 
     @staticmethod
-    def backward(ctx, dcol):
-        import ctypes
+    def backward(ctx, dout):
         from . import _lib
-        L = _lib.lib()
-        L.glowtts_col2im3x3s2.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
-        B, H, W, C, ldc = ctx.cfg
-        dcol = dcol.contiguous()
-        dx = torch.empty(B, H, W, C, device=dcol.device)
-        _lib.check(L.glowtts_col2im3x3s2(_lib.ptr(dcol), _lib.ptr(dx), B, H, W, C, ldc, _lib.stream()), "glowtts_col2im3x3s2")
-        return dx, None
+        L = _c2d()
+        images, precision, shapes, B = ctx.cfg
+        n = len(shapes)
+        acts, weights = ctx.saved_tensors[:n + 1], ctx.saved_tensors[n + 1:]
+        s = _lib.stream()
+        dpre = dout.contiguous() * (acts[n] > 0).to(dout.dtype)          # the last layer's ReLU (tiny: [B, 2, 13, 128] at the default sizes)
+        jobs = (_ReduceJob * n)()
+        keep, grads = [], [None] * n
+        for l in range(n - 1, -1, -1):
+            H, W, Ci, Co = shapes[l]
+            x = acts[l]
+            partial = torch.empty(int(L.glowtts_conv3x3s2_wgrad_scratch_floats(B, H, W, Ci, Co)), device=x.device)
+            splits = ctypes.c_int(0)
+            _lib.check(L.glowtts_conv3x3s2_wgrad(x.data_ptr(), dpre.data_ptr(), partial.data_ptr(), B, H, W, Ci, Co, ctypes.byref(splits), s),
+                       "glowtts_conv3x3s2_wgrad")
+            dw = torch.empty_like(weights[l])
+            jobs[l].partial, jobs[l].dw, jobs[l].splits, jobs[l].Ci, jobs[l].Co = partial.data_ptr(), dw.data_ptr(), splits.value, Ci, Co
+            keep.append(partial)
+            grads[l] = dw
+            if l > 0:
+                dx = torch.empty_like(x)
+                imgs = (ctypes.c_void_p * 4)(*images.dgrad[l])
+                _lib.check(L.glowtts_conv3x3s2_dgrad(dpre.data_ptr(), imgs, x.data_ptr(), dx.data_ptr(), B, H, W, Ci, Co, precision, s),
+                           "glowtts_conv3x3s2_dgrad")
+                dpre = dx
+        _lib.check(L.glowtts_conv3x3s2_wgrad_reduce(jobs, n, s), "glowtts_conv3x3s2_wgrad_reduce")
+        return (None, None, None) + tuple(grads)
 
 
-def conv_stack_hip(convs, mels, precision):
-    """The reference encoder's Conv2d(3x3, stride 2, padding 1, no bias) + ReLU stack (Modules.py:320-333, 366-368) on the HIP path: per layer a
-    patch-matrix gather and ONE MFMA GEMM with the ReLU in its epilogue (conv_fn.conv_rows -> glowtts_conv_cl; its backward: gate, data-gradient
-    GEMM, weight-gradient kernel), activations channels-last.  mels [B, Mel, T] -> [B, T', C * Mel'] (the GRU's input, feature = c * Mel' + h as
-    in the reference's reshape at :369)."""
-    from .conv_fn import conv_rows
-    x = mels.unsqueeze(-1)                                    # [B, H = Mel, W = T, C = 1]
-    for conv in convs:
-        w = conv.weight                                       # [Co, Ci, 3, 3]
-        B, H, W, C = x.shape
-        Co, K = w.shape[0], 9 * C
-        ldc = max(32, -(-K // 32) * 32)
-        col = _Im2ColS2.apply(x, ldc)
-        w2 = torch.nn.functional.pad(w.permute(0, 2, 3, 1).reshape(Co, K), (0, ldc - K)).unsqueeze(-1)      # [Co, (kh, kw, ci) + zero pad, 1]
-        x = conv_rows(col, w2, None, None, relu=True, precision=precision).view(B, (H + 1) // 2, (W + 1) // 2, Co)
+def conv_stack_supported(convs, mels):
+    """The HIP conv stack takes: 3x3 / stride 2 / padding 1 / no bias, first layer one input channel, every other layer 32 / 64 / 128 channels in
+    and out (the reference's defaults, Hyper_Parameters.yaml Prosody_Encoder.Reference_Encoder); anything else runs torch's Conv2d."""
+    if not (mels.is_cuda and mels.dtype == torch.float32 and mels.dim() == 3):
+        return False
+    if not all(c.kernel_size == (3, 3) and c.stride == (2, 2) and c.padding == (1, 1) and c.bias is None and c.weight.dtype == torch.float32 for c in convs):
+        return False
+    L = _c2d()
+    B, H, W = (int(v) for v in mels.shape)
+    for c in convs:
+        if not L.glowtts_conv3x3s2_supported(B, H, W, c.in_channels, c.out_channels):
+            return False
+        H, W = (H + 1) // 2, (W + 1) // 2
+    return convs[0].in_channels == 1 and all(c.in_channels > 1 for c in convs[1:])
+
+
+def conv_stack_hip(convs, mels, precision, cache=None):
+    """mels [B, Mel, T] -> [B, T', C * Mel'] (the GRU's input, feature = c * Mel' + h as in the reference's reshape at Modules.py:369)."""
+    weights = [c.weight for c in convs]
+    need_bwd = torch.is_grad_enabled() and any(w.requires_grad for w in weights)
+    key = (tuple(w.data_ptr() for w in weights), int(precision), bool(need_bwd))
+    images = cache.get("images") if cache is not None else None
+    if images is None or images.key != key:
+        images = _ConvImages([w.detach() for w in weights], int(precision), need_bwd)
+        if cache is not None:
+            cache["images"] = images
+    x = _ConvStack.apply(mels, images, int(precision), *weights)
     B, H, W, C = x.shape
     return x.permute(0, 2, 3, 1).reshape(B, W, C * H)
 
@@ -151,17 +280,18 @@ class Prosody_Encoder(torch.nn.Module):
         self.n_conv = len(self.strides)
 
     hip_precision = 0                                         # ops.F32 / ops.BF16: arithmetic of the HIP conv stack (set by GlowTTS from HIP_Precision)
-    # The six stride-2 Conv2d layers through the library's own GEMM path (conv_stack_hip) instead of torch's Conv2d (MIOpen).  Off by
-    # default: measured on the MI355X at B = 32 (bench.py --config 5) the patch-matrix form is no faster than MIOpen's direct kernels
-    # (7.97 vs 7.82 ms forward + backward per step; 1.15 ms of kernels, a third of it writing and re-reading the patch matrices), see DESIGN.md.
-    use_hip_convs = False
+    # The six stride-2 Conv2d layers as direct HIP kernels (conv_stack_hip -> csrc/conv2d_ops.hip; round 6).  Until round 5 this switch selected a
+    # patch-matrix + GEMM path that was no faster than MIOpen's direct kernels and stayed off; yaml shapes the kernels do not take (other kernel
+    # sizes / strides / channel counts) still run torch's Conv2d.
+    use_hip_convs = True
 
     def forward(self, x, lengths):
         convs = [self.layer_Dict[f"Conv_{i}"].Conv for i in range(self.n_conv)]
-        hip_convs = self.use_hip_convs and x.is_cuda and x.dtype == torch.float32 and all(
-            c.kernel_size == (3, 3) and c.stride == (2, 2) and c.padding == (1, 1) and c.bias is None and c.out_channels % 4 == 0 for c in convs)
+        hip_convs = self.use_hip_convs and conv_stack_supported(convs, x)
         if hip_convs:
-            xt = conv_stack_hip(convs, x, self.hip_precision)                              # [B, T', C * Mel']
+            if not hasattr(self, "_c2d_cache"):
+                self._c2d_cache = {}
+            xt = conv_stack_hip(convs, x, self.hip_precision, self._c2d_cache)             # [B, T', C * Mel']
         else:                                                 # other kernel sizes / strides of the yaml: torch's Conv2d (on the same device)
             x = x.unsqueeze(1)
             for i in range(self.n_conv):

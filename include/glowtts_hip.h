@@ -20,9 +20,9 @@ extern "C" {
 #define GLOWTTS_OK            0
 #define GLOWTTS_E_ARG        -1   /* bad argument / unsupported size */
 #define GLOWTTS_E_LAUNCH     -2   /* hip launch error */
-#define GLOWTTS_ABI_VERSION    5
+#define GLOWTTS_ABI_VERSION    6
 
-/* Library / device identification.  Returns the ABI version (currently 5: additions only - glowtts_cond_linear_fwd / _bwd, glowtts_prep_launch_dev,
+/* Library / device identification.  Returns the ABI version (currently 6: glowtts_cond_linear_supported, the direct 3x3 stride-2 conv trio glowtts_conv3x3s2_*; 5: additions only - glowtts_cond_linear_fwd / _bwd, glowtts_prep_launch_dev,
  * glowtts_rpr_attention_bwd_partial_rows (and NULL drelk / drelv), glowtts_sum_slices / _seg, GLOWTTS_F_GATE_IN0, GLOWTTS_F_COND_FX, glowtts_flow_acts.skip may be NULL on
  * the fused forward launch, glowtts_flow_grads.dcond holds 64-bit fixed-point accumulators; 4: glowtts_flow_acts grew next_* / actnorm_done - the next flow's ActNorm + 1x1 conv in the
  * fused coupling launch's epilogue - and glowtts_proj_layernorm / glowtts_layernorm_qkv were added; 3: glowtts_prep_job / glowtts_prep_launch / glowtts_wavenet_prep_jobs,
@@ -521,6 +521,9 @@ int glowtts_utt_colsum(const float *x, int64_t ldx, float *out, int64_t ldout, i
 int glowtts_cond_linear_fwd(const float *v, const float *g, const float *bias, const float *vec, float *out, float *inv_out,
                             int N, int D, int B, int accumulate, void *stream);
 int64_t glowtts_cond_linear_bwd_scratch_floats(int N, int D, int B);
+/* 1 when glowtts_cond_linear_fwd AND _bwd take (N, D, B) - D in {128, 256, 384, 512}, B <= 64 and both kernels' LDS tiles ((32 + B') (D + 4) floats
+ * plus the backward's extras) within 160 KiB, e.g. not D = 512 with B > 40 - else 0: the caller then forms the product itself (ABI 6). */
+int glowtts_cond_linear_supported(int N, int D, int B);
 int glowtts_cond_linear_bwd(const float *dcond, int64_t ldd, const float *v, const float *g, const float *inv, const float *vec,
                             float *dv, float *dg, float *dbias, float *dvec, float *scratch, int N, int D, int B, void *stream);
 
@@ -534,12 +537,42 @@ int glowtts_cond_linear_bwd(const float *dcond, int64_t ldd, const float *v, con
 int glowtts_gru_fwd(const float *gi, const float *w_hh, const float *b_hh, float *hs, float *keep, int B, int T, int H, void *stream);
 int glowtts_gru_bwd(const float *dhs, const float *hs, const float *keep, const float *w_hh, float *dgi, float *dgh,
                     int B, int T, int H, void *stream);
-/* Patch matrix of Conv2d(3x3, stride 2, padding 1) - the six layers of the GST reference encoder (Modules.py:320-333) - and its adjoint.
- * x [B][H][W][C] channels-last fp32; col [B*Ho*Wo][ldc], Ho = ceil(H/2), Wo = ceil(W/2), column (kh*3 + kw)*C + c = x[b][2ho+kh-1][2wo+kw-1][c]
- * (0 outside the image; columns 9C..ldc-1 are written as 0).  The conv is then glowtts_conv_cl (1x1, ReLU) on `col` with the weight viewed as
- * [Cout][kh][kw][Cin]; col2im sums, per input pixel, the patch entries that read it (a gather: no atomics, dx is overwritten). */
-int glowtts_im2col3x3s2(const float *x, float *col, int B, int H, int W, int C, int ldc, void *stream);
-int glowtts_col2im3x3s2(const float *dcol, float *dx, int B, int H, int W, int C, int ldc, void *stream);
+/* ------------------------------------------------------------------------------------------
+ * Direct Conv2d(3x3, stride 2, padding 1, no bias) (+ ReLU) on channels-last activations x [B][H][W][Ci] -> y [B][Ho][Wo][Co], Ho = ceil(H / 2), Wo =
+ * ceil(W / 2): the six layers of the GST reference encoder (Modules.py:320-333, 366-368; ABI 6, csrc/conv2d_ops.hip).  w is the torch Conv2d weight
+ * [Co][Ci][3][3] fp32.  No patch matrix, no layout change: the forward and the data gradient are implicit GEMMs on MFMA whose A rows are gathered while
+ * they are staged, the weight gradient runs on the exact-fp32 MFMA in both arithmetic modes.  Supported (glowtts_conv3x3s2_supported): Ci = 1 with
+ * Co % 4 == 0, Co <= 128 (VALU kernels), or Ci, Co in {32, 64, 128}; B H W max(Ci, Co) < 2^31.
+ *
+ * Weight images (MFMA tile order, like glowtts_pack_weight): one forward image per layer with Ci > 1 and four data-gradient images, one per parity class
+ * cls = 2 (h & 1) + (w & 1) of the INPUT pixel (a pixel of class (1, 1) is read by four taps, (0, 0) by one).  glowtts_conv3x3s2_image_bytes reports the
+ * sizes; all images of a stack are written by ONE launch over a device job table (fill the jobs on the host with glowtts_conv3x3s2_pack_job_init - cls
+ * = -1: forward image -, block0 = running sum of *blocks_out, copy the table to the device once: it stays valid while the pointers do). */
+typedef struct glowtts_c2d_pack_job {
+    const float *w; void *img;
+    int Ci, Co, cls, N, K, npad, kchunks, block0;
+} glowtts_c2d_pack_job;
+int glowtts_conv3x3s2_supported(int B, int H, int W, int Ci, int Co);
+int glowtts_conv3x3s2_image_bytes(int Ci, int Co, int precision, int64_t *fwd_bytes /* host */, int64_t *dgrad_bytes /* host [4] */);
+int glowtts_conv3x3s2_pack_job_init(glowtts_c2d_pack_job *job /* host */, const float *w, int Ci, int Co, int cls, int precision, void *img,
+                                    int block0, int *blocks_out /* host */);
+int glowtts_conv3x3s2_pack(const glowtts_c2d_pack_job *dev_jobs, int njobs, int total_blocks, int precision, void *stream);
+/* y = relu?(conv(x)).  Ci = 1: reads w; else reads img_fwd (w may be NULL). */
+int glowtts_conv3x3s2_fwd(const float *x, const float *w, const void *img_fwd, float *y, int B, int H, int W, int Ci, int Co, int relu,
+                          int precision, void *stream);
+/* dx [B][H][W][Ci] from dpre [B][Ho][Wo][Co] (the gradient of the conv's output BEFORE its ReLU); gate (optional, shaped like dx: the layer's input = the
+ * previous layer's ReLU output): dx = gate > 0 ? dx : 0, i.e. dx leaves as the previous layer's dpre.  img_dgrad: HOST array of the four class images. */
+int glowtts_conv3x3s2_dgrad(const float *dpre, const void *const *img_dgrad, const float *gate, float *dx, int B, int H, int W, int Ci, int Co,
+                            int precision, void *stream);
+/* Weight gradient in two steps: _wgrad writes *splits_out partial images [splits][Co][(kh, kw, ci)] into `partial`
+ * (glowtts_conv3x3s2_wgrad_scratch_floats(...) floats), one glowtts_conv3x3s2_wgrad_reduce over up to GLOWTTS_C2D_MAX_LAYERS layers sums them in a fixed
+ * order into dw [Co][Ci][3][3] (overwritten).  Deterministic, no atomics. */
+#define GLOWTTS_C2D_MAX_LAYERS 8
+typedef struct glowtts_c2d_reduce_job { const float *partial; float *dw; int splits, Ci, Co, block0 /* set by the call */; } glowtts_c2d_reduce_job;
+int64_t glowtts_conv3x3s2_wgrad_scratch_floats(int B, int H, int W, int Ci, int Co);
+int glowtts_conv3x3s2_wgrad(const float *x, const float *dpre, float *partial, int B, int H, int W, int Ci, int Co, int *splits_out /* host */,
+                            void *stream);
+int glowtts_conv3x3s2_wgrad_reduce(const glowtts_c2d_reduce_job *jobs /* host */, int njobs, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Text-encoder kernels that are not convolutions (rows layout).

@@ -10,7 +10,9 @@
 (b) The full-size SE (LUT, 109 speakers) and PE (GST prosody encoder) models, B = 4 ragged, same bars (f32) - the conditioning path of
     configs 3 and 5 at real width.
 (c) tests/longform_check.py (child process: it captures hipGraphs): long-form inverse flow at full width, 2 utterances x > 2000 frames,
-    `GlowTTS.inference` and `GraphedInference` against `oracle.inference` with injected noise (Modules.py:128-204)."""
+    `GlowTTS.inference` and `GraphedInference` against `oracle.inference` with injected noise (Modules.py:128-204), Vanilla and PE mode; the
+    bf16 inverse flow's mel error against the oracle on identical prior inputs is measured and bounded there.
+(d) BASELINE config 5 at its per-GPU batch (PE mode, B = 32 x 800) against the oracle, f32 and bf16."""
 import copy
 import os
 import subprocess
@@ -220,6 +222,16 @@ def test_config3_batch32_speaker_lut():
     check_bf16(case, run_hip(case, "bf16"))
 
 
+def test_config5_batch32_pe():
+    """BASELINE config 5 at ITS per-GPU batch (PE / GST prosody-encoder mode, B = 32 x 800 frames; the prosody reference is the target mel,
+    Modules.py:81-82): the shape `bench.py --config 5` times - prosody conv stack, GRU, style-token attention, the Prosody_l conditioning of all 48
+    WaveNet layers and the duration predictor's 448-channel input at the chip-filling launch shapes - against the oracle, bars of config 3's test
+    (the PE-conditioned long-form inverse is tests/longform_check.py's second mode)."""
+    case = make_case("PE", [120] * 32, [800] * 32, 53, f64=True)
+    check_f32(case, run_hip(case, "f32"), grad_tol64=2e-3)
+    check_bf16(case, run_hip(case, "bf16"))
+
+
 def test_config4_batch16_ge2e_dvectors():
     """BASELINE config 4 at its per-GPU batch (SE, GE2E d-vectors [B, 256], B = 16 x 800 frames): 125 fused workgroups leave CUs free, so the
     backward takes the fused data-gradient kernel on ALL flows (decoder.TUNE["fused_wn_bwd"] automatic) - asserted - with the conditioning
@@ -260,6 +272,7 @@ def test_run_to_run_reproducibility(mode):
 @pytest.mark.late(1)
 def test_long_form_inverse_at_full_width():
     here = os.path.dirname(os.path.abspath(__file__))
-    out = subprocess.run([sys.executable, os.path.join(here, "longform_check.py")], capture_output=True, text=True, timeout=1200, cwd=os.path.dirname(here))
+    out = subprocess.run([sys.executable, os.path.join(here, "longform_check.py")], capture_output=True, text=True, timeout=1800, cwd=os.path.dirname(here))
     assert out.returncode == 0 and "LONGFORM OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
-    print(out.stdout[-600:])
+    assert out.stdout.count("BF16 INVERSE MEL") == 2          # the bf16 inverse-flow mel bar ran in both modes (Vanilla, PE)
+    print(out.stdout[-1500:])
