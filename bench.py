@@ -500,7 +500,13 @@ def parity_sample(model, cfg, batch, cond, n=4):
     mmask = O.mask_from_lengths(ml.cpu(), mels.shape[2])
     a, oa = attn.cpu(), o["attn"]
     differ = ((a[:, :, :oa.shape[2]] != oa).any(1).float() * mmask[:, 0, :oa.shape[2]]).sum().item() / max(1.0, mmask.sum().item())
-    return {"utterances": int(n), "frames_aligned_differently": round(differ, 5),
+    # the moved frames in the oracle's own terms: the total score of this path on the oracle's fp32 score matrix against the oracle's optimum, per frame and relative
+    # to the mean score magnitude (tests/test_gpu_benchmarked_sizes.py check_bf16: <= 1e-3 is the bar there) - near-ties move frames without losing score
+    logp = o["logp"]
+    frames = oa.sum((1, 2)).clamp_min(1)
+    spread = (logp * oa).abs().sum((1, 2)) / frames
+    deficit = (((logp * oa).sum((1, 2)) - (logp * a[:, :, :logp.shape[2]]).sum((1, 2))) / frames / spread.clamp_min(1e-6)).max().item()
+    return {"utterances": int(n), "frames_aligned_differently": round(differ, 5), "path_score_deficit": float(f"{deficit:.3e}"),
             "z_max_err": round(float(((z.cpu() - o["z"]) * mmask).abs().max()), 6), "nll_abs_err": round(abs(float(nll) - float(onll)), 7),
             "note": "benchmarked model (current weights, eval mode, this run's arithmetic mode) vs oracle/glowtts_ref.py (fp32 CPU) on the first utterances "
                     "of the timed batch; alignment bit-exactness is a property of the MAS operator on identical fp32 scores and of the f32 mode"}

@@ -85,12 +85,13 @@ struct c2d_args {
 
 #define C2D_PICK(ci, f) ((ci) == 0 ? p.cls[0].f : (ci) == 1 ? p.cls[1].f : (ci) == 2 ? p.cls[2].f : p.cls[3].f)
 
-template <typename CT, int NI, int WM>
+// NI x 32 columns per workgroup (blockIdx.y walks the column tiles: small problems are cut along N as well, so that more than a dozen CUs work on them),
+// WM x 32 rows, NSUB K chunks per super-step (one barrier pair; deep K with few rows: 4, so that the serial chain of steps is short)
+template <typename CT, int NI, int WM, int NSUB>
 __global__ __launch_bounds__(WM * 64) void c2d_gemm_kernel(const c2d_args p)
 {
     constexpr int KC = P2<CT>::KC, E = P2<CT>::E;
     constexpr int BM = WM * 32, BN = NI * 32, NT = WM * 64;
-    constexpr int NSUB = 2;                                    // K chunks per super-step (one barrier pair)
     constexpr int A_IT = 2;                                    // BM * 4 slots / NT threads
     constexpr int W_IT = (BN * 4 + NT - 1) / NT;
     constexpr int NLD = E / 4;                                 // 16-byte global loads per LDS slot
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(WM * 64) void c2d_gemm_kernel(const c2d_args p)
     if (p.ncls > 1 && (int)blockIdx.x >= p.cls[1].tile0) ci = 1;
     if (p.ncls > 2 && (int)blockIdx.x >= p.cls[2].tile0) ci = 2;
     if (p.ncls > 3 && (int)blockIdx.x >= p.cls[3].tile0) ci = 3;
-    const unsigned char* wimg = reinterpret_cast<const unsigned char*>(C2D_PICK(ci, w));
+    const int n0 = blockIdx.y * BN, npad = C2D_PICK(ci, npad);
+    const unsigned char* wimg = reinterpret_cast<const unsigned char*>(C2D_PICK(ci, w)) + (long)n0 * 64;
     const int KCH = C2D_PICK(ci, kchunks), K = C2D_PICK(ci, K);
     const int Hr = C2D_PICK(ci, Hr), Wr = C2D_PICK(ci, Wr);
     const int sh = C2D_PICK(ci, sh), oh0 = C2D_PICK(ci, oh0), nseg = C2D_PICK(ci, nseg);
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(WM * 64) void c2d_gemm_kernel(const c2d_args p)
 #pragma unroll
         for (int j = 0; j < NSUB; ++j) {
             const int kc = min(ss * NSUB + j, KCH - 1);
-            const unsigned char* wb = wimg + (long)kc * BN * 64;
+            const unsigned char* wb = wimg + (long)kc * npad * 64;
 #pragma unroll
             for (int it = 0; it < W_IT; ++it) {
                 const int idx = min(tid + it * NT, BN * 4 - 1);
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(WM * 64) void c2d_gemm_kernel(const c2d_args p)
         if (off < 0) continue;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const int n = ni * 32 + l31;
+            const int n = n0 + ni * 32 + l31;
             if (n >= p.N) continue;
             float v = acc[ni][r];
             if (p.relu) v = fmaxf(v, 0.f);
@@ -263,19 +265,24 @@ __global__ __launch_bounds__(WM * 64) void c2d_gemm_kernel(const c2d_args p)
     }
 }
 
-template <typename CT, int NI>
-int c2d_launch(const c2d_args& a, int total_tiles128, int total_tiles64, bool wide, hipStream_t s)
+template <typename CT, int NI, int WM, int NSUB>
+int c2d_launch(const c2d_args& a, int tiles, int ny, hipStream_t s)
 {
-    if (wide) hipLaunchKernelGGL((c2d_gemm_kernel<CT, NI, 4>), dim3(total_tiles128), dim3(256), 0, s, a);
-    else      hipLaunchKernelGGL((c2d_gemm_kernel<CT, NI, 2>), dim3(total_tiles64), dim3(128), 0, s, a);
+    hipLaunchKernelGGL((c2d_gemm_kernel<CT, NI, WM, NSUB>), dim3(tiles, ny), dim3(WM * 64), 0, s, a);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
-int c2d_dispatch(c2d_args& a, int precision, hipStream_t s)
+template <typename CT>
+int c2d_dispatch_t(c2d_args& a, hipStream_t s)
 {
-    // rows per workgroup: 128 when that still gives every CU two workgroups, else 64
-    long t128 = 0, t64 = 0;
-    for (int c = 0; c < a.ncls; ++c) { const long rows = (long)a.B * a.cls[c].Hr * a.cls[c].Wr; t128 += (rows + 127) / 128; t64 += (rows + 63) / 64; }
+    // rows per workgroup: 128 when that still gives every CU two workgroups, else 64; few row tiles: one 32-column tile per workgroup
+    long t128 = 0;
+    int kmax = 0;
+    for (int c = 0; c < a.ncls; ++c) {
+        const long rows = (long)a.B * a.cls[c].Hr * a.cls[c].Wr;
+        t128 += (rows + 127) / 128;
+        if (a.cls[c].kchunks > kmax) kmax = a.cls[c].kchunks;
+    }
     const bool wide = t128 >= 512;
     int t0 = 0;
     for (int c = 0; c < a.ncls; ++c) {
@@ -283,21 +290,28 @@ int c2d_dispatch(c2d_args& a, int precision, hipStream_t s)
         a.cls[c].tile0 = t0;
         t0 += (int)(wide ? (rows + 127) / 128 : (rows + 63) / 64);
     }
-    const int NI = pad32(a.N) / 32;
-    if (precision == GLOWTTS_BF16) {
-        switch (NI) {
-            case 1: return c2d_launch<__bf16, 1>(a, (int)t128, (int)t64, wide, s);
-            case 2: return c2d_launch<__bf16, 2>(a, (int)t128, (int)t64, wide, s);
-            case 4: return c2d_launch<__bf16, 4>(a, (int)t128, (int)t64, wide, s);
-            default: return GLOWTTS_E_ARG;
+    const int NIall = pad32(a.N) / 32;
+    if (NIall != 1 && NIall != 2 && NIall != 4) return GLOWTTS_E_ARG;
+    if (wide) {
+        switch (NIall) {
+            case 1: return c2d_launch<CT, 1, 4, 2>(a, t0, 1, s);
+            case 2: return c2d_launch<CT, 2, 4, 2>(a, t0, 1, s);
+            default: return c2d_launch<CT, 4, 4, 2>(a, t0, 1, s);
         }
     }
-    switch (NI) {
-        case 1: return c2d_launch<float, 1>(a, (int)t128, (int)t64, wide, s);
-        case 2: return c2d_launch<float, 2>(a, (int)t128, (int)t64, wide, s);
-        case 4: return c2d_launch<float, 4>(a, (int)t128, (int)t64, wide, s);
-        default: return GLOWTTS_E_ARG;
+    const bool cutn = NIall > 1 && (long)t0 * NIall <= 1024;           // column tiles of 32: the chip still is not over-subscribed
+    const bool deep = kmax >= 12;
+    if (cutn) return deep ? c2d_launch<CT, 1, 2, 4>(a, t0, NIall, s) : c2d_launch<CT, 1, 2, 2>(a, t0, NIall, s);
+    switch (NIall) {
+        case 1: return deep ? c2d_launch<CT, 1, 2, 4>(a, t0, 1, s) : c2d_launch<CT, 1, 2, 2>(a, t0, 1, s);
+        case 2: return deep ? c2d_launch<CT, 2, 2, 4>(a, t0, 1, s) : c2d_launch<CT, 2, 2, 2>(a, t0, 1, s);
+        default: return deep ? c2d_launch<CT, 4, 2, 4>(a, t0, 1, s) : c2d_launch<CT, 4, 2, 2>(a, t0, 1, s);
     }
+}
+
+int c2d_dispatch(c2d_args& a, int precision, hipStream_t s)
+{
+    return precision == GLOWTTS_BF16 ? c2d_dispatch_t<__bf16>(a, s) : c2d_dispatch_t<float>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -359,16 +373,28 @@ __global__ __launch_bounds__(512) void c2d_first_wgrad_kernel(const float* __res
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[k][i] = 0.f;
     if (slot < slots) {
-        for (long px = (long)blockIdx.x * slots + slot; px < npx; px += (long)gridDim.x * slots) {
-            const int b = (int)(px / (Ho * Wo)), rem = (int)(px - (long)b * Ho * Wo);
-            const int ho = rem / Wo, wo = rem - ho * Wo;
-            float xv[9];
-            first_patch(x, b, ho, wo, H, W, xv);
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dpre + px * Co + 4 * g);
+        // four pixels per round: their 4 + 36 loads are issued together (a round is one memory round trip, whatever it carries)
+        const long stride = (long)gridDim.x * slots;
+        for (long px0 = (long)blockIdx.x * slots + slot; px0 < npx; px0 += 4 * stride) {
+            float xv[4][9];
+            f32x4 d[4];
 #pragma unroll
-            for (int k = 0; k < 9; ++k)
+            for (int u = 0; u < 4; ++u) {
+                const long px = px0 + u * stride;
+                const bool ok = px < npx;
+                const long pc = ok ? px : px0;
+                const int b = (int)(pc / (Ho * Wo)), rem = (int)(pc - (long)b * Ho * Wo);
+                const int ho = rem / Wo, wo = rem - ho * Wo;
+                first_patch(x, b, ho, wo, H, W, xv[u]);
+                const f32x4 dv = *reinterpret_cast<const f32x4*>(dpre + pc * Co + 4 * g);
+                d[u] = ok ? dv : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[k][i] += xv[k] * d[i];
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[k][i] += xv[u][k] * d[u][i];
         }
     }
 #pragma unroll
@@ -396,10 +422,10 @@ struct c2d_wgrad_args {
 template <int MF>
 __global__ __launch_bounds__(256) void c2d_wgrad_kernel(const c2d_wgrad_args p)
 {
-    constexpr int RS = 32, CO = MF * 32;
+    constexpr int RS = MF <= 2 ? 64 : 32, CO = MF * 32;                 // rows per step (a step is one memory round trip: the fatter the better; LDS: 2 x RS x (AST + BST) x 4 B)
     constexpr int AST = CO + ((MF & 1) ? 0 : 32), BST = 128 + 32;         // row strides = 32 mod 64 floats: the two half-waves of a read hit disjoint banks
     constexpr int A_IT = RS * CO / 4 / 256 > 0 ? RS * CO / 4 / 256 : 1;    // float4 items per thread (Co = 32: one)
-    constexpr int B_IT = RS * 128 / 4 / 256;                               // 4
+    constexpr int B_IT = RS * 128 / 4 / 256;                               // 4 or 8
     extern __shared__ __attribute__((aligned(16))) float wg_smem[];         // At [2][RS * AST] | Bt [2][RS * BST] (80 KiB at Co = 128: dynamic)
     float (*At)[RS * AST] = reinterpret_cast<float (*)[RS * AST]>(wg_smem);
     float (*Bt)[RS * BST] = reinterpret_cast<float (*)[RS * BST]>(wg_smem + 2 * RS * AST);
@@ -506,6 +532,9 @@ struct c2d_reduce_table { glowtts_c2d_reduce_job j[GLOWTTS_C2D_MAX_LAYERS]; int 
 
 __global__ __launch_bounds__(256) void c2d_reduce_kernel(const c2d_reduce_table t)
 {
+    // 64 elements per workgroup x 4 split lanes: lane g of an element sums the splits g, g + 4, ... four loads at a time (a serial walk over 500 partial
+    // images was 180 us of load latency), the four lane sums are added in a fixed order: deterministic
+    __shared__ float lanes[4][64];
     int i = 0;
 #pragma unroll
     for (int k = 1; k < GLOWTTS_C2D_MAX_LAYERS; ++k) if (k < t.n && (int)blockIdx.x >= t.j[k].block0) i = k;
@@ -514,13 +543,26 @@ __global__ __launch_bounds__(256) void c2d_reduce_kernel(const c2d_reduce_table 
     const int splits = C2D_RPICK(i, splits), Ci = C2D_RPICK(i, Ci), Co = C2D_RPICK(i, Co), block0 = C2D_RPICK(i, block0);
     const int K9 = 9 * Ci;
     const long total = (long)Co * K9;
-    const long e = (long)((int)blockIdx.x - block0) * 256 + threadIdx.x;          // e = co * K9 + col
-    if (e >= total) return;
+    const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long e = (long)((int)blockIdx.x - block0) * 64 + el;                    // e = co * K9 + col
     float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += partial[(long)sp * total + e];
-    const int co = (int)(e / K9), col = (int)(e - (long)co * K9);
-    const int kh = col / (3 * Ci), kw = (col / Ci) % 3, ci = col % Ci;
-    dw[(((long)co * Ci + ci) * 3 + kh) * 3 + kw] = s;
+    if (e < total) {
+        int sp = g;
+        for (; sp + 12 < splits; sp += 16) {
+            const float a0 = partial[(long)sp * total + e], a1 = partial[(long)(sp + 4) * total + e];
+            const float a2 = partial[(long)(sp + 8) * total + e], a3 = partial[(long)(sp + 12) * total + e];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; sp < splits; sp += 4) s += partial[(long)sp * total + e];
+    }
+    lanes[g][el] = s;
+    __syncthreads();
+    if (g == 0 && e < total) {
+        s = ((lanes[0][el] + lanes[1][el]) + lanes[2][el]) + lanes[3][el];
+        const int co = (int)(e / K9), col = (int)(e - (long)co * K9);
+        const int kh = col / (3 * Ci), kw = (col / Ci) % 3, ci = col % Ci;
+        dw[(((long)co * Ci + ci) * 3 + kh) * 3 + kw] = s;
+    }
 }
 
 bool c2d_shape_ok(int B, int H, int W, int Ci, int Co)
@@ -535,14 +577,15 @@ void wgrad_plan(int B, int H, int W, int Ci, int Co, int* nsplit, int* rows_per_
 {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const long rows = (long)B * Ho * Wo;
-    if (Ci == 1) { *nsplit = (int)((rows + 1023) / 1024 < 512 ? (rows + 1023) / 1024 : 512); if (*nsplit < 1) *nsplit = 1; *rows_per_split = 0; return; }
+    if (Ci == 1) { *nsplit = (int)((rows + 255) / 256 < 512 ? (rows + 255) / 256 : 512); if (*nsplit < 1) *nsplit = 1; *rows_per_split = 0; return; }
     const int K9 = 9 * Ci, ntn = (K9 + 127) / 128;
-    long cap_bytes = (long)(4.7 * 1024 * 1024) / ((long)Co * K9 * 4);
-    long ns = 768 / ntn;
+    const int RS = Co <= 64 ? 64 : 32;
+    long cap_bytes = (long)(12 * 1024 * 1024) / ((long)Co * K9 * 4);       // partial images: at most ~12 MB per layer
+    long ns = 1024 / ntn;                                                  // ~4 workgroups per CU
     if (cap_bytes < ns) ns = cap_bytes;
-    if ((rows + 31) / 32 < ns) ns = (rows + 31) / 32;
+    if ((rows + RS - 1) / RS < ns) ns = (rows + RS - 1) / RS;
     if (ns < 1) ns = 1;
-    long rps = ((rows + ns - 1) / ns + 31) / 32 * 32;
+    long rps = ((rows + ns - 1) / ns + RS - 1) / RS * RS;
     *rows_per_split = (int)rps;
     *nsplit = (int)((rows + rps - 1) / rps);
 }
@@ -675,7 +718,7 @@ extern "C" int glowtts_conv3x3s2_wgrad(const float* x, const float* dpre, float*
     a.rows = (long)B * Ho * Wo; a.rows_per_split = rps;
     const dim3 grid((a.K9 + 127) / 128, ns);
     GLOWTTS_NOTE_STATIC("conv3x3s2_wgrad");
-#define C2D_WG(MF) do { constexpr int AST_ = MF * 32 + ((MF & 1) ? 0 : 32); constexpr size_t lds = (size_t)2 * 32 * (AST_ + 160) * sizeof(float); \
+#define C2D_WG(MF) do { constexpr int AST_ = MF * 32 + ((MF & 1) ? 0 : 32); constexpr size_t lds = (size_t)2 * (MF <= 2 ? 64 : 32) * (AST_ + 160) * sizeof(float); \
         static bool done = false; if (!done) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&c2d_wgrad_kernel<MF>), \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GLOWTTS_E_LAUNCH; done = true; } \
         hipLaunchKernelGGL(c2d_wgrad_kernel<MF>, grid, dim3(256), lds, s, a); } while (0)
@@ -698,7 +741,7 @@ extern "C" int glowtts_conv3x3s2_wgrad_reduce(const glowtts_c2d_reduce_job* jobs
         if (!jobs[i].partial || !jobs[i].dw || jobs[i].splits < 1) return GLOWTTS_E_ARG;
         t.j[i] = jobs[i];
         t.j[i].block0 = b0;
-        b0 += (int)(((long)jobs[i].Co * 9 * jobs[i].Ci + 255) / 256);
+        b0 += (int)(((long)jobs[i].Co * 9 * jobs[i].Ci + 63) / 64);
     }
     t.n = njobs;
     GLOWTTS_NOTE_STATIC("conv3x3s2_wgrad_reduce");

@@ -150,6 +150,12 @@ class PrepJobs:
 _WSTREAM = {}
 
 
+def _engine_callbacks_ok():
+    """queue_callback is only legal while the autograd engine is running a backward pass (it is, whenever DecoderFunction.backward runs under
+    loss.backward() / torch.autograd.grad)."""
+    return hasattr(torch.autograd.Variable._execution_engine, "queue_callback")
+
+
 # Data parallel overlap (bench.py, N > 1): the big k-tap weight gradients are launched first and their all-reduce starts while the
 # "tail" - the 1x1 weight-gradient groups and the weight-norm backward of their classes - is still running.  With TAIL["defer"] set the
 # backward queues the tail's launches here instead of issuing them; `flush_tail_wgrads()` issues them (bench.py captures that as a
@@ -180,7 +186,7 @@ TAIL = {"defer": False, "pending": []}
 #       memory system at the head of the step and the decoder's forward ends 45 us later: 5.24-5.30 against 5.20-5.23 ms/step (three alternating pairs)
 #   prep_fused: training on the fused bf16 path forms w = g v / ||v|| and every weight image in ONE launch (csrc/prep_ops.hip) instead of 4 weight-norm +
 #       ~22 packing launches (0.42 -> ~0.1 ms at the head of the step, round 4)
-TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0, "dec_chunks": 1, "cond_hip": True, "fwd_tail_aside": False, "drop_skip32": True, "wgrad_tail_splits": 2, "prep_bwd_late": True, "prep_bwd_gentle": True}
+TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0, "dec_chunks": 1, "cond_hip": True, "fwd_tail_aside": False, "drop_skip32": True, "wgrad_tail_splits": 2, "prep_bwd_late": True, "prep_bwd_gentle": True, "tail_aside": True}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
@@ -1022,7 +1028,7 @@ class DecoderFunction(torch.autograd.Function):
         # bytes a workgroup keeps in flight; S x the workgroups over B / S utterances each (one tap: no halo, any row cut is exact) into S partial images,
         # summed in a fixed order into the gradient tensors by ONE launch (glowtts_sum_slices_seg)
         S_t = int(TUNE["wgrad_tail_splits"])
-        tail_seg = None
+        tail_seg = tail_part = tail_ctx = None
         if S_t > 1 and h0bf and B % S_t == 0 and int(TUNE["wgrad_split"]) == 1:
             names = ["w_end", "b_end", "w_rs_last", "b_rs_last", "w_start", "b_start"] + (["w_rs", "b_rs"] if Lw > 1 else [])
             if all(G[k].is_contiguous() and G[k].numel() % 4 == 0 and G[k].data_ptr() % 16 == 0 for k in names):
@@ -1155,6 +1161,15 @@ class DecoderFunction(torch.autograd.Function):
             keep = (buf, dins, dskip, dh0, dhn, douts, G)
             TAIL["pending"].append(lambda keep=keep: (gp.launch_segment(0), g1.launch_segment(0), sum_tail()))
         else:
+            # Conditioned modes (SE / PE / GR): the conditioning gradient is complete when the data-gradient chain ends, and a whole backward pass hangs
+            # on it (CondLinear, then the prosody encoder: ~60 launches; config 5 ran them BEHIND the decoder's ~0.9 ms of weight-gradient launches).
+            # The tail - weight-gradient groups, weight-norm backward, parameter-gradient sums - needs nothing from that pass and nothing of the pass
+            # needs the tail: it goes to the weight-gradient stream, the caller's stream carries on with the conditioning encoders' backward, and the
+            # two are joined by a callback the autograd engine runs when the whole backward has been issued (TUNE["tail_aside"]).
+            if dcond is not None and TUNE["tail_aside"] and _engine_callbacks_ok():
+                side.wait_stream(main)
+                tail_ctx = torch.cuda.stream(side)
+                tail_ctx.__enter__()
             for grp in (gk, gp, g1):
                 grp.launch_segment(0)
             sum_tail()
@@ -1185,6 +1200,12 @@ class DecoderFunction(torch.autograd.Function):
         _lib.check(L.glowtts_decoder_param_grads(d_an.data_ptr(), dld.data_ptr(), rowmask.data_ptr(), prep.winfo.data_ptr(), G["an_logs"].data_ptr(),
                                                  G["an_bias"].data_ptr(), G["inv_w"].data_ptr(), F_, B, T + 2 * ROW_PAD, C, _lib.stream()),
                    "glowtts_decoder_param_grads")
+        if tail_ctx is not None:
+            tail_ctx.__exit__(None, None, None)
+            # everything the tail reads or writes stays alive until the join has been queued on the caller's stream (blocks handed back to the caching
+            # allocator before that could be given out on that stream while the tail still uses them)
+            keep = (buf, dins, dskip, dh0, dhn, douts, douts_bf, G, RET, GV, scratch, d_an, dld, tail_part, gk, gp, g1, prep, rowmask)
+            torch.autograd.Variable._execution_engine.queue_callback(lambda keep=keep, main=main, side=side: main.wait_stream(side))
         dmel = unsqueeze_rows(cfg, dx, ctx.lengths, B, Tm) if ctx.want_dmel else None
         if dcond is not None:
             dcond = (dcond.to(torch.float64) * 2.0 ** -40).to(torch.float32)

@@ -54,12 +54,14 @@ def run_mode(mode):
         ref[1, :, 300:] = -4.0
         pe = dict(mels_for_prosody=ref, mel_lengths_for_prosody=ref_l)
         pe_dev = {k: v.cuda() for k, v in pe.items()}
-    # length scales that stretch whatever the (random-init) duration predictor says to > 2000 frames per utterance
-    with torch.no_grad():
-        base = O.inference(sd, cfg, tokens, tl, noise, torch.ones(B), noise_scale=0.667, **pe)[1].float()
-    ls = (2300.0 / base) * torch.tensor([1.0, 0.93])
-    with torch.no_grad():
-        want, wl, wa = O.inference(sd, cfg, tokens, tl, noise, ls, noise_scale=0.667, **pe)
+    # length scales that stretch whatever the (random-init) duration predictor says to > 2000 frames per utterance (ceil() per token: iterate)
+    ls = torch.tensor([8.0, 8.0])
+    for _ in range(4):
+        with torch.no_grad():
+            want, wl, wa = O.inference(sd, cfg, tokens, tl, noise, ls, noise_scale=0.667, **pe)
+        if int(wl.min()) >= 2100 and int(wl.max()) <= 2900:
+            break
+        ls = ls * torch.tensor([2400.0, 2250.0]) / wl.float()
     assert int(wl.min()) >= 2000 and int(wl.max()) <= 3072, wl
     f32_front = None
     for precision in ("f32", "bf16"):
