@@ -889,7 +889,15 @@ def actnorm_data_init(cfg, W, mels, lengths, cond=None, allreduce=None, pitch=No
 # the second branch late), and the 80-us preparation launch sat behind that.  `early_prepare` builds the _Prepared; DecoderFunction.forward picks it up.
 EARLY = {"prep": None, "key": None}
 # A stream the caller joins with its own before it consumes z / the log-determinants (modules.GlowTTS.forward: the text encoder's stream), or None
-AUX = {"stream": None}
+AUX = {"stream": None, "stacks": None}
+
+
+def _leaf_grads_unset():
+    """True when no leaf parameter of the decoder holds a gradient yet (zero_grad(set_to_none=True), the trainer's and torch's default): AccumulateGrad then
+    takes the returned tensors over without reading them."""
+    st = AUX["stacks"]() if AUX["stacks"] is not None else None
+    return st is not None and all(p.grad is None for ls in st.S.values() for p in ls.leaves)
+
 
 
 def _split_gv(weights):
@@ -1028,7 +1036,7 @@ class DecoderFunction(torch.autograd.Function):
         # bytes a workgroup keeps in flight; S x the workgroups over B / S utterances each (one tap: no halo, any row cut is exact) into S partial images,
         # summed in a fixed order into the gradient tensors by ONE launch (glowtts_sum_slices_seg)
         S_t = int(TUNE["wgrad_tail_splits"])
-        tail_seg = tail_part = tail_ctx = None
+        tail_seg = tail_part = tail_fns = None
         if S_t > 1 and h0bf and B % S_t == 0 and int(TUNE["wgrad_split"]) == 1:
             names = ["w_end", "b_end", "w_rs_last", "b_rs_last", "w_start", "b_start"] + (["w_rs", "b_rs"] if Lw > 1 else [])
             if all(G[k].is_contiguous() and G[k].numel() % 4 == 0 and G[k].data_ptr() % 16 == 0 for k in names):
@@ -1164,15 +1172,17 @@ class DecoderFunction(torch.autograd.Function):
             # Conditioned modes (SE / PE / GR): the conditioning gradient is complete when the data-gradient chain ends, and a whole backward pass hangs
             # on it (CondLinear, then the prosody encoder: ~60 launches; config 5 ran them BEHIND the decoder's ~0.9 ms of weight-gradient launches).
             # The tail - weight-gradient groups, weight-norm backward, parameter-gradient sums - needs nothing from that pass and nothing of the pass
-            # needs the tail: it goes to the weight-gradient stream, the caller's stream carries on with the conditioning encoders' backward, and the
-            # two are joined by a callback the autograd engine runs when the whole backward has been issued (TUNE["tail_aside"]).
-            if dcond is not None and TUNE["tail_aside"] and _engine_callbacks_ok():
-                side.wait_stream(main)
-                tail_ctx = torch.cuda.stream(side)
-                tail_ctx.__enter__()
-            for grp in (gk, gp, g1):
-                grp.launch_segment(0)
-            sum_tail()
+            # needs the tail: it goes to the weight-gradient stream (`tail_fns`, issued by `release`), the caller's stream carries on with the conditioning
+            # encoders' backward, and the two are joined by a callback the autograd engine runs when the whole backward has been issued
+            # (TUNE["tail_aside"]; config 5 6.38 -> 6.08 ms/step, config 3 5.14 -> 5.11).  Only where what this function RETURNS for the tail's classes is
+            # final - the (g, v) form, whose gradients nothing but AccumulateGrad touches, and only while those leaves hold no gradient yet (an
+            # accumulating AccumulateGrad would read them on the caller's stream): with plain weights WeightNorm's own backward reads d w right away.
+            # Measured and rejected: holding the tail back until the prosody encoder's ~45 tiny launches are through (they take 24 us each beside 216
+            # one-per-CU weight-gradient workgroups): 6.20 against 6.08 - the tail is then the critical path behind them (profiles/r06_config5_timeline_hold.txt).
+            if dcond is not None and GV is not None and TUNE["tail_aside"] and _engine_callbacks_ok() and _leaf_grads_unset():
+                tail_fns = []
+            (tail_fns.append if tail_fns is not None else (lambda f: f()))(lambda: [grp.launch_segment(0) for grp in (gk, gp, g1)])
+            (tail_fns.append if tail_fns is not None else (lambda f: f()))(sum_tail)
         # weight-norm backward of the (g, v) form (Modules.py:766, 818, 825): d g, d v from d w; the classes whose d w comes from the deferrable
         # 1x1 groups are queued behind them
         GVgrad = {}
@@ -1191,21 +1201,42 @@ class DecoderFunction(torch.autograd.Function):
                     "glowtts_weightnorm_bwd")
                 if TAIL["defer"] and halves == 1 and k != "w_in":
                     TAIL["pending"].append(run)
+                elif tail_fns is not None:
+                    tail_fns.append(run)
                 else:
                     run()
-        stamp("dec_wgrads_done")
-        _lib.check(L.glowtts_colsum_batched(scratch.data_ptr(), d_an.data_ptr(), nblk_all, 2 * C + 16, F_, nscr, 2 * C + 16, _lib.stream()),
-                   "glowtts_colsum_batched")
-        # + the log-determinant terms of the parameters (Modules.py:694, 747): logdet_b += (sum logs + logdet(W) C/4) * len_b
-        _lib.check(L.glowtts_decoder_param_grads(d_an.data_ptr(), dld.data_ptr(), rowmask.data_ptr(), prep.winfo.data_ptr(), G["an_logs"].data_ptr(),
-                                                 G["an_bias"].data_ptr(), G["inv_w"].data_ptr(), F_, B, T + 2 * ROW_PAD, C, _lib.stream()),
-                   "glowtts_decoder_param_grads")
-        if tail_ctx is not None:
-            tail_ctx.__exit__(None, None, None)
+
+        def param_sums():
+            stamp("dec_wgrads_done")
+            _lib.check(L.glowtts_colsum_batched(scratch.data_ptr(), d_an.data_ptr(), nblk_all, 2 * C + 16, F_, nscr, 2 * C + 16, _lib.stream()),
+                       "glowtts_colsum_batched")
+            # + the log-determinant terms of the parameters (Modules.py:694, 747): logdet_b += (sum logs + logdet(W) C/4) * len_b
+            _lib.check(L.glowtts_decoder_param_grads(d_an.data_ptr(), dld.data_ptr(), rowmask.data_ptr(), prep.winfo.data_ptr(), G["an_logs"].data_ptr(),
+                                                     G["an_bias"].data_ptr(), G["inv_w"].data_ptr(), F_, B, T + 2 * ROW_PAD, C, _lib.stream()),
+                       "glowtts_decoder_param_grads")
+        if tail_fns is None:
+            param_sums()
+        else:
+            tail_fns.append(param_sums)
             # everything the tail reads or writes stays alive until the join has been queued on the caller's stream (blocks handed back to the caching
             # allocator before that could be given out on that stream while the tail still uses them)
-            keep = (buf, dins, dskip, dh0, dhn, douts, douts_bf, G, RET, GV, scratch, d_an, dld, tail_part, gk, gp, g1, prep, rowmask)
-            torch.autograd.Variable._execution_engine.queue_callback(lambda keep=keep, main=main, side=side: main.wait_stream(side))
+            keep = [(buf, dins, dskip, dh0, dhn, douts, douts_bf, G, RET, GV, scratch, d_an, dld, tail_part, gk, gp, g1, prep, rowmask), tail_fns]
+
+            def release():
+                if keep[1] is None:
+                    return
+                fns, keep[1] = keep[1], None
+                side.wait_stream(torch.cuda.current_stream(dev))          # (behind everything the releasing stream holds: the chain, or the held-back pass)
+                with torch.cuda.stream(side):
+                    for fn in fns:
+                        fn()
+
+            def at_end():
+                release()
+                main.wait_stream(side)
+                keep[0] = None
+            release()
+            torch.autograd.Variable._execution_engine.queue_callback(at_end)
         dmel = unsqueeze_rows(cfg, dx, ctx.lengths, B, Tm) if ctx.want_dmel else None
         if dcond is not None:
             dcond = (dcond.to(torch.float64) * 2.0 ** -40).to(torch.float32)

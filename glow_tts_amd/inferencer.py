@@ -24,6 +24,12 @@ class Inferencer:
         self.Load_Checkpoint(checkpoint_path)
 
     def Model_Generate(self):                                                    # Inference.py:116-136
+        # Arithmetic of the inverse flow: exact fp32 (the reference's; mels within 2e-4 of it) unless the yaml asks otherwise with the optional key
+        # `HIP_Inference_Precision`.  bf16 - the TRAINING default, `HIP_Precision` - leaves ~1e-2 rms / 0.3 worst-element error on the generated mel
+        # (tests/longform_check.py "BF16 INVERSE MEL"), above the 1e-3 the path promises, and inference is not the throughput-critical half.
+        import copy
+        self.hp = copy.copy(self.hp)
+        self.hp.HIP_Precision = str(getattr(self.hp, "HIP_Inference_Precision", "f32"))
         self.model_Dict = {"GlowTTS": GlowTTS(self.hp).to(self.device).eval()}
         self._graphed = None
 

@@ -300,6 +300,7 @@ class GlowTTS(torch.nn.Module):
         if not mels.is_cuda:
             raise RuntimeError("glow_tts_amd runs on the GPU only (no CPU fallback)")
         P = self._params()
+        decoder.stamp("fwd_begin")
         spk, pro = self._conditioning(P, speakers, mels_for_ge2e, mels, mel_lengths)
         ns_ = int(hp.Decoder.Num_Squeeze)
         if mels.shape[2] % ns_:                               # Squeeze cuts the frames that do not fill a group (Modules.py:897-898):
@@ -313,6 +314,8 @@ class GlowTTS(torch.nn.Module):
         decoder.stamp("fwd_enter_main")
         # the decoder's weight preparation goes out first: see decoder.EARLY
         stacks = self._stacks(P)
+        import weakref
+        decoder.AUX["stacks"] = weakref.ref(stacks)
         use_gv = bool(decoder.TUNE["prep_fused"] and torch.is_grad_enabled() and decoder.fused_wn_supported(self.dec_cfg) and
                       self.dec_cfg.precision == ops.BF16)
         W = stacks.weights(gv=use_gv)

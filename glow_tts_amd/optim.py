@@ -200,6 +200,8 @@ def grad_norm_and_coef(parameters, max_norm, _table_key="fused"):
     `RAdam.step(grad_scale=coef)`."""
     params = [p for p in parameters if p.grad is not None]
     dev = params[0].grad.device
+    from . import decoder
+    decoder.stamp("clip_begin")
     tab = _CLIP_TABLES.setdefault((_table_key, id(params[0]), len(params)), _JobTable())
     tab.update([(p.grad, p.grad, None, None) for p in params], dev, canonical=True)
     partial, out = torch.empty(tab.blocks, device=dev), torch.empty(2, device=dev)

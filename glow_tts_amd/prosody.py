@@ -157,6 +157,8 @@ class _ConvStack(torch.autograd.Function):
             H, W = Ho, Wo
         ctx.save_for_backward(*acts, *weights)
         ctx.cfg = (images, precision, shapes, B)
+        from . import decoder
+        decoder.stamp("pros_convs_fwd_end")
         return acts[-1]
 
     @staticmethod
@@ -167,6 +169,8 @@ class _ConvStack(torch.autograd.Function):
         n = len(shapes)
         acts, weights = ctx.saved_tensors[:n + 1], ctx.saved_tensors[n + 1:]
         s = _lib.stream()
+        from . import decoder
+        decoder.stamp("pros_convs_bwd_begin")
         dpre = dout.contiguous() * (acts[n] > 0).to(dout.dtype)          # the last layer's ReLU (tiny: [B, 2, 13, 128] at the default sizes)
         jobs = (_ReduceJob * n)()
         keep, grads = [], [None] * n
@@ -188,6 +192,8 @@ class _ConvStack(torch.autograd.Function):
                            "glowtts_conv3x3s2_dgrad")
                 dpre = dx
         _lib.check(L.glowtts_conv3x3s2_wgrad_reduce(jobs, n, s), "glowtts_conv3x3s2_wgrad_reduce")
+        from . import decoder
+        decoder.stamp("pros_convs_bwd_end")
         return (None, None, None) + tuple(grads)
 
 
