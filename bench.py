@@ -588,7 +588,6 @@ def main():
                     "even with one rank: exercises RCCL on a single-GPU box")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to smoke-test the "
                     "multi-rank code path on a single-GPU box together with --one-device)")
-    ap.add_argument("--split-backward", action="store_true", help="experiment: the duration loss's backward as a second pass behind the main one")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel eagerly instead of replaying the "
                     "captured hipGraph of the step (default: graph replay; at B = 32 the eager step is bound by host launch work)")
     ap.set_defaults(graph=True)
@@ -635,9 +634,9 @@ def main():
 
     from glow_tts_amd import _lib, decoder as _dec
     from glow_tts_amd import conv_fn as _cf, ops as _ops
-    for kv in args.tune:                                      # decoder.TUNE, or the encoder's block-function / packing switches (conv_fn.FUSE, ops.FAST_PACK)
+    for kv in args.tune:                                      # decoder.TUNE, or the encoder's block-function switches (conv_fn.FUSE)
         k, v = kv.split("=")
-        d = _dec.TUNE if k in _dec.TUNE else _cf.FUSE if k in _cf.FUSE else _ops.FAST_PACK
+        d = _dec.TUNE if k in _dec.TUNE else _cf.FUSE
         d[k] = type(d[k])(int(v))
     if args.timeline:
         _dec.STAMPS["buf"] = torch.zeros(4096, dtype=torch.int64, device=dev)
@@ -700,14 +699,8 @@ def main():
             def fwd_bwd():
                 mle, length = forward_losses(model, mle_loss, batch, cond)
                 model.zero_grad(set_to_none=True)
-                if args.split_backward:
-                    # experiment: the duration loss in a backward pass of its own BEHIND the main one - its chain (torch glue, two conv data gradients) otherwise runs
-                    # first on the encoder's stream, in front of the transformer's backward (autograd runs the nodes created last first)
-                    from glow_tts_amd.conv_fn import backward_main_then_late
-                    backward_main_then_late(mle * wfr if dp else mle, length / world if dp else length, model.aux_stream())
-                else:
-                    total = mle * wfr + length / world if dp else mle + length
-                    total.backward()
+                total = mle * wfr + length / world if dp else mle + length
+                total.backward()
                 if opt is not None and not dp:
                     clip_and_update()
                 return (mle + length).detach()

@@ -200,24 +200,6 @@ class ParamGate(torch.autograd.Function):
         return (None,) + grads
 
 
-# Two-pass backward (round 5 experiment, bench.py --split-backward; NOT adopted).  autograd runs the nodes created last first: the duration predictor's backward - ~25
-# launches of loss / projection glue and two conv data gradients, none of which the transformer's gradients depend on (Modules.py:277-282: it reads DETACHED
-# features) - sits at the head of the encoder stream's backward, in front of the chain the step waits for.  `backward_main_then_late(main, late, stream)` runs
-# `main.backward()` and then `late.backward()` with `stream` (the encoder's) current, so that the second pass queues behind the first one's work on THAT stream instead
-# of behind everything the first pass put on the caller's stream (autograd makes the caller's stream wait for every stream a pass used, and seeds the next pass there).
-# Gradients are those of (main + late).backward(): the two losses share no differentiable path.  (Holding the first pass's weight-gradient flush back for the second
-# is not possible: AccumulateGrad may copy a gradient that is a view of the tape's arena, and would copy it unfilled.)
-def backward_main_then_late(main, late, stream=None):
-    main.backward()
-    if stream is None:
-        late.backward()
-        return
-    cur = torch.cuda.current_stream()
-    with torch.cuda.stream(stream):
-        late.backward()
-    cur.wait_stream(stream)
-
-
 def bf16_of(t):
     """The bf16 copy a producer attached to its fp32 rows (`LayerNormRows` with want_bf16), or None."""
     return getattr(t, "_bf16", None)

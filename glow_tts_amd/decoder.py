@@ -177,16 +177,15 @@ TAIL = {"defer": False, "pending": []}
 #       first half of the step waits for (enc_fwd_project 87 us after dec_fwd_end with every flow fused); one per-conv flow gives it the
 #       CUs it needs: 5.55 / 5.56 vs 5.61 / 5.59 ms/step (2 flows: 5.57 / 5.56), same box, alternating runs.  (Round 3's first measurement,
 #       before the alignment test compared path QUALITY instead of a count of moved frames, had left it off.)
-#   bwd_packs_side / enc_priority: two scheduling experiments of round 3, both off: the backward-only weight images
-#       packed on a third stream joined when the backward starts (5.61 / 5.67 vs 5.68 / 5.66 ms/step: inside the spread); the encoder's
-#       stream at high priority (-1: 9.1 vs 5.6 ms/step - its ~170 short launches then take the CUs from under the chip-filling kernels)
+#   bwd_packs_side: a scheduling experiment of round 3, off: the backward-only weight images
+#       packed on a third stream joined when the backward starts (5.61 / 5.67 vs 5.68 / 5.66 ms/step: inside the spread)
 #   enc_pack_split: round-4 experiment, off.  The encoder's weight images in two launches - the prenet's forward images on its stream, the other 95 % on a
 #       third stream forked from the origin stream and joined in front of the transformer (forked from the encoder's stream - a fork of a fork - hipStreamEndCapture
 #       crashed on ROCm 7.2): the encoder's projection then lands 7 us after the decoder's forward instead of 60-90, but the three packing kernels share the
 #       memory system at the head of the step and the decoder's forward ends 45 us later: 5.24-5.30 against 5.20-5.23 ms/step (three alternating pairs)
 #   prep_fused: training on the fused bf16 path forms w = g v / ||v|| and every weight image in ONE launch (csrc/prep_ops.hip) instead of 4 weight-norm +
 #       ~22 packing launches (0.42 -> ~0.1 ms at the head of the step, round 4)
-TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "enc_priority": 0, "fwd_packs_split": 0, "dec_chunks": 1, "cond_hip": True, "fwd_tail_aside": False, "drop_skip32": True, "wgrad_tail_splits": 2, "prep_bwd_late": True, "prep_bwd_gentle": True, "tail_aside": True}
+TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "fwd_packs_split": 0, "cond_hip": True, "drop_skip32": True, "wgrad_tail_splits": 2, "prep_bwd_late": True, "prep_bwd_gentle": True, "tail_aside": True}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
@@ -617,7 +616,7 @@ class _Prepared:
 
 def _dims(cfg, B, T, drop_p=0.0, seed=None, flow=0, chunk=0):
     """seed: None or a device int32/uint32 tensor with one element (re-drawn on device every step, hipGraph-safe).
-    chunk: index of the utterance chunk this launch serves (TUNE["dec_chunks"]; its rows are numbered from 0: the dropout hash gets its own key)."""
+    chunk: 0 (round 5's utterance-chunk experiment numbered its chunks' rows from 0 and gave each its own dropout key)."""
     return FlowDims(B, T, cfg.C, cfg.H, cfg.L, cfg.k, cfg.precision, float(drop_p), (1000003 * flow + 7368787 * chunk) & 0xFFFFFFFF,
                     seed.data_ptr() if seed is not None else None, int(cfg.act_bf16))
 
@@ -698,21 +697,6 @@ def _cond_rows(cfg, prep, f, prow, pitch_w, pitch_b, Tp):
     return cr.contiguous()
 
 
-# Utterance chunks (TUNE["dec_chunks"] = n > 1): the flows' launches are row-local per utterance, so the batch can run as n independent chains - utterances
-# [b0, b0 + B / n) each - on n streams forked from the caller's and joined behind the last flow.  A fused coupling workgroup owns its CU for ~100 us and the
-# whole batch's launch fills the chip: the text encoder's short dependent launches on the other stream then advance ONE launch per decoder kernel boundary.
-# n chains of a quarter-chip launch each drift apart and give the encoder a boundary every ~25 us instead of every ~110.
-_CHUNK_STREAMS = {}
-
-
-def _chunks(B, prep, pitch):
-    """[(index, first utterance, utterances)] of the decoder's utterance chunks for this batch."""
-    n = int(TUNE["dec_chunks"])
-    if n <= 1 or pitch is not None or B % n or B // n < 1:
-        return [(0, 0, B)]
-    return [(i, i * (B // n), B // n) for i in range(n)]
-
-
 def _params_at(prep, f, b0):
     """Flow f's parameter struct as utterance b0's chunk sees it: the per-utterance conditioning rows start at b0."""
     p = prep.params[f]
@@ -721,24 +705,6 @@ def _params_at(prep, f, b0):
     q = FlowParams.from_buffer_copy(p)
     q.cond = p.cond + 4 * b0 * p.ldcond
     return q
-
-
-def _run_chunks(chunks, chain, device):
-    if len(chunks) == 1:
-        chain(*chunks[0])
-        return
-    main = torch.cuda.current_stream(device)
-    key = (str(device), len(chunks))
-    if key not in _CHUNK_STREAMS:
-        _CHUNK_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in chunks[1:]]
-    # chunk 0 stays on the caller's stream: one branch less for the graph executor
-    for c, st in zip(chunks[1:], _CHUNK_STREAMS[key]):
-        st.wait_stream(main)
-        with torch.cuda.stream(st):
-            chain(*c)
-    chain(*chunks[0])
-    for st in _CHUNK_STREAMS[key]:
-        main.wait_stream(st)
 
 
 def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
@@ -751,7 +717,6 @@ def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
     prow = pitch_rows(cfg, pitch[0], rowmask, B, T) if pitch is not None else None
     stamp("dec_fwd_begin")
     Tp = T + 2 * ROW_PAD
-    chunks = _chunks(B, prep, pitch)
 
     def chain(ci, b0, nb):
         """All flows of utterances [b0, b0 + nb) on the current stream."""
@@ -774,16 +739,10 @@ def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
             dims = _dims(cfg, nb, T, drop_p, seed, f, ci)
             _lib.check(L.glowtts_flow_forward(ctypes.byref(dims), ctypes.byref(_params_at(prep, f, b0)), ctypes.byref(acts), _lib.stream()),
                        "glowtts_flow_forward")
-    _run_chunks(chunks, chain, mels.device)
+    chain(0, 0, B)
     stamp("dec_fwd_end")
-    # z in the reference's [B, C, T] layout and the log-determinants are read by the losses only - the log-prior / MAS side of the step reads the rows
-    # tensor: with a side stream given (AUX["stream"], the text encoder's, which the caller joins before it returns) the two passes (14 + 35 us) leave
-    # the chain  decoder forward -> log-prior -> MAS -> losses -> decoder backward.  MEASURED AND OFF (TUNE["fwd_tail_aside"]): 5.07 against 5.01 ms/step, three
-    # alternating pairs - the extra cross-stream edges cost the replayed graph more (dec_fwd_end -> dec_bwd_begin 330 us against 219) than the two passes take
-    main, aux = torch.cuda.current_stream(mels.device), AUX["stream"]
-    if aux is not None and TUNE["fwd_tail_aside"]:
-        aux.wait_stream(main)
-        torch.cuda.set_stream(aux)
+    # (z in the reference's [B, C, T] layout and the log-determinants on the encoder's stream, off the chain to the log-prior, was measured in round 5 and lost:
+    #  5.07 against 5.01 ms/step - the extra cross-stream edges cost the replayed graph more than the two passes take)
     an_logs = prep.keep["an_logs"].contiguous()
     z = unsqueeze_rows(cfg, buf.x[cfg.F], lengths, B, Tm)
     part = torch.empty(cfg.F * B, device=mels.device)
@@ -791,10 +750,6 @@ def _run_forward(cfg, prep, mels, lengths, drop_p=0.0, seed=None, pitch=None):
     _lib.check(L.glowtts_decoder_logdet(_lib.ptr(buf.outs), R * prep.ldo, _lib.ptr(an_logs), _lib.ptr(prep.winfo),
                                         _lib.ptr(rowmask), _lib.ptr(part), _lib.ptr(logdet), cfg.F, B, T + 2 * ROW_PAD, cfg.C, prep.ldo,
                                         _lib.stream()), "glowtts_decoder_logdet")
-    if aux is not None and TUNE["fwd_tail_aside"]:
-        torch.cuda.set_stream(main)
-        for t_ in (z, logdet, part, an_logs):
-            t_.record_stream(main)
     if pitch is not None:
         prep.set_cond(prep.cond)            # the backward addresses the conditioning gradient per utterance
     return z, logdet, buf, rowmask, T, prow
@@ -1110,9 +1065,7 @@ class DecoderFunction(torch.autograd.Function):
         side = _wgrad_stream(dev)
         stamp("dec_bwd_begin")
         Tp = T + 2 * ROW_PAD
-        chunks = _chunks(B, prep, None if ctx.prow is None else ctx.prow)
-        if halves > 1:
-            chunks = [(0, 0, B)]
+        chunks = [(0, 0, B)]
         # the ActNorm / 1x1 backward leaves one row of partial sums per block of its launch: a chunk's blocks follow the previous chunk's
         blk_off, nblk_all = [], 0
         for _, _, nb in chunks:
@@ -1155,7 +1108,7 @@ class DecoderFunction(torch.autograd.Function):
                         with torch.cuda.stream(side):
                             for grp in (gk, gp, g1):
                                 grp.launch_segment(pos // per - 1)
-        _run_chunks(chunks, chain, dev)
+        chain(0, 0, B)
         if halves > 1:
             side.wait_stream(main)
             with torch.cuda.stream(side):

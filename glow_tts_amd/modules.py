@@ -321,7 +321,7 @@ class GlowTTS(torch.nn.Module):
         W = stacks.weights(gv=use_gv)
         main = torch.cuda.current_stream()
         if self._enc_stream is None:
-            self._enc_stream = torch.cuda.Stream(priority=int(decoder.TUNE["enc_priority"]))      # (experiment: -1 = high priority)
+            self._enc_stream = torch.cuda.Stream()      # (equal priority: a priority difference between the two branches of the replayed graph, in either direction, doubles the step - DESIGN.md section 5)
         side = self._enc_stream if self.overlap_encoder else main
         side.wait_stream(main)
         pack_aux = None

@@ -77,11 +77,6 @@ class PackJob(ctypes.Structure):
                 ("O", "I", "taps", "transpose", "perm", "perm_h", "N", "K", "npad", "kchunks", "block0", "reserved")]
 
 
-# Measured and OFF: the tile kernel of the decoder's weight preparation over the encoder's 60 images (glowtts_prep_launch_dev) - alone 47 us per launch against 33
-# for the element-wise gather (tools/bench_pack.py; 74 KB of LDS per workgroup for the 2 304-float rows of the 768-channel convs), in the step 100 against 70
-FAST_PACK = {"on": False}
-
-
 class PackSet:
     """Conv weights of different shapes packed by ONE launch (glowtts_pack_weight_multi) into one buffer.
     items: [(key, fp32 weight [O, I, taps], transpose)].  The device job table is built once; `run()` re-packs the current values
@@ -117,32 +112,12 @@ class PackSet:
         self.table = torch.frombuffer(bytearray(jobs), dtype=torch.uint8).to(dev)
         self.njobs, self.blocks, self.precision = n, b0, precision
         self.sig = self.signature(items)
-        # bf16 images: the same bytes by the tile kernel of the decoder's weight preparation (csrc/prep_ops.hip: coalesced row reads, 16-byte image stores)
-        # over a device job table built here, once
-        self.prep = None
-        if precision == BF16 and FAST_PACK["on"] and all(w.shape[1] * w.shape[2] <= 4096 for _, w, _ in items):
-            from .decoder import PrepJob, _L as _dec_L
-            Ld = _dec_L()
-            Ld.glowtts_prep_launch_dev.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
-            pj = (PrepJob * n)()
-            nb, pb0 = c_int(0), 0
-            for i, (key, w, tr) in enumerate(items):
-                O, I, k = w.shape
-                _lib.check(Ld.glowtts_prep_job_init(ctypes.byref(pj[i]), w.data_ptr(), None, None, 1, 1, O, I, k, int(tr), PERM_NONE, 0,
-                                                    self.data.data_ptr() + offs[i], 0, 0, 0, 0, pb0, ctypes.byref(nb)), "glowtts_prep_job_init")
-                assert (pj[i].npad, pj[i].kchunks) == (jobs[i].npad, jobs[i].kchunks)
-                pb0 += nb.value
-            self.prep = (torch.frombuffer(bytearray(pj), dtype=torch.uint8).to(dev), pb0, max(w.shape[1] * w.shape[2] for _, w, _ in items))
 
     @staticmethod
     def signature(items):
         return tuple((k, w.data_ptr(), tuple(w.shape), bool(tr)) for k, w, tr in items)
 
     def run(self):
-        if self.prep is not None:
-            _lib.check(_lib.lib().glowtts_prep_launch_dev(self.prep[0].data_ptr(), self.njobs, self.prep[1], self.prep[2], _lib.stream()),
-                       "glowtts_prep_launch_dev")
-            return
         _lib.check(_lib.lib().glowtts_pack_weight_multi(self.table.data_ptr(), self.njobs, self.blocks, self.precision, _lib.stream()),
                    "glowtts_pack_weight_multi")
 

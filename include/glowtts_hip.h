@@ -168,7 +168,7 @@ int glowtts_prep_job_init(glowtts_prep_job *job /* host */, const float *v, cons
 int glowtts_prep_launch(const glowtts_prep_job *host_jobs, int njobs, int total_blocks, int max_cols, void *stream);
 /* Round 5: the same kernel over a job table in DEVICE memory, any number of jobs - for tables that do not change between steps (the text encoder's ~60
  * images of plain conv weights: built and uploaded once).  Measured against glowtts_pack_weight_multi's element-wise gather on those images: 47 vs 33 us
- * alone - the host library keeps the gather (ops.FAST_PACK). */
+ * alone - the host library keeps the gather and no longer calls this entry point (round 6). */
 int glowtts_prep_launch_dev(const glowtts_prep_job *dev_jobs, int njobs, int total_blocks, int max_cols, void *stream);
 
 #define GLOWTTS_APRO_NONE    0
