@@ -94,7 +94,8 @@ def forward_losses(model, mle_loss, batch, cond):
     from glow_tts_amd.modules import Beside
     with Beside(model) as beside:                                                        # (as Trainer._losses: beside the MLE reduction)
         beside.uses(log_dur, log_dur_t)
-        length = torch.nn.functional.mse_loss(log_dur, log_dur_t)                        # Train.py:203-211
+        from glow_tts_amd.alignment import duration_mse
+        length = duration_mse(log_dur, log_dur_t)                                        # Train.py:203-211 MSELoss (one launch per direction)
     mle = mle_loss(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=ml)
     beside.join(length)
     return mle, length

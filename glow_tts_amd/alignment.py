@@ -24,6 +24,10 @@ def _lib2():
         L.glowtts_duration_targets.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
         L.glowtts_mle_loss_fwd.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.glowtts_mle_loss_bwd.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.glowtts_expand_pair_targets.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        L.glowtts_prior_loss_bwd.argtypes = [ctypes.c_void_p] * 10 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        L.glowtts_mse_loss_fwd.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.glowtts_mse_loss_bwd.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _decl = True
     return L
 
@@ -133,6 +137,83 @@ def duration_targets(idx, token_lengths, Tx):
     return out.unsqueeze(1)
 
 
+def _segment_sums(dout, idx, Tx, stream):
+    """glowtts_expand_bwd on `stream` (behind the caller's), see ExpandPrior."""
+    dout = dout.contiguous()
+    B, C, Ty = dout.shape
+    cur = torch.cuda.current_stream()
+
+    def run():
+        dsrc = torch.empty(B, C, Tx, device=dout.device)
+        _lib.check(_lib2().glowtts_expand_bwd(_lib.ptr(dout), _lib.ptr(idx), _lib.ptr(dsrc), B, C, Tx, Ty, _lib.stream()), "glowtts_expand_bwd")
+        return dsrc
+    if stream is None or stream == cur:
+        return run()
+    stream.wait_stream(cur)
+    with torch.cuda.stream(stream):
+        dsrc = run()
+    dout.record_stream(stream)
+    idx.record_stream(stream)
+    return dsrc
+
+
+class ExpandPair(torch.autograd.Function):
+    """Modules.py:120-122 in ONE launch (round 6): mel_Mean = mean @ attentions, mel_Log_Std = log_Std @ attentions (gathers by the MAS token index) and
+    log_Duration_Targets = log(sum_t attentions + 1e-7) * token_mask -> (mel_mean [B, C, Ty], mel_log_std [B, C, Ty], targets [B, Tx]; the targets carry no
+    gradient, Modules.py:107).  The general backward is ExpandPrior's (two segment-sum passes); `MLE_Loss` on exactly these two outputs never runs it - it
+    differentiates through the expansion itself (`PriorLoss`).  Ty % 4 != 0: the three separate launches."""
+
+    @staticmethod
+    def forward(ctx, mean, log_std, idx, token_lengths, bwd_stream=None):
+        mean, log_std = mean.contiguous(), log_std.contiguous()
+        B, C, Tx = mean.shape
+        Ty = idx.shape[1]
+        dev = mean.device
+        om, ol, tg = torch.empty(B, C, Ty, device=dev), torch.empty(B, C, Ty, device=dev), torch.empty(B, Tx, device=dev)
+        L = _lib2()
+        if Ty % 4 == 0:
+            _lib.check(L.glowtts_expand_pair_targets(_lib.ptr(mean), _lib.ptr(log_std), _lib.ptr(idx), _lib.ptr(token_lengths.contiguous()), _lib.ptr(om),
+                                                     _lib.ptr(ol), _lib.ptr(tg), B, C, Tx, Ty, _lib.stream()), "glowtts_expand_pair_targets")
+        else:
+            _lib.check(L.glowtts_expand_fwd(_lib.ptr(mean), _lib.ptr(idx), _lib.ptr(om), B, C, Tx, Ty, _lib.stream()), "glowtts_expand_fwd")
+            _lib.check(L.glowtts_expand_fwd(_lib.ptr(log_std), _lib.ptr(idx), _lib.ptr(ol), B, C, Tx, Ty, _lib.stream()), "glowtts_expand_fwd")
+            _lib.check(L.glowtts_duration_targets(_lib.ptr(idx), _lib.ptr(token_lengths.contiguous()), _lib.ptr(tg), B, Tx, Ty, _lib.stream()),
+                       "glowtts_duration_targets")
+        ctx.save_for_backward(idx)
+        ctx.Tx, ctx.bwd_stream = Tx, bwd_stream
+        ctx.mark_non_differentiable(tg)
+        return om, ol, tg
+
+    @staticmethod
+    def backward(ctx, dm, dl, _dt):
+        (idx,) = ctx.saved_tensors
+        return (None if dm is None else _segment_sums(dm, idx, ctx.Tx, ctx.bwd_stream), None if dl is None else _segment_sums(dl, idx, ctx.Tx, ctx.bwd_stream),
+                None, None, None)
+
+
+class PriorTag:
+    """What `GlowTTS.forward` remembers about the expanded prior it returns: the token-space tensors it was gathered from (with their autograd history) and the
+    token index.  `MLE_Loss` finds it on its `mean` / `std` arguments and then differentiates through the expansion in its own backward launch."""
+
+    def __init__(self, mean, log_std, idx):
+        self.mean, self.log_std, self.idx = mean, log_std, idx
+
+
+def tag_prior(mel_mean, mel_log_std, mean, log_std, idx):
+    tag = PriorTag(mean, log_std, idx)
+    mel_mean._glow_prior, mel_log_std._glow_prior = (tag, 0), (tag, 1)
+
+
+def prior_tag_of(mel_mean, mel_log_std):
+    a, b = getattr(mel_mean, "_glow_prior", None), getattr(mel_log_std, "_glow_prior", None)
+    if a is None or b is None or a[0] is not b[0] or (a[1], b[1]) != (0, 1):
+        return None
+    tag = a[0]
+    if tuple(mel_mean.shape[:2]) != tuple(tag.mean.shape[:2]) or mel_mean.shape[2] != tag.idx.shape[1] or tag.mean.shape[2] > 1024:
+        return None
+    return tag
+
+
 class MLELoss(torch.autograd.Function):
     """Modules.py:1020-1029 as one reduction + one elementwise backward kernel."""
 
@@ -158,6 +239,76 @@ class MLELoss(torch.autograd.Function):
         _lib.check(_lib2().glowtts_mle_loss_bwd(_lib.ptr(z), _lib.ptr(mean), _lib.ptr(log_std), _lib.ptr(dl_), _lib.ptr(inv), _lib.ptr(dz),
                                                 _lib.ptr(dm), _lib.ptr(dl), z.numel(), _lib.ptr(dlogdet), ctx.B, _lib.stream()), "glowtts_mle_loss_bwd")
         return dz, dm, dl, dlogdet, None, None, None
+
+
+class PriorLoss(torch.autograd.Function):
+    """MLE_Loss (Modules.py:1020-1029) on the expanded prior of `GlowTTS.forward`, differentiated THROUGH the expansion (:120-121): the forward is MLELoss's (same
+    kernels, same value), the backward is one launch that writes d z per frame and the gradients of the TOKEN-space mean / log_std as sums over each token's
+    contiguous run of frames (csrc/loss_ops.hip prior_loss_bwd_kernel) - the expanded gradients (2 x 8 MB) and the two segment-sum passes behind them never exist.
+    Same bits as MLELoss + ExpandPrior.  apply(z, mean_tok, log_std_tok, log_dets, lengths, n_squeeze, mel_dim, mel_mean, mel_log_std, idx)."""
+
+    @staticmethod
+    def forward(ctx, z, mean_tok, ls_tok, log_dets, lengths, n_squeeze, mel_dim, mel_mean, mel_ls, idx):
+        z, log_dets = z.contiguous(), log_dets.contiguous()
+        dev = z.device
+        loss, inv = torch.empty((), device=dev), torch.empty(1, device=dev)
+        scratch = torch.empty(1024, device=dev)
+        _lib.check(_lib2().glowtts_mle_loss_fwd(_lib.ptr(z), _lib.ptr(mel_mean.contiguous()), _lib.ptr(mel_ls.contiguous()), _lib.ptr(log_dets),
+                                                _lib.ptr(lengths.contiguous()), loss.data_ptr(), inv.data_ptr(), _lib.ptr(scratch), z.numel(), z.shape[0], n_squeeze,
+                                                mel_dim, _lib.stream()), "glowtts_mle_loss_fwd")
+        ctx.save_for_backward(z, mean_tok.contiguous(), ls_tok.contiguous(), idx, inv)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        z, mean_tok, ls_tok, idx, inv = ctx.saved_tensors
+        B, C, Ty = z.shape
+        Tx = mean_tok.shape[2]
+        dz, dm, dl = torch.empty_like(z), torch.empty_like(mean_tok), torch.empty_like(ls_tok)
+        dlogdet = torch.empty(B, device=z.device)
+        _lib.check(_lib2().glowtts_prior_loss_bwd(_lib.ptr(z), _lib.ptr(mean_tok), _lib.ptr(ls_tok), _lib.ptr(idx), _lib.ptr(dloss.contiguous().reshape(1)), _lib.ptr(inv),
+                                                  _lib.ptr(dz), _lib.ptr(dm), _lib.ptr(dl), _lib.ptr(dlogdet), B, C, Tx, Ty, _lib.stream()), "glowtts_prior_loss_bwd")
+        return dz, dm, dl, dlogdet, None, None, None, None, None, None
+
+
+def mle_loss(z, mean, std, log_dets, lengths, n_squeeze, mel_dim):
+    """`MLE_Loss.forward`: through the expansion when (mean, std) are the expanded prior `GlowTTS.forward` returned (and carry its tag), else on the tensors as given."""
+    tag = prior_tag_of(mean, std) if (torch.is_grad_enabled() and z.is_cuda) else None
+    if tag is not None and (tag.mean.requires_grad or tag.log_std.requires_grad):
+        return PriorLoss.apply(z, tag.mean, tag.log_std, log_dets, lengths, n_squeeze, mel_dim, mean.detach(), std.detach(), tag.idx)
+    return MLELoss.apply(z, mean, std, log_dets, lengths, n_squeeze, mel_dim)
+
+
+class DurationMSE(torch.autograd.Function):
+    """The duration loss (Train.py:203-211 `MSELoss()(log_Durations, log_Duration_Targets)`) as one launch per direction.  denom: None = the element count (torch's
+    mean); token_lengths [B] i64 = B x the batch's own longest text (trainer.duration_loss: the token axis is padded to a shape bucket); extent = a 0-d device
+    tensor holding the longest text of the GLOBAL batch (data parallel)."""
+
+    @staticmethod
+    def forward(ctx, a, target, token_lengths=None, extent=None):
+        a, target = a.contiguous(), target.contiguous()
+        loss = torch.empty((), device=a.device)
+        B = int(a.shape[0])
+        ext = None if extent is None else extent.to(torch.float32).reshape(1).contiguous()
+        tl = None if (token_lengths is None or ext is not None) else token_lengths.contiguous()
+        _lib.check(_lib2().glowtts_mse_loss_fwd(_lib.ptr(a), _lib.ptr(target), loss.data_ptr(), a.numel(), 1.0 / a.numel(), _lib.ptr(tl), B, _lib.ptr(ext),
+                                                _lib.stream()), "glowtts_mse_loss_fwd")
+        ctx.save_for_backward(a, target, tl, ext)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        a, target, tl, ext = ctx.saved_tensors
+        da = torch.empty_like(a)
+        _lib.check(_lib2().glowtts_mse_loss_bwd(_lib.ptr(a), _lib.ptr(target), _lib.ptr(dloss.contiguous().reshape(1)), _lib.ptr(da), a.numel(), 1.0 / a.numel(),
+                                                _lib.ptr(tl), int(a.shape[0]), _lib.ptr(ext), _lib.stream()), "glowtts_mse_loss_bwd")
+        return da, None, None, None
+
+
+def duration_mse(log_durations, log_duration_targets, token_lengths=None, extent=None):
+    if not log_durations.is_cuda:
+        raise _lib.GlowTTSHipError("glow_tts_amd runs on the GPU only (no CPU fallback)")
+    return DurationMSE.apply(log_durations, log_duration_targets.detach(), token_lengths, extent)
 
 
 @torch.no_grad()

@@ -111,6 +111,116 @@ __global__ __launch_bounds__(256) void mle_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// Round 6.  Both expansions (Modules.py:120-121) and the duration targets (:122) in ONE launch: blocks [0, nexp) sweep 16-byte groups of the two outputs
+// (expand_fwd4_kernel's pattern, one int4 of token indices serves both rows), the last B blocks count the run lengths (dur_target_kernel).
+__global__ __launch_bounds__(256) void expand_pair_kernel(const float* __restrict__ mean, const float* __restrict__ ls, const int32_t* __restrict__ idx,
+                                                          const int64_t* __restrict__ t_x, float* __restrict__ omean, float* __restrict__ ols,
+                                                          float* __restrict__ targets, int C, int Tx, int Ty, unsigned int total4, int nexp)
+{
+    extern __shared__ int cnt[];
+    if ((int)blockIdx.x >= nexp) {
+        const int b = blockIdx.x - nexp;
+        for (int x = threadIdx.x; x < Tx; x += 256) cnt[x] = 0;
+        __syncthreads();
+        const int32_t* ib = idx + (long)b * Ty;
+        for (int y = threadIdx.x; y < Ty; y += 256) { const int x = ib[y]; if (x >= 0) atomicAdd(&cnt[x], 1); }    // integer LDS atomics: exact
+        __syncthreads();
+        const int tx = (int)t_x[b];
+        for (int x = threadIdx.x; x < Tx; x += 256) targets[(long)b * Tx + x] = (x < tx) ? logf((float)cnt[x] + 1e-7f) : 0.f;
+        return;
+    }
+    const unsigned int q = (unsigned int)Ty >> 2;
+    for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < total4; i += (unsigned int)nexp * 256u) {
+        const unsigned int row = i / q, y4 = i - row * q;          // row = b * C + c
+        const unsigned int b = row / (unsigned int)C;
+        const int4 id = *reinterpret_cast<const int4*>(idx + (size_t)b * Ty + (size_t)y4 * 4);
+        const float* sm = mean + (size_t)row * Tx;
+        const float* sl = ls + (size_t)row * Tx;
+        float4 v, w;
+        v.x = id.x >= 0 ? sm[id.x] : 0.f; v.y = id.y >= 0 ? sm[id.y] : 0.f; v.z = id.z >= 0 ? sm[id.z] : 0.f; v.w = id.w >= 0 ? sm[id.w] : 0.f;
+        w.x = id.x >= 0 ? sl[id.x] : 0.f; w.y = id.y >= 0 ? sl[id.y] : 0.f; w.z = id.z >= 0 ? sl[id.z] : 0.f; w.w = id.w >= 0 ? sl[id.w] : 0.f;
+        *reinterpret_cast<float4*>(omean + (size_t)i * 4) = v;
+        *reinterpret_cast<float4*>(ols + (size_t)i * 4) = w;
+    }
+}
+
+// Round 6.  The backward of MLE_Loss (Modules.py:1020-1029) THROUGH the expansion (:120-121) in one launch: d z per frame, and the gradients of the
+// TOKEN-space mean / log_std as sums over each token's frames - a monotonic alignment gives every token a contiguous run, so the expanded gradients
+// (2 x 8 MB at B = 32) are never written and the two expand_bwd passes (2 x 56 us in the step, at the head of the text encoder's backward) disappear.
+// One wavefront per (utterance, channel) row, 64 frames per pass, the token-keyed segmented scan of expand_bwd_kernel on both sums at once; the values
+// and the order of every addition are those of mle_bwd_kernel + expand_bwd_kernel: the results are the same bits.
+__global__ __launch_bounds__(256) void prior_loss_bwd_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ ls,
+                                                             const int32_t* __restrict__ idx, const float* __restrict__ dloss,
+                                                             const float* __restrict__ inv_denom, float* __restrict__ dz, float* __restrict__ dmean,
+                                                             float* __restrict__ dls, float* __restrict__ dlogdet, int B, int C, int Tx, int Ty)
+{
+    extern __shared__ float pl_sm[];                     // per wave: m [Tx], e [Tx], acc1 [Tx], acc2 [Tx]
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float g = dloss[0] * inv_denom[0];
+    if (dlogdet && blockIdx.x == 0 && blockIdx.y == 0) for (int i = threadIdx.x; i < B; i += 256) dlogdet[i] = -g;      // Modules.py:1025-1027
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= C) return;                                  // (no workgroup barrier below)
+    float* m = pl_sm + (size_t)wave * 4 * Tx;
+    float* e = m + Tx;
+    float* a1 = e + Tx;
+    float* a2 = a1 + Tx;
+    const long trow = ((long)b * C + c) * Tx, frow = ((long)b * C + c) * Ty;
+    for (int x = lane; x < Tx; x += 64) { m[x] = mean[trow + x]; e[x] = expf(-2.f * ls[trow + x]); a1[x] = 0.f; a2[x] = 0.f; }
+    __builtin_amdgcn_wave_barrier();
+    const int32_t* ib = idx + (long)b * Ty;
+    for (int y0 = 0; y0 < Ty; y0 += 64) {
+        const int y = y0 + lane;
+        const int x = y < Ty ? ib[y] : -1;
+        const float zz = y < Ty ? z[frow + y] : 0.f;
+        // frames outside the alignment read mean = log_std = 0 from the expansion (Modules.py:120-121 multiply by an all-zero column)
+        const float mm = x >= 0 ? m[x] : 0.f, ee = x >= 0 ? e[x] : 1.f;
+        const float d = zz - mm;
+        const float t = g * ee * d;
+        if (y < Ty) dz[frow + y] = t;
+        float v1 = x >= 0 ? -t : 0.f;
+        float v2 = x >= 0 ? g * (1.f - ee * d * d) : 0.f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float u1 = __shfl_up(v1, o), u2 = __shfl_up(v2, o);
+            const int xx = __shfl_up(x, o);
+            if (lane >= o && xx == x) { v1 += u1; v2 += u2; }
+        }
+        const int xn = __shfl_down(x, 1);
+        if (x >= 0 && (lane == 63 || xn != x)) { a1[x] += v1; a2[x] += v2; }     // one lane per token and pass; LDS accesses of a wave complete in order
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int x = lane; x < Tx; x += 64) { dmean[trow + x] = a1[x]; dls[trow + x] = a2[x]; }
+}
+
+// Duration loss (Train.py:203-211: MSELoss(log_Durations, log_Duration_Targets), mean over the padded [B, 1, T_tok]) and its gradient: one workgroup, one launch
+// per direction (torch: sub / pow / mean forward, three more backward, each a launch on the encoder stream's chain).  scale = 1 / elements (or the caller's own
+// normaliser); n up to a few thousand.
+// scale: 1 / denominator given by the host, or - lengths != NULL - 1 / (B * max(lengths)) (the trainer's mean over the batch's own longest text), or - extent != NULL -
+// 1 / (B * extent[0]) (data parallel: the longest text of the GLOBAL batch, a device scalar)
+__device__ __forceinline__ float mse_scale(float scale, const int64_t* lengths, int B, const float* extent)
+{
+    if (extent) return 1.f / ((float)B * extent[0]);
+    if (lengths) { long mx = 1; for (int i = 0; i < B; ++i) mx = lengths[i] > mx ? lengths[i] : mx; return 1.f / ((float)B * (float)mx); }
+    return scale;
+}
+__global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ a, const float* __restrict__ t, float* __restrict__ loss, long n, float scale,
+                                                      const int64_t* __restrict__ lengths, int B, const float* __restrict__ extent)
+{
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (long i = threadIdx.x; i < n; i += 256) { const float d = a[i] - t[i]; acc += (double)d * d; }
+    red[threadIdx.x] = acc; __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) *loss = (float)(red[0] * (double)mse_scale(scale, lengths, B, extent));
+}
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ t, const float* __restrict__ dloss,
+                                                      float* __restrict__ da, long n, float scale, const int64_t* __restrict__ lengths, int B,
+                                                      const float* __restrict__ extent)
+{
+    const float g = 2.f * mse_scale(scale, lengths, B, extent) * dloss[0];
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) da[i] = g * (a[i] - t[i]);
+}
+
 #define RET_LAUNCH() return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH
 }  // namespace
 
@@ -292,5 +402,44 @@ extern "C" int glowtts_mle_loss_bwd(const float* z, const float* mean, const flo
     const long g = (n + 255) / 256;
     hipLaunchKernelGGL(mle_bwd_kernel, dim3((int)(g > 2048 ? 2048 : g)), dim3(256), 0, static_cast<hipStream_t>(stream), z, mean, log_std, dloss, inv_denom, dz, dmean, dlog_std, (long)n,
                        dlogdet, B);
+    RET_LAUNCH();
+}
+
+extern "C" int glowtts_expand_pair_targets(const float* mean, const float* log_std, const int32_t* idx, const int64_t* token_lengths, float* mel_mean,
+                                           float* mel_log_std, float* targets, int B, int C, int Tx, int Ty, void* stream)
+{
+    if (!mean || !log_std || !idx || !token_lengths || !mel_mean || !mel_log_std || !targets || B < 1 || C < 1 || Tx < 1 || Ty < 4 || (Ty & 3)) return GLOWTTS_E_ARG;
+    const uint64_t total4 = (uint64_t)B * C * Ty / 4;
+    if (((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(mel_mean) | reinterpret_cast<uintptr_t>(mel_log_std)) & 15) != 0 || total4 >= (1ull << 31) ||
+        (size_t)Tx * sizeof(int) > 64 * 1024) return GLOWTTS_E_ARG;
+    const int nexp = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(expand_pair_kernel, dim3(nexp + B), dim3(256), Tx * sizeof(int), static_cast<hipStream_t>(stream), mean, log_std, idx, token_lengths,
+                       mel_mean, mel_log_std, targets, C, Tx, Ty, (unsigned int)total4, nexp);
+    RET_LAUNCH();
+}
+extern "C" int glowtts_prior_loss_bwd(const float* z, const float* mean, const float* log_std, const int32_t* idx, const float* dloss, const float* inv_denom,
+                                      float* dz, float* dmean, float* dlog_std, float* dlogdet, int B, int C, int Tx, int Ty, void* stream)
+{
+    if (!z || !mean || !log_std || !idx || !dloss || !inv_denom || !dz || !dmean || !dlog_std || B < 1 || C < 1 || Tx < 1 || Ty < 1) return GLOWTTS_E_ARG;
+    const size_t lds = (size_t)16 * Tx * sizeof(float);
+    if (lds > 64 * 1024) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(prior_loss_bwd_kernel, dim3((C + 3) / 4, B), dim3(256), lds, static_cast<hipStream_t>(stream), z, mean, log_std, idx, dloss, inv_denom,
+                       dz, dmean, dlog_std, dlogdet, B, C, Tx, Ty);
+    RET_LAUNCH();
+}
+extern "C" int glowtts_mse_loss_fwd(const float* a, const float* target, float* loss, int64_t n, float scale, const int64_t* lengths, int B, const float* extent,
+                                    void* stream)
+{
+    if (!a || !target || !loss || n < 1 || ((lengths || extent) && B < 1)) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(mse_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a, target, loss, (long)n, scale, lengths, B, extent);
+    RET_LAUNCH();
+}
+extern "C" int glowtts_mse_loss_bwd(const float* a, const float* target, const float* dloss, float* da, int64_t n, float scale, const int64_t* lengths, int B,
+                                    const float* extent, void* stream)
+{
+    if (!a || !target || !dloss || !da || n < 1 || ((lengths || extent) && B < 1)) return GLOWTTS_E_ARG;
+    const long g = (n + 255) / 256;
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3((int)(g > 256 ? 256 : g)), dim3(256), 0, static_cast<hipStream_t>(stream), a, target, dloss, da, (long)n, scale, lengths, B,
+                       extent);
     RET_LAUNCH();
 }

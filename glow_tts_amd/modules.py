@@ -388,9 +388,10 @@ class GlowTTS(torch.nn.Module):
         with torch.cuda.stream(side):
             attn = path_from_idx(idx, tokens.shape[1], torch.float32)
         bwd_side = side if (side is not main and torch.is_grad_enabled()) else None
-        mel_mean = alignment.ExpandPrior.apply(mean, idx, bwd_side)                                  # Modules.py:120 (gather by the MAS index)
-        mel_log_std = alignment.ExpandPrior.apply(log_std, idx, bwd_side)                            # Modules.py:121
-        log_dur_targets = alignment.duration_targets(idx, token_lengths, tokens.shape[1])            # Modules.py:122
+        # Modules.py:120-122 in one launch (gathers by the MAS index + run lengths); MLE_Loss on these two tensors differentiates through the gather itself
+        mel_mean, mel_log_std, log_dur_targets = alignment.ExpandPair.apply(mean, log_std, idx, token_lengths, bwd_side)
+        alignment.tag_prior(mel_mean, mel_log_std, mean, log_std, idx)
+        log_dur_targets = log_dur_targets.unsqueeze(1)
         if side is not main:
             main.wait_stream(side)
             attn.record_stream(main)
@@ -533,4 +534,4 @@ class MLE_Loss(torch.nn.modules.loss._Loss):
 
     def forward(self, z, mean, std, log_dets, lengths):
         hp = self.hp
-        return alignment.MLELoss.apply(z, mean, std, log_dets, lengths, int(hp.Decoder.Num_Squeeze), int(hp.Sound.Mel_Dim))
+        return alignment.mle_loss(z, mean, std, log_dets, lengths, int(hp.Decoder.Num_Squeeze), int(hp.Sound.Mel_Dim))

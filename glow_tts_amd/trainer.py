@@ -23,9 +23,14 @@ def duration_loss(log_durations, log_duration_targets, token_lengths, extent=Non
     its collater pads to the batch maximum (Datasets.py:225-250).  This package pads the token axis to a shape bucket, so the mean is taken
     over the unpadded extent explicitly: padded positions are zero in both tensors and must not enlarge the denominator (a plain MSELoss would
     scale the loss and its gradient by max_len / bucket_len, a batch-dependent factor down to ~0.75).  No host sync: the extent stays on the device."""
-    d = (log_durations - log_duration_targets).reshape(log_durations.shape[0], -1)
     # extent (data parallel): the longest text of the GLOBAL batch, a 0-d device tensor (`distributed.global_token_extent`) - the single-process
-    # step divides every rank's shard by the same B x max length (VERDICT r3 / ADVICE r3: each rank used its own longest text)
+    # step divides every rank's shard by the same B x max length (VERDICT r3 / ADVICE r3: each rank used its own longest text).
+    # One launch per direction (alignment.DurationMSE; was six torch launches forward and backward on the text encoder's stream).
+    if log_durations.is_cuda:
+        from .alignment import duration_mse
+        return duration_mse(log_durations, log_duration_targets, token_lengths, extent)
+    # host tensors (the world-2 gloo tests of the loss weighting, tests/test_trainer_losses.py): the same expression in torch
+    d = (log_durations - log_duration_targets).reshape(log_durations.shape[0], -1)
     ext = token_lengths.max() if extent is None else extent
     return (d * d).sum() / (d.shape[0] * ext.to(d.dtype))
 

@@ -665,6 +665,22 @@ int glowtts_mle_loss_fwd(const float *z, const float *mean, const float *log_std
 /* dlogdet (optional, [B]): also writes d loss / d log_dets[b] = -dloss * inv_denom */
 int glowtts_mle_loss_bwd(const float *z, const float *mean, const float *log_std, const float *dloss, const float *inv_denom,
                          float *dz, float *dmean, float *dlog_std, int64_t n, float *dlogdet, int B, void *stream);
+/* ABI 6.  Both expansions and the duration targets of Modules.py:120-122 in one launch (Ty % 4 == 0, 16-byte aligned idx / outputs): mel_mean, mel_log_std
+ * [B][C][Ty] as glowtts_expand_fwd, targets [B][Tx] as glowtts_duration_targets. */
+int glowtts_expand_pair_targets(const float *mean, const float *log_std, const int32_t *idx, const int64_t *token_lengths, float *mel_mean,
+                                float *mel_log_std, float *targets, int B, int C, int Tx, int Ty, void *stream);
+/* ABI 6.  glowtts_mle_loss_bwd THROUGH the expansion, in one launch: z [B][C][Ty], the TOKEN-space mean / log_std [B][C][Tx] the expansion gathered from and idx
+ * [B][Ty] -> dz [B][C][Ty] and the token-space gradients dmean / dlog_std [B][C][Tx] (each token's frames are one contiguous run: segment sums, no atomics;
+ * the same bits as glowtts_mle_loss_bwd followed by two glowtts_expand_bwd); dlogdet optional as above.  Tx <= 1024. */
+int glowtts_prior_loss_bwd(const float *z, const float *mean, const float *log_std, const int32_t *idx, const float *dloss, const float *inv_denom,
+                           float *dz, float *dmean, float *dlog_std, float *dlogdet, int B, int C, int Tx, int Ty, void *stream);
+/* ABI 6.  loss = s * sum (a - target)^2 and da = 2 s dloss (a - target), one launch per direction; loss / dloss are device scalars.  s = `scale` (Train.py:203-211:
+ * MSELoss on the log durations, scale = 1 / n), or - lengths [B] i64 given - 1 / (B max(lengths)): the mean over the batch's own longest text when the token axis is
+ * padded to a shape bucket, or - extent (device scalar) given - 1 / (B extent[0]): data parallel, the global batch's longest text. */
+int glowtts_mse_loss_fwd(const float *a, const float *target, float *loss, int64_t n, float scale, const int64_t *lengths, int B, const float *extent,
+                         void *stream);
+int glowtts_mse_loss_bwd(const float *a, const float *target, const float *dloss, float *da, int64_t n, float scale, const int64_t *lengths, int B,
+                         const float *extent, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Old-style weight normalisation of the WaveNet convolutions (Modules.py:766,818,825,838,845: torch.nn.utils.weight_norm,

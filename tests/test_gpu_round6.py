@@ -68,3 +68,78 @@ def test_wide_conditioning_vectors_take_the_matmul_path():
     assert (wide[:32] - half).abs().max() <= 1e-4 * half.abs().max()
     wide.sum().backward()
     assert all(p.grad is not None for k, p in model.named_parameters() if "Speaker_" in k)
+
+
+def _prior_case(B=3, C=80, Tx=37, Ty=96, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    tl = torch.tensor([Tx, 20, 5][:B])
+    ml = torch.tensor([Ty, 64, 80][:B])
+    idx = torch.full((B, Ty), -1, dtype=torch.int32)
+    for b in range(B):                                    # a monotonic alignment with skewed runs (one token owns half the frames)
+        cuts = torch.sort(torch.randint(1, int(ml[b]), (int(tl[b]) - 1,), generator=g)).values if tl[b] > 1 else torch.zeros(0, dtype=torch.long)
+        x = torch.zeros(int(ml[b]), dtype=torch.int32)
+        for c in cuts.tolist():
+            x[c:] += 1
+        idx[b, :int(ml[b])] = x
+    mean, ls = torch.randn(B, C, Tx, generator=g), torch.randn(B, C, Tx, generator=g) * 0.3
+    mmask = (torch.arange(Ty)[None] < ml[:, None]).float()
+    z = torch.randn(B, C, Ty, generator=g) * mmask[:, None]
+    ld = torch.randn(B, generator=g)
+    return tl, ml, idx, mean, ls, z, ld
+
+
+def test_expand_pair_and_prior_loss_equal_the_separate_launches():
+    """Round 6 fusions of Modules.py:120-122 and of the MLE backward through them: `ExpandPair` (one launch) == two `ExpandPrior` + `duration_targets`, and
+    `PriorLoss` (one backward launch: d z + token-space segment sums) == `MLELoss` behind `ExpandPrior` - bit for bit, values and all four gradients; and
+    `MLE_Loss` takes the fused path exactly when it is handed the tagged tensors."""
+    from glow_tts_amd import alignment as A
+    from helpers import launch_counts, launch_reset
+    tl, ml, idx, mean, ls, z, ld = _prior_case()
+    dev = lambda t: t.cuda()
+    res = []
+    for fused in (False, True):
+        m, l, zz, dd = (dev(t).requires_grad_(True) for t in (mean, ls, z, ld))
+        if fused:
+            mm, ms, tg = A.ExpandPair.apply(m, l, dev(idx), dev(tl), None)
+            A.tag_prior(mm, ms, m, l, dev(idx))
+            loss = A.mle_loss(zz, mm, ms, dd, dev(ml), 2, 80)
+            assert type(loss.grad_fn).__name__.startswith("PriorLoss")
+        else:
+            mm, ms = A.ExpandPrior.apply(m, dev(idx)), A.ExpandPrior.apply(l, dev(idx))
+            tg = A.duration_targets(dev(idx), dev(tl), mean.shape[2]).squeeze(1)
+            loss = A.mle_loss(zz, mm, ms, dd, dev(ml), 2, 80)
+            assert type(loss.grad_fn).__name__.startswith("MLELoss")
+        (loss * 1.7).backward()
+        res.append([t.detach().cpu() for t in (mm, ms, tg, loss, m.grad, l.grad, zz.grad, dd.grad)])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # the tagged outputs used anywhere else still get the general backward
+    m, l = dev(mean).requires_grad_(True), dev(ls).requires_grad_(True)
+    mm, ms, _ = A.ExpandPair.apply(m, l, dev(idx), dev(tl), None)
+    (mm.sum() + 2 * ms.sum()).backward()
+    cnt = (idx[:, None, :] == torch.arange(mean.shape[2])[None, :, None]).sum(-1).float()
+    assert torch.allclose(m.grad.cpu(), cnt[:, None, :].expand_as(mean)) and torch.allclose(l.grad.cpu(), 2 * cnt[:, None, :].expand_as(mean))
+
+
+def test_duration_mse_matches_torch():
+    """`alignment.duration_mse` (one launch per direction) against torch's MSELoss (Train.py:203-211) and against the trainer's extent-normalised form."""
+    from glow_tts_amd.alignment import duration_mse
+    from glow_tts_amd.trainer import duration_loss
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn(5, 1, 64, generator=g).cuda().requires_grad_(True)
+    t = torch.randn(5, 1, 64, generator=g).cuda()
+    tl = torch.tensor([64, 31, 9, 50, 12]).cuda()
+    ref_a = a.detach().clone().requires_grad_(True)
+    want = torch.nn.functional.mse_loss(ref_a, t)
+    (want * 3).backward()
+    got = duration_mse(a, t)
+    (got * 3).backward()
+    assert abs(got.item() - want.item()) <= 1e-6 * abs(want.item()) and torch.allclose(a.grad, ref_a.grad, rtol=1e-6, atol=1e-9)
+    for ext in (None, torch.tensor(70.0).cuda()):
+        a.grad = None
+        got = duration_loss(a, t, tl, ext)
+        got.backward()
+        den = 5 * (64.0 if ext is None else 70.0)
+        want = ((a.detach() - t) ** 2).sum() / den
+        assert abs(got.item() - want.item()) <= 1e-6 * abs(want.item())
+        assert torch.allclose(a.grad, 2 * (a.detach() - t) / den, rtol=1e-6, atol=1e-9)
