@@ -235,6 +235,14 @@ def step_launch_counts(n_flows=12, n_layers=4):
     CALLS_SOURCE[0] = "glowtts_launch_count over the capture pass of the timed step"
 
 
+def blob_sha(path):
+    """git's blob hash of a file (sha1 over "blob <size>\\0" + bytes): the JSON line names the exact committed evidence file a field was read from."""
+    import hashlib
+    with open(path, "rb") as f:
+        data = f.read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 def in_step_durations():
     """Average launch durations INSIDE the replayed step from the newest committed per-step kernel statistics (profiles/r*_step_kernel_stats.csv, a
     rocprofv3 --kernel-trace of `bench.py --profile-run`): evidence read from a file, named as such - not measured by this run."""
@@ -251,7 +259,7 @@ def in_step_durations():
                              ("in_fwd", "conv_dma_kernel<1, 5, 2")):
                 if pat in nm and key not in out:
                     out[key] = (float(row["AverageNs"]) * 1e-3, float(row["CallsPerStep"]))
-    return out, "profiles/" + cands[-1]
+    return out, "profiles/" + cands[-1] + "@" + blob_sha(os.path.join(pdir, cands[-1]))[:12]
 
 
 def time_kernel(run, iters=30):
@@ -275,7 +283,7 @@ def measured_traffic():
     if not cands:
         return None, None
     with open(os.path.join(pdir, cands[-1])) as f:
-        return json.load(f), "profiles/" + cands[-1]
+        return json.load(f), "profiles/" + cands[-1] + "@" + blob_sha(os.path.join(pdir, cands[-1]))[:12]
 
 
 def sustained_mfma_clock():
@@ -327,7 +335,9 @@ def roofline(precision, B, T, step_tflops):
            "step_frac": round(step_tflops / peak, 4), "kernels": rows}
     if "frac_in_step" in top:
         # the same kernel's average duration inside the replayed step (both streams busy, lower clock): the smaller, stricter fraction
-        out.update(frac_in_step=top["frac_in_step"], in_step_us_per_launch=top["in_step_us_per_launch"], in_step_source=instep_src)
+        out.update(frac_in_step=top["frac_in_step"], in_step_us_per_launch=top["in_step_us_per_launch"], in_step_source=instep_src,
+                   evidence_note="traffic / frac_in_step / in_step_us_per_launch are READ from the committed profiles/ files named in traffic_source / in_step_source "
+                                 "(path@git-blob-hash), not measured by this run; achieved / frac / us_per_launch are measured here")
     if precision == "bf16":
         # context, not the graded fraction: the clock (and with it the matrix rate) the chip actually sustains under MFMA load
         ghz, sus = sustained_mfma_clock()
@@ -801,6 +811,7 @@ def main():
         return train_step(model, mle_loss, batch, cond, reducer, world, opt)
 
     host_replay = []
+    own = [0.0]                                                 # this rank's own time of the last window (before the MAX over ranks)
 
     def timed_window():
         barrier()
@@ -815,6 +826,7 @@ def main():
                 out = one_step()
         barrier()
         el = time.time() - t0
+        own[0] = el
         if dp:
             import torch.distributed as dist
             t = torch.tensor([el], device=dev)
@@ -824,6 +836,7 @@ def main():
 
     one_step()
     elapsed, loss = timed_window()                              # the reported window: exactly --steps steps
+    own_elapsed = own[0]
     if args.sync_each and rank == 0:
         print(f"[sync-each] host time of one step's enqueue (replay call): median {sorted(host_replay)[len(host_replay) // 2] * 1e6:.0f} us", file=sys.stderr)
     extra = [timed_window()[0] for _ in range(max(0, args.windows))]
@@ -893,11 +906,22 @@ def main():
         except Exception as exc:                               # noqa: BLE001 - an extra, never fatal
             print(f"[bench] forward+backward-only leg skipped ({type(exc).__name__}: {exc})", file=sys.stderr)
     frames = int(batch[3].sum().item())
+    dist_check = None
     if dp:
         import torch.distributed as dist
         ft = torch.tensor([frames], device=dev, dtype=torch.float64)
         _gd._collective(dist.all_reduce, ft)
         frames = int(ft.item())
+        # self-check of the first real multi-GPU run: how many ranks the process group REALLY has (an all-reduce of ones), and the spread of
+        # the per-rank step time over the reported window (`elapsed` above is the MAX, as the contract asks)
+        ones = torch.ones(1, device=dev)
+        _gd._collective(dist.all_reduce, ones)
+        mine = torch.tensor([own_elapsed], device=dev, dtype=torch.float64)
+        lo_t, hi_t = mine.clone(), mine.clone()
+        _gd._collective(dist.all_reduce, lo_t, op=dist.ReduceOp.MIN)
+        _gd._collective(dist.all_reduce, hi_t, op=dist.ReduceOp.MAX)
+        dist_check = {"rccl_ranks_seen": int(ones.item()), "world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                      "ms_per_step_rank_min": round(1e3 * float(lo_t) / args.steps, 3), "ms_per_step_rank_max": round(1e3 * float(hi_t) / args.steps, 3)}
     inv = inverse_flow_leg(model, hp, dev, B, 99 + rank) if (args.config == 5 and rank == 0) else None
     if rank == 0:
         value = frames * args.steps / elapsed
@@ -927,6 +951,8 @@ def main():
                                    "note": "forward + losses + backward without the parameter update (the step round 1 reported)"}
         if inv is not None:
             out["inverse_flow"] = inv
+        if dist_check is not None:
+            out["distributed"] = dist_check
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             try:

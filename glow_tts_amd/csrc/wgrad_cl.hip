@@ -481,7 +481,13 @@ __global__ __launch_bounds__(DNT) void wgrad_dma_kernel(const glowtts_wgrad_job*
             const bool isx = q >= DNDY;
             const uint32_t dst = __builtin_amdgcn_readfirstlane(st + (uint32_t)(isx ? DDY_BYTES + x_base(q) : q * 1024));
             const i32x4w rs = isx ? rx : rdy;
+            // (m0 = the LDS destination of a `buffer_load ... lds`.  hipcc reserves m0 and warns about it in a clobber list ("clobber list contains reserved
+            //  registers", 119 x per build until round 6); the clobber stays - it is what tells the compiler that the s_mov changes m0 - and the diagnostic is
+            //  silenced for this one statement)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
             asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voff[j]), "s"(rs), "s"(dst) : "memory", "m0");
+#pragma clang diagnostic pop
             voff[j] += isx ? stepx : stepdy;
         }
     };
