@@ -352,6 +352,8 @@ class GlowTTS(torch.nn.Module):
                                                              on_prior_ready=prior_done if prior_ready is not None else None,
                                                              pack_stream=pack_aux)
         decoder.stamp("main_after_enc_launch")
+        # (the conditioning convs on a third stream, forked in front of the decoder's weight preparation and joined here, were measured in round 6: config 3 6.00
+        #  against 5.11 ms/step, config 4 4.65 against 3.9 - a third branch in the replayed graph costs far more than the ~35 us it would hide)
         cond = stacks.conditioning(spk, pro)
         pitch_w, pitch_b = stacks.pitch_weights()
         if pitch_w is None:
