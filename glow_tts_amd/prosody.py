@@ -171,7 +171,12 @@ class _ConvStack(torch.autograd.Function):
         s = _lib.stream()
         from . import decoder
         decoder.stamp("pros_convs_bwd_begin")
-        dpre = dout.contiguous() * (acts[n] > 0).to(dout.dtype)          # the last layer's ReLU (tiny: [B, 2, 13, 128] at the default sizes)
+        # the last layer's ReLU (tiny: [B, 2, 13, 128] at the default sizes): d pre = d out where the output is not zero - one launch
+        dout = dout.contiguous()
+        dpre = torch.empty_like(dout)
+        L.glowtts_gate_bwd.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+        _lib.check(L.glowtts_gate_bwd(_lib.ptr(dout), _lib.ptr(acts[n]), None, _lib.ptr(dpre), dout.numel() // dout.shape[-1], int(dout.shape[-1]), 1.0, s),
+                   "glowtts_gate_bwd")
         jobs = (_ReduceJob * n)()
         keep, grads = [], [None] * n
         for l in range(n - 1, -1, -1):
@@ -226,6 +231,69 @@ def conv_stack_hip(convs, mels, precision, cache=None):
     x = _ConvStack.apply(mels, images, int(precision), *weights)
     B, H, W, C = x.shape
     return x.permute(0, 2, 3, 1).reshape(B, W, C * H)
+
+
+_GST_DECLARED = []
+
+
+def _gst():
+    from . import _lib
+    L = _lib.lib()
+    if not _GST_DECLARED:
+        vp, ci, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        L.glowtts_gst_supported.argtypes = [ci] * 7
+        L.glowtts_gst_keep_floats.argtypes = [ci] * 5
+        L.glowtts_gst_keep_floats.restype = i64
+        L.glowtts_gst_fwd.argtypes = [vp, vp, ci] + [vp] * 13 + [ci] * 7 + [vp]
+        L.glowtts_gst_bwd.argtypes = [vp, vp, vp, ci] + [vp] * 18 + [ci] * 7 + [vp]
+        _GST_DECLARED.append(True)
+    return L
+
+
+class _GSTTail(torch.autograd.Function):
+    """Modules.py:371-385 behind the GRU - the state at each utterance's last valid step attends over tanh(gst_Tokens) - as two launches forward (token keys / values;
+    one workgroup per utterance for gather, query, four-head softmax attention and output projection) and three backward (csrc/gst_ops.hip).  PyTorch ran ~35 / ~45
+    launches here, on the chain in front of the flow decoder / in front of the conv stack's backward.
+    apply(hs [B, T', G], lengths [B], stride_prod, heads, tokens [I, NT], Wq, bq, Wk, bk, Wv, bv, Wp, bp) -> [B, C]."""
+
+    @staticmethod
+    def forward(ctx, hs, lengths, stride_prod, heads, tokens, Wq, bq, Wk, bk, Wv, bv, Wp, bp):
+        from . import _lib
+        L = _gst()
+        hs = hs.contiguous()
+        B, Tp, G = hs.shape
+        I, NT = tokens.shape
+        C = Wq.shape[0]
+        dev = hs.device
+        c = lambda t: None if t is None else t.contiguous()
+        tokens, Wq, bq, Wk, bk, Wv, bv, Wp, bp = (c(t) for t in (tokens, Wq, bq, Wk, bk, Wv, bv, Wp, bp))
+        lengths = lengths.to(torch.int64).contiguous()
+        K, V, out = torch.empty(C, NT, device=dev), torch.empty(C, NT, device=dev), torch.empty(B, C, device=dev)
+        keep = torch.empty(int(L.glowtts_gst_keep_floats(B, G, C, heads, NT)), device=dev)
+        _lib.check(L.glowtts_gst_fwd(_lib.ptr(hs), _lib.ptr(lengths), int(stride_prod), _lib.ptr(tokens), _lib.ptr(Wq), _lib.ptr(bq), _lib.ptr(Wk), _lib.ptr(bk),
+                                     _lib.ptr(Wv), _lib.ptr(bv), _lib.ptr(Wp), _lib.ptr(bp), _lib.ptr(K), _lib.ptr(V), _lib.ptr(out), _lib.ptr(keep),
+                                     B, Tp, G, C, int(heads), NT, I, _lib.stream()), "glowtts_gst_fwd")
+        ctx.save_for_backward(keep, lengths, tokens, Wq, Wk, Wv, Wp, K, V)
+        ctx.cfg = (B, Tp, G, C, int(heads), NT, I, int(stride_prod), bq is not None, bk is not None, bv is not None, bp is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import _lib
+        L = _gst()
+        keep, lengths, tokens, Wq, Wk, Wv, Wp, K, V = ctx.saved_tensors
+        B, Tp, G, C, H, NT, I, sp, hbq, hbk, hbv, hbp = ctx.cfg
+        dev = dout.device
+        dout = dout.contiguous()
+        dhs = torch.empty(B, Tp, G, device=dev)
+        scratch = torch.empty(B * (2 * C + H * NT) + 2 * C * NT, device=dev)
+        dWq, dWk, dWv, dWp, dtok = torch.empty_like(Wq), torch.empty_like(Wk), torch.empty_like(Wv), torch.empty_like(Wp), torch.empty_like(tokens)
+        db = [torch.empty(C, device=dev) if has else None for has in (hbq, hbk, hbv, hbp)]
+        _lib.check(L.glowtts_gst_bwd(_lib.ptr(dout), _lib.ptr(keep), _lib.ptr(lengths), sp, _lib.ptr(tokens), _lib.ptr(Wq), _lib.ptr(Wk), _lib.ptr(Wv), _lib.ptr(Wp),
+                                     _lib.ptr(K), _lib.ptr(V), _lib.ptr(dhs), _lib.ptr(scratch), _lib.ptr(dWq), _lib.ptr(db[0]), _lib.ptr(dWk), _lib.ptr(db[1]),
+                                     _lib.ptr(dWv), _lib.ptr(db[2]), _lib.ptr(dWp), _lib.ptr(db[3]), _lib.ptr(dtok), B, Tp, G, C, H, NT, I, _lib.stream()),
+                   "glowtts_gst_bwd")
+        return dhs, None, None, None, dtok, dWq, db[0], dWk, db[1], dWv, db[2], dWp, db[3]
 
 
 class _ConvBlock(torch.nn.Sequential):
@@ -290,6 +358,9 @@ class Prosody_Encoder(torch.nn.Module):
     # patch-matrix + GEMM path that was no faster than MIOpen's direct kernels and stayed off; yaml shapes the kernels do not take (other kernel
     # sizes / strides / channel counts) still run torch's Conv2d.
     use_hip_convs = True
+    # The style-token tail behind the GRU (gather of the last valid state, four-head attention over tanh(gst_Tokens), projections) as five HIP launches
+    # forward + backward (_GSTTail -> csrc/gst_ops.hip) instead of ~80 PyTorch ones
+    use_hip_gst = True
 
     def forward(self, x, lengths):
         convs = [self.layer_Dict[f"Conv_{i}"].Conv for i in range(self.n_conv)]
@@ -314,6 +385,13 @@ class Prosody_Encoder(torch.nn.Module):
                 x = self.layer_Dict["GRU"](x.transpose(2, 1))[0]
         else:
             x = self.layer_Dict["GRU"](x.transpose(2, 1))[0]                              # [B, T', G]
+        att = self.layer_Dict["Attention"]
+        q_, k_, v_, p_ = (att.layer_Dict[n] for n in ("Query", "Key", "Value", "Projection"))
+        if (self.use_hip_gst and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and
+                _gst().glowtts_gst_supported(x.size(0), x.size(1), x.size(2), q_.weight.shape[0], att.heads, self.gst_Tokens.shape[1], self.gst_Tokens.shape[0])):
+            sq = lambda w: w.squeeze(-1)                       # Conv1d(k = 1) weights [O, I, 1]
+            return _GSTTail.apply(x, lengths, int(math.prod(self.strides)), att.heads, self.gst_Tokens, sq(q_.weight), q_.bias, sq(k_.weight), k_.bias,
+                                  sq(v_.weight), v_.bias, sq(p_.weight), p_.bias)
         idx = (torch.ceil(lengths / float(math.prod(self.strides))).long() - 1).clamp_min(0)   # Modules.py:373
         x = x[torch.arange(x.size(0), device=x.device), idx]                               # [B, G]
         keys = torch.tanh(self.gst_Tokens).unsqueeze(0).expand(x.size(0), -1, -1)

@@ -538,6 +538,23 @@ int glowtts_gru_fwd(const float *gi, const float *w_hh, const float *b_hh, float
 int glowtts_gru_bwd(const float *dhs, const float *hs, const float *keep, const float *w_hh, float *dgi, float *dgh,
                     int B, int T, int H, void *stream);
 /* ------------------------------------------------------------------------------------------
+ * Style-token tail of the GST prosody encoder (Modules.py:345-355, 371-385; ABI 6, csrc/gst_ops.hip): the GRU state at each utterance's last valid step
+ * (index ceil(length / stride_prod) - 1, :373) attends over tanh(gst_Tokens) with `H` heads (RPR_MHA.py:69-128 without relative positions / masks, one query):
+ *   hs [B][Tp][G] GRU states, lengths [B] i64 (mel frames), tokens [I][NT] = gst_Tokens, Wq [C][G], Wk / Wv [C][I], Wp [C][C] (Conv1d k = 1 weights) + biases [C]
+ *   (may be NULL) -> out [B][C].  K, V [C][NT] (batch independent) and keep (glowtts_gst_keep_floats floats) are written for the backward; fp32 arithmetic.
+ * _bwd: dout [B][C] -> dhs [B][Tp][G] (fully written: zeros but the gathered step) and every parameter gradient (overwritten; deterministic sums over the batch);
+ * scratch: B (2 C + H NT) + 2 C NT floats.  C a multiple of 64, <= 1024; NT <= 256; H <= 8 (glowtts_gst_supported). */
+int glowtts_gst_supported(int B, int Tp, int G, int C, int H, int NT, int I);
+int64_t glowtts_gst_keep_floats(int B, int G, int C, int H, int NT);
+int glowtts_gst_fwd(const float *hs, const int64_t *lengths, int stride_prod, const float *tokens, const float *Wq, const float *bq, const float *Wk,
+                    const float *bk, const float *Wv, const float *bv, const float *Wp, const float *bp, float *K, float *V, float *out, float *keep,
+                    int B, int Tp, int G, int C, int H, int NT, int I, void *stream);
+int glowtts_gst_bwd(const float *dout, const float *keep, const int64_t *lengths, int stride_prod, const float *tokens, const float *Wq, const float *Wk,
+                    const float *Wv, const float *Wp, const float *K, const float *V, float *dhs, float *scratch,
+                    float *dWq, float *dbq, float *dWk, float *dbk, float *dWv, float *dbv, float *dWp, float *dbp, float *dtokens,
+                    int B, int Tp, int G, int C, int H, int NT, int I, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Direct Conv2d(3x3, stride 2, padding 1, no bias) (+ ReLU) on channels-last activations x [B][H][W][Ci] -> y [B][Ho][Wo][Co], Ho = ceil(H / 2), Wo =
  * ceil(W / 2): the six layers of the GST reference encoder (Modules.py:320-333, 366-368; ABI 6, csrc/conv2d_ops.hip).  w is the torch Conv2d weight
  * [Co][Ci][3][3] fp32.  No patch matrix, no layout change: the forward and the data gradient are implicit GEMMs on MFMA whose A rows are gathered while

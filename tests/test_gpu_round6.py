@@ -143,3 +143,56 @@ def test_duration_mse_matches_torch():
         want = ((a.detach() - t) ** 2).sum() / den
         assert abs(got.item() - want.item()) <= 1e-6 * abs(want.item())
         assert torch.allclose(a.grad, 2 * (a.detach() - t) / den, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("B,Tp,lens", [(5, 13, [800, 64, 1, 513, 130]), (32, 13, None), (2, 4, [256, 200])])
+def test_gst_tail_matches_the_torch_modules(B, Tp, lens):
+    """The style-token tail (Modules.py:371-385: last valid GRU state -> 4-head attention over tanh(gst_Tokens) -> projection) as HIP launches (prosody._GSTTail,
+    csrc/gst_ops.hip) against the same module run through torch ops in fp64: output, d(GRU states) and all nine parameter gradients."""
+    import copy
+    from glow_tts_amd import hparams
+    from glow_tts_amd.hparams import Recursive_Parse
+    from glow_tts_amd.prosody import Prosody_Encoder
+    from helpers import launch_counts, launch_reset
+    torch.manual_seed(B + Tp)
+    hp = Recursive_Parse(copy.deepcopy(hparams.load_yaml(hparams.DEFAULT_YAML)))
+    pe = Prosody_Encoder(hp).cuda()
+    att = pe.layer_Dict["Attention"]
+    g = torch.Generator().manual_seed(7)
+    lengths = torch.tensor(lens if lens is not None else torch.randint(1, Tp * 64 + 1, (B,), generator=g).tolist())
+    hs = torch.randn(B, Tp, 128, generator=g).cuda().requires_grad_(True)
+    dout = torch.randn(B, 256, generator=g).cuda()
+
+    def tail(x, lengths_, mod, tokens):                     # prosody.Prosody_Encoder.forward's torch branch
+        import math
+        idx = (torch.ceil(lengths_ / 64.0).long() - 1).clamp_min(0)
+        h = x[torch.arange(x.size(0), device=x.device), idx]
+        keys = torch.tanh(tokens).unsqueeze(0).expand(x.size(0), -1, -1)
+        return mod(h.unsqueeze(2), keys).squeeze(2)
+
+    from glow_tts_amd.prosody import _GSTTail
+    launch_reset()
+    sq = lambda w: w.squeeze(-1)
+    q_, k_, v_, p_ = (att.layer_Dict[n] for n in ("Query", "Key", "Value", "Projection"))
+    out = _GSTTail.apply(hs, lengths.cuda(), 64, att.heads, pe.gst_Tokens, sq(q_.weight), q_.bias, sq(k_.weight), k_.bias, sq(v_.weight), v_.bias, sq(p_.weight), p_.bias)
+    out.backward(dout)
+    torch.cuda.synchronize()
+    counts = launch_counts()
+    assert counts.get("gst_fwd", 0) == 1 and counts.get("gst_bwd", 0) == 1, counts
+    params = [pe.gst_Tokens] + [t for m in (q_, k_, v_, p_) for t in (m.weight, m.bias)]
+    got = [out.detach().double().cpu(), hs.grad.double().cpu()] + [t.grad.double().cpu() for t in params]
+    ref_att = copy.deepcopy(att).double().cpu()
+    tok64 = pe.gst_Tokens.detach().double().cpu().requires_grad_(True)
+    hs64 = hs.detach().double().cpu().requires_grad_(True)
+    ref = tail(hs64, lengths.double(), ref_att, tok64)
+    ref.backward(dout.double().cpu())
+    rq, rk, rv, rp = (ref_att.layer_Dict[n] for n in ("Query", "Key", "Value", "Projection"))
+    want = [ref.detach(), hs64.grad, tok64.grad] + [t.grad for m in (rq, rk, rv, rp) for t in (m.weight, m.bias)]
+    names = ["out", "dhs", "dtokens"] + [f"d{n}.{w}" for n in ("Query", "Key", "Value", "Projection") for w in ("weight", "bias")]
+    for name, a, b_ in zip(names, got, want):
+        assert a.shape == b_.shape, (name, a.shape, b_.shape)
+        if name == "dKey.bias":                             # softmax ignores a key bias: the true gradient is 0, both sides hold rounding noise
+            assert a.abs().max() <= 1e-4 * max(1.0, want[0].abs().max().item())
+            continue
+        err = (a - b_).abs().max().item() / max(1e-6, b_.abs().max().item())
+        assert err < 2e-5, (name, err)
