@@ -647,7 +647,8 @@ def main():
     from glow_tts_amd import conv_fn as _cf, ops as _ops
     for kv in args.tune:                                      # decoder.TUNE, or the encoder's block-function switches (conv_fn.FUSE)
         k, v = kv.split("=")
-        d = _dec.TUNE if k in _dec.TUNE else _cf.FUSE
+        from glow_tts_amd import alignment as _al
+        d = _dec.TUNE if k in _dec.TUNE else _cf.FUSE if k in _cf.FUSE else _al.FUSED
         d[k] = type(d[k])(int(v))
     if args.timeline:
         _dec.STAMPS["buf"] = torch.zeros(4096, dtype=torch.int64, device=dev)

@@ -1130,8 +1130,9 @@ class DecoderFunction(torch.autograd.Function):
             # (TUNE["tail_aside"]; config 5 6.38 -> 6.08 ms/step, config 3 5.14 -> 5.11).  Only where what this function RETURNS for the tail's classes is
             # final - the (g, v) form, whose gradients nothing but AccumulateGrad touches, and only while those leaves hold no gradient yet (an
             # accumulating AccumulateGrad would read them on the caller's stream): with plain weights WeightNorm's own backward reads d w right away.
-            # Measured and rejected: holding the tail back until the prosody encoder's ~45 tiny launches are through (they take 24 us each beside 216
-            # one-per-CU weight-gradient workgroups): 6.20 against 6.08 - the tail is then the critical path behind them (profiles/r06_config5_timeline_hold.txt).
+            # Measured and rejected, twice: holding the tail back until the prosody encoder's chain of small launches is through (they take 24-45 us each beside
+            # 216 one-per-CU weight-gradient workgroups): 6.20 against 6.08 ms/step with ~45 launches in that chain, 6.00 against 5.85 with ~15 - the tail
+            # (0.95 ms) is then the critical path behind them (profiles/r06_config5_timeline_hold.txt).
             if dcond is not None and GV is not None and TUNE["tail_aside"] and _engine_callbacks_ok() and _leaf_grads_unset():
                 tail_fns = []
             (tail_fns.append if tail_fns is not None else (lambda f: f()))(lambda: [grp.launch_segment(0) for grp in (gk, gp, g1)])

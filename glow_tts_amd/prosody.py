@@ -242,7 +242,7 @@ def _gst():
     if not _GST_DECLARED:
         vp, ci, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
         L.glowtts_gst_supported.argtypes = [ci] * 7
-        L.glowtts_gst_keep_floats.argtypes = [ci] * 5
+        L.glowtts_gst_keep_floats.argtypes = [ci] * 6
         L.glowtts_gst_keep_floats.restype = i64
         L.glowtts_gst_fwd.argtypes = [vp, vp, ci] + [vp] * 13 + [ci] * 7 + [vp]
         L.glowtts_gst_bwd.argtypes = [vp, vp, vp, ci] + [vp] * 18 + [ci] * 7 + [vp]
@@ -269,7 +269,7 @@ class _GSTTail(torch.autograd.Function):
         tokens, Wq, bq, Wk, bk, Wv, bv, Wp, bp = (c(t) for t in (tokens, Wq, bq, Wk, bk, Wv, bv, Wp, bp))
         lengths = lengths.to(torch.int64).contiguous()
         K, V, out = torch.empty(C, NT, device=dev), torch.empty(C, NT, device=dev), torch.empty(B, C, device=dev)
-        keep = torch.empty(int(L.glowtts_gst_keep_floats(B, G, C, heads, NT)), device=dev)
+        keep = torch.empty(int(L.glowtts_gst_keep_floats(B, G, C, heads, NT, I)), device=dev)
         _lib.check(L.glowtts_gst_fwd(_lib.ptr(hs), _lib.ptr(lengths), int(stride_prod), _lib.ptr(tokens), _lib.ptr(Wq), _lib.ptr(bq), _lib.ptr(Wk), _lib.ptr(bk),
                                      _lib.ptr(Wv), _lib.ptr(bv), _lib.ptr(Wp), _lib.ptr(bp), _lib.ptr(K), _lib.ptr(V), _lib.ptr(out), _lib.ptr(keep),
                                      B, Tp, G, C, int(heads), NT, I, _lib.stream()), "glowtts_gst_fwd")

@@ -545,7 +545,7 @@ int glowtts_gru_bwd(const float *dhs, const float *hs, const float *keep, const 
  * _bwd: dout [B][C] -> dhs [B][Tp][G] (fully written: zeros but the gathered step) and every parameter gradient (overwritten; deterministic sums over the batch);
  * scratch: B (2 C + H NT) + 2 C NT floats.  C a multiple of 64, <= 1024; NT <= 256; H <= 8 (glowtts_gst_supported). */
 int glowtts_gst_supported(int B, int Tp, int G, int C, int H, int NT, int I);
-int64_t glowtts_gst_keep_floats(int B, int G, int C, int H, int NT);
+int64_t glowtts_gst_keep_floats(int B, int G, int C, int H, int NT, int I);
 int glowtts_gst_fwd(const float *hs, const int64_t *lengths, int stride_prod, const float *tokens, const float *Wq, const float *bq, const float *Wk,
                     const float *bk, const float *Wv, const float *bv, const float *Wp, const float *bp, float *K, float *V, float *out, float *keep,
                     int B, int Tp, int G, int C, int H, int NT, int I, void *stream);

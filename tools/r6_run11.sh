@@ -1,0 +1,8 @@
+mkdir -p gpurun_out
+python -X faulthandler -m pytest tests/test_gpu_entrypoints.py -x -q > gpurun_out/t2.log 2>&1; grep -n "Fatal\|Segmentation\|File \"/root\|File \"/tmp/code\|passed\|failed" gpurun_out/t2.log | head -40
+run() { python bench.py --no-cpu-baseline --no-f32-key --windows 2 "$@" > gpurun_out/ab.json 2> gpurun_out/ab.err; python -c "
+import json,sys;d=json.loads(open('gpurun_out/ab.json').read().strip().splitlines()[-1]);print(' '.join(sys.argv[1:]), d['ms_per_step'], d['windows']['ms_per_step_median'], d['windows']['ms_per_step_min'])" -- "$@"; }
+run --config 3
+run --config 5
+run --config 4
+python bench.py --config 5 --no-cpu-baseline --windows 0 --timeline > gpurun_out/r06f_config5_tl.json 2> gpurun_out/r06f_config5_timeline.txt; grep timeline gpurun_out/r06f_config5_timeline.txt | egrep "fwd_begin|pros|fwd_enter|dec_fwd_begin|dec_fwd_end|dec_bwd_begin|dec_bwd_flow0|wgrads|clip|enc_bwd"
