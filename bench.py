@@ -923,7 +923,7 @@ def main():
         _gd._collective(dist.all_reduce, hi_t, op=dist.ReduceOp.MAX)
         dist_check = {"rccl_ranks_seen": int(ones.item()), "world_size": dist.get_world_size(), "backend": dist.get_backend(),
                       "ms_per_step_rank_min": round(1e3 * float(lo_t) / args.steps, 3), "ms_per_step_rank_max": round(1e3 * float(hi_t) / args.steps, 3)}
-    inv = inverse_flow_leg(model, hp, dev, B, 99 + rank) if (args.config == 5 and rank == 0) else None
+    inv = inverse_flow_leg(model, hp, dev, B, 99 + rank) if (args.config == 5 and rank == 0 and not args.profile_run) else None      # (kernel-trace runs: the step's launches only)
     if rank == 0:
         value = frames * args.steps / elapsed
         ms = [1e3 * e / args.steps for e in [elapsed] + extra]

@@ -12,8 +12,9 @@
 //             x is applied in the epilogue (dx *= x > 0), so what leaves the kernel is that layer's pre-activation gradient.
 //   wgrad     dw[co][ci][kh][kw] = sum over pixels of dpre[px][co] * patch[px][(kh, kw, ci)]: the reduction runs over the slow axis of both
 //             operands, which is exactly the operand layout of v_mfma_f32_32x32x2_f32 (a lane supplies ONE element, row-major tiles are read
-//             conflict-free with ds_read_b32) - exact fp32 in both arithmetic modes, rows split over workgroups, partial images summed in a
-//             fixed order by one launch for all layers (deterministic, no atomics).
+//             conflict-free with ds_read_b32) - the f32 mode; bf16 mode: the same tiles, eight rows gathered and rounded per fragment for
+//             v_mfma_f32_32x32x16_bf16.  Rows split over workgroups, partial images summed in a fixed order by one launch for all layers
+//             (deterministic, no atomics).
 //   layer 0   (Ci = 1, K = 9) is bandwidth work - 8 MB of mel in, 65 MB of activations out at B = 32 - and runs on the VALU.
 // bf16 mode: forward / dgrad operands are rounded to bf16 while staged (v_mfma_f32_32x32x16_bf16, fp32 accumulate), f32 mode: exact fp32 MFMA.
 #include <hip/hip_runtime.h>
@@ -419,7 +420,9 @@ struct c2d_wgrad_args {
     long rows; int rows_per_split;
 };
 
-template <int MF>
+// BF: bf16 arithmetic mode - the fragments are gathered from the same row-major fp32 tiles (eight ds_read_b32 at the row pitch), rounded to bf16 in registers and
+// multiplied by v_mfma_f32_32x32x16_bf16 (1/16 of the exact-fp32 MFMA's time for the same 16 rows; the staging then sets the pace).  !BF: exact fp32.
+template <int MF, bool BF>
 __global__ __launch_bounds__(256) void c2d_wgrad_kernel(const c2d_wgrad_args p)
 {
     constexpr int RS = MF <= 2 ? 64 : 32, CO = MF * 32;                 // rows per step (a step is one memory round trip: the fatter the better; LDS: 2 x RS x (AST + BST) x 4 B)
@@ -499,14 +502,33 @@ __global__ __launch_bounds__(256) void c2d_wgrad_kernel(const c2d_wgrad_args p)
     for (int st = 0; st < nsteps; ++st) {
         const int buf = st & 1;
         if (st + 1 < nsteps) gload(r_begin + (long)(st + 1) * RS);
+        if constexpr (BF) {
 #pragma unroll
-        for (int k2 = 0; k2 < RS / 2; ++k2) {
-            const int rk = 2 * k2 + lhi;
-            const float bv = Bt[buf][rk * BST + wave * 32 + l31];
+            for (int k16 = 0; k16 < RS / 16; ++k16) {
+                const int r0 = k16 * 16 + lhi * 8;               // this lane's eight consecutive rows (the MFMA's k group)
+                Chunk16 bb;
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf) {
-                const float av = At[buf][rk * AST + mf * 32 + l31];
-                acc[mf] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mf], 0, 0, 0);
+                for (int e = 0; e < 4; ++e)
+                    bb[e] = pack_bf16x2(Bt[buf][(r0 + 2 * e) * BST + wave * 32 + l31], Bt[buf][(r0 + 2 * e + 1) * BST + wave * 32 + l31]);
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) {
+                    Chunk16 aa;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        aa[e] = pack_bf16x2(At[buf][(r0 + 2 * e) * AST + mf * 32 + l31], At[buf][(r0 + 2 * e + 1) * AST + mf * 32 + l31]);
+                    acc[mf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&aa), *reinterpret_cast<const bf16x8*>(&bb), acc[mf], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k2 = 0; k2 < RS / 2; ++k2) {
+                const int rk = 2 * k2 + lhi;
+                const float bv = Bt[buf][rk * BST + wave * 32 + l31];
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) {
+                    const float av = At[buf][rk * AST + mf * 32 + l31];
+                    acc[mf] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mf], 0, 0, 0);
+                }
             }
         }
         if (st + 1 < nsteps) sstore(buf ^ 1);
@@ -693,7 +715,8 @@ extern "C" int64_t glowtts_conv3x3s2_wgrad_scratch_floats(int B, int H, int W, i
     return (int64_t)ns * Co * 9 * Ci;
 }
 
-extern "C" int glowtts_conv3x3s2_wgrad(const float* x, const float* dpre, float* partial, int B, int H, int W, int Ci, int Co, int* splits_out, void* stream)
+extern "C" int glowtts_conv3x3s2_wgrad(const float* x, const float* dpre, float* partial, int B, int H, int W, int Ci, int Co, int precision, int* splits_out,
+                                       void* stream)
 {
     if (!x || !dpre || !partial || !c2d_shape_ok(B, H, W, Ci, Co)) return GLOWTTS_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -717,15 +740,16 @@ extern "C" int glowtts_conv3x3s2_wgrad(const float* x, const float* dpre, float*
     a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.K9 = 9 * Ci;
     a.rows = (long)B * Ho * Wo; a.rows_per_split = rps;
     const dim3 grid((a.K9 + 127) / 128, ns);
-    GLOWTTS_NOTE_STATIC("conv3x3s2_wgrad");
-#define C2D_WG(MF) do { constexpr int AST_ = MF * 32 + ((MF & 1) ? 0 : 32); constexpr size_t lds = (size_t)2 * (MF <= 2 ? 64 : 32) * (AST_ + 160) * sizeof(float); \
-        static bool done = false; if (!done) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&c2d_wgrad_kernel<MF>), \
+    GLOWTTS_NOTE("conv3x3s2_wgrad<%s>", precision == GLOWTTS_BF16 ? "bf16" : "f32");
+#define C2D_WG(MF, BF) do { constexpr int AST_ = MF * 32 + ((MF & 1) ? 0 : 32); constexpr size_t lds = (size_t)2 * (MF <= 2 ? 64 : 32) * (AST_ + 160) * sizeof(float); \
+        static bool done = false; if (!done) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&c2d_wgrad_kernel<MF, BF>), \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GLOWTTS_E_LAUNCH; done = true; } \
-        hipLaunchKernelGGL(c2d_wgrad_kernel<MF>, grid, dim3(256), lds, s, a); } while (0)
+        hipLaunchKernelGGL((c2d_wgrad_kernel<MF, BF>), grid, dim3(256), lds, s, a); } while (0)
+    const bool bf = precision == GLOWTTS_BF16;
     switch (Co / 32) {
-        case 1: C2D_WG(1); break;
-        case 2: C2D_WG(2); break;
-        case 4: C2D_WG(4); break;
+        case 1: if (bf) C2D_WG(1, true); else C2D_WG(1, false); break;
+        case 2: if (bf) C2D_WG(2, true); else C2D_WG(2, false); break;
+        case 4: if (bf) C2D_WG(4, true); else C2D_WG(4, false); break;
         default: return GLOWTTS_E_ARG;
     }
 #undef C2D_WG

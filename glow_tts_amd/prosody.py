@@ -71,7 +71,7 @@ def _c2d():
         L.glowtts_conv3x3s2_dgrad.argtypes = [vp, ctypes.POINTER(vp), vp, vp] + [ci] * 6 + [vp]
         L.glowtts_conv3x3s2_wgrad_scratch_floats.argtypes = [ci] * 5
         L.glowtts_conv3x3s2_wgrad_scratch_floats.restype = i64
-        L.glowtts_conv3x3s2_wgrad.argtypes = [vp, vp, vp] + [ci] * 5 + [ctypes.POINTER(ci), vp]
+        L.glowtts_conv3x3s2_wgrad.argtypes = [vp, vp, vp] + [ci] * 6 + [ctypes.POINTER(ci), vp]
         L.glowtts_conv3x3s2_wgrad_reduce.argtypes = [ctypes.POINTER(_ReduceJob), ci, vp]
         _C2D_DECLARED.append(True)
     return L
@@ -184,7 +184,7 @@ class _ConvStack(torch.autograd.Function):
             x = acts[l]
             partial = torch.empty(int(L.glowtts_conv3x3s2_wgrad_scratch_floats(B, H, W, Ci, Co)), device=x.device)
             splits = ctypes.c_int(0)
-            _lib.check(L.glowtts_conv3x3s2_wgrad(x.data_ptr(), dpre.data_ptr(), partial.data_ptr(), B, H, W, Ci, Co, ctypes.byref(splits), s),
+            _lib.check(L.glowtts_conv3x3s2_wgrad(x.data_ptr(), dpre.data_ptr(), partial.data_ptr(), B, H, W, Ci, Co, precision, ctypes.byref(splits), s),
                        "glowtts_conv3x3s2_wgrad")
             dw = torch.empty_like(weights[l])
             jobs[l].partial, jobs[l].dw, jobs[l].splits, jobs[l].Ci, jobs[l].Co = partial.data_ptr(), dw.data_ptr(), splits.value, Ci, Co

@@ -558,7 +558,7 @@ int glowtts_gst_bwd(const float *dout, const float *keep, const int64_t *lengths
  * Direct Conv2d(3x3, stride 2, padding 1, no bias) (+ ReLU) on channels-last activations x [B][H][W][Ci] -> y [B][Ho][Wo][Co], Ho = ceil(H / 2), Wo =
  * ceil(W / 2): the six layers of the GST reference encoder (Modules.py:320-333, 366-368; ABI 6, csrc/conv2d_ops.hip).  w is the torch Conv2d weight
  * [Co][Ci][3][3] fp32.  No patch matrix, no layout change: the forward and the data gradient are implicit GEMMs on MFMA whose A rows are gathered while
- * they are staged, the weight gradient runs on the exact-fp32 MFMA in both arithmetic modes.  Supported (glowtts_conv3x3s2_supported): Ci = 1 with
+ * they are staged, the weight gradient reads row-major tiles of both operands (exact-fp32 MFMA, or bf16 MFMA on fragments rounded in registers; layer 0: fp32 VALU).  Supported (glowtts_conv3x3s2_supported): Ci = 1 with
  * Co % 4 == 0, Co <= 128 (VALU kernels), or Ci, Co in {32, 64, 128}; B H W max(Ci, Co) < 2^31.
  *
  * Weight images (MFMA tile order, like glowtts_pack_weight): one forward image per layer with Ci > 1 and four data-gradient images, one per parity class
@@ -587,8 +587,8 @@ int glowtts_conv3x3s2_dgrad(const float *dpre, const void *const *img_dgrad, con
 #define GLOWTTS_C2D_MAX_LAYERS 8
 typedef struct glowtts_c2d_reduce_job { const float *partial; float *dw; int splits, Ci, Co, block0 /* set by the call */; } glowtts_c2d_reduce_job;
 int64_t glowtts_conv3x3s2_wgrad_scratch_floats(int B, int H, int W, int Ci, int Co);
-int glowtts_conv3x3s2_wgrad(const float *x, const float *dpre, float *partial, int B, int H, int W, int Ci, int Co, int *splits_out /* host */,
-                            void *stream);
+int glowtts_conv3x3s2_wgrad(const float *x, const float *dpre, float *partial, int B, int H, int W, int Ci, int Co, int precision,
+                            int *splits_out /* host */, void *stream);
 int glowtts_conv3x3s2_wgrad_reduce(const glowtts_c2d_reduce_job *jobs /* host */, int njobs, void *stream);
 
 /* ------------------------------------------------------------------------------------------
