@@ -445,8 +445,31 @@ __global__ __launch_bounds__(256) void c2d_wgrad_kernel(const c2d_wgrad_args p)
     const bool colok = col < p.K9;
     const int kh = colok ? col / (3 * p.Ci) : 0, kw = colok ? (col / p.Ci) % 3 : 0, cc = colok ? col % p.Ci : 0;
 
+    // Row table of a step: for each of its RS rows the element offset of input pixel (2 ho - 1, 2 wo - 1) of that row's utterance and 3 + 3 validity bits of the
+    // lines 2 ho - 1 + kh / the pixels 2 wo - 1 + kw.  RS threads fill it two steps ahead (one row -> (b, ho, wo) decomposition each); the gather of a
+    // thread's 4 - 8 rows is then an LDS read, an add of its column's constant and a shift instead of two integer divisions per row (they were the loop).
+    __shared__ int rinfo[2][RS][2];
+    const long coloff = colok ? ((long)kh * p.W + kw) * p.Ci + cc : 0;
+    const unsigned colbit = (1u << kh) | (8u << kw);
+    auto fill_rinfo = [&](long r0, int slot) __attribute__((always_inline)) {
+        if (tid < RS) {
+            const long r = r0 + tid;
+            int base = 0;
+            unsigned m = 0;
+            if (r < r_end) {
+                const int b = (int)(r / HWo), rem = (int)(r - (long)b * HWo);
+                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                const int h0 = 2 * ho - 1, w0 = 2 * wo - 1;
+                base = (int)((((long)b * p.H + h0) * p.W + w0) * p.Ci);          // (may be negative; only added to in-range columns.  |base| < 2^31: host guard)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { if (h0 + k >= 0 && h0 + k < p.H) m |= 1u << k; if (w0 + k >= 0 && w0 + k < p.W) m |= 8u << k; }
+            }
+            rinfo[slot][tid][0] = base;
+            rinfo[slot][tid][1] = (int)m;
+        }
+    };
     f32x4 ra[A_IT], rb[B_IT];
-    auto gload = [&](long r0) __attribute__((always_inline)) {
+    auto gload = [&](long r0, int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int idx = tid + it * 256;
@@ -459,17 +482,10 @@ __global__ __launch_bounds__(256) void c2d_wgrad_kernel(const c2d_wgrad_args p)
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             const int rr = (tid >> 5) + 8 * it;
-            const long r = r0 + rr;
-            bool ok = colok && (r < r_end);
-            long src = 0;
-            if (ok) {
-                const int b = (int)(r / HWo), rem = (int)(r - (long)b * HWo);
-                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                const int h = 2 * ho + kh - 1, w = 2 * wo + kw - 1;
-                ok = h >= 0 && h < p.H && w >= 0 && w < p.W;
-                src = ok ? (((long)b * p.H + h) * p.W + w) * p.Ci + cc : 0;
-            }
-            const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + src);
+            const int base = rinfo[slot][rr][0];
+            const unsigned m = (unsigned)rinfo[slot][rr][1];
+            const bool ok = colok && ((m & colbit) == colbit);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (ok ? (long)base + coloff : 0));
             rb[it] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -494,14 +510,15 @@ __global__ __launch_bounds__(256) void c2d_wgrad_kernel(const c2d_wgrad_args p)
         for (int r = 0; r < 16; ++r) acc[mf][r] = 0.f;
 
     const int nsteps = (int)((r_end - r_begin + RS - 1) / RS);
-    if (nsteps > 0) {
-        gload(r_begin);
-        sstore(0);
-    }
+    fill_rinfo(r_begin, 0);
+    __syncthreads();
+    if (nsteps > 0) gload(r_begin, 0);
+    fill_rinfo(r_begin + RS, 1);
+    if (nsteps > 0) sstore(0);
     __syncthreads();
     for (int st = 0; st < nsteps; ++st) {
         const int buf = st & 1;
-        if (st + 1 < nsteps) gload(r_begin + (long)(st + 1) * RS);
+        if (st + 1 < nsteps) gload(r_begin + (long)(st + 1) * RS, (st + 1) & 1);
         if constexpr (BF) {
 #pragma unroll
             for (int k16 = 0; k16 < RS / 16; ++k16) {
@@ -531,6 +548,8 @@ __global__ __launch_bounds__(256) void c2d_wgrad_kernel(const c2d_wgrad_args p)
                 }
             }
         }
+        // (the table slot of step st was last read by gload(st), one barrier ago: it takes step st + 2's rows now)
+        if (st + 2 < nsteps) fill_rinfo(r_begin + (long)(st + 2) * RS, buf);
         if (st + 1 < nsteps) sstore(buf ^ 1);
         __syncthreads();
     }
