@@ -20,7 +20,7 @@ extern "C" int glowtts_device_arch(char* buf, int buflen)
 
 // ---- launch log (see launch_log.h) ----
 namespace {
-constexpr int LOG_SLOTS = 128;
+constexpr int LOG_SLOTS = 1024;        // (128 filled up in a full test-suite process once round 6 added its kernel classes: later classes went uncounted)
 struct Slot { char name[96]; std::atomic<long long> n; };
 Slot g_slots[LOG_SLOTS];
 std::atomic<int> g_used{0};

@@ -84,7 +84,7 @@ def launch_counts():
     """name -> launches since the last reset (glowtts_launch_log_dump)."""
     import ctypes
     from glow_tts_amd import _lib
-    buf = ctypes.create_string_buffer(16384)
+    buf = ctypes.create_string_buffer(1 << 17)
     _lib.lib().glowtts_launch_log_dump(buf, len(buf))
     out = {}
     for line in buf.value.decode().splitlines():
