@@ -91,13 +91,9 @@ def build_model(precision, device, mode="Vanilla", spk_type="LUT"):
 def forward_losses(model, mle_loss, batch, cond):
     tokens, tl, mels, ml = batch
     z, mel_mean, mel_log_std, log_dets, log_dur, log_dur_t, _, _ = model(tokens, tl, mels, ml, cond[0], cond[1], None)
-    from glow_tts_amd.modules import Beside
-    with Beside(model) as beside:                                                        # (as Trainer._losses: beside the MLE reduction)
-        beside.uses(log_dur, log_dur_t)
-        from glow_tts_amd.alignment import duration_mse
-        length = duration_mse(log_dur, log_dur_t)                                        # Train.py:203-211 MSELoss (one launch per direction)
+    from glow_tts_amd.alignment import duration_mse
+    length = duration_mse(log_dur, log_dur_t)                                            # Train.py:203-211 MSELoss (one launch per direction; as Trainer._losses)
     mle = mle_loss(z=z, mean=mel_mean, std=mel_log_std, log_dets=log_dets, lengths=ml)
-    beside.join(length)
     return mle, length
 
 

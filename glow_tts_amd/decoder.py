@@ -185,7 +185,7 @@ TAIL = {"defer": False, "pending": []}
 #       memory system at the head of the step and the decoder's forward ends 45 us later: 5.24-5.30 against 5.20-5.23 ms/step (three alternating pairs)
 #   prep_fused: training on the fused bf16 path forms w = g v / ||v|| and every weight image in ONE launch (csrc/prep_ops.hip) instead of 4 weight-norm +
 #       ~22 packing launches (0.42 -> ~0.1 ms at the head of the step, round 4)
-TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "fwd_packs_split": 0, "cond_hip": True, "drop_skip32": True, "wgrad_tail_splits": 2, "prep_bwd_late": True, "prep_bwd_gentle": True, "tail_aside": True}
+TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "fwd_packs_split": 0, "cond_hip": True, "drop_skip32": True, "wgrad_tail_splits": 2, "prep_bwd_late": False, "prep_bwd_gentle": True, "tail_aside": True}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
@@ -395,7 +395,10 @@ class _Prepared:
         jobs = PrepJobs() if GV is not None else None
         # (round 5) the images only the BACKWARD reads - the fused data-gradient image, the per-conv transposed images - are a second launch that the caller
         # may issue later, off the decoder's chain (`launch_bwd_images`: modules.GlowTTS.forward queues it on the encoder's stream behind the encoder's forward,
-        # where it runs under the log-prior / MAS section of the step; DecoderFunction.backward issues it itself if nobody has)
+        # where it runs under the log-prior / MAS section of the step; DecoderFunction.backward issues it itself if nobody has).  Round 6: OFF by default
+        # (TUNE["prep_bwd_late"]) - one launch for every image at the head of the step again: what the deferred launch saves at the head (~40 us) is less than the
+        # two cross-stream edges it adds to the replayed graph cost (4.80 / 4.83 against 4.84 / 4.87 ms/step, two alternating rounds; an extra event edge
+        # between the two branches was measured at + 0.5 ms in the same session)
         jobs_b = PrepJobs() if (jobs is not None and need_bwd and TUNE["prep_bwd_late"]) else None
         cur = [jobs]
         self.inv = None

@@ -371,7 +371,8 @@ class GlowTTS(torch.nn.Module):
             decoder.AUX["stream"] = None
         if side is not main:
             # the log-prior needs mean / log_std only: the duration predictor still runs on the encoder's stream (joined below, before the
-            # losses read log_dur) - the encoder's forward is what this point of the step waits for (timeline)
+            # losses read log_dur) - the encoder's forward is what this point of the step waits for (timeline).  (One join behind
+            # the duration predictor instead of this event + the join below: 4.86-4.91 against 4.84-4.87 ms/step, round 6.)
             main.wait_event(prior_ready)
             for t_ in (mean, log_std, log_dur):
                 t_.record_stream(main)
@@ -381,14 +382,10 @@ class GlowTTS(torch.nn.Module):
         idx = alignment.maximum_path_t(value_t, tx32, ty32)                                          # :115-116
         if idx.shape[1] != z.shape[2]:
             idx = idx[:, :z.shape[2]].contiguous()
-        # The dense 0/1 attentions are only RETURNED (the losses use the per-frame token index): written on the encoder's stream, next to
-        # the expansion and the losses, and joined at the end of this call
+        # The dense 0/1 attentions are only RETURNED (the losses use the per-frame token index).  (Until round 6 they were written on the encoder's stream, behind a
+        # second fork of it: the 4-us launch on this stream costs the replayed graph less than that edge did - 4.78 against 4.81 ms/step.)
         from .monotonic_align import path_from_idx
-        if side is not main:
-            side.wait_stream(main)
-            idx.record_stream(side)
-        with torch.cuda.stream(side):
-            attn = path_from_idx(idx, tokens.shape[1], torch.float32)
+        attn = path_from_idx(idx, tokens.shape[1], torch.float32)
         bwd_side = side if (side is not main and torch.is_grad_enabled()) else None
         # Modules.py:120-122 in one launch (gathers by the MAS index + run lengths); MLE_Loss on these two tensors differentiates through the gather itself
         mel_mean, mel_log_std, log_dur_targets = alignment.ExpandPair.apply(mean, log_std, idx, token_lengths, bwd_side)
@@ -399,8 +396,7 @@ class GlowTTS(torch.nn.Module):
             alignment.tag_prior(mel_mean, mel_log_std, mean, log_std, idx)
         log_dur_targets = log_dur_targets.unsqueeze(1)
         if side is not main:
-            main.wait_stream(side)
-            attn.record_stream(main)
+            main.wait_stream(side)                                # (joins the duration predictor, which ran on behind the prior on the encoder's stream)
         classified = None
         if "Speaker_Classifier_GR" in self.layer_Dict:
             classified = self.layer_Dict["Speaker_Classifier_GR"](pro)                                    # Modules.py:84-87

@@ -147,21 +147,28 @@ class Trainer:
         global batch's mel frames, a 0-d device tensor computed outside the captured step (`distributed.global_frame_weight`)."""
         z, mel_Mean, mel_Log_Std, log_Dets, log_Durations, log_Duration_Targets, _, classified = model(
             tokens, token_lengths, mels, mel_lengths, speakers, mels_for_ge2e, pitches)
-        # the duration loss (and, GR, the speaker classifier's) on the encoder's stream, beside the MLE reduction: neither they nor their backward
-        # sit in front of the flow decoder's backward on this stream
+        # (GR: the duration loss and the speaker classifier's on the encoder's stream, beside the MLE reduction: neither they nor their backward
+        # sit in front of the flow decoder's backward on this stream)
         from .modules import Beside
         if self.dp and (token_extent is None or frame_weight is None):
             from .distributed import global_step_scalars
             fw, te = global_step_scalars(mel_lengths.sum(), token_lengths.max())
             frame_weight = fw if frame_weight is None else frame_weight
             token_extent = te if token_extent is None else token_extent
-        with Beside(model) as beside:
-            beside.uses(log_Durations, log_Duration_Targets, token_lengths, token_extent, classified, speakers)
+        if classified is None:
+            # round 6: the duration loss is one HIP launch per direction now - it stays on this stream (a fork and a join of the encoder's stream around it cost the
+            # replayed graph more than the two launches take: 4.78 against 4.81-4.84 ms/step)
             length = duration_loss(log_Durations, log_Duration_Targets, token_lengths, token_extent)
-            ce = self.criterion_Dict["CE"](classified, speakers) if classified is not None else None
-            rest = length + ce if ce is not None else length
-        mle = self.criterion_Dict["MLE"](z=z, mean=mel_Mean, std=mel_Log_Std, log_dets=log_Dets, lengths=mel_lengths)
-        beside.join(length, ce, rest)
+            ce, rest = None, length
+            mle = self.criterion_Dict["MLE"](z=z, mean=mel_Mean, std=mel_Log_Std, log_dets=log_Dets, lengths=mel_lengths)
+        else:
+            with Beside(model) as beside:                     # GR: the speaker classifier's cross entropy is a dozen torch launches
+                beside.uses(log_Durations, log_Duration_Targets, token_lengths, token_extent, classified, speakers)
+                length = duration_loss(log_Durations, log_Duration_Targets, token_lengths, token_extent)
+                ce = self.criterion_Dict["CE"](classified, speakers)
+                rest = length + ce
+            mle = self.criterion_Dict["MLE"](z=z, mean=mel_Mean, std=mel_Log_Std, log_dets=log_Dets, lengths=mel_lengths)
+            beside.join(length, ce, rest)
         total = mle + length
         if self.dp:
             loss = mle * frame_weight + rest / self.world
