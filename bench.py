@@ -595,6 +595,7 @@ def main():
                     "even with one rank: exercises RCCL on a single-GPU box")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to smoke-test the "
                     "multi-rank code path on a single-GPU box together with --one-device)")
+    ap.add_argument("--no-defer-uploads", action="store_true", help="A/B: job tables as memcpy nodes inside the captured graphs (rounds 2-5) instead of one eager upload after the capture")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel eagerly instead of replaying the "
                     "captured hipGraph of the step (default: graph replay; at B = 32 the eager step is bound by host launch work)")
     ap.set_defaults(graph=True)
@@ -640,6 +641,7 @@ def main():
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from glow_tts_amd import _lib, decoder as _dec
+    _lib.DEFER_UPLOADS = not args.no_defer_uploads
     from glow_tts_amd import conv_fn as _cf, ops as _ops
     for kv in args.tune:                                      # decoder.TUNE, or the encoder's block-function switches (conv_fn.FUSE)
         k, v = kv.split("=")

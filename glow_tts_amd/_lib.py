@@ -91,26 +91,54 @@ _SPARE = {}            # nbytes -> [pinned uint8 tensors not owned by any captur
 _SPARE_CAP = 4         # same-size tables per step (e.g. the optimizer's and the gradient-norm table of one parameter list)
 _OWNED = []            # buffers handed to captures when no sink is active (live as long as the process)
 _SINKS = []
+DEFER_UPLOADS = True    # (A/B switch of bench.py --no-defer-uploads: False = the copy nodes of rounds 2-5)
 
 
 class pinned_sink:
-    """`with pinned_sink(lst):` - pinned buffers taken by captures inside the block are appended to `lst` (keep it alive with the graph)."""
+    """`with pinned_sink(lst):` around one or more hipGraph captures - pinned buffers taken by captures inside the block are appended to `lst` (keep it alive with the
+    graphs).  Round 6, `defer` (default): a table uploaded under capture does NOT become a memcpy node of the graph.  Its contents never change between replays (the
+    pointers in it are the graph's own buffers), so the device copy is a slice of an arena allocated when the block is entered (outside the captures), filled ONCE,
+    eagerly, when the block exits - before the first replay.
+    A memcpy node in front of a launch was two dependency hops on that chain in every replay (~15-25 us at the head of the decoder's backward, ~10 in front of the
+    gradient norm, more on the encoder's side)."""
 
-    def __init__(self, keep):
-        self.keep = keep
+    ARENA_BYTES = 2 << 20
+
+    def __init__(self, keep, defer=None):
+        self.keep, self.defer, self.pending = keep, bool(DEFER_UPLOADS if defer is None else defer), []
+        self.arena, self.used = None, 0
 
     def __enter__(self):
-        _SINKS.append(self.keep)
+        _SINKS.append(self)
+        if self.defer and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            # the tables' device memory is allocated HERE, outside the captures: a block allocated under capture may be one that an earlier launch of the same
+            # capture used as scratch and freed - every replay would then overwrite a table that is only uploaded once
+            self.arena = torch.empty(self.ARENA_BYTES, dtype=torch.uint8, device=torch.cuda.current_device())
+            self.keep.append(self.arena)
         return self.keep
+
+    def take(self, n, device):
+        """n bytes of the arena (256-byte aligned), or None when it is exhausted / on another device."""
+        if self.arena is None or self.arena.device != torch.device(device) or self.used + n > self.arena.numel():
+            return None
+        t = self.arena[self.used:self.used + n]
+        self.used += (n + 255) & ~255
+        return t
 
     def __exit__(self, *exc):
         _SINKS.pop()
+        if self.pending and exc[0] is None:
+            for pinned, dst in self.pending:
+                dst.copy_(pinned, non_blocking=True)
+            torch.cuda.synchronize()
+        self.pending = []
         return False
 
 
 def staged_upload(raw, device):
     """bytes -> device uint8 tensor.  Eager: synchronous copy from a private buffer (the host may run ahead of the stream) and one more
-    spare pinned buffer of this size is put aside; capturing: the copy node reads a pinned buffer that from now on belongs to the graph."""
+    spare pinned buffer of this size is put aside; capturing: the table is filled once when the enclosing `pinned_sink` exits (see there), or - no sink - by a
+    copy node that reads a pinned buffer that from now on belongs to the graph."""
     n = len(raw)
     src = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
     if torch.cuda.is_current_stream_capturing():
@@ -120,7 +148,12 @@ def staged_upload(raw, device):
                                   f"{n} bytes; pinned memory cannot be allocated during capture)")
         pinned = pool.pop()
         pinned.copy_(src)
-        (_SINKS[-1] if _SINKS else _OWNED).append(pinned)
+        sink = _SINKS[-1] if _SINKS else None
+        (sink.keep if sink is not None else _OWNED).append(pinned)
+        dst = sink.take(n, device) if (sink is not None and sink.defer) else None
+        if dst is not None:
+            sink.pending.append((pinned, dst))
+            return dst
         return pinned.to(device, non_blocking=True)
     pool = _SPARE.setdefault(n, [])
     if len(pool) < _SPARE_CAP:
