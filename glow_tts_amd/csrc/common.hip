@@ -128,6 +128,25 @@ extern "C" int glowtts_debug_stamp(long long* slot, void* stream)
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
+// One 31-bit dropout seed word per training step from a counter in device memory (see glowtts_step_seed in the header)
+__global__ void step_seed_kernel(uint32_t* state, uint32_t* out)
+{
+    if (threadIdx.x == 0) {
+        const uint32_t c = state[0] + 1u;
+        state[0] = c;
+        uint32_t h = state[1] + c * 0x9E3779B9u;
+        h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+        out[0] = h & 0x7FFFFFFFu;
+    }
+}
+
+extern "C" int glowtts_step_seed(uint32_t* state, uint32_t* out, void* stream)
+{
+    if (!state || !out) return GLOWTTS_E_ARG;
+    hipLaunchKernelGGL(step_seed_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), state, out);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
 extern "C" int glowtts_mfma_clock_probe(long long* out, int nwg, int iters, int* wall_khz, void* stream)
 {
     if (!out || nwg <= 0 || iters <= 0) return GLOWTTS_E_ARG;

@@ -189,6 +189,31 @@ TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pac
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
+_SEED_STATE = {}
+
+
+def step_seed(device):
+    """-> int32 tensor [1]: the dropout seed word of this training step.  Eager: one draw from torch's generator, as ever (torch.manual_seed reproduces the masks; every
+    forward owns its word, so several forwards may precede a backward).  Under hipGraph capture: glowtts_step_seed - a counter in device memory advanced by a launch of
+    the graph itself, so that every replay draws a new word without torch's philox machinery (an RNG launch on each stream's chain and two fills of the generator's
+    offset words in front of every replay); the base is a hash of torch.initial_seed() at the first eager call (per-rank seeds give per-rank masks)."""
+    key = str(device)
+    st = _SEED_STATE.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if st is None:
+        if capturing:
+            raise _lib.GlowTTSHipError("run one eager training step before capturing a hipGraph (the dropout seed state is created eagerly)")
+        st = _SEED_STATE[key] = torch.zeros(2, dtype=torch.int32, device=device)
+        st[1] = int((torch.initial_seed() * 0x9E3779B97F4A7C15 >> 33) & 0x7FFFFFFF)      # (torch.manual_seed decides it; no draw is consumed)
+    if not capturing:
+        return torch.randint(0, 2 ** 31 - 1, (1,), device=device, dtype=torch.int32)
+    out = torch.empty(1, dtype=torch.int32, device=device)
+    L = _L()
+    L.glowtts_step_seed.argtypes = [c_void_p, c_void_p, c_void_p]
+    _lib.check(L.glowtts_step_seed(st.data_ptr(), out.data_ptr(), _lib.stream()), "glowtts_step_seed")
+    return out
+
+
 def stamp(name):
     """Diagnostics: record when the current stream reaches this point (one tiny launch; only while tools/step_timeline.py armed it)."""
     if STAMPS["buf"] is None:
@@ -847,7 +872,7 @@ def actnorm_data_init(cfg, W, mels, lengths, cond=None, allreduce=None, pitch=No
 # the second branch late), and the 80-us preparation launch sat behind that.  `early_prepare` builds the _Prepared; DecoderFunction.forward picks it up.
 EARLY = {"prep": None, "key": None}
 # A stream the caller joins with its own before it consumes z / the log-determinants (modules.GlowTTS.forward: the text encoder's stream), or None
-AUX = {"stream": None, "stacks": None}
+AUX = {"stream": None, "stacks": None, "seed": None}
 
 
 def _leaf_grads_unset():
@@ -899,7 +924,11 @@ class DecoderFunction(torch.autograd.Function):
                              rows=mels.shape[0] * (mels.shape[2] // cfg.ns + 2 * ROW_PAD), GV=GV)
         ctx.GV = GV
         # one random word on the device (torch's graph-safe generator); kept for the backward, which regenerates the masks
-        seed = torch.randint(0, 2 ** 31 - 1, (1,), device=mels.device, dtype=torch.int32) if drop_p > 0 else None
+        seed = None
+        if drop_p > 0:                                          # (GlowTTS.forward hands the step's word over; a direct caller draws one here)
+            seed, AUX["seed"] = AUX.get("seed"), None
+            if seed is None:
+                seed = step_seed(mels.device)
         pitch = (pitches.detach(), pitch_w.detach().contiguous(), pitch_b.detach().contiguous()) if pitches is not None else None
         if pitch is not None and condc is None:
             raise _lib.GlowTTSHipError("per-frame pitch conditioning comes with the GR mode's speaker / prosody conditioning (Modules.py:84-90)")

@@ -83,7 +83,7 @@ def token_masks(token_lengths, T):
 
 
 def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training=False, prefix="layer_Dict.Encoder",
-                    precision=1, cache=None, on_prior_ready=None, pack_stream=None, rowmask=None):
+                    precision=1, cache=None, on_prior_ready=None, pack_stream=None, rowmask=None, seed_t=None):
     """Modules.py:262-284 -> mean [B,mel,T], log_std [B,mel,T], log_durations [B,1,T] (channel-first, like the reference).
     pack_stream: a stream forked from the step's origin stream for the second weight-packing launch (see `_PackSets.run`)."""
     e = hp.Encoder
@@ -93,7 +93,11 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
     # [B*Tp] row mask (0 on pad rows); `rowmask`: already built with the mask (token_masks)
     rmf = rowmask if rowmask is not None else F.pad(mask.squeeze(1), (ROW_PAD, ROW_PAD)).reshape(-1).contiguous()
     dev = tokens.device
-    seed_t = torch.randint(0, 2 ** 31 - 1, (1,), device=dev, dtype=torch.int32) if training else None
+    if training and seed_t is None:
+        from .decoder import step_seed
+        seed_t = step_seed(dev)
+    elif not training:
+        seed_t = None
     counter = [0]
 
     def nseed():                                     # a distinct dropout stream per call site (added to the device seed word)

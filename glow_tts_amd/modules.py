@@ -323,7 +323,12 @@ class GlowTTS(torch.nn.Module):
         if self._enc_stream is None:
             self._enc_stream = torch.cuda.Stream()      # (equal priority: a priority difference between the two branches of the replayed graph, in either direction, doubles the step - DESIGN.md section 5)
         side = self._enc_stream if self.overlap_encoder else main
+        # the step's dropout seed word: one launch here, in front of the fork - both streams' dropout kernels read it (round 6; torch.randint drew one word on each
+        # stream: two RNG launches inside the graph and two fills of the generator's offset words in front of every replay)
+        seed_word = decoder.step_seed(mels.device) if self.training else None
         side.wait_stream(main)
+        if seed_word is not None and side is not main:
+            seed_word.record_stream(side)
         pack_aux = None
         if side is not main and decoder.TUNE["enc_pack_split"]:
             if self._pack_stream is None:
@@ -350,7 +355,7 @@ class GlowTTS(torch.nn.Module):
             mean, log_std, log_dur = encoder.encoder_forward(P, hp, tokens, token_mask, spk, pro, self.training, precision=self.dec_cfg.precision,
                                                              cache=self._enc_cache, rowmask=token_rowmask,
                                                              on_prior_ready=prior_done if prior_ready is not None else None,
-                                                             pack_stream=pack_aux)
+                                                             pack_stream=pack_aux, seed_t=seed_word)
         decoder.stamp("main_after_enc_launch")
         # (the conditioning convs on a third stream, forked in front of the decoder's weight preparation and joined here, were measured in round 6: config 3 6.00
         #  against 5.11 ms/step, config 4 4.65 against 3.9 - a third branch in the replayed graph costs far more than the ~35 us it would hide)
@@ -364,11 +369,12 @@ class GlowTTS(torch.nn.Module):
         # (training on the fused bf16 path: W holds the weight-norm pairs themselves - every weight image was prepared by one launch above)
         drop_p = float(hp.Decoder.Affine_Coupling.WaveNet.Dropout_Rate) if self.training else 0.0      # Modules.py:854-862
         decoder.AUX["stream"] = side if side is not main else None          # (z / log-determinant passes: off the chain to the log-prior, joined below)
+        decoder.AUX["seed"] = seed_word
         try:
             z, log_dets, z_rows = decoder.DecoderFunction.apply(self.dec_cfg, mels, mel_lengths, cond, drop_p, pitches, pitch_w if pitches is not None else None,
                                                                 pitch_b if pitches is not None else None, *W)
         finally:
-            decoder.AUX["stream"] = None
+            decoder.AUX["stream"] = decoder.AUX["seed"] = None
         if side is not main:
             # the log-prior needs mean / log_std only: the duration predictor still runs on the encoder's stream (joined below, before the
             # losses read log_dur) - the encoder's forward is what this point of the step waits for (timeline).  (One join behind

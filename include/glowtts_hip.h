@@ -49,6 +49,11 @@ int glowtts_mfma_clock_probe(long long *out, int nwg, int iters, int *wall_khz, 
 /* Diagnostics: a one-thread kernel that writes the constant-rate wall counter (the rate glowtts_mfma_clock_probe reports) to *slot when the
  * stream reaches it - a timeline of a replayed hipGraph from inside the graph (tools/step_timeline.py). */
 int glowtts_debug_stamp(long long *slot, void *stream);
+/* The dropout seed word of a training step (ABI 6; Modules.py:481, 561-569, 862: torch's Dropout draws from the global generator).  state (device, 2 words:
+ * counter, base - the base drawn once from torch's generator) -> counter += 1, out[0] = a 31-bit hash of (base, counter): every dropout kernel of the step adds its own
+ * layer constant to this word (the `seed_ptr` arguments).  A launch of its own instead of torch.randint: inside a replayed hipGraph the philox draw costs two fills of
+ * the generator's offset words in front of EVERY replay and an RNG launch on each of the two streams' chains. */
+int glowtts_step_seed(uint32_t *state, uint32_t *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Monotonic Alignment Search.
