@@ -188,7 +188,7 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
                                      const glowtts_flow_grads* g, void* stream)
 {
     CHECK(check_dims(d));
-    if (!p || !a || !g || !g->dx || !g->dlogdet || !g->douts || !g->dskip || !g->dh[0] || !g->dins[0] || !g->scratch) return GLOWTTS_E_ARG;
+    if (!p || !a || !g || !g->dx || !g->dlogdet || !g->dskip || !g->dh[0] || !g->dins[0] || !g->scratch) return GLOWTTS_E_ARG;
     const Ctx c = make_ctx(d, p, a, stream);
     const int H = c.H, L = d->L, C = d->C, C2 = c.C2, R = c.R;
     const int ldo = p->end.npad;          // PAIR-packed (m, logs) width
@@ -204,6 +204,7 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
     const bool bfg = bf;                      // ... and so are dskip and dh[l >= 1] (dh[0] stays fp32: it feeds the fp32 Start conv gradients)
     // 1. affine coupling backward                                               autograd of Modules.py:805-806
     const bool dbf = bfg && g->douts_bf != nullptr;        // a bf16 copy of douts feeds the End data gradient (DMA / chained kernel)
+    if (!g->douts && (!dbf || !g->defer_wgrad)) return GLOWTTS_E_ARG;      // (douts == NULL: the bf16 copy alone is kept - every reader here must take it)
     if (g->coupling_done) { /* fused into the previous call's last kernel */ }
     else if (dbf) CHECK(glowtts_coupling_bwd_bf16(g->dx, a->xmid, a->outs, g->douts, g->douts_bf, a->rowmask, g->dlogdet, R, C, ldo, c.Tp, stream));
     else     CHECK(glowtts_coupling_bwd(g->dx, a->xmid, a->outs, g->douts, a->rowmask, g->dlogdet, R, C, ldo, c.Tp, stream));

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void coupling_bwd_kernel(float* __restrict__ d
         const int j = (int)(i - r * P2);
         const int pc = (j >> 5) * 64 + (j & 31);
         if (j >= C2) {
-            douts[r * ldo + pc] = 0.f; douts[r * ldo + pc + 32] = 0.f;
+            if (douts) { douts[r * ldo + pc] = 0.f; douts[r * ldo + pc + 32] = 0.f; }
             if (douts16) { douts16[r * ldo + pc] = (__bf16)0.f; douts16[r * ldo + pc + 32] = (__bf16)0.f; }
             continue;
         }
@@ -236,8 +236,10 @@ __global__ __launch_bounds__(256) void coupling_bwd_kernel(float* __restrict__ d
         const float d = dz[r * C + C2 + j];
         const float xb = xmid[r * C + C2 + j];
         const float dm = d * m, dl = (d * e * xb + dld[r / rows_per_utt]) * m;
-        douts[r * ldo + pc] = dm;
-        douts[r * ldo + pc + 32] = dl;
+        if (douts) {
+            douts[r * ldo + pc] = dm;
+            douts[r * ldo + pc + 32] = dl;
+        }
         if (douts16) { douts16[r * ldo + pc] = (__bf16)dm; douts16[r * ldo + pc + 32] = (__bf16)dl; }
         dz[r * C + C2 + j] = d * e * m;
     }
@@ -317,12 +319,12 @@ __global__ __launch_bounds__(256) void actnorm_inv_bwd_kernel(const float* __res
                     const int j = 2 * g + k, pc = (j >> 5) * 64 + (j & 31);
                     const float d = o[2 + k], e = expf(nc.outs[r * nc.ldo + pc + 32]);
                     const float dm = d * m, dlg = (d * e * (k ? xb.y : xb.x) + dl) * m;
-                    nc.douts[r * nc.ldo + pc] = dm; nc.douts[r * nc.ldo + pc + 32] = dlg;
+                    if (nc.douts) { nc.douts[r * nc.ldo + pc] = dm; nc.douts[r * nc.ldo + pc + 32] = dlg; }
                     if (nc.douts16) { nc.douts16[r * nc.ldo + pc] = (__bf16)dm; nc.douts16[r * nc.ldo + pc + 32] = (__bf16)dlg; }
                     ob[k] = d * e * m;
                     for (int jp = C2 + j; jp < nc.ldo / 2; jp += C2) {       // pad slots of the PAIR packing: zero (see coupling_bwd_kernel)
                         const int pp = (jp >> 5) * 64 + (jp & 31);
-                        nc.douts[r * nc.ldo + pp] = 0.f; nc.douts[r * nc.ldo + pp + 32] = 0.f;
+                        if (nc.douts) { nc.douts[r * nc.ldo + pp] = 0.f; nc.douts[r * nc.ldo + pp + 32] = 0.f; }
                         if (nc.douts16) { nc.douts16[r * nc.ldo + pp] = (__bf16)0.f; nc.douts16[r * nc.ldo + pp + 32] = (__bf16)0.f; }
                     }
                 }
@@ -430,9 +432,11 @@ __global__ __launch_bounds__(256) void actnorm_inv_bwd4_kernel(const float* __re
                     const float d = o[4 + k], e = expf(lgv[k]);
                     dm[k] = d * m; dg[k] = (d * e * xbv[k] + dl) * m; ob[k] = d * e * m;
                 }
-                float* dob = nc.douts + r * nc.ldo;
-                *reinterpret_cast<float4*>(dob + pc) = make_float4(dm[0], dm[1], dm[2], dm[3]);
-                *reinterpret_cast<float4*>(dob + pc + 32) = make_float4(dg[0], dg[1], dg[2], dg[3]);
+                float* dob = nc.douts ? nc.douts + r * nc.ldo : nullptr;      // (NULL: only the bf16 copy is kept - round 6, the fp32 rows had no reader on the bf16 path)
+                if (dob) {
+                    *reinterpret_cast<float4*>(dob + pc) = make_float4(dm[0], dm[1], dm[2], dm[3]);
+                    *reinterpret_cast<float4*>(dob + pc + 32) = make_float4(dg[0], dg[1], dg[2], dg[3]);
+                }
                 typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
                 if (nc.douts16) {
                     bf4 a, b;
@@ -443,8 +447,10 @@ __global__ __launch_bounds__(256) void actnorm_inv_bwd4_kernel(const float* __re
                 }
                 for (int jp = C2 + j0; jp < nc.ldo / 2; jp += C2) {      // pad slots of the PAIR packing: zero (see coupling_bwd_kernel)
                     const int pp = (jp >> 5) * 64 + (jp & 31);
-                    *reinterpret_cast<float4*>(dob + pp) = make_float4(0.f, 0.f, 0.f, 0.f);
-                    *reinterpret_cast<float4*>(dob + pp + 32) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (dob) {
+                        *reinterpret_cast<float4*>(dob + pp) = make_float4(0.f, 0.f, 0.f, 0.f);
+                        *reinterpret_cast<float4*>(dob + pp + 32) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
                     if (nc.douts16) {
                         *reinterpret_cast<uint2*>(nc.douts16 + r * nc.ldo + pp) = make_uint2(0u, 0u);
                         *reinterpret_cast<uint2*>(nc.douts16 + r * nc.ldo + pp + 32) = make_uint2(0u, 0u);
@@ -647,7 +653,7 @@ extern "C" int glowtts_coupling_bwd(float* dz, const float* xmid, const float* o
 extern "C" int glowtts_coupling_bwd_bf16(float* dz, const float* xmid, const float* outs, float* douts, void* douts_bf16, const float* rowmask,
                                          const float* dlogdet, int64_t rows, int C, int ldo, int rows_per_utt, void* stream)
 {
-    if (!dz || !xmid || !outs || !douts || !douts_bf16 || !rowmask || !dlogdet || rows < 1 || C < 2) return GLOWTTS_E_ARG;
+    if (!dz || !xmid || !outs || !douts_bf16 || !rowmask || !dlogdet || rows < 1 || C < 2) return GLOWTTS_E_ARG;       // (douts may be NULL: bf16 copy only)
     if ((ldo & 63) || ldo < C) return GLOWTTS_E_ARG;
     hipLaunchKernelGGL(coupling_bwd_kernel, dim3(grid_for(rows * (ldo / 2))), dim3(256), 0, static_cast<hipStream_t>(stream),
                        dz, xmid, outs, douts, static_cast<__bf16*>(douts_bf16), rowmask, dlogdet, (long)rows, C, ldo, rows_per_utt);
@@ -689,7 +695,7 @@ extern "C" int glowtts_actnorm_inv1x1_bwd_coupling(const float* dz, float* dx, c
                                                    const float* dlogdet, int ldo, int rows_per_utt, void* stream)
 {
     if (!dz || !dx || !x || !logs || !bias || !winfo || !rowmask || !scratch || rows < 1 || C < 4 || (C & 3) || C / 4 > 256) return GLOWTTS_E_ARG;
-    if (!prev_xmid || !prev_outs || !prev_douts || !dlogdet || (ldo & 63) || ldo < C || rows_per_utt < 1) return GLOWTTS_E_ARG;
+    if (!prev_xmid || !prev_outs || (!prev_douts && !prev_douts_bf16) || !dlogdet || (ldo & 63) || ldo < C || rows_per_utt < 1) return GLOWTTS_E_ARG;
     const int rpb = an_bwd_rpb();
     const int nblk = (int)((rows + rpb - 1) / rpb);
     const NextCoupling nc{prev_xmid, prev_outs, prev_douts, static_cast<__bf16*>(prev_douts_bf16), dlogdet, ldo, rows_per_utt};

@@ -996,7 +996,10 @@ class DecoderFunction(torch.autograd.Function):
         d_an = torch.empty(F_, 2 * C + 16, device=dev)
         # every flow / layer keeps its own gradient buffers: the weight gradients of ALL flows are computed afterwards by
         # two grouped launches (k-tap problems, 1x1 problems) whose tiles fill the chip without split-K or atomics
-        douts = torch.empty(F_, R, prep.ldo, device=dev)           # (pad columns are zeroed by the coupling backward kernel)
+        # (fp32 rows of d(m, logs): only where somebody reads them - with bf16-stored activations every consumer, the End conv's data and weight gradients, takes
+        #  the bf16 copy below, and the coupling backward then writes that copy alone: 768 of the 4 480 bytes per row of its pass, round 6)
+        h0bf_ = bool(cfg.act_bf16 and buf.xa_bf is not None and buf.skipb is not None)
+        douts = None if h0bf_ else torch.empty(F_, R, prep.ldo, device=dev)           # (pad columns are zeroed by the coupling backward kernel)
         # bf16 copy of d(m, logs): the End data gradient's operand and (round 4) DY of the End conv's weight gradient - one per flow, like everything the
         # deferred weight-gradient launches read
         douts_bf = torch.empty(F_, R, prep.ldo, device=dev, dtype=torch.bfloat16) if cfg.act_bf16 else None
@@ -1110,13 +1113,13 @@ class DecoderFunction(torch.autograd.Function):
             r0 = b0 * Tp
             for f in order:
                 g = FlowGrads()
-                g.dx, g.dlogdet, g.douts, g.dskip = at(dx, r0), dld.data_ptr() + 4 * b0, at(douts[f], r0), at(dskip[f], r0)
+                g.dx, g.dlogdet, g.douts, g.dskip = at(dx, r0), dld.data_ptr() + 4 * b0, (at(douts[f], r0) if douts is not None else None), at(dskip[f], r0)
                 g.douts_bf = at(douts_bf[f], r0) if douts_bf is not None else None
                 g.dh0_bf16 = int(h0bf)
                 # the last kernel of this flow's backward also applies the coupling backward of the flow that runs next (f - 1)
                 g.coupling_done = int(fuse and f != order[0])
                 if fuse and f > 0:
-                    g.prev_xmid, g.prev_outs, g.prev_douts = at(buf.xmid[f - 1], r0), at(buf.outs[f - 1], r0), at(douts[f - 1], r0)
+                    g.prev_xmid, g.prev_outs, g.prev_douts = at(buf.xmid[f - 1], r0), at(buf.outs[f - 1], r0), (at(douts[f - 1], r0) if douts is not None else None)
                     g.prev_douts_bf = at(douts_bf[f - 1], r0) if douts_bf is not None else None
                 g.scratch, g.d_an, g.defer_wgrad = scratch[f].data_ptr() + 4 * blk_off[ci] * (2 * C + 16), None, 1
                 for l in range(Lw):

@@ -432,7 +432,8 @@ typedef struct glowtts_flow_acts {        /* rows tensors, R = B*(T+2*PAD) rows 
 typedef struct glowtts_flow_grads {       /* backward outputs; weight grads are ADDED (zero them first) */
     float *dx;                            /* [R][C] in: dL/dxout, out: dL/dxin (in place) */
     const float *dlogdet;                 /* [B] dL/dlogdet */
-    float *douts;                         /* [R][ldo] scratch (pad columns must be zero on entry) */
+    float *douts;                         /* [R][ldo] scratch (pad columns must be zero on entry).  ABI 6: may be NULL with douts_bf given and defer_wgrad set -
+                                           * the coupling backward then writes the bf16 copy alone (no reader of the fp32 rows is left on that path) */
     float *dskip;                         /* [R][H] scratch */
     float *dh[GLOWTTS_MAX_WN_LAYERS];     /* [R][H] d(WaveNet state entering layer l) * mask; may alias as a ping-pong pair
                                              (dh[l] != dh[l+1]) unless defer_wgrad, which needs them all distinct */
