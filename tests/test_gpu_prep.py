@@ -18,11 +18,12 @@ def _stacks(n_flows, seed):
     return D, dc, D.DecoderStacks(P, dc), P, g
 
 
-@pytest.mark.parametrize("nskip,nfb", [(1, 2), (0, 3), (2, 0), (1, 1)])
-def test_prep_images_byte_identical(nskip, nfb):
+@pytest.mark.parametrize("nskip,nfb,late", [(1, 2, True), (0, 3, True), (2, 0, True), (1, 1, True), (1, 2, False), (0, 3, False)])
+def test_prep_images_byte_identical(nskip, nfb, late):
+    """late: the backward-only images as a second launch (TUNE["prep_bwd_late"], round 5's default) or every image in the one launch at the head (round 6's)."""
     D, dc, st, P, _ = _stacks(3, 5)
     old = dict(D.TUNE)
-    D.TUNE.update(fused_wn_fwd_skip=nskip, fused_wn_bwd=nfb)
+    D.TUNE.update(fused_wn_fwd_skip=nskip, fused_wn_bwd=nfb, prep_bwd_late=late)
     try:
         with torch.no_grad():
             W = dict(zip(D.WEIGHT_KEYS, [w.contiguous() for w in st.weights()]))
@@ -37,7 +38,7 @@ def test_prep_images_byte_identical(nskip, nfb):
             got.launch_bwd_images()                                     # (idempotent)
             torch.cuda.synchronize()
             lc = launch_counts()
-        assert lc.get("prep_weights", 0) == 2 and not any(k.startswith("pack") or k.startswith("weightnorm") for k in lc), lc
+        assert lc.get("prep_weights", 0) == (2 if late else 1) and not any(k.startswith("pack") or k.startswith("weightnorm") for k in lc), lc
         # (the Start conv's three K chunks fill 1.5 of its two slabs; the other half slab is never written nor read)
         hole = slice(36864, 49152)
         a, b = got.wn_img.clone(), ref.wn_img.clone()
