@@ -104,10 +104,17 @@ def train_step(model, mle_loss, batch, cond, reducer=None, world=1, opt=None):
     duration MSE (a mean over its padded [B,1,Tt]) by 1/world, and gradients are SUMMED: the result is the gradient of the
     single-process loss on the global batch (tests/test_distributed_cpu.py)."""
     from glow_tts_amd.distributed import global_frame_weight
-    mle, length = forward_losses(model, mle_loss, batch, cond)
-    loss = mle * global_frame_weight(batch[3].sum()) + length / world if reducer is not None else mle + length
+    from glow_tts_amd import alignment
+    seeds = None
+    if reducer is not None:
+        seeds = [global_frame_weight(batch[3].sum()), torch.full((), 1.0 / world, device=batch[2].device)]
+        alignment.SEEDS["mle"], alignment.SEEDS["rest"] = seeds
+    try:
+        mle, length = forward_losses(model, mle_loss, batch, cond)
+    finally:
+        alignment.SEEDS["mle"] = alignment.SEEDS["rest"] = None
     model.zero_grad(set_to_none=True)
-    loss.backward()
+    alignment.LossTerms([mle, length], seeds).backward()        # Train.py:213-216 `loss = MLE + Length; loss.backward()` (as Trainer._losses: seeded per term)
     if reducer is not None:
         reducer.reduce(average=False)
     if opt is not None:
@@ -706,11 +713,17 @@ def main():
                 _, coef = grad_norm_and_coef(params, opt[2])
                 opt[0].step(grad_scale=coef)
 
+            inv_world = torch.full((), 1.0 / world, device=batch[2].device) if dp else None
+
             def fwd_bwd():
-                mle, length = forward_losses(model, mle_loss, batch, cond)
+                from glow_tts_amd import alignment
+                alignment.SEEDS["mle"], alignment.SEEDS["rest"] = (wfr, inv_world) if dp else (None, None)
+                try:
+                    mle, length = forward_losses(model, mle_loss, batch, cond)
+                finally:
+                    alignment.SEEDS["mle"] = alignment.SEEDS["rest"] = None
                 model.zero_grad(set_to_none=True)
-                total = mle * wfr + length / world if dp else mle + length
-                total.backward()
+                alignment.LossTerms([mle, length], [wfr, inv_world] if dp else None).backward()      # (as Trainer._losses: no sum node in front of the backward)
                 if opt is not None and not dp:
                     clip_and_update()
                 return (mle + length).detach()
@@ -880,9 +893,10 @@ def main():
         # round 1's definition of the step (forward + losses + backward, no update), for continuity: a second graph of the same model
         try:
             def fwd_bwd_noopt():
+                from glow_tts_amd import alignment
                 mle, length = forward_losses(model, mle_loss, batch, cond)
                 model.zero_grad(set_to_none=True)
-                (mle + length).backward()
+                alignment.LossTerms([mle, length]).backward()
                 return (mle + length).detach()
             g2, keep2 = torch.cuda.CUDAGraph(), []
             with torch.cuda.stream(side):

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libglowtts_hip.so")
 if os.environ.get("GLOWTTS_LIB_PATH"):
     LIB_PATH = os.environ["GLOWTTS_LIB_PATH"]
 _lib = None
-ABI_VERSION = 6                          # GLOWTTS_ABI_VERSION of include/glowtts_hip.h
+ABI_VERSION = 7                          # GLOWTTS_ABI_VERSION of include/glowtts_hip.h
 
 c_int, c_float, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -87,6 +87,45 @@ def stream():
 # (2) Eager copies from a pinned buffer that the host rewrites every step go through a ring with one event per slot (`PinnedRing`),
 #     so that the host running ahead of the stream never overwrites words an in-flight copy has not read yet.
 # --------------------------------------------------------------------------------------------------------------------
+_PERSIST = {}
+
+
+def persistent(device, key, factory):
+    """A small device tensor that lives as long as the process (the constant 1 a backward pass is seeded with, the zeroed completion counters of the
+    last-workgroup reductions), created on first use OUTSIDE a capture; under a capture that is the first use: None (the caller takes its unfused path)."""
+    import torch
+    k = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), key)
+    t = _PERSIST.get(k)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        t = _PERSIST[k] = factory()
+    return t
+
+
+def one(device):
+    """The constant 1.0 (a 0-d fp32 device tensor): `LossTerms.backward` seeds the loss terms with THIS tensor, and a loss node whose forward launch already wrote
+    the gradients for that seed recognises it by identity and launches nothing (alignment.PriorLoss / DurationMSE)."""
+    import torch
+    return persistent(device, "one", lambda: torch.ones((), device=device))
+
+
+def counter(device, key, owner=None):
+    """The zeroed uint32 a last-workgroup reduction counts its finished workgroups in (the kernel leaves it zero).  One launch at a time may use it: `owner` (a
+    dict that lives with the module issuing the launches - MLE_Loss, the encoder's cache) keeps one per module; without an owner it is one per process and
+    device."""
+    import torch
+    if owner is None:
+        return persistent(device, ("counter", key), lambda: torch.zeros(1, dtype=torch.int32, device=device))
+    k = ("counter", key, str(device))
+    t = owner.get(k)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        t = owner[k] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
 _SPARE = {}            # nbytes -> [pinned uint8 tensors not owned by any captured graph]
 _SPARE_CAP = 4         # same-size tables per step (e.g. the optimizer's and the gradient-norm table of one parameter list)
 _OWNED = []            # buffers handed to captures when no sink is active (live as long as the process)

@@ -24,24 +24,24 @@ def _lib2():
         L.glowtts_duration_targets.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
         L.glowtts_mle_loss_fwd.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.glowtts_mle_loss_bwd.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
-        L.glowtts_expand_pair_targets.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        L.glowtts_expand_pair_targets.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        L.glowtts_prior_loss.argtypes = [ctypes.c_void_p] * 17 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
         L.glowtts_prior_loss_bwd.argtypes = [ctypes.c_void_p] * 10 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
-        L.glowtts_mse_loss_fwd.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.glowtts_mse_loss_fwd.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p]
         L.glowtts_mse_loss_bwd.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _decl = True
     return L
 
 
 @torch.no_grad()
-def log_prior_t(mean, log_std, z, token_lengths, mel_lengths, mel_multiple=1, return_lengths=False, z_rows=None):
-    """Modules.py:108-114, transposed: returns value_t [B, T_mel, T_tok] = log N(z_y; mean_x, std_x) * mask.
-    mean/log_std [B, Cm, Tx], z [B, Cm, Ty] (channel-first like the reference).  Always fp32 (MAS ties).
-    mel_multiple: mel lengths are rounded down to a multiple of it on the device (Decoder.Num_Squeeze); return_lengths: also return the
-    int32 (token, mel) lengths the kernels used, for maximum_path_t."""
+def log_prior_prepare(mean, log_std, token_lengths, mel_lengths, Ty, mel_multiple=1):
+    """The operands of the log-prior GEMM that depend on the ENCODER's outputs and the lengths only (csrc/loss_ops.hip logprior_prep_tile_kernel): the packed
+    (sigma^-2 | mu sigma^-2) weight image, the per-token constant, the frame mask and the int32 lengths.  `GlowTTS.forward` calls it on the encoder's stream, right
+    behind the projection - off the chain between the flow decoder's last launch and its backward - and hands the result to `log_prior_t`."""
     B, Cm, Tx = mean.shape
-    Ty = z.shape[2]
     L = _lib2()
-    dev = z.device
+    dev = mean.device
     mean, log_std = mean.contiguous(), log_std.contiguous()
     npad, kch = ctypes.c_int(0), ctypes.c_int(0)
     _lib.check(L.glowtts_logprior_prep(None, None, None, None, None, None, None, None, None, B, Cm, Tx, Ty, int(mel_multiple), ctypes.byref(npad), ctypes.byref(kch), None),
@@ -53,6 +53,27 @@ def log_prior_t(mean, log_std, z, token_lengths, mel_lengths, mel_multiple=1, re
     _lib.check(L.glowtts_logprior_prep(_lib.ptr(mean), _lib.ptr(log_std), _lib.ptr(token_lengths.contiguous()), _lib.ptr(mel_lengths.contiguous()),
                                        _lib.ptr(packed), _lib.ptr(cb), _lib.ptr(fmask), _lib.ptr(tx), _lib.ptr(ty), B, Cm, Tx, Ty, int(mel_multiple), None, None,
                                        _lib.stream()), "glowtts_logprior_prep")
+    return {"packed": packed, "cb": cb, "fmask": fmask, "tx": tx, "ty": ty, "npad": npad.value, "kch": kch.value, "stride": stride, "dims": (B, Cm, Tx, Ty)}
+
+
+@torch.no_grad()
+def log_prior_t(mean, log_std, z, token_lengths, mel_lengths, mel_multiple=1, return_lengths=False, z_rows=None, prepared=None):
+    """Modules.py:108-114, transposed: returns value_t [B, T_mel, T_tok] = log N(z_y; mean_x, std_x) * mask.
+    mean/log_std [B, Cm, Tx], z [B, Cm, Ty] (channel-first like the reference).  Always fp32 (MAS ties).
+    mel_multiple: mel lengths are rounded down to a multiple of it on the device (Decoder.Num_Squeeze); return_lengths: also return the
+    int32 (token, mel) lengths the kernels used, for maximum_path_t.  prepared: `log_prior_prepare`'s result for these tensors."""
+    B, Cm, Tx = mean.shape
+    Ty = z.shape[2]
+    dev = z.device
+    if prepared is None or prepared["dims"] != (B, Cm, Tx, Ty):
+        prepared = log_prior_prepare(mean, log_std, token_lengths, mel_lengths, Ty, mel_multiple)
+    packed, cb, fmask, tx, ty = (prepared[k] for k in ("packed", "cb", "fmask", "tx", "ty"))
+    stride = prepared["stride"]
+
+    class _V:                                                               # (the two sizes the launch below reads)
+        def __init__(self, v):
+            self.value = v
+    npad, kch = _V(prepared["npad"]), _V(prepared["kch"])
     # frames x channels operand: the decoder's own output rows when the caller has them (z_rows [B*(Ty/ns + 2*ROW_PAD), ns*Cm]: a squeezed
     # row holds ns consecutive frames x Cm channels, ROW_PAD pad rows in front of every utterance), else a transposed copy of z
     from . import decoder as _D
@@ -158,37 +179,47 @@ def _segment_sums(dout, idx, Tx, stream):
 
 
 class ExpandPair(torch.autograd.Function):
-    """Modules.py:120-122 in ONE launch (round 6): mel_Mean = mean @ attentions, mel_Log_Std = log_Std @ attentions (gathers by the MAS token index) and
-    log_Duration_Targets = log(sum_t attentions + 1e-7) * token_mask -> (mel_mean [B, C, Ty], mel_log_std [B, C, Ty], targets [B, Tx]; the targets carry no
-    gradient, Modules.py:107).  The general backward is ExpandPrior's (two segment-sum passes); `MLE_Loss` on exactly these two outputs never runs it - it
-    differentiates through the expansion itself (`PriorLoss`).  Ty % 4 != 0: the three separate launches."""
+    """Modules.py:116, 120-122 in ONE launch (round 6): mel_Mean = mean @ attentions, mel_Log_Std = log_Std @ attentions (gathers by the MAS token index),
+    log_Duration_Targets = log(sum_t attentions + 1e-7) * token_mask and - want_path - the dense 0/1 attentions themselves -> (mel_mean [B, C, Ty],
+    mel_log_std [B, C, Ty], targets [B, Tx], attentions [B, Tx, Ty] or None; targets and attentions carry no gradient, Modules.py:107).  The general backward is
+    ExpandPrior's (two segment-sum passes); `MLE_Loss` on exactly these two outputs never runs it - it differentiates through the expansion itself
+    (`PriorLoss`).  Ty % 4 != 0: the separate launches."""
 
     @staticmethod
-    def forward(ctx, mean, log_std, idx, token_lengths, bwd_stream=None):
+    def forward(ctx, mean, log_std, idx, token_lengths, bwd_stream=None, want_path=False):
         mean, log_std = mean.contiguous(), log_std.contiguous()
         B, C, Tx = mean.shape
         Ty = idx.shape[1]
         dev = mean.device
         om, ol, tg = torch.empty(B, C, Ty, device=dev), torch.empty(B, C, Ty, device=dev), torch.empty(B, Tx, device=dev)
+        path = None
         L = _lib2()
         if Ty % 4 == 0:
+            if want_path:
+                path = torch.empty(B, Tx, Ty, device=dev)
             _lib.check(L.glowtts_expand_pair_targets(_lib.ptr(mean), _lib.ptr(log_std), _lib.ptr(idx), _lib.ptr(token_lengths.contiguous()), _lib.ptr(om),
-                                                     _lib.ptr(ol), _lib.ptr(tg), B, C, Tx, Ty, _lib.stream()), "glowtts_expand_pair_targets")
+                                                     _lib.ptr(ol), _lib.ptr(tg), _lib.ptr(path), B, C, Tx, Ty, _lib.stream()), "glowtts_expand_pair_targets")
         else:
             _lib.check(L.glowtts_expand_fwd(_lib.ptr(mean), _lib.ptr(idx), _lib.ptr(om), B, C, Tx, Ty, _lib.stream()), "glowtts_expand_fwd")
             _lib.check(L.glowtts_expand_fwd(_lib.ptr(log_std), _lib.ptr(idx), _lib.ptr(ol), B, C, Tx, Ty, _lib.stream()), "glowtts_expand_fwd")
             _lib.check(L.glowtts_duration_targets(_lib.ptr(idx), _lib.ptr(token_lengths.contiguous()), _lib.ptr(tg), B, Tx, Ty, _lib.stream()),
                        "glowtts_duration_targets")
+            if want_path:
+                from .monotonic_align import path_from_idx
+                path = path_from_idx(idx, Tx, torch.float32)
         ctx.save_for_backward(idx)
         ctx.Tx, ctx.bwd_stream = Tx, bwd_stream
         ctx.mark_non_differentiable(tg)
-        return om, ol, tg
+        if path is None:
+            return om, ol, tg, None
+        ctx.mark_non_differentiable(path)
+        return om, ol, tg, path
 
     @staticmethod
-    def backward(ctx, dm, dl, _dt):
+    def backward(ctx, dm, dl, _dt, _dp=None):
         (idx,) = ctx.saved_tensors
         return (None if dm is None else _segment_sums(dm, idx, ctx.Tx, ctx.bwd_stream), None if dl is None else _segment_sums(dl, idx, ctx.Tx, ctx.bwd_stream),
-                None, None, None)
+                None, None, None, None)
 
 
 class PriorTag:
@@ -242,76 +273,156 @@ class MLELoss(torch.autograd.Function):
 
 
 class PriorLoss(torch.autograd.Function):
-    """MLE_Loss (Modules.py:1020-1029) on the expanded prior of `GlowTTS.forward`, differentiated THROUGH the expansion (:120-121): the forward is MLELoss's (same
-    kernels, same value), the backward is one launch that writes d z per frame and the gradients of the TOKEN-space mean / log_std as sums over each token's
-    contiguous run of frames (csrc/loss_ops.hip prior_loss_bwd_kernel) - the expanded gradients (2 x 8 MB) and the two segment-sum passes behind them never exist.
-    Same bits as MLELoss + ExpandPrior.  apply(z, mean_tok, log_std_tok, log_dets, lengths, n_squeeze, mel_dim, mel_mean, mel_log_std, idx)."""
+    """MLE_Loss (Modules.py:1020-1029) on the expanded prior of `GlowTTS.forward`, differentiated THROUGH the expansion (:120-121): the value is MLELoss's (same
+    reduction, same bits), the gradients are d z per frame and the gradients of the TOKEN-space mean / log_std as sums over each token's contiguous run of
+    frames (csrc/loss_ops.hip prior_bwd_block) - the expanded gradients (2 x 8 MB) and the two segment-sum passes behind them never exist.  Same bits as
+    MLELoss + ExpandPrior.  apply(z, mean_tok, log_std_tok, log_dets, lengths, n_squeeze, mel_dim, mel_mean, mel_log_std, idx, seed, owner).
+
+    `seed` (a 0-d device tensor, normally `_lib.one`): the value the caller's backward will be seeded with.  Given, ONE launch writes the loss AND the
+    gradients for that seed (glowtts_prior_loss), and a backward that arrives with exactly this tensor launches nothing; any other seed: the separate
+    backward launch (glowtts_prior_loss_bwd)."""
 
     @staticmethod
-    def forward(ctx, z, mean_tok, ls_tok, log_dets, lengths, n_squeeze, mel_dim, mel_mean, mel_ls, idx):
+    def forward(ctx, z, mean_tok, ls_tok, log_dets, lengths, n_squeeze, mel_dim, mel_mean, mel_ls, idx, seed=None, owner=None):
         z, log_dets = z.contiguous(), log_dets.contiguous()
+        mean_tok, ls_tok = mean_tok.contiguous(), ls_tok.contiguous()
         dev = z.device
+        B, C, Ty = z.shape
+        Tx = mean_tok.shape[2]
         loss, inv = torch.empty((), device=dev), torch.empty(1, device=dev)
         scratch = torch.empty(1024, device=dev)
-        _lib.check(_lib2().glowtts_mle_loss_fwd(_lib.ptr(z), _lib.ptr(mel_mean.contiguous()), _lib.ptr(mel_ls.contiguous()), _lib.ptr(log_dets),
-                                                _lib.ptr(lengths.contiguous()), loss.data_ptr(), inv.data_ptr(), _lib.ptr(scratch), z.numel(), z.shape[0], n_squeeze,
-                                                mel_dim, _lib.stream()), "glowtts_mle_loss_fwd")
-        ctx.save_for_backward(z, mean_tok.contiguous(), ls_tok.contiguous(), idx, inv)
+        L = _lib2()
+        counter = _lib.counter(dev, "prior_loss", owner) if seed is not None else None
+        ctx.seed, ctx.stash = None, None
+        if counter is not None:
+            dz, dm, dl = torch.empty_like(z), torch.empty_like(mean_tok), torch.empty_like(ls_tok)
+            dlogdet = torch.empty(B, device=dev)
+            _lib.check(L.glowtts_prior_loss(_lib.ptr(z), _lib.ptr(mel_mean.contiguous()), _lib.ptr(mel_ls.contiguous()), _lib.ptr(mean_tok), _lib.ptr(ls_tok),
+                                            _lib.ptr(idx), _lib.ptr(log_dets), _lib.ptr(lengths.contiguous()), _lib.ptr(seed), _lib.ptr(scratch), _lib.ptr(counter),
+                                            loss.data_ptr(), inv.data_ptr(), _lib.ptr(dz), _lib.ptr(dm), _lib.ptr(dl), _lib.ptr(dlogdet), B, C, Tx, Ty,
+                                            int(n_squeeze), int(mel_dim), _lib.stream()), "glowtts_prior_loss")
+            ctx.seed, ctx.stash = seed, (dz, dm, dl, dlogdet)
+        else:
+            _lib.check(L.glowtts_mle_loss_fwd(_lib.ptr(z), _lib.ptr(mel_mean.contiguous()), _lib.ptr(mel_ls.contiguous()), _lib.ptr(log_dets),
+                                              _lib.ptr(lengths.contiguous()), loss.data_ptr(), inv.data_ptr(), _lib.ptr(scratch), z.numel(), B, n_squeeze,
+                                              mel_dim, _lib.stream()), "glowtts_mle_loss_fwd")
+        ctx.save_for_backward(z, mean_tok, ls_tok, idx, inv)
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
         z, mean_tok, ls_tok, idx, inv = ctx.saved_tensors
+        none = (None,) * 8
+        if ctx.seed is not None and dloss.data_ptr() == ctx.seed.data_ptr() and dloss.numel() == 1:
+            stash, ctx.stash = ctx.stash, None
+            return stash + none
+        ctx.stash = None
         B, C, Ty = z.shape
         Tx = mean_tok.shape[2]
         dz, dm, dl = torch.empty_like(z), torch.empty_like(mean_tok), torch.empty_like(ls_tok)
         dlogdet = torch.empty(B, device=z.device)
         _lib.check(_lib2().glowtts_prior_loss_bwd(_lib.ptr(z), _lib.ptr(mean_tok), _lib.ptr(ls_tok), _lib.ptr(idx), _lib.ptr(dloss.contiguous().reshape(1)), _lib.ptr(inv),
                                                   _lib.ptr(dz), _lib.ptr(dm), _lib.ptr(dl), _lib.ptr(dlogdet), B, C, Tx, Ty, _lib.stream()), "glowtts_prior_loss_bwd")
-        return dz, dm, dl, dlogdet, None, None, None, None, None, None
+        return (dz, dm, dl, dlogdet) + none
 
 
-FUSED = {"prior_loss": True}        # tests / A-B runs: False keeps MLELoss + the expansion's own backward
+FUSED = {"prior_loss": True,        # tests / A-B runs: False keeps MLELoss + the expansion's own backward
+         "seeded": True}            # False: loss nodes never write their gradients in the forward launch (the backward launches of rounds 1-5)
+SEEDS = {"mle": None, "rest": None}  # what `LossTerms.backward` will seed the terms with (None = `_lib.one`); a data-parallel trainer sets its frame weight / 1 / world here
 
 
-def mle_loss(z, mean, std, log_dets, lengths, n_squeeze, mel_dim):
+def _seed(kind, device):
+    if not FUSED["seeded"] or not torch.is_grad_enabled():
+        return None
+    s = SEEDS.get(kind)
+    if s is not None:
+        return s if (torch.is_tensor(s) and s.is_cuda and s.numel() == 1 and s.dtype == torch.float32) else None
+    return _lib.one(device)
+
+
+def mle_loss(z, mean, std, log_dets, lengths, n_squeeze, mel_dim, owner=None):
     """`MLE_Loss.forward`: through the expansion when (mean, std) are the expanded prior `GlowTTS.forward` returned (and carry its tag), else on the tensors as given."""
     tag = prior_tag_of(mean, std) if (FUSED["prior_loss"] and torch.is_grad_enabled() and z.is_cuda) else None
     if tag is not None and (tag.mean.requires_grad or tag.log_std.requires_grad):
-        return PriorLoss.apply(z, tag.mean, tag.log_std, log_dets, lengths, n_squeeze, mel_dim, mean.detach(), std.detach(), tag.idx)
+        return PriorLoss.apply(z, tag.mean, tag.log_std, log_dets, lengths, n_squeeze, mel_dim, mean.detach(), std.detach(), tag.idx, _seed("mle", z.device), owner)
     return MLELoss.apply(z, mean, std, log_dets, lengths, n_squeeze, mel_dim)
+
+
+class LossTerms:
+    """The sum of loss terms a training step differentiates (Train.py:213-216 `loss = MLE + Length (+ Speaker)`, `loss.backward()`), kept as its terms: `backward()`
+    seeds every term with its weight directly - no sum node, no ones_like fill in front of the backward - and with the very tensors the terms' forward launches
+    were told about (`SEEDS`), so that nodes which wrote their gradients in the forward launch recognise the seed and launch nothing.  The weighted sum itself
+    (for the log) is computed AFTER the backward was queued.  Duck-types the one tensor method the step loops use (`backward`, `detach`)."""
+
+    def __init__(self, terms, seeds=None, after=None):
+        self.terms = [t for t in terms if t is not None]
+        seeds = list(seeds) if seeds is not None else [None] * len(terms)
+        self.seeds = [s for t, s in zip(terms, seeds) if t is not None]
+        self.after, self._total = after, None
+
+    def _seed_of(self, t, s):
+        if s is not None:
+            return s.reshape(()) if s.dim() else s
+        o = _lib.one(t.device) if t.is_cuda else None
+        return o if o is not None else torch.ones_like(t)
+
+    def backward(self):
+        torch.autograd.backward(self.terms, [self._seed_of(t, s) for t, s in zip(self.terms, self.seeds)])
+        self.detach()
+        if self.after is not None:
+            self.after()
+
+    def detach(self):
+        if self._total is None:
+            tot = None
+            for t, s in zip(self.terms, self.seeds):
+                v = t.detach() if s is None else t.detach() * s
+                tot = v if tot is None else tot + v
+            self._total = tot
+        return self._total
+
+    def item(self):
+        return self.detach().item()
 
 
 class DurationMSE(torch.autograd.Function):
     """The duration loss (Train.py:203-211 `MSELoss()(log_Durations, log_Duration_Targets)`) as one launch per direction.  denom: None = the element count (torch's
     mean); token_lengths [B] i64 = B x the batch's own longest text (trainer.duration_loss: the token axis is padded to a shape bucket); extent = a 0-d device
-    tensor holding the longest text of the GLOBAL batch (data parallel)."""
+    tensor holding the longest text of the GLOBAL batch (data parallel).  seed: see PriorLoss - with the constant 1 the forward launch also writes the gradient,
+    and a backward seeded with that tensor launches nothing (any other seed scales it in one launch)."""
 
     @staticmethod
-    def forward(ctx, a, target, token_lengths=None, extent=None):
+    def forward(ctx, a, target, token_lengths=None, extent=None, seed=None):
         a, target = a.contiguous(), target.contiguous()
         loss = torch.empty((), device=a.device)
         B = int(a.shape[0])
         ext = None if extent is None else extent.to(torch.float32).reshape(1).contiguous()
         tl = None if (token_lengths is None or ext is not None) else token_lengths.contiguous()
+        one = _lib.one(a.device) if seed is not None else None
+        unit = seed is not None and one is not None and seed.data_ptr() == one.data_ptr()        # (the forward writes the gradient for the seed 1 only)
+        da = torch.empty_like(a) if unit else None
         _lib.check(_lib2().glowtts_mse_loss_fwd(_lib.ptr(a), _lib.ptr(target), loss.data_ptr(), a.numel(), 1.0 / a.numel(), _lib.ptr(tl), B, _lib.ptr(ext),
-                                                _lib.stream()), "glowtts_mse_loss_fwd")
+                                                _lib.ptr(da), _lib.stream()), "glowtts_mse_loss_fwd")
         ctx.save_for_backward(a, target, tl, ext)
+        ctx.seed, ctx.stash = (seed if unit else None), da
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
         a, target, tl, ext = ctx.saved_tensors
+        stash, ctx.stash = ctx.stash, None
+        if ctx.seed is not None and dloss.data_ptr() == ctx.seed.data_ptr() and dloss.numel() == 1:
+            return stash, None, None, None, None
         da = torch.empty_like(a)
         _lib.check(_lib2().glowtts_mse_loss_bwd(_lib.ptr(a), _lib.ptr(target), _lib.ptr(dloss.contiguous().reshape(1)), _lib.ptr(da), a.numel(), 1.0 / a.numel(),
                                                 _lib.ptr(tl), int(a.shape[0]), _lib.ptr(ext), _lib.stream()), "glowtts_mse_loss_bwd")
-        return da, None, None, None
+        return da, None, None, None, None
 
 
 def duration_mse(log_durations, log_duration_targets, token_lengths=None, extent=None):
     if not log_durations.is_cuda:
         raise _lib.GlowTTSHipError("glow_tts_amd runs on the GPU only (no CPU fallback)")
-    return DurationMSE.apply(log_durations, log_duration_targets.detach(), token_lengths, extent)
+    return DurationMSE.apply(log_durations, log_duration_targets.detach(), token_lengths, extent, _seed("rest", log_durations.device))
 
 
 @torch.no_grad()

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/glowtts_hip.h"
+#include "launch_log.h"
 
 namespace {
 
@@ -65,36 +66,60 @@ __global__ __launch_bounds__(256) void dur_target_kernel(const int32_t* __restri
 }
 
 // MLE_Loss (Modules.py:1025): partial sums of  log_std + 0.5 * exp(-2 log_std) * (z - mean)^2  (two-stage, deterministic)
-__global__ __launch_bounds__(256) void mle_partial_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ ls,
-                                                          float* __restrict__ partial, long n)
+template <bool PUBLISH>
+__device__ __forceinline__ void mle_partial_block(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ ls,
+                                                  float* __restrict__ partial, long n, int blk, int nblk, float* red)
 {
-    __shared__ float red[256];
     float acc = 0.f;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    for (long i = blk * 256L + threadIdx.x; i < n; i += (long)nblk * 256) {
         const float d = z[i] - mean[i];
         acc += ls[i] + 0.5f * expf(-2.f * ls[i]) * d * d;
     }
     red[threadIdx.x] = acc; __syncthreads();
     for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
-    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+    if (threadIdx.x == 0) {
+        if (PUBLISH) {                                         // a RETURNING device-scope exchange: when its value is back it has been performed (see prior_loss_kernel)
+            const float old = atomicExch(partial + blk, red[0]);
+            asm volatile("s_waitcnt vmcnt(0)" :: "v"(old) : "memory");
+        } else partial[blk] = red[0];
+    }
+}
+__global__ __launch_bounds__(256) void mle_partial_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ ls,
+                                                          float* __restrict__ partial, long n)
+{
+    __shared__ float red[256];
+    mle_partial_block<false>(z, mean, ls, partial, n, blockIdx.x, gridDim.x, red);
+}
+// 1 / (sum(len // ns) * ns * mel_dim): the denominator of the loss (Modules.py:1026) - a function of the lengths alone
+__device__ __forceinline__ double mle_denominator(const int64_t* __restrict__ lengths, int B, int ns, int mel_dim)
+{
+    long frames = 0;
+    for (int i = 0; i < B; ++i) frames += (lengths[i] / ns) * ns;
+    return (double)frames * mel_dim;
 }
 // loss = (sum partial - sum logdet) / (sum(len // ns) * ns * mel_dim) + 0.5 log(2 pi);  also writes 1/denominator for the backward
-__global__ __launch_bounds__(256) void mle_final_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ logdet, const int64_t* __restrict__ lengths,
-                                                        int B, int ns, int mel_dim, float* __restrict__ loss, float* __restrict__ inv_denom)
+// COHERENT: `partial` was published by other workgroups of the SAME launch (prior_loss_kernel's last workgroup): read back by device-scope atomics
+template <bool COHERENT>
+__device__ __forceinline__ void mle_final_block(const float* __restrict__ partial, int nblk, const float* __restrict__ logdet, const int64_t* __restrict__ lengths,
+                                                int B, int ns, int mel_dim, float* __restrict__ loss, float* __restrict__ inv_denom, double* red)
 {
-    __shared__ double red[256];
     double acc = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 256) acc += partial[i];
+    for (int i = threadIdx.x; i < nblk; i += 256)
+        acc += COHERENT ? __uint_as_float(atomicOr(reinterpret_cast<unsigned int*>(const_cast<float*>(partial)) + i, 0u)) : partial[i];
     for (int i = threadIdx.x; i < B; i += 256) acc -= logdet[i];
     red[threadIdx.x] = acc; __syncthreads();
     for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
     if (threadIdx.x == 0) {
-        long frames = 0;
-        for (int i = 0; i < B; ++i) frames += (lengths[i] / ns) * ns;
-        const double den = (double)frames * mel_dim;
+        const double den = mle_denominator(lengths, B, ns, mel_dim);
         *loss = (float)(red[0] / den + 0.5 * 1.8378770664093453);
         *inv_denom = (float)(1.0 / den);
     }
+}
+__global__ __launch_bounds__(256) void mle_final_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ logdet, const int64_t* __restrict__ lengths,
+                                                        int B, int ns, int mel_dim, float* __restrict__ loss, float* __restrict__ inv_denom)
+{
+    __shared__ double red[256];
+    mle_final_block<false>(partial, nblk, logdet, lengths, B, ns, mel_dim, loss, inv_denom, red);
 }
 // gradients: dz = g e (z - m), dmean = -dz, dls = g (1 - e (z - m)^2), with e = exp(-2 ls), g = dloss / denom
 __global__ __launch_bounds__(256) void mle_bwd_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ ls,
@@ -111,15 +136,17 @@ __global__ __launch_bounds__(256) void mle_bwd_kernel(const float* __restrict__ 
     }
 }
 
-// Round 6.  Both expansions (Modules.py:120-121) and the duration targets (:122) in ONE launch: blocks [0, nexp) sweep 16-byte groups of the two outputs
-// (expand_fwd4_kernel's pattern, one int4 of token indices serves both rows), the last B blocks count the run lengths (dur_target_kernel).
+// Round 6.  Both expansions (Modules.py:120-121), the duration targets (:122) and - path != NULL - the dense attentions (:116) in ONE launch: blocks [0, nexp)
+// sweep 16-byte groups of the two outputs (expand_fwd4_kernel's pattern, one int4 of token indices serves both rows), blocks [nexp, nexp + npath) write the
+// 0/1 matrix, the last B blocks count the run lengths (dur_target_kernel).
 __global__ __launch_bounds__(256) void expand_pair_kernel(const float* __restrict__ mean, const float* __restrict__ ls, const int32_t* __restrict__ idx,
                                                           const int64_t* __restrict__ t_x, float* __restrict__ omean, float* __restrict__ ols,
-                                                          float* __restrict__ targets, int C, int Tx, int Ty, unsigned int total4, int nexp)
+                                                          float* __restrict__ targets, int C, int Tx, int Ty, unsigned int total4, int nexp,
+                                                          float* __restrict__ path, unsigned int ptotal4, int npath)
 {
     extern __shared__ int cnt[];
-    if ((int)blockIdx.x >= nexp) {
-        const int b = blockIdx.x - nexp;
+    if ((int)blockIdx.x >= nexp + npath) {
+        const int b = blockIdx.x - nexp - npath;
         for (int x = threadIdx.x; x < Tx; x += 256) cnt[x] = 0;
         __syncthreads();
         const int32_t* ib = idx + (long)b * Ty;
@@ -130,6 +157,18 @@ __global__ __launch_bounds__(256) void expand_pair_kernel(const float* __restric
         return;
     }
     const unsigned int q = (unsigned int)Ty >> 2;
+    if ((int)blockIdx.x >= nexp) {
+        // the dense 0/1 attentions [B][Tx][Ty] (Modules.py:116; only RETURNED by GlowTTS.forward): mas.hip's mas_path_linear_kernel, same bytes
+        for (unsigned int i = (blockIdx.x - (unsigned int)nexp) * 256u + threadIdx.x; i < ptotal4; i += (unsigned int)npath * 256u) {
+            const unsigned int row = i / q, y4 = i - row * q;      // row = b * Tx + x
+            const unsigned int b = row / (unsigned int)Tx, x = row - b * (unsigned int)Tx;
+            const int4 id = *reinterpret_cast<const int4*>(idx + (size_t)b * Ty + (size_t)y4 * 4);
+            float4 v;
+            v.x = id.x == (int)x ? 1.f : 0.f; v.y = id.y == (int)x ? 1.f : 0.f; v.z = id.z == (int)x ? 1.f : 0.f; v.w = id.w == (int)x ? 1.f : 0.f;
+            *reinterpret_cast<float4*>(path + (size_t)i * 4) = v;
+        }
+        return;
+    }
     for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < total4; i += (unsigned int)nexp * 256u) {
         const unsigned int row = i / q, y4 = i - row * q;          // row = b * C + c
         const unsigned int b = row / (unsigned int)C;
@@ -149,16 +188,14 @@ __global__ __launch_bounds__(256) void expand_pair_kernel(const float* __restric
 // (2 x 8 MB at B = 32) are never written and the two expand_bwd passes (2 x 56 us in the step, at the head of the text encoder's backward) disappear.
 // One wavefront per (utterance, channel) row, 64 frames per pass, the token-keyed segmented scan of expand_bwd_kernel on both sums at once; the values
 // and the order of every addition are those of mle_bwd_kernel + expand_bwd_kernel: the results are the same bits.
-__global__ __launch_bounds__(256) void prior_loss_bwd_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ ls,
-                                                             const int32_t* __restrict__ idx, const float* __restrict__ dloss,
-                                                             const float* __restrict__ inv_denom, float* __restrict__ dz, float* __restrict__ dmean,
-                                                             float* __restrict__ dls, float* __restrict__ dlogdet, int B, int C, int Tx, int Ty)
+__device__ __forceinline__ void prior_bwd_block(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ ls,
+                                                const int32_t* __restrict__ idx, const float g, float* __restrict__ dz, float* __restrict__ dmean,
+                                                float* __restrict__ dls, float* __restrict__ dlogdet, int B, int C, int Tx, int Ty, int bx, int b, float* pl_sm)
 {
-    extern __shared__ float pl_sm[];                     // per wave: m [Tx], e [Tx], acc1 [Tx], acc2 [Tx]
-    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float g = dloss[0] * inv_denom[0];
-    if (dlogdet && blockIdx.x == 0 && blockIdx.y == 0) for (int i = threadIdx.x; i < B; i += 256) dlogdet[i] = -g;      // Modules.py:1025-1027
-    const int c = blockIdx.x * 4 + wave;
+    // pl_sm per wave: m [Tx], e [Tx], acc1 [Tx], acc2 [Tx]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (dlogdet && bx == 0 && b == 0) for (int i = threadIdx.x; i < B; i += 256) dlogdet[i] = -g;      // Modules.py:1025-1027
+    const int c = bx * 4 + wave;
     if (c >= C) return;                                  // (no workgroup barrier below)
     float* m = pl_sm + (size_t)wave * 4 * Tx;
     float* e = m + Tx;
@@ -191,6 +228,54 @@ __global__ __launch_bounds__(256) void prior_loss_bwd_kernel(const float* __rest
     __builtin_amdgcn_wave_barrier();
     for (int x = lane; x < Tx; x += 64) { dmean[trow + x] = a1[x]; dls[trow + x] = a2[x]; }
 }
+__global__ __launch_bounds__(256) void prior_loss_bwd_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ ls,
+                                                             const int32_t* __restrict__ idx, const float* __restrict__ dloss,
+                                                             const float* __restrict__ inv_denom, float* __restrict__ dz, float* __restrict__ dmean,
+                                                             float* __restrict__ dls, float* __restrict__ dlogdet, int B, int C, int Tx, int Ty)
+{
+    extern __shared__ float pl_sm[];
+    prior_bwd_block(z, mean, ls, idx, dloss[0] * inv_denom[0], dz, dmean, dls, dlogdet, B, C, Tx, Ty, blockIdx.x, blockIdx.y, pl_sm);
+}
+
+// Round 6.  MLE_Loss on the expanded prior, forward AND the gradients for d loss = dloss[0] (the caller passes the constant 1 its backward will be seeded with),
+// in ONE launch: workgroups [0, nblk) are mle_partial_kernel's, the next cg * B are prior_loss_bwd_kernel's (their scale 1 / denominator depends on the
+// lengths alone, not on the sum), and the workgroup that finishes LAST (a device counter, reset for the next launch) runs mle_final_kernel's reduction.
+// Same values in the same order as the three launches: the same bits.  What it buys: the chain between the alignment search and the flow decoder's
+// backward is two dependent launches shorter, and the 15-us gradient pass runs beside the 14-us reduction.
+__global__ __launch_bounds__(256) void prior_loss_kernel(const float* __restrict__ z, const float* __restrict__ mel_mean, const float* __restrict__ mel_ls,
+                                                         const float* __restrict__ mean, const float* __restrict__ ls, const int32_t* __restrict__ idx,
+                                                         const float* __restrict__ logdet, const int64_t* __restrict__ lengths, const float* __restrict__ dloss,
+                                                         float* __restrict__ partial, unsigned int* __restrict__ counter, float* __restrict__ loss,
+                                                         float* __restrict__ inv_denom, float* __restrict__ dz, float* __restrict__ dmean,
+                                                         float* __restrict__ dls, float* __restrict__ dlogdet, long n, int nblk, int cg, int B, int C, int Tx,
+                                                         int Ty, int ns, int mel_dim)
+{
+    extern __shared__ float pl_sm[];
+    __shared__ double redd[256];
+    __shared__ int last;
+    if ((int)blockIdx.x >= nblk) {
+        // (the gradient workgroups publish nothing: their outputs are read by later launches only)
+        const int w = blockIdx.x - nblk;
+        if (threadIdx.x == 0) redd[0] = 1.0 / mle_denominator(lengths, B, ns, mel_dim);
+        __syncthreads();
+        const float inv = (float)redd[0];
+        prior_bwd_block(z, mean, ls, idx, dloss[0] * inv, dz, dmean, dls, dlogdet, B, C, Tx, Ty, w % cg, w / cg, pl_sm);
+        return;
+    }
+    // Cross-workgroup hand-over WITHOUT a release fence: on this chip a device-scope release writes back the whole L2 of the XCD (eight L2s, one agent) - with
+    // 8 MB of d z dirty in it, once per workgroup, that cost the step more than the two launches it saves (measured: + 70 us).  Device-scope atomic
+    // read-modify-writes are performed at the memory side: the partial sum goes out as an atomic exchange, the wave waits for its return, then counts itself;
+    // the workgroup that counts last reads the partial sums back with atomic ORs of zero.
+    mle_partial_block<true>(z, mel_mean, mel_ls, partial, n, blockIdx.x, nblk, reinterpret_cast<float*>(redd));
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        last = atomicAdd(counter, 1u) == (unsigned int)nblk - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    mle_final_block<true>(partial, nblk, logdet, lengths, B, ns, mel_dim, loss, inv_denom, redd);
+    if (threadIdx.x == 0) atomicExch(counter, 0u);
+}
 
 // Duration loss (Train.py:203-211: MSELoss(log_Durations, log_Duration_Targets), mean over the padded [B, 1, T_tok]) and its gradient: one workgroup, one launch
 // per direction (torch: sub / pow / mean forward, three more backward, each a launch on the encoder stream's chain).  scale = 1 / elements (or the caller's own
@@ -203,15 +288,19 @@ __device__ __forceinline__ float mse_scale(float scale, const int64_t* lengths, 
     if (lengths) { long mx = 1; for (int i = 0; i < B; ++i) mx = lengths[i] > mx ? lengths[i] : mx; return 1.f / ((float)B * (float)mx); }
     return scale;
 }
+// da_unit != NULL: also the gradient for d loss = 1 (mse_bwd_kernel's value for that seed, same bits) - the caller's backward returns it without a launch
+// when it is seeded with the constant 1 (alignment.DurationMSE)
 __global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ a, const float* __restrict__ t, float* __restrict__ loss, long n, float scale,
-                                                      const int64_t* __restrict__ lengths, int B, const float* __restrict__ extent)
+                                                      const int64_t* __restrict__ lengths, int B, const float* __restrict__ extent, float* __restrict__ da_unit)
 {
     __shared__ double red[256];
     double acc = 0.0;
-    for (long i = threadIdx.x; i < n; i += 256) { const float d = a[i] - t[i]; acc += (double)d * d; }
+    const float sc = mse_scale(scale, lengths, B, extent);
+    const float g = 2.f * sc * 1.f;
+    for (long i = threadIdx.x; i < n; i += 256) { const float d = a[i] - t[i]; acc += (double)d * d; if (da_unit) da_unit[i] = g * d; }
     red[threadIdx.x] = acc; __syncthreads();
     for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
-    if (threadIdx.x == 0) *loss = (float)(red[0] * (double)mse_scale(scale, lengths, B, extent));
+    if (threadIdx.x == 0) *loss = (float)(red[0] * (double)sc);
 }
 __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ t, const float* __restrict__ dloss,
                                                       float* __restrict__ da, long n, float scale, const int64_t* __restrict__ lengths, int B,
@@ -400,21 +489,24 @@ extern "C" int glowtts_mle_loss_bwd(const float* z, const float* mean, const flo
 {
     if (!z || !mean || !log_std || !dloss || !inv_denom || !dz || !dmean || !dlog_std || n < 1 || (dlogdet && B < 1)) return GLOWTTS_E_ARG;
     const long g = (n + 255) / 256;
+    GLOWTTS_NOTE_STATIC("mle_loss_bwd");
     hipLaunchKernelGGL(mle_bwd_kernel, dim3((int)(g > 2048 ? 2048 : g)), dim3(256), 0, static_cast<hipStream_t>(stream), z, mean, log_std, dloss, inv_denom, dz, dmean, dlog_std, (long)n,
                        dlogdet, B);
     RET_LAUNCH();
 }
 
 extern "C" int glowtts_expand_pair_targets(const float* mean, const float* log_std, const int32_t* idx, const int64_t* token_lengths, float* mel_mean,
-                                           float* mel_log_std, float* targets, int B, int C, int Tx, int Ty, void* stream)
+                                           float* mel_log_std, float* targets, float* path, int B, int C, int Tx, int Ty, void* stream)
 {
     if (!mean || !log_std || !idx || !token_lengths || !mel_mean || !mel_log_std || !targets || B < 1 || C < 1 || Tx < 1 || Ty < 4 || (Ty & 3)) return GLOWTTS_E_ARG;
-    const uint64_t total4 = (uint64_t)B * C * Ty / 4;
-    if (((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(mel_mean) | reinterpret_cast<uintptr_t>(mel_log_std)) & 15) != 0 || total4 >= (1ull << 31) ||
-        (size_t)Tx * sizeof(int) > 64 * 1024) return GLOWTTS_E_ARG;
+    const uint64_t total4 = (uint64_t)B * C * Ty / 4, ptotal4 = path ? (uint64_t)B * Tx * Ty / 4 : 0;
+    if (((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(mel_mean) | reinterpret_cast<uintptr_t>(mel_log_std) | reinterpret_cast<uintptr_t>(path)) & 15) != 0 ||
+        total4 >= (1ull << 31) || ptotal4 >= (1ull << 31) || (size_t)Tx * sizeof(int) > 64 * 1024) return GLOWTTS_E_ARG;
     const int nexp = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(expand_pair_kernel, dim3(nexp + B), dim3(256), Tx * sizeof(int), static_cast<hipStream_t>(stream), mean, log_std, idx, token_lengths,
-                       mel_mean, mel_log_std, targets, C, Tx, Ty, (unsigned int)total4, nexp);
+    const int npath = (int)((ptotal4 + 255) / 256 < 8192 ? (ptotal4 + 255) / 256 : 8192);
+    GLOWTTS_NOTE_STATIC("expand_pair");
+    hipLaunchKernelGGL(expand_pair_kernel, dim3(nexp + npath + B), dim3(256), Tx * sizeof(int), static_cast<hipStream_t>(stream), mean, log_std, idx, token_lengths,
+                       mel_mean, mel_log_std, targets, C, Tx, Ty, (unsigned int)total4, nexp, path, (unsigned int)ptotal4, npath);
     RET_LAUNCH();
 }
 extern "C" int glowtts_prior_loss_bwd(const float* z, const float* mean, const float* log_std, const int32_t* idx, const float* dloss, const float* inv_denom,
@@ -423,15 +515,34 @@ extern "C" int glowtts_prior_loss_bwd(const float* z, const float* mean, const f
     if (!z || !mean || !log_std || !idx || !dloss || !inv_denom || !dz || !dmean || !dlog_std || B < 1 || C < 1 || Tx < 1 || Ty < 1) return GLOWTTS_E_ARG;
     const size_t lds = (size_t)16 * Tx * sizeof(float);
     if (lds > 64 * 1024) return GLOWTTS_E_ARG;
+    GLOWTTS_NOTE_STATIC("prior_loss_bwd");
     hipLaunchKernelGGL(prior_loss_bwd_kernel, dim3((C + 3) / 4, B), dim3(256), lds, static_cast<hipStream_t>(stream), z, mean, log_std, idx, dloss, inv_denom,
                        dz, dmean, dlog_std, dlogdet, B, C, Tx, Ty);
     RET_LAUNCH();
 }
+extern "C" int glowtts_prior_loss(const float* z, const float* mel_mean, const float* mel_log_std, const float* mean, const float* log_std, const int32_t* idx,
+                                  const float* log_dets, const int64_t* lengths, const float* dloss, float* scratch /* 1024 floats */, uint32_t* counter /* zeroed once */,
+                                  float* loss, float* inv_denom, float* dz, float* dmean, float* dlog_std, float* dlogdet, int B, int C, int Tx, int Ty,
+                                  int n_squeeze, int mel_dim, void* stream)
+{
+    if (!z || !mel_mean || !mel_log_std || !mean || !log_std || !idx || !log_dets || !lengths || !dloss || !scratch || !counter || !loss || !inv_denom || !dz ||
+        !dmean || !dlog_std || B < 1 || C < 1 || Tx < 1 || Ty < 1 || n_squeeze < 1 || mel_dim < 1) return GLOWTTS_E_ARG;
+    const size_t lds = (size_t)16 * Tx * sizeof(float);
+    if (lds > 64 * 1024) return GLOWTTS_E_ARG;
+    const int64_t n = (int64_t)B * C * Ty;
+    const int nblk = (int)((n + 4095) / 4096 > 1024 ? 1024 : (n + 4095) / 4096);      // (glowtts_mle_loss_fwd's)
+    const int cg = (C + 3) / 4;
+    GLOWTTS_NOTE_STATIC("prior_loss");
+    hipLaunchKernelGGL(prior_loss_kernel, dim3(nblk + cg * B), dim3(256), lds, static_cast<hipStream_t>(stream), z, mel_mean, mel_log_std, mean, log_std, idx, log_dets,
+                       lengths, dloss, scratch, counter, loss, inv_denom, dz, dmean, dlog_std, dlogdet, (long)n, nblk, cg, B, C, Tx, Ty, n_squeeze, mel_dim);
+    RET_LAUNCH();
+}
 extern "C" int glowtts_mse_loss_fwd(const float* a, const float* target, float* loss, int64_t n, float scale, const int64_t* lengths, int B, const float* extent,
-                                    void* stream)
+                                    float* da_unit, void* stream)
 {
     if (!a || !target || !loss || n < 1 || ((lengths || extent) && B < 1)) return GLOWTTS_E_ARG;
-    hipLaunchKernelGGL(mse_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a, target, loss, (long)n, scale, lengths, B, extent);
+    GLOWTTS_NOTE_STATIC("mse_loss_fwd");
+    hipLaunchKernelGGL(mse_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a, target, loss, (long)n, scale, lengths, B, extent, da_unit);
     RET_LAUNCH();
 }
 extern "C" int glowtts_mse_loss_bwd(const float* a, const float* target, const float* dloss, float* da, int64_t n, float scale, const int64_t* lengths, int B,
@@ -439,6 +550,7 @@ extern "C" int glowtts_mse_loss_bwd(const float* a, const float* target, const f
 {
     if (!a || !target || !dloss || !da || n < 1 || ((lengths || extent) && B < 1)) return GLOWTTS_E_ARG;
     const long g = (n + 255) / 256;
+    GLOWTTS_NOTE_STATIC("mse_loss_bwd");
     hipLaunchKernelGGL(mse_bwd_kernel, dim3((int)(g > 256 ? 256 : g)), dim3(256), 0, static_cast<hipStream_t>(stream), a, target, dloss, da, (long)n, scale, lengths, B,
                        extent);
     RET_LAUNCH();

@@ -3,9 +3,9 @@ channels-last "rows" layout ([B, T + 4, C] with two zero pad rows around every u
 
 Every stage runs in the HIP library: embedding (glowtts_embedding_*), convolutions incl. the fused Q|K|V projection
 (glowtts_conv_cl / glowtts_wgrad_cl), LayerNorm with its fused residual / ReLU / dropout / mask (glowtts_layernorm_*), the
-relative-position attention core (glowtts_rpr_attention_*).  Remaining PyTorch device ops here are glue only: the
-concatenation of the Q/K/V weights, the speaker-vector broadcast of the duration predictor, and its final 1-channel projection
-(a per-frame dot product).  Nothing runs on the CPU.
+relative-position attention core (glowtts_rpr_attention_*), the split of the projection into mean / log_std and the duration predictor's
+1-channel projection (glowtts_prior_split_*, glowtts_dur_proj_*).  Remaining PyTorch device ops here are glue only: the
+concatenation of the Q/K/V weights and the speaker-vector broadcast of the duration predictor.  Nothing runs on the CPU.
 
 Layout invariant: every stored activation is zero on padded frames and pad rows.  The reference multiplies by the mask only in
 front of convolutions (Modules.py:484,565,568,616,643) and at block ends; masking earlier only changes rows the reference
@@ -25,6 +25,88 @@ def _with_bf16(y, yb):
     """Attaches the bf16 copy of fp32 rows (see conv_fn.bf16_of)."""
     y._bf16 = yb
     return y
+
+
+_decl = False
+
+
+def _dur_lib():
+    global _decl
+    import ctypes
+    from . import _lib
+    L = _lib.lib()
+    if not _decl:
+        L.glowtts_dur_proj_supported.argtypes = [ctypes.c_int]
+        L.glowtts_dur_proj_fwd.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        L.glowtts_dur_proj_bwd.argtypes = [ctypes.c_void_p] * 9 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        L.glowtts_prior_split_fwd.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        L.glowtts_prior_split_bwd.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        _decl = True
+    return L
+
+
+class DurProj(torch.autograd.Function):
+    """Duration_Predictor's Projection (Modules.py:596-618: Conv1d(C -> 1, k = 1) on the masked features, times the mask) on rows, one launch per direction
+    (csrc/dur_ops.hip; was mul / sum / add / mul forward and a dozen elementwise / reduce / fill launches at the head of the encoder's backward chain).
+    apply(d [B (T + 2 ROW_PAD), C] fp32 rows, weight [1, C, 1], bias [1], mask [B, 1, T], owner) -> [B, 1, T]."""
+
+    @staticmethod
+    def forward(ctx, d, w, bias, mask, owner=None):
+        from . import _lib
+        B, T = int(mask.shape[0]), int(mask.shape[2])
+        C = int(d.shape[1])
+        d, w, bias, mask = d.contiguous(), w.contiguous(), bias.contiguous(), mask.contiguous()
+        out = torch.empty(B, 1, T, device=d.device)
+        _lib.check(_dur_lib().glowtts_dur_proj_fwd(_lib.ptr(d), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(mask), _lib.ptr(out), B, T, ROW_PAD, C, _lib.stream()),
+                   "glowtts_dur_proj_fwd")
+        ctx.save_for_backward(d, w, mask)
+        ctx.owner = owner
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        d, w, mask = ctx.saved_tensors
+        B, T = int(mask.shape[0]), int(mask.shape[2])
+        C = int(d.shape[1])
+        dev = d.device
+        g = g.contiguous()
+        dd, dw, db = torch.empty_like(d), torch.empty_like(w), torch.empty(1, device=dev)
+        counter = _lib.counter(dev, "dur_proj", ctx.owner)
+        if counter is None:                                   # (first use inside a capture: a counter of this launch's own, zeroed by a fill)
+            counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        scratch = torch.empty(B * (C + 1), device=dev)
+        _lib.check(_dur_lib().glowtts_dur_proj_bwd(_lib.ptr(g), _lib.ptr(mask), _lib.ptr(d), _lib.ptr(w), _lib.ptr(dd), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(scratch),
+                                                   _lib.ptr(counter), B, T, ROW_PAD, C, _lib.stream()), "glowtts_dur_proj_bwd")
+        return dd, dw, db, None, None
+
+
+class PriorSplit(torch.autograd.Function):
+    """The encoder's projected rows [B (T + 2 ROW_PAD), 2 M] -> mean, log_std [B, M, T] (Modules.py:283-286 `torch.split` of the projection; rows -> channel-first),
+    one launch per direction (was two strided copies forward; two zero fills, two slice copies, an add and the transposes backward)."""
+
+    @staticmethod
+    def forward(ctx, rows, B, T):
+        from . import _lib
+        rows = rows.contiguous()
+        M = int(rows.shape[1]) // 2
+        mean, ls = torch.empty(B, M, T, device=rows.device), torch.empty(B, M, T, device=rows.device)
+        _lib.check(_dur_lib().glowtts_prior_split_fwd(_lib.ptr(rows), _lib.ptr(mean), _lib.ptr(ls), B, T, ROW_PAD, M, _lib.stream()), "glowtts_prior_split_fwd")
+        ctx.dims = (B, T, M)
+        return mean, ls
+
+    @staticmethod
+    def backward(ctx, dm, dl):
+        from . import _lib
+        B, T, M = ctx.dims
+        ref = dm if dm is not None else dl
+        if ref is None:
+            return None, None, None
+        dm = None if dm is None else dm.contiguous()
+        dl = None if dl is None else dl.contiguous()
+        drows = torch.empty(B * (T + 2 * ROW_PAD), 2 * M, device=ref.device)
+        _lib.check(_dur_lib().glowtts_prior_split_bwd(_lib.ptr(dm), _lib.ptr(dl), _lib.ptr(drows), B, T, ROW_PAD, M, _lib.stream()), "glowtts_prior_split_bwd")
+        return drows, None, None
 
 
 def from_rows(rows_btc):
@@ -231,13 +313,16 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
         h = conv(x, q + ".Conv_0", relu=True, mask_out=True, drop=dr, out_bf16=True)                         # :565-567 (only Conv_1 reads it)
         h = conv(h, q + ".Conv_1", mask_out=True, drop=dr)                                                   # :568-569 (x*mask at :571)
         x = ln(h, x, q + ".LayerNorm_1")                                                                     # :571
-    proj = conv(x, prefix + ".layer_Dict.Project", mask_out=True).view(B, Tp, -1)
+    proj = conv(x, prefix + ".layer_Dict.Project", mask_out=True)
     stamp("enc_fwd_project")
     M = hp.Sound.Mel_Dim
-    proj = from_rows(proj)
-    mean, log_std = proj[:, :M].contiguous(), proj[:, M:].contiguous()      # (here, on the encoder stream: the consumers need dense rows)
+    if proj.is_cuda and proj.dtype == torch.float32 and proj.shape[1] == 2 * M and 32 * (2 * M + 1) * 4 <= 64 * 1024:
+        mean, log_std = PriorSplit.apply(proj, B, Tp - 2 * ROW_PAD)         # (here, on the encoder stream: the consumers need dense channel-first tensors)
+    else:
+        proj = from_rows(proj.view(B, Tp, -1))
+        mean, log_std = proj[:, :M].contiguous(), proj[:, M:].contiguous()
     if on_prior_ready is not None:
-        on_prior_ready()         # the log-prior / MAS side of the step can start: what follows (duration predictor) is only needed by the losses
+        on_prior_ready(mean, log_std)         # the log-prior / MAS side of the step can start: what follows (duration predictor) is only needed by the losses
     # Duration predictor on detached features (:277-282, 602-618)
     d, db = x.detach(), bf16_of(x)
     cond = None
@@ -255,5 +340,8 @@ def encoder_forward(P, hp, tokens, mask, speakers=None, prosodies=None, training
     # Projection to one channel: N = 1 is not a GEMM; a masked dot product per frame (multiply + row reduction: rocBLAS' gemv took
     # 82 us for these 3.5k x 256 rows, 5x the two elementwise kernels)
     wq = prefix + ".layer_Dict.Duration_Predictor.layer_Dict.Projection"
-    log_dur = ((d * Pc[wq + ".weight"][0, :, 0]).sum(-1) + Pc[wq + ".bias"]).view(B, Tp)[:, ROW_PAD:-ROW_PAD].unsqueeze(1) * mask
+    if d.is_cuda and d.dtype == torch.float32 and Pc[wq + ".weight"].dtype == torch.float32 and _dur_lib().glowtts_dur_proj_supported(int(d.shape[1])):
+        log_dur = DurProj.apply(d, Pc[wq + ".weight"], Pc[wq + ".bias"], mask, cache)
+    else:
+        log_dur = ((d * Pc[wq + ".weight"][0, :, 0]).sum(-1) + Pc[wq + ".bias"]).view(B, Tp)[:, ROW_PAD:-ROW_PAD].unsqueeze(1) * mask
     return mean, log_std, log_dur

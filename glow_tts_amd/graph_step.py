@@ -52,10 +52,10 @@ class GraphedTrainStep:
         return gd.is_dist()
 
     def _fwd_bwd(self, inputs):
-        loss = self.loss_fn(self.model, *inputs)
+        loss = self.loss_fn(self.model, *inputs)          # a scalar tensor or `alignment.LossTerms`
         self.model.zero_grad(set_to_none=True)
         loss.backward()
-        return loss
+        return loss.detach()
 
     def _update(self):
         coef = None

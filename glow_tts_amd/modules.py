@@ -341,7 +341,13 @@ class GlowTTS(torch.nn.Module):
             decoder.early_prepare(self.dec_cfg, W, mels.shape, fused_bwd_ok=(pitches is None or "Pitch_v" not in stacks.S))
         early_prep = decoder.EARLY["prep"]
 
-        def prior_done():
+        prepared = {}
+
+        def prior_done(mean_, log_std_):
+            # the log-prior GEMM's operands that need the encoder's outputs only: here, on the encoder's stream (one launch off the chain between the flow
+            # decoder's forward and its backward)
+            ns_sq = int(hp.Decoder.Num_Squeeze)
+            prepared["p"] = alignment.log_prior_prepare(mean_.detach(), log_std_.detach(), token_lengths, mel_lengths, (mels.shape[2] // ns_sq) * ns_sq, ns_sq)
             prior_ready.record(side)
             # the decoder's backward-only weight images: on the encoder's stream right behind its projection (they need nothing but the weights) - under the
             # decoder's z / log-determinant passes and in front of the duration predictor, whose result only the losses read.  (Behind the duration
@@ -384,17 +390,20 @@ class GlowTTS(torch.nn.Module):
                 t_.record_stream(main)
         ns = int(hp.Decoder.Num_Squeeze)
         value_t, tx32, ty32 = alignment.log_prior_t(mean.detach(), log_std.detach(), z.detach(), token_lengths, mel_lengths, ns,
-                                                    return_lengths=True, z_rows=z_rows)        # Modules.py:107-114 (lengths of the squeezed z)
+                                                    return_lengths=True, z_rows=z_rows, prepared=prepared.get("p"))        # Modules.py:107-114 (lengths of the squeezed z)
+        if side is not main and prepared.get("p") is not None:
+            for t_ in prepared["p"].values():
+                if torch.is_tensor(t_):
+                    t_.record_stream(main)
         idx = alignment.maximum_path_t(value_t, tx32, ty32)                                          # :115-116
         if idx.shape[1] != z.shape[2]:
             idx = idx[:, :z.shape[2]].contiguous()
-        # The dense 0/1 attentions are only RETURNED (the losses use the per-frame token index).  (Until round 6 they were written on the encoder's stream, behind a
-        # second fork of it: the 4-us launch on this stream costs the replayed graph less than that edge did - 4.78 against 4.81 ms/step.)
-        from .monotonic_align import path_from_idx
-        attn = path_from_idx(idx, tokens.shape[1], torch.float32)
+        # The dense 0/1 attentions are only RETURNED (the losses use the per-frame token index): written by the expansion's launch below.  (Until round 6 they were
+        # written on the encoder's stream, behind a second fork of it - that edge cost the replayed graph more than a launch on this stream.)
         bwd_side = side if (side is not main and torch.is_grad_enabled()) else None
-        # Modules.py:120-122 in one launch (gathers by the MAS index + run lengths); MLE_Loss on these two tensors differentiates through the gather itself
-        mel_mean, mel_log_std, log_dur_targets = alignment.ExpandPair.apply(mean, log_std, idx, token_lengths, bwd_side)
+        # Modules.py:116, 120-122 in one launch (the 0/1 matrix, the gathers by the MAS index, the run lengths); MLE_Loss on these two tensors differentiates through
+        # the gather itself
+        mel_mean, mel_log_std, log_dur_targets, attn = alignment.ExpandPair.apply(mean, log_std, idx, token_lengths, bwd_side, True)
         if cond is None:
             # (conditioned modes keep the expansion's own backward: there the decoder's weight-gradient tail runs on a third stream (decoder.TUNE["tail_aside"]), and
             #  with the encoder's backward hanging off MLE_Loss's node instead of off an explicit fork the replayed graph serialises it behind the conditioning
@@ -539,7 +548,8 @@ class MLE_Loss(torch.nn.modules.loss._Loss):
     def __init__(self, hp=None):
         super().__init__()
         self.hp = hp if hp is not None else get_hp()
+        self._state = {}          # (this module's completion counter of the one-launch loss, alignment.PriorLoss)
 
     def forward(self, z, mean, std, log_dets, lengths):
         hp = self.hp
-        return alignment.mle_loss(z, mean, std, log_dets, lengths, int(hp.Decoder.Num_Squeeze), int(hp.Sound.Mel_Dim))
+        return alignment.mle_loss(z, mean, std, log_dets, lengths, int(hp.Decoder.Num_Squeeze), int(hp.Sound.Mel_Dim), owner=self._state)

@@ -140,11 +140,13 @@ class Trainer:
             model.actnorm_allreduce = actnorm_stats_allreduce
             self.reducer = FlatGradReducer(list(model.parameters()))
         self._comp = torch.zeros(4, device=self.device)      # MLE, Length, Total, Speaker of the last step (written inside the graph)
+        self._inv_world = None
         self._graphed = None
 
     def _losses(self, model, tokens, token_lengths, mels, mel_lengths, speakers, mels_for_ge2e, pitches, frame_weight=None, token_extent=None):
-        """Train.py:193-216 -> (loss to differentiate, [MLE, Length, Total, Speaker]).  frame_weight (data parallel): this rank's share of the
-        global batch's mel frames, a 0-d device tensor computed outside the captured step (`distributed.global_frame_weight`)."""
+        """Train.py:193-216 -> the loss to differentiate, as its terms (`alignment.LossTerms`; `.backward()` also writes [MLE, Length, Total, Speaker] into
+        `self._comp`).  frame_weight (data parallel): this rank's share of the global batch's mel frames, a 0-d device tensor computed outside the captured
+        step (`distributed.global_frame_weight`)."""
         z, mel_Mean, mel_Log_Std, log_Dets, log_Durations, log_Duration_Targets, _, classified = model(
             tokens, token_lengths, mels, mel_lengths, speakers, mels_for_ge2e, pitches)
         # (GR: the duration loss and the speaker classifier's on the encoder's stream, beside the MLE reduction: neither they nor their backward
@@ -155,27 +157,41 @@ class Trainer:
             fw, te = global_step_scalars(mel_lengths.sum(), token_lengths.max())
             frame_weight = fw if frame_weight is None else frame_weight
             token_extent = te if token_extent is None else token_extent
-        if classified is None:
-            # round 6: the duration loss is one HIP launch per direction now - it stays on this stream (a fork and a join of the encoder's stream around it cost the
-            # replayed graph more than the two launches take: 4.78 against 4.81-4.84 ms/step)
-            length = duration_loss(log_Durations, log_Duration_Targets, token_lengths, token_extent)
-            ce, rest = None, length
-            mle = self.criterion_Dict["MLE"](z=z, mean=mel_Mean, std=mel_Log_Std, log_dets=log_Dets, lengths=mel_lengths)
-        else:
-            with Beside(model) as beside:                     # GR: the speaker classifier's cross entropy is a dozen torch launches
-                beside.uses(log_Durations, log_Duration_Targets, token_lengths, token_extent, classified, speakers)
-                length = duration_loss(log_Durations, log_Duration_Targets, token_lengths, token_extent)
-                ce = self.criterion_Dict["CE"](classified, speakers)
-                rest = length + ce
-            mle = self.criterion_Dict["MLE"](z=z, mean=mel_Mean, std=mel_Log_Std, log_dets=log_Dets, lengths=mel_lengths)
-            beside.join(length, ce, rest)
-        total = mle + length
+        from . import alignment
+        # what the terms will be seeded with by `LossTerms.backward` (data parallel: this rank's frame share / 1 / world, device scalars): loss nodes that know
+        # their seed write their gradients in the forward launch
+        inv_world = None
         if self.dp:
-            loss = mle * frame_weight + rest / self.world
-        else:
-            loss = mle + rest
-        comp = torch.stack([mle.detach(), length.detach(), total.detach(), ce.detach() if ce is not None else torch.zeros((), device=mle.device)])
-        return loss, comp
+            if self._inv_world is None:
+                self._inv_world = torch.full((), 1.0 / self.world, device=self.device)
+            inv_world = self._inv_world
+        alignment.SEEDS["mle"], alignment.SEEDS["rest"] = (frame_weight if self.dp else None), inv_world
+        try:
+            if classified is None:
+                # round 6: the duration loss is one HIP launch per direction now - it stays on this stream (a fork and a join of the encoder's stream around it cost the
+                # replayed graph more than the two launches take: 4.78 against 4.81-4.84 ms/step)
+                length = duration_loss(log_Durations, log_Duration_Targets, token_lengths, token_extent)
+                ce = None
+                mle = self.criterion_Dict["MLE"](z=z, mean=mel_Mean, std=mel_Log_Std, log_dets=log_Dets, lengths=mel_lengths)
+            else:
+                with Beside(model) as beside:                     # GR: the speaker classifier's cross entropy is a dozen torch launches
+                    beside.uses(log_Durations, log_Duration_Targets, token_lengths, token_extent, classified, speakers)
+                    length = duration_loss(log_Durations, log_Duration_Targets, token_lengths, token_extent)
+                    ce = self.criterion_Dict["CE"](classified, speakers)
+                mle = self.criterion_Dict["MLE"](z=z, mean=mel_Mean, std=mel_Log_Std, log_dets=log_Dets, lengths=mel_lengths)
+                beside.join(length, ce)
+        finally:
+            alignment.SEEDS["mle"] = alignment.SEEDS["rest"] = None
+
+        def log_components():
+            # [MLE, Length, Total, Speaker] of this step (Train.py:218-222), queued BEHIND the backward: three small launches that used to sit between the loss and
+            # the flow decoder's backward
+            total = mle.detach() + length.detach()
+            self._comp.copy_(torch.stack([mle.detach(), length.detach(), total, ce.detach() if ce is not None else torch.zeros((), device=mle.device)]))
+        # Train.py:213-216: loss = MLE + Length (+ Speaker); data parallel: this rank's MLE (a mean over ITS frames) weighs its share of the global frames, the
+        # other terms 1 / world, gradients are SUMMED
+        seeds = [frame_weight, inv_world, inv_world] if self.dp else None
+        return alignment.LossTerms([mle, length, ce], seeds, after=log_components)
 
     def _batch_to_device(self, batch):
         # (worker-collated batches arrive in the loader's pinned memory; in-process ones in the collater's own pinned ring, whose slot the copy guards)
@@ -198,9 +214,7 @@ class Trainer:
         inputs = self._batch_to_device(batch)
 
         def loss_fn(m, *inp):
-            loss, comp = self._losses(m, *inp)
-            self._comp.copy_(comp)
-            return loss
+            return self._losses(m, *inp)
         if self.dp:                                            # one tiny all-gather per step, outside the captured graphs
             from .distributed import global_step_scalars
             inputs = tuple(inputs) + global_step_scalars(inputs[3].sum(), inputs[1].max())

@@ -20,7 +20,7 @@ extern "C" {
 #define GLOWTTS_OK            0
 #define GLOWTTS_E_ARG        -1   /* bad argument / unsupported size */
 #define GLOWTTS_E_LAUNCH     -2   /* hip launch error */
-#define GLOWTTS_ABI_VERSION    6
+#define GLOWTTS_ABI_VERSION    7
 
 /* Library / device identification.  Returns the ABI version (currently 6: glowtts_cond_linear_supported, the direct 3x3 stride-2 conv trio glowtts_conv3x3s2_*; 5: additions only - glowtts_cond_linear_fwd / _bwd, glowtts_prep_launch_dev,
  * glowtts_rpr_attention_bwd_partial_rows (and NULL drelk / drelv), glowtts_sum_slices / _seg, GLOWTTS_F_GATE_IN0, GLOWTTS_F_COND_FX, glowtts_flow_acts.skip may be NULL on
@@ -689,9 +689,10 @@ int glowtts_mle_loss_fwd(const float *z, const float *mean, const float *log_std
 int glowtts_mle_loss_bwd(const float *z, const float *mean, const float *log_std, const float *dloss, const float *inv_denom,
                          float *dz, float *dmean, float *dlog_std, int64_t n, float *dlogdet, int B, void *stream);
 /* ABI 6.  Both expansions and the duration targets of Modules.py:120-122 in one launch (Ty % 4 == 0, 16-byte aligned idx / outputs): mel_mean, mel_log_std
- * [B][C][Ty] as glowtts_expand_fwd, targets [B][Tx] as glowtts_duration_targets. */
+ * [B][C][Ty] as glowtts_expand_fwd, targets [B][Tx] as glowtts_duration_targets.  ABI 7: path (optional, fp32 [B][Tx][Ty], 16-byte aligned): the dense 0/1
+ * attentions of Modules.py:116 as glowtts_mas_path_from_idx writes them, in the same launch. */
 int glowtts_expand_pair_targets(const float *mean, const float *log_std, const int32_t *idx, const int64_t *token_lengths, float *mel_mean,
-                                float *mel_log_std, float *targets, int B, int C, int Tx, int Ty, void *stream);
+                                float *mel_log_std, float *targets, float *path, int B, int C, int Tx, int Ty, void *stream);
 /* ABI 6.  glowtts_mle_loss_bwd THROUGH the expansion, in one launch: z [B][C][Ty], the TOKEN-space mean / log_std [B][C][Tx] the expansion gathered from and idx
  * [B][Ty] -> dz [B][C][Ty] and the token-space gradients dmean / dlog_std [B][C][Tx] (each token's frames are one contiguous run: segment sums, no atomics;
  * the same bits as glowtts_mle_loss_bwd followed by two glowtts_expand_bwd); dlogdet optional as above.  Tx <= 1024. */
@@ -701,9 +702,27 @@ int glowtts_prior_loss_bwd(const float *z, const float *mean, const float *log_s
  * MSELoss on the log durations, scale = 1 / n), or - lengths [B] i64 given - 1 / (B max(lengths)): the mean over the batch's own longest text when the token axis is
  * padded to a shape bucket, or - extent (device scalar) given - 1 / (B extent[0]): data parallel, the global batch's longest text. */
 int glowtts_mse_loss_fwd(const float *a, const float *target, float *loss, int64_t n, float scale, const int64_t *lengths, int B, const float *extent,
-                         void *stream);
+                         float *da_unit, void *stream);
 int glowtts_mse_loss_bwd(const float *a, const float *target, const float *dloss, float *da, int64_t n, float scale, const int64_t *lengths, int B,
                          const float *extent, void *stream);
+/* ABI 7.  glowtts_mse_loss_fwd's da_unit (optional, [n]): the gradient for d loss = 1, written by the forward launch (glowtts_mse_loss_bwd's value for that seed). */
+/* ABI 7.  MLE_Loss (Modules.py:1020-1029) on the expanded prior - value AND gradients for the seed dloss[0] - in ONE launch: glowtts_mle_loss_fwd on
+ * (z, mel_mean, mel_log_std) [B][C][Ty] and glowtts_prior_loss_bwd on the token-space (mean, log_std) [B][C][Tx] + idx [B][Ty], the same bits as those calls.
+ * scratch: 1024 floats; counter: one uint32 zeroed once by the caller (the kernel leaves it zero).  dlogdet optional.  Tx <= 1024. */
+int glowtts_prior_loss(const float *z, const float *mel_mean, const float *mel_log_std, const float *mean, const float *log_std, const int32_t *idx,
+                       const float *log_dets, const int64_t *lengths, const float *dloss, float *scratch, uint32_t *counter, float *loss, float *inv_denom,
+                       float *dz, float *dmean, float *dlog_std, float *dlogdet, int B, int C, int Tx, int Ty, int n_squeeze, int mel_dim, void *stream);
+/* ABI 7.  Duration_Predictor's Projection (Modules.py:596-618: Conv1d(C -> 1, k = 1) on masked features, times the mask) on rows: d [B][T + 2 pad][C] fp32
+ * (16-byte aligned, C % 4 == 0, C <= 1024), w [C], bias [1], mask [B][T] -> out [B][T].  Backward: g [B][T] -> dd rows (pad rows zero), dw [C], dbias [1];
+ * scratch B * (C + 1) floats, counter one uint32 zeroed once (left zero).  Fixed summation order. */
+int glowtts_dur_proj_supported(int C);
+int glowtts_dur_proj_fwd(const float *d, const float *w, const float *bias, const float *mask, float *out, int B, int T, int pad, int C, void *stream);
+int glowtts_dur_proj_bwd(const float *g, const float *mask, const float *d, const float *w, float *dd, float *dw, float *dbias, float *scratch,
+                         uint32_t *counter, int B, int T, int pad, int C, void *stream);
+/* ABI 7.  The encoder's projected rows [B][T + 2 pad][2 M] -> mean, log_std [B][M][T] (Modules.py:283-286) and back (dmean / dlog_std may be NULL = zero;
+ * pad rows of drows are zeroed). */
+int glowtts_prior_split_fwd(const float *rows, float *mean, float *log_std, int B, int T, int pad, int M, void *stream);
+int glowtts_prior_split_bwd(const float *dmean, const float *dlog_std, float *drows, int B, int T, int pad, int M, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Old-style weight normalisation of the WaveNet convolutions (Modules.py:766,818,825,838,845: torch.nn.utils.weight_norm,

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 5
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/glowtts_hip.h but not exported"
-    assert L.glowtts_abi_version() == 6
+    assert L.glowtts_abi_version() == 7
 
 
 def test_product_path_has_no_oracle_import():

@@ -100,7 +100,9 @@ def test_expand_pair_and_prior_loss_equal_the_separate_launches():
     for fused in (False, True):
         m, l, zz, dd = (dev(t).requires_grad_(True) for t in (mean, ls, z, ld))
         if fused:
-            mm, ms, tg = A.ExpandPair.apply(m, l, dev(idx), dev(tl), None)
+            mm, ms, tg, path = A.ExpandPair.apply(m, l, dev(idx), dev(tl), None, True)
+            from glow_tts_amd.monotonic_align import path_from_idx
+            assert torch.equal(path, path_from_idx(dev(idx), mean.shape[2], torch.float32)) and not path.requires_grad       # Modules.py:116 in the same launch
             A.tag_prior(mm, ms, m, l, dev(idx))
             loss = A.mle_loss(zz, mm, ms, dd, dev(ml), 2, 80)
             assert type(loss.grad_fn).__name__.startswith("PriorLoss")
@@ -115,10 +117,121 @@ def test_expand_pair_and_prior_loss_equal_the_separate_launches():
         assert torch.equal(a, b)
     # the tagged outputs used anywhere else still get the general backward
     m, l = dev(mean).requires_grad_(True), dev(ls).requires_grad_(True)
-    mm, ms, _ = A.ExpandPair.apply(m, l, dev(idx), dev(tl), None)
+    mm, ms, _, none = A.ExpandPair.apply(m, l, dev(idx), dev(tl), None)
+    assert none is None
     (mm.sum() + 2 * ms.sum()).backward()
     cnt = (idx[:, None, :] == torch.arange(mean.shape[2])[None, :, None]).sum(-1).float()
     assert torch.allclose(m.grad.cpu(), cnt[:, None, :].expand_as(mean)) and torch.allclose(l.grad.cpu(), 2 * cnt[:, None, :].expand_as(mean))
+
+
+def test_seeded_losses_write_their_gradients_in_the_forward_launch():
+    """`LossTerms.backward` seeds the loss terms with `_lib.one` (no sum node, no ones_like fill); `PriorLoss` and `DurationMSE`, told that seed, write their
+    gradients in the forward launch (glowtts_prior_loss: reduction + gradients + last-workgroup finalisation in one launch) and launch NOTHING in the backward -
+    same bits as `(mle + length).backward()` on the unseeded nodes; any other seed takes the backward launches; a second module's counter is its own."""
+    from glow_tts_amd import _lib, alignment as A
+    from helpers import launch_counts, launch_reset
+    tl, ml, idx, mean, ls, z, ld = _prior_case()
+    dev = lambda t: t.cuda()
+    g = torch.Generator().manual_seed(9)
+    a0, t0 = torch.randn(mean.shape[0], 1, mean.shape[2], generator=g), torch.randn(mean.shape[0], 1, mean.shape[2], generator=g)
+
+    def run(mode):
+        m, l, zz, dd, a = (dev(t).requires_grad_(True) for t in (mean, ls, z, ld, a0))
+        A.FUSED["seeded"] = mode != "plain"
+        try:
+            mm, ms, tg, _ = A.ExpandPair.apply(m, l, dev(idx), dev(tl), None)
+            A.tag_prior(mm, ms, m, l, dev(idx))
+            owner = {}
+            mle = A.mle_loss(zz, mm, ms, dd, dev(ml), 2, 80, owner=owner)
+            length = A.duration_mse(a, dev(t0))
+        finally:
+            A.FUSED["seeded"] = True
+        launch_reset()
+        if mode == "plain":
+            (mle + length).backward()
+        elif mode == "seeded":
+            A.LossTerms([mle, length]).backward()
+        else:                                                  # seeded nodes, foreign seed: the general backward launches
+            (mle + length).backward()
+        counts = launch_counts()
+        if mode == "foreign":
+            assert counts.get("prior_loss_bwd") == 1 and counts.get("mse_loss_bwd") == 1, counts
+        if mode == "seeded":
+            assert not any(n and k.startswith(("prior", "mse", "mle")) for k, n in counts.items()), counts
+            assert int(owner[next(iter(owner))].item()) == 0          # the completion counter is left zero
+        return [t.detach().cpu() for t in (mle, length, m.grad, l.grad, zz.grad, dd.grad, a.grad)]
+    plain, seeded, foreign = run("plain"), run("seeded"), run("foreign")
+    for x, y, w in zip(plain, seeded, foreign):
+        assert torch.equal(x, y) and torch.equal(x, w)
+    # weighted terms (data parallel): seeds are device scalars the forward launches read
+    wm, wr = torch.tensor(0.37).cuda(), torch.tensor(0.5).cuda()
+    m, l, zz, dd, a = (dev(t).requires_grad_(True) for t in (mean, ls, z, ld, a0))
+    A.SEEDS["mle"], A.SEEDS["rest"] = wm, wr
+    try:
+        mm, ms, tg, _ = A.ExpandPair.apply(m, l, dev(idx), dev(tl), None)
+        A.tag_prior(mm, ms, m, l, dev(idx))
+        mle, length = A.mle_loss(zz, mm, ms, dd, dev(ml), 2, 80), A.duration_mse(a, dev(t0))
+    finally:
+        A.SEEDS["mle"] = A.SEEDS["rest"] = None
+    terms = A.LossTerms([mle, length], [wm, wr])
+    terms.backward()
+    got = [t.grad.detach().cpu() for t in (m, l, zz, dd, a)]
+    m2, l2, zz2, dd2, a2 = (dev(t).requires_grad_(True) for t in (mean, ls, z, ld, a0))
+    mm2, ms2 = A.ExpandPrior.apply(m2, dev(idx)), A.ExpandPrior.apply(l2, dev(idx))
+    tot = A.mle_loss(zz2, mm2, ms2, dd2, dev(ml), 2, 80) * wm + A.duration_mse(a2, dev(t0)) * wr
+    tot.backward()
+    for x, y in zip(got, [t.grad.detach().cpu() for t in (m2, l2, zz2, dd2, a2)]):
+        assert torch.allclose(x, y, rtol=1e-6, atol=1e-12)
+    assert abs(terms.item() - tot.item()) <= 1e-6 * abs(tot.item())
+
+
+@pytest.mark.parametrize("B,T,C", [(32, 120, 256), (3, 7, 448), (1, 1, 4), (5, 33, 1024)])
+def test_duration_projection_and_prior_split_match_torch(B, T, C):
+    """csrc/dur_ops.hip: Duration_Predictor's Projection (Modules.py:596-618) and the split of the encoder's projected rows into mean / log_std
+    (Modules.py:283-286), one launch per direction each, against the torch expressions they replace (fp64)."""
+    from glow_tts_amd.encoder import ROW_PAD, DurProj, PriorSplit, from_rows
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    Tp = T + 2 * ROW_PAD
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0] = T
+    mask = (torch.arange(T)[None] < lens[:, None]).float().unsqueeze(1)
+    d = torch.randn(B, Tp, C, generator=g)
+    d[:, :ROW_PAD] = 0
+    d[:, -ROW_PAD:] = 0
+    w, b = torch.randn(1, C, 1, generator=g) * 0.1, torch.randn(1, generator=g)
+    gout = torch.randn(B, 1, T, generator=g)
+    dc, wc, bc = (t.cuda().requires_grad_(True) for t in (d.reshape(B * Tp, C), w, b))
+    owner = {}
+    out = DurProj.apply(dc, wc, bc, mask.cuda(), owner)
+    out.backward(gout.cuda())
+    d64, w64, b64 = (t.double().requires_grad_(True) for t in (d.reshape(B * Tp, C), w, b))
+    want = ((d64 * w64[0, :, 0]).sum(-1) + b64).view(B, Tp)[:, ROW_PAD:-ROW_PAD].unsqueeze(1) * mask.double()
+    want.backward(gout.double())
+    assert torch.allclose(out.detach().cpu().double(), want.detach(), rtol=1e-5, atol=1e-5)
+    for got, ref in ((dc.grad, d64.grad), (wc.grad, w64.grad), (bc.grad, b64.grad)):
+        assert torch.allclose(got.cpu().double(), ref, rtol=1e-5, atol=1e-5 * max(1.0, float(ref.abs().max()))), (got.cpu().double() - ref).abs().max()
+    assert int(owner[next(iter(owner))].item()) == 0
+    # a second backward through the same counter (left zero by the first)
+    dc.grad = wc.grad = bc.grad = None
+    DurProj.apply(dc, wc, bc, mask.cuda(), owner).backward(gout.cuda())
+    assert torch.allclose(wc.grad.cpu().double(), w64.grad, rtol=1e-5, atol=1e-5 * max(1.0, float(w64.grad.abs().max())))
+    # the split
+    M = 8 if C % 16 else min(C // 2, 80)
+    rows = torch.randn(B * Tp, 2 * M, generator=g)
+    rc = rows.cuda().requires_grad_(True)
+    mean, ls = PriorSplit.apply(rc, B, T)
+    ref = from_rows(rows.view(B, Tp, -1))
+    assert torch.equal(mean.cpu(), ref[:, :M].contiguous()) and torch.equal(ls.cpu(), ref[:, M:].contiguous())
+    gm, gl = torch.randn(B, M, T, generator=g), torch.randn(B, M, T, generator=g)
+    torch.autograd.backward([mean, ls], [gm.cuda(), gl.cuda()])
+    r2 = rows.clone().requires_grad_(True)
+    p2 = from_rows(r2.view(B, Tp, -1))
+    torch.autograd.backward([p2[:, :M].contiguous(), p2[:, M:].contiguous()], [gm, gl])
+    assert torch.equal(rc.grad.cpu(), r2.grad)
+    rc.grad = None
+    mean, ls = PriorSplit.apply(rc, B, T)
+    ls.sum().backward()                                        # one of the two unused: zeros in its half
+    assert torch.equal(rc.grad.cpu().view(B, Tp, -1)[:, ROW_PAD:-ROW_PAD, :M], torch.zeros(B, T, M)) and float(rc.grad.sum()) == B * T * M
 
 
 def test_duration_mse_matches_torch():
