@@ -352,7 +352,7 @@ class LossTerms:
     """The sum of loss terms a training step differentiates (Train.py:213-216 `loss = MLE + Length (+ Speaker)`, `loss.backward()`), kept as its terms: `backward()`
     seeds every term with its weight directly - no sum node, no ones_like fill in front of the backward - and with the very tensors the terms' forward launches
     were told about (`SEEDS`), so that nodes which wrote their gradients in the forward launch recognise the seed and launch nothing.  The weighted sum itself
-    (for the log) is computed AFTER the backward was queued.  Duck-types the one tensor method the step loops use (`backward`, `detach`)."""
+    (for the log) is computed when `detach()` asks for it.  Duck-types the tensor methods the step loops use (`backward`, `detach`, `item`)."""
 
     def __init__(self, terms, seeds=None, after=None):
         self.terms = [t for t in terms if t is not None]
@@ -368,17 +368,18 @@ class LossTerms:
 
     def backward(self):
         torch.autograd.backward(self.terms, [self._seed_of(t, s) for t, s in zip(self.terms, self.seeds)])
-        self.detach()
-        if self.after is not None:
-            self.after()
 
     def detach(self):
+        """The weighted sum (computed on first use - the step loops ask for it behind the parameter update, so that its launches and `after`'s do not sit between
+        the backward and the gradient norm)."""
         if self._total is None:
             tot = None
             for t, s in zip(self.terms, self.seeds):
                 v = t.detach() if s is None else t.detach() * s
                 tot = v if tot is None else tot + v
             self._total = tot
+            if self.after is not None:
+                self.after()
         return self._total
 
     def item(self):

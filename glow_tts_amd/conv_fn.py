@@ -262,7 +262,12 @@ class ConvRows(torch.autograd.Function):
             _lib.check(_L().glowtts_gate_bwd_io(dy.data_ptr(), out.data_ptr(), _sp(rowmask) if mask_out else None, dz.data_ptr(), R, O,
                                                 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0, io, _lib.stream()), "glowtts_gate_bwd_io")
         elif mask_out:
-            dz = dy * rowmask.unsqueeze(1)
+            if dy.dtype == torch.float32 and O % 4 == 0:           # the row mask alone (glowtts_gate_bwd_io without a gate tensor): one vectorised launch
+                dz = torch.empty(R, O, device=dy.device, dtype=bf if bfpath else torch.float32)
+                _lib.check(_L().glowtts_gate_bwd_io(dy.data_ptr(), None, _sp(rowmask), dz.data_ptr(), R, O, 1.0, 4 if bfpath else 0, _lib.stream()),
+                           "glowtts_gate_bwd_io")
+            else:
+                dz = dy * rowmask.unsqueeze(1)
         else:
             dz = dy
         dres = dz if (has_res and ctx.needs_input_grad[4]) else None

@@ -267,7 +267,8 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const void* __restrict__ 
         float4 d, o;
         if (DYB) { const ushort4 t = reinterpret_cast<const ushort4*>(dy_)[i]; d = make_float4(bf2f(t.x), bf2f(t.y), bf2f(t.z), bf2f(t.w)); }
         else d = reinterpret_cast<const float4*>(dy_)[i];
-        if (OUTB) { const ushort4 t = reinterpret_cast<const ushort4*>(out_)[i]; o = make_float4(bf2f(t.x), bf2f(t.y), bf2f(t.z), bf2f(t.w)); }
+        if (!out_) o = make_float4(1.f, 1.f, 1.f, 1.f);       // (no gate: the row mask alone - the backward of a conv whose output is only masked)
+        else if (OUTB) { const ushort4 t = reinterpret_cast<const ushort4*>(out_)[i]; o = make_float4(bf2f(t.x), bf2f(t.y), bf2f(t.z), bf2f(t.w)); }
         else o = reinterpret_cast<const float4*>(out_)[i];
         const float4 z = make_float4(o.x != 0.f ? d.x * m : 0.f, o.y != 0.f ? d.y * m : 0.f, o.z != 0.f ? d.z * m : 0.f, o.w != 0.f ? d.w * m : 0.f);
         if (DZB) { ushort4 t; t.x = f2bf(z.x); t.y = f2bf(z.y); t.z = f2bf(z.z); t.w = f2bf(z.w); reinterpret_cast<ushort4*>(dz_)[i] = t; }
@@ -636,7 +637,7 @@ extern "C" int glowtts_layernorm_bwd(const float* dy, const float* y, const floa
 
 extern "C" int glowtts_gate_bwd_io(const void* dy, const void* out, const float* rowmask, void* dz, int64_t rows, int C, float scale, int io_flags, void* stream)
 {
-    if (!dy || !out || !dz || rows < 1 || C < 4 || (C & 3) || (io_flags & ~7)) return GLOWTTS_E_ARG;
+    if (!dy || (!out && !rowmask) || !dz || rows < 1 || C < 4 || (C & 3) || (io_flags & ~7)) return GLOWTTS_E_ARG;
     const dim3 grid(grid_for(rows * C / 4));
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define GATE_CASE(F, A, B, Z) case F: hipLaunchKernelGGL((gate_bwd_kernel<A, B, Z>), grid, dim3(256), 0, st, dy, out, rowmask, dz, (long)rows, C, scale); break;

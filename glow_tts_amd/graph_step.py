@@ -52,10 +52,10 @@ class GraphedTrainStep:
         return gd.is_dist()
 
     def _fwd_bwd(self, inputs):
-        loss = self.loss_fn(self.model, *inputs)          # a scalar tensor or `alignment.LossTerms`
+        loss = self.loss_fn(self.model, *inputs)          # a scalar tensor or `alignment.LossTerms` (whose sum is computed by the first `detach()`)
         self.model.zero_grad(set_to_none=True)
         loss.backward()
-        return loss.detach()
+        return loss
 
     def _update(self):
         coef = None
@@ -84,7 +84,7 @@ class GraphedTrainStep:
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             for _ in range(self.warmup):
-                eager_loss = self._fwd_bwd(static_in)          # no update: a new shape must not cost extra optimizer / scheduler steps
+                eager_loss = self._fwd_bwd(static_in).detach()  # no update: a new shape must not cost extra optimizer / scheduler steps
             if self.optimizer is not None and not self._opt_ready:
                 if dp:
                     self._reducer_all().reduce(average=False)
@@ -111,7 +111,7 @@ class GraphedTrainStep:
                 from .distributed import FlatGradReducer
                 with D.defer_tail_wgrads():
                     with torch.cuda.graph(g, pool=self.pool, capture_error_mode=mode):
-                        loss = self._fwd_bwd(static_in)
+                        loss = self._fwd_bwd(static_in).detach()
                 tail = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(tail, pool=self.pool, capture_error_mode=mode):
                     D.flush_tail_wgrads()
@@ -131,6 +131,7 @@ class GraphedTrainStep:
                     loss = self._fwd_bwd(static_in)
                     if self.optimizer is not None:
                         self._update()
+                    loss = loss.detach()                       # (the logged sum: behind the update on this stream)
                 if self.optimizer is not None:
                     self._uncount_capture_pass()
         entry.update(graph=g, loss=loss, grads=[p.grad for p in self.params])

@@ -237,6 +237,7 @@ class Trainer:
             self.optimizer.step()
             self.scheduler.step()
             self.steps += 1
+            loss.detach()                                          # (LossTerms: writes the step's loss components into self._comp)
         for tag, v in zip(("MLE", "Length", "Total", "Speaker"), self._comp.unbind(0)):
             self.scalar_Dict["Train"]["Loss/" + tag] += v          # device scalars: no host sync per step
 
