@@ -403,8 +403,8 @@ _TAIL_OF = {k: not (k.startswith(("an_", "inv_")) or k.endswith("_in")) for k in
 class _Prepared:
     """Packed weight images + per-flow parameter structs for one set of stacked weights."""
 
-    def __init__(self, cfg, W, need_bwd, cond=None, fused_bwd_ok=True, rows=None, GV=None):
-        """fused_bwd_ok = False: the backward needs what only the per-conv kernels produce (GR mode: the per-row pitch conditioning and the
+    def __init__(self, cfg, W, need_bwd, cond=None, fused_bwd_ok=True, rows=None, GV=None, conditioned=None):
+        """conditioned: whether a conditioning vector will be set (early_prepare runs before it exists); None = `cond is not None`.  fused_bwd_ok = False: the backward needs what only the per-conv kernels produce (GR mode: the per-row pitch conditioning and the
         Pitch_l weight gradient).  rows: B * (T + 4) of the batch this is prepared for (sizes the automatic choice of TUNE["fused_wn_bwd"]).
         GV (training, bf16, fused coupling network): {"w_start" | "w_in" | "w_rs" | "w_rs_last": (weight_g, weight_v)} stacked like W's entries, which
         are then absent from W - every image is produced from the weight-norm pairs by ONE launch (csrc/prep_ops.hip; `self.inv` keeps 1 / ||v||
@@ -529,7 +529,11 @@ class _Prepared:
             cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
             # (round 5: 8 of 12 - the encoder's backward chain lost its gate passes, the relative-position sums and ~100 us of weight packing at its head:
             # 5.02 vs 5.07 ms/step for 7, three alternating pairs on one box; 9: 5.23)
-            nfb = F_ if (nwg is not None and 4 * nwg <= 3 * cus) else max(1, (2 * F_) // 3)
+            # (round 6: 9 of 12 - the head of the encoder's backward lost its dozen PyTorch launches (duration projection, prior split: enc_dgrads_done 4 006 ->
+            # 3 580 us): 4.69 / 4.73 vs 4.77 / 4.78 ms/step for 8, two alternating rounds on one box; 10: 4.80, 12: 4.95)
+            # (conditioned modes stay at 8 of 12: config 3 5.01 vs 5.11 ms/step for 9 - their encoder stream also carries the conditioning encoders' backward)
+            is_cond = (cond is not None) if conditioned is None else bool(conditioned)
+            nfb = F_ if (nwg is not None and 4 * nwg <= 3 * cus) else max(1, ((2 if is_cond else 3) * F_) // (3 if is_cond else 4))
         else:
             nfb = min(int(nfb), F_)                             # flows 0 .. nfb-1 take the fused kernel
         f0 = min(max(int(TUNE["fused_wn_bwd_from"]), 0), F_ - nfb)               # (experiments: the fused flows are f0 .. f0 + nfb - 1)
@@ -889,15 +893,15 @@ def _split_gv(weights):
     return A, GV
 
 
-def early_prepare(cfg, weights, mel_shape, fused_bwd_ok=True):
+def early_prepare(cfg, weights, mel_shape, fused_bwd_ok=True, conditioned=False):
     """weights: DecoderStacks.weights(gv=True).  Must be followed by DecoderFunction.apply on the same weights in the same forward."""
     if len(weights) != len(WEIGHT_KEYS_GV):
         return
     W, GV = _split_gv(weights)
     need_bwd = any(w.requires_grad for w in weights)
     EARLY["prep"] = _Prepared(cfg, W, need_bwd=need_bwd, cond=None, fused_bwd_ok=fused_bwd_ok,
-                              rows=mel_shape[0] * (mel_shape[2] // cfg.ns + 2 * ROW_PAD), GV=GV)
-    EARLY["key"] = (tuple(w.data_ptr() for w in weights), need_bwd, bool(fused_bwd_ok), GV)
+                              rows=mel_shape[0] * (mel_shape[2] // cfg.ns + 2 * ROW_PAD), GV=GV, conditioned=conditioned)
+    EARLY["key"] = (tuple(w.data_ptr() for w in weights), need_bwd, bool(fused_bwd_ok), GV, bool(conditioned))
 
 
 class DecoderFunction(torch.autograd.Function):
@@ -916,7 +920,8 @@ class DecoderFunction(torch.autograd.Function):
         condc = cond.detach().contiguous() if cond is not None else None
         early, ekey = EARLY["prep"], EARLY["key"]
         EARLY["prep"] = EARLY["key"] = None
-        if early is not None and GV is not None and ekey[0] == tuple(w.data_ptr() for w in weights) and ekey[1] == need_bwd and ekey[2] == (pitches is None):
+        if early is not None and GV is not None and ekey[0] == tuple(w.data_ptr() for w in weights) and ekey[1] == need_bwd and ekey[2] == (pitches is None) and \
+                ekey[4] == (cond is not None):
             prep, GV = early, ekey[3]                           # (issued before the encoder's launches; the same weights)
             prep.set_cond(condc)
         else:

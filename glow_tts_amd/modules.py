@@ -338,7 +338,8 @@ class GlowTTS(torch.nn.Module):
         prior_ready = torch.cuda.Event() if side is not main else None
         # (behind the fork: the encoder's stream does not wait for it)
         if use_gv and decoder.TUNE["prep_early"] and all(f.layers[0].initialized for f in self._flows()):
-            decoder.early_prepare(self.dec_cfg, W, mels.shape, fused_bwd_ok=(pitches is None or "Pitch_v" not in stacks.S))
+            decoder.early_prepare(self.dec_cfg, W, mels.shape, fused_bwd_ok=(pitches is None or "Pitch_v" not in stacks.S),
+                                  conditioned=(spk is not None or pro is not None))
         early_prep = decoder.EARLY["prep"]
 
         prepared = {}
