@@ -1,0 +1,6 @@
+for i in 1 2; do
+for arm in "" "--tune fused_wn_bwd=9" "--tune fused_wn_bwd=10" "--tune fused_wn_bwd=12" "--tune fused_wn_fwd_skip=2" "--tune fused_wn_fwd_skip=1" "--tune fused_wn_bwd=10 --tune fused_wn_fwd_skip=2"; do
+  python bench.py --no-cpu-baseline --no-f32-key --windows 4 $arm 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('-- $arm', d['ms_per_step'], d['windows']['ms_per_step_median'], (d.get('fwd_bwd_only') or {}).get('ms_per_step'))"
+done; done
