@@ -22,7 +22,8 @@ extern "C" {
 #define GLOWTTS_E_LAUNCH     -2   /* hip launch error */
 #define GLOWTTS_ABI_VERSION    7
 
-/* Library / device identification.  Returns the ABI version (currently 6: glowtts_cond_linear_supported, the direct 3x3 stride-2 conv trio glowtts_conv3x3s2_*; 5: additions only - glowtts_cond_linear_fwd / _bwd, glowtts_prep_launch_dev,
+/* Library / device identification.  Returns the ABI version (currently 7: glowtts_prior_loss, glowtts_dur_proj_*, glowtts_prior_split_*, the `path` argument of
+ * glowtts_expand_pair_targets, the `da_unit` argument of glowtts_mse_loss_fwd, glowtts_gate_bwd_io with out == NULL; 6: glowtts_cond_linear_supported, the direct 3x3 stride-2 conv trio glowtts_conv3x3s2_*; 5: additions only - glowtts_cond_linear_fwd / _bwd, glowtts_prep_launch_dev,
  * glowtts_rpr_attention_bwd_partial_rows (and NULL drelk / drelv), glowtts_sum_slices / _seg, GLOWTTS_F_GATE_IN0, GLOWTTS_F_COND_FX, glowtts_flow_acts.skip may be NULL on
  * the fused forward launch, glowtts_flow_grads.dcond holds 64-bit fixed-point accumulators; 4: glowtts_flow_acts grew next_* / actnorm_done - the next flow's ActNorm + 1x1 conv in the
  * fused coupling launch's epilogue - and glowtts_proj_layernorm / glowtts_layernorm_qkv were added; 3: glowtts_prep_job / glowtts_prep_launch / glowtts_wavenet_prep_jobs,
@@ -635,7 +636,7 @@ int glowtts_layernorm_bwd_io(const float *dy, const float *y, const float *s, co
                              uint16_t *ds_bf16, const float *gate_out, float gate_scale, void *stream);
 /* dz = dy * (out != 0 ? scale : 0) * rowmask : backward gate of relu / dropout given the forward output */
 int glowtts_gate_bwd(const float *dy, const float *out, const float *rowmask, float *dz, int64_t rows, int C, float scale, void *stream);
-/* io_flags: 1 = dy, 2 = out, 4 = dz stored as bf16 instead of fp32 (C a multiple of 4) */
+/* io_flags: 1 = dy, 2 = out, 4 = dz stored as bf16 instead of fp32 (C a multiple of 4).  ABI 7: out == NULL (with a rowmask) = no gate, dz = dy * scale * rowmask. */
 int glowtts_gate_bwd_io(const void *dy, const void *out, const float *rowmask, void *dz, int64_t rows, int C, float scale, int io_flags, void *stream);
 /* rows[b][PAD+t][:] = table[tokens[b][t]][:] * scale * mask (Modules.py:267), and its gradient (deterministic) */
 /* mask [B][T] = (t < lengths[b]) and the rows layout's row mask [B][T + 2 GLOWTTS_ROW_PAD] (zero pad rows) in one launch (Modules.py:206-211; round 5) */
