@@ -234,6 +234,18 @@ def test_duration_projection_and_prior_split_match_torch(B, T, C):
     assert torch.equal(rc.grad.cpu().view(B, Tp, -1)[:, ROW_PAD:-ROW_PAD, :M], torch.zeros(B, T, M)) and float(rc.grad.sum()) == B * T * M
 
 
+def test_last_workgroup_hand_over_under_load():
+    """The one-launch loss and the duration projection's backward hand their partial sums to the last workgroup through returning device-scope atomics (no release
+    fence: that writes the XCD's L2 back).  `tools/stress_handover.py`: 200 launches beside a stream that keeps the CUs and the L2s busy, every result bit-identical
+    to the first and to the unfused launches, the completion counters left at zero."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_handover.py"), "200"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_duration_mse_matches_torch():
     """`alignment.duration_mse` (one launch per direction) against torch's MSELoss (Train.py:203-211) and against the trainer's extent-normalised form."""
     from glow_tts_amd.alignment import duration_mse
