@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include "../../include/glowtts_hip.h"
 #include "launch_log.h"
+#include "device_common.h"
 
 namespace {
 
@@ -256,5 +257,25 @@ extern "C" int glowtts_cond_linear_bwd(const float* dcond, int64_t ldd, const fl
         const int64_t n = (int64_t)B * D;
         hipLaunchKernelGGL(cond_dvec_kernel, dim3((int)((n + 63) / 64)), dim3(1024), 0, s, scratch, dvec, nwg, n);
     }
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
+
+// The conditioning gradient's fixed-point accumulators (device_common.h fx_atomic_add) -> float; a poisoned accumulator (non-finite / out-of-range addend) reads NaN.
+namespace {
+__global__ __launch_bounds__(256) void fx_to_float_kernel(const long long* __restrict__ acc, float* __restrict__ out, long n)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long long a = acc[i];
+        const bool bad = a >= GLOWTTS_FX_POISON || a <= -GLOWTTS_FX_POISON;
+        out[i] = bad ? __int_as_float(0x7FC00000) : (float)((double)a * (1.0 / 1099511627776.0));
+    }
+}
+}  // namespace
+extern "C" int glowtts_fx_to_float(const int64_t* acc, float* out, int64_t n, void* stream)
+{
+    if (!acc || !out || n < 1) return GLOWTTS_E_ARG;
+    const long g = (n + 255) / 256;
+    GLOWTTS_NOTE_STATIC("fx_to_float");
+    hipLaunchKernelGGL(fx_to_float_kernel, dim3((int)(g > 4096 ? 4096 : g)), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const long long*>(acc), out, (long)n);
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }

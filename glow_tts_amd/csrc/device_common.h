@@ -59,9 +59,15 @@ __device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t id, float p,
 
 // Conditioning-gradient accumulators (round 5): fixed point, units of 2^-40, 64-bit integer atomics.  Integer addition commutes, so the per-utterance sums that the
 // workgroups of a launch (and the launches of the twelve flows' layers) add into one buffer no longer depend on the order they arrive in: the gradients of the
-// Speaker_l / Prosody_l / Pitch_l convs are bit-reproducible from run to run (fp32 atomic adds were not).  Range +- 8.4e6, resolution 9.1e-13 per addend.
+// Speaker_l / Prosody_l / Pitch_l convs are bit-reproducible from run to run (fp32 atomic adds were not).  Range +- 2.1e6 (beyond: poisoned, below), resolution 9.1e-13 per addend.
 constexpr float GLOWTTS_FX_SCALE = 1099511627776.f;          // 2^40
+// A non-finite addend, or one beyond +- 2^21 (2^61 units - a quarter of the range), POISONS the accumulator instead of vanishing in the float -> integer conversion
+// (NaN -> 0, Inf -> saturation): it is set to the largest value, later addends only move it within |acc| >= 2^61, and glowtts_fx_to_float (cond_ops.hip)
+// reads such an accumulator as NaN - the Speaker_l / Prosody_l / Pitch_l gradients propagate a diverging step like fp32 sums did.
+constexpr long long GLOWTTS_FX_POISON = 0x2000000000000000LL;        // 2^61
 __device__ __forceinline__ void fx_atomic_add(long long* dst, float v) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__float2ll_rn(v * GLOWTTS_FX_SCALE));
+    const float s = v * GLOWTTS_FX_SCALE;
+    if (!(fabsf(s) < 2.3e18f)) { atomicExch(reinterpret_cast<unsigned long long*>(dst), 0x7FFFFFFFFFFFFFFFull); return; }
+    atomicAdd(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__float2ll_rn(s));
 }
 

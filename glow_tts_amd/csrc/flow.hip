@@ -244,8 +244,8 @@ extern "C" int glowtts_flow_backward(const glowtts_flow_dims* d, const glowtts_f
             q.io_flags = bf ? (GLOWTTS_IO_IN0_BF16 | GLOWTTS_IO_OUT0_BF16 | (bfg ? GLOWTTS_IO_A_BF16 : 0)) : 0;
             // conditioning gradient (autograd of Modules.py:863-866): per-utterance sums of the gate gradients before the dropout mask
             if (g->dcond && p->cond) {
-                // (64-bit fixed-point accumulators, glowtts_flow_grads.dcond: layer l starts 2 H ELEMENTS = 4 H floats in)
-                q.out1 = g->dcond + (int64_t)l * 4 * H; q.ld1 = p->ldcond; q.flags |= GLOWTTS_F_COND_FX;
+                // (64-bit fixed-point accumulators, glowtts_flow_grads.dcond: layer l starts 2 H elements in)
+                q.out1 = reinterpret_cast<float*>(g->dcond + (int64_t)l * 2 * H); q.ld1 = p->ldcond; q.flags |= GLOWTTS_F_COND_FX;
                 if (g->pitch_rows) {       // + the Pitch_l weight gradient, into the rows behind the utterances' (see glowtts_flow_grads)
                     if (g->pitch_ns < 1 || g->pitch_ns > 2) return GLOWTTS_E_ARG;
                     q.cond = g->pitch_rows; q.ldcond = g->pitch_ns; q.flags |= GLOWTTS_F_COND_ROWS;

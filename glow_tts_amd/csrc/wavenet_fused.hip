@@ -722,6 +722,7 @@ int glowtts_wavenet_pack_bwd_images(const float* w_start, const float* w_in, con
                                     int F, int L, int C2, void* img_bwd, void* stream);      // wavenet_fused_bwd.hip
 static int g_wn_safe_waits = 0;
 extern "C" void glowtts_wavenet_debug_safe_waits(int on) { g_wn_safe_waits = on ? 1 : 0; }
+int glowtts_wavenet_safe_waits_flag() { return g_wn_safe_waits; }
 
 extern "C" int glowtts_wavenet_image_bytes(int L, int transposed, int64_t* bytes_out)
 {

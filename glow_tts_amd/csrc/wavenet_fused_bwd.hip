@@ -29,6 +29,8 @@
 #include "launch_log.h"
 #include "wavenet_common.h"
 
+int glowtts_wavenet_safe_waits_flag();        // wavenet_fused.hip
+
 namespace {
 
 constexpr int BW_NS = 3;                                        // ring slots
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(WN_NT) void wn_bwd_kernel(const wn_bwd_args p)
     // for exactly slab snext; a smaller count would also wait for the wave's own stores to be acknowledged / its gate loads to return.  X must never
     // exceed the real count: every counted operation is an unconditional buffer instruction.  The conditioned variants (their atomics make the
     // count data-dependent) run the conservative vmcnt(2) everywhere.  The last two slabs (Start^T) drain the ring with conservative counts.
-    constexpr bool EXACT = !COND;
+    constexpr bool EXACT = !COND && !(ABL & 128);              // (ABL & 128: the test hook glowtts_wavenet_debug_safe_waits - conservative counts, same bits)
     auto begin_step = [&](auto X_) __attribute__((always_inline)) -> const unsigned char* {
         constexpr int X = EXACT ? decltype(X_)::value : 0;
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(2 + X) : "memory");
@@ -645,6 +647,9 @@ int launch_wn_bwd(const wn_bwd_args& k, dim3 grid, hipStream_t s)
         }
     }
 #endif
+    if constexpr (ABL == 0 && DROP && !COND) {                  // (test hook: the unconditioned training shape with conservative waits)
+        if (glowtts_wavenet_safe_waits_flag()) return launch_wn_bwd<DROP, COND, 128>(k, grid, s);
+    }
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wn_bwd_kernel<DROP, COND, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GLOWTTS_E_LAUNCH;
@@ -706,7 +711,7 @@ extern "C" int glowtts_wavenet_bwd(const glowtts_flow_dims* d, const glowtts_flo
     const int nvalid = WN_WIN - 2 * WN_PAD * (d->L - 1);
     const dim3 grid((unsigned)((R + nvalid - 1) / nvalid));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (cnd) { k.dcond = g->dcond; k.ldcond = p->ldcond; }
+    if (cnd) { k.dcond = reinterpret_cast<float*>(g->dcond); k.ldcond = p->ldcond; }
 #ifdef GLOWTTS_TOOLS
     k.stagger = GLOWTTS_TUNABLE("GLOWTTS_WN_STAGGER", 0);
     if (!cnd && (GLOWTTS_TUNABLE("GLOWTTS_WN_BWD_ABL", 0) & 64)) k.tl = reinterpret_cast<long long*>(g->dcond);      // tools/bench_wn.py passes the stamp buffer here

@@ -987,7 +987,7 @@ class DecoderFunction(torch.autograd.Function):
                     out[k] = flat[off:off + n].view(shapes[k])
                     off += npad
                 if ks:
-                    register_arena(out[ks[0]])                               # (its pads are private and zero: the reducer may sum the whole span)
+                    register_arena(*[out[k] for k in ks])                    # (its pads are private and zero: the reducer may sum the whole span)
             return out
         ret_shapes = {}
         for k in (WEIGHT_KEYS_GV if GV is not None else WEIGHT_KEYS):
@@ -1233,7 +1233,10 @@ class DecoderFunction(torch.autograd.Function):
             torch.autograd.Variable._execution_engine.queue_callback(at_end)
         dmel = unsqueeze_rows(cfg, dx, ctx.lengths, B, Tm) if ctx.want_dmel else None
         if dcond is not None:
-            dcond = (dcond.to(torch.float64) * 2.0 ** -40).to(torch.float32)
+            # (one launch; a non-finite gate gradient poisons its accumulator and reads NaN here - ADVICE r5)
+            acc, dcond = dcond.contiguous(), torch.empty(dcond.shape, device=dcond.device)
+            _L().glowtts_fx_to_float.argtypes = [c_void_p, c_void_p, ctypes.c_int64, c_void_p]
+            _lib.check(_L().glowtts_fx_to_float(acc.data_ptr(), dcond.data_ptr(), acc.numel(), _lib.stream()), "glowtts_fx_to_float")
         dpw = dpb = None
         if ctx.prow is not None:
             # Pitch_l conv (Modules.py:846-852, 867-869): bias gradient = the conditioning gradient summed over utterances; weight gradient =

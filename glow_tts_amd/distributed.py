@@ -144,17 +144,29 @@ def global_batch_weight(local_utterances, device=None):
 _ARENAS = {}
 
 
-def register_arena(view):
-    _ARENAS[view.untyped_storage().data_ptr()] = weakref.ref(view)
+def register_arena(*views):
+    """Declares the storage under `views` (views that tile it, up to alignment pads the caller owns and keeps zero) as one arena: `FlatGradReducer` may then
+    all-reduce the whole span in place.  The registration holds weak references to EVERY view given - it stays valid as long as any of them is alive (one
+    particular wrapper could be dropped while the others kept the storage) - and is only taken when a process group exists."""
+    if not views or not is_dist():
+        return
+    sptr = views[0].untyped_storage().data_ptr()
+    _ARENAS[sptr] = [weakref.ref(v) for v in views]
+    if len(_ARENAS) > 64:                                       # (eager data-parallel steps allocate new arenas every step: drop the dead ones)
+        for k in [k for k, refs in _ARENAS.items() if not any(r() is not None for r in refs)]:
+            _ARENAS.pop(k, None)
 
 
 def _is_arena(storage_ptr):
-    ref = _ARENAS.get(storage_ptr)
-    t = ref() if ref is not None else None
-    if t is None or t.untyped_storage().data_ptr() != storage_ptr:
-        _ARENAS.pop(storage_ptr, None)
+    refs = _ARENAS.get(storage_ptr)
+    if refs is None:
         return False
-    return True
+    for r in refs:
+        t = r()
+        if t is not None and t.untyped_storage().data_ptr() == storage_ptr:
+            return True
+    _ARENAS.pop(storage_ptr, None)
+    return False
 
 
 class FlatGradReducer:
@@ -165,11 +177,13 @@ class FlatGradReducer:
       * the remaining small tensors are concatenated into flat buckets, reduced, and copied back.
     Buckets follow reverse parameter order, i.e. the order the backward pass produces them."""
 
-    def __init__(self, params, bucket_bytes=64 << 20, direct_bytes=8 << 20, static=False):
+    def __init__(self, params, bucket_bytes=64 << 20, direct_bytes=8 << 20, static=False, frozen=False):
         """static: the gradients keep their addresses from call to call (a replayed hipGraph of the step writes them in place): the plan and the
-        flat buckets are built on the first call and kept - no per-step Python over hundreds of parameters, no allocation."""
+        flat buckets are built on the first call and kept - no allocation per step; every call still checks (a data_ptr per parameter) that no gradient
+        appeared, vanished or moved.  frozen: the caller guarantees that (GraphedTrainStep: the gradients of a captured shape are the graph's own buffers) -
+        no per-step Python over hundreds of parameters at all."""
         self.params = [p for p in params if p.requires_grad]
-        self.bucket_bytes, self.direct_bytes, self.static = bucket_bytes, direct_bytes, static
+        self.bucket_bytes, self.direct_bytes, self.static, self.frozen = bucket_bytes, direct_bytes, static or frozen, frozen
         self._kept = self._kept_sig = None
 
     def _signature(self):
@@ -215,7 +229,7 @@ class FlatGradReducer:
         if not is_dist():
             return None
         _check_not_capturing("FlatGradReducer.begin")
-        if self.static and self._kept is not None and self._signature() != self._kept_sig:
+        if self.static and not self.frozen and self._kept is not None and self._signature() != self._kept_sig:
             self._kept = None                                  # a gradient appeared, vanished or moved since the plan was made: plan again
         if self.static and self._kept is not None:
             direct, buckets, flats, views = self._kept

@@ -118,8 +118,9 @@ class GraphedTrainStep:
                 stacks = getattr(self.model, "_dec_stacks", None)
                 tail_ids = {id(p) for p in stacks.tail_leaves()} if stacks is not None else set()
                 entry["tail"] = tail
-                entry["early"] = FlatGradReducer([p for p in self.params if id(p) not in tail_ids], static=True)
-                entry["late"] = FlatGradReducer([p for p in self.params if id(p) in tail_ids], static=True)
+                # (frozen: __call__ points every .grad at this entry's buffers before the replay - their addresses cannot change)
+                entry["early"] = FlatGradReducer([p for p in self.params if id(p) not in tail_ids], frozen=True)
+                entry["late"] = FlatGradReducer([p for p in self.params if id(p) in tail_ids], frozen=True)
                 if self.optimizer is not None:
                     og = torch.cuda.CUDAGraph()                # the update reads the REDUCED gradients: its own graph behind the exchange
                     with torch.cuda.graph(og, pool=self.pool, capture_error_mode=mode):

@@ -341,6 +341,12 @@ class GlowTTS(torch.nn.Module):
             decoder.early_prepare(self.dec_cfg, W, mels.shape, fused_bwd_ok=(pitches is None or "Pitch_v" not in stacks.S),
                                   conditioned=(spk is not None or pro is not None))
         early_prep = decoder.EARLY["prep"]
+        # (TUNE["prep_bwd_late"], off by default: the deferred launch writes buffers that early_prepare allocated on THIS stream behind the fork - the encoder's
+        #  stream must see this stream's allocator history first: an event here, waited for in front of the deferred launch.  ADVICE r5)
+        images_allocated = None
+        if early_prep is not None and side is not main and getattr(early_prep, "bwd_pending", None) is not None:
+            images_allocated = torch.cuda.Event()
+            images_allocated.record(main)
 
         prepared = {}
 
@@ -353,7 +359,9 @@ class GlowTTS(torch.nn.Module):
             # the decoder's backward-only weight images: on the encoder's stream right behind its projection (they need nothing but the weights) - under the
             # decoder's z / log-determinant passes and in front of the duration predictor, whose result only the losses read.  (Behind the duration
             # predictor they ran under the alignment search, a single-wave latency chain: mas_dp2 36 -> 52 us.)  Joined with this stream before the call returns.
-            if early_prep is not None:
+            if early_prep is not None and getattr(early_prep, "bwd_pending", None) is not None:
+                if images_allocated is not None:
+                    side.wait_event(images_allocated)
                 early_prep.launch_bwd_images(gentle=bool(decoder.TUNE["prep_bwd_gentle"]))
         with torch.cuda.stream(side):
             decoder.stamp("enc_branch_first_node")

@@ -23,7 +23,7 @@ extern "C" {
 #define GLOWTTS_ABI_VERSION    7
 
 /* Library / device identification.  Returns the ABI version (currently 7: glowtts_prior_loss, glowtts_dur_proj_*, glowtts_prior_split_*, the `path` argument of
- * glowtts_expand_pair_targets, the `da_unit` argument of glowtts_mse_loss_fwd, glowtts_gate_bwd_io with out == NULL; 6: glowtts_cond_linear_supported, the direct 3x3 stride-2 conv trio glowtts_conv3x3s2_*; 5: additions only - glowtts_cond_linear_fwd / _bwd, glowtts_prep_launch_dev,
+ * glowtts_expand_pair_targets, the `da_unit` argument of glowtts_mse_loss_fwd, glowtts_gate_bwd_io with out == NULL, glowtts_fx_to_float and glowtts_flow_grads.dcond typed int64_t *; 6: glowtts_cond_linear_supported, the direct 3x3 stride-2 conv trio glowtts_conv3x3s2_*; 5: additions only - glowtts_cond_linear_fwd / _bwd, glowtts_prep_launch_dev,
  * glowtts_rpr_attention_bwd_partial_rows (and NULL drelk / drelv), glowtts_sum_slices / _seg, GLOWTTS_F_GATE_IN0, GLOWTTS_F_COND_FX, glowtts_flow_acts.skip may be NULL on
  * the fused forward launch, glowtts_flow_grads.dcond holds 64-bit fixed-point accumulators; 4: glowtts_flow_acts grew next_* / actnorm_done - the next flow's ActNorm + 1x1 conv in the
  * fused coupling launch's epilogue - and glowtts_proj_layernorm / glowtts_layernorm_qkv were added; 3: glowtts_prep_job / glowtts_prep_launch / glowtts_wavenet_prep_jobs,
@@ -448,8 +448,9 @@ typedef struct glowtts_flow_grads {       /* backward outputs; weight grads are 
     float *dw_in[GLOWTTS_MAX_WN_LAYERS], *db_in[GLOWTTS_MAX_WN_LAYERS];   /* [2H][H][k], [2H] */
     float *dw_rs[GLOWTTS_MAX_WN_LAYERS], *db_rs[GLOWTTS_MAX_WN_LAYERS];   /* [2H|H][H][1], [2H|H] */
     float *dw_end, *db_end;               /* [C][H][1], [C] */
-    float *dcond;                         /* [B][ldcond] or NULL: grad of the conditioning, ACCUMULATED (zero it first).  ABI 5: the ELEMENTS are int64 fixed-point
-                                           * accumulators in units of 2^-40 (the pointer type is nominal; value = (double)acc * 2^-40): integer atomics, reproducible sums */
+    int64_t *dcond;                       /* [B][ldcond] or NULL: grad of the conditioning, ACCUMULATED (zero it first): int64 fixed-point accumulators in units of
+                                           * 2^-40 (integer atomics: reproducible sums; ABI 5 - typed int64_t since ABI 7, a float buffer no longer compiles).  A non-finite
+                                           * or out-of-range (|v| >= 2^21) addend POISONS its accumulator (|acc| >= 2^61); glowtts_fx_to_float turns it into NaN */
     float *douts_bf;                      /* act_bf16 only (else NULL): [R][ldo] bf16 copy of douts, scratch (End data gradient operand) */
     /* fusion across flows (backward runs flow F-1 .. 0): */
     int coupling_done;                    /* 1: the previous call already applied THIS flow's coupling backward (dx, douts, douts_bf are ready) */
@@ -531,6 +532,9 @@ int64_t glowtts_cond_linear_bwd_scratch_floats(int N, int D, int B);
 /* 1 when glowtts_cond_linear_fwd AND _bwd take (N, D, B) - D in {128, 256, 384, 512}, B <= 64 and both kernels' LDS tiles ((32 + B') (D + 4) floats
  * plus the backward's extras) within 160 KiB, e.g. not D = 512 with B > 40 - else 0: the caller then forms the product itself (ABI 6). */
 int glowtts_cond_linear_supported(int N, int D, int B);
+/* ABI 7.  The fixed-point accumulators of glowtts_flow_grads.dcond -> float: out[i] = (float)((double)acc[i] * 2^-40), NaN where the accumulator is poisoned
+ * (a NaN / Inf / out-of-range addend: the conditioning gradients propagate non-finite values like fp32 sums would). */
+int glowtts_fx_to_float(const int64_t *acc, float *out, int64_t n, void *stream);
 int glowtts_cond_linear_bwd(const float *dcond, int64_t ldd, const float *v, const float *g, const float *inv, const float *vec,
                             float *dv, float *dg, float *dbias, float *dvec, float *scratch, int N, int D, int B, void *stream);
 

@@ -250,6 +250,36 @@ def test_fused_backward_matches_per_conv_backward(lengths, tm, drop):
     print("fused vs per-conv backward: worst gradient cosine", worst)
 
 
+def test_backward_exact_wait_counts_equal_conservative_waits():
+    """The fused BACKWARD kernel's hand-counted `vmcnt(2 + X)` waits (wavenet_fused_bwd.hip begin_step: they step over the wave's own prefetched gate loads and
+    copy-out stores) against the same kernel compiled with the conservative `vmcnt(2)` everywhere (`glowtts_wavenet_debug_safe_waits`): every gradient bit for
+    bit, several shapes, repeated launches - a count that is one too large would read a weight slab before it has landed."""
+    from glow_tts_amd import _lib, decoder as D
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    cfg, sd = full_width_state(2, g)
+    dc = D.DecoderConfig(cfg.mel_dim, cfg.n_flows, cfg.n_squeeze, cfg.n_split, cfg.wn_channels, cfg.wn_layers, cfg.wn_kernel, 1)
+    P = {k: v.cuda() for k, v in sd.items()}
+    for lengths, tm, drop in (([800] * 32, 800, 0.05), ([640, 522, 240, 2], 640, 0.3), ([104], 104, 0.05)):
+        B = len(lengths)
+        mels = (torch.randn(B, 80, tm, generator=g) * 1.5).clamp(-4, 4).cuda()
+        ml = torch.tensor(lengths).cuda()
+        wz, wl = torch.randn(B, 80, tm, generator=g).cuda(), (torch.randn(B, generator=g) * 0.05).cuda()
+        try:
+            L.glowtts_wavenet_debug_safe_waits(1)
+            torch.manual_seed(3)
+            ref, dxr, cr = _grads(D, dc, P, mels, ml, wz, wl, True, drop)
+        finally:
+            L.glowtts_wavenet_debug_safe_waits(0)
+        assert sum(n for k, n in cr.items() if k.startswith("wn_bwd<")) == 2, cr
+        for _ in range(3):
+            torch.manual_seed(3)
+            got, dxg, _ = _grads(D, dc, P, mels, ml, wz, wl, True, drop)
+            assert torch.equal(dxg, dxr)
+            for k in ref:
+                assert torch.equal(got[k], ref[k]), k
+
+
 @pytest.mark.parametrize("lengths,tm,drop", [([640, 522, 240, 2], 640, 0.3), ([40, 36, 20, 8, 40, 40, 12], 40, 0.3), ([800] * 3, 800, 0.0)])
 def test_fused_backward_conditioning_gradient(lengths, tm, drop):
     """Speaker / prosody conditioning (Modules.py:863-866) joins the gate pre-activation AFTER the dropout: its gradient is the per-utterance sum
@@ -286,6 +316,30 @@ def test_fused_backward_conditioning_gradient(lengths, tm, drop):
         a, b = gf["<conditioning>"][b_].flatten().double(), gu["<conditioning>"][b_].flatten().double()
         if b.norm() > 0:
             assert (a @ b / (a.norm() * b.norm() + 1e-30)).item() >= 0.999, (b_, (a @ b / (a.norm() * b.norm() + 1e-30)).item())
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_conditioning_gradient_propagates_non_finite_values(fused):
+    """The conditioning gradient is summed in 64-bit fixed point (integer atomics: reproducible).  A NaN / Inf gate gradient must not vanish in the float ->
+    integer conversion: it poisons its accumulator and `glowtts_fx_to_float` reads NaN - for the utterance it belongs to, and only that one."""
+    from glow_tts_amd import decoder as D
+    g = torch.Generator().manual_seed(19)
+    cfg, sd = full_width_state(2, g, spk_dim=256)
+    dc = D.DecoderConfig(cfg.mel_dim, cfg.n_flows, cfg.n_squeeze, cfg.n_split, cfg.wn_channels, cfg.wn_layers, cfg.wn_kernel, 1)
+    P = {k: v.cuda() for k, v in sd.items()}
+    lengths, tm = [640, 522, 240], 640
+    B = len(lengths)
+    mels = (torch.randn(B, 80, tm, generator=g) * 1.5).clamp(-4, 4).cuda()
+    ml = torch.tensor(lengths).cuda()
+    spk = torch.randn(B, 256, generator=g)
+    cond = D.conditioning(P, dc, speakers=(spk / spk.norm(dim=1, keepdim=True)).cuda()).detach()
+    wz, wl = torch.randn(B, 80, tm, generator=g).cuda(), (torch.randn(B, generator=g) * 0.05).cuda()
+    wz[1, 7, 100] = float("nan")                               # d loss / d z of one frame of utterance 1
+    torch.manual_seed(3)
+    grads, _, _ = _grads(D, dc, P, mels, ml, wz, wl, fused, 0.05, cond)
+    dc_ = grads["<conditioning>"]
+    assert torch.isnan(dc_[1]).any(), "the non-finite gate gradient vanished from the conditioning gradient"
+    assert torch.isfinite(dc_[0]).all() and torch.isfinite(dc_[2]).all()
 
 
 def test_mixed_forward_first_flow_per_conv():
