@@ -57,7 +57,7 @@ template <int N> struct WStaticFor {
 };
 template <> struct WStaticFor<0> { template <class F> __device__ __forceinline__ static void run(F&&) {} };
 
-struct WCommon { int rows, pad, accumulate, njobs, xcd; };
+struct WCommon { int rows, pad, accumulate, njobs, xcd; int phase = 0; };      // phase: tiles of the first phase (glowtts_wgrad_grouped_phased), 0 = one phase
 
 // pointers that come out of the device job table are "generic" to the compiler, which would emit flat_load (counted on
 // BOTH vmcnt and lgkmcnt, i.e. every LDS wait would also drain the prefetch).  They are global: say so.
@@ -431,8 +431,14 @@ __global__ __launch_bounds__(DNT) void wgrad_dma_kernel(const glowtts_wgrad_job*
     extern __shared__ __attribute__((aligned(1024))) unsigned char dsm[];
     int tile = blockIdx.x;
     if (cm.xcd) {
-        const int G = gridDim.x, q = G >> 3, r = G & 7, x = tile & 7, k = tile >> 3;
-        tile = x * q + min(x, r) + k;
+        // workgroup b runs on XCD b & 7: the workgroups of an XCD take a contiguous run of tiles (a problem's tiles share operand columns: one L2 fetches them).
+        // Phased launches (cm.phase): the same inside each phase [lo, hi) of workgroups / tiles.  cnt(N, x) = workgroups below N on XCD x.
+        const int b = tile, x = b & 7;
+        const int plo = (cm.phase > 0 && b >= cm.phase) ? cm.phase : 0, phi = (cm.phase > 0 && b < cm.phase) ? cm.phase : (int)gridDim.x;
+        auto cnt = [](int N, int y) __attribute__((always_inline)) -> int { return (N - y + 7) >> 3; };
+        int off = 0;
+        for (int y = 0; y < x; ++y) off += cnt(phi, y) - cnt(plo, y);
+        tile = plo + off + cnt(b, x) - cnt(plo, x);
     }
     int lo = 0, hi = cm.njobs - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[mid].tile0 <= tile) lo = mid; else hi = mid - 1; }
@@ -444,7 +450,8 @@ __global__ __launch_bounds__(DNT) void wgrad_dma_kernel(const glowtts_wgrad_job*
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;                 // wave tile: o [96 wm, + 96) x c [16 NC wn, + 16 NC)
     const int s16 = lane & 15, kg = lane >> 4;
-    const int nsteps = (cm.rows + DBK - 1) / DBK;
+    const int jrows = p.rows > 0 ? p.rows : cm.rows;         // (a row split of a phased launch has its own row count)
+    const int nsteps = (jrows + DBK - 1) / DBK;
     // buffer descriptors by hand (raw buffer, 32-bit offsets checked against the byte size) for the DMA below, which is issued from inline assembly: through the
     // builtin the compiler orders every later LDS read behind it with s_waitcnt vmcnt(0) - a full memory round trip at the head of every step
     auto make_rsrc = [](const void* ptr, int64_t bytes) __attribute__((always_inline)) -> i32x4w {
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(DNT) void wgrad_dma_kernel(const glowtts_wgrad_job*
         return i32x4w{(int)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), (int)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32) & 0xFFFF),
                       (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
     };
-    const i32x4w rdy = make_rsrc(p.dy, (int64_t)cm.rows * p.lddy * 2), rx = make_rsrc(p.x, (int64_t)cm.rows * p.ldx * 2);
+    const i32x4w rdy = make_rsrc(p.dy, (int64_t)jrows * p.lddy * 2), rx = make_rsrc(p.x, (int64_t)jrows * p.ldx * 2);
     // ---- this wave's DMA slots per stage: slot j = instruction SLOTS wave + j (those past the last repeat it: same bytes to the same place, and every wave counts SLOTS).
     // Per-lane byte offsets inside the operand for step 0; + 64 rows per step ----
     // (branch-free: q is a wave-uniform run-time value.)  The last X instruction is pulled back to END at the tile's end - it overlaps its predecessor
@@ -701,6 +708,20 @@ extern "C" int glowtts_wgrad_cl(const glowtts_wgrad_args* args, void* stream)
     if (a.precision == GLOWTTS_BF16) return launch_w<__bf16>(j, nullptr, cm, a.taps, a.xpro, a.io_flags, grid, s);
     if (a.precision == GLOWTTS_F32) return launch_w<float>(j, nullptr, cm, a.taps, a.xpro, a.io_flags, grid, s);
     return GLOWTTS_E_ARG;
+}
+
+extern "C" int glowtts_wgrad_grouped_phased(const glowtts_wgrad_job* dev_jobs, int njobs, int total_tiles, int whole_tiles, int rows, int taps, void* stream)
+{
+    if (!dev_jobs || njobs < 1 || total_tiles < 1 || whole_tiles < 0 || whole_tiles > total_tiles || rows < 1) return GLOWTTS_E_ARG;
+    WCommon cmd{rows, (taps - 1) / 2, 0, njobs, xcd_mode()};
+    cmd.phase = (whole_tiles > 0 && whole_tiles < total_tiles) ? whole_tiles : 0;
+    hipStream_t sd = static_cast<hipStream_t>(stream);
+    switch (taps) {
+        case 1: return launch_wgrad_dma<1>(dev_jobs, cmd, dim3(total_tiles), sd);
+        case 3: return launch_wgrad_dma<3>(dev_jobs, cmd, dim3(total_tiles), sd);
+        case 5: return launch_wgrad_dma<5>(dev_jobs, cmd, dim3(total_tiles), sd);
+        default: return GLOWTTS_E_ARG;
+    }
 }
 
 extern "C" int glowtts_wgrad_grouped(const glowtts_wgrad_job* dev_jobs, int njobs, int total_tiles, int rows, int taps, int pad,

@@ -80,6 +80,7 @@ def _L():
         L.glowtts_flow_backward.argtypes = [c_void_p] * 5
         L.glowtts_wgrad_grouped.argtypes = [c_void_p] + [c_int] * 9 + [c_void_p]
         L.glowtts_wgrad_grouped_io.argtypes = [c_void_p] + [c_int] * 10 + [c_void_p]
+        L.glowtts_wgrad_grouped_phased.argtypes = [c_void_p] + [c_int] * 5 + [c_void_p]
         L.glowtts_colsum_batched.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_i64, c_i64, c_void_p]
         L.glowtts_weightnorm_fwd.argtypes = [c_void_p] * 4 + [c_i64, c_int, c_void_p]
         L.glowtts_weightnorm_bwd.argtypes = [c_void_p] * 6 + [c_i64, c_int, c_void_p]
@@ -109,7 +110,7 @@ class WgradJob(ctypes.Structure):
     _fields_ = [("dy", c_void_p), ("x", c_void_p), ("xmask", c_void_p), ("dw", c_void_p), ("dbias", c_void_p),
                 ("lddy", c_i64), ("ldx", c_i64),
                 ("m", c_int), ("ca", c_int), ("xpro", c_int), ("perm", c_int), ("perm_h", c_int),
-                ("tile0", c_int), ("mt", c_int), ("nt", c_int), ("reserved", c_i64)]
+                ("tile0", c_int), ("mt", c_int), ("nt", c_int), ("rows", c_int), ("reserved", c_int)]
 
 
 class PrepJob(ctypes.Structure):
@@ -185,7 +186,7 @@ TAIL = {"defer": False, "pending": []}
 #       memory system at the head of the step and the decoder's forward ends 45 us later: 5.24-5.30 against 5.20-5.23 ms/step (three alternating pairs)
 #   prep_fused: training on the fused bf16 path forms w = g v / ||v|| and every weight image in ONE launch (csrc/prep_ops.hip) instead of 4 weight-norm +
 #       ~22 packing launches (0.42 -> ~0.1 ms at the head of the step, round 4)
-TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "fwd_packs_split": 0, "cond_hip": True, "drop_skip32": True, "wgrad_tail_splits": 2, "prep_bwd_late": False, "prep_bwd_gentle": True, "tail_aside": True}
+TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "fwd_packs_split": 0, "cond_hip": True, "drop_skip32": True, "wgrad_tail_splits": 2, "prep_bwd_late": False, "prep_bwd_gentle": True, "tail_aside": True, "wgrad_balance": False}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 
@@ -319,9 +320,82 @@ class WgradGroup:
             g.table = table[off:off + len(r)]
             off += len(r)
 
+    def balance(self, B, rows_per_utt, device):
+        """Two-phase form of a one-segment LDS-DMA group whose tile count exceeds the CU count by a fraction (the decoder's In_l group at B = 32: 288 one-per-CU
+        tiles on 256 CUs = two rounds, the second with 32 tiles): the first jobs stay whole (at most one round), the rest are cut into S row splits over B / S
+        utterances each - short tiles that fill the idle CUs beside the whole ones and ONE short round behind them (288 tiles: 1 + 1/8 rounds instead of 2).
+        The splits write partial images (`self.part` [S, n]), summed in a fixed order by `sum_parts` (one glowtts_sum_slices_seg launch).  A cut between
+        utterances is exact for any tap count: the pad rows around every utterance are zero.  -> True when the group was rebuilt."""
+        if not (self._dma and self._wide) or len(self.segments) != 0 or self._start != 0 or not self.jobs or self.rows != B * rows_per_utt:
+            return False
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
+        bm, bn = 192, (192 if self.taps == 1 else 64)
+        tiles = [((j.m + bm - 1) // bm) * ((j.ca + bn - 1) // bn) for j in self.jobs]
+        if len(set(tiles)) != 1 or any(j.dbias is None for j in self.jobs):
+            return False
+        tpj, nj = tiles[0], len(self.jobs)
+        unsplit = float(-(-nj * tpj // cus))
+        best = None
+        for S in (2, 4, 8, 16):
+            if B % S:
+                continue
+            for a in range(nj, -1, -1):                        # (most whole jobs first: ties go to the fewest partial images)
+                W = a * tpj
+                if W > cus:
+                    continue
+                P = (nj - a) * S * tpj
+                t, done = (1.0, min(P, (cus - W) * S)) if W else (0.0, 0)
+                t += -(-(P - done) // cus) / S
+                if best is None or t < best[0] - 1e-9:
+                    best = (t, a, S)
+        if best is None or best[0] > unsplit - 0.25 or best[1] == nj:
+            return False
+        _, a, S = best
+        whole, cut = self.jobs[:a], self.jobs[a:]
+        # destinations of the partial images: (dw, dbias) of every cut job, contiguous neighbours merged (glowtts_sum_slices_seg takes 12 segments)
+        segs, tot = [], 0
+        place = {}
+        for j in cut:
+            for ptr, n in ((j.dw, j.m * j.ca * self.taps), (j.dbias, j.m)):
+                if n % 4 or ptr % 16:
+                    return False
+                place[ptr] = tot
+                if segs and segs[-1][0] + 4 * segs[-1][1] == ptr:
+                    segs[-1] = (segs[-1][0], segs[-1][1] + n, segs[-1][2])
+                else:
+                    segs.append((ptr, n, tot))
+                tot += n
+        if len(segs) > 12:
+            return False
+        self.part = torch.empty(S, tot, device=device)
+        Rs = (B // S) * rows_per_utt
+        jobs = list(whole)
+        for j in cut:
+            for s_ in range(S):
+                c = WgradJob()
+                ctypes.memmove(ctypes.byref(c), ctypes.byref(j), ctypes.sizeof(WgradJob))
+                c.dy, c.x = j.dy + 2 * s_ * Rs * j.lddy, j.x + 2 * s_ * Rs * j.ldx          # (bf16 operands)
+                c.dw = self.part.data_ptr() + 4 * (s_ * tot + place[j.dw])
+                c.dbias = self.part.data_ptr() + 4 * (s_ * tot + place[j.dbias])
+                c.rows = Rs
+                jobs.append(c)
+        self.jobs, self.part_segs, self.part_S, self.whole_tiles = jobs, segs, S, a * tpj
+        return True
+
+    def sum_parts(self):
+        if getattr(self, "part", None) is None:
+            return
+        segs = (SumSeg * len(self.part_segs))(*[SumSeg(p0, off, n) for p0, n, off in self.part_segs])
+        _lib.check(_L().glowtts_sum_slices_seg(self.part.data_ptr(), self.part_S, self.part.shape[1], segs, len(self.part_segs), _lib.stream()), "glowtts_sum_slices_seg")
+
     def launch_segment(self, i):
         start, n, tiles = self.segments[i]
         if n == 0:
+            return
+        if getattr(self, "part", None) is not None:
+            _lib.check(_L().glowtts_wgrad_grouped_phased(self.table.data_ptr() + start * ctypes.sizeof(WgradJob), n, tiles, self.whole_tiles, self.rows, self.taps,
+                                                         _lib.stream()), "glowtts_wgrad_grouped_phased")
+            self.sum_parts()
             return
         _lib.check(_L().glowtts_wgrad_grouped_io(self.table.data_ptr() + start * ctypes.sizeof(WgradJob), n, tiles, self.rows, self.taps,
                                                  (self.taps - 1) // 2, self.xpro, self.precision, 1, 0,
@@ -1092,6 +1166,12 @@ class DecoderFunction(torch.autograd.Function):
                         grp.end_segment()
         # Few, large launches: 216-432 k-tap tiles per launch fill the chip without split-K (per-flow launches of 36 tiles were
         # measured 3x slower in total, even on a second stream).
+        # TUNE["wgrad_balance"] (round 6, OFF): 288 one-per-CU In_l tiles on 256 CUs are two rounds, the second with 32 tiles; the balanced two-phase launch
+        # (WgradGroup.balance) runs them in 1 + 1/8 rounds and ends the decoder's tail 126 us earlier (dec_wgrads_done 4 311 against 4 437 us) - and the step
+        # takes as long as before (4.71-4.77 against 4.66-4.76 ms/step, five alternating pairs on two boxes): the idle CUs of the second round were where the
+        # encoder's backward ran, which now ends that much later (enc_wgrads_done 4 523 against 4 292).  Kept for a step whose second half is not shared.
+        if TUNE["wgrad_balance"] and int(TUNE["wgrad_split"]) == 1 and bf:
+            gk.balance(B, T + 2 * ROW_PAD, dev)
         for grp in (gk, g1, gp):
             grp.end_segment()
         WgradGroup.upload_all((gk, g1, gp), dev)

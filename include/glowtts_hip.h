@@ -360,7 +360,8 @@ typedef struct glowtts_wgrad_job {
     int64_t lddy, ldx;
     int m, ca, xpro, perm, perm_h;
     int tile0, mt, nt;
-    int64_t reserved;
+    int rows;                          /* ABI 7 (was reserved, 0): > 0 = this job's own row count (glowtts_wgrad_grouped_phased), 0 = the launch's */
+    int reserved;
 } glowtts_wgrad_job;
 /* every job of one launch uses the same X prologue `xpro` (job.xpro is ignored); m and ca must be multiples of 4 */
 int glowtts_wgrad_grouped(const glowtts_wgrad_job *dev_jobs, int njobs, int total_tiles, int rows, int taps, int pad,
@@ -368,6 +369,14 @@ int glowtts_wgrad_grouped(const glowtts_wgrad_job *dev_jobs, int njobs, int tota
 /* same, with the storage types of DY / X (GLOWTTS_WIO_*) shared by every job of the launch */
 int glowtts_wgrad_grouped_io(const glowtts_wgrad_job *dev_jobs, int njobs, int total_tiles, int rows, int taps, int pad,
                              int xpro, int precision, int splits, int accumulate, int io_flags, void *stream);
+
+/* ABI 7.  The LDS-DMA kernel (GLOWTTS_WIO_DMA's conditions: bf16 rows operands, no prologue, 192 x 64 tiles - 192 x 192 at one tap) over a job table in TWO
+ * PHASES for load balance: a launch of one-workgroup-per-CU tiles that exceeds the CU count by a fraction runs a second, almost empty round (288 tiles on 256
+ * CUs: 2 x 169 us).  The caller puts whole problems first (`whole_tiles` tiles, at most the CU count) and the remaining problems behind them cut into row
+ * splits (job.rows = rows / S, row-offset operand pointers, partial outputs summed afterwards by glowtts_sum_slices_seg): the short tiles fill the idle CUs and
+ * the tail of the round.  Workgroup -> tile mapping stays XCD-contiguous inside each phase.  A cut must fall on an utterance boundary of the rows layout (the
+ * pad rows make it exact for any tap count). */
+int glowtts_wgrad_grouped_phased(const glowtts_wgrad_job *dev_jobs, int njobs, int total_tiles, int whole_tiles, int rows, int taps, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * One flow step of the decoder = Activation_Norm -> Invertible_1x1_Conv -> Affine_Coupling_Layer

@@ -318,6 +318,42 @@ def test_fused_backward_conditioning_gradient(lengths, tm, drop):
             assert (a @ b / (a.norm() * b.norm() + 1e-30)).item() >= 0.999, (b_, (a @ b / (a.norm() * b.norm() + 1e-30)).item())
 
 
+def test_balanced_weight_gradient_launch_equals_the_single_round_form():
+    """decoder.TUNE["wgrad_balance"] (round 6; off by default - it shortens the decoder's tail, not the step): at B = 32 x 800 frames the In_l weight-gradient group is 48 problems x 6 one-per-CU tiles = 288 tiles on 256 CUs -
+    two rounds, the second almost empty.  The balanced form keeps 42 problems whole and cuts 6 into 8 row splits over 4 utterances each (short tiles beside and
+    behind the whole ones, partial images summed in a fixed order).  Same gradients up to fp32 summation order, for every class; repeated runs bit-identical."""
+    from glow_tts_amd import decoder as D
+    g = torch.Generator().manual_seed(29)
+    cfg, sd = full_width_state(12, g)
+    dc = D.DecoderConfig(cfg.mel_dim, cfg.n_flows, cfg.n_squeeze, cfg.n_split, cfg.wn_channels, cfg.wn_layers, cfg.wn_kernel, 1)
+    P = {k: v.cuda() for k, v in sd.items()}
+    B, tm = 32, 800
+    mels = (torch.randn(B, 80, tm, generator=g) * 1.5).clamp(-4, 4).cuda()
+    ml = torch.tensor([800] * 20 + [640, 522, 240, 2, 798, 400, 96, 12, 800, 700, 600, 500]).cuda()
+    wz, wl = torch.randn(B, 80, tm, generator=g).cuda(), (torch.randn(B, generator=g) * 0.05).cuda()
+    res = []
+    for bal in (True, False, True):
+        D.TUNE["wgrad_balance"] = bal
+        try:
+            torch.manual_seed(3)
+            grads, dx, counts = _grads(D, dc, P, mels, ml, wz, wl, -1, 0.05)
+        finally:
+            D.TUNE["wgrad_balance"] = False
+        assert counts.get("wgrad_dma<5>/grouped") == 1, counts
+        res.append((grads, dx))
+    (ga, dxa), (gb, dxb), (gc, dxc) = res
+    assert torch.equal(dxa, dxb) and torch.equal(dxa, dxc)
+    n_diff = 0
+    for k in gb:
+        assert torch.equal(ga[k], gc[k]), k                                     # deterministic
+        if not torch.equal(ga[k], gb[k]):
+            n_diff += 1
+            assert "In_" in k, k                                                # only the In_l classes are cut
+            scale = gb[k].abs().max()
+            assert (ga[k] - gb[k]).abs().max() <= 2e-5 * scale, (k, ((ga[k] - gb[k]).abs().max() / scale).item())
+    assert n_diff > 0, "the balanced launch did not engage at B = 32 x 800"
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_conditioning_gradient_propagates_non_finite_values(fused):
     """The conditioning gradient is summed in 64-bit fixed point (integer atomics: reproducible).  A NaN / Inf gate gradient must not vanish in the float ->
