@@ -4,6 +4,7 @@
 // One wavefront per row; a row (<= a few KB) is read once and kept in registers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "../../include/glowtts_hip.h"
 #include "launch_log.h"
 
@@ -81,7 +82,65 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __rest
     if (lane == 0) dg[r] = dot * inv;
 }
 
+// several weight-norm backward problems in ONE launch (the decoder's four weight-normalised classes: four dependent launches of 5 - 40 us at the very end of the
+// step's critical chain; as one launch they run side by side).  The table travels in the argument segment.
+struct wn_bwd_table { glowtts_wn_bwd_job job[GLOWTTS_WN_BWD_MAX_JOBS]; int block0[GLOWTTS_WN_BWD_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void weightnorm_bwd_multi_kernel(const wn_bwd_table tab, int njobs)
+{
+    int lo = 0;
+#pragma unroll
+    for (int i = 1; i < GLOWTTS_WN_BWD_MAX_JOBS; ++i) lo = (i < njobs && tab.block0[i] <= (int)blockIdx.x) ? i : lo;
+    const glowtts_wn_bwd_job& j = tab.job[lo];
+    const long r = (long)(blockIdx.x - tab.block0[lo]) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, cols = j.cols;
+    if (r >= j.rows) return;
+    const float* vr = j.v + r * cols;
+    const float* dr = j.dw + r * cols;
+    float* or_ = j.dv + r * cols;
+    float xv[WN_MAXK], xd[WN_MAXK];
+    float dot = 0.f;
+    const bool fits = cols <= 64 * WN_MAXK;
+    if (fits) {
+#pragma unroll
+        for (int k = 0; k < WN_MAXK; ++k) {
+            const int c = lane + 64 * k;
+            xv[k] = c < cols ? vr[c] : 0.f; xd[k] = c < cols ? dr[c] : 0.f;
+            dot += xv[k] * xd[k];
+        }
+    } else {
+        for (int c = lane; c < cols; c += 64) dot += vr[c] * dr[c];
+    }
+    dot = wave_sum(dot);
+    const float inv = j.inv_norm[r], sc = j.g[r] * inv, k2 = dot * inv * inv;
+    if (fits) {
+#pragma unroll
+        for (int k = 0; k < WN_MAXK; ++k) { const int c = lane + 64 * k; if (c < cols) or_[c] = sc * (xd[k] - xv[k] * k2); }
+    } else {
+        for (int c = lane; c < cols; c += 64) or_[c] = sc * (dr[c] - vr[c] * k2);
+    }
+    if (lane == 0) j.dg[r] = dot * inv;
+}
+
 }  // namespace
+
+extern "C" int glowtts_weightnorm_bwd_multi(const glowtts_wn_bwd_job* jobs, int njobs, void* stream)
+{
+    if (!jobs || njobs < 1 || njobs > GLOWTTS_WN_BWD_MAX_JOBS) return GLOWTTS_E_ARG;
+    wn_bwd_table tab;
+    memset(&tab, 0, sizeof(tab));
+    long blocks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const glowtts_wn_bwd_job& j = jobs[i];
+        if (!j.dw || !j.v || !j.g || !j.inv_norm || !j.dv || !j.dg || j.rows < 1 || j.cols < 1) return GLOWTTS_E_ARG;
+        tab.job[i] = j;
+        tab.block0[i] = (int)blocks;
+        blocks += (j.rows + 3) / 4;
+    }
+    if (blocks >= (1L << 31)) return GLOWTTS_E_ARG;
+    GLOWTTS_NOTE_STATIC("weightnorm_bwd_multi");
+    hipLaunchKernelGGL(weightnorm_bwd_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), tab, njobs);
+    return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
+}
 
 extern "C" int glowtts_weightnorm_fwd(const float* v, const float* g, float* w, float* inv_norm, int64_t rows, int cols, void* stream)
 {

@@ -100,6 +100,12 @@ def _L():
     return L
 
 
+class WnBwdJob(ctypes.Structure):
+    """Mirror of `glowtts_wn_bwd_job`."""
+    _fields_ = [("dw", c_void_p), ("v", c_void_p), ("g", c_void_p), ("inv_norm", c_void_p), ("dv", c_void_p), ("dg", c_void_p),
+                ("rows", c_i64), ("cols", c_int), ("reserved", c_int)]
+
+
 class SumSeg(ctypes.Structure):
     """Mirror of `glowtts_sum_seg`."""
     _fields_ = [("dst", c_void_p), ("off", c_i64), ("n", c_i64)]
@@ -1261,6 +1267,9 @@ class DecoderFunction(torch.autograd.Function):
         # 1x1 groups are queued behind them
         GVgrad = {}
         if GV is not None:
+            # one launch per destination (now / the deferred tail / the weight-gradient stream) for all classes that go there: as four dependent launches
+            # (5 - 40 us each) they were the last ~85 us of the decoder's chain in front of the gradient norm
+            wn_now, wn_pending, wn_keep = [], [], []
             for k in WN_KEYS:
                 g_, v_ = GV[k]
                 if v_.numel() == 0:
@@ -1270,15 +1279,22 @@ class DecoderFunction(torch.autograd.Function):
                 rows_ = v_.numel() // cols
                 dv, dg = RET["v" + k[1:]], RET["g" + k[1:]]
                 GVgrad[k] = (dg, dv)
-                run = lambda k=k, g_=g_, v_=v_, dv=dv, dg=dg, rows_=rows_, cols=cols, inv=prep.inv[k], dw=G[k]: _lib.check(
-                    L.glowtts_weightnorm_bwd(dw.data_ptr(), v_.data_ptr(), g_.data_ptr(), inv.data_ptr(), dv.data_ptr(), dg.data_ptr(), rows_, cols, _lib.stream()),
-                    "glowtts_weightnorm_bwd")
-                if TAIL["defer"] and halves == 1 and k != "w_in":
-                    TAIL["pending"].append(run)
-                elif tail_fns is not None:
-                    tail_fns.append(run)
-                else:
-                    run()
+                j = WnBwdJob()
+                j.dw, j.v, j.g, j.inv_norm, j.dv, j.dg = G[k].data_ptr(), v_.data_ptr(), g_.data_ptr(), prep.inv[k].data_ptr(), dv.data_ptr(), dg.data_ptr()
+                j.rows, j.cols = rows_, cols
+                wn_keep.append((g_, v_, dv, dg, prep.inv[k], G[k]))
+                (wn_pending if (TAIL["defer"] and halves == 1 and k != "w_in") else wn_now).append(j)
+
+            def wn_run(jobs, keep=wn_keep):
+                if jobs:                                        # (4.70 / 4.72 / 4.70 against 4.75 / 4.70 / 4.76 ms/step for one launch per class, three alternating pairs)
+                    L.glowtts_weightnorm_bwd_multi.argtypes = [c_void_p, c_int, c_void_p]
+                    _lib.check(L.glowtts_weightnorm_bwd_multi((WnBwdJob * len(jobs))(*jobs), len(jobs), _lib.stream()), "glowtts_weightnorm_bwd_multi")
+            if wn_pending:
+                TAIL["pending"].append(lambda jobs=wn_pending: wn_run(jobs))
+            if tail_fns is not None:
+                tail_fns.append(lambda jobs=wn_now: wn_run(jobs))
+            else:
+                wn_run(wn_now)
 
         def param_sums():
             stamp("dec_wgrads_done")

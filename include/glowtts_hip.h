@@ -747,6 +747,13 @@ int glowtts_prior_split_bwd(const float *dmean, const float *dlog_std, float *dr
 int glowtts_weightnorm_fwd(const float *v, const float *g, float *w, float *inv_norm, int64_t rows, int cols, void *stream);
 int glowtts_weightnorm_bwd(const float *dw, const float *v, const float *g, const float *inv_norm, float *dv, float *dg,
                            int64_t rows, int cols, void *stream);
+/* ABI 7.  Up to GLOWTTS_WN_BWD_MAX_JOBS glowtts_weightnorm_bwd problems in one launch (`jobs` is a HOST array; same arithmetic, same bits). */
+#define GLOWTTS_WN_BWD_MAX_JOBS 8
+typedef struct glowtts_wn_bwd_job {
+    const float *dw, *v, *g, *inv_norm; float *dv, *dg;
+    int64_t rows; int cols, reserved;
+} glowtts_wn_bwd_job;
+int glowtts_weightnorm_bwd_multi(const glowtts_wn_bwd_job *jobs, int njobs, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer side of the training step: multi-tensor launches over a DEVICE job table.
