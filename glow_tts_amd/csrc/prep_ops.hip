@@ -14,6 +14,7 @@
 #include <string.h>
 #include "../../include/glowtts_hip.h"
 #include "launch_log.h"
+#include "tunable.h"
 #include "device_common.h"
 
 namespace {
@@ -36,7 +37,8 @@ __device__ __forceinline__ unsigned short bf16_bits_prep(float v) { const __bf16
 constexpr int PREP_MAXJOBS = GLOWTTS_PREP_MAX_JOBS;
 struct prep_table { glowtts_prep_job jobs[PREP_MAXJOBS]; };
 
-__device__ __forceinline__ void prep_body(const glowtts_prep_job& j, const int rel)
+// abl (tools builds, GLOWTTS_PREP_ABL): 1 = no image stores (phase 3), 2 = no LDS tile writes (phase 2), 4 = no phase 3 at all
+__device__ __forceinline__ void prep_body(const glowtts_prep_job& j, const int rel, const int abl = 0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char prep_smem[];
     unsigned short* const tile = reinterpret_cast<unsigned short*>(prep_smem);
@@ -98,9 +100,14 @@ __device__ __forceinline__ void prep_body(const glowtts_prep_job& j, const int r
                 }
             }
         }
+        // (round 6: the four rows' reductions side by side and their g loads issued with the row loads above - same arithmetic, same bits; measured neutral:
+        //  58-61 us per launch either way.  tools/bench_prep.py ablations: rows -> norm -> tile alone 41 us of the 58, the image writes 16, i.e. the kernel is
+        //  bound by its load phase at ~3 TB/s with 4 workgroups per CU - 119 VGPRs -, not by the LDS traffic of the transposition)
+        float gv[PREP_RP], ss[PREP_RP];
+#pragma unroll
+        for (int h = 0; h < PREP_RP; ++h) gv[h] = (j.g && ok[h]) ? j.g[(int64_t)b * j.g_stride + o[h]] : 0.f;
 #pragma unroll
         for (int h = 0; h < PREP_RP; ++h) {
-            const int r = wave * (PREP_TR / 4) + rr + h;
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < PREP_MAXPL; ++k) {
@@ -108,21 +115,33 @@ __device__ __forceinline__ void prep_body(const glowtts_prep_job& j, const int r
                 x[h][k] = (ok[h] && c < cols) ? x[h][k] : 0.f;
                 s += x[h][k] * x[h][k];
             }
+            ss[h] = s;
+        }
+        if (j.g) {
+#pragma unroll
+            for (int o_ = 32; o_ > 0; o_ >>= 1) {
+#pragma unroll
+                for (int h = 0; h < PREP_RP; ++h) ss[h] += __shfl_xor(ss[h], o_, 64);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < PREP_RP; ++h) {
+            const int r = wave * (PREP_TR / 4) + rr + h;
             float sc = 1.f;
             if (j.g) {
-                s = prep_wave_sum(s);
-                const float inv = ok[h] ? 1.f / sqrtf(s) : 0.f;
-                sc = ok[h] ? j.g[(int64_t)b * j.g_stride + o[h]] * inv : 0.f;
+                const float inv = ok[h] ? 1.f / sqrtf(ss[h]) : 0.f;
+                sc = ok[h] ? gv[h] * inv : 0.f;
                 if (j.inv_out && ok[h] && lane == 0) j.inv_out[(int64_t)b * j.g_stride + o[h]] = inv;
             }
 #pragma unroll
             for (int k = 0; k < PREP_MAXPL; ++k) {
                 const int c = lane + 64 * k;
-                if (k < nk && c < cols) tile[r * pitch + c] = bf16_bits_prep(x[h][k] * sc);
+                if (k < nk && c < cols && !(abl & 2)) tile[r * pitch + c] = bf16_bits_prep(x[h][k] * sc);
             }
         }
     }
     __syncthreads();
+    if (abl & 4) return;
     // ---- 3: the tile's part of the image ----
     unsigned char* const img = static_cast<unsigned char*>(j.packed) + (int64_t)(b / j.inner) * j.outer_stride + (int64_t)(b % j.inner) * j.inner_stride;
     const int taps = j.taps, kch = j.kchunks, npad = j.npad, I = j.I;
@@ -140,7 +159,7 @@ __device__ __forceinline__ void prep_body(const glowtts_prep_job& j, const int r
                 const uint32_t a = ca < I ? tile[r * pitch + ca * taps + t] : 0u, bb = cb < I ? tile[r * pitch + cb * taps + t] : 0u;
                 w[e] = a | (bb << 16);
             }
-            *reinterpret_cast<uint4*>(img + ((int64_t)(t * kch + kc) * npad + tl * PREP_TR + r) * 64 + q * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+            if (!(abl & 1)) *reinterpret_cast<uint4*>(img + ((int64_t)(t * kch + kc) * npad + tl * PREP_TR + r) * 64 + q * 16) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     } else {
         // (part of) K chunk kc = tl * PREP_TR / 32 of every (tap, n): piece = (t', n, q): 8 consecutive k = tile rows 8 q ..; n = source channel, taps
@@ -160,18 +179,22 @@ __device__ __forceinline__ void prep_body(const glowtts_prep_job& j, const int r
                     w[e] = a | (bb << 16);
                 }
             }
-            *reinterpret_cast<uint4*>(img + ((int64_t)(t * kch + kc) * npad + n) * 64 + (q0 + q) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+            if (!(abl & 1)) *reinterpret_cast<uint4*>(img + ((int64_t)(t * kch + kc) * npad + n) * 64 + (q0 + q) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
 }
 
-__global__ __launch_bounds__(PREP_NT) void prep_kernel(const prep_table tab, int njobs)
+__global__ __launch_bounds__(PREP_NT) void prep_kernel(const prep_table tab, int njobs, int abl)
 {
     int lo = 0;
 #pragma unroll 1
     for (int i = 1; i < njobs; ++i) lo = tab.jobs[i].block0 <= (int)blockIdx.x ? i : lo;
     const glowtts_prep_job& j = tab.jobs[lo];
+#ifdef GLOWTTS_TOOLS
+    prep_body(j, blockIdx.x - j.block0, abl);
+#else
     prep_body(j, blockIdx.x - j.block0);
+#endif
 }
 
 // the same with the job table in device memory (a table that does not change between steps - the text encoder's ~60 images: built and uploaded once)
@@ -239,7 +262,7 @@ extern "C" int glowtts_prep_launch(const glowtts_prep_job* host_jobs, int njobs,
         attr_done = true;
     }
     GLOWTTS_NOTE_STATIC("prep_weights");
-    hipLaunchKernelGGL(prep_kernel, dim3(total_blocks), dim3(PREP_NT), lds, static_cast<hipStream_t>(stream), tab, njobs);
+    hipLaunchKernelGGL(prep_kernel, dim3(total_blocks), dim3(PREP_NT), lds, static_cast<hipStream_t>(stream), tab, njobs, GLOWTTS_TUNABLE("GLOWTTS_PREP_ABL", 0));
     return hipGetLastError() == hipSuccess ? GLOWTTS_OK : GLOWTTS_E_LAUNCH;
 }
 
