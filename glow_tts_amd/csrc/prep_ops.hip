@@ -37,6 +37,30 @@ __device__ __forceinline__ unsigned short bf16_bits_prep(float v) { const __bf16
 constexpr int PREP_MAXJOBS = GLOWTTS_PREP_MAX_JOBS;
 struct prep_table { glowtts_prep_job jobs[PREP_MAXJOBS]; };
 
+// (part of) K chunk kc = tl * PREP_TR / 32 of every (tap, n) of a TRANSPOSED image: piece = (t', n, q): 8 consecutive k = tile rows 8 q ..; n = source channel, taps
+// reversed (dgrad)
+__device__ __forceinline__ void prep_write_transposed(const unsigned short* tile, int pitch, unsigned char* img, int tl, int taps, int kch, int npad, int I, int tid,
+                                                      int abl)
+{
+    constexpr int QP = PREP_TR / 8;                               // pieces of a 64-byte row this tile owns
+    const int kc = (tl * PREP_TR) >> 5, q0 = ((tl * PREP_TR) & 31) >> 3;
+    const int npieces = taps * npad * QP;
+    for (int pc = tid; pc < npieces; pc += PREP_NT) {
+        const int q = pc % QP, tn = pc / QP;
+        const int t = tn / npad, n = tn - t * npad;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (n < I) {
+            const int src = n * taps + (taps - 1 - t);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t a = tile[(q * 8 + 2 * e) * pitch + src], bb = tile[(q * 8 + 2 * e + 1) * pitch + src];
+                w[e] = a | (bb << 16);
+            }
+        }
+        if (!(abl & 1)) *reinterpret_cast<uint4*>(img + ((int64_t)(t * kch + kc) * npad + n) * 64 + (q0 + q) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 // abl (tools builds, GLOWTTS_PREP_ABL): 1 = no image stores (phase 3), 2 = no LDS tile writes (phase 2), 4 = no phase 3 at all
 __device__ __forceinline__ void prep_body(const glowtts_prep_job& j, const int rel, const int abl = 0)
 {
@@ -162,25 +186,15 @@ __device__ __forceinline__ void prep_body(const glowtts_prep_job& j, const int r
             if (!(abl & 1)) *reinterpret_cast<uint4*>(img + ((int64_t)(t * kch + kc) * npad + tl * PREP_TR + r) * 64 + q * 16) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     } else {
-        // (part of) K chunk kc = tl * PREP_TR / 32 of every (tap, n): piece = (t', n, q): 8 consecutive k = tile rows 8 q ..; n = source channel, taps
-        // reversed (dgrad)
-        constexpr int QP = PREP_TR / 8;                               // pieces of a 64-byte row this tile owns
-        const int kc = (tl * PREP_TR) >> 5, q0 = ((tl * PREP_TR) & 31) >> 3;
-        const int npieces = taps * npad * QP;
-        for (int pc = tid; pc < npieces; pc += PREP_NT) {
-            const int q = pc % QP, tn = pc / QP;
-            const int t = tn / npad, n = tn - t * npad;
-            uint32_t w[4] = {0u, 0u, 0u, 0u};
-            if (n < I) {
-                const int src = n * taps + (taps - 1 - t);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t a = tile[(q * 8 + 2 * e) * pitch + src], bb = tile[(q * 8 + 2 * e + 1) * pitch + src];
-                    w[e] = a | (bb << 16);
-                }
-            }
-            if (!(abl & 1)) *reinterpret_cast<uint4*>(img + ((int64_t)(t * kch + kc) * npad + n) * 64 + (q0 + q) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
-        }
+        prep_write_transposed(tile, pitch, img, tl, taps, kch, npad, I, tid, abl);
+    }
+    if (!j.transpose && j.twin && b < j.twin_batch) {
+        // twin output: this forward tile's 16 PAIR-packed rows are 16 consecutive source rows of half hsel (rows hsel * perm_h + 32 p + 16 s ..): tile 2 p + s
+        // of that half's transposed image
+        const int oi0 = tl * PREP_TR, hsel = (oi0 >> 5) & 1, tl2 = ((oi0 >> 6) << 1) + ((oi0 >> 4) & 1);
+        unsigned char* const img2 = static_cast<unsigned char*>(j.twin) + (int64_t)(b / j.inner) * j.twin_outer + (int64_t)(b % j.inner) * j.twin_inner +
+                                    (int64_t)hsel * j.twin_half;
+        prep_write_transposed(tile, pitch, img2, tl2, taps, (j.perm_h + 31) / 32, j.twin_npad, I, tid, abl);
     }
 }
 
@@ -232,6 +246,44 @@ extern "C" int glowtts_prep_job_init(glowtts_prep_job* job, const float* v, cons
     job->tiles = (transpose ? job->kchunks * 32 : job->npad) / PREP_TR;
     job->block0 = block0;
     if (blocks_out) *blocks_out = job->tiles * batch;
+    return GLOWTTS_OK;
+}
+
+extern "C" int glowtts_prep_jobs_twin_in(glowtts_prep_job* jobs, int* njobs, int* blocks)
+{
+    if (!jobs || !njobs || !blocks || *njobs < 1) return GLOWTTS_E_ARG;
+    int fi = -1, ti[2] = {-1, -1};
+    for (int i = 0; i < *njobs; ++i) {
+        const glowtts_prep_job& a = jobs[i];
+        if (!a.transpose && a.perm == GLOWTTS_PERM_PAIR && a.taps > 1 && a.g && !a.twin && fi < 0) fi = i;
+    }
+    if (fi < 0) return GLOWTTS_OK;
+    const glowtts_prep_job f = jobs[fi];
+    const int64_t half_rows = (int64_t)f.perm_h * f.I * f.taps;              // floats between the two halves of one conv
+    for (int i = 0; i < *njobs; ++i) {
+        const glowtts_prep_job& a = jobs[i];
+        if (!a.transpose || a.taps != f.taps || a.I != f.I || a.O != f.perm_h || a.perm != GLOWTTS_PERM_NONE || a.inner != f.inner || a.batch > f.batch) continue;
+        for (int h = 0; h < 2; ++h)
+            if (a.v == f.v + h * half_rows && a.g == f.g + h * f.perm_h && a.w_stride == f.w_stride && a.g_stride == f.g_stride) ti[h] = i;
+    }
+    if (ti[0] < 0 || ti[1] < 0) return GLOWTTS_OK;
+    const glowtts_prep_job &t0 = jobs[ti[0]], &t1 = jobs[ti[1]];
+    if (t0.batch != t1.batch || t0.outer_stride != t1.outer_stride || t0.inner_stride != t1.inner_stride || t0.npad != t1.npad || (f.perm_h & 31) ||
+        t0.kchunks != (f.perm_h + 31) / 32) return GLOWTTS_OK;
+    jobs[fi].twin = t0.packed;
+    jobs[fi].twin_outer = t0.outer_stride; jobs[fi].twin_inner = t0.inner_stride;
+    jobs[fi].twin_half = static_cast<const unsigned char*>(t1.packed) - static_cast<const unsigned char*>(t0.packed);
+    jobs[fi].twin_batch = t0.batch; jobs[fi].twin_npad = t0.npad;
+    // drop the two transposed jobs, renumber the workgroups
+    int n = 0, blk = 0;
+    for (int i = 0; i < *njobs; ++i) {
+        if (i == ti[0] || i == ti[1]) continue;
+        jobs[n] = jobs[i];
+        jobs[n].block0 = blk;
+        blk += jobs[n].tiles * jobs[n].batch;
+        ++n;
+    }
+    *njobs = n; *blocks = blk;
     return GLOWTTS_OK;
 }
 

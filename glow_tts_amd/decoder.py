@@ -124,13 +124,14 @@ class PrepJob(ctypes.Structure):
     _fields_ = [("v", c_void_p), ("g", c_void_p), ("inv_out", c_void_p), ("packed", c_void_p),
                 ("outer_stride", c_i64), ("inner_stride", c_i64), ("w_stride", c_i64), ("g_stride", c_i64),
                 ("batch", c_int), ("inner", c_int), ("O", c_int), ("I", c_int), ("taps", c_int), ("transpose", c_int), ("perm", c_int), ("perm_h", c_int),
-                ("o_ext", c_int), ("npad", c_int), ("kchunks", c_int), ("tiles", c_int), ("block0", c_int), ("reserved", c_int)]
+                ("o_ext", c_int), ("npad", c_int), ("kchunks", c_int), ("tiles", c_int), ("block0", c_int), ("reserved", c_int),
+                ("twin", c_void_p), ("twin_outer", c_i64), ("twin_inner", c_i64), ("twin_half", c_i64), ("twin_batch", c_int), ("twin_npad", c_int)]
 
 
 class PrepJobs:
     """Collects the weight-preparation jobs of a training step (every image of the decoder's convs, straight from the weight-norm pairs) and
     issues them as ONE launch (glowtts_prep_launch)."""
-    CAP = 24                             # GLOWTTS_PREP_MAX_JOBS
+    CAP = 22                             # GLOWTTS_PREP_MAX_JOBS
 
     def __init__(self):
         self.jobs = (PrepJob * self.CAP)()
@@ -150,6 +151,11 @@ class PrepJobs:
     def launch(self, device):
         if self.n.value == 0:
             return
+        if TUNE["prep_twin"] and not getattr(self, "_twinned", False):
+            # the In_l pairs are read ONCE: the forward image's tiles also write the two transposed half images (csrc/prep_ops.hip; no-op without that pattern)
+            _L().glowtts_prep_jobs_twin_in.argtypes = [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+            _lib.check(_L().glowtts_prep_jobs_twin_in(ctypes.cast(self.jobs, c_void_p), ctypes.byref(self.n), ctypes.byref(self.blocks)), "glowtts_prep_jobs_twin_in")
+            self._twinned = True
         # (the table is a HOST array: it travels in the launch's argument segment - no copy node in a captured step)
         _lib.check(_L().glowtts_prep_launch(ctypes.cast(self.jobs, c_void_p), self.n.value, self.blocks.value, self.max_cols, _lib.stream()), "glowtts_prep_launch")
 
@@ -192,7 +198,7 @@ TAIL = {"defer": False, "pending": []}
 #       memory system at the head of the step and the decoder's forward ends 45 us later: 5.24-5.30 against 5.20-5.23 ms/step (three alternating pairs)
 #   prep_fused: training on the fused bf16 path forms w = g v / ||v|| and every weight image in ONE launch (csrc/prep_ops.hip) instead of 4 weight-norm +
 #       ~22 packing launches (0.42 -> ~0.1 ms at the head of the step, round 4)
-TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "fwd_packs_split": 0, "cond_hip": True, "drop_skip32": True, "wgrad_tail_splits": 2, "prep_bwd_late": False, "prep_bwd_gentle": True, "tail_aside": True, "wgrad_balance": False}
+TUNE = {"chain_actnorm": True, "enc_ln_qkv": True, "enc_proj_ln": True, "enc_pack_split": False, "wgrad_dma": True, "wgrad_dma_k1": False, "prep_fused": True, "prep_early": True, "wgrad_wide": True, "fuse_coupling_bwd": True, "wgrad_split": 1, "act_bf16": True, "fused_wn": True, "fused_wn_bwd": -1, "fused_wn_bwd_from": 0, "fused_wn_fwd_skip": -1, "bwd_packs_side": 0, "fwd_packs_split": 0, "cond_hip": True, "drop_skip32": True, "wgrad_tail_splits": 2, "prep_bwd_late": False, "prep_bwd_gentle": True, "tail_aside": True, "wgrad_balance": False, "prep_twin": True}
 STAMPS = {"buf": None, "names": []}      # tools/step_timeline.py: an int64 device buffer; stamp(name) appends a slot
 
 

@@ -159,14 +159,21 @@ int glowtts_pack_weight_strided(const float *w, int batch, int inner, int O, int
  * g / inv_out rows (0 = O; larger when a job covers the leading [O] slice of a bigger conv).  bf16 images only.  I * taps <= 1024 (plain weights: 4096).
  * Jobs are a HOST array (fill with glowtts_prep_job_init, block0 = running sum of *blocks_out; at most GLOWTTS_PREP_MAX_JOBS per launch): the launch
  * carries the table in its argument segment, so a captured step needs no copy node for it. */
-#define GLOWTTS_PREP_MAX_JOBS 24
+#define GLOWTTS_PREP_MAX_JOBS 22
 typedef struct glowtts_prep_job {
     const float *v; const float *g; float *inv_out; void *packed;
     int64_t outer_stride, inner_stride, w_stride, g_stride;
     int batch, inner, O, I, taps, transpose, perm, perm_h;
     int o_ext, npad, kchunks, tiles;       /* derived (glowtts_prep_job_init) */
     int block0, reserved;
+    /* ABI 7: twin output (glowtts_prep_jobs_twin_in): a forward PAIR-packed job whose tiles ALSO write the transposed half images of the same rows - the pairs
+     * are read once for all three images.  twin == NULL: none */
+    void *twin; int64_t twin_outer, twin_inner, twin_half;
+    int twin_batch, twin_npad;
 } glowtts_prep_job;
+/* Folds the two transposed In_l half jobs of a table built by glowtts_wavenet_prep_jobs (forward images, then the backward images of the FIRST F_bwd flows)
+ * into the forward In_l job as its twin output, removes them and renumbers block0.  No-op (returns GLOWTTS_OK) when the pattern is not found. */
+int glowtts_prep_jobs_twin_in(glowtts_prep_job *jobs /* host */, int *njobs, int *blocks);
 int glowtts_prep_job_init(glowtts_prep_job *job /* host */, const float *v, const float *g, float *inv_out, int batch, int inner, int O, int I, int taps,
                           int transpose, int perm, int perm_h, void *packed, int64_t outer_stride, int64_t inner_stride, int64_t w_stride,
                           int64_t g_stride, int block0, int *blocks_out /* host */);
