@@ -205,10 +205,18 @@ __device__ __forceinline__ void prior_bwd_block(const float* __restrict__ z, con
     for (int x = lane; x < Tx; x += 64) { m[x] = mean[trow + x]; e[x] = expf(-2.f * ls[trow + x]); a1[x] = 0.f; a2[x] = 0.f; }
     __builtin_amdgcn_wave_barrier();
     const int32_t* ib = idx + (long)b * Ty;
+    // (the next pass's two loads are issued before this pass's scan: the 13 passes of a row were 13 exposed round trips)
+    int xn_ = lane < Ty ? ib[lane] : -1;
+    float zn_ = lane < Ty ? z[frow + lane] : 0.f;
     for (int y0 = 0; y0 < Ty; y0 += 64) {
         const int y = y0 + lane;
-        const int x = y < Ty ? ib[y] : -1;
-        const float zz = y < Ty ? z[frow + y] : 0.f;
+        const int x = xn_;
+        const float zz = zn_;
+        {
+            const int yn = y + 64;
+            xn_ = yn < Ty ? ib[yn] : -1;
+            zn_ = yn < Ty ? z[frow + yn] : 0.f;
+        }
         // frames outside the alignment read mean = log_std = 0 from the expansion (Modules.py:120-121 multiply by an all-zero column)
         const float mm = x >= 0 ? m[x] : 0.f, ee = x >= 0 ? e[x] : 1.f;
         const float d = zz - mm;
@@ -297,6 +305,7 @@ __global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ 
     double acc = 0.0;
     const float sc = mse_scale(scale, lengths, B, extent);
     const float g = 2.f * sc * 1.f;
+#pragma unroll 4
     for (long i = threadIdx.x; i < n; i += 256) { const float d = a[i] - t[i]; acc += (double)d * d; if (da_unit) da_unit[i] = g * d; }
     red[threadIdx.x] = acc; __syncthreads();
     for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
