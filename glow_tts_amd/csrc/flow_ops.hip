@@ -187,7 +187,14 @@ __global__ __launch_bounds__(256) void colstats_final_kernel(const float* __rest
     const int lane = threadIdx.x & 63;
     if (i >= n) return;
     float s = 0.f;
-    for (int k = lane; k < nblk; k += 64) s += partial[(long)k * n + i];
+    // (eight loads in flight, same order of additions: as a rolled loop every strided load was waited for on its own)
+    for (int k0 = lane; k0 < nblk; k0 += 8 * 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = k0 + 64 * u; v[u] = partial[(long)(k < nblk ? k : nblk - 1) * n + i]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (k0 + 64 * u < nblk) s += v[u];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if (lane == 0) stats[i] = s;

@@ -205,7 +205,14 @@ __global__ __launch_bounds__(256) void multi_sqnorm_kernel(const glowtts_opt_job
 __global__ __launch_bounds__(256) void norm_final_kernel(const float* __restrict__ partial, int n, float max_norm, float* __restrict__ norm)
 {
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    // (eight loads in flight, same order of additions)
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + 256 * u; v[u] = partial[i < n ? i : n - 1]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + 256 * u < n) s += v[u];
+    }
     s = wave_sum(s);
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
