@@ -67,6 +67,43 @@ def test_rpr_attention_core_forward_backward(T, D):
         assert err < 2e-5, (name, err)
 
 
+@pytest.mark.parametrize("T,D", [(120, 96), (57, 96), (200, 96), (40, 16)])
+def test_rpr_attention_core_against_the_oracle(T, D):
+    """The attention kernels against `oracle.glowtts_ref.rpr_attention` ITSELF (the restatement that is pinned against the imported reference's RPR_MHA), not only
+    against this file's local copy of the banded form: Q / K / V convs from random weights, an identity Projection, ragged lengths - a wrong band or offset
+    convention (row d + w of weight_K / weight_V = offset d = j - i) shows here, one level below the whole-encoder parity tests."""
+    from oracle import glowtts_ref as O
+    from glow_tts_amd.conv_fn import RPRAttention
+    B, H, win = 3, 2, 4
+    C, Tp = H * D, T + 4
+    g = torch.Generator().manual_seed(1000 + T + D)
+    lens = torch.tensor([T, T - 9, max(5, T // 3)])
+    mask = (torch.arange(T)[None] < lens[:, None]).float().unsqueeze(1)                 # [B, 1, T]
+    x = torch.randn(B, C, T, generator=g) * 0.5 * mask
+    p = "att"
+    sd = {}
+    for name in ("Query", "Key", "Value"):
+        sd[f"{p}.layer_Dict.{name}.weight"] = torch.randn(C, C, 1, generator=g) * C ** -0.5
+        sd[f"{p}.layer_Dict.{name}.bias"] = torch.randn(C, generator=g) * 0.1
+    sd[f"{p}.layer_Dict.Projection.weight"] = torch.eye(C).unsqueeze(-1)
+    sd[f"{p}.layer_Dict.Projection.bias"] = torch.zeros(C)
+    sd[f"{p}.weight_K"] = torch.randn(1, 2 * win + 1, D, generator=g) * D ** -0.5
+    sd[f"{p}.weight_V"] = torch.randn(1, 2 * win + 1, D, generator=g) * D ** -0.5
+    cfg = O.Cfg(enc_channels=C, heads=H, window=win)
+    want = O.rpr_attention({k: v.double() for k, v in sd.items()}, p, x.double(), mask.double(), cfg)      # [B, C, T]
+    # the kernel's operands: fused Q | K | V rows with two pad rows around every utterance
+    q, k, v = (O.conv(sd, f"{p}.layer_Dict.{n}", x) for n in ("Query", "Key", "Value"))  # [B, C, T] each
+    rows = torch.zeros(B, Tp, 3 * C)
+    rows[:, 2:2 + T] = torch.cat([q, k, v], dim=1).transpose(1, 2)
+    rowmask = torch.zeros(B, Tp)
+    rowmask[:, 2:2 + T] = mask[:, 0]
+    out = RPRAttention.apply(rows.reshape(B * Tp, 3 * C).cuda(), sd[f"{p}.weight_K"].cuda(), sd[f"{p}.weight_V"].cuda(), rowmask.reshape(-1).cuda(),
+                             B, Tp, H, win, 0.0, 0, None)
+    got = out.view(B, Tp, C)[:, 2:2 + T].transpose(1, 2).cpu().double()
+    err = ((got - want) * mask.double()).abs().max().item() / max(1.0, want.abs().max().item())
+    assert err < 2e-5, err
+
+
 @pytest.mark.parametrize("T,D", [(120, 96), (57, 96), (100, 64), (124, 96)])
 def test_rpr_attention_core_bf16_mode(T, D):
     """bf16 arithmetic mode of the single-workgroup attention core (the benchmarked configuration: 120 tokens, D = 96): the five contractions
